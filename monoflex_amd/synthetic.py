@@ -1,0 +1,118 @@
+"""Deterministic synthetic weights, images and per-image targets for the hot path.
+
+There is no network for datasets or checkpoints, so every test, golden fixture and
+benchmark runs on KITTI-shaped synthetic data.  Everything here is a pure
+function of integer seeds through torch's CPU generator, so this container and the GPU
+box regenerate bit-identical tensors (same torch build in both).
+
+Weights are "trained-like" rather than the reference's init distributions: the init leaves
+every DCN offset conv at zero (reference dcn_v2.py:114-116) and BN at identity, which would
+exercise neither the deformable sampling nor the BN folding.  Here activations stay O(1)
+through all ~55 layers and DCN offsets have a std of ~1.5 pixels, including samples that
+leave the feature map.
+"""
+import math
+
+import numpy as np
+import torch
+
+# typical KITTI P2
+KITTI_P2 = np.array([[721.5377, 0.0, 609.5593, 44.85728],
+                     [0.0, 721.5377, 172.854, 0.2163791],
+                     [0.0, 0.0, 1.0, 0.002745884]], dtype=np.float64)
+
+
+def _gen(seed):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed))
+    return g
+
+
+def synthetic_images(batch, height=384, width=1280, seed=1000):
+    """(B,3,H,W) fp32 ~ N(0,1); image i uses seed+i (ImageNet-normalised KITTI pixels are ~N(0,1))."""
+    return torch.stack([torch.randn(3, height, width, generator=_gen(seed + i)) for i in range(batch)])
+
+
+def edge_indices(image_size, pad_size, down_ratio=4):
+    """Border of the un-padded image on the stride-4 grid, in the reference's traversal order
+    (data/datasets/kitti.py:126-179): left top->bottom, bottom left->right, right bottom->top,
+    top right->left.  Returns (n,2) int64 (x,y)."""
+    img_w, img_h = image_size
+    x_min, y_min = int(math.ceil(pad_size[0] / down_ratio)), int(math.ceil(pad_size[1] / down_ratio))
+    x_max, y_max = (pad_size[0] + img_w - 1) // down_ratio, (pad_size[1] + img_h - 1) // down_ratio
+    pts = [(x_min, y) for y in range(y_min, y_max)]
+    pts += [(x, y_max) for x in range(x_min, x_max)]
+    pts += [(x_max, y) for y in range(y_max, y_min, -1)]
+    pts += [(x, y_min) for x in range(x_max, x_min - 1, -1)]
+    return torch.tensor(pts, dtype=torch.int64).view(-1, 2)
+
+
+def synthetic_target(out_w=320, out_h=96, down_ratio=4, orig_size=None, P=KITTI_P2):
+    """Test-split `targets` fields of one image (data/datasets/kitti.py:287-299) as a plain dict:
+    pad_size (2,), size (W,H) of the padded frame, calib P (3,4), edge_indices (max_len,2), edge_len."""
+    W, H = out_w * down_ratio, out_h * down_ratio
+    if orig_size is None:                        # 1242x375 inside 1280x384; scaled for small grids
+        orig_size = (W - 38, H - 9) if (W, H) == (1280, 384) else (W - 2 * (W // 64), H - 2 * (H // 64))
+    pad = ((W - orig_size[0]) // 2, (H - orig_size[1]) // 2)          # kitti.py:218-228 centre pad
+    ei = edge_indices(orig_size, pad, down_ratio)
+    max_len = (out_w + out_h) * 2                                      # kitti.py:69
+    padded = torch.zeros(max_len, 2, dtype=torch.int64)
+    padded[:ei.shape[0]] = ei
+    return dict(pad_size=torch.tensor(pad, dtype=torch.int64), size=(W, H), P=np.array(P, dtype=np.float64),
+                edge_indices=padded, edge_len=int(ei.shape[0]) - 1)    # kitti.py:282-285 count-1
+
+
+def synthetic_state_dict(template_state, seed=0, cls_bias=-1.0, offset_std=1.5):
+    """Fill a state_dict with the reference's 478 keys (taken from `template_state`: name -> tensor
+    of the right shape) deterministically.  Rules by key suffix / shape:
+      conv weight            N(0, 2/fan_in) * gain   (He; keeps activations O(1) through ReLU)
+      BN weight/bias/mean/var U(0.8,1.2) / N(0,0.1) / N(0,0.1) / U(0.8,1.2)
+      conv_offset_mask       weight scaled so offsets ~ N(0, offset_std), bias N(0,0.2)
+      depthwise up_k.weight  bilinear kernel * U(0.9,1.1)
+      head 1x1 convs         N(0, 1/fan_in); class bias = cls_bias; other biases N(0,0.1)
+    """
+    g = _gen(seed)
+    out = {}
+    for name in sorted(template_state.keys()):
+        t = template_state[name]
+        shape = tuple(t.shape)
+        if name.endswith("num_batches_tracked"):
+            v = torch.zeros(shape, dtype=t.dtype)
+        elif name.endswith("running_mean"):
+            v = torch.randn(shape, generator=g) * 0.1
+        elif name.endswith("running_var"):
+            v = torch.rand(shape, generator=g) * 0.4 + 0.8
+        elif ".up_" in name and name.endswith("weight"):
+            k = shape[2]
+            f = math.ceil(k / 2)
+            c = (2 * f - 1 - f % 2) / (2.0 * f)
+            ker = torch.tensor([[(1 - abs(i / f - c)) * (1 - abs(j / f - c)) for j in range(k)] for i in range(k)])
+            v = ker.view(1, 1, k, k) * (torch.rand(shape[0], 1, 1, 1, generator=g) * 0.2 + 0.9)
+        elif "conv_offset_mask" in name:
+            if name.endswith("weight"):
+                fan_in = shape[1] * shape[2] * shape[3]
+                # inputs to a DCN are post-ReLU features with E[x^2] ~ 1 -> out std ~ sqrt(fan_in)*w_std
+                v = torch.randn(shape, generator=g) * (offset_std / math.sqrt(fan_in))
+            else:
+                v = torch.randn(shape, generator=g) * 0.2
+        elif len(shape) >= 3 and name.endswith("weight"):              # conv2d / conv1d / DCN weight
+            fan_in = int(np.prod(shape[1:]))
+            is_head_out = ("class_head.2" in name or "reg_heads" in name or name.endswith("conv.3.weight")
+                           or ".3.weight" in name)
+            std = math.sqrt((1.0 if is_head_out else 2.0) / fan_in)
+            v = torch.randn(shape, generator=g) * std
+        elif name.endswith("weight"):                                   # BN gamma
+            v = torch.rand(shape, generator=g) * 0.4 + 0.8
+            if ".bn2." in name:                                         # residual branch: keep sums O(1)
+                v = v * 0.4
+        elif name.endswith("bias"):
+            if "class_head.2" in name:
+                v = torch.full(shape, float(cls_bias))
+            elif "bn" in name or "actf" in name or ".1.bias" in name or "project.1" in name:
+                v = torch.randn(shape, generator=g) * 0.1
+            else:
+                v = torch.randn(shape, generator=g) * 0.1
+        else:
+            raise KeyError("synthetic_state_dict: unhandled key %s %s" % (name, shape))
+        out[name] = v.to(t.dtype).reshape(shape).contiguous()
+    return out

@@ -1,0 +1,100 @@
+"""Pins oracle/monoflex_ref.py against fixtures captured from the reference's own Python
+(tests/golden/*.npz, produced by oracle/gen_golden.py in the build container)."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from monoflex_amd import synthetic as S
+from oracle import monoflex_ref as R
+
+
+def _model(cls_bias):
+    m = R.KeypointDetectorRef().eval()
+    m.load_state_dict(S.synthetic_state_dict(m.state_dict(), seed=0, cls_bias=cls_bias))
+    return m
+
+
+def _check_sum(g, prefix, t, rtol=2e-4):
+    t = t.detach().double().flatten()
+    assert list(g[prefix + "shape"]) == [t.numel()] or int(np.prod(g[prefix + "shape"])) == t.numel()
+    s = t[torch.as_tensor(g[prefix + "idx"])].float().numpy()
+    assert np.allclose(s, g[prefix + "samples"], rtol=rtol, atol=2e-4), prefix
+    assert abs(float(t.abs().sum()) - float(g[prefix + "abssum"])) <= rtol * float(g[prefix + "abssum"]), prefix
+
+
+def _run_case(g, n, meta, full):
+    m = _model(meta["cls_bias"])
+    ow, oh = meta["out_w"], meta["out_h"]
+    img = S.synthetic_images(1, oh * 4, ow * 4, seed=meta["seeds"][n])
+    tgt = S.synthetic_target(ow, oh)
+    taps = {}
+    with torch.no_grad():
+        maps = m.forward_maps(img, tgt["edge_indices"][None], torch.tensor([tgt["edge_len"]]), taps)
+        dec = R.decode_image(maps["cls"], maps["reg"], R.Calib(tgt["P"]), tgt["pad_size"], tgt["size"])
+    p = "img%d_" % n
+    for i, t in enumerate(taps["base"]):
+        _check_sum(g, p + "base%d_" % i, t)
+    _check_sum(g, p + "feature_", taps["feature"])
+    logits, reg = taps["cls_logits"][0], maps["reg"][0]
+    if full:
+        assert np.abs(taps["feature"][0].numpy() - g[p + "feature"]).max() < 1e-4
+        assert np.abs(logits.numpy() - g[p + "cls_logits"]).max() < 1e-4      # <= 1e-3 is the north-star bar
+        assert np.abs(reg.numpy() - g[p + "reg"]).max() < 1e-4
+    else:
+        pix = torch.as_tensor(g[p + "pix"])
+        assert np.abs(logits.reshape(3, -1)[:, pix].numpy() - g[p + "cls_logits_at"]).max() < 2e-4
+        assert np.abs(reg.reshape(50, -1)[:, pix].numpy() - g[p + "reg_at"]).max() < 2e-4
+    assert np.array_equal(dec["indexs"].numpy(), g[p + "topk_index"])          # identical top-K indices
+    assert np.array_equal(dec["clses"].numpy(), g[p + "topk_cls"])
+    assert np.array_equal(dec["ys"].numpy(), g[p + "topk_ys"]) and np.array_equal(dec["xs"].numpy(), g[p + "topk_xs"])
+    assert np.abs(dec["scores"].numpy() - g[p + "topk_scores"]).max() < 1e-5
+    assert dec["result"].shape == g[p + "result"].shape
+    assert np.allclose(dec["result"].numpy(), g[p + "result"], rtol=2e-4, atol=2e-3)
+
+
+def test_e2e_small_vs_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "e2e_small.npz"))
+    meta = ast.literal_eval(str(g["meta"]))
+    for n in range(len(meta["seeds"])):
+        _run_case(g, n, meta, full=True)
+
+
+def test_e2e_full_vs_reference(golden_dir):
+    path = os.path.join(golden_dir, "e2e_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("full-size fixture not generated")
+    g = np.load(path)
+    meta = ast.literal_eval(str(g["meta"]))
+    _run_case(g, 0, meta, full=False)
+
+
+def test_decode_only_vs_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "decode_only.npz"))
+    tgt = S.synthetic_target(320, 96)
+    n = 0
+    shapes = []
+    while "case%d_seed" % n in g:
+        gen = torch.Generator().manual_seed(int(g["case%d_seed" % n]))
+        logits = torch.randn(1, 3, 96, 320, generator=gen) * 0.8 - 2.0 + float(g["case%d_shift" % n])
+        cls = torch.sigmoid(logits).clamp(1e-4, 1 - 1e-4)
+        reg = torch.randn(1, 50, 96, 320, generator=gen) * 0.7
+        dec = R.decode_image(cls, reg, R.Calib(tgt["P"]), tgt["pad_size"], tgt["size"])
+        want = g["case%d_result" % n]
+        assert dec["result"].shape == want.shape
+        if want.shape[0]:
+            assert np.allclose(dec["result"].numpy(), want, rtol=1e-5, atol=1e-4)
+        shapes.append(want.shape[0])
+        n += 1
+    assert 0 in shapes and any(0 < s < 50 for s in shapes) and 50 in shapes   # all three decode paths covered
+
+
+def test_edge_indices_match_reference_count():
+    # 1242x375 in 1280x384 with pad (19,4) -> 807 border points, edge_len 806
+    t = S.synthetic_target(320, 96)
+    assert tuple(t["pad_size"].tolist()) == (19, 4) and t["edge_len"] == 806
+    ei = t["edge_indices"][:807]
+    assert len({(int(x), int(y)) for x, y in ei[:806]}) == 806              # unique -> no atomics needed
+    assert tuple(ei[0].tolist()) == (5, 1) and tuple(ei[806].tolist()) == (5, 1)   # duplicated corner dropped
