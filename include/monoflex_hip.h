@@ -1,0 +1,181 @@
+/*
+ * include/monoflex_hip.h -- C ABI of libmonoflex_hip.so (gfx950 / MI355X).
+ *
+ * Plain pointers and sizes only; no torch types.  Every pointer is a DEVICE pointer unless a
+ * comment says otherwise; `stream` is a hipStream_t passed as void*.  Every entry point returns 0
+ * on success or a negative error code and records a message readable with mfx_last_error().
+ * Kernels are enqueued on `stream` and never synchronise (hipGraph-capturable).
+ *
+ * Two groups of entry points:
+ *  (1) The reference's native boundary for this path -- what its pybind module `_ext` binds
+ *      (/root/reference/model/backbone/DCNv2/src/vision.cpp:3-8):
+ *        dcn_v2_forward   src/dcn_v2.h:9-46   -> mfx_dcn_v2_forward
+ *        dcn_v2_backward  src/dcn_v2.h:48-92  -> mfx_dcn_v2_backward
+ *      Same layouts as the reference (NCHW fp32; offset channel 2k = dh, 2k+1 = dw of tap k;
+ *      mask channel k), same argument meaning; outputs are caller-allocated instead of ATen-allocated.
+ *  (2) The NHWC operators the rest of the path is built from (they replace what the reference gets
+ *      from cuDNN/cuBLAS/torch through nn.Conv2d, BatchNorm2d, MaxPool2d, ConvTranspose2d, topk, ...;
+ *      call sites cited per function).
+ */
+#ifndef MONOFLEX_HIP_H
+#define MONOFLEX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFX_ABI_VERSION 1
+
+/* element types of activations / packed weights */
+enum { MFX_F32 = 0, MFX_BF16 = 1 };
+/* epilogue activations */
+enum { MFX_ACT_NONE = 0, MFX_ACT_RELU = 1, MFX_ACT_LEAKY = 2 /* slope 0.01 */, MFX_ACT_DCN_OFFMASK = 3 /* sigmoid on ch 18..26 */ };
+/* error codes */
+enum { MFX_OK = 0, MFX_ERR_ARG = -1, MFX_ERR_UNSUPPORTED = -2, MFX_ERR_LAUNCH = -3, MFX_ERR_WORKSPACE = -4 };
+
+int mfx_abi_version(void);
+const char* mfx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * (1) reference `_ext` boundary
+ * ------------------------------------------------------------------------------------------ */
+
+/* Scratch bytes mfx_dcn_v2_forward / _backward need for the given shape. */
+size_t mfx_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw,
+                                  int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                                  int backward);
+
+/* output (B,Cout,Ho,Wo) = bias + W * (mask . bilinear(input @ offsets))   -- src/dcn_v2.h:9-23.
+ * deformable_group must be 1 (the only value MonoFlex uses, dla_dcn.py:391), stride_h == stride_w,
+ * dil_h == dil_w; otherwise MFX_ERR_UNSUPPORTED. */
+int mfx_dcn_v2_forward(const float* input, const float* weight, const float* bias,
+                       const float* offset, const float* mask, float* output,
+                       int B, int C, int H, int W, int Cout, int kh, int kw,
+                       int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                       int deformable_group, void* workspace, size_t workspace_bytes, void* stream);
+
+/* grads wrt input, offset, mask, weight, bias (all overwritten)            -- src/dcn_v2.h:48-59 */
+int mfx_dcn_v2_backward(const float* input, const float* weight, const float* bias,
+                        const float* offset, const float* mask, const float* grad_output,
+                        float* grad_input, float* grad_offset, float* grad_mask,
+                        float* grad_weight, float* grad_bias,
+                        int B, int C, int H, int W, int Cout, int kh, int kw,
+                        int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                        int deformable_group, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (2) NHWC operators
+ * ------------------------------------------------------------------------------------------ */
+
+#define MFX_MAX_SEG 9
+
+/* Implicit-GEMM convolution, NHWC in / NHWC out, fused y = act(conv(x)*scale + shift (+ res)).
+ * Replaces nn.Conv2d + BatchNorm2d(eval) + ReLU (+ residual add) of dla_dcn.py:84-98,195-203,
+ * 268-276,312-322, the DCN offset/mask conv (dcn_v2.py:104-122) and the head convs.
+ * Weights are pre-packed [Cout_pad][K_pad], K = (tap, channel) with Ck elements per tap. */
+typedef struct {
+    const void* x;            /* input [B][H][W][x_pixstride]                                  */
+    const void* w;            /* packed weights [Cout_pad][K_pad], element type = dtype        */
+    const float* scale;       /* [Cout_pad] or NULL (=1)                                        */
+    const float* shift;       /* [Cout_pad] or NULL (=0)                                        */
+    const void* res;          /* residual [M][ldres] (element type = dtype) or NULL            */
+    void* y;                  /* output [M][ldy], element type = out_dtype                      */
+    const int32_t* rowmap;    /* optional [M]: output row -> pixel index b*Ho*Wo+oh*Wo+ow, -1 = zero row */
+    int32_t B, H, W;
+    int32_t x_pixstride;      /* elements between consecutive input pixels                      */
+    int32_t Ck;               /* K elements per tap: power of two, >= 16 bytes worth            */
+    int32_t kh, kw, stride, pad_h, pad_w, dil_w;
+    int32_t Ho, Wo;
+    int32_t M;                /* rows: B*Ho*Wo, or the rowmap length                            */
+    int32_t Cout;             /* valid output channels (multiple of 4 for f32 out, 8 for bf16)  */
+    int32_t Cout_pad;         /* weight rows; multiple of 16, and of 64 when > 32                */
+    int32_t K_pad;            /* multiple of 64 bytes of K                                      */
+    int32_t ldy, ldres;
+    int32_t act;
+    int32_t dtype, out_dtype;
+} mfx_conv_desc;
+int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream);
+
+/* 1x1 convolution over a virtual channel concat of up to MFX_MAX_SEG sources (DLA Root,
+ * dla_dcn.py:195-203): no concatenated tensor is materialised.  Every segment contributes
+ * Cseg channels (power of two) read at src[s] + pixel*stride[s] + off[s]. */
+typedef struct {
+    const void* src[MFX_MAX_SEG];
+    int32_t stride[MFX_MAX_SEG];
+    int32_t off[MFX_MAX_SEG];
+    int32_t nseg, Cseg;
+    const void* w; const float* scale; const float* shift; const void* res; void* y;
+    int32_t M, Cout, Cout_pad, K_pad, ldy, ldres, act, dtype;
+} mfx_cat_desc;
+int mfx_cat_conv1x1_nhwc(const mfx_cat_desc* d, void* stream);
+
+/* Fused modulated deformable convolution, NHWC: bilinear gather straight into the LDS A tile,
+ * MFMA against the packed weights, + scale/shift (bias and BN folded) + activation; the reference's
+ * `columns` buffer (src/cuda/dcn_v2_cuda.cu:139-163) is never written.
+ * offmask: fp32 [B*Ho*Wo][32]: ch 2k = dh, 2k+1 = dw, 18+k = mask (already sigmoided), kh*kw <= 9. */
+typedef struct {
+    const void* x; const float* offmask; const void* w; const float* scale; const float* shift; void* y;
+    int32_t B, H, W, C;       /* C: power of two >= 64 (bf16) / 16 (f32) elements                */
+    int32_t kh, kw, stride, pad, dil;
+    int32_t Ho, Wo, Cout, Cout_pad, K_pad, ldy, act, dtype;
+} mfx_dcn_desc;
+int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream);
+
+/* 2x2/stride-2 max pooling (dla_dcn.py:237-238), NHWC, C % (16 bytes) == 0 */
+int mfx_maxpool2x2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+
+/* depthwise ConvTranspose2d(k=2f, stride=f, pad=f/2) + skip add (dla_dcn.py:409-411,419-425):
+ * y[b,oh,ow,c] = sum x[b,ih,iw,c]*w[c][kh][kw] + skip[b,oh,ow,c];  w fp32 [C][2f][2f]; skip may be NULL */
+int mfx_upsample_add_nhwc(const void* x, const float* w, const void* skip, void* y,
+                          int B, int H, int W, int C, int f, int dtype, void* stream);
+
+/* layout helpers for the NCHW fp32 boundary */
+int mfx_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, int W, int ldy, int dtype, void* stream);
+int mfx_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int ldx, int dtype, void* stream);
+/* network input: NCHW fp32 (B,3,H,W) -> zero-padded NHWC4 [B][H+2*pad][W+2*pad_w][4] (stem, dla_dcn.py:268-272) */
+int mfx_pack_image_nhwc4(const float* x, void* y, int B, int H, int W, int pad_h, int pad_w_left, int pad_w_right,
+                         int dtype, void* stream);
+
+/* Nine head branches fused (detector_predictor.py:47-96,125-134): per branch
+ * 3x3 conv 64->256 (no bias) -> BN(+leaky 0.01) -> 1x1 conv 256->c_k (+bias); the 256-ch trunks
+ * never reach HBM.  out: fp32 [M][ld_out]; branch k writes c_out[k] channels at ch_off[k]. */
+typedef struct {
+    const void* x;            /* feature [B][H][W][64]                                          */
+    const void* w1;           /* [nbranch*256][K_pad] packed 3x3 weights                        */
+    const float* scale1; const float* shift1;   /* [nbranch*256] folded BN                      */
+    const void* w2;           /* [nbranch][32][256] packed 1x1 weights (rows >= c_out zero)     */
+    const float* bias2;       /* [nbranch][32]                                                   */
+    float* out;               /* [M][ld_out] fp32                                                */
+    int32_t B, H, W, nbranch, K_pad, ld_out, dtype;
+    int32_t ch_off[16]; int32_t c_out[16];
+} mfx_heads_desc;
+int mfx_heads_fused(const mfx_heads_desc* d, void* stream);
+
+/* Edge fusion tail (detector_predictor.py:152-158): out[b, y, x, ch_off + c] += v[b][i][c] for the
+ * first edge_len[b] border points i of image b.  v: fp32 [B][L][ldv], edge_xy: int32 [B][L][2]. */
+int mfx_edge_scatter_add(float* out, int ld_out, int ch_off, int C, const float* v, int ldv,
+                         const int32_t* edge_xy, const int32_t* edge_len, int B, int L, int H, int W, void* stream);
+
+/* Decode stage 1 (layers/utils.py:39-58,61-77): per (image, class) sigmoid+clamp, 3x3 max NMS, top-K.
+ * hmap: fp32 [B][H*W][ld] with class logits at channels ch_off..ch_off+ncls.  Outputs [B][ncls][K].
+ * Ties are broken towards the lower flat index (torch.topk leaves the order unspecified). */
+int mfx_decode_topk(const float* hmap, int ld, int ch_off, int ncls, int B, int H, int W, int K,
+                    float* scores, int32_t* index, void* stream);
+
+/* Decode stage 2 (layers/utils.py:88-100,120-145; detector_infer.py:96-232; anno_encoder.py:69-295):
+ * merge ncls*K -> K, gather the 50 regression channels, 3D box recovery.
+ * calib: fp32 [B][6] = f_u,f_v,c_u,c_v,b_x,b_y; pad: int32 [B][2]; img_size: int32 [2] = (W,H) of image 0.
+ * det: fp32 [B][K][14] rows [cls,alpha,x1,y1,x2,y2,h,w,l,x,y,z,ry,score], sorted by merged score;
+ * topk: fp32 [B][K][5] = score, flat index, cls, y, x;  valid: int32 [B][K] (score >= threshold). */
+int mfx_decode_boxes(const float* hmap, int ld, int reg_off, const float* scores, const int32_t* index,
+                     int ncls, int B, int H, int W, int K, const float* calib, const int32_t* pad,
+                     const int32_t* img_size, float threshold, float* det, float* topk, int32_t* valid,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOFLEX_HIP_H */

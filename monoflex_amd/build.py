@@ -1,0 +1,63 @@
+"""Builds libmonoflex_hip.so (hand-written HIP for gfx950).
+
+`hipcc --offload-arch=gfx950` cross-compiles without a GPU.  The .so is built in-tree
+(monoflex_amd/csrc/libmonoflex_hip.so) so it travels to the GPU box with the repo snapshot.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(CSRC, "libmonoflex_hip.so")
+SOURCES = ["capi.hip", "conv_kernels.hip", "misc_kernels.hip", "heads.hip", "decode.hip", "dcn_ext.hip", "dcn_bwd.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    return "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+
+
+def _stamp():
+    h = hashlib.sha1()
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for fn in sorted(os.listdir(root)):
+            if fn.endswith((".hip", ".h")):
+                with open(os.path.join(root, fn), "rb") as f:
+                    h.update(fn.encode() + f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build_lib(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    stamp_file = os.path.join(OBJ, "stamp")
+    stamp = _stamp()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return LIB
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
+        if verbose and r.stderr:
+            sys.stderr.write(r.stderr)
+        return obj
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr)
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

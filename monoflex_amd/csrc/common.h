@@ -1,0 +1,96 @@
+// Shared device helpers for the MonoFlex gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mfx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+// ---- element types: float (parity mode) and bf16 (perf mode) -------------------------------
+struct bf16_t { uint16_t v; };
+
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int ELEMS = 4;            // elements per 16-byte chunk
+    static constexpr int DT = 0;
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+    // unpack a 16-byte chunk to floats / pack floats to a chunk
+    __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
+        f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y);
+        f[2] = __uint_as_float(c.z); f[3] = __uint_as_float(c.w);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        u32x4 c; c.x = __float_as_uint(f[0]); c.y = __float_as_uint(f[1]);
+        c.z = __float_as_uint(f[2]); c.w = __float_as_uint(f[3]); return c;
+    }
+};
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int ELEMS = 8;
+    static constexpr int DT = 1;
+    __device__ static __forceinline__ float load(const bf16_t* p) { return bf2f(p->v); }
+    __device__ static __forceinline__ void store(bf16_t* p, float v) { p->v = f2bf(v); }
+    __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
+        f[0] = __uint_as_float(c.x << 16); f[1] = __uint_as_float(c.x & 0xffff0000u);
+        f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
+        f[4] = __uint_as_float(c.z << 16); f[5] = __uint_as_float(c.z & 0xffff0000u);
+        f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        u32x4 c;
+        c.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+        c.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+        c.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+        c.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+        return c;
+    }
+};
+
+// ---- MFMA step over one 16-byte K-chunk per lane -------------------------------------------
+// A fragment: lane l holds row (l&15), k-group (l>>4): 8 bf16 or 4 f32 consecutive in K.
+// D layout (both dtypes): col = lane&15, row = (lane>>4)*4 + reg.
+template <typename T> __device__ __forceinline__ void mma_chunk(const u32x4& a, const u32x4& b, f32x4& acc);
+template <> __device__ __forceinline__ void mma_chunk<bf16_t>(const u32x4& a, const u32x4& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                  acc, 0, 0, 0);
+}
+// f32: the lane's 4 consecutive k feed 4 MFMAs (element j of every lane forms one K=4 step);
+// the k order inside the 16-wide block is permuted identically for A and B, so the sum is the same.
+template <> __device__ __forceinline__ void mma_chunk<float>(const u32x4& a, const u32x4& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// activation codes shared with the host (include/monoflex_hip.h)
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_DCN_OFFMASK = 3 };
+
+__device__ __forceinline__ float apply_act(float v, int act, int n) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
+    if (act == ACT_DCN_OFFMASK) return (n >= 18 && n < 27) ? 1.f / (1.f + __expf(-v)) : v;
+    return v;
+}
+
+// XCD-aware tile order: block b runs on XCD b%8 (observed, speed only); give every XCD a contiguous
+// range of tile ids so neighbouring tiles (shared halos / shared A rows) meet in one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace mfx

@@ -1,0 +1,363 @@
+// Implicit-GEMM convolution kernels for gfx950: plain conv, concat-1x1 (DLA Root) and the fused
+// modulated deformable convolution.  All share igemm.h's LDS-tiled MFMA main loop and epilogue.
+#include "../../include/monoflex_hip.h"
+#include "err.h"
+#include "igemm.h"
+
+namespace mfx {
+
+// ------------------------------------------------------------------------------------------------
+// A-operand loaders
+// ------------------------------------------------------------------------------------------------
+struct ConvGeom {
+    int H, W, Ho, Wo, x_pixstride, lgC, kh, kw, inv_kw, stride, pad_h, pad_w, dil_w, M;
+};
+
+// im2col on the fly: row m = output pixel, chunk -> (tap, channel); out-of-image taps read zeros.
+template <typename T, int BM> struct ConvALoader {
+    static constexpr int ELEMS = ElemTraits<T>::ELEMS;
+    static constexpr int R = BM / 64;
+    const T* x; ConvGeom g; int c, r0;
+    int ih0[R], iw0[R], pix0[R]; bool ok[R];
+    u32x4 regs[R];
+    __device__ __forceinline__ void init(const T* x_, const ConvGeom& g_, const int* rowmap, int m0, int tid) {
+        x = x_; g = g_; c = tid & 3; r0 = tid >> 2;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int m = m0 + r0 + 64 * i;
+            int pm = (m < g.M) ? (rowmap ? rowmap[m] : m) : -1;
+            ok[i] = pm >= 0;
+            pm = pm < 0 ? 0 : pm;
+            const int hw = g.Ho * g.Wo;
+            const int b = pm / hw, rem = pm - b * hw;
+            const int oh = rem / g.Wo, ow = rem - oh * g.Wo;
+            ih0[i] = oh * g.stride - g.pad_h;
+            iw0[i] = ow * g.stride - g.pad_w;
+            pix0[i] = b * g.H * g.W;
+        }
+    }
+    __device__ __forceinline__ void load(int kiter) {
+        const int e = kiter * (kChunks * ELEMS) + c * ELEMS;
+        const int tap = e >> g.lgC, ci = e & ((1 << g.lgC) - 1);
+        const int th = (tap * g.inv_kw) >> 16, tw = tap - th * g.kw;
+        const bool tap_ok = tap < g.kh * g.kw;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int ih = ih0[i] + th, iw = iw0[i] + tw * g.dil_w;
+            const bool v = ok[i] && tap_ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if (v) z = *reinterpret_cast<const u32x4*>(x + (size_t)(pix0[i] + ih * g.W + iw) * g.x_pixstride + ci);
+            regs[i] = z;
+        }
+    }
+    __device__ __forceinline__ void store(char* As) const {
+#pragma unroll
+        for (int i = 0; i < R; ++i) *reinterpret_cast<u32x4*>(As + (r0 + 64 * i) * kRowBytes + c * 16) = regs[i];
+    }
+};
+
+struct CatSegs {
+    const void* src[MFX_MAX_SEG]; int stride[MFX_MAX_SEG]; int off[MFX_MAX_SEG]; int lgC; int M;
+};
+
+// virtual channel concat for the 1x1 Root conv: k-iteration -> (segment, channel) is wave-uniform.
+template <typename T, int BM> struct CatALoader {
+    static constexpr int ELEMS = ElemTraits<T>::ELEMS;
+    static constexpr int R = BM / 64;
+    const CatSegs* s; int c, r0, m0;
+    u32x4 regs[R];
+    __device__ __forceinline__ void init(const CatSegs* s_, int m0_, int tid) { s = s_; m0 = m0_; c = tid & 3; r0 = tid >> 2; }
+    __device__ __forceinline__ void load(int kiter) {
+        const int e = kiter * (kChunks * ELEMS);
+        const int seg = e >> s->lgC, ci = (e & ((1 << s->lgC) - 1)) + c * ELEMS;
+        const T* base = reinterpret_cast<const T*>(s->src[seg]) + s->off[seg] + ci;
+        const int st = s->stride[seg];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int m = m0 + r0 + 64 * i;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if (m < s->M) z = *reinterpret_cast<const u32x4*>(base + (size_t)m * st);
+            regs[i] = z;
+        }
+    }
+    __device__ __forceinline__ void store(char* As) const {
+#pragma unroll
+        for (int i = 0; i < R; ++i) *reinterpret_cast<u32x4*>(As + (r0 + 64 * i) * kRowBytes + c * 16) = regs[i];
+    }
+};
+
+struct DcnGeom { int H, W, C, lgC, Ho, Wo, kh, kw, inv_kw, stride, pad, dil, M; };
+
+// Deformable sampler: A[m][(tap,c)] = mask * bilinear(x[b,:,:,c] at (oh*s-p+th*d+dh, ow*s-p+tw*d+dw)).
+// In NHWC the four corners are contiguous channel vectors, so every lane gathers 4 x 16 bytes and
+// blends them in fp32; offsets/mask are read once per (pixel, tap) and reused across all channels.
+// Sample validity and per-corner zeroing follow src/cuda/dcn_v2_im2col_cuda.cu:25-54,178-189.
+template <typename T, int BM> struct DcnALoader {
+    static constexpr int ELEMS = ElemTraits<T>::ELEMS;
+    static constexpr int R = BM / 64;
+    const T* x; const float* om; DcnGeom g; int c, r0;
+    int oh_[R], ow_[R], pix0[R], mrow[R]; bool ok[R];
+    int coff[R][4]; float cw[R][4];
+    u32x4 regs[R][4];
+    __device__ __forceinline__ void init(const T* x_, const float* om_, const DcnGeom& g_, int m0, int tid) {
+        x = x_; om = om_; g = g_; c = tid & 3; r0 = tid >> 2;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int m = m0 + r0 + 64 * i;
+            ok[i] = m < g.M;
+            const int pm = ok[i] ? m : 0;
+            mrow[i] = pm;
+            const int hw = g.Ho * g.Wo;
+            const int b = pm / hw, rem = pm - b * hw;
+            oh_[i] = rem / g.Wo; ow_[i] = rem - oh_[i] * g.Wo;
+            pix0[i] = b * g.H * g.W;
+        }
+    }
+    __device__ __forceinline__ void tap_setup(int tap) {
+        const int th = (tap * g.inv_kw) >> 16, tw = tap - th * g.kw;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float* o = om + (size_t)mrow[i] * 32;
+            const float dh = o[2 * tap], dw = o[2 * tap + 1], mk = o[18 + tap];
+            const float h = (float)(oh_[i] * g.stride - g.pad + th * g.dil) + dh;
+            const float w = (float)(ow_[i] * g.stride - g.pad + tw * g.dil) + dw;
+            const bool inside = ok[i] && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
+            const float hf = floorf(h), wf = floorf(w);
+            const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
+            const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw_ = 1.f - lw;
+            const bool t0 = inside && h0 >= 0, t1 = inside && h1 <= g.H - 1;
+            const bool l0 = w0 >= 0, l1 = w1 <= g.W - 1;
+            const int ch0 = min(max(h0, 0), g.H - 1), ch1 = min(max(h1, 0), g.H - 1);
+            const int cw0 = min(max(w0, 0), g.W - 1), cw1 = min(max(w1, 0), g.W - 1);
+            coff[i][0] = pix0[i] + ch0 * g.W + cw0; cw[i][0] = (t0 && l0) ? hh * hw_ * mk : 0.f;
+            coff[i][1] = pix0[i] + ch0 * g.W + cw1; cw[i][1] = (t0 && l1) ? hh * lw * mk : 0.f;
+            coff[i][2] = pix0[i] + ch1 * g.W + cw0; cw[i][2] = (t1 && l0) ? lh * hw_ * mk : 0.f;
+            coff[i][3] = pix0[i] + ch1 * g.W + cw1; cw[i][3] = (t1 && l1) ? lh * lw * mk : 0.f;
+        }
+    }
+    __device__ __forceinline__ void load(int kiter) {
+        const int e = kiter * (kChunks * ELEMS);
+        const int ci = (e & (g.C - 1)) + c * ELEMS;
+        if ((e & (g.C - 1)) == 0) tap_setup(e >> g.lgC);      // wave-uniform: a new tap starts
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                regs[i][q] = *reinterpret_cast<const u32x4*>(x + (size_t)coff[i][q] * g.C + ci);
+    }
+    // blend weights cw[] were (re)computed by the load() that filled regs[]: load(k+1) -> mma(k) -> store(k+1)
+    __device__ __forceinline__ void store(char* As) const {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            float v[4][ELEMS], o[ELEMS];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ElemTraits<T>::unpack(regs[i][q], v[q]);
+#pragma unroll
+            for (int e = 0; e < ELEMS; ++e)
+                o[e] = cw[i][0] * v[0][e] + cw[i][1] * v[1][e] + cw[i][2] * v[2][e] + cw[i][3] * v[3][e];
+            *reinterpret_cast<u32x4*>(As + (r0 + 64 * i) * kRowBytes + c * 16) = ElemTraits<T>::pack(o);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+struct EpiArgs {
+    const float* scale; const float* shift; const void* res; void* y;
+    int ldy, ldres, Cout, act, tiles_n, K_pad, nk;
+};
+
+template <typename T, typename TO, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const T* x, const T* w, ConvGeom g, const int* rowmap, EpiArgs ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % ep.tiles_n, tm = tile / ep.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    ConvALoader<T, BM> al; al.init(x, g, rowmap, m0, threadIdx.x);
+    WeightLoader<T, BN> bl; bl.init(w, n0, ep.K_pad, threadIdx.x);
+    f32x4 acc[BM / WM / 16][BN / WN / 16];
+    gemm_mainloop<T, BM, BN, WM, WN>(al, bl, ep.nk, smem, acc);
+    epilogue_store<T, TO, BM, BN, WM, WN>(acc, smem, ep.scale, ep.shift, reinterpret_cast<const T*>(ep.res), ep.ldres,
+                                          reinterpret_cast<TO*>(ep.y), ep.ldy, m0, n0, g.M, ep.Cout, ep.act);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(kThreads) void cat_igemm_kernel(CatSegs segs, const T* w, EpiArgs ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % ep.tiles_n, tm = tile / ep.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    CatALoader<T, BM> al; al.init(&segs, m0, threadIdx.x);
+    WeightLoader<T, BN> bl; bl.init(w, n0, ep.K_pad, threadIdx.x);
+    f32x4 acc[BM / WM / 16][BN / WN / 16];
+    gemm_mainloop<T, BM, BN, WM, WN>(al, bl, ep.nk, smem, acc);
+    epilogue_store<T, T, BM, BN, WM, WN>(acc, smem, ep.scale, ep.shift, reinterpret_cast<const T*>(ep.res), ep.ldres,
+                                         reinterpret_cast<T*>(ep.y), ep.ldy, m0, n0, segs.M, ep.Cout, ep.act);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(kThreads) void dcn_igemm_kernel(const T* x, const float* om, const T* w, DcnGeom g, EpiArgs ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % ep.tiles_n, tm = tile / ep.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    DcnALoader<T, BM> al; al.init(x, om, g, m0, threadIdx.x);
+    WeightLoader<T, BN> bl; bl.init(w, n0, ep.K_pad, threadIdx.x);
+    f32x4 acc[BM / WM / 16][BN / WN / 16];
+    gemm_mainloop<T, BM, BN, WM, WN>(al, bl, ep.nk, smem, acc);
+    epilogue_store<T, T, BM, BN, WM, WN>(acc, smem, ep.scale, ep.shift, nullptr, 0,
+                                         reinterpret_cast<T*>(ep.y), ep.ldy, m0, n0, g.M, ep.Cout, ep.act);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <typename T, typename TO, int BM, int BN, int WM, int WN>
+static int launch_conv(const mfx_conv_desc* d, const ConvGeom& g, EpiArgs ep, hipStream_t st) {
+    ep.tiles_n = d->Cout_pad / BN;
+    const int tiles = cdiv(d->M, BM) * ep.tiles_n;
+    auto k = conv_igemm_kernel<T, TO, BM, BN, WM, WN>;
+    constexpr int smem = TileSmem<BM, BN>::bytes;
+    static bool attr_set = false;
+    if (!attr_set) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), smem, st, reinterpret_cast<const T*>(d->x),
+                       reinterpret_cast<const T*>(d->w), g, d->rowmap, ep);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+template <typename T, typename TO>
+static int dispatch_conv(const mfx_conv_desc* d, const ConvGeom& g, const EpiArgs& ep, hipStream_t st) {
+    const int N = d->Cout_pad;
+    if (N == 16) return launch_conv<T, TO, 256, 16, 4, 1>(d, g, ep, st);
+    if (N == 32) return launch_conv<T, TO, 256, 32, 4, 1>(d, g, ep, st);
+    if (N % 64 != 0) return mfx_fail(MFX_ERR_ARG, "conv2d: Cout_pad must be 16, 32 or a multiple of 64");
+    if (N == 64) {
+        if (cdiv(d->M, 128) >= 512) return launch_conv<T, TO, 128, 64, 4, 1>(d, g, ep, st);
+        return launch_conv<T, TO, 64, 64, 2, 2>(d, g, ep, st);
+    }
+    if (N % 128 == 0 && cdiv(d->M, 128) * (N / 128) >= 512) return launch_conv<T, TO, 128, 128, 2, 2>(d, g, ep, st);
+    return launch_conv<T, TO, 64, 64, 2, 2>(d, g, ep, st);
+}
+
+}  // namespace mfx
+
+using namespace mfx;
+
+extern "C" int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream) {
+    if (!d || !d->x || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "conv2d: null pointer");
+    const int elems = d->dtype == MFX_BF16 ? 8 : 4;
+    if (d->dtype != MFX_F32 && d->dtype != MFX_BF16) return mfx_fail(MFX_ERR_ARG, "conv2d: bad dtype");
+    if (!is_pow2(d->Ck) || d->Ck < elems) return mfx_fail(MFX_ERR_ARG, "conv2d: Ck must be a power of two >= one 16-byte chunk");
+    if (d->K_pad % (4 * elems) != 0 || d->K_pad < d->kh * d->kw * d->Ck) return mfx_fail(MFX_ERR_ARG, "conv2d: bad K_pad");
+    const int oe = d->out_dtype == MFX_BF16 ? 8 : 4;
+    if (d->Cout % oe != 0 || d->Cout > d->Cout_pad) return mfx_fail(MFX_ERR_ARG, "conv2d: Cout must be a multiple of the output chunk and <= Cout_pad");
+    if (d->kh * d->kw > 64 || d->kw > 8) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: kernel too large");
+    if (d->M <= 0) return MFX_OK;
+    ConvGeom g;
+    g.H = d->H; g.W = d->W; g.Ho = d->Ho; g.Wo = d->Wo; g.x_pixstride = d->x_pixstride; g.lgC = ilog2(d->Ck);
+    g.kh = d->kh; g.kw = d->kw; g.inv_kw = (65536 + d->kw - 1) / d->kw; g.stride = d->stride;
+    g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.dil_w = d->dil_w; g.M = d->M;
+    EpiArgs ep;
+    ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
+    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = d->K_pad / (4 * elems); ep.tiles_n = 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MFX_F32) {
+        if (d->out_dtype != MFX_F32) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: f32 input needs f32 output");
+        return dispatch_conv<float, float>(d, g, ep, st);
+    }
+    if (d->out_dtype == MFX_BF16) return dispatch_conv<bf16_t, bf16_t>(d, g, ep, st);
+    if (d->res) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: residual needs out_dtype == dtype");
+    return dispatch_conv<bf16_t, float>(d, g, ep, st);
+}
+
+namespace mfx {
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_cat(const mfx_cat_desc* d, const CatSegs& s, EpiArgs ep, hipStream_t st) {
+    ep.tiles_n = d->Cout_pad / BN;
+    const int tiles = cdiv(d->M, BM) * ep.tiles_n;
+    auto k = cat_igemm_kernel<T, BM, BN, WM, WN>;
+    constexpr int smem = TileSmem<BM, BN>::bytes;
+    static bool attr_set = false;
+    if (!attr_set) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), smem, st, s, reinterpret_cast<const T*>(d->w), ep);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+template <typename T> static int dispatch_cat(const mfx_cat_desc* d, const CatSegs& s, const EpiArgs& ep, hipStream_t st) {
+    const int N = d->Cout_pad;
+    if (N % 64 != 0) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: Cout_pad must be a multiple of 64");
+    if (N % 128 == 0 && cdiv(d->M, 128) * (N / 128) >= 512) return launch_cat<T, 128, 128, 2, 2>(d, s, ep, st);
+    return launch_cat<T, 64, 64, 2, 2>(d, s, ep, st);
+}
+}  // namespace mfx
+
+extern "C" int mfx_cat_conv1x1_nhwc(const mfx_cat_desc* d, void* stream) {
+    if (!d || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: null pointer");
+    if (d->nseg < 1 || d->nseg > MFX_MAX_SEG) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: 1..9 segments");
+    const int elems = d->dtype == MFX_BF16 ? 8 : 4;
+    if (!is_pow2(d->Cseg) || d->Cseg < 4 * elems) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: Cseg must be a power of two >= 64 bytes");
+    if (d->K_pad != d->nseg * d->Cseg) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: K_pad != nseg*Cseg");
+    if (d->Cout % elems != 0) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: Cout must be a multiple of the chunk");
+    if (d->M <= 0) return MFX_OK;
+    CatSegs s;
+    for (int i = 0; i < MFX_MAX_SEG; ++i) {
+        s.src[i] = i < d->nseg ? d->src[i] : nullptr; s.stride[i] = i < d->nseg ? d->stride[i] : 0; s.off[i] = i < d->nseg ? d->off[i] : 0;
+        if (i < d->nseg && !d->src[i]) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: null segment");
+    }
+    s.lgC = ilog2(d->Cseg); s.M = d->M;
+    EpiArgs ep;
+    ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
+    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = d->K_pad / (4 * elems); ep.tiles_n = 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MFX_F32) return dispatch_cat<float>(d, s, ep, st);
+    if (d->dtype == MFX_BF16) return dispatch_cat<bf16_t>(d, s, ep, st);
+    return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: bad dtype");
+}
+
+namespace mfx {
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_dcn(const mfx_dcn_desc* d, const DcnGeom& g, EpiArgs ep, hipStream_t st) {
+    ep.tiles_n = d->Cout_pad / BN;
+    const int tiles = cdiv(g.M, BM) * ep.tiles_n;
+    auto k = dcn_igemm_kernel<T, BM, BN, WM, WN>;
+    constexpr int smem = TileSmem<BM, BN>::bytes;
+    static bool attr_set = false;
+    if (!attr_set) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), smem, st, reinterpret_cast<const T*>(d->x), d->offmask,
+                       reinterpret_cast<const T*>(d->w), g, ep);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+template <typename T> static int dispatch_dcn(const mfx_dcn_desc* d, const DcnGeom& g, const EpiArgs& ep, hipStream_t st) {
+    const int N = d->Cout_pad;
+    if (N % 64 != 0) return mfx_fail(MFX_ERR_ARG, "dcn: Cout_pad must be a multiple of 64");
+    if (N == 64 && cdiv(g.M, 128) >= 512) return launch_dcn<T, 128, 64, 4, 1>(d, g, ep, st);
+    if (N % 128 == 0 && cdiv(g.M, 128) * (N / 128) >= 512) return launch_dcn<T, 128, 128, 2, 2>(d, g, ep, st);
+    return launch_dcn<T, 64, 64, 2, 2>(d, g, ep, st);
+}
+}  // namespace mfx
+
+extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
+    if (!d || !d->x || !d->offmask || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "dcn: null pointer");
+    const int elems = d->dtype == MFX_BF16 ? 8 : 4;
+    if (d->dtype != MFX_F32 && d->dtype != MFX_BF16) return mfx_fail(MFX_ERR_ARG, "dcn: bad dtype");
+    if (!is_pow2(d->C) || d->C < 4 * elems) return mfx_fail(MFX_ERR_ARG, "dcn: C must be a power of two >= 64 bytes of channels");
+    if (d->kh * d->kw > 9) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn: at most 9 taps (offmask row is 32 floats)");
+    if (d->K_pad != d->kh * d->kw * d->C) return mfx_fail(MFX_ERR_ARG, "dcn: K_pad != kh*kw*C");
+    if (d->Cout % elems != 0 || d->Cout > d->Cout_pad) return mfx_fail(MFX_ERR_ARG, "dcn: bad Cout");
+    DcnGeom g;
+    g.H = d->H; g.W = d->W; g.C = d->C; g.lgC = ilog2(d->C); g.Ho = d->Ho; g.Wo = d->Wo; g.kh = d->kh; g.kw = d->kw;
+    g.inv_kw = (65536 + d->kw - 1) / d->kw; g.stride = d->stride; g.pad = d->pad; g.dil = d->dil; g.M = d->B * d->Ho * d->Wo;
+    if (g.M <= 0) return MFX_OK;
+    EpiArgs ep;
+    ep.scale = d->scale; ep.shift = d->shift; ep.res = nullptr; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = 0;
+    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = d->K_pad / (4 * elems); ep.tiles_n = 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return d->dtype == MFX_F32 ? dispatch_dcn<float>(d, g, ep, st) : dispatch_dcn<bf16_t>(d, g, ep, st);
+}

@@ -1,0 +1,311 @@
+// Backward of the modulated deformable convolution at the reference `_ext.dcn_v2_backward` boundary
+// (/root/reference/model/backbone/DCNv2/src/dcn_v2.h:48-92; math of src/cuda/dcn_v2_cuda.cu:206-335 and
+// src/cuda/dcn_v2_im2col_cuda.cu:197-327), restructured for NHWC / gfx950:
+//   * no per-image host loop: the whole batch is one set of launches;
+//   * d(columns) = grad_out x W is one MFMA GEMM (the shared implicit-GEMM kernel as a 1x1 conv);
+//   * grad_offset / grad_mask: one wavefront per (pixel, tap), lanes over channels, wave reduction
+//     (the reference loops over channels inside one thread);
+//   * grad_input: the same wavefront scatters to the four corners; lanes hit consecutive channels,
+//     so the float atomics are coalesced 256-byte bursts;
+//   * grad_weight: re-samples the columns tile into LDS (never to HBM) and contracts it with grad_out
+//     over a slab of pixels per workgroup (split over pixels, atomics on the small weight gradient).
+#include "../../include/monoflex_hip.h"
+#include "common.h"
+#include "err.h"
+
+namespace mfx {
+
+static inline int next_pow2_(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline int cdv(long a, long b) { return (int)((a + b - 1) / b); }
+
+struct BwdGeom { int B, H, W, Cp, lgC, Ho, Wo, kh, kw, kk, stride, pad, dil, M, K, Kp, Coutp; };
+
+struct TapGeo { int off[4]; float w[4]; float lh, lw, hh, hw; bool inside; bool cv[4]; };
+
+// geometry of one (pixel, tap) sample -- same rules as the forward sampler (dcn_v2_im2col_cuda.cu:25-54,178-189)
+__device__ __forceinline__ TapGeo tap_geometry(const BwdGeom& g, const float* om_row, int b, int oh, int ow, int tap) {
+    TapGeo t;
+    const int th = tap / g.kw, tw = tap - th * g.kw;
+    const float h = (float)(oh * g.stride - g.pad + th * g.dil) + om_row[2 * tap];
+    const float w = (float)(ow * g.stride - g.pad + tw * g.dil) + om_row[2 * tap + 1];
+    t.inside = h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
+    const float hf = floorf(h), wf = floorf(w);
+    const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
+    t.lh = h - hf; t.lw = w - wf; t.hh = 1.f - t.lh; t.hw = 1.f - t.lw;
+    const bool t0 = t.inside && h0 >= 0, t1 = t.inside && h1 <= g.H - 1, l0 = w0 >= 0, l1 = w1 <= g.W - 1;
+    const int ch0 = min(max(h0, 0), g.H - 1), ch1 = min(max(h1, 0), g.H - 1);
+    const int cw0 = min(max(w0, 0), g.W - 1), cw1 = min(max(w1, 0), g.W - 1);
+    const int pix0 = b * g.H * g.W;
+    t.off[0] = pix0 + ch0 * g.W + cw0; t.cv[0] = t0 && l0; t.w[0] = t.hh * t.hw;
+    t.off[1] = pix0 + ch0 * g.W + cw1; t.cv[1] = t0 && l1; t.w[1] = t.hh * t.lw;
+    t.off[2] = pix0 + ch1 * g.W + cw0; t.cv[2] = t1 && l0; t.w[2] = t.lh * t.hw;
+    t.off[3] = pix0 + ch1 * g.W + cw1; t.cv[3] = t1 && l1; t.w[3] = t.lh * t.lw;
+    return t;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// grad wrt offsets, mask and input from d(columns).  One wavefront per (pixel m, tap).
+__global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const float* x, const float* om, const float* gcol, BwdGeom g,
+                                                             float* gx, float* gom) {
+    const int lane = threadIdx.x & 63;
+    const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long pair = wave_id; pair < (long)g.M * g.kk; pair += nwaves) {
+        const int m = (int)(pair / g.kk), tap = (int)(pair - (long)m * g.kk);
+        const int hw = g.Ho * g.Wo, b = m / hw, rem = m - b * hw, oh = rem / g.Wo, ow = rem - oh * g.Wo;
+        const float* om_row = om + (size_t)m * 32;
+        const float mask = om_row[18 + tap];
+        const TapGeo t = tap_geometry(g, om_row, b, oh, ow, tap);
+        float gm = 0.f, gh = 0.f, gw = 0.f;
+        if (t.inside) {
+            for (int c = lane; c < g.Cp; c += 64) {
+                const float gc = gcol[(size_t)m * g.Kp + tap * g.Cp + c];
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = t.cv[q] ? x[(size_t)t.off[q] * g.Cp + c] : 0.f;
+                gm += gc * (t.w[0] * v[0] + t.w[1] * v[1] + t.w[2] * v[2] + t.w[3] * v[3]);
+                // dmcn_get_coordinate_weight (dcn_v2_im2col_cuda.cu:82-122)
+                gh += (-t.hw * v[0] - t.lw * v[1] + t.hw * v[2] + t.lw * v[3]) * gc * mask;
+                gw += (-t.hh * v[0] + t.hh * v[1] - t.lh * v[2] + t.lh * v[3]) * gc * mask;
+                const float top = gc * mask;                  // col2im (dcn_v2_im2col_cuda.cu:197-254)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (t.cv[q]) unsafeAtomicAdd(gx + (size_t)t.off[q] * g.Cp + c, t.w[q] * top);
+            }
+        }
+        gm = wave_sum(gm); gh = wave_sum(gh); gw = wave_sum(gw);
+        if (lane == 0) {
+            float* o = gom + (size_t)m * 32;
+            o[2 * tap] = gh; o[2 * tap + 1] = gw; o[18 + tap] = gm;
+        }
+    }
+}
+
+// grad_weight[o][k] += sum over a slab of pixels of go[m][o] * col[m][k]; col re-sampled into LDS.
+// Block = 64 k x 64 o output tile, 256 threads each owning a 4x4 register block.
+constexpr int WG_MCH = 16;     // pixels staged per step
+__global__ __launch_bounds__(256) void dcn_bwd_wgrad_kernel(const float* x, const float* om, const float* go, BwdGeom g,
+                                                            int m_per_block, float* gw) {
+    __shared__ float cs[WG_MCH][64 + 4];     // col chunk  [m][k]
+    __shared__ float gs[WG_MCH][64 + 4];     // grad chunk [m][o]
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+    const int m_begin = blockIdx.z * m_per_block, m_end = min(m_begin + m_per_block, g.M);
+    const int tk = (tid & 15) * 4, to = (tid >> 4) * 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    // staging role: thread -> (row r = tid/16, 4 consecutive k / o at (tid%16)*4)
+    const int sr = tid >> 4, sc = (tid & 15) * 4;
+    const int hw = g.Ho * g.Wo;
+    for (int mb = m_begin; mb < m_end; mb += WG_MCH) {
+        const int m = mb + sr;
+        float cv4[4] = {0.f, 0.f, 0.f, 0.f}, gv4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < m_end) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(go + (size_t)m * g.Coutp + o0 + sc);
+            gv4[0] = gg[0]; gv4[1] = gg[1]; gv4[2] = gg[2]; gv4[3] = gg[3];
+            const int k = k0 + sc;
+            if (k < g.K) {                                   // Cp >= 16 -> the 4 k's share one tap
+                const int tap = k >> g.lgC, c = k & (g.Cp - 1);
+                const int b = m / hw, rem = m - b * hw, oh = rem / g.Wo, ow = rem - oh * g.Wo;
+                const float* om_row = om + (size_t)m * 32;
+                const TapGeo t = tap_geometry(g, om_row, b, oh, ow, tap);
+                const float mask = om_row[18 + tap];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (t.cv[q]) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)t.off[q] * g.Cp + c);
+                        const float wq = t.w[q] * mask;
+                        cv4[0] += wq * v[0]; cv4[1] += wq * v[1]; cv4[2] += wq * v[2]; cv4[3] += wq * v[3];
+                    }
+            }
+        }
+        __syncthreads();                                      // previous step's readers are done
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs[sr][sc + e] = cv4[e]; gs[sr][sc + e] = gv4[e]; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < WG_MCH; ++r) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&cs[r][tk]);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(&gs[r][to]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bb[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + tk + i < g.K) unsafeAtomicAdd(gw + (size_t)(o0 + to + j) * g.K + k0 + tk + i, acc[i][j]);
+}
+
+// grad_bias[o] = sum_m go[m][o]
+__global__ void dcn_bwd_bias_kernel(const float* go, int M, int Coutp, int rows_per_block, float* gb) {
+    const int o = blockIdx.y * 64 + threadIdx.x;
+    const int r0 = blockIdx.x * rows_per_block;
+    float s = 0.f;
+    for (int r = r0 + threadIdx.y; r < min(r0 + rows_per_block, M); r += blockDim.y) s += go[(size_t)r * Coutp + o];
+    __shared__ float red[4][64];
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0) unsafeAtomicAdd(gb + o, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// packing / unpacking between the reference layouts and the kernels' layouts
+__global__ void bwd_pack_offmask(const float* offset, const float* mask, float* om, int B, int HW, int kk) {
+    const long total = (long)B * HW * 32;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i & 31);
+        const long m = i >> 5;
+        const int b = (int)(m / HW), p = (int)(m - (long)b * HW);
+        float v = 0.f;
+        if (ch < 18) { if (ch < 2 * kk) v = offset[((size_t)b * 2 * kk + ch) * HW + p]; }
+        else if (ch < 27) { if (ch - 18 < kk) v = mask[((size_t)b * kk + (ch - 18)) * HW + p]; }
+        om[i] = v;
+    }
+}
+__global__ void bwd_unpack_offmask(const float* gom, float* goff, float* gmask, int B, int HW, int kk) {
+    const long total = (long)B * HW * 3 * kk;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const int ch = (int)((i / HW) % (3 * kk));
+        const int b = (int)(i / ((long)HW * 3 * kk));
+        const size_t m = (size_t)b * HW + p;
+        if (ch < 2 * kk) goff[((size_t)b * 2 * kk + ch) * HW + p] = gom[m * 32 + ch];
+        else gmask[((size_t)b * kk + (ch - 2 * kk)) * HW + p] = gom[m * 32 + 18 + (ch - 2 * kk)];
+    }
+}
+// weight (Cout,C,kk) -> transposed pack wT[Kp][Coutp]: wT[tap*Cp+c][o]
+__global__ void bwd_pack_weight_t(const float* w, float* wT, int Cout, int C, int kk, int Cp, int Kp, int Coutp) {
+    const long total = (long)Kp * Coutp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % Coutp);
+        const int k = (int)(i / Coutp);
+        const int tap = k / Cp, c = k - tap * Cp;
+        wT[i] = (o < Cout && c < C && tap < kk) ? w[((size_t)o * C + c) * kk + tap] : 0.f;
+    }
+}
+// packed grad [Coutp][K] (k = tap*Cp+c) -> (Cout,C,kk)
+__global__ void bwd_unpack_weight(const float* gwp, float* gw, int Cout, int C, int kk, int Cp, int K) {
+    const long total = (long)Cout * C * kk;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % kk);
+        const int c = (int)((i / kk) % C);
+        const int o = (int)(i / ((long)kk * C));
+        gw[i] = gwp[(size_t)o * K + tap * Cp + c];
+    }
+}
+
+}  // namespace mfx
+using namespace mfx;
+
+#define BWD_GRID(total) dim3((unsigned)(cdv((total), 256) < 8192 ? cdv((total), 256) : 8192))
+
+struct BwdLayout { size_t x, om, wT, go, gcol, gx, gom, gwp, gb, total; };
+static BwdLayout bwd_layout(const BwdGeom& g) {
+    BwdLayout L; size_t o = 0;
+    L.x = o;    o += al256((size_t)g.B * g.H * g.W * g.Cp * 4);
+    L.om = o;   o += al256((size_t)g.M * 32 * 4);
+    L.wT = o;   o += al256((size_t)g.Kp * g.Coutp * 4);
+    L.go = o;   o += al256((size_t)g.M * g.Coutp * 4);
+    L.gcol = o; o += al256((size_t)g.M * g.Kp * 4);
+    L.gx = o;   o += al256((size_t)g.B * g.H * g.W * g.Cp * 4);
+    L.gom = o;  o += al256((size_t)g.M * 32 * 4);
+    L.gwp = o;  o += al256((size_t)g.Coutp * g.K * 4);
+    L.gb = o;   o += al256((size_t)g.Coutp * 4);
+    L.total = o;
+    return L;
+}
+static BwdGeom bwd_geom(int B, int C, int H, int W, int Cout, int kh, int kw, int s, int p, int d) {
+    BwdGeom g;
+    g.B = B; g.H = H; g.W = W; g.Cp = next_pow2_(C < 16 ? 16 : C); g.lgC = 0; while ((1 << g.lgC) < g.Cp) ++g.lgC;
+    g.kh = kh; g.kw = kw; g.kk = kh * kw; g.stride = s; g.pad = p; g.dil = d;
+    g.Ho = (H + 2 * p - (d * (kh - 1) + 1)) / s + 1; g.Wo = (W + 2 * p - (d * (kw - 1) + 1)) / s + 1;
+    g.M = B * g.Ho * g.Wo; g.K = g.kk * g.Cp; g.Kp = ((g.K + 63) / 64) * 64;
+    g.Coutp = next_pow2_(Cout < 64 ? 64 : Cout);
+    return g;
+}
+
+extern "C" size_t mfx_dcn_v2_backward_workspace_bytes_(int B, int C, int H, int W, int Cout, int kh, int kw, int s, int p, int d) {
+    return bwd_layout(bwd_geom(B, C, H, W, Cout, kh, kw, s, p, d)).total;
+}
+
+extern "C" int mfx_dcn_v2_backward(const float* input, const float* weight, const float* bias,
+                                   const float* offset, const float* mask, const float* grad_output,
+                                   float* grad_input, float* grad_offset, float* grad_mask,
+                                   float* grad_weight, float* grad_bias,
+                                   int B, int C, int H, int W, int Cout, int kh, int kw,
+                                   int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                                   int deformable_group, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)bias;
+    if (!input || !weight || !offset || !mask || !grad_output || !grad_input || !grad_offset || !grad_mask || !grad_weight || !grad_bias)
+        return mfx_fail(MFX_ERR_ARG, "dcn_v2_backward: null pointer");
+    if (deformable_group != 1) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_v2_backward: deformable_group must be 1");
+    if (stride_h != stride_w || dil_h != dil_w || pad_h != pad_w) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_v2_backward: square stride/pad/dilation only");
+    if (kh * kw > 9) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_v2_backward: at most 9 taps");
+    const BwdGeom g = bwd_geom(B, C, H, W, Cout, kh, kw, stride_h, pad_h, dil_h);
+    if (g.Ho <= 0 || g.Wo <= 0) return mfx_fail(MFX_ERR_ARG, "dcn_v2_backward: empty output");
+    const BwdLayout L = bwd_layout(g);
+    if (!workspace || workspace_bytes < L.total) return mfx_fail(MFX_ERR_WORKSPACE, "dcn_v2_backward: workspace too small");
+    if (g.M == 0) return MFX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* x = (float*)(ws + L.x); float* om = (float*)(ws + L.om); float* wT = (float*)(ws + L.wT);
+    float* go = (float*)(ws + L.go); float* gcol = (float*)(ws + L.gcol); float* gx = (float*)(ws + L.gx);
+    float* gom = (float*)(ws + L.gom); float* gwp = (float*)(ws + L.gwp); float* gb = (float*)(ws + L.gb);
+    const int HWo = g.Ho * g.Wo;
+
+    int rc = mfx_nchw_to_nhwc(input, x, B, C, H, W, g.Cp, MFX_F32, stream);
+    if (rc) return rc;
+    rc = mfx_nchw_to_nhwc(grad_output, go, B, Cout, g.Ho, g.Wo, g.Coutp, MFX_F32, stream);   // .contiguous() is the caller's job (App. C item 18)
+    if (rc) return rc;
+    hipLaunchKernelGGL(bwd_pack_offmask, BWD_GRID((long)g.M * 32), dim3(256), 0, st, offset, mask, om, B, HWo, g.kk);
+    hipLaunchKernelGGL(bwd_pack_weight_t, BWD_GRID((long)g.Kp * g.Coutp), dim3(256), 0, st, weight, wT, Cout, C, g.kk, g.Cp, g.Kp, g.Coutp);
+    MFX_HIP_CHECK(hipMemsetAsync(gx, 0, (size_t)B * H * W * g.Cp * 4, st));
+    MFX_HIP_CHECK(hipMemsetAsync(gwp, 0, (size_t)g.Coutp * g.K * 4, st));
+    MFX_HIP_CHECK(hipMemsetAsync(gb, 0, (size_t)g.Coutp * 4, st));
+    MFX_HIP_CHECK(hipGetLastError());
+
+    // d(columns)[m][k] = sum_o go[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM
+    mfx_conv_desc cd;
+    cd.x = go; cd.w = wT; cd.scale = nullptr; cd.shift = nullptr; cd.res = nullptr; cd.y = gcol; cd.rowmap = nullptr;
+    cd.B = 1; cd.H = 1; cd.W = g.M; cd.x_pixstride = g.Coutp; cd.Ck = g.Coutp; cd.kh = 1; cd.kw = 1; cd.stride = 1;
+    cd.pad_h = 0; cd.pad_w = 0; cd.dil_w = 1; cd.Ho = 1; cd.Wo = g.M; cd.M = g.M; cd.Cout = g.Kp; cd.Cout_pad = g.Kp;
+    cd.K_pad = g.Coutp; cd.ldy = g.Kp; cd.ldres = 0; cd.act = MFX_ACT_NONE; cd.dtype = MFX_F32; cd.out_dtype = MFX_F32;
+    rc = mfx_conv2d_nhwc(&cd, stream);
+    if (rc) return rc;
+
+    {   // grad_offset, grad_mask, grad_input
+        const long pairs = (long)g.M * g.kk;
+        const int blocks = (int)((pairs + 3) / 4 < 65536 ? (pairs + 3) / 4 : 65536);
+        hipLaunchKernelGGL(dcn_bwd_sample_kernel, dim3(blocks), dim3(256), 0, st, x, om, gcol, g, gx, gom);
+    }
+    {   // grad_weight
+        const int m_per_block = 2048;
+        dim3 grid(g.Kp / 64, g.Coutp / 64, cdv(g.M, m_per_block));
+        hipLaunchKernelGGL(dcn_bwd_wgrad_kernel, grid, dim3(256), 0, st, x, om, go, g, m_per_block, gwp);
+    }
+    {   // grad_bias
+        const int rows = 1024;
+        hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3(cdv(g.M, rows), g.Coutp / 64), dim3(64, 4), 0, st, go, g.M, g.Coutp, rows, gb);
+    }
+    MFX_HIP_CHECK(hipGetLastError());
+
+    rc = mfx_nhwc_to_nchw(gx, grad_input, B, C, H, W, g.Cp, MFX_F32, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bwd_unpack_offmask, BWD_GRID((long)g.M * 3 * g.kk), dim3(256), 0, st, gom, grad_offset, grad_mask, B, HWo, g.kk);
+    hipLaunchKernelGGL(bwd_unpack_weight, BWD_GRID((long)Cout * C * g.kk), dim3(256), 0, st, gwp, grad_weight, Cout, C, g.kk, g.Cp, g.K);
+    MFX_HIP_CHECK(hipMemcpyAsync(grad_bias, gb, (size_t)Cout * 4, hipMemcpyDeviceToDevice, st));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}

@@ -1,0 +1,234 @@
+// Detection decode on device (reference model/layers/utils.py:39-145, model/head/detector_infer.py:77-237,
+// model/anno_encoder.py:69-295): sigmoid/clamp -> 3x3 max NMS -> per-class top-K -> merge to K ->
+// POI gather (free in NHWC) -> 2D box / dimensions / 4 depths / soft fusion / location / orientation.
+// Latency-bound (reads 3*H*W + K*50 values per image); two launches, no host sync.
+#include "../../include/monoflex_hip.h"
+#include "common.h"
+#include "err.h"
+
+namespace mfx {
+
+constexpr int kTopkThreads = 1024;
+constexpr float kPi = 3.14159265358979323846f;
+
+__device__ __forceinline__ float sigmoid_clamp(float x) {          // layers/utils.py:39-43
+    const float s = 1.f / (1.f + expf(-x));
+    return fminf(fmaxf(s, 1e-4f), 1.f - 1e-4f);
+}
+
+// (value desc, index asc) ordering; ties go to the lower flat index
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+// One workgroup per (class, image).  Scores live in LDS; K rounds of block-wide arg-max extraction.
+__global__ __launch_bounds__(kTopkThreads) void decode_topk_kernel(const float* hmap, int ld, int ch_off, int H, int W, int K,
+                                                                    float* scores, int* index) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* nm = reinterpret_cast<float*>(smem_raw);                // [H*W] heat after NMS
+    __shared__ float red_v[kTopkThreads / 64];
+    __shared__ int red_i[kTopkThreads / 64];
+    __shared__ int win_i;
+    const int cls = blockIdx.x, b = blockIdx.y, ncls = gridDim.x, HW = H * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = hmap + (size_t)b * HW * ld + ch_off + cls;
+    // nms_hm: keep where the 3x3 max-pool (implicit -inf padding) equals the value (plateaus survive).
+    // Neighbour heats are recomputed from the logits (L2-resident) so LDS holds one map only.
+    for (int p = tid; p < HW; p += kTopkThreads) {
+        const int y = p / W, x = p - y * W;
+        const float v = sigmoid_clamp(src[(size_t)p * ld]);
+        float mx = v;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W || (dx == 0 && dy == 0)) continue;
+                mx = fmaxf(mx, sigmoid_clamp(src[(size_t)(yy * W + xx) * ld]));
+            }
+        }
+        nm[p] = (mx == v) ? v : 0.f;
+    }
+    __syncthreads();
+    // thread-local best over its strided elements
+    float bv = -1.f; int bi = 0x7fffffff;
+    for (int p = tid; p < HW; p += kTopkThreads) { const float v = nm[p]; if (better(v, p, bv, bi)) { bv = v; bi = p; } }
+    for (int k = 0; k < K; ++k) {
+        float v = bv; int i = bi;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off); const int oi = __shfl_xor(i, off);
+            if (better(ov, oi, v, i)) { v = ov; i = oi; }
+        }
+        if (lane == 0) { red_v[wave] = v; red_i[wave] = i; }
+        __syncthreads();
+        if (wave == 0) {
+            float v2 = lane < kTopkThreads / 64 ? red_v[lane] : -2.f;
+            int i2 = lane < kTopkThreads / 64 ? red_i[lane] : 0x7fffffff;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(v2, off); const int oi = __shfl_xor(i2, off);
+                if (better(ov, oi, v2, i2)) { v2 = ov; i2 = oi; }
+            }
+            if (lane == 0) {
+                win_i = i2;
+                scores[((size_t)b * ncls + cls) * K + k] = v2;
+                index[((size_t)b * ncls + cls) * K + k] = i2;
+            }
+        }
+        __syncthreads();
+        const int wi = win_i;
+        if (wi < HW && (wi % kTopkThreads) == tid) {       // owner removes the winner and rescans its elements
+            nm[wi] = -1.f;
+            bv = -1.f; bi = 0x7fffffff;
+            for (int p = tid; p < HW; p += kTopkThreads) { const float v3 = nm[p]; if (better(v3, p, bv, bi)) { bv = v3; bi = p; } }
+        }
+        // win_i / red_* are rewritten only after the next round's first barrier -> no extra barrier needed
+    }
+}
+
+struct DecodeConst {
+    float dim_mean[3][3];     // (l,h,w) per class, config/defaults.py:206-208
+    float depth_min, depth_max;
+    float down_ratio, eps;
+};
+
+// key2channel offsets of runs/monoflex.yaml:27-28
+enum { R_2D = 0, R_OFF3D = 4, R_KPT = 6, R_KPT_UNC = 26, R_DIM3D = 29, R_ORI_CLS = 32, R_ORI_OFF = 40, R_DEPTH = 48, R_DEPTH_UNC = 49, R_TOTAL = 50 };
+
+__global__ __launch_bounds__(256) void decode_boxes_kernel(const float* hmap, int ld, int reg_off, const float* scores, const int* index,
+                                                           int ncls, int H, int W, int K, const float* calib, const int* pad,
+                                                           const int* img_size, float threshold, DecodeConst dc,
+                                                           float* det, float* topk, int* valid) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* cs = reinterpret_cast<float*>(smem_raw);          // [ncls*K]
+    int* ci = reinterpret_cast<int*>(cs + ncls * K);         // [ncls*K]
+    int* slot = ci + ncls * K;                               // [K] position (in the ncls*K list) of rank j
+    const int b = blockIdx.x, tid = threadIdx.x, n = ncls * K;
+    for (int t = tid; t < n; t += blockDim.x) { cs[t] = scores[(size_t)b * n + t]; ci[t] = index[(size_t)b * n + t]; }
+    __syncthreads();
+    // select_topk stage 2 (utils.py:88-91): top-K of the concatenated list, ties -> lower position
+    for (int t = tid; t < n; t += blockDim.x) {
+        const float v = cs[t];
+        int rank = 0;
+        for (int u = 0; u < n; ++u) rank += better(cs[u], u, v, t) ? 1 : 0;
+        if (rank < K) slot[rank] = t;
+    }
+    __syncthreads();
+    if (tid >= K) return;
+    const int j = tid, pos = slot[j];
+    const int cls = pos / K;                                  // utils.py:91 (integer floor division)
+    const float score = cs[pos];
+    const int idx = ci[pos];
+    const int ys = idx / W, xs = idx - ys * W;                // utils.py:80-81
+    const float* r = hmap + ((size_t)b * H * W + idx) * ld + reg_off;   // POI gather: one contiguous NHWC row
+    const float fu = calib[b * 6 + 0], fv = calib[b * 6 + 1], cu = calib[b * 6 + 2], cv = calib[b * 6 + 3];
+    const float bx = calib[b * 6 + 4], by = calib[b * 6 + 5];
+    const float padx = (float)pad[b * 2], pady = (float)pad[b * 2 + 1];
+    const float px = (float)xs, py = (float)ys;
+
+    // decode_box2d_fcos (anno_encoder.py:69-86); clamp uses image 0's padded size
+    float x1 = (px - fmaxf(r[R_2D + 0], 0.f)) * dc.down_ratio - padx;
+    float y1 = (py - fmaxf(r[R_2D + 1], 0.f)) * dc.down_ratio - pady;
+    float x2 = (px + fmaxf(r[R_2D + 2], 0.f)) * dc.down_ratio - padx;
+    float y2 = (py + fmaxf(r[R_2D + 3], 0.f)) * dc.down_ratio - pady;
+    const float wmax = (float)(img_size[0] - 1), hmax = (float)(img_size[1] - 1);
+    x1 = fminf(fmaxf(x1, 0.f), wmax); x2 = fminf(fmaxf(x2, 0.f), wmax);
+    y1 = fminf(fmaxf(y1, 0.f), hmax); y2 = fminf(fmaxf(y2, 0.f), hmax);
+
+    // decode_dimension (anno_encoder.py:221-243): exp(offset) * mean[cls], order (l,h,w)
+    const float dl = expf(r[R_DIM3D + 0]) * dc.dim_mean[cls][0];
+    const float dh = expf(r[R_DIM3D + 1]) * dc.dim_mean[cls][1];
+    const float dw = expf(r[R_DIM3D + 2]) * dc.dim_mean[cls][2];
+
+    // decode_depth inv_sigmoid (anno_encoder.py:124-140)
+    float d0 = 1.f / (1.f / (1.f + expf(-r[R_DEPTH]))) - 1.f;
+    d0 = fminf(fmaxf(d0, dc.depth_min), dc.depth_max);
+    const float u0 = expf(r[R_DEPTH_UNC]);
+
+    // decode_depth_from_keypoints_batch (anno_encoder.py:187-219); keypoint k = (r[6+2k], r[7+2k])
+    auto ky = [&](int k) { return r[R_KPT + 2 * k + 1]; };
+    auto kdepth = [&](float dy) { return fu * dh / (fmaxf(dy, 0.f) * dc.down_ratio + dc.eps); };
+    float d1 = kdepth(ky(8) - ky(9));
+    float d2 = (kdepth(ky(0) - ky(4)) + kdepth(ky(2) - ky(6))) / 2.f;
+    float d3 = (kdepth(ky(1) - ky(5)) + kdepth(ky(3) - ky(7))) / 2.f;
+    d1 = fminf(fmaxf(d1, dc.depth_min), dc.depth_max);
+    d2 = fminf(fmaxf(d2, dc.depth_min), dc.depth_max);
+    d3 = fminf(fmaxf(d3, dc.depth_min), dc.depth_max);
+    const float u1 = expf(r[R_KPT_UNC + 0]), u2 = expf(r[R_KPT_UNC + 1]), u3 = expf(r[R_KPT_UNC + 2]);
+
+    // 'soft' fusion (detector_infer.py:176-198)
+    float w0 = 1.f / u0, w1 = 1.f / u1, w2 = 1.f / u2, w3 = 1.f / u3;
+    const float ws = ((w0 + w1) + w2) + w3;
+    w0 /= ws; w1 /= ws; w2 /= ws; w3 /= ws;
+    const float depth = ((d0 * w0 + d1 * w1) + d2 * w2) + d3 * w3;
+    const float sigma = ((w0 * u0 + w1 * u1) + w2 * u2) + w3 * u3;
+
+    // decode_location_flatten (anno_encoder.py:142-155) + project_image_to_rect (kitti_utils.py:350-369)
+    const float u = (px + r[R_OFF3D + 0]) * dc.down_ratio - padx;
+    const float v = (py + r[R_OFF3D + 1]) * dc.down_ratio - pady;
+    const float X = ((u - cu) * depth) / fu + bx;
+    float Y = ((v - cv) * depth) / fv + by;
+    const float Z = depth;
+
+    // decode_axes_orientation, multi-bin (anno_encoder.py:245-295)
+    int best = 0; float bestp = -1.f;
+    for (int i = 0; i < 4; ++i) {
+        const float a = r[R_ORI_CLS + 2 * i], c = r[R_ORI_CLS + 2 * i + 1];
+        const float m = fmaxf(a, c), e0 = expf(a - m), e1 = expf(c - m);
+        const float p1 = e1 / (e0 + e1);
+        if (p1 > bestp) { bestp = p1; best = i; }
+    }
+    const float centers[4] = {0.f, kPi / 2.f, kPi, -kPi / 2.f};
+    float alpha = atan2f(r[R_ORI_OFF + 2 * best], r[R_ORI_OFF + 2 * best + 1]) + centers[best];
+    float ry = alpha + atan2f(X, Z);
+    if (ry > kPi) ry -= 2.f * kPi;
+    if (ry < -kPi) ry += 2.f * kPi;
+    if (alpha > kPi) alpha -= 2.f * kPi;
+    if (alpha < -kPi) alpha += 2.f * kPi;
+
+    Y += dh / 2.f;                                            // detector_infer.py:215
+    const float final_score = score * (1.f - fminf(fmaxf(sigma, 0.01f), 1.f));   // :225-227
+
+    float* o = det + ((size_t)b * K + j) * 14;
+    o[0] = (float)cls; o[1] = alpha; o[2] = x1; o[3] = y1; o[4] = x2; o[5] = y2;
+    o[6] = dh; o[7] = dw; o[8] = dl;                          // roll(-1): (l,h,w) -> (h,w,l)
+    o[9] = X; o[10] = Y; o[11] = Z; o[12] = ry; o[13] = final_score;
+    float* t = topk + ((size_t)b * K + j) * 5;
+    t[0] = score; t[1] = (float)idx; t[2] = (float)cls; t[3] = py; t[4] = px;
+    valid[b * K + j] = score >= threshold ? 1 : 0;
+}
+
+}  // namespace mfx
+using namespace mfx;
+
+extern "C" int mfx_decode_topk(const float* hmap, int ld, int ch_off, int ncls, int B, int H, int W, int K,
+                               float* scores, int32_t* index, void* stream) {
+    if (!hmap || !scores || !index) return mfx_fail(MFX_ERR_ARG, "decode_topk: null pointer");
+    if (K < 1 || K > H * W) return mfx_fail(MFX_ERR_ARG, "decode_topk: need 1 <= K <= H*W");
+    const size_t smem = (size_t)H * W * sizeof(float);
+    if (smem > 150 * 1024) return mfx_fail(MFX_ERR_UNSUPPORTED, "decode_topk: heat map larger than LDS (H*W <= 38400)");
+    if (B * ncls == 0) return MFX_OK;
+    auto k = decode_topk_kernel;
+    static size_t attr_smem = 0;
+    if (smem > attr_smem) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr_smem = smem; }
+    hipLaunchKernelGGL(k, dim3(ncls, B), dim3(kTopkThreads), smem, reinterpret_cast<hipStream_t>(stream),
+                       hmap, ld, ch_off, H, W, K, scores, index);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_decode_boxes(const float* hmap, int ld, int reg_off, const float* scores, const int32_t* index,
+                                int ncls, int B, int H, int W, int K, const float* calib, const int32_t* pad,
+                                const int32_t* img_size, float threshold, float* det, float* topk, int32_t* valid,
+                                void* stream) {
+    if (!hmap || !scores || !index || !calib || !pad || !img_size || !det || !topk || !valid)
+        return mfx_fail(MFX_ERR_ARG, "decode_boxes: null pointer");
+    if (K > 256 || ncls != 3) return mfx_fail(MFX_ERR_UNSUPPORTED, "decode_boxes: K <= 256, 3 classes (dimension means)");
+    if (B == 0) return MFX_OK;
+    DecodeConst dc = {{{3.8840f, 1.5261f, 1.6286f}, {0.8423f, 1.7607f, 0.6602f}, {1.7635f, 1.7372f, 0.5968f}},
+                      0.1f, 100.f, 4.f, 1e-3f};
+    const size_t smem = (size_t)ncls * K * 8 + (size_t)K * 4;
+    hipLaunchKernelGGL(decode_boxes_kernel, dim3(B), dim3(256), smem, reinterpret_cast<hipStream_t>(stream),
+                       hmap, ld, reg_off, scores, index, ncls, H, W, K, calib, pad, img_size, threshold, dc, det, topk, valid);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}

@@ -1,0 +1,154 @@
+// LDS-tiled MFMA main loop shared by the conv, concat-1x1 (DLA Root), deformable-conv and head kernels.
+//
+// GEMM view (NHWC activations, KRSC weights): D[m][n] = sum_k A[m][k] * Wt[n][k]
+//   m = output pixel (B*Ho*Wo), n = output channel, k = (tap, input channel)
+// Both operands are K-contiguous, so a 16-byte chunk (8 bf16 / 4 f32) is one lane's MFMA
+// fragment.  Per k-iteration a tile row is 64 bytes of K (4 chunks), padded to 80 bytes in LDS:
+// 16 rows x 80 B land on 16 distinct 16-byte bank slots -> conflict-free ds_read_b128.
+//
+// 256 threads = 4 waves in a WM x WN grid; register-staged double buffering: global loads of
+// k+1 are issued before the MFMAs of k and written to the other LDS stage afterwards, one
+// barrier per k-iteration.
+#pragma once
+#include "common.h"
+
+namespace mfx {
+
+constexpr int kThreads = 256;
+constexpr int kRowBytes = 80;          // 64 B of K + 16 B pad
+constexpr int kChunks = 4;             // 16-byte chunks per row per k-iteration
+
+template <int BM, int BN> struct TileSmem {
+    static constexpr int stage_bytes = (BM + BN) * kRowBytes;
+    static constexpr int mainloop_bytes = 2 * stage_bytes;
+    static constexpr int ldc = BN + 4;
+    static constexpr int epilogue_bytes = BM * ldc * 4;
+    static constexpr int bytes = mainloop_bytes > epilogue_bytes ? mainloop_bytes : epilogue_bytes;
+};
+
+// Weight (B operand) loader: rows n0.. of a [N_pad][K_pad] K-contiguous matrix.
+template <typename T, int BN> struct WeightLoader {
+    static constexpr int ELEMS = ElemTraits<T>::ELEMS;
+    static constexpr int R = (BN + 63) / 64;
+    const T* w; int ldk; int c, r0;
+    u32x4 regs[R];
+    __device__ __forceinline__ void init(const T* w_, int n0, int K_pad, int tid) {
+        c = tid & 3; r0 = tid >> 2; ldk = K_pad;
+        w = w_ + (size_t)n0 * K_pad + c * ELEMS;
+    }
+    __device__ __forceinline__ void load(int kiter) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int n = r0 + 64 * i;
+            if (BN >= 64 || n < BN)
+                regs[i] = *reinterpret_cast<const u32x4*>(w + (size_t)n * ldk + kiter * (kChunks * ELEMS));
+        }
+    }
+    __device__ __forceinline__ void store(char* Bs) const {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int n = r0 + 64 * i;
+            if (BN >= 64 || n < BN) *reinterpret_cast<u32x4*>(Bs + n * kRowBytes + c * 16) = regs[i];
+        }
+    }
+};
+
+// acc[FM][FN] += A-tile x B-tile over nk k-iterations.  ALoader provides load(kiter)/store(As).
+template <typename T, int BM, int BN, int WM, int WN, typename ALoader>
+__device__ __forceinline__ void gemm_mainloop(ALoader& al, WeightLoader<T, BN>& bl, int nk, char* smem,
+                                              f32x4 (&acc)[BM / WM / 16][BN / WN / 16]) {
+    constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+    constexpr int STAGE = TileSmem<BM, BN>::stage_bytes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int frag_off = (lane & 15) * kRowBytes + (lane >> 4) * 16;
+    const int a_off = wm * (BM / WM) * kRowBytes + frag_off;
+    const int b_off = BM * kRowBytes + wn * (BN / WN) * kRowBytes + frag_off;
+
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    al.load(0);
+    bl.load(0);
+    al.store(smem);
+    bl.store(smem + BM * kRowBytes);
+    __syncthreads();
+
+    for (int k = 0; k < nk; ++k) {
+        char* cur = smem + (k & 1) * STAGE;
+        char* nxt = smem + ((k + 1) & 1) * STAGE;
+        const bool more = (k + 1) < nk;
+        if (more) { al.load(k + 1); bl.load(k + 1); }
+
+        u32x4 af[FM], bf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(cur + a_off + i * 16 * kRowBytes);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(cur + b_off + j * 16 * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) mma_chunk<T>(af[i], bf[j], acc[i][j]);
+
+        if (more) { al.store(nxt); bl.store(nxt + BM * kRowBytes); }
+        __syncthreads();
+    }
+}
+
+// Epilogue: acc*scale+shift -> LDS (fp32) -> (+residual) -> activation -> coalesced 16-byte stores.
+template <typename T, typename TO, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem,
+                                               const float* scale, const float* shift, const T* res, int ldres,
+                                               TO* y, int ldy, int m0, int n0, int M, int Cout, int act) {
+    constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+    constexpr int LDC = TileSmem<BM, BN>::ldc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    float* Cs = reinterpret_cast<float*>(smem);
+    // (the main loop ended with a barrier: every wave is done reading the stage buffers)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = wn * (BN / WN) + j * 16 + (lane & 15);
+        const float sc = scale ? scale[n0 + n] : 1.f;
+        const float sh = shift ? shift[n0 + n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = wm * (BM / WM) + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(m + r) * LDC + n] = acc[i][j][r] * sc + sh;
+        }
+    }
+    __syncthreads();
+    constexpr int OE = ElemTraits<TO>::ELEMS;
+    constexpr int GPR = BN / OE;
+    for (int g = tid; g < BM * GPR; g += kThreads) {
+        const int m = g / GPR, ng = g - m * GPR;
+        const int gm = m0 + m, gn = n0 + ng * OE;
+        if (gm >= M || gn >= Cout) continue;
+        float v[OE];
+#pragma unroll
+        for (int e = 0; e < OE; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(Cs + m * LDC + ng * OE + e);
+            v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+        }
+        if (res) {
+            const T* rp = res + (size_t)gm * ldres + gn;
+            if constexpr (ElemTraits<T>::ELEMS == OE) {      // same element type: one 16-byte chunk
+                float rv[OE];
+                ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(rp), rv);
+#pragma unroll
+                for (int e = 0; e < OE; ++e) v[e] += rv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < OE; ++e) v[e] += ElemTraits<T>::load(rp + e);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < OE; ++e) v[e] = apply_act(v[e], act, gn + e);
+        *reinterpret_cast<u32x4*>(y + (size_t)gm * ldy + gn) = ElemTraits<TO>::pack(v);
+    }
+}
+
+}  // namespace mfx

@@ -1,0 +1,98 @@
+"""ctypes binding of libmonoflex_hip.so (the C ABI declared in include/monoflex_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or an entry point returns an
+error code, a RuntimeError is raised with the library's own message.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libmonoflex_hip.so")
+
+MFX_F32, MFX_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_DCN_OFFMASK = 0, 1, 2, 3
+MAX_SEG = 9
+
+c_int, c_void_p, c_float, c_size_t = ctypes.c_int32, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("res", c_void_p),
+                ("y", c_void_p), ("rowmap", c_void_p),
+                ("B", c_int), ("H", c_int), ("W", c_int), ("x_pixstride", c_int), ("Ck", c_int),
+                ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad_h", c_int), ("pad_w", c_int), ("dil_w", c_int),
+                ("Ho", c_int), ("Wo", c_int), ("M", c_int), ("Cout", c_int), ("Cout_pad", c_int), ("K_pad", c_int),
+                ("ldy", c_int), ("ldres", c_int), ("act", c_int), ("dtype", c_int), ("out_dtype", c_int)]
+
+
+class CatDesc(ctypes.Structure):
+    _fields_ = [("src", c_void_p * MAX_SEG), ("stride", c_int * MAX_SEG), ("off", c_int * MAX_SEG),
+                ("nseg", c_int), ("Cseg", c_int),
+                ("w", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("y", c_void_p),
+                ("M", c_int), ("Cout", c_int), ("Cout_pad", c_int), ("K_pad", c_int), ("ldy", c_int),
+                ("ldres", c_int), ("act", c_int), ("dtype", c_int)]
+
+
+class DcnDesc(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("offmask", c_void_p), ("w", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("y", c_void_p),
+                ("B", c_int), ("H", c_int), ("W", c_int), ("C", c_int),
+                ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad", c_int), ("dil", c_int),
+                ("Ho", c_int), ("Wo", c_int), ("Cout", c_int), ("Cout_pad", c_int), ("K_pad", c_int),
+                ("ldy", c_int), ("act", c_int), ("dtype", c_int)]
+
+
+class HeadsDesc(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("w1", c_void_p), ("scale1", c_void_p), ("shift1", c_void_p), ("w2", c_void_p),
+                ("bias2", c_void_p), ("out", c_void_p),
+                ("B", c_int), ("H", c_int), ("W", c_int), ("nbranch", c_int), ("K_pad", c_int), ("ld_out", c_int),
+                ("dtype", c_int), ("ch_off", c_int * 16), ("c_out", c_int * 16)]
+
+
+# every symbol include/monoflex_hip.h declares: name -> (restype, argtypes)
+_P, _I, _F, _S = c_void_p, c_int, c_float, c_size_t
+SYMBOLS = {
+    "mfx_abi_version": (_I, []),
+    "mfx_last_error": (ctypes.c_char_p, []),
+    "mfx_dcn_v2_workspace_bytes": (_S, [_I] * 14),
+    "mfx_dcn_v2_forward": (_I, [_P] * 6 + [_I] * 14 + [_P, _S, _P]),
+    "mfx_dcn_v2_backward": (_I, [_P] * 11 + [_I] * 14 + [_P, _S, _P]),
+    "mfx_conv2d_nhwc": (_I, [ctypes.POINTER(ConvDesc), _P]),
+    "mfx_cat_conv1x1_nhwc": (_I, [ctypes.POINTER(CatDesc), _P]),
+    "mfx_dcn_nhwc": (_I, [ctypes.POINTER(DcnDesc), _P]),
+    "mfx_maxpool2x2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "mfx_upsample_add_nhwc": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mfx_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mfx_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mfx_pack_image_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mfx_heads_fused": (_I, [ctypes.POINTER(HeadsDesc), _P]),
+    "mfx_edge_scatter_add": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "mfx_decode_topk": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mfx_decode_boxes": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (building it is __graft_entry__.build()'s / build.py's job)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libmonoflex_hip.so is missing (%s): run `python -m monoflex_amd.build`; "
+                           "the MonoFlex HIP path has no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.mfx_abi_version() != 1:
+        raise RuntimeError("libmonoflex_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mfx_last_error().decode(errors="replace")
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg))

@@ -1,0 +1,121 @@
+"""DCNv2 operator surface of the reference (model/backbone/DCNv2/dcn_v2.py:16-128):
+`_DCNv2` autograd Function, `dcn_v2_conv`, `DCNv2`, `DCN` -- same names, arguments and error
+behaviour, backed by the gfx950 kernels through `_ext`."""
+import math
+
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair
+
+from . import _ext as _backend
+from .... import lib as L
+from .... import ops
+
+
+class _DCNv2(Function):
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+        ctx.stride = _pair(stride)
+        ctx.padding = _pair(padding)
+        ctx.dilation = _pair(dilation)
+        ctx.kernel_size = _pair(weight.shape[2:4])
+        ctx.deformable_groups = deformable_groups
+        output = _backend.dcn_v2_forward(input, weight, bias, offset, mask,
+                                         ctx.kernel_size[0], ctx.kernel_size[1], ctx.stride[0], ctx.stride[1],
+                                         ctx.padding[0], ctx.padding[1], ctx.dilation[0], ctx.dilation[1],
+                                         ctx.deformable_groups)
+        ctx.save_for_backward(input, offset, mask, weight, bias)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input, offset, mask, weight, bias = ctx.saved_tensors
+        grad_input, grad_offset, grad_mask, grad_weight, grad_bias = _backend.dcn_v2_backward(
+            input, weight, bias, offset, mask, grad_output,
+            ctx.kernel_size[0], ctx.kernel_size[1], ctx.stride[0], ctx.stride[1],
+            ctx.padding[0], ctx.padding[1], ctx.dilation[0], ctx.dilation[1], ctx.deformable_groups)
+        return grad_input, grad_offset, grad_mask, grad_weight, grad_bias, None, None, None, None
+
+
+dcn_v2_conv = _DCNv2.apply
+
+
+class DCNv2(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        self.deformable_groups = deformable_groups
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.Tensor(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1.0 / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+        self.bias.data.zero_()
+
+    def forward(self, input, offset, mask):
+        assert 2 * self.deformable_groups * self.kernel_size[0] * self.kernel_size[1] == offset.shape[1]
+        assert self.deformable_groups * self.kernel_size[0] * self.kernel_size[1] == mask.shape[1]
+        return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                           self.dilation, self.deformable_groups)
+
+
+class DCN(DCNv2):
+    """DCNv2 + its own 27-channel offset/mask conv (zero-initialised), reference dcn_v2.py:97-128."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, deformable_groups)
+        channels_ = self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1]
+        self.conv_offset_mask = nn.Conv2d(self.in_channels, channels_, kernel_size=self.kernel_size,
+                                          stride=self.stride, padding=self.padding, bias=True)
+        self.init_offset()
+        self._packs = {}
+
+    def init_offset(self):
+        self.conv_offset_mask.weight.data.zero_()
+        self.conv_offset_mask.bias.data.zero_()
+
+    # ---- NHWC fast path ------------------------------------------------------------------------
+    def packed_offset(self, dtype):
+        key = ("off", dtype)
+        if key not in self._packs:
+            c = self.conv_offset_mask
+            self._packs[key] = ops.pack_conv(c.weight, dtype, None, c.bias, stride=self.stride[0], pad=self.padding[0],
+                                             act=L.ACT_DCN_OFFMASK, cout=32)
+        return self._packs[key]
+
+    def packed_main(self, dtype, bn=None, act=L.ACT_NONE):
+        key = ("main", dtype, id(bn), act)
+        if key not in self._packs:
+            if bn is not None:
+                scale, shift = ops.fold_bn(bn, self.bias)
+            else:
+                scale, shift = None, self.bias
+            p = ops.pack_conv(self.weight, dtype, scale, shift, stride=self.stride[0], pad=self.padding[0], act=act)
+            p.dil_w = self.dilation[0]
+            self._packs[key] = p
+        return self._packs[key]
+
+    def forward_nhwc(self, x, bn=None, act=L.ACT_NONE):
+        """x (B,H,W,C) NHWC; offset/mask conv (fp32 out, sigmoid on the 9 mask channels fused) then the
+        fused gather+MFMA kernel with bias (+BN, +act) folded into its epilogue."""
+        offmask = ops.conv2d(x, self.packed_offset(x.dtype), out_dtype=torch.float32)
+        return ops.dcn(x, offmask, self.packed_main(x.dtype, bn, act))
+
+    def forward(self, input):
+        if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad and self.training):
+            raise NotImplementedError("DCN training path (offset conv backward) lands with the backward kernels; "
+                                      "use dcn_v2_conv / DCNv2 for a differentiable deformable conv")
+        dtype = torch.float32 if input.dtype == torch.float32 else torch.bfloat16
+        x = ops.nchw_to_nhwc(input, dtype)
+        y = self.forward_nhwc(x)
+        return ops.nhwc_to_nchw(y)

@@ -1,0 +1,195 @@
+"""Detection heads (reference model/head/detector_predictor.py:19-169) on the gfx950 kernels.
+
+Parameter names follow the reference (`class_head.{0,1,2}`, `reg_features.{i}.{0,1}`,
+`reg_heads.{i}.{j}`, `trunc_heatmap_conv.{0,1,3}`, `trunc_offset_conv.{0,1,3}`).  InPlaceABN
+(third-party, not vendored) is held as a BatchNorm2d subclass with the same parameter/buffer names;
+its semantics here are BN(eps=1e-5) -> leaky_relu(0.01) (`abn_abs_weight`
+selects upstream's |gamma|+eps variant).
+
+Forward: one fused launch for the nine 3x3->ABN->1x1 branches, then the edge-fusion tail
+(re-evaluates the two needed trunks at the <=832 border points only, Conv1d k3 (replicate pad) +
+BN1d + Conv1d 1x1, scatter-add into the class / 3d_offset channels).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from ... import lib as L
+from ... import ops
+from ..backbone.dla_dcn import _eval_only
+
+HM_LD = 64          # fp32 head map row: [0:3] class logits, [8:58] regression channels
+REG_OFF = 8
+
+
+class InPlaceABN(nn.BatchNorm2d):
+    """Parameter holder for the head's fused BN + leaky_relu(0.01)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation="leaky_relu", activation_param=0.01):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine)
+        self.activation, self.activation_param = activation, activation_param
+
+
+class _predictor(nn.Module):
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        classes = len(cfg.DATASETS.DETECT_CLASSES)
+        self.regression_head_cfg = cfg.MODEL.HEAD.REGRESSION_HEADS
+        self.regression_channel_cfg = cfg.MODEL.HEAD.REGRESSION_CHANNELS
+        self.output_width = cfg.INPUT.WIDTH_TRAIN // cfg.MODEL.BACKBONE.DOWN_RATIO
+        self.output_height = cfg.INPUT.HEIGHT_TRAIN // cfg.MODEL.BACKBONE.DOWN_RATIO
+        self.head_conv = cfg.MODEL.HEAD.NUM_CHANNEL
+        self.use_inplace_abn = cfg.MODEL.INPLACE_ABN
+        self.bn_momentum = cfg.MODEL.HEAD.BN_MOMENTUM
+        self.abn_abs_weight = False
+        if not self.use_inplace_abn or cfg.MODEL.HEAD.USE_NORMALIZATION != "BN":
+            raise NotImplementedError("the HIP heads implement the runs/monoflex.yaml configuration "
+                                      "(INPLACE_ABN True, BN): conv3x3 -> BN -> leaky_relu(0.01) -> conv1x1")
+        if self.head_conv != 256 or in_channels != 64:
+            raise NotImplementedError("fused heads kernel is built for 64 -> 256 trunks")
+
+        def trunk():
+            return [nn.Conv2d(in_channels, self.head_conv, kernel_size=3, padding=1, bias=False),
+                    InPlaceABN(self.head_conv, momentum=self.bn_momentum, activation="leaky_relu")]
+        self.class_head = nn.Sequential(*trunk(), nn.Conv2d(self.head_conv, classes, kernel_size=1, padding=0, bias=True))
+        self.class_head[-1].bias.data.fill_(-np.log(1 / cfg.MODEL.HEAD.INIT_P - 1))
+        self.reg_features, self.reg_heads = nn.ModuleList(), nn.ModuleList()
+        for idx, keys in enumerate(self.regression_head_cfg):
+            self.reg_features.append(nn.Sequential(*trunk()))
+            head_list = nn.ModuleList()
+            for key_index, key in enumerate(keys):
+                out_head = nn.Conv2d(self.head_conv, self.regression_channel_cfg[idx][key_index], kernel_size=1, bias=True)
+                if key.find('uncertainty') >= 0 and cfg.MODEL.HEAD.UNCERTAINTY_INIT:
+                    torch.nn.init.xavier_normal_(out_head.weight, gain=0.01)
+                if key == '3d_offset':
+                    self.offset_index = [idx, key_index]
+                nn.init.constant_(out_head.bias, 0)
+                head_list.append(out_head)
+            self.reg_heads.append(head_list)
+
+        self.enable_edge_fusion = cfg.MODEL.HEAD.ENABLE_EDGE_FUSION
+        self.edge_fusion_kernel_size = cfg.MODEL.HEAD.EDGE_FUSION_KERNEL_SIZE
+        self.edge_fusion_relu = cfg.MODEL.HEAD.EDGE_FUSION_RELU
+        if self.enable_edge_fusion:
+            if cfg.MODEL.HEAD.EDGE_FUSION_NORM != 'BN' or self.edge_fusion_kernel_size != 3:
+                raise NotImplementedError("edge fusion: k=3 + BN1d configuration only")
+            act = nn.ReLU(inplace=True) if self.edge_fusion_relu else nn.Identity()
+
+            def trunc(cout):
+                k = self.edge_fusion_kernel_size
+                return nn.Sequential(nn.Conv1d(self.head_conv, self.head_conv, kernel_size=k, padding=k // 2, padding_mode='replicate'),
+                                     nn.BatchNorm1d(self.head_conv, momentum=self.bn_momentum), act,
+                                     nn.Conv1d(self.head_conv, cout, kernel_size=1))
+            self.trunc_heatmap_conv = trunc(classes)
+            self.trunc_offset_conv = trunc(2)
+        self.num_classes = classes
+        self._packs = {}
+
+    # ---- packing ---------------------------------------------------------------------------------
+    def _abn_fold(self, abn):
+        if self.abn_abs_weight:                                   # upstream inplace_abn: gamma_eff = |gamma| + eps
+            g = abn.weight.detach().float().abs() + abn.eps
+            scale = g / torch.sqrt(abn.running_var.detach().float() + abn.eps)
+            return scale, abn.bias.detach().float() - abn.running_mean.detach().float() * scale
+        return ops.fold_bn(abn)
+
+    def _pack(self, dtype):
+        key = ("heads", dtype)
+        if key in self._packs:
+            return self._packs[key]
+        trunks = [self.class_head] + list(self.reg_features)
+        w1, sc, sh = [], [], []
+        for t in trunks:
+            w1.append(t[0].weight.detach().float().permute(0, 2, 3, 1).reshape(self.head_conv, -1))
+            s, b = self._abn_fold(t[1])
+            sc.append(s); sh.append(b)
+        bk = 4 * (4 if dtype == torch.float32 else 8)
+        K = w1[0].shape[1]
+        K_pad = (K + bk - 1) // bk * bk
+        w1 = torch.cat(w1, 0)
+        if K_pad != K:
+            w1 = torch.cat((w1, w1.new_zeros(w1.shape[0], K_pad - K)), 1)
+        dev = w1.device
+        nb = len(trunks)
+        w2 = torch.zeros(nb, 32, self.head_conv, device=dev)
+        b2 = torch.zeros(nb, 32, device=dev)
+        ch_off, c_out = [0], [self.num_classes]
+        w2[0, :self.num_classes] = self.class_head[2].weight.detach().float().reshape(self.num_classes, -1)
+        b2[0, :self.num_classes] = self.class_head[2].bias.detach().float()
+        off = REG_OFF
+        for i, heads in enumerate(self.reg_heads):
+            r = 0
+            for h in heads:
+                c = h.weight.shape[0]
+                w2[i + 1, r:r + c] = h.weight.detach().float().reshape(c, -1)
+                b2[i + 1, r:r + c] = h.bias.detach().float()
+                r += c
+            ch_off.append(off); c_out.append(r)
+            off += r
+        assert off <= HM_LD
+        p = ops.PackedHeads(w1.to(dtype).contiguous(), torch.cat(sc).contiguous(), torch.cat(sh).contiguous(),
+                            w2.to(dtype).contiguous(), b2.contiguous(), K_pad, ch_off, c_out, HM_LD)
+        # edge fusion: trunks of the class branch and of the 3d_offset branch at the border points
+        if self.enable_edge_fusion:
+            oi = self.offset_index[0]
+            w_e = torch.cat((self.class_head[0].weight, self.reg_features[oi][0].weight), 0)
+            s0, b0 = self._abn_fold(self.class_head[1])
+            s1, b1 = self._abn_fold(self.reg_features[oi][1])
+            p.edge_trunk = ops.pack_conv(w_e, dtype, torch.cat((s0, s1)), torch.cat((b0, b1)), stride=1, pad=1, act=L.ACT_LEAKY)
+            p.edge_branches = []
+            for seq, cout, choff in ((self.trunc_heatmap_conv, self.num_classes, 0),
+                                     (self.trunc_offset_conv, 2, REG_OFF + sum(sum(c) for c in self.regression_channel_cfg[:oi])
+                                      + sum(self.regression_channel_cfg[oi][:self.offset_index[1]]))):
+                c1, bn, c3 = seq[0], seq[1], seq[3]
+                scale, shift = ops.fold_bn(bn, c1.bias)
+                # Conv1d weight (256,256,3) -> conv over a 1 x (L+2) "image", taps along W
+                pk1 = ops.pack_conv(c1.weight.detach().unsqueeze(2), dtype, scale, shift, stride=1, pad=0,
+                                    act=L.ACT_RELU if self.edge_fusion_relu else L.ACT_NONE)
+                pk2 = ops.pack_conv(c3.weight.detach().unsqueeze(2), dtype, None, c3.bias, stride=1, pad=0, act=L.ACT_NONE, cout=4)
+                p.edge_branches.append((pk1, pk2, cout, choff))
+        self._packs[key] = p
+        return p
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def forward_nhwc(self, features, edge_indices=None, edge_lens=None):
+        """features (B,H,W,64) NHWC -> fp32 head map (B,H,W,64): [0:3] class logits (pre-sigmoid, after
+        edge fusion), [8:58] the 50 regression channels.  edge_indices int32 (B,L,2) (x,y), edge_lens int32 (B,)."""
+        _eval_only(self)
+        p = self._pack(features.dtype)
+        hm = ops.heads_fused(features, p)
+        if self.enable_edge_fusion:
+            if edge_indices is None:
+                raise ValueError("edge fusion is enabled: targets must carry edge_indices / edge_len")
+            B, H, W, _ = features.shape
+            Lmax = edge_indices.shape[1]
+            # sequence positions -1..L (replicate padding of the k=3 Conv1d) -> pixel rows
+            pos = torch.arange(-1, Lmax + 1, device=features.device).clamp(0, Lmax - 1)
+            xy = edge_indices[:, pos].long()
+            rowmap = (torch.arange(B, device=features.device).view(B, 1) * (H * W) + xy[..., 1] * W + xy[..., 0]).to(torch.int32)
+            trunk = ops.conv2d(features, p.edge_trunk, rowmap=rowmap.reshape(-1).contiguous())   # (B*(L+2), 512)
+            trunk = trunk.view(B, 1, Lmax + 2, 2 * self.head_conv)
+            for bi, (pk1, pk2, cout, choff) in enumerate(p.edge_branches):
+                f1 = ops.conv2d(trunk, pk1, x_ch_off=bi * self.head_conv)                  # (B,1,L,256)
+                o = ops.conv2d(f1, pk2, out_dtype=torch.float32)                           # (B,1,L,4) fp32
+                ops.edge_scatter_add(hm, choff, cout, o, edge_indices, edge_lens)
+        return hm
+
+    def forward(self, features, targets):
+        """Reference surface: features (B,64,H,W) (any strides) + targets -> {'cls','reg'} NCHW views."""
+        x = features.permute(0, 2, 3, 1).contiguous()
+        ei, el = stack_edge_fields(targets, x.device)
+        hm = self.forward_nhwc(x, ei, el)
+        cls = torch.sigmoid(hm[..., :self.num_classes]).clamp(min=1e-4, max=1 - 1e-4).permute(0, 3, 1, 2)
+        return {'cls': cls, 'reg': hm[..., REG_OFF:REG_OFF + 50].permute(0, 3, 1, 2), 'hm_nhwc': hm}
+
+
+def stack_edge_fields(targets, device):
+    ei = torch.stack([torch.as_tensor(t.get_field("edge_indices")) for t in targets]).to(device=device, dtype=torch.int32)
+    el = torch.stack([torch.as_tensor(t.get_field("edge_len")) for t in targets]).to(device=device, dtype=torch.int32)
+    return ei.contiguous(), el.contiguous()
+
+
+def make_predictor(cfg, in_channels):
+    if cfg.MODEL.HEAD.PREDICTOR != "Base_Predictor":
+        raise KeyError(cfg.MODEL.HEAD.PREDICTOR)
+    return _predictor(cfg, in_channels)

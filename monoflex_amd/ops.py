@@ -1,0 +1,400 @@
+"""Tensor-level wrappers over the C ABI (include/monoflex_hip.h).
+
+Activations are torch CUDA tensors in physical NHWC layout, shape (B, H, W, C), dtype float32
+(parity mode) or bfloat16 (perf mode).  torch is used for device memory and the current HIP stream
+only; every arithmetic op below runs in libmonoflex_hip.so.  Weight packing (done once per
+`prepare`) uses torch indexing ops -- it is not on the hot path.
+"""
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(dtype):
+    if dtype == torch.float32:
+        return L.MFX_F32
+    if dtype == torch.bfloat16:
+        return L.MFX_BF16
+    raise TypeError("MonoFlex HIP kernels take float32 or bfloat16, got %s" % dtype)
+
+
+def _elems(dtype):
+    return 4 if dtype == torch.float32 else 8
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("MonoFlex HIP operator called with a CPU tensor: the product path has no CPU "
+                               "fallback (the CPU oracle lives in oracle/ and is test-only)")
+
+
+def _pow2(v):
+    return v > 0 and (v & (v - 1)) == 0
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def cout_pad(c):
+    return 16 if c <= 16 else 32 if c <= 32 else _round_up(c, 64)
+
+
+# --------------------------------------------------------------------------------------------
+# packed parameter containers
+# --------------------------------------------------------------------------------------------
+@dataclass
+class PackedConv:
+    w: torch.Tensor                 # [Cout_pad][K_pad]
+    scale: Optional[torch.Tensor]   # fp32 [Cout_pad]
+    shift: Optional[torch.Tensor]
+    kh: int
+    kw: int
+    stride: int
+    pad_h: int
+    pad_w: int
+    dil_w: int
+    Ck: int
+    Cout: int
+    Cout_pad: int
+    K_pad: int
+    act: int
+
+
+def fold_bn(bn, conv_bias=None, cout_padded=None):
+    """Eval-mode BatchNorm as y = x*scale + shift (a preceding conv bias folded in)."""
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.detach().float() * scale
+    if cout_padded is not None and cout_padded > scale.numel():
+        padn = cout_padded - scale.numel()
+        scale = torch.cat((scale, scale.new_ones(padn)))
+        shift = torch.cat((shift, shift.new_zeros(padn)))
+    return scale.contiguous(), shift.contiguous()
+
+
+def _pad_rows_cols(w2d, rows, cols):
+    out = w2d.new_zeros(rows, cols)
+    out[:w2d.shape[0], :w2d.shape[1]] = w2d
+    return out
+
+
+def pack_conv(weight, dtype, scale=None, shift=None, stride=1, pad=0, act=L.ACT_NONE, cout=None):
+    """weight (Cout,Cin,kh,kw) -> K-contiguous [Cout_pad][K_pad], K = (tap, channel)."""
+    Cout, Cin, kh, kw = weight.shape
+    if not _pow2(Cin) or Cin < _elems(dtype):
+        raise ValueError("pack_conv: Cin must be a power of two >= %d (got %d)" % (_elems(dtype), Cin))
+    bk = 4 * _elems(dtype)
+    K = kh * kw * Cin
+    K_pad = _round_up(K, bk)
+    cout = Cout if cout is None else cout
+    cp = cout_pad(cout)
+    w2 = weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, K)
+    w2 = _pad_rows_cols(w2, cp, K_pad).to(dtype).contiguous()
+
+    def padv(v, fill):
+        if v is None:
+            return None
+        v = v.detach().float()
+        if v.numel() < cp:
+            v = torch.cat((v, v.new_full((cp - v.numel(),), fill)))
+        return v.contiguous()
+    return PackedConv(w2, padv(scale, 1.0), padv(shift, 0.0), kh, kw, stride, pad, pad, 1, Cin, cout, cp, K_pad, act)
+
+
+# stem geometry: zero-padded NHWC4 image, 3 columns left / 5 right, 3 rows top/bottom
+STEM_PAD_H, STEM_PAD_WL, STEM_PAD_WR = 3, 3, 5
+
+
+def pack_stem(weight, dtype, scale, shift, act=L.ACT_RELU):
+    """7x7/s1/p3 conv on 3 channels (dla_dcn.py:268-272) over the padded NHWC4 image.
+    bf16: a 16-byte chunk is 2 adjacent pixels x 4 ch -> 7 x 4 'super taps' of 8 elements, dil_w = 2.
+    f32 : a chunk is 1 pixel x 4 ch -> 7 x 7 taps of 4 elements."""
+    Cout = weight.shape[0]
+    w = weight.detach().float()
+    w4 = torch.cat((w, w.new_zeros(Cout, 1, 7, 7)), dim=1)              # (Cout,4,7,7)
+    if dtype == torch.bfloat16:
+        w8 = torch.cat((w4, w4.new_zeros(Cout, 4, 7, 1)), dim=3)        # kw 7 -> 8
+        # [n][th][j][u][c] with kw = 2j+u
+        wp = w8.permute(0, 2, 3, 1).reshape(Cout, 7, 4, 2, 4).reshape(Cout, 7 * 4 * 8)
+        kh, kw, Ck, dil = 7, 4, 8, 2
+    else:
+        wp = w4.permute(0, 2, 3, 1).reshape(Cout, 7 * 7 * 4)
+        kh, kw, Ck, dil = 7, 7, 4, 1
+    bk = 4 * _elems(dtype)
+    K_pad = _round_up(wp.shape[1], bk)
+    cp = cout_pad(Cout)
+    wp = _pad_rows_cols(wp, cp, K_pad).to(dtype).contiguous()
+    return PackedConv(wp, scale.contiguous(), shift.contiguous(), kh, kw, 1, 0, 0, dil, Ck, Cout, cp, K_pad, act)
+
+
+# --------------------------------------------------------------------------------------------
+# operators
+# --------------------------------------------------------------------------------------------
+def conv2d(x, p: PackedConv, res=None, out_dtype=None, rowmap=None, x_channels=None, x_ch_off=0,
+           out_hw=None, in_hw=None):
+    """y = act(conv(x)*scale + shift (+res)).  x: (B,H,W,Cx) NHWC.  With `rowmap` (int32 [M], pixel
+    indices into the (B,Ho,Wo) grid, -1 = zero row) the output is the dense (M, Cout) row list."""
+    _need_cuda(x, res, rowmap)
+    B, H, W, Cx = x.shape
+    if in_hw is not None:
+        H, W = in_hw
+    out_dtype = out_dtype or x.dtype
+    if out_hw is None:
+        Ho = (H + 2 * p.pad_h - ((p.kh - 1) + 1)) // p.stride + 1
+        Wo = (W + 2 * p.pad_w - (p.dil_w * (p.kw - 1) + 1)) // p.stride + 1
+    else:
+        Ho, Wo = out_hw
+    M = B * Ho * Wo if rowmap is None else rowmap.numel()
+    y = torch.empty((B, Ho, Wo, p.Cout) if rowmap is None else (M, p.Cout), dtype=out_dtype, device=x.device)
+    d = L.ConvDesc()
+    d.x = x.data_ptr() + x_ch_off * x.element_size()
+    d.w, d.scale, d.shift = p.w.data_ptr(), (p.scale.data_ptr() if p.scale is not None else None), \
+        (p.shift.data_ptr() if p.shift is not None else None)
+    d.res = res.data_ptr() if res is not None else None
+    d.y = y.data_ptr()
+    d.rowmap = rowmap.data_ptr() if rowmap is not None else None
+    d.B, d.H, d.W, d.x_pixstride, d.Ck = B, H, W, Cx, p.Ck
+    d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil_w = p.kh, p.kw, p.stride, p.pad_h, p.pad_w, p.dil_w
+    d.Ho, d.Wo, d.M, d.Cout, d.Cout_pad, d.K_pad = Ho, Wo, M, p.Cout, p.Cout_pad, p.K_pad
+    d.ldy, d.ldres = p.Cout, (res.shape[-1] if res is not None else 0)
+    d.act, d.dtype, d.out_dtype = p.act, _dt(x.dtype), _dt(out_dtype)
+    L.check(L.load().mfx_conv2d_nhwc(ctypes.byref(d), _stream()), "mfx_conv2d_nhwc")
+    return y
+
+
+@dataclass
+class PackedCat:
+    w: torch.Tensor
+    scale: torch.Tensor
+    shift: torch.Tensor
+    Cseg: int
+    Cout: int
+    Cout_pad: int
+    K_pad: int
+    act: int
+
+
+def pack_cat(weight, dtype, scale, shift, src_channels, act=L.ACT_RELU):
+    Cout, Ctot = weight.shape[:2]
+    assert sum(src_channels) == Ctot
+    Cseg = min(src_channels)
+    assert all(c % Cseg == 0 for c in src_channels) and _pow2(Cseg)
+    cp = cout_pad(Cout)
+    w2 = _pad_rows_cols(weight.detach().float().reshape(Cout, Ctot), cp, Ctot).to(dtype).contiguous()
+    return PackedCat(w2, scale.contiguous(), shift.contiguous(), Cseg, Cout, cp, Ctot, act)
+
+
+def cat_conv1x1(srcs, p: PackedCat):
+    """Root: 1x1 conv over the virtual concat of `srcs` (list of (B,H,W,Ci) tensors)."""
+    _need_cuda(*srcs)
+    B, H, W, _ = srcs[0].shape
+    y = torch.empty((B, H, W, p.Cout), dtype=srcs[0].dtype, device=srcs[0].device)
+    d = L.CatDesc()
+    n = 0
+    for s in srcs:
+        C = s.shape[3]
+        for part in range(C // p.Cseg):
+            d.src[n], d.stride[n], d.off[n] = s.data_ptr(), C, part * p.Cseg
+            n += 1
+    d.nseg, d.Cseg = n, p.Cseg
+    d.w, d.scale, d.shift, d.res, d.y = p.w.data_ptr(), p.scale.data_ptr(), p.shift.data_ptr(), None, y.data_ptr()
+    d.M, d.Cout, d.Cout_pad, d.K_pad, d.ldy, d.ldres, d.act, d.dtype = B * H * W, p.Cout, p.Cout_pad, p.K_pad, p.Cout, 0, p.act, _dt(y.dtype)
+    L.check(L.load().mfx_cat_conv1x1_nhwc(ctypes.byref(d), _stream()), "mfx_cat_conv1x1_nhwc")
+    return y
+
+
+def dcn(x, offmask, p: PackedConv):
+    """Fused DCNv2 + scale/shift + act.  x (B,H,W,C) NHWC, offmask fp32 (B,Ho,Wo,32)."""
+    _need_cuda(x, offmask)
+    B, H, W, C = x.shape
+    Ho, Wo = offmask.shape[1], offmask.shape[2]
+    y = torch.empty((B, Ho, Wo, p.Cout), dtype=x.dtype, device=x.device)
+    d = L.DcnDesc()
+    d.x, d.offmask, d.w, d.y = x.data_ptr(), offmask.data_ptr(), p.w.data_ptr(), y.data_ptr()
+    d.scale = p.scale.data_ptr() if p.scale is not None else None
+    d.shift = p.shift.data_ptr() if p.shift is not None else None
+    d.B, d.H, d.W, d.C = B, H, W, C
+    d.kh, d.kw, d.stride, d.pad, d.dil = p.kh, p.kw, p.stride, p.pad_h, p.dil_w
+    d.Ho, d.Wo, d.Cout, d.Cout_pad, d.K_pad, d.ldy, d.act, d.dtype = Ho, Wo, p.Cout, p.Cout_pad, p.K_pad, p.Cout, p.act, _dt(x.dtype)
+    L.check(L.load().mfx_dcn_nhwc(ctypes.byref(d), _stream()), "mfx_dcn_nhwc")
+    return y
+
+
+def maxpool2x2(x):
+    _need_cuda(x)
+    B, H, W, C = x.shape
+    y = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+    L.check(L.load().mfx_maxpool2x2_nhwc(_ptr(x), _ptr(y), B, H, W, C, _dt(x.dtype), _stream()), "mfx_maxpool2x2_nhwc")
+    return y
+
+
+def pack_upsample(weight):
+    """(C,1,k,k) depthwise deconv weight -> fp32 [k*k][C]."""
+    C, _, k, _ = weight.shape
+    return weight.detach().float().reshape(C, k * k).t().contiguous()
+
+
+def upsample_add(x, w_taps, f, skip=None):
+    _need_cuda(x, w_taps, skip)
+    B, H, W, C = x.shape
+    y = torch.empty((B, H * f, W * f, C), dtype=x.dtype, device=x.device)
+    L.check(L.load().mfx_upsample_add_nhwc(_ptr(x), _ptr(w_taps), _ptr(skip), _ptr(y), B, H, W, C, f, _dt(x.dtype), _stream()),
+            "mfx_upsample_add_nhwc")
+    return y
+
+
+def nchw_to_nhwc(x, dtype, channels=None):
+    """fp32 NCHW -> NHWC of `dtype`, channel axis zero-padded to `channels`."""
+    _need_cuda(x)
+    x = x.float().contiguous()
+    B, C, H, W = x.shape
+    ld = channels or C
+    y = torch.empty((B, H, W, ld), dtype=dtype, device=x.device)
+    L.check(L.load().mfx_nchw_to_nhwc(_ptr(x), _ptr(y), B, C, H, W, ld, _dt(dtype), _stream()), "mfx_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x, channels=None):
+    _need_cuda(x)
+    B, H, W, ld = x.shape
+    C = channels or ld
+    y = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    L.check(L.load().mfx_nhwc_to_nchw(_ptr(x), _ptr(y), B, C, H, W, ld, _dt(x.dtype), _stream()), "mfx_nhwc_to_nchw")
+    return y
+
+
+def pack_image(images, dtype):
+    """(B,3,H,W) fp32 NCHW -> zero-padded NHWC4 (B, H+6, W+8, 4) for the stem conv."""
+    _need_cuda(images)
+    images = images.float().contiguous()
+    B, C, H, W = images.shape
+    assert C == 3
+    y = torch.empty((B, H + 2 * STEM_PAD_H, W + STEM_PAD_WL + STEM_PAD_WR, 4), dtype=dtype, device=images.device)
+    L.check(L.load().mfx_pack_image_nhwc4(_ptr(images), _ptr(y), B, H, W, STEM_PAD_H, STEM_PAD_WL, STEM_PAD_WR,
+                                          _dt(dtype), _stream()), "mfx_pack_image_nhwc4")
+    return y
+
+
+@dataclass
+class PackedHeads:
+    w1: torch.Tensor
+    scale1: torch.Tensor
+    shift1: torch.Tensor
+    w2: torch.Tensor
+    bias2: torch.Tensor
+    K_pad: int
+    ch_off: list
+    c_out: list
+    ld_out: int
+
+
+def heads_fused(x, p: PackedHeads):
+    _need_cuda(x)
+    B, H, W, C = x.shape
+    assert C == 64
+    out = torch.zeros((B, H, W, p.ld_out), dtype=torch.float32, device=x.device)
+    d = L.HeadsDesc()
+    d.x, d.w1, d.scale1, d.shift1 = x.data_ptr(), p.w1.data_ptr(), p.scale1.data_ptr(), p.shift1.data_ptr()
+    d.w2, d.bias2, d.out = p.w2.data_ptr(), p.bias2.data_ptr(), out.data_ptr()
+    d.B, d.H, d.W, d.nbranch, d.K_pad, d.ld_out, d.dtype = B, H, W, len(p.c_out), p.K_pad, p.ld_out, _dt(x.dtype)
+    for i, (o, c) in enumerate(zip(p.ch_off, p.c_out)):
+        d.ch_off[i], d.c_out[i] = o, c
+    L.check(L.load().mfx_heads_fused(ctypes.byref(d), _stream()), "mfx_heads_fused")
+    return out
+
+
+def edge_scatter_add(out, ch_off, C, v, edge_xy, edge_len):
+    _need_cuda(out, v, edge_xy, edge_len)
+    B, H, W, ld = out.shape
+    Lmax = edge_xy.shape[1]
+    L.check(L.load().mfx_edge_scatter_add(_ptr(out), ld, ch_off, C, _ptr(v), v.shape[-1], _ptr(edge_xy), _ptr(edge_len),
+                                          B, Lmax, H, W, _stream()), "mfx_edge_scatter_add")
+
+
+def decode_topk(hmap, ch_off, ncls, K):
+    _need_cuda(hmap)
+    B, H, W, ld = hmap.shape
+    scores = torch.empty((B, ncls, K), dtype=torch.float32, device=hmap.device)
+    index = torch.empty((B, ncls, K), dtype=torch.int32, device=hmap.device)
+    L.check(L.load().mfx_decode_topk(_ptr(hmap), ld, ch_off, ncls, B, H, W, K, _ptr(scores), _ptr(index), _stream()),
+            "mfx_decode_topk")
+    return scores, index
+
+
+def decode_boxes(hmap, reg_off, scores, index, calib, pad, img_size, threshold):
+    _need_cuda(hmap, scores, index, calib, pad, img_size)
+    B, H, W, ld = hmap.shape
+    ncls, K = scores.shape[1], scores.shape[2]
+    det = torch.empty((B, K, 14), dtype=torch.float32, device=hmap.device)
+    topk = torch.empty((B, K, 5), dtype=torch.float32, device=hmap.device)
+    valid = torch.empty((B, K), dtype=torch.int32, device=hmap.device)
+    L.check(L.load().mfx_decode_boxes(_ptr(hmap), ld, reg_off, _ptr(scores), _ptr(index), ncls, B, H, W, K, _ptr(calib),
+                                      _ptr(pad), _ptr(img_size), ctypes.c_float(threshold), _ptr(det), _ptr(topk),
+                                      _ptr(valid), _stream()), "mfx_decode_boxes")
+    return det, topk, valid
+
+
+# ---- reference `_ext` boundary (NCHW fp32) ---------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def ext_dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg):
+    _need_cuda(input, weight, bias, offset, mask)
+    ts = [t.float().contiguous() for t in (input, weight, bias, offset, mask)]
+    x, w, b, off, msk = ts
+    B, C, H, W = x.shape
+    Cout = w.shape[0]
+    if w.shape[2] != kh or w.shape[3] != kw:
+        raise RuntimeError("Input shape and kernel shape wont match: (%d x %d vs %d x %d)." % (kh, kw, w.shape[2], w.shape[3]))
+    if w.shape[1] != C:
+        raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (C, w.shape[1]))
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    lib_ = L.load()
+    nbytes = lib_.mfx_dcn_v2_workspace_bytes(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, 0)
+    ws = _workspace(nbytes, x.device)
+    out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    L.check(lib_.mfx_dcn_v2_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(off), _ptr(msk), _ptr(out), B, C, H, W, Cout, kh, kw,
+                                    sh, sw, ph, pw, dh, dw, dg, _ptr(ws), ws.numel(), _stream()), "mfx_dcn_v2_forward")
+    return out
+
+
+def ext_dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kh, kw, sh, sw, ph, pw, dh, dw, dg):
+    _need_cuda(input, weight, bias, offset, mask, grad_output)
+    x, w, b, off, msk, go = [t.float().contiguous() for t in (input, weight, bias, offset, mask, grad_output)]
+    B, C, H, W = x.shape
+    Cout = w.shape[0]
+    lib_ = L.load()
+    nbytes = lib_.mfx_dcn_v2_workspace_bytes(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, 1)
+    ws = _workspace(nbytes, x.device)
+    gi, gw, gb = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
+    goff, gm = torch.empty_like(off), torch.empty_like(msk)
+    L.check(lib_.mfx_dcn_v2_backward(_ptr(x), _ptr(w), _ptr(b), _ptr(off), _ptr(msk), _ptr(go), _ptr(gi), _ptr(goff), _ptr(gm),
+                                     _ptr(gw), _ptr(gb), B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg,
+                                     _ptr(ws), ws.numel(), _stream()), "mfx_dcn_v2_backward")
+    return [gi, goff, gm, gw, gb]

@@ -1,0 +1,296 @@
+"""GPU parity tests, operator level: every HIP operator (through the C ABI) against a plain torch fp32
+CPU reference of the same op, or the C DCN oracle.  fp32 mode: tight tolerances (f32 MFMA is an exact
+fmaf chain); bf16 mode: inputs/weights rounded to bf16 first, tolerance ~ bf16 epsilon x sqrt(K)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from monoflex_amd import lib as L, ops
+    L.load()                                   # fail loudly if the HIP library is missing
+    return ops, L
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _to_nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def _from_nhwc(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+def _tol(dtype, K):
+    return (2e-5 * max(1.0, K ** 0.5 / 8), 1e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+
+
+def _close(a, b, dtype, K, what):
+    rtol, atol = _tol(dtype, K)
+    scale = float(b.abs().max().clamp(min=1.0))
+    err = float((a - b).abs().max())
+    assert err <= atol * scale + rtol * scale, "%s: max abs err %.3e (scale %.3e)" % (what, err, scale)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, k, stride, residual, act
+    (2, 16, 16, 24, 40, 3, 1, False, 1),
+    (1, 16, 32, 24, 40, 3, 2, False, 1),
+    (2, 32, 64, 16, 24, 3, 2, False, 1),
+    (2, 64, 64, 12, 20, 3, 1, True, 1),
+    (1, 64, 128, 12, 20, 3, 2, False, 0),
+    (1, 128, 128, 64, 72, 3, 1, True, 1),       # > 512 tiles of 128x128 -> big-tile path
+    (1, 32, 64, 6, 10, 1, 1, False, 0),
+    (1, 256, 512, 6, 10, 3, 1, False, 1),
+    (3, 64, 64, 5, 7, 3, 1, False, 2),          # ragged M (105 rows), leaky
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case, dtype):
+    ops, L = _ops()
+    B, Cin, Cout, H, W, k, s, use_res, act = case
+    g = _g(hash(case) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(x, w, None, s, k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        if dtype == torch.bfloat16:
+            res = res.bfloat16().float()
+        ref = ref + res
+    ref = F.relu(ref) if act == 1 else F.leaky_relu(ref, 0.01) if act == 2 else ref
+    p = ops.pack_conv(w.to(DEV), dtype, scale.to(DEV), shift.to(DEV), stride=s, pad=k // 2, act=act)
+    y = ops.conv2d(_to_nhwc(x, dtype), p, res=_to_nhwc(res, dtype) if use_res else None)
+    torch.cuda.synchronize()
+    _close(_from_nhwc(y), ref, dtype, Cin * k * k, "conv2d %s" % (case,))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv2d_a_identity_asymmetric(dtype):
+    # transpose-detecting check: identity weights on an asymmetric input must return the input
+    ops, L = _ops()
+    x = torch.arange(2 * 64 * 5 * 9, dtype=torch.float32).reshape(2, 64, 5, 9) % 251 / 16.0
+    w = torch.zeros(64, 64, 1, 1)
+    w[torch.arange(64), torch.arange(64), 0, 0] = 1.0
+    p = ops.pack_conv(w.to(DEV), dtype, None, None, stride=1, pad=0, act=0)
+    y = ops.conv2d(_to_nhwc(x, dtype), p)
+    assert torch.equal(_from_nhwc(y), x.to(dtype).float())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_conv7x7(dtype):
+    ops, L = _ops()
+    g = _g(11)
+    x = torch.randn(2, 3, 20, 36, generator=g)
+    w = torch.randn(16, 3, 7, 7, generator=g) / 147 ** 0.5
+    scale, shift = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.relu(F.conv2d(x, w, None, 1, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    p = ops.pack_stem(w.to(DEV), dtype, scale.to(DEV), shift.to(DEV))
+    y = ops.conv2d(ops.pack_image(x.to(DEV), dtype), p, out_hw=(20, 36))
+    torch.cuda.synchronize()
+    _close(_from_nhwc(y), ref, dtype, 147, "stem")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_root_cat_conv1x1(dtype):
+    ops, L = _ops()
+    g = _g(12)
+    chans = [128, 128, 64, 128]                     # level3.tree2.root: 448 -> 128
+    xs = [torch.randn(2, c, 6, 10, generator=g) for c in chans]
+    w = torch.randn(128, sum(chans), 1, 1, generator=g) / sum(chans) ** 0.5
+    scale, shift = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    if dtype == torch.bfloat16:
+        xs, w = [t.bfloat16().float() for t in xs], w.bfloat16().float()
+    ref = F.relu(F.conv2d(torch.cat(xs, 1), w) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    p = ops.pack_cat(w.to(DEV), dtype, scale.to(DEV), shift.to(DEV), chans)
+    y = ops.cat_conv1x1([_to_nhwc(t, dtype) for t in xs], p)
+    torch.cuda.synchronize()
+    _close(_from_nhwc(y), ref, dtype, sum(chans), "root cat conv")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_and_upsample(dtype):
+    ops, L = _ops()
+    g = _g(13)
+    x = torch.randn(2, 64, 8, 12, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    y = ops.maxpool2x2(_to_nhwc(x, dtype))
+    assert torch.equal(_from_nhwc(y), F.max_pool2d(x, 2, 2))
+    for f in (2, 4):
+        w = torch.rand(64, 1, 2 * f, 2 * f, generator=g)
+        skip = torch.randn(2, 64, 8 * f, 12 * f, generator=g)
+        if dtype == torch.bfloat16:
+            skip = skip.bfloat16().float()
+        ref = F.conv_transpose2d(x, w, None, stride=f, padding=f // 2, groups=64) + skip
+        y = ops.upsample_add(_to_nhwc(x, dtype), ops.pack_upsample(w.to(DEV)), f, skip=_to_nhwc(skip, dtype))
+        torch.cuda.synchronize()
+        _close(_from_nhwc(y), ref, dtype, 4, "upsample f=%d" % f)
+
+
+def _dcn_case(seed, B, C, Co, H, W, off_scale=2.0):
+    g = _g(seed)
+    x = torch.randn(B, C, H, W, generator=g)
+    off = torch.randn(B, 18, H, W, generator=g) * off_scale
+    msk = torch.sigmoid(torch.randn(B, 9, H, W, generator=g))
+    w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(Co, generator=g)
+    off[0, :, 0, 0] = 30.0                           # samples far outside the map
+    off[-1, :, H // 2, W // 3] = -30.0
+    off[0, 0::2, 1, 1] = -1.0                        # exactly on the -1 boundary (must be excluded: h > -1)
+    return x, off, msk, w, b
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 2, 4, 4), (2, 8, 8, 12, 20), (1, 64, 64, 24, 40), (2, 128, 64, 12, 20), (1, 256, 128, 6, 10)])
+def test_ext_dcn_v2_forward_vs_oracle(shape):
+    """The `_ext.dcn_v2_forward` boundary (NCHW fp32) against oracle/dcn_v2_ref.c."""
+    from monoflex_amd.model.backbone.DCNv2 import _ext
+    from oracle import dcn_ref
+    x, off, msk, w, b = _dcn_case(21, *shape)
+    want = dcn_ref.dcn_v2_forward(x, w, b, off, msk, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    got = _ext.dcn_v2_forward(x.to(DEV), w.to(DEV), b.to(DEV), off.to(DEV), msk.to(DEV), 3, 3, 1, 1, 1, 1, 1, 1, 1).cpu()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_ext_dcn_zero_offset_known_answer():
+    # reference testcpu.py:32-67: zero offsets, mask 0.5, identity weight -> |input - 2*output| < 1e-10
+    from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCNv2
+    torch.manual_seed(0)
+    x = torch.randn(2, 2, 4, 4)
+    m = DCNv2(2, 2, (3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV)
+    m.weight.data.zero_(); m.bias.data.zero_()
+    m.weight.data[0, 0, 1, 1] = 1.0; m.weight.data[1, 1, 1, 1] = 1.0
+    out = m(x.to(DEV), torch.zeros(2, 18, 4, 4, device=DEV), torch.full((2, 9, 4, 4), 0.5, device=DEV)).cpu()
+    assert float((x - 2 * out).abs().max()) < 1e-10
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 2, 4, 4), (2, 8, 8, 12, 20), (1, 64, 64, 12, 20), (2, 128, 64, 6, 10)])
+def test_ext_dcn_v2_backward_vs_oracle(shape):
+    from monoflex_amd.model.backbone.DCNv2 import _ext
+    from oracle import dcn_ref
+    x, off, msk, w, b = _dcn_case(22, *shape)
+    go = torch.randn(shape[0], shape[2], shape[3], shape[4], generator=_g(5))
+    want = dcn_ref.dcn_v2_backward(x, w, b, off, msk, go, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    got = _ext.dcn_v2_backward(*[t.to(DEV) for t in (x, w, b, off, msk, go)], 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    for g_, w_, name in zip(got, want, ["grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"]):
+        scale = max(1.0, float(w_.abs().max()))
+        assert float((g_.cpu() - w_).abs().max()) < 1e-4 * scale, name
+
+
+def test_dcn_autograd_gradcheck_reference_tolerances():
+    # reference testcpu.py:69-97 on the HIP autograd Function (fp32, eps 1e-3, atol 1e-4, rtol 1e-2)
+    from torch.autograd import gradcheck
+    from monoflex_amd.model.backbone.DCNv2.dcn_v2 import dcn_v2_conv
+    torch.manual_seed(3)
+    inp = (torch.rand(2, 2, 4, 4) * 0.01).to(DEV).requires_grad_()
+    offset = (torch.randn(2, 18, 4, 4) * 2).to(DEV).requires_grad_()
+    mask = torch.sigmoid(torch.rand(2, 9, 4, 4)).to(DEV).requires_grad_()
+    weight = torch.randn(2, 2, 3, 3).to(DEV).requires_grad_()
+    bias = torch.rand(2).to(DEV).requires_grad_()
+    assert gradcheck(dcn_v2_conv, (inp, offset, mask, weight, bias, 1, 1, 1, 1), eps=1e-3, atol=1e-4, rtol=1e-2,
+                     nondet_tol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dcn_module_fused_bn_relu(dtype):
+    """DeformConv = DCN + BN + ReLU (dla_dcn.py:384-396), NHWC fused path, against the oracle module."""
+    from monoflex_amd.model.backbone.dla_dcn import DeformConv
+    from oracle import monoflex_ref as R
+    torch.manual_seed(4)
+    ref = R.DeformConv(64, 64).eval()
+    torch.nn.init.normal_(ref.conv.conv_offset_mask.weight, std=1.5 / 24)
+    torch.nn.init.normal_(ref.conv.conv_offset_mask.bias, std=0.2)
+    ref.actf[0].running_mean.normal_(0, 0.1); ref.actf[0].running_var.uniform_(0.8, 1.2)
+    ref.actf[0].weight.data.uniform_(0.8, 1.2); ref.actf[0].bias.data.normal_(0, 0.1)
+    x = torch.randn(2, 64, 24, 40).relu()
+    with torch.no_grad():
+        want = ref(x)
+    m = DeformConv(64, 64).eval()
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV)
+    got = _from_nhwc(m(_to_nhwc(x, dtype)))
+    if dtype == torch.float32:
+        assert float((got - want).abs().max()) < 5e-5 * max(1.0, float(want.abs().max()))
+    else:   # bf16: offsets carry ~3 significant digits -> sampled values move; check relative L2 error
+        rel = float((got - want).norm() / want.norm())
+        assert rel < 3e-2, rel
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_heads_fused_vs_torch(dtype):
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.model.head.detector_predictor import _predictor, REG_OFF
+    from monoflex_amd import synthetic as S
+    from oracle import monoflex_ref as R
+    import os
+    cfg = get_cfg(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "runs", "monoflex.yaml"))
+    ref = R.Predictor().eval()
+    sd = S.synthetic_state_dict({"heads.predictor." + k: v for k, v in ref.state_dict().items()}, seed=3)
+    ref.load_state_dict({k[len("heads.predictor."):]: v for k, v in sd.items()})
+    m = _predictor(cfg, 64).eval()
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV)
+    tgt = S.synthetic_target(40, 24)
+    x = torch.randn(2, 64, 24, 40, generator=_g(9)).relu()
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    taps = {}
+    ei = torch.stack([tgt["edge_indices"]] * 2)
+    el = torch.tensor([tgt["edge_len"]] * 2)
+    with torch.no_grad():
+        maps = ref(x, ei, el, taps)
+    hm = m.forward_nhwc(_to_nhwc(x, dtype), ei.to(DEV, torch.int32), el.to(DEV, torch.int32)).cpu()
+    got_cls = hm[..., :3].permute(0, 3, 1, 2)
+    got_reg = hm[..., REG_OFF:REG_OFF + 50].permute(0, 3, 1, 2)
+    tol = 1e-4 if dtype == torch.float32 else 5e-2
+    assert float((got_cls - taps["cls_logits"]).abs().max()) < tol
+    assert float((got_reg - maps["reg"]).abs().max()) < tol * max(1.0, float(maps["reg"].abs().max()))
+
+
+def test_decode_vs_reference_goldens(golden_dir):
+    """Device decode against fixtures captured from the reference's own PostProcessor."""
+    import os
+    from monoflex_amd import synthetic as S
+    from monoflex_amd.structures.params_3d import Calibration
+    ops, L = _ops()
+    g = np.load(os.path.join(golden_dir, "decode_only.npz"))
+    tgt = S.synthetic_target(320, 96)
+    n = 0
+    while "case%d_seed" % n in g:
+        gen = _g(int(g["case%d_seed" % n]))
+        logits = torch.randn(1, 3, 96, 320, generator=gen) * 0.8 - 2.0 + float(g["case%d_shift" % n])
+        reg = torch.randn(1, 50, 96, 320, generator=gen) * 0.7
+        hm = torch.zeros(1, 96, 320, 64)
+        hm[..., :3] = logits.permute(0, 2, 3, 1)
+        hm[..., 8:58] = reg.permute(0, 2, 3, 1)
+        hm = hm.to(DEV)
+        scores, index = ops.decode_topk(hm, 0, 3, 50)
+        calib = torch.from_numpy(Calibration(tgt["P"]).as_f32()).view(1, 6).to(DEV)
+        pad = tgt["pad_size"].view(1, 2).to(DEV, torch.int32)
+        size = torch.tensor(list(tgt["size"]), dtype=torch.int32, device=DEV)
+        det, topk, valid = ops.decode_boxes(hm, 8, scores, index, calib, pad, size, 0.2)
+        res = det[0][valid[0].bool()].cpu().numpy()
+        want = g["case%d_result" % n]
+        assert res.shape == want.shape, (n, res.shape, want.shape)
+        if want.shape[0]:
+            assert np.allclose(res, want, rtol=1e-4, atol=2e-3), (n, np.abs(res - want).max())
+        n += 1
+    assert n >= 4
