@@ -38,6 +38,9 @@ enum { MFX_OK = 0, MFX_ERR_ARG = -1, MFX_ERR_UNSUPPORTED = -2, MFX_ERR_LAUNCH = 
 
 int mfx_abi_version(void);
 const char* mfx_last_error(void);
+/* tuning/debug overrides: "conv_tile" | "dcn_tile" | "cat_tile" (tile id, 0 = automatic), "kc" (4 | 8 | 0),
+ * "halo" (0 = generic kernel only, 1 = automatic, 2.. = force LDS-halo variant) */
+int mfx_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------
  * (1) reference `_ext` boundary
@@ -128,7 +131,7 @@ int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream);
 int mfx_maxpool2x2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 
 /* depthwise ConvTranspose2d(k=2f, stride=f, pad=f/2) + skip add (dla_dcn.py:409-411,419-425):
- * y[b,oh,ow,c] = sum x[b,ih,iw,c]*w[c][kh][kw] + skip[b,oh,ow,c];  w fp32 [C][2f][2f]; skip may be NULL */
+ * y[b,oh,ow,c] = sum x[b,ih,iw,c]*w[c][kh][kw] + skip[b,oh,ow,c];  w fp32 [2f*2f][C] (tap-major); skip may be NULL */
 int mfx_upsample_add_nhwc(const void* x, const float* w, const void* skip, void* y,
                           int B, int H, int W, int C, int f, int dtype, void* stream);
 

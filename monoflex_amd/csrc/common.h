@@ -6,6 +6,8 @@
 namespace mfx {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
@@ -41,7 +43,7 @@ template <> struct ElemTraits<bf16_t> {
     static constexpr int ELEMS = 8;
     static constexpr int DT = 1;
     __device__ static __forceinline__ float load(const bf16_t* p) { return bf2f(p->v); }
-    __device__ static __forceinline__ void store(bf16_t* p, float v) { p->v = f2bf(v); }
+    __device__ static __forceinline__ void store(bf16_t* p, float v) { p->v = __builtin_bit_cast(uint16_t, (__bf16)v); }
     __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
         f[0] = __uint_as_float(c.x << 16); f[1] = __uint_as_float(c.x & 0xffff0000u);
         f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
@@ -49,11 +51,12 @@ template <> struct ElemTraits<bf16_t> {
         f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
     }
     __device__ static __forceinline__ u32x4 pack(const float* f) {
+        // v_cvt_pk_bf16_f32: hardware round-to-nearest-even, two floats per instruction
         u32x4 c;
-        c.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-        c.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-        c.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-        c.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+        c.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){f[0], f[1]}, bf16x2));
+        c.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){f[2], f[3]}, bf16x2));
+        c.z = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){f[4], f[5]}, bf16x2));
+        c.w = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){f[6], f[7]}, bf16x2));
         return c;
     }
 };
@@ -81,7 +84,7 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_DCN_OFFMASK = 3 };
 __device__ __forceinline__ float apply_act(float v, int act, int n) {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
-    if (act == ACT_DCN_OFFMASK) return (n >= 18 && n < 27) ? 1.f / (1.f + __expf(-v)) : v;
+    if (act == ACT_DCN_OFFMASK) return (n >= 18 && n < 27) ? 1.f / (1.f + expf(-v)) : v;
     return v;
 }
 

@@ -1,0 +1,291 @@
+// 3x3 / stride-1 / pad-1 convolution: LDS-staged input halo, wave-private output slices, weights
+// streamed L2 -> registers.  No workgroup barrier inside the K loop.
+//
+// Why (measured on MI355X, profiles/r01_*): the generic implicit-GEMM kernel rebuilds its A tile from
+// global memory every k-iteration (each input element fetched 9x), pushes both operands through
+// ds_write_b128 (~79 B/clk/CU) and synchronises the workgroup every 16 MFMAs -> 10-20 % MFMA utilisation,
+// insensitive to tile shape.  Here:
+//   * a workgroup = WN waves owns an 8 x 16 block of output pixels of one image; its (8+2) x 18 input halo
+//     patch (one channel group) is written to LDS once, all loads in flight together, zero-filled outside
+//     the image; pixel stride C*sizeof(T)+16 bytes puts 16 consecutive pixels on 16 distinct 16-byte bank
+//     slots, so fragment reads are conflict-free ds_read_b128;
+//   * wave wn computes all 128 pixels x its FN*16 output channels (FM = 8 row fragments): every weight
+//     fragment (16 n x 64 B of K, loaded straight from L1/L2 into VGPRs, prefetched one step ahead) feeds
+//     8 MFMAs, every A fragment FN MFMAs; LDS carries only the A reads (<= 50 % of its bandwidth);
+//   * waves never exchange data in the K loop -> no barriers; 5-6 waves per CU overlap each other's latency;
+//   * epilogue: each wave transposes its accumulators through a private 16-pixel LDS buffer (no block
+//     barrier) so stores and residual loads are 16 bytes per lane along channels.
+#include "../../include/monoflex_hip.h"
+#include "err.h"
+#include "igemm.h"
+#include <type_traits>
+
+namespace mfx {
+
+struct HaloGeom {
+    int B, H, W, C, lgCG, CG, ngroups;     // CG = channels per patch pass (power of two), ngroups = C / CG
+    int tiles_x, tiles_y, tiles_n, K_pad;  // weight row length (elements); K index = tap*C + c
+    int steps_per_group;                   // ceil(9*CG / (4*ELEMS)): 64-byte K steps per channel group
+};
+
+constexpr int kHaloRows = 8;               // output rows per workgroup (FM)
+
+template <typename T, int WN, int FN> struct HaloSmem {
+    static constexpr int stage_ld = FN * 16 + 4;                              // fp32 words per staged pixel row
+    static constexpr int stage_bytes = 16 * stage_ld * 4;                     // per wave
+    static __host__ __device__ constexpr int patch_stride(int CG) { return CG * (int)sizeof(T) + 16; }
+    static __host__ __device__ constexpr int patch_bytes(int CG) { return (kHaloRows + 2) * 18 * patch_stride(CG); }
+    static __host__ __device__ constexpr int total(int CG) { return patch_bytes(CG) + WN * stage_bytes; }
+};
+
+template <typename T, typename TO, int WN, int FN>
+__global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                                 HaloGeom g, EpiArgs ep) {
+    constexpr int NT = WN * 64, FM = kHaloRows;
+    using SM = HaloSmem<T, WN, FN>;
+    constexpr int ELEMS = ElemTraits<T>::ELEMS;
+    constexpr int BN = WN * FN * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // tile decode: n-tile fastest, then x, y, image -> neighbours share halos in one XCD's L2
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % g.tiles_n; tile /= g.tiles_n;
+    const int tx = tile % g.tiles_x; tile /= g.tiles_x;
+    const int ty = tile % g.tiles_y; const int b = tile / g.tiles_y;
+    const int x0 = tx * 16, y0 = ty * kHaloRows, n0 = tn * BN + wn * (FN * 16);
+
+    const int PS = SM::patch_stride(g.CG);
+    char* patch = smem;
+    float* stage = reinterpret_cast<float*>(smem + SM::patch_bytes(g.CG) + wn * SM::stage_bytes);
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int CPP = g.CG * (int)sizeof(T) / 16;              // 16-byte chunks per patch pixel
+    const int lgCPP = g.lgCG - (ELEMS == 8 ? 3 : 2);
+    const int xl = lane & 15, kq = lane >> 4;
+    const T* wrow = w + (size_t)(n0 + xl) * g.K_pad;         // this lane's weight row (fragment j adds 16 rows)
+    const size_t wfrag = (size_t)16 * g.K_pad;
+
+    for (int grp = 0; grp < g.ngroups; ++grp) {
+        if (grp > 0) __syncthreads();                         // every wave is done reading the previous patch
+        // ---- halo patch: 10 x 18 pixels x CG channels
+        const T* xg = x + (size_t)b * g.H * g.W * g.C + grp * g.CG;
+        const int nchunks = (kHaloRows + 2) * 18 * CPP;
+        // batches of PU independent loads per lane (all in flight together), then the LDS writes
+        constexpr int PU = FN >= 4 ? 4 : 8;
+        for (int base = 0; base < nchunks; base += NT * PU) {
+            u32x4 pr[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int idx = base + u * NT + tid;
+                const int pix = idx >> lgCPP, ch = idx & (CPP - 1);
+                const int py = pix / 18, px = pix - py * 18;
+                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                u32x4 z = {0u, 0u, 0u, 0u};
+                if (idx < nchunks && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                    z = *reinterpret_cast<const u32x4*>(xg + ((size_t)iy * g.W + ix) * g.C + ch * ELEMS);
+                pr[u] = z;
+            }
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int idx = base + u * NT + tid;
+                if (idx < nchunks) *reinterpret_cast<u32x4*>(patch + (idx >> lgCPP) * PS + (idx & (CPP - 1)) * 16) = pr[u];
+            }
+        }
+
+        // lane's K chunk at step s: e = s*4*ELEMS + kq*ELEMS -> (tap, local channel)
+        auto wfetch = [&](int s, u32x4 (&bf)[FN]) {
+            const int e = s * (4 * ELEMS) + kq * ELEMS;
+            const int tap = e >> g.lgCG, cl = e & (g.CG - 1);
+            const T* p = wrow + tap * g.C + grp * g.CG + cl;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                u32x4 z = {0u, 0u, 0u, 0u};
+                if (tap < 9) z = *reinterpret_cast<const u32x4*>(p + j * wfrag);
+                bf[j] = z;
+            }
+        };
+        // weight fragments: ring of 3 register buffers, fetched two steps ahead of their use
+        u32x4 wb[3][FN];
+        const int ns = g.steps_per_group;
+        wfetch(0, wb[0]);
+        if (ns > 1) wfetch(1, wb[1]);
+        __syncthreads();                                      // patch visible to all waves
+
+        auto compute = [&](int s, const u32x4 (&bf)[FN]) {
+            const int e = s * (4 * ELEMS) + kq * ELEMS;
+            int tap = e >> g.lgCG;
+            const int cl = e & (g.CG - 1);
+            tap = tap > 8 ? 8 : tap;                          // K padding: weights are zero there, keep the address valid
+            const int th = (tap * 21846) >> 16, tw = tap - th * 3;
+            const char* ap = patch + (th * 18 + xl + tw) * PS + cl * (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const u32x4 af = *reinterpret_cast<const u32x4*>(ap + i * 18 * PS);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma_chunk<T>(af, bf[j], acc[i][j]);
+            }
+        };
+        int s = 0;
+        for (; s + 3 <= ns; s += 3) {                         // unrolled by 3 so the ring indices are static
+            if (s + 2 < ns) wfetch(s + 2, wb[2]);
+            compute(s, wb[0]);
+            if (s + 3 < ns) wfetch(s + 3, wb[0]);
+            compute(s + 1, wb[1]);
+            if (s + 4 < ns) wfetch(s + 4, wb[1]);
+            compute(s + 2, wb[2]);
+        }
+        if (s < ns) {                                         // 1 or 2 steps left; their fragments are already in flight
+            if (s + 2 < ns) wfetch(s + 2, wb[2]);
+            compute(s, wb[0]);
+            if (s + 1 < ns) compute(s + 1, wb[1]);
+        }
+    }
+
+    // ---- epilogue, wave-private: acc row-fragment i (16 pixels of output row y0+i) -> stage -> 16-byte stores
+    constexpr int LDS_ = SM::stage_ld;
+    constexpr int OE = ElemTraits<TO>::ELEMS;
+    constexpr int GPR = FN * 16 / OE;                         // output chunks per pixel
+    const T* res = reinterpret_cast<const T*>(ep.res);
+    TO* y = reinterpret_cast<TO*>(ep.y);
+    float sc[FN], sh[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        sc[j] = ep.scale ? ep.scale[n0 + j * 16 + xl] : 1.f;
+        sh[j] = ep.shift ? ep.shift[n0 + j * 16 + xl] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        // D layout: col n = lane&15, row (pixel x) = (lane>>4)*4 + r
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[((lane >> 4) * 4 + r) * LDS_ + j * 16 + xl] = acc[i][j][r] * sc[j] + sh[j];
+        __builtin_amdgcn_wave_barrier();                      // same wave: DS ops complete in order
+        const int oy = y0 + i;
+        for (int it = lane; it < 16 * GPR; it += 64) {
+            const int px = it / GPR, ng = it - px * GPR;
+            const int ox = x0 + px, gn = n0 + ng * OE;
+            if (oy < g.H && ox < g.W && gn < ep.Cout) {
+                const size_t gm = ((size_t)b * g.H + oy) * g.W + ox;
+                float v[OE];
+#pragma unroll
+                for (int e = 0; e < OE; e += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(stage + px * LDS_ + ng * OE + e);
+                    v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+                }
+                if (res) {
+                    const T* rp = res + gm * ep.ldres + gn;
+                    if constexpr (ElemTraits<T>::ELEMS == OE) {
+                        float rv[OE];
+                        ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(rp), rv);
+#pragma unroll
+                        for (int e = 0; e < OE; ++e) v[e] += rv[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < OE; ++e) v[e] += ElemTraits<T>::load(rp + e);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < OE; ++e) v[e] = apply_act(v[e], ep.act, gn + e);
+                *reinterpret_cast<u32x4*>(y + gm * ep.ldy + gn) = ElemTraits<TO>::pack(v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+static inline int cdivh(int a, int b) { return (a + b - 1) / b; }
+static inline int ilog2h(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+int g_opt_halo = 1;          // 0 = generic kernel only, 1 = automatic, >= 2 = force variant (value - 1)
+int g_opt_halo_cg = 0;       // max channels per patch pass (0 = default)
+
+template <typename T, typename TO, int WN, int FN>
+static int launch_halo(const mfx_conv_desc* d, hipStream_t st) {
+    using SM = HaloSmem<T, WN, FN>;
+    constexpr int ELEMS = ElemTraits<T>::ELEMS;
+    constexpr int BN = WN * FN * 16;
+    HaloGeom g;
+    g.B = d->B; g.H = d->H; g.W = d->W; g.C = d->Ck;
+    int cg_max = g_opt_halo_cg > 0 ? g_opt_halo_cg : 512 / (int)sizeof(T);      // 512-byte channel rows: 256 bf16 / 128 f32
+    if (cg_max < 2 * ELEMS) cg_max = 2 * ELEMS;
+    g.CG = d->Ck < cg_max ? d->Ck : cg_max; g.lgCG = ilog2h(g.CG); g.ngroups = d->Ck / g.CG;
+    g.tiles_x = cdivh(d->W, 16); g.tiles_y = cdivh(d->H, kHaloRows); g.tiles_n = d->Cout_pad / BN; g.K_pad = d->K_pad;
+    g.steps_per_group = cdivh(9 * g.CG, 4 * ELEMS);
+    EpiArgs ep;
+    ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
+    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
+    const int smem = SM::total(g.CG);
+    auto k = conv3x3_wave_kernel<T, TO, WN, FN>;
+    static int attr_smem = 0;
+    if (smem > 64 * 1024 && smem > attr_smem) {
+        MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_smem = smem;
+    }
+    const int tiles = g.tiles_n * g.tiles_x * g.tiles_y * d->B;
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(WN * 64), smem, st, reinterpret_cast<const T*>(d->x), reinterpret_cast<const T*>(d->w), g, ep);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+// variants (value of option "halo" minus 1):  1: BN16 (1 wave x FN1)  2: BN32 (1 x 2)  3: BN64 (1 x 4)  4: BN128 (2 x 4)
+//                                              5: BN256 (4 x 4)        6: BN64 (2 x 2)  7: BN128 (4 x 2)
+template <typename T, typename TO> static int halo_variant(int v, const mfx_conv_desc* d, hipStream_t st) {
+    switch (v) {
+        case 1: return launch_halo<T, TO, 1, 1>(d, st);
+        case 2: return launch_halo<T, TO, 1, 2>(d, st);
+        default: break;
+    }
+    if constexpr (std::is_same<T, TO>::value) {
+        switch (v) {
+            case 3: return launch_halo<T, TO, 1, 4>(d, st);
+            case 4: return launch_halo<T, TO, 2, 4>(d, st);
+            case 5: return launch_halo<T, TO, 4, 4>(d, st);
+            case 6: return launch_halo<T, TO, 2, 2>(d, st);
+            case 7: return launch_halo<T, TO, 4, 2>(d, st);
+            default: break;
+        }
+    }
+    return mfx_fail(MFX_ERR_UNSUPPORTED, "conv halo: no such variant");
+}
+
+static int variant_bn(int v) { const int bn[8] = {0, 16, 32, 64, 128, 256, 64, 128}; return (v >= 1 && v <= 7) ? bn[v] : 0; }
+
+// returns 1 if the halo kernel handled the convolution, 0 if the caller should use the generic kernel, <0 on error
+int try_conv_halo(const mfx_conv_desc* d, hipStream_t st) {
+    if (g_opt_halo == 0) return 0;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_h != 1 || d->pad_w != 1 || d->dil_w != 1) return 0;
+    if (d->rowmap || d->x_pixstride != d->Ck || d->Ho != d->H || d->Wo != d->W || d->M != d->B * d->H * d->W) return 0;
+    const int elems = d->dtype == MFX_BF16 ? 8 : 4;
+    if (d->Ck < 2 * elems || d->K_pad < 9 * d->Ck) return 0;
+    const int N = d->Cout_pad;
+    const int px_tiles = d->B * cdivh(d->H, kHaloRows) * cdivh(d->W, 16);
+    // variant table from tools/conv_probe.py on MI355X (profiles/r01_*): two or four waves share a patch,
+    // 32 output channels per wave; narrow outputs on small maps split N further to get more waves in flight
+    int v;
+    if (N == 16) v = 1;
+    else if (N == 32) v = px_tiles >= 1024 ? 2 : 1;
+    else if (N == 64) v = 6;
+    else if (N % 128 == 0) {
+        if (px_tiles * (N / 128) < 300) return 0;             // tiny maps (12x40): the generic 64x64 tiling has more parallelism
+        v = 7;
+    } else v = 6;
+    if (g_opt_halo >= 2) {
+        const int f = g_opt_halo - 1, bn = variant_bn(f);
+        if (bn && N % bn == 0 && (bn >= 64) == (N >= 64)) v = f;
+    }
+    int rc;
+    if (d->dtype == MFX_F32) rc = halo_variant<float, float>(v, d, st);
+    else if (d->out_dtype == MFX_BF16) rc = halo_variant<bf16_t, bf16_t>(v, d, st);
+    else rc = halo_variant<bf16_t, float>(v, d, st);
+    return rc == MFX_OK ? 1 : rc;
+}
+
+}  // namespace mfx

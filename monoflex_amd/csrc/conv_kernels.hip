@@ -3,6 +3,8 @@
 #include "../../include/monoflex_hip.h"
 #include "err.h"
 #include "igemm.h"
+#include <string>
+#include <type_traits>
 
 namespace mfx {
 
@@ -14,17 +16,20 @@ struct ConvGeom {
 };
 
 // im2col on the fly: row m = output pixel, chunk -> (tap, channel); out-of-image taps read zeros.
-template <typename T, int BM> struct ConvALoader {
+template <typename T, int BM, int NT, int KC> struct ConvALoader {
     static constexpr int ELEMS = ElemTraits<T>::ELEMS;
-    static constexpr int R = BM / 64;
+    static constexpr int RPP = NT / KC;
+    static constexpr int R = BM / RPP;
+    static constexpr int kRowBytes = RowGeom<KC>::bytes;
+    static_assert(BM % RPP == 0, "BM must be a multiple of the rows covered per pass");
     const T* x; ConvGeom g; int c, r0;
     int ih0[R], iw0[R], pix0[R]; bool ok[R];
     u32x4 regs[R];
     __device__ __forceinline__ void init(const T* x_, const ConvGeom& g_, const int* rowmap, int m0, int tid) {
-        x = x_; g = g_; c = tid & 3; r0 = tid >> 2;
+        x = x_; g = g_; c = tid % KC; r0 = tid / KC;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const int m = m0 + r0 + 64 * i;
+            const int m = m0 + r0 + RPP * i;
             int pm = (m < g.M) ? (rowmap ? rowmap[m] : m) : -1;
             ok[i] = pm >= 0;
             pm = pm < 0 ? 0 : pm;
@@ -37,7 +42,7 @@ template <typename T, int BM> struct ConvALoader {
         }
     }
     __device__ __forceinline__ void load(int kiter) {
-        const int e = kiter * (kChunks * ELEMS) + c * ELEMS;
+        const int e = kiter * (KC * ELEMS) + c * ELEMS;
         const int tap = e >> g.lgC, ci = e & ((1 << g.lgC) - 1);
         const int th = (tap * g.inv_kw) >> 16, tw = tap - th * g.kw;
         const bool tap_ok = tap < g.kh * g.kw;
@@ -52,7 +57,7 @@ template <typename T, int BM> struct ConvALoader {
     }
     __device__ __forceinline__ void store(char* As) const {
 #pragma unroll
-        for (int i = 0; i < R; ++i) *reinterpret_cast<u32x4*>(As + (r0 + 64 * i) * kRowBytes + c * 16) = regs[i];
+        for (int i = 0; i < R; ++i) *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * kRowBytes + c * 16) = regs[i];
     }
 };
 
@@ -61,20 +66,23 @@ struct CatSegs {
 };
 
 // virtual channel concat for the 1x1 Root conv: k-iteration -> (segment, channel) is wave-uniform.
-template <typename T, int BM> struct CatALoader {
+template <typename T, int BM, int NT, int KC> struct CatALoader {
     static constexpr int ELEMS = ElemTraits<T>::ELEMS;
-    static constexpr int R = BM / 64;
+    static constexpr int RPP = NT / KC;
+    static constexpr int R = BM / RPP;
+    static constexpr int kRowBytes = RowGeom<KC>::bytes;
+    static_assert(BM % RPP == 0, "BM must be a multiple of the rows covered per pass");
     const CatSegs* s; int c, r0, m0;
     u32x4 regs[R];
-    __device__ __forceinline__ void init(const CatSegs* s_, int m0_, int tid) { s = s_; m0 = m0_; c = tid & 3; r0 = tid >> 2; }
+    __device__ __forceinline__ void init(const CatSegs* s_, int m0_, int tid) { s = s_; m0 = m0_; c = tid % KC; r0 = tid / KC; }
     __device__ __forceinline__ void load(int kiter) {
-        const int e = kiter * (kChunks * ELEMS);
+        const int e = kiter * (KC * ELEMS);
         const int seg = e >> s->lgC, ci = (e & ((1 << s->lgC) - 1)) + c * ELEMS;
         const T* base = reinterpret_cast<const T*>(s->src[seg]) + s->off[seg] + ci;
         const int st = s->stride[seg];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const int m = m0 + r0 + 64 * i;
+            const int m = m0 + r0 + RPP * i;
             u32x4 z = {0u, 0u, 0u, 0u};
             if (m < s->M) z = *reinterpret_cast<const u32x4*>(base + (size_t)m * st);
             regs[i] = z;
@@ -82,7 +90,7 @@ template <typename T, int BM> struct CatALoader {
     }
     __device__ __forceinline__ void store(char* As) const {
 #pragma unroll
-        for (int i = 0; i < R; ++i) *reinterpret_cast<u32x4*>(As + (r0 + 64 * i) * kRowBytes + c * 16) = regs[i];
+        for (int i = 0; i < R; ++i) *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * kRowBytes + c * 16) = regs[i];
     }
 };
 
@@ -92,18 +100,21 @@ struct DcnGeom { int H, W, C, lgC, Ho, Wo, kh, kw, inv_kw, stride, pad, dil, M; 
 // In NHWC the four corners are contiguous channel vectors, so every lane gathers 4 x 16 bytes and
 // blends them in fp32; offsets/mask are read once per (pixel, tap) and reused across all channels.
 // Sample validity and per-corner zeroing follow src/cuda/dcn_v2_im2col_cuda.cu:25-54,178-189.
-template <typename T, int BM> struct DcnALoader {
+template <typename T, int BM, int NT, int KC> struct DcnALoader {
     static constexpr int ELEMS = ElemTraits<T>::ELEMS;
-    static constexpr int R = BM / 64;
+    static constexpr int RPP = NT / KC;
+    static constexpr int R = BM / RPP;
+    static constexpr int kRowBytes = RowGeom<KC>::bytes;
+    static_assert(BM % RPP == 0, "BM must be a multiple of the rows covered per pass");
     const T* x; const float* om; DcnGeom g; int c, r0;
     int oh_[R], ow_[R], pix0[R], mrow[R]; bool ok[R];
     int coff[R][4]; float cw[R][4];
     u32x4 regs[R][4];
     __device__ __forceinline__ void init(const T* x_, const float* om_, const DcnGeom& g_, int m0, int tid) {
-        x = x_; om = om_; g = g_; c = tid & 3; r0 = tid >> 2;
+        x = x_; om = om_; g = g_; c = tid % KC; r0 = tid / KC;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const int m = m0 + r0 + 64 * i;
+            const int m = m0 + r0 + RPP * i;
             ok[i] = m < g.M;
             const int pm = ok[i] ? m : 0;
             mrow[i] = pm;
@@ -136,7 +147,7 @@ template <typename T, int BM> struct DcnALoader {
         }
     }
     __device__ __forceinline__ void load(int kiter) {
-        const int e = kiter * (kChunks * ELEMS);
+        const int e = kiter * (KC * ELEMS);
         const int ci = (e & (g.C - 1)) + c * ELEMS;
         if ((e & (g.C - 1)) == 0) tap_setup(e >> g.lgC);      // wave-uniform: a new tap starts
 #pragma unroll
@@ -155,7 +166,7 @@ template <typename T, int BM> struct DcnALoader {
 #pragma unroll
             for (int e = 0; e < ELEMS; ++e)
                 o[e] = cw[i][0] * v[0][e] + cw[i][1] * v[1][e] + cw[i][2] * v[2][e] + cw[i][3] * v[3][e];
-            *reinterpret_cast<u32x4*>(As + (r0 + 64 * i) * kRowBytes + c * 16) = ElemTraits<T>::pack(o);
+            *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * kRowBytes + c * 16) = ElemTraits<T>::pack(o);
         }
     }
 };
@@ -163,91 +174,156 @@ template <typename T, int BM> struct DcnALoader {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-struct EpiArgs {
-    const float* scale; const float* shift; const void* res; void* y;
-    int ldy, ldres, Cout, act, tiles_n, K_pad, nk;
-};
 
-template <typename T, typename TO, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const T* x, const T* w, ConvGeom g, const int* rowmap, EpiArgs ep) {
+template <typename T, typename TO, int BM, int BN, int WM, int WN, int KC>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const T* x, const T* w, ConvGeom g, const int* rowmap, EpiArgs ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % ep.tiles_n, tm = tile / ep.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    ConvALoader<T, BM> al; al.init(x, g, rowmap, m0, threadIdx.x);
-    WeightLoader<T, BN> bl; bl.init(w, n0, ep.K_pad, threadIdx.x);
+    ConvALoader<T, BM, WM * WN * 64, KC> al; al.init(x, g, rowmap, m0, threadIdx.x);
+    WeightLoader<T, BN, WM * WN * 64, KC> bl; bl.init(w, n0, ep.K_pad, threadIdx.x);
     f32x4 acc[BM / WM / 16][BN / WN / 16];
-    gemm_mainloop<T, BM, BN, WM, WN>(al, bl, ep.nk, smem, acc);
+    gemm_mainloop<T, BM, BN, WM, WN, KC>(al, bl, ep.nk, smem, acc);
     epilogue_store<T, TO, BM, BN, WM, WN>(acc, smem, ep.scale, ep.shift, reinterpret_cast<const T*>(ep.res), ep.ldres,
                                           reinterpret_cast<TO*>(ep.y), ep.ldy, m0, n0, g.M, ep.Cout, ep.act);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(kThreads) void cat_igemm_kernel(CatSegs segs, const T* w, EpiArgs ep) {
+template <typename T, int BM, int BN, int WM, int WN, int KC>
+__global__ __launch_bounds__(WM * WN * 64) void cat_igemm_kernel(CatSegs segs, const T* w, EpiArgs ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % ep.tiles_n, tm = tile / ep.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    CatALoader<T, BM> al; al.init(&segs, m0, threadIdx.x);
-    WeightLoader<T, BN> bl; bl.init(w, n0, ep.K_pad, threadIdx.x);
+    CatALoader<T, BM, WM * WN * 64, KC> al; al.init(&segs, m0, threadIdx.x);
+    WeightLoader<T, BN, WM * WN * 64, KC> bl; bl.init(w, n0, ep.K_pad, threadIdx.x);
     f32x4 acc[BM / WM / 16][BN / WN / 16];
-    gemm_mainloop<T, BM, BN, WM, WN>(al, bl, ep.nk, smem, acc);
+    gemm_mainloop<T, BM, BN, WM, WN, KC>(al, bl, ep.nk, smem, acc);
     epilogue_store<T, T, BM, BN, WM, WN>(acc, smem, ep.scale, ep.shift, reinterpret_cast<const T*>(ep.res), ep.ldres,
                                          reinterpret_cast<T*>(ep.y), ep.ldy, m0, n0, segs.M, ep.Cout, ep.act);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(kThreads) void dcn_igemm_kernel(const T* x, const float* om, const T* w, DcnGeom g, EpiArgs ep) {
+template <typename T, int BM, int BN, int WM, int WN, int KC>
+__global__ __launch_bounds__(WM * WN * 64) void dcn_igemm_kernel(const T* x, const float* om, const T* w, DcnGeom g, EpiArgs ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % ep.tiles_n, tm = tile / ep.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    DcnALoader<T, BM> al; al.init(x, om, g, m0, threadIdx.x);
-    WeightLoader<T, BN> bl; bl.init(w, n0, ep.K_pad, threadIdx.x);
+    DcnALoader<T, BM, WM * WN * 64, KC> al; al.init(x, om, g, m0, threadIdx.x);
+    WeightLoader<T, BN, WM * WN * 64, KC> bl; bl.init(w, n0, ep.K_pad, threadIdx.x);
     f32x4 acc[BM / WM / 16][BN / WN / 16];
-    gemm_mainloop<T, BM, BN, WM, WN>(al, bl, ep.nk, smem, acc);
+    gemm_mainloop<T, BM, BN, WM, WN, KC>(al, bl, ep.nk, smem, acc);
     epilogue_store<T, T, BM, BN, WM, WN>(acc, smem, ep.scale, ep.shift, nullptr, 0,
                                          reinterpret_cast<T*>(ep.y), ep.ldy, m0, n0, g.M, ep.Cout, ep.act);
 }
 
 // ------------------------------------------------------------------------------------------------
-// launch helpers
+// launch helpers + tile selection
 // ------------------------------------------------------------------------------------------------
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-template <typename T, typename TO, int BM, int BN, int WM, int WN>
+int try_conv_halo(const mfx_conv_desc* d, hipStream_t st);   // conv_halo.hip
+extern int g_opt_halo, g_opt_halo_cg;
+
+// tuning overrides (mfx_set_option): 0 = automatic
+int g_opt_conv_tile = 0, g_opt_dcn_tile = 0, g_opt_cat_tile = 0, g_opt_kc = 0;
+
+template <typename K> static int set_smem(K k, int smem) {
+    if (smem > 64 * 1024) MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    return MFX_OK;
+}
+
+template <typename T, typename TO, int BM, int BN, int WM, int WN, int KC>
 static int launch_conv(const mfx_conv_desc* d, const ConvGeom& g, EpiArgs ep, hipStream_t st) {
     ep.tiles_n = d->Cout_pad / BN;
+    ep.nk = d->K_pad / (KC * ElemTraits<T>::ELEMS);
     const int tiles = cdiv(d->M, BM) * ep.tiles_n;
-    auto k = conv_igemm_kernel<T, TO, BM, BN, WM, WN>;
-    constexpr int smem = TileSmem<BM, BN>::bytes;
+    auto k = conv_igemm_kernel<T, TO, BM, BN, WM, WN, KC>;
+    constexpr int smem = TileSmem<BM, BN, KC>::bytes;
     static bool attr_set = false;
-    if (!attr_set) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), smem, st, reinterpret_cast<const T*>(d->x),
+    if (!attr_set) { int rc = set_smem(k, smem); if (rc) return rc; attr_set = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), smem, st, reinterpret_cast<const T*>(d->x),
                        reinterpret_cast<const T*>(d->w), g, d->rowmap, ep);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
 
+// tile ids (also the values of the "conv_tile" / "dcn_tile" / "cat_tile" options)
+enum { T_256x16 = 1, T_256x32 = 2, T_128x64 = 3, T_64x64 = 4, T_128x128 = 5, T_64x128 = 6, T_256x64 = 7, T_256x128_8w = 8, T_128x128_8w = 9 };
+
+template <typename T, typename TO, int KC>
+static int dispatch_conv_kc(int tile, const mfx_conv_desc* d, const ConvGeom& g, const EpiArgs& ep, hipStream_t st) {
+    switch (tile) {
+        case T_256x16: return launch_conv<T, TO, 256, 16, 4, 1, 4>(d, g, ep, st);
+        case T_256x32: return launch_conv<T, TO, 256, 32, 4, 1, 4>(d, g, ep, st);
+        default: break;
+    }
+    if constexpr (std::is_same<T, TO>::value) {
+        switch (tile) {
+            case T_128x64: return launch_conv<T, TO, 128, 64, 4, 1, KC>(d, g, ep, st);
+            case T_64x64: return launch_conv<T, TO, 64, 64, 2, 2, KC>(d, g, ep, st);
+            case T_128x128: return launch_conv<T, TO, 128, 128, 2, 2, KC>(d, g, ep, st);
+            case T_64x128: return launch_conv<T, TO, 64, 128, 2, 2, KC>(d, g, ep, st);
+            case T_256x64: return launch_conv<T, TO, 256, 64, 4, 1, KC>(d, g, ep, st);
+            case T_256x128_8w: return launch_conv<T, TO, 256, 128, 4, 2, KC>(d, g, ep, st);
+            case T_128x128_8w: return launch_conv<T, TO, 128, 128, 2, 4, KC>(d, g, ep, st);
+            default: break;
+        }
+    }
+    return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: no kernel for this tile / dtype combination");
+}
+
+static bool tile_fits(int tile, int N) {
+    switch (tile) {
+        case T_256x16: return N == 16;
+        case T_256x32: return N == 32;
+        case T_128x64: case T_64x64: case T_256x64: return N % 64 == 0;
+        default: return N % 128 == 0;
+    }
+}
+
+static int pick_conv_tile(int M, int N) {
+    if (N == 16) return T_256x16;
+    if (N == 32) return T_256x32;
+    if (N == 64) return cdiv(M, 128) >= 512 ? T_128x64 : T_64x64;
+    if (N % 128 == 0) {
+        const int t128 = cdiv(M, 128) * (N / 128);
+        if (t128 >= 384) return T_128x128;
+        if (cdiv(M, 64) * (N / 128) >= 384) return T_64x128;
+    }
+    return T_64x64;
+}
+
 template <typename T, typename TO>
 static int dispatch_conv(const mfx_conv_desc* d, const ConvGeom& g, const EpiArgs& ep, hipStream_t st) {
     const int N = d->Cout_pad;
-    if (N == 16) return launch_conv<T, TO, 256, 16, 4, 1>(d, g, ep, st);
-    if (N == 32) return launch_conv<T, TO, 256, 32, 4, 1>(d, g, ep, st);
-    if (N % 64 != 0) return mfx_fail(MFX_ERR_ARG, "conv2d: Cout_pad must be 16, 32 or a multiple of 64");
-    if (N == 64) {
-        if (cdiv(d->M, 128) >= 512) return launch_conv<T, TO, 128, 64, 4, 1>(d, g, ep, st);
-        return launch_conv<T, TO, 64, 64, 2, 2>(d, g, ep, st);
-    }
-    if (N % 128 == 0 && cdiv(d->M, 128) * (N / 128) >= 512) return launch_conv<T, TO, 128, 128, 2, 2>(d, g, ep, st);
-    return launch_conv<T, TO, 64, 64, 2, 2>(d, g, ep, st);
+    if (N != 16 && N != 32 && N % 64 != 0) return mfx_fail(MFX_ERR_ARG, "conv2d: Cout_pad must be 16, 32 or a multiple of 64");
+    int tile = pick_conv_tile(d->M, N);
+    if (g_opt_conv_tile && tile_fits(g_opt_conv_tile, N)) tile = g_opt_conv_tile;
+    const int elems = ElemTraits<T>::ELEMS;
+    const bool kc8_ok = d->K_pad % (8 * elems) == 0;
+    const int kc = (g_opt_kc == 4 || !kc8_ok) ? 4 : 8;
+    return kc == 8 ? dispatch_conv_kc<T, TO, 8>(tile, d, g, ep, st) : dispatch_conv_kc<T, TO, 4>(tile, d, g, ep, st);
 }
 
 }  // namespace mfx
 
 using namespace mfx;
+
+extern "C" int mfx_set_option(const char* name, int value) {
+    if (!name) return mfx_fail(MFX_ERR_ARG, "set_option: null name");
+    const std::string n(name);
+    if (n == "conv_tile") g_opt_conv_tile = value;
+    else if (n == "dcn_tile") g_opt_dcn_tile = value;
+    else if (n == "cat_tile") g_opt_cat_tile = value;
+    else if (n == "kc") g_opt_kc = value;
+    else if (n == "halo") g_opt_halo = value;
+    else if (n == "halo_cg") g_opt_halo_cg = value;
+    else return mfx_fail(MFX_ERR_ARG, "set_option: unknown option");
+    return MFX_OK;
+}
 
 extern "C" int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "conv2d: null pointer");
@@ -259,13 +335,19 @@ extern "C" int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream) {
     if (d->Cout % oe != 0 || d->Cout > d->Cout_pad) return mfx_fail(MFX_ERR_ARG, "conv2d: Cout must be a multiple of the output chunk and <= Cout_pad");
     if (d->kh * d->kw > 64 || d->kw > 8) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: kernel too large");
     if (d->M <= 0) return MFX_OK;
+    if (d->dtype == MFX_BF16 && d->out_dtype == MFX_F32 && d->res) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: residual needs out_dtype == dtype");
+    if (d->dtype == MFX_F32 && d->out_dtype != MFX_F32) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: f32 input needs f32 output");
+    {
+        const int h = try_conv_halo(d, reinterpret_cast<hipStream_t>(stream));   // 3x3/s1: LDS-staged halo kernel
+        if (h != 0) return h < 0 ? h : MFX_OK;
+    }
     ConvGeom g;
     g.H = d->H; g.W = d->W; g.Ho = d->Ho; g.Wo = d->Wo; g.x_pixstride = d->x_pixstride; g.lgC = ilog2(d->Ck);
     g.kh = d->kh; g.kw = d->kw; g.inv_kw = (65536 + d->kw - 1) / d->kw; g.stride = d->stride;
     g.pad_h = d->pad_h; g.pad_w = d->pad_w; g.dil_w = d->dil_w; g.M = d->M;
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
-    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = d->K_pad / (4 * elems); ep.tiles_n = 1;
+    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == MFX_F32) {
         if (d->out_dtype != MFX_F32) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: f32 input needs f32 output");
@@ -277,23 +359,30 @@ extern "C" int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream) {
 }
 
 namespace mfx {
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int KC>
 static int launch_cat(const mfx_cat_desc* d, const CatSegs& s, EpiArgs ep, hipStream_t st) {
     ep.tiles_n = d->Cout_pad / BN;
+    ep.nk = d->K_pad / (KC * ElemTraits<T>::ELEMS);
     const int tiles = cdiv(d->M, BM) * ep.tiles_n;
-    auto k = cat_igemm_kernel<T, BM, BN, WM, WN>;
-    constexpr int smem = TileSmem<BM, BN>::bytes;
+    auto k = cat_igemm_kernel<T, BM, BN, WM, WN, KC>;
+    constexpr int smem = TileSmem<BM, BN, KC>::bytes;
     static bool attr_set = false;
-    if (!attr_set) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), smem, st, s, reinterpret_cast<const T*>(d->w), ep);
+    if (!attr_set) { int rc = set_smem(k, smem); if (rc) return rc; attr_set = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), smem, st, s, reinterpret_cast<const T*>(d->w), ep);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
 template <typename T> static int dispatch_cat(const mfx_cat_desc* d, const CatSegs& s, const EpiArgs& ep, hipStream_t st) {
     const int N = d->Cout_pad;
     if (N % 64 != 0) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: Cout_pad must be a multiple of 64");
-    if (N % 128 == 0 && cdiv(d->M, 128) * (N / 128) >= 512) return launch_cat<T, 128, 128, 2, 2>(d, s, ep, st);
-    return launch_cat<T, 64, 64, 2, 2>(d, s, ep, st);
+    int tile = pick_conv_tile(d->M, N);
+    if (g_opt_cat_tile && tile_fits(g_opt_cat_tile, N)) tile = g_opt_cat_tile;
+    switch (tile) {
+        case T_128x64: return launch_cat<T, 128, 64, 4, 1, 8>(d, s, ep, st);
+        case T_128x128: return launch_cat<T, 128, 128, 2, 2, 8>(d, s, ep, st);
+        case T_64x128: return launch_cat<T, 64, 128, 2, 2, 8>(d, s, ep, st);
+        default: return launch_cat<T, 64, 64, 2, 2, 8>(d, s, ep, st);
+    }
 }
 }  // namespace mfx
 
@@ -301,7 +390,7 @@ extern "C" int mfx_cat_conv1x1_nhwc(const mfx_cat_desc* d, void* stream) {
     if (!d || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: null pointer");
     if (d->nseg < 1 || d->nseg > MFX_MAX_SEG) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: 1..9 segments");
     const int elems = d->dtype == MFX_BF16 ? 8 : 4;
-    if (!is_pow2(d->Cseg) || d->Cseg < 4 * elems) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: Cseg must be a power of two >= 64 bytes");
+    if (!is_pow2(d->Cseg) || d->Cseg < 8 * elems) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: Cseg must be a power of two >= 128 bytes");
     if (d->K_pad != d->nseg * d->Cseg) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: K_pad != nseg*Cseg");
     if (d->Cout % elems != 0) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: Cout must be a multiple of the chunk");
     if (d->M <= 0) return MFX_OK;
@@ -313,7 +402,7 @@ extern "C" int mfx_cat_conv1x1_nhwc(const mfx_cat_desc* d, void* stream) {
     s.lgC = ilog2(d->Cseg); s.M = d->M;
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
-    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = d->K_pad / (4 * elems); ep.tiles_n = 1;
+    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == MFX_F32) return dispatch_cat<float>(d, s, ep, st);
     if (d->dtype == MFX_BF16) return dispatch_cat<bf16_t>(d, s, ep, st);
@@ -321,15 +410,16 @@ extern "C" int mfx_cat_conv1x1_nhwc(const mfx_cat_desc* d, void* stream) {
 }
 
 namespace mfx {
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int KC>
 static int launch_dcn(const mfx_dcn_desc* d, const DcnGeom& g, EpiArgs ep, hipStream_t st) {
     ep.tiles_n = d->Cout_pad / BN;
+    ep.nk = d->K_pad / (KC * ElemTraits<T>::ELEMS);
     const int tiles = cdiv(g.M, BM) * ep.tiles_n;
-    auto k = dcn_igemm_kernel<T, BM, BN, WM, WN>;
-    constexpr int smem = TileSmem<BM, BN>::bytes;
+    auto k = dcn_igemm_kernel<T, BM, BN, WM, WN, KC>;
+    constexpr int smem = TileSmem<BM, BN, KC>::bytes;
     static bool attr_set = false;
-    if (!attr_set) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), smem, st, reinterpret_cast<const T*>(d->x), d->offmask,
+    if (!attr_set) { int rc = set_smem(k, smem); if (rc) return rc; attr_set = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), smem, st, reinterpret_cast<const T*>(d->x), d->offmask,
                        reinterpret_cast<const T*>(d->w), g, ep);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -337,9 +427,16 @@ static int launch_dcn(const mfx_dcn_desc* d, const DcnGeom& g, EpiArgs ep, hipSt
 template <typename T> static int dispatch_dcn(const mfx_dcn_desc* d, const DcnGeom& g, const EpiArgs& ep, hipStream_t st) {
     const int N = d->Cout_pad;
     if (N % 64 != 0) return mfx_fail(MFX_ERR_ARG, "dcn: Cout_pad must be a multiple of 64");
-    if (N == 64 && cdiv(g.M, 128) >= 512) return launch_dcn<T, 128, 64, 4, 1>(d, g, ep, st);
-    if (N % 128 == 0 && cdiv(g.M, 128) * (N / 128) >= 512) return launch_dcn<T, 128, 128, 2, 2>(d, g, ep, st);
-    return launch_dcn<T, 64, 64, 2, 2>(d, g, ep, st);
+    int tile = N == 64 ? (cdiv(g.M, 128) >= 512 ? T_128x64 : T_64x64)
+                       : (N % 128 == 0 && cdiv(g.M, 64) * (N / 128) >= 256 ? T_64x128 : T_64x64);
+    if (g_opt_dcn_tile && tile_fits(g_opt_dcn_tile, N)) tile = g_opt_dcn_tile;
+    const bool kc8 = g_opt_kc != 4 && d->C >= 8 * ElemTraits<T>::ELEMS;
+    switch (tile) {
+        case T_128x64: return kc8 ? launch_dcn<T, 128, 64, 4, 1, 8>(d, g, ep, st) : launch_dcn<T, 128, 64, 4, 1, 4>(d, g, ep, st);
+        case T_64x128: return kc8 ? launch_dcn<T, 64, 128, 2, 2, 8>(d, g, ep, st) : launch_dcn<T, 64, 128, 2, 2, 4>(d, g, ep, st);
+        case T_128x128: return kc8 ? launch_dcn<T, 128, 128, 2, 2, 8>(d, g, ep, st) : launch_dcn<T, 128, 128, 2, 2, 4>(d, g, ep, st);
+        default: return kc8 ? launch_dcn<T, 64, 64, 2, 2, 8>(d, g, ep, st) : launch_dcn<T, 64, 64, 2, 2, 4>(d, g, ep, st);
+    }
 }
 }  // namespace mfx
 
@@ -357,7 +454,7 @@ extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
     if (g.M <= 0) return MFX_OK;
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = nullptr; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = 0;
-    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = d->K_pad / (4 * elems); ep.tiles_n = 1;
+    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return d->dtype == MFX_F32 ? dispatch_dcn<float>(d, g, ep, st) : dispatch_dcn<bf16_t>(d, g, ep, st);
 }

@@ -18,7 +18,7 @@ struct HeadTabs { int ch_off[16]; int c_out[16]; };
 template <typename T> struct HeadSmem {
     static constexpr int BM = 64, BN = 256;
     static constexpr int trunk_stride = BN * (int)sizeof(T) + 16;         // bytes; == 16 mod 256 -> conflict-free b128 reads
-    static constexpr int main_bytes = TileSmem<BM, BN>::mainloop_bytes;   // 51200
+    static constexpr int main_bytes = TileSmem<BM, BN, 4>::mainloop_bytes;   // 51200
     static constexpr int trunk_bytes = BM * trunk_stride;
     static constexpr int region0 = main_bytes > trunk_bytes ? main_bytes : trunk_bytes;   // main loop stages, then trunk
     static constexpr int w2_bytes = 32 * trunk_stride;
@@ -38,7 +38,7 @@ template <typename T> struct HeadALoader {
         oh = rem / W; ow = rem - oh * W; pix0 = b * hw;
     }
     __device__ __forceinline__ void load(int kiter) {
-        const int e = kiter * (kChunks * ELEMS) + c * ELEMS;
+        const int e = kiter * (4 * ELEMS) + c * ELEMS;
         const int tap = e >> 6, ci = e & 63;
         const int th = (tap * 21846) >> 16, tw = tap - th * 3;
         const int ih = oh - 1 + th, iw = ow - 1 + tw;
@@ -47,11 +47,11 @@ template <typename T> struct HeadALoader {
         if (v) z = *reinterpret_cast<const u32x4*>(x + (size_t)(pix0 + ih * W + iw) * 64 + ci);
         reg = z;
     }
-    __device__ __forceinline__ void store(char* As) const { *reinterpret_cast<u32x4*>(As + r0 * kRowBytes + c * 16) = reg; }
+    __device__ __forceinline__ void store(char* As) const { *reinterpret_cast<u32x4*>(As + r0 * RowGeom<4>::bytes + c * 16) = reg; }
 };
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void heads_fused_kernel(const T* x, const T* w1, const float* scale1, const float* shift1,
+__global__ __launch_bounds__(256) void heads_fused_kernel(const T* x, const T* w1, const float* scale1, const float* shift1,
                                                                const T* w2, const float* bias2, float* out, HeadGeom g, HeadTabs tabs) {
     constexpr int BM = 64, BN = 256, WM = 1, WN = 4;
     constexpr int TS = HeadSmem<T>::trunk_stride;
@@ -68,16 +68,16 @@ __global__ __launch_bounds__(kThreads) void heads_fused_kernel(const T* x, const
     {
         constexpr int CPR = BN / ELEMS;                  // 16-byte chunks per row
         const T* src = w2 + (size_t)br * 32 * BN;
-        for (int i = tid; i < 32 * CPR; i += kThreads) {
+        for (int i = tid; i < 32 * CPR; i += 256) {
             const int r = i / CPR, cc = i - r * CPR;
             *reinterpret_cast<u32x4*>(w2s + r * TS + cc * 16) = *reinterpret_cast<const u32x4*>(src + (size_t)r * BN + cc * ELEMS);
         }
     }
 
     HeadALoader<T> al; al.init(x, g.H, g.W, g.M, m0, tid);
-    WeightLoader<T, BN> bl; bl.init(w1, br * BN, g.K_pad, tid);
+    WeightLoader<T, BN, 256, 4> bl; bl.init(w1, br * BN, g.K_pad, tid);
     f32x4 acc[4][4];
-    gemm_mainloop<T, BM, BN, WM, WN>(al, bl, g.nk, smem, acc);
+    gemm_mainloop<T, BM, BN, WM, WN, 4>(al, bl, g.nk, smem, acc);
 
     // epilogue 1: folded BN + leaky -> T -> LDS trunk tile [64][256] (wave `wave` owns columns wave*64..+64)
 #pragma unroll
@@ -134,7 +134,7 @@ template <typename T> static int launch_heads(const mfx_heads_desc* d, hipStream
     constexpr int smem = HeadSmem<T>::bytes;
     static bool attr_set = false;
     if (!attr_set) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(kThreads), smem, st, reinterpret_cast<const T*>(d->x), reinterpret_cast<const T*>(d->w1),
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, st, reinterpret_cast<const T*>(d->x), reinterpret_cast<const T*>(d->w1),
                        d->scale1, d->shift1, reinterpret_cast<const T*>(d->w2), d->bias2, d->out, g, t);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;

@@ -14,51 +14,60 @@
 
 namespace mfx {
 
-constexpr int kThreads = 256;
-constexpr int kRowBytes = 80;          // 64 B of K + 16 B pad
-constexpr int kChunks = 4;             // 16-byte chunks per row per k-iteration
+// KC = 16-byte chunks of K per tile row per k-iteration (4 -> 64 B, 8 -> 128 B); a row is padded by one
+// chunk so 16 consecutive rows land on 16 distinct 16-byte bank slots (80 B and 144 B strides both do).
+template <int KC> struct RowGeom { static constexpr int bytes = KC * 16 + 16; };
 
-template <int BM, int BN> struct TileSmem {
-    static constexpr int stage_bytes = (BM + BN) * kRowBytes;
+template <int BM, int BN, int KC = 4> struct TileSmem {
+    static constexpr int stage_bytes = (BM + BN) * RowGeom<KC>::bytes;
     static constexpr int mainloop_bytes = 2 * stage_bytes;
     static constexpr int ldc = BN + 4;
     static constexpr int epilogue_bytes = BM * ldc * 4;
     static constexpr int bytes = mainloop_bytes > epilogue_bytes ? mainloop_bytes : epilogue_bytes;
 };
 
+// epilogue / launch arguments shared by the GEMM-shaped kernels
+struct EpiArgs {
+    const float* scale; const float* shift; const void* res; void* y;
+    int ldy, ldres, Cout, act, tiles_n, K_pad, nk;
+};
+
 // Weight (B operand) loader: rows n0.. of a [N_pad][K_pad] K-contiguous matrix.
-template <typename T, int BN> struct WeightLoader {
+template <typename T, int BN, int NT = 256, int KC = 4> struct WeightLoader {
     static constexpr int ELEMS = ElemTraits<T>::ELEMS;
-    static constexpr int R = (BN + 63) / 64;
+    static constexpr int RPP = NT / KC;                 // rows covered per pass
+    static constexpr int R = (BN + RPP - 1) / RPP;
+    static constexpr int RB = RowGeom<KC>::bytes;
     const T* w; int ldk; int c, r0;
     u32x4 regs[R];
     __device__ __forceinline__ void init(const T* w_, int n0, int K_pad, int tid) {
-        c = tid & 3; r0 = tid >> 2; ldk = K_pad;
+        c = tid % KC; r0 = tid / KC; ldk = K_pad;
         w = w_ + (size_t)n0 * K_pad + c * ELEMS;
     }
     __device__ __forceinline__ void load(int kiter) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const int n = r0 + 64 * i;
-            if (BN >= 64 || n < BN)
-                regs[i] = *reinterpret_cast<const u32x4*>(w + (size_t)n * ldk + kiter * (kChunks * ELEMS));
+            const int n = r0 + RPP * i;
+            if (BN % RPP == 0 || n < BN)
+                regs[i] = *reinterpret_cast<const u32x4*>(w + (size_t)n * ldk + kiter * (KC * ELEMS));
         }
     }
     __device__ __forceinline__ void store(char* Bs) const {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const int n = r0 + 64 * i;
-            if (BN >= 64 || n < BN) *reinterpret_cast<u32x4*>(Bs + n * kRowBytes + c * 16) = regs[i];
+            const int n = r0 + RPP * i;
+            if (BN % RPP == 0 || n < BN) *reinterpret_cast<u32x4*>(Bs + n * RB + c * 16) = regs[i];
         }
     }
 };
 
 // acc[FM][FN] += A-tile x B-tile over nk k-iterations.  ALoader provides load(kiter)/store(As).
-template <typename T, int BM, int BN, int WM, int WN, typename ALoader>
-__device__ __forceinline__ void gemm_mainloop(ALoader& al, WeightLoader<T, BN>& bl, int nk, char* smem,
+template <typename T, int BM, int BN, int WM, int WN, int KC, typename ALoader>
+__device__ __forceinline__ void gemm_mainloop(ALoader& al, WeightLoader<T, BN, WM * WN * 64, KC>& bl, int nk, char* smem,
                                               f32x4 (&acc)[BM / WM / 16][BN / WN / 16]) {
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
-    constexpr int STAGE = TileSmem<BM, BN>::stage_bytes;
+    constexpr int STAGE = TileSmem<BM, BN, KC>::stage_bytes;
+    constexpr int kRowBytes = RowGeom<KC>::bytes;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int frag_off = (lane & 15) * kRowBytes + (lane >> 4) * 16;
@@ -82,15 +91,18 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, WeightLoader<T, BN>& 
         const bool more = (k + 1) < nk;
         if (more) { al.load(k + 1); bl.load(k + 1); }
 
-        u32x4 af[FM], bf[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(cur + a_off + i * 16 * kRowBytes);
+        for (int ks = 0; ks < KC / 4; ++ks) {               // 64 bytes of K per sub-step
+            u32x4 af[FM], bf[FN];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(cur + b_off + j * 16 * kRowBytes);
+            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(cur + a_off + i * 16 * kRowBytes + ks * 64);
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(cur + b_off + j * 16 * kRowBytes + ks * 64);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) mma_chunk<T>(af[i], bf[j], acc[i][j]);
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma_chunk<T>(af[i], bf[j], acc[i][j]);
+        }
 
         if (more) { al.store(nxt); bl.store(nxt + BM * kRowBytes); }
         __syncthreads();
@@ -104,6 +116,7 @@ __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[BM / WM / 16][
                                                TO* y, int ldy, int m0, int n0, int M, int Cout, int act) {
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     constexpr int LDC = TileSmem<BM, BN>::ldc;
+    constexpr int kThreads = WM * WN * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     float* Cs = reinterpret_cast<float*>(smem);

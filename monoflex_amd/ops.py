@@ -99,7 +99,7 @@ def pack_conv(weight, dtype, scale=None, shift=None, stride=1, pad=0, act=L.ACT_
     Cout, Cin, kh, kw = weight.shape
     if not _pow2(Cin) or Cin < _elems(dtype):
         raise ValueError("pack_conv: Cin must be a power of two >= %d (got %d)" % (_elems(dtype), Cin))
-    bk = 4 * _elems(dtype)
+    bk = 8 * _elems(dtype)                      # 128 bytes of K: lets the kernel run 64- or 128-byte k-iterations
     K = kh * kw * Cin
     K_pad = _round_up(K, bk)
     cout = Cout if cout is None else cout
@@ -136,7 +136,7 @@ def pack_stem(weight, dtype, scale, shift, act=L.ACT_RELU):
     else:
         wp = w4.permute(0, 2, 3, 1).reshape(Cout, 7 * 7 * 4)
         kh, kw, Ck, dil = 7, 7, 4, 1
-    bk = 4 * _elems(dtype)
+    bk = 8 * _elems(dtype)
     K_pad = _round_up(wp.shape[1], bk)
     cp = cout_pad(Cout)
     wp = _pad_rows_cols(wp, cp, K_pad).to(dtype).contiguous()

@@ -67,16 +67,16 @@ def test_weight_packing_layouts():
     from monoflex_amd import ops
     w = torch.arange(2 * 16 * 3 * 3, dtype=torch.float32).reshape(2, 16, 3, 3)
     p = ops.pack_conv(w, torch.float32, None, None, stride=1, pad=1)
-    assert p.w.shape == (16, 144) and p.Ck == 16 and p.K_pad == 144 and p.Cout == 2
+    assert p.w.shape == (16, 160) and p.Ck == 16 and p.K_pad == 160 and p.Cout == 2      # K padded to 128 bytes
     # k = tap*Cin + c
     assert float(p.w[1, 5 * 16 + 3]) == float(w[1, 3, 1, 2])
     ws = torch.arange(16 * 3 * 7 * 7, dtype=torch.float32).reshape(16, 3, 7, 7)
     pb = ops.pack_stem(ws, torch.bfloat16, torch.ones(16), torch.zeros(16))
-    assert pb.w.shape == (16, 224) and (pb.kh, pb.kw, pb.Ck, pb.dil_w) == (7, 4, 8, 2)
+    assert pb.w.shape == (16, 256) and (pb.kh, pb.kw, pb.Ck, pb.dil_w) == (7, 4, 8, 2)
     # super tap (th=2, j=1): elements [kw=2: c0..3][kw=3: c0..3], 4th channel zero
     row = pb.w[5].float()
     base = (2 * 4 + 1) * 8
     assert float(row[base + 1]) == float(ws[5, 1, 2, 2].bfloat16()) and float(row[base + 4 + 2]) == float(ws[5, 2, 2, 3].bfloat16())
     assert float(row[base + 3]) == 0.0 and float(row[(2 * 4 + 3) * 8 + 4]) == 0.0      # pad channel, pad tap kw=7
     pf = ops.pack_stem(ws, torch.float32, torch.ones(16), torch.zeros(16))
-    assert pf.w.shape == (16, 208) and (pf.kh, pf.kw, pf.Ck, pf.dil_w) == (7, 7, 4, 1)
+    assert pf.w.shape == (16, 224) and (pf.kh, pf.kw, pf.Ck, pf.dil_w) == (7, 7, 4, 1)
