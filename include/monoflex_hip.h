@@ -152,7 +152,8 @@ typedef struct {
     const void* w2;           /* [nbranch][32][256] packed 1x1 weights (rows >= c_out zero)     */
     const float* bias2;       /* [nbranch][32]                                                   */
     float* out;               /* [M][ld_out] fp32                                                */
-    int32_t B, H, W, nbranch, K_pad, ld_out, dtype;
+    float* planar;            /* optional fp32 [B][planar_c][H*W]: branch 0's channels again, class-planar */
+    int32_t B, H, W, nbranch, K_pad, ld_out, dtype, planar_c;
     int32_t ch_off[16]; int32_t c_out[16];
 } mfx_heads_desc;
 int mfx_heads_fused(const mfx_heads_desc* d, void* stream);
@@ -160,12 +161,15 @@ int mfx_heads_fused(const mfx_heads_desc* d, void* stream);
 /* Edge fusion tail (detector_predictor.py:152-158): out[b, y, x, ch_off + c] += v[b][i][c] for the
  * first edge_len[b] border points i of image b.  v: fp32 [B][L][ldv], edge_xy: int32 [B][L][2]. */
 int mfx_edge_scatter_add(float* out, int ld_out, int ch_off, int C, const float* v, int ldv,
-                         const int32_t* edge_xy, const int32_t* edge_len, int B, int L, int H, int W, void* stream);
+                         const int32_t* edge_xy, const int32_t* edge_len, int B, int L, int H, int W,
+                         float* planar /* optional [B][C][H*W], updated too */, void* stream);
 
 /* Decode stage 1 (layers/utils.py:39-58,61-77): per (image, class) sigmoid+clamp, 3x3 max NMS, top-K.
- * hmap: fp32 [B][H*W][ld] with class logits at channels ch_off..ch_off+ncls.  Outputs [B][ncls][K].
- * Ties are broken towards the lower flat index (torch.topk leaves the order unspecified). */
-int mfx_decode_topk(const float* hmap, int ld, int ch_off, int ncls, int B, int H, int W, int K,
+ * Class logit of (image b, class c, pixel p) is hmap[b*b_stride + c*c_stride + p*p_stride] (elements): either the
+ * NHWC head map (c_stride 1, p_stride ld) or a planar (B,ncls,H*W) copy (c_stride H*W, p_stride 1: coalesced).
+ * Outputs [B][ncls][K], sorted by descending score.  Ties are broken towards the lower flat index
+ * (torch.topk leaves the order unspecified). */
+int mfx_decode_topk(const float* hmap, long b_stride, long c_stride, long p_stride, int ncls, int B, int H, int W, int K,
                     float* scores, int32_t* index, void* stream);
 
 /* Decode stage 2 (layers/utils.py:88-100,120-145; detector_infer.py:96-232; anno_encoder.py:69-295):

@@ -19,69 +19,120 @@ __device__ __forceinline__ float sigmoid_clamp(float x) {          // layers/uti
 // (value desc, index asc) ordering; ties go to the lower flat index
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
-// One workgroup per (class, image).  Scores live in LDS; K rounds of block-wide arg-max extraction.
-__global__ __launch_bounds__(kTopkThreads) void decode_topk_kernel(const float* hmap, int ld, int ch_off, int H, int W, int K,
-                                                                    float* scores, int* index) {
+// Exact k-th-largest selection by radix histograms over LDS-resident keys.
+// Among the elements p in [0,n) with `pred(p)`, returns the key of rank `need` (1 = largest) and writes how many
+// of the elements EQUAL to that key belong to the top `need` into *take_eq.  keys are < 2^32, examined in
+// three digit levels (12 + 10 + 10 bits).  One workgroup; hist has 4096 ints; sh[0..1] is scratch.
+template <class KeyF, class PredF>
+__device__ uint32_t select_kth(KeyF key, PredF pred, int n, int need, int* hist, int* sh, int* take_eq) {
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int shifts[3] = {20, 10, 0}, nbits[3] = {12, 10, 10};
+    uint32_t prefix = 0;
+    for (int lev = 0; lev < 3; ++lev) {
+        const int nb = 1 << nbits[lev], sft = shifts[lev];
+        for (int i = tid; i < nb; i += nthreads) hist[i] = 0;
+        __syncthreads();
+        for (int p = tid; p < n; p += nthreads) {
+            if (!pred(p)) continue;
+            const uint32_t k = key(p);
+            const bool match = lev == 0 || (k >> (sft + nbits[lev])) == prefix;
+            if (match) atomicAdd(&hist[(k >> sft) & (nb - 1)], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {                                   // one wave walks the bins from the top
+            const int per = nb / 64;
+            int local = 0;
+            for (int j = 0; j < per; ++j) local += hist[lane * per + j];
+            int incl = local;                             // inclusive suffix sum over lanes (lane 63 = highest bins)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_down(incl, off);
+                if (lane + off < 64) incl += v;
+            }
+            const int excl = incl - local;
+            if (incl >= need && excl < need) {            // exactly one lane owns the bin
+                int c = excl, bsel = lane * per;
+                for (int j = per - 1; j >= 0; --j) {
+                    const int h = hist[lane * per + j];
+                    if (c + h >= need) { bsel = lane * per + j; break; }
+                    c += h;
+                }
+                sh[0] = bsel; sh[1] = need - c;           // remaining rank inside the chosen bin
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << nbits[lev]) | (uint32_t)sh[0];
+        need = sh[1];
+        __syncthreads();
+    }
+    *take_eq = need;
+    return prefix;
+}
+
+// One workgroup per (class, image): sigmoid/clamp + 3x3 NMS into LDS, exact top-K by radix selection
+// (ties toward the lower flat index), rank-sort of the K winners.
+__global__ __launch_bounds__(kTopkThreads) void decode_topk_kernel(const float* hmap, long b_stride, long c_stride, long p_stride,
+                                                                    int H, int W, int K, float* scores, int* index) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* nm = reinterpret_cast<float*>(smem_raw);                // [H*W] heat after NMS
-    __shared__ float red_v[kTopkThreads / 64];
-    __shared__ int red_i[kTopkThreads / 64];
-    __shared__ int win_i;
+    float* nm = reinterpret_cast<float*>(smem_raw);                // [H*W]: logits, then heat after NMS
+    __shared__ int hist[4096];
+    __shared__ int sh[2];
+    __shared__ int cnt;
+    __shared__ float cand_v[256];
+    __shared__ int cand_i[256];
     const int cls = blockIdx.x, b = blockIdx.y, ncls = gridDim.x, HW = H * W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* src = hmap + (size_t)b * HW * ld + ch_off + cls;
-    // nms_hm: keep where the 3x3 max-pool (implicit -inf padding) equals the value (plateaus survive).
-    // Neighbour heats are recomputed from the logits (L2-resident) so LDS holds one map only.
-    for (int p = tid; p < HW; p += kTopkThreads) {
+    const int tid = threadIdx.x;
+    const float* src = hmap + (size_t)b * b_stride + (size_t)cls * c_stride;
+    // stage the class logits in LDS: one global read per pixel (contiguous when the map is planar)
+    for (int p = tid; p < HW; p += kTopkThreads) nm[p] = src[(size_t)p * p_stride];
+    __syncthreads();
+    // nms_hm (layers/utils.py:45-58): keep where the 3x3 max-pool equals the value (plateaus survive).
+    // sigmoid/clamp is monotone: compare logits, evaluate the heat only to decide ties after rounding/clamping.
+    unsigned long long keepmask = 0ull;                           // this thread's pixels p = tid + i*1024, i < 64
+    int i = 0;
+    for (int p = tid; p < HW; p += kTopkThreads, ++i) {
         const int y = p / W, x = p - y * W;
-        const float v = sigmoid_clamp(src[(size_t)p * ld]);
-        float mx = v;
+        const float xv = nm[p];
+        float xm = -3.0e38f;
         for (int dy = -1; dy <= 1; ++dy) {
             const int yy = y + dy;
             if (yy < 0 || yy >= H) continue;
             for (int dx = -1; dx <= 1; ++dx) {
                 const int xx = x + dx;
                 if (xx < 0 || xx >= W || (dx == 0 && dy == 0)) continue;
-                mx = fmaxf(mx, sigmoid_clamp(src[(size_t)(yy * W + xx) * ld]));
+                xm = fmaxf(xm, nm[yy * W + xx]);
             }
         }
-        nm[p] = (mx == v) ? v : 0.f;
+        const bool keep = xv >= xm || sigmoid_clamp(xv) == sigmoid_clamp(xm);
+        keepmask |= (unsigned long long)(keep ? 1 : 0) << i;
     }
     __syncthreads();
-    // thread-local best over its strided elements
-    float bv = -1.f; int bi = 0x7fffffff;
-    for (int p = tid; p < HW; p += kTopkThreads) { const float v = nm[p]; if (better(v, p, bv, bi)) { bv = v; bi = p; } }
-    for (int k = 0; k < K; ++k) {
-        float v = bv; int i = bi;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(v, off); const int oi = __shfl_xor(i, off);
-            if (better(ov, oi, v, i)) { v = ov; i = oi; }
+    i = 0;
+    for (int p = tid; p < HW; p += kTopkThreads, ++i) nm[p] = ((keepmask >> i) & 1ull) ? sigmoid_clamp(nm[p]) : 0.f;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    // K-th largest heat T; take_eq = how many of the elements equal to T are in the top K
+    int take_eq = 0;
+    const uint32_t T = select_kth([&](int p) { return __float_as_uint(nm[p]); }, [&](int) { return true; }, HW, K, hist, sh, &take_eq);
+    // among the elements equal to T keep the take_eq lowest flat indices: k-th largest of (HW-1-p)
+    int dummy = 0;
+    const uint32_t I = select_kth([&](int p) { return (uint32_t)(HW - 1 - p); },
+                                  [&](int p) { return __float_as_uint(nm[p]) == T; }, HW, take_eq, hist, sh, &dummy);
+    for (int p = tid; p < HW; p += kTopkThreads) {
+        const uint32_t kb = __float_as_uint(nm[p]);
+        if (kb > T || (kb == T && (uint32_t)(HW - 1 - p) >= I)) {
+            const int slot = atomicAdd(&cnt, 1);
+            if (slot < 256) { cand_v[slot] = nm[p]; cand_i[slot] = p; }
         }
-        if (lane == 0) { red_v[wave] = v; red_i[wave] = i; }
-        __syncthreads();
-        if (wave == 0) {
-            float v2 = lane < kTopkThreads / 64 ? red_v[lane] : -2.f;
-            int i2 = lane < kTopkThreads / 64 ? red_i[lane] : 0x7fffffff;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) {
-                const float ov = __shfl_xor(v2, off); const int oi = __shfl_xor(i2, off);
-                if (better(ov, oi, v2, i2)) { v2 = ov; i2 = oi; }
-            }
-            if (lane == 0) {
-                win_i = i2;
-                scores[((size_t)b * ncls + cls) * K + k] = v2;
-                index[((size_t)b * ncls + cls) * K + k] = i2;
-            }
-        }
-        __syncthreads();
-        const int wi = win_i;
-        if (wi < HW && (wi % kTopkThreads) == tid) {       // owner removes the winner and rescans its elements
-            nm[wi] = -1.f;
-            bv = -1.f; bi = 0x7fffffff;
-            for (int p = tid; p < HW; p += kTopkThreads) { const float v3 = nm[p]; if (better(v3, p, bv, bi)) { bv = v3; bi = p; } }
-        }
-        // win_i / red_* are rewritten only after the next round's first barrier -> no extra barrier needed
+    }
+    __syncthreads();
+    const int n = cnt < K ? cnt : K;                      // == K by construction
+    if (tid < n) {
+        const float v = cand_v[tid]; const int i = cand_i[tid];
+        int rank = 0;
+        for (int u = 0; u < n; ++u) rank += better(cand_v[u], cand_i[u], v, i) ? 1 : 0;
+        scores[((size_t)b * ncls + cls) * K + rank] = v;
+        index[((size_t)b * ncls + cls) * K + rank] = i;
     }
 }
 
@@ -200,18 +251,18 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(const float* hmap, in
 }  // namespace mfx
 using namespace mfx;
 
-extern "C" int mfx_decode_topk(const float* hmap, int ld, int ch_off, int ncls, int B, int H, int W, int K,
+extern "C" int mfx_decode_topk(const float* hmap, long b_stride, long c_stride, long p_stride, int ncls, int B, int H, int W, int K,
                                float* scores, int32_t* index, void* stream) {
     if (!hmap || !scores || !index) return mfx_fail(MFX_ERR_ARG, "decode_topk: null pointer");
-    if (K < 1 || K > H * W) return mfx_fail(MFX_ERR_ARG, "decode_topk: need 1 <= K <= H*W");
+    if (K < 1 || K > H * W || K > 256) return mfx_fail(MFX_ERR_ARG, "decode_topk: need 1 <= K <= min(H*W, 256)");
     const size_t smem = (size_t)H * W * sizeof(float);
-    if (smem > 150 * 1024) return mfx_fail(MFX_ERR_UNSUPPORTED, "decode_topk: heat map larger than LDS (H*W <= 38400)");
+    if (smem > 136 * 1024) return mfx_fail(MFX_ERR_UNSUPPORTED, "decode_topk: heat map larger than LDS (H*W <= 34816)");
     if (B * ncls == 0) return MFX_OK;
     auto k = decode_topk_kernel;
     static size_t attr_smem = 0;
     if (smem > attr_smem) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr_smem = smem; }
     hipLaunchKernelGGL(k, dim3(ncls, B), dim3(kTopkThreads), smem, reinterpret_cast<hipStream_t>(stream),
-                       hmap, ld, ch_off, H, W, K, scores, index);
+                       hmap, b_stride, c_stride, p_stride, H, W, K, scores, index);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

@@ -12,7 +12,7 @@
 
 namespace mfx {
 
-struct HeadGeom { int H, W, M, K_pad, nk, nbranch, ld_out; };
+struct HeadGeom { int H, W, M, K_pad, nk, nbranch, ld_out, planar_c; float* planar; };
 struct HeadTabs { int ch_off[16]; int c_out[16]; };
 
 template <typename T> struct HeadSmem {
@@ -118,7 +118,13 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const T* x, const T* w
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wave * 16 + (lane >> 4) * 4 + r;
-                if (m < g.M) out[(size_t)m * g.ld_out + co + n] = o[j][r] + bias;
+                if (m < g.M) {
+                    out[(size_t)m * g.ld_out + co + n] = o[j][r] + bias;
+                    if (br == 0 && g.planar && n < g.planar_c) {      // class-planar copy for the top-K kernel
+                        const int hw = g.H * g.W, bi = m / hw;
+                        g.planar[((size_t)bi * g.planar_c + n) * hw + (m - bi * hw)] = o[j][r] + bias;
+                    }
+                }
             }
         }
     }
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const T* x, const T* w
 template <typename T> static int launch_heads(const mfx_heads_desc* d, hipStream_t st) {
     HeadGeom g; g.H = d->H; g.W = d->W; g.M = d->B * d->H * d->W; g.K_pad = d->K_pad;
     g.nk = d->K_pad / (4 * ElemTraits<T>::ELEMS); g.nbranch = d->nbranch; g.ld_out = d->ld_out;
+    g.planar = d->planar; g.planar_c = d->planar_c;
     HeadTabs t;
     for (int i = 0; i < 16; ++i) { t.ch_off[i] = d->ch_off[i]; t.c_out[i] = d->c_out[i]; }
     const int tiles = ((g.M + 63) / 64) * d->nbranch;

@@ -141,14 +141,16 @@ __global__ void pack_image_kernel(const float* x, T* y, int B, int H, int W, int
 
 // ---- edge fusion tail: add the fused edge outputs back at the border pixels ----------------------
 __global__ void edge_scatter_add_kernel(float* out, int ld_out, int ch_off, int C, const float* v, int ldv,
-                                        const int* edge_xy, const int* edge_len, int B, int L, int H, int W) {
+                                        const int* edge_xy, const int* edge_len, int B, int L, int H, int W, float* planar) {
     const int total = B * L * C;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int c = i % C, j = (i / C) % L, b = i / (C * L);
         if (j >= edge_len[b]) continue;
         const int x = edge_xy[(b * L + j) * 2], y = edge_xy[(b * L + j) * 2 + 1];
         // indices of the first edge_len points are unique -> plain read-modify-write
-        out[((size_t)(b * H + y) * W + x) * ld_out + ch_off + c] += v[(size_t)(b * L + j) * ldv + c];
+        const float add = v[(size_t)(b * L + j) * ldv + c];
+        out[((size_t)(b * H + y) * W + x) * ld_out + ch_off + c] += add;
+        if (planar) planar[((size_t)b * C + c) * H * W + y * W + x] += add;
     }
 }
 
@@ -219,12 +221,13 @@ extern "C" int mfx_pack_image_nhwc4(const float* x, void* y, int B, int H, int W
 }
 
 extern "C" int mfx_edge_scatter_add(float* out, int ld_out, int ch_off, int C, const float* v, int ldv,
-                                    const int32_t* edge_xy, const int32_t* edge_len, int B, int L, int H, int W, void* stream) {
+                                    const int32_t* edge_xy, const int32_t* edge_len, int B, int L, int H, int W,
+                                    float* planar, void* stream) {
     if (!out || !v || !edge_xy || !edge_len) return mfx_fail(MFX_ERR_ARG, "edge_scatter_add: null pointer");
     const int total = B * L * C;
     if (total == 0) return MFX_OK;
     hipLaunchKernelGGL(edge_scatter_add_kernel, MFX_GRID(total, 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       out, ld_out, ch_off, C, v, ldv, edge_xy, edge_len, B, L, H, W);
+                       out, ld_out, ch_off, C, v, ldv, edge_xy, edge_len, B, L, H, W, planar);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

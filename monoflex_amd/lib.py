@@ -44,9 +44,9 @@ class DcnDesc(ctypes.Structure):
 
 class HeadsDesc(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("w1", c_void_p), ("scale1", c_void_p), ("shift1", c_void_p), ("w2", c_void_p),
-                ("bias2", c_void_p), ("out", c_void_p),
+                ("bias2", c_void_p), ("out", c_void_p), ("planar", c_void_p),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("nbranch", c_int), ("K_pad", c_int), ("ld_out", c_int),
-                ("dtype", c_int), ("ch_off", c_int * 16), ("c_out", c_int * 16)]
+                ("dtype", c_int), ("planar_c", c_int), ("ch_off", c_int * 16), ("c_out", c_int * 16)]
 
 
 # every symbol include/monoflex_hip.h declares: name -> (restype, argtypes)
@@ -67,8 +67,8 @@ SYMBOLS = {
     "mfx_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_pack_image_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_heads_fused": (_I, [ctypes.POINTER(HeadsDesc), _P]),
-    "mfx_edge_scatter_add": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
-    "mfx_decode_topk": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mfx_edge_scatter_add": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "mfx_decode_topk": (_I, [_P, ctypes.c_long, ctypes.c_long, ctypes.c_long, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mfx_decode_boxes": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P]),
 }
 

@@ -41,7 +41,7 @@ class KeypointDetector(nn.Module):
     def detect_device(self, images, edge_indices, edge_lens, pad, calib, size):
         feat = self.backbone.forward_nhwc(images)
         hm = self.heads.predictor.forward_nhwc(feat, edge_indices, edge_lens)
-        det, topk, valid = self.heads.post_processor.decode_device(hm, pad, calib, size)
+        det, topk, valid = self.heads.post_processor.decode_device(hm, pad, calib, size, self.heads.predictor.last_cls_planar)
         return det, topk, valid, hm
 
     def device_targets(self, targets, device):

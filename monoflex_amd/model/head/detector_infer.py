@@ -51,15 +51,15 @@ class PostProcessor(nn.Module):
         size = torch.tensor(list(targets[0].size), dtype=torch.int32, device=device)
         return pad.contiguous(), calib.contiguous(), size
 
-    def decode_device(self, hm, pad, calib, size):
+    def decode_device(self, hm, pad, calib, size, cls_planar=None):
         """hm fp32 (B,H,W,64) -> det (B,K,14), topk (B,K,5) [score, flat index, cls, y, x], valid (B,K) int32."""
-        scores, index = ops.decode_topk(hm, 0, self.num_classes, self.max_detection)
+        scores, index = ops.decode_topk(hm, 0, self.num_classes, self.max_detection, planar=cls_planar)
         return ops.decode_boxes(hm, REG_OFF, scores, index, calib, pad, size, float(self.det_threshold))
 
     def forward(self, predictions, targets, features=None, test=False, refine_module=None):
         hm = predictions['hm_nhwc']
         pad, calib, size = self.prepare_targets(targets, hm.device)
-        det, topk, valid = self.decode_device(hm, pad, calib, size)
+        det, topk, valid = self.decode_device(hm, pad, calib, size, predictions.get('cls_planar'))
         keep = valid.bool()
         results = [det[b][keep[b]] for b in range(det.shape[0])]          # host sync, as detector_infer.py:106
         vis_scores = [topk[b][keep[b], 0] for b in range(det.shape[0])]

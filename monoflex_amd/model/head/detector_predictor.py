@@ -156,7 +156,8 @@ class _predictor(nn.Module):
         edge fusion), [8:58] the 50 regression channels.  edge_indices int32 (B,L,2) (x,y), edge_lens int32 (B,)."""
         _eval_only(self)
         p = self._pack(features.dtype)
-        hm = ops.heads_fused(features, p)
+        hm, planar = ops.heads_fused(features, p, planar_classes=self.num_classes)
+        self.last_cls_planar = planar                               # (B,3,H*W) class logits for the top-K kernel
         if self.enable_edge_fusion:
             if edge_indices is None:
                 raise ValueError("edge fusion is enabled: targets must carry edge_indices / edge_len")
@@ -171,7 +172,7 @@ class _predictor(nn.Module):
             for bi, (pk1, pk2, cout, choff) in enumerate(p.edge_branches):
                 f1 = ops.conv2d(trunk, pk1, x_ch_off=bi * self.head_conv)                  # (B,1,L,256)
                 o = ops.conv2d(f1, pk2, out_dtype=torch.float32)                           # (B,1,L,4) fp32
-                ops.edge_scatter_add(hm, choff, cout, o, edge_indices, edge_lens)
+                ops.edge_scatter_add(hm, choff, cout, o, edge_indices, edge_lens, planar=planar if choff == 0 else None)
         return hm
 
     def forward(self, features, targets):
@@ -180,7 +181,7 @@ class _predictor(nn.Module):
         ei, el = stack_edge_fields(targets, x.device)
         hm = self.forward_nhwc(x, ei, el)
         cls = torch.sigmoid(hm[..., :self.num_classes]).clamp(min=1e-4, max=1 - 1e-4).permute(0, 3, 1, 2)
-        return {'cls': cls, 'reg': hm[..., REG_OFF:REG_OFF + 50].permute(0, 3, 1, 2), 'hm_nhwc': hm}
+        return {'cls': cls, 'reg': hm[..., REG_OFF:REG_OFF + 50].permute(0, 3, 1, 2), 'hm_nhwc': hm, 'cls_planar': self.last_cls_planar}
 
 
 def stack_edge_fields(targets, device):

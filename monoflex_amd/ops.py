@@ -304,35 +304,43 @@ class PackedHeads:
     ld_out: int
 
 
-def heads_fused(x, p: PackedHeads):
+def heads_fused(x, p: PackedHeads, planar_classes=0):
+    """-> (head map fp32 (B,H,W,ld_out), class-planar logits (B,planar_classes,H*W) or None)."""
     _need_cuda(x)
     B, H, W, C = x.shape
     assert C == 64
-    out = torch.zeros((B, H, W, p.ld_out), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, H, W, p.ld_out), dtype=torch.float32, device=x.device)
+    planar = torch.empty((B, planar_classes, H * W), dtype=torch.float32, device=x.device) if planar_classes else None
     d = L.HeadsDesc()
+    d.planar, d.planar_c = (planar.data_ptr() if planar is not None else None), planar_classes
     d.x, d.w1, d.scale1, d.shift1 = x.data_ptr(), p.w1.data_ptr(), p.scale1.data_ptr(), p.shift1.data_ptr()
     d.w2, d.bias2, d.out = p.w2.data_ptr(), p.bias2.data_ptr(), out.data_ptr()
     d.B, d.H, d.W, d.nbranch, d.K_pad, d.ld_out, d.dtype = B, H, W, len(p.c_out), p.K_pad, p.ld_out, _dt(x.dtype)
     for i, (o, c) in enumerate(zip(p.ch_off, p.c_out)):
         d.ch_off[i], d.c_out[i] = o, c
     L.check(L.load().mfx_heads_fused(ctypes.byref(d), _stream()), "mfx_heads_fused")
-    return out
+    return out, planar
 
 
-def edge_scatter_add(out, ch_off, C, v, edge_xy, edge_len):
-    _need_cuda(out, v, edge_xy, edge_len)
+def edge_scatter_add(out, ch_off, C, v, edge_xy, edge_len, planar=None):
+    _need_cuda(out, v, edge_xy, edge_len, planar)
     B, H, W, ld = out.shape
     Lmax = edge_xy.shape[1]
     L.check(L.load().mfx_edge_scatter_add(_ptr(out), ld, ch_off, C, _ptr(v), v.shape[-1], _ptr(edge_xy), _ptr(edge_len),
-                                          B, Lmax, H, W, _stream()), "mfx_edge_scatter_add")
+                                          B, Lmax, H, W, _ptr(planar), _stream()), "mfx_edge_scatter_add")
 
 
-def decode_topk(hmap, ch_off, ncls, K):
-    _need_cuda(hmap)
+def decode_topk(hmap, ch_off, ncls, K, planar=None):
+    """Per-(image,class) NMS + top-K.  Reads the class-planar logits when given (coalesced), else the NHWC map."""
+    _need_cuda(hmap, planar)
     B, H, W, ld = hmap.shape
     scores = torch.empty((B, ncls, K), dtype=torch.float32, device=hmap.device)
     index = torch.empty((B, ncls, K), dtype=torch.int32, device=hmap.device)
-    L.check(L.load().mfx_decode_topk(_ptr(hmap), ld, ch_off, ncls, B, H, W, K, _ptr(scores), _ptr(index), _stream()),
+    if planar is not None:
+        src, bs, cs, ps = planar.data_ptr(), ncls * H * W, H * W, 1
+    else:
+        src, bs, cs, ps = hmap.data_ptr() + 4 * ch_off, H * W * ld, 1, ld
+    L.check(L.load().mfx_decode_topk(ctypes.c_void_p(src), bs, cs, ps, ncls, B, H, W, K, _ptr(scores), _ptr(index), _stream()),
             "mfx_decode_topk")
     return scores, index
 

@@ -258,6 +258,7 @@ def test_heads_fused_vs_torch(dtype):
     with torch.no_grad():
         maps = ref(x, ei, el, taps)
     hm = m.forward_nhwc(_to_nhwc(x, dtype), ei.to(DEV, torch.int32), el.to(DEV, torch.int32)).cpu()
+    assert torch.equal(m.last_cls_planar.cpu().view(2, 3, 24, 40), hm[..., :3].permute(0, 3, 1, 2))   # planar copy stays in sync
     got_cls = hm[..., :3].permute(0, 3, 1, 2)
     got_reg = hm[..., REG_OFF:REG_OFF + 50].permute(0, 3, 1, 2)
     tol = 1e-4 if dtype == torch.float32 else 5e-2

@@ -30,7 +30,7 @@ def test_ctypes_struct_layout_matches_header_sizes():
     assert ctypes.sizeof(L.ConvDesc) == 7 * 8 + 22 * 4
     assert ctypes.sizeof(L.DcnDesc) == 6 * 8 + 17 * 4 + 4        # tail padding to 8
     assert ctypes.sizeof(L.CatDesc) == 9 * 8 + 18 * 4 + 2 * 4 + 5 * 8 + 8 * 4
-    assert ctypes.sizeof(L.HeadsDesc) == 7 * 8 + 7 * 4 + 32 * 4 + 4
+    assert ctypes.sizeof(L.HeadsDesc) == 8 * 8 + 8 * 4 + 32 * 4
 
 
 def test_reference_yaml_drives_the_config():

@@ -76,9 +76,9 @@ def d_dcn(y, x, om, p):
     return ("dcn %d -> %d  M=%d" % (x.shape[-1], p.Cout, M), 2.0 * M * p.Cout_pad * p.K_pad, nbytes(x, y, om, p.w))
 
 
-def d_heads(y, x, p):
+def d_heads(y, x, p, **k):
     M = x.numel() // 64
-    return ("heads fused M=%d" % M, 2.0 * M * 9 * (256 * 576 + 32 * 256), nbytes(x, y))
+    return ("heads fused M=%d" % M, 2.0 * M * 9 * (256 * 576 + 32 * 256), nbytes(x, y[0]))
 
 
 def d_mem(name):
