@@ -1,128 +1,216 @@
-// Fused detection heads (reference model/head/detector_predictor.py:47-96,125-134).
+// Fused detection heads (reference model/head/detector_predictor.py:47-96,125-134):
+// nine branches of  conv3x3 64->256 (no bias) -> BN + leaky_relu(0.01) -> conv1x1 256->c_k (+bias).
 //
-// One workgroup = 64 output pixels x one branch:
-//   GEMM1  trunk[64][256] = im2col3x3(feature)[64][576] x W1_b[256][576]^T      (MFMA, shared main loop)
-//   epi1   BN (folded) + leaky_relu(0.01) -> element type T, kept in LDS only
-//   GEMM2  out[64][<=32] = trunk[64][256] x W2_b[32][256]^T + bias              (MFMA from LDS)
-// The nine 256-channel trunk maps (71 M elements per image in the reference) never touch HBM;
-// only 3 + 50 fp32 channels per pixel are written.
+// One workgroup (4 waves) owns an 8 x 16 block of output pixels of one image and runs ALL branches:
+//   * the 10 x 18 x 64-channel input halo patch is staged in LDS once (pixel stride 64*sizeof(T)+16 bytes:
+//     conflict-free ds_read_b128) and reused by the 9 branches x 9 taps x 4 waves;
+//   * wave wn owns trunk channels [64wn, 64wn+64) of the current branch for all 128 pixels.  GEMM1 runs
+//     "transposed" -- weights are the MFMA A operand, pixels the B operand -- so a lane ends up holding 4
+//     consecutive trunk channels of one pixel;  weights are pre-packed fragment-major (each wave-load is one
+//     contiguous KiB) and streamed L2 -> registers through a 3-deep ring: no LDS, no barrier in the K loop;
+//   * BN + leaky are applied in registers and the accumulators are fed STRAIGHT into GEMM2 as its B operand
+//     (the K order inside a k-block is permuted identically in the pre-packed 1x1 weights), so the nine
+//     256-channel trunk maps (71 M elements per image in the reference) touch neither HBM nor LDS;
+//   * the four waves' partial 1x1 sums (over their 64 trunk channels each) are written to per-wave LDS slices
+//     with conflict-free ds_write_b128 and summed by all waves (each takes 32 pixels): two barriers per branch,
+//     no atomics (ds_add_f32 with this access pattern kept the LDS 72 % busy, profiles/r01_*).
+// Only 3 + 50 fp32 channels per pixel are written.
 #include "../../include/monoflex_hip.h"
 #include "err.h"
 #include "igemm.h"
 
 namespace mfx {
 
-struct HeadGeom { int H, W, M, K_pad, nk, nbranch, ld_out, planar_c; float* planar; };
+constexpr int kHeadC = 64, kHeadTrunk = 256, kHeadRows = 8, kHeadWaves = 4, kHeadFN = 4;
+
+struct HeadGeom {
+    int B, H, W, tiles_x, tiles_y, nbranch, ld_out, planar_c, steps;
+    float* planar;
+};
 struct HeadTabs { int ch_off[16]; int c_out[16]; };
 
 template <typename T> struct HeadSmem {
-    static constexpr int BM = 64, BN = 256;
-    static constexpr int trunk_stride = BN * (int)sizeof(T) + 16;         // bytes; == 16 mod 256 -> conflict-free b128 reads
-    static constexpr int main_bytes = TileSmem<BM, BN, 4>::mainloop_bytes;   // 51200
-    static constexpr int trunk_bytes = BM * trunk_stride;
-    static constexpr int region0 = main_bytes > trunk_bytes ? main_bytes : trunk_bytes;   // main loop stages, then trunk
-    static constexpr int w2_bytes = 32 * trunk_stride;
-    static constexpr int bytes = region0 + w2_bytes;
+    static constexpr int PS = kHeadC * (int)sizeof(T) + 16;
+    static constexpr int patch_bytes = (kHeadRows + 2) * 18 * PS;
+    static constexpr int red_ld = 20;                                   // fp32 words per pixel row of a partial-sum slice (16 + pad)
+    static constexpr int red_bytes = kHeadRows * 16 * red_ld * 4;       // one wave's slice: [128 px][20]
+    static constexpr int bytes = patch_bytes + kHeadWaves * red_bytes;
 };
 
-// minimal conv loader for the 3x3/s1/p1, Cin=64 feature (same scheme as ConvALoader, fixed geometry)
-template <typename T> struct HeadALoader {
-    static constexpr int ELEMS = ElemTraits<T>::ELEMS;
-    const T* x; int H, W, c, r0, oh, ow, pix0; bool ok;
-    u32x4 reg;
-    __device__ __forceinline__ void init(const T* x_, int H_, int W_, int M, int m0, int tid) {
-        x = x_; H = H_; W = W_; c = tid & 3; r0 = tid >> 2;
-        const int m = m0 + r0;
-        ok = m < M;
-        const int pm = ok ? m : 0, hw = H * W, b = pm / hw, rem = pm - b * hw;
-        oh = rem / W; ow = rem - oh * W; pix0 = b * hw;
+// trunk values of one pixel held by a lane after GEMM1 -> B-operand chunk of GEMM2
+template <typename T> struct TrunkPack;
+template <> struct TrunkPack<bf16_t> {      // k-block = 32 trunk channels = D fragments (2kb, 2kb+1): 8 values per lane
+    static constexpr int KBLK = 2;
+    __device__ static __forceinline__ u32x4 make(const float (&t)[kHeadFN][4], int kb) {
+        float v[8] = {t[2 * kb][0], t[2 * kb][1], t[2 * kb][2], t[2 * kb][3], t[2 * kb + 1][0], t[2 * kb + 1][1], t[2 * kb + 1][2], t[2 * kb + 1][3]};
+        return ElemTraits<bf16_t>::pack(v);
     }
-    __device__ __forceinline__ void load(int kiter) {
-        const int e = kiter * (4 * ELEMS) + c * ELEMS;
-        const int tap = e >> 6, ci = e & 63;
-        const int th = (tap * 21846) >> 16, tw = tap - th * 3;
-        const int ih = oh - 1 + th, iw = ow - 1 + tw;
-        const bool v = ok && tap < 9 && ih >= 0 && ih < H && iw >= 0 && iw < W;
-        u32x4 z = {0u, 0u, 0u, 0u};
-        if (v) z = *reinterpret_cast<const u32x4*>(x + (size_t)(pix0 + ih * W + iw) * 64 + ci);
-        reg = z;
+};
+template <> struct TrunkPack<float> {       // k-block = 16 trunk channels = D fragment kb: 4 values per lane
+    static constexpr int KBLK = 4;
+    __device__ static __forceinline__ u32x4 make(const float (&t)[kHeadFN][4], int kb) {
+        return ElemTraits<float>::pack(t[kb]);
     }
-    __device__ __forceinline__ void store(char* As) const { *reinterpret_cast<u32x4*>(As + r0 * RowGeom<4>::bytes + c * 16) = reg; }
 };
 
+// w1p: fragment-major 3x3 weights  [branch][wn 4][step][j 4][lane 64][16 B]
+// w2p: fragment-major 1x1 weights  [branch][wn 4][kblk][of 2][lane 64][16 B]  (K order matching TrunkPack)
 template <typename T>
-__global__ __launch_bounds__(256) void heads_fused_kernel(const T* x, const T* w1, const float* scale1, const float* shift1,
-                                                               const T* w2, const float* bias2, float* out, HeadGeom g, HeadTabs tabs) {
-    constexpr int BM = 64, BN = 256, WM = 1, WN = 4;
-    constexpr int TS = HeadSmem<T>::trunk_stride;
+__global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T* __restrict__ x, const u32x4* __restrict__ w1p,
+                                                                         const float* __restrict__ scale1, const float* __restrict__ shift1,
+                                                                         const u32x4* __restrict__ w2p, const float* __restrict__ bias2,
+                                                                         float* __restrict__ out, HeadGeom g, HeadTabs tabs) {
+    constexpr int NT = kHeadWaves * 64, FM = kHeadRows, FN = kHeadFN;
     constexpr int ELEMS = ElemTraits<T>::ELEMS;
+    constexpr int PS = HeadSmem<T>::PS;
+    constexpr int KBLK = TrunkPack<T>::KBLK;
+    constexpr int RLD = HeadSmem<T>::red_ld;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* trunk = smem;                                  // aliases the main-loop stages (used after them)
-    char* w2s = smem + HeadSmem<T>::region0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int br = tile % g.nbranch, tm = tile / g.nbranch;     // branch fastest: 9 neighbours share the A tile in L2
-    const int m0 = tm * BM;
+    char* patch = smem;
+    float* red = reinterpret_cast<float*>(smem + HeadSmem<T>::patch_bytes);      // [4 waves][128 px][20]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xl = lane & 15, kq = lane >> 4;
 
-    // stage this branch's 1x1 weights [32][256] (read after several barriers)
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = tile % g.tiles_x; tile /= g.tiles_x;
+    const int ty = tile % g.tiles_y; const int b = tile / g.tiles_y;
+    const int x0 = tx * 16, y0 = ty * kHeadRows;
+
+    // ---- halo patch (zero outside the image)
     {
-        constexpr int CPR = BN / ELEMS;                  // 16-byte chunks per row
-        const T* src = w2 + (size_t)br * 32 * BN;
-        for (int i = tid; i < 32 * CPR; i += 256) {
-            const int r = i / CPR, cc = i - r * CPR;
-            *reinterpret_cast<u32x4*>(w2s + r * TS + cc * 16) = *reinterpret_cast<const u32x4*>(src + (size_t)r * BN + cc * ELEMS);
-        }
-    }
-
-    HeadALoader<T> al; al.init(x, g.H, g.W, g.M, m0, tid);
-    WeightLoader<T, BN, 256, 4> bl; bl.init(w1, br * BN, g.K_pad, tid);
-    f32x4 acc[4][4];
-    gemm_mainloop<T, BM, BN, WM, WN, 4>(al, bl, g.nk, smem, acc);
-
-    // epilogue 1: folded BN + leaky -> T -> LDS trunk tile [64][256] (wave `wave` owns columns wave*64..+64)
+        constexpr int CPP = kHeadC * (int)sizeof(T) / 16;
+        constexpr int nchunks = (kHeadRows + 2) * 18 * CPP;
+        const T* xg = x + (size_t)b * g.H * g.W * kHeadC;
+        constexpr int PU = 4;
+        for (int base = 0; base < nchunks; base += NT * PU) {
+            u32x4 pr[PU];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = wave * 64 + j * 16 + (lane & 15);
-        const float sc = scale1[br * BN + n], sh = shift1[br * BN + n];
+            for (int u = 0; u < PU; ++u) {
+                const int idx = base + u * NT + tid;
+                const int pix = idx / CPP, ch = idx - pix * CPP;
+                const int py = pix / 18, px = pix - py * 18;
+                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                u32x4 z = {0u, 0u, 0u, 0u};
+                if (idx < nchunks && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                    z = *reinterpret_cast<const u32x4*>(xg + ((size_t)iy * g.W + ix) * kHeadC + ch * ELEMS);
+                pr[u] = z;
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = i * 16 + (lane >> 4) * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[i][j][r] * sc + sh;
-                v = v > 0.f ? v : 0.01f * v;
-                ElemTraits<T>::store(reinterpret_cast<T*>(trunk + (m + r) * TS) + n, v);
+            for (int u = 0; u < PU; ++u) {
+                const int idx = base + u * NT + tid;
+                if (idx < nchunks) *reinterpret_cast<u32x4*>(patch + (idx / CPP) * PS + (idx % CPP) * 16) = pr[u];
             }
         }
     }
     __syncthreads();
 
-    // GEMM2: wave w -> rows w*16..+16, all 32 output columns, K = 256
-    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    const char* ap = trunk + (wave * 16 + (lane & 15)) * TS + (lane >> 4) * 16;
-    const char* bp = w2s + (lane & 15) * TS + (lane >> 4) * 16;
+    const int steps = g.steps;                               // 9 * 64 / (4 * ELEMS): 18 (bf16) / 36 (f32)
+    for (int br = 0; br < g.nbranch; ++br) {
+        f32x4 acc[FM][FN];
 #pragma unroll
-    for (int kb = 0; kb < BN * (int)sizeof(T); kb += 64) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(ap + kb);
-        const u32x4 b0 = *reinterpret_cast<const u32x4*>(bp + kb);
-        const u32x4 b1 = *reinterpret_cast<const u32x4*>(bp + 16 * TS + kb);
-        mma_chunk<T>(a, b0, o[0]);
-        mma_chunk<T>(a, b1, o[1]);
-    }
-    const int cn = tabs.c_out[br], co = tabs.ch_off[br];
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = j * 16 + (lane & 15);
-        if (n < cn) {
-            const float bias = bias2[br * 32 + n];
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- GEMM1 (transposed): D[j][i] rows = trunk channel 64wn+16j+.., cols = pixel (row i, x = lane&15)
+        const u32x4* wsrc = w1p + ((size_t)(br * kHeadWaves + wn) * steps) * (FN * 64) + lane;
+        auto wfetch = [&](int s, u32x4 (&wf)[FN]) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wave * 16 + (lane >> 4) * 4 + r;
-                if (m < g.M) {
-                    out[(size_t)m * g.ld_out + co + n] = o[j][r] + bias;
-                    if (br == 0 && g.planar && n < g.planar_c) {      // class-planar copy for the top-K kernel
-                        const int hw = g.H * g.W, bi = m / hw;
-                        g.planar[((size_t)bi * g.planar_c + n) * hw + (m - bi * hw)] = o[j][r] + bias;
+            for (int j = 0; j < FN; ++j) wf[j] = wsrc[(size_t)(s * FN + j) * 64];
+        };
+        auto compute = [&](int s, const u32x4 (&wf)[FN]) {
+            const int e = s * (4 * ELEMS) + kq * ELEMS;      // this lane's K chunk -> (tap, channel)
+            const int tap = e >> 6, cl = e & 63;
+            const int th = (tap * 21846) >> 16, tw = tap - th * 3;
+            const char* ap = patch + (th * 18 + xl + tw) * PS + cl * (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const u32x4 pf = *reinterpret_cast<const u32x4*>(ap + i * 18 * PS);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma_chunk<T>(wf[j], pf, acc[i][j]);
+            }
+        };
+        u32x4 wb[3][FN];
+        wfetch(0, wb[0]);
+        wfetch(1, wb[1]);
+        for (int s = 0; s < steps; s += 3) {                 // steps is a multiple of 3 (18 / 36)
+            wfetch(s + 2, wb[2]);
+            compute(s, wb[0]);
+            if (s + 3 < steps) wfetch(s + 3, wb[0]);
+            compute(s + 1, wb[1]);
+            if (s + 4 < steps) wfetch(s + 4, wb[1]);
+            compute(s + 2, wb[2]);
+        }
+
+        // ---- BN + leaky in registers; GEMM2 straight from the accumulators
+        float sc[FN][4], sh[FN][4];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(scale1 + br * kHeadTrunk + wn * 64 + j * 16 + kq * 4);
+            const f32x4 h4 = *reinterpret_cast<const f32x4*>(shift1 + br * kHeadTrunk + wn * 64 + j * 16 + kq * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[j][r] = s4[r]; sh[j][r] = h4[r]; }
+        }
+        const int cn = tabs.c_out[br];
+        const bool two = cn > 16;                            // second 16-row output fragment needed?
+        u32x4 w2f[KBLK][2];
+        const u32x4* w2src = w2p + ((size_t)(br * kHeadWaves + wn) * KBLK) * (2 * 64) + lane;
+#pragma unroll
+        for (int kb = 0; kb < KBLK; ++kb) {
+            w2f[kb][0] = w2src[(size_t)(kb * 2 + 0) * 64];
+            w2f[kb][1] = w2src[(size_t)(kb * 2 + 1) * 64];
+        }
+        const int co = tabs.ch_off[br];
+        float* mine = red + wn * (kHeadRows * 16 * RLD);
+        // partial 1x1 outputs of this wave: po[i][of] = D2[o = 16*of + 4*kq + r][pixel (row i, x = xl)]
+        f32x4 po[FM][2];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            float t[FN][4];
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[i][j][r] * sc[j][r] + sh[j][r];
+                    t[j][r] = v > 0.f ? v : 0.01f * v;
+                }
+            po[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; po[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KBLK; ++kb) {
+                const u32x4 tb = TrunkPack<T>::make(t, kb);
+                mma_chunk<T>(w2f[kb][0], tb, po[i][0]);
+                if (two) mma_chunk<T>(w2f[kb][1], tb, po[i][1]);
+            }
+        }
+        for (int of = 0; of < (two ? 2 : 1); ++of) {         // 16 output channels per pass
+            __syncthreads();                                 // slices free (previous pass / branch fully summed)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) *reinterpret_cast<f32x4*>(mine + (i * 16 + xl) * RLD + kq * 4) = po[i][of];
+            __syncthreads();
+            // wave wn sums pixels [32wn, 32wn+32): lane -> (pixel, group of 4 outputs), 2 items per lane
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int item = it * 64 + lane;
+                const int px = wn * 32 + (item >> 2), og = item & 3;
+                f32x4 sum = *reinterpret_cast<const f32x4*>(red + px * RLD + og * 4);
+#pragma unroll
+                for (int w = 1; w < kHeadWaves; ++w) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(red + w * (kHeadRows * 16 * RLD) + px * RLD + og * 4);
+                    sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+                }
+                const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
+                if (oy < g.H && ox < g.W) {
+                    const size_t m = ((size_t)b * g.H + oy) * g.W + ox;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = of * 16 + og * 4 + r;
+                        if (o < cn) {
+                            const float res = sum[r] + bias2[br * 32 + o];
+                            out[m * g.ld_out + co + o] = res;
+                            if (br == 0 && g.planar && o < g.planar_c)
+                                g.planar[((size_t)b * g.planar_c + o) * g.H * g.W + (size_t)oy * g.W + ox] = res;
+                        }
                     }
                 }
             }
@@ -131,18 +219,20 @@ __global__ __launch_bounds__(256) void heads_fused_kernel(const T* x, const T* w
 }
 
 template <typename T> static int launch_heads(const mfx_heads_desc* d, hipStream_t st) {
-    HeadGeom g; g.H = d->H; g.W = d->W; g.M = d->B * d->H * d->W; g.K_pad = d->K_pad;
-    g.nk = d->K_pad / (4 * ElemTraits<T>::ELEMS); g.nbranch = d->nbranch; g.ld_out = d->ld_out;
-    g.planar = d->planar; g.planar_c = d->planar_c;
+    HeadGeom g;
+    g.B = d->B; g.H = d->H; g.W = d->W; g.tiles_x = (d->W + 15) / 16; g.tiles_y = (d->H + kHeadRows - 1) / kHeadRows;
+    g.nbranch = d->nbranch; g.ld_out = d->ld_out; g.planar = d->planar; g.planar_c = d->planar_c;
+    g.steps = 9 * kHeadC / (4 * ElemTraits<T>::ELEMS);
     HeadTabs t;
     for (int i = 0; i < 16; ++i) { t.ch_off[i] = d->ch_off[i]; t.c_out[i] = d->c_out[i]; }
-    const int tiles = ((g.M + 63) / 64) * d->nbranch;
+    const int tiles = g.tiles_x * g.tiles_y * d->B;
     auto k = heads_fused_kernel<T>;
     constexpr int smem = HeadSmem<T>::bytes;
     static bool attr_set = false;
-    if (!attr_set) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, st, reinterpret_cast<const T*>(d->x), reinterpret_cast<const T*>(d->w1),
-                       d->scale1, d->shift1, reinterpret_cast<const T*>(d->w2), d->bias2, d->out, g, t);
+    if (!attr_set && smem > 64 * 1024) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(kHeadWaves * 64), smem, st, reinterpret_cast<const T*>(d->x),
+                       reinterpret_cast<const u32x4*>(d->w1), d->scale1, d->shift1, reinterpret_cast<const u32x4*>(d->w2), d->bias2,
+                       d->out, g, t);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -154,8 +244,7 @@ extern "C" int mfx_heads_fused(const mfx_heads_desc* d, void* stream) {
     if (!d || !d->x || !d->w1 || !d->scale1 || !d->shift1 || !d->w2 || !d->bias2 || !d->out)
         return mfx_fail(MFX_ERR_ARG, "heads_fused: null pointer");
     if (d->nbranch < 1 || d->nbranch > 16) return mfx_fail(MFX_ERR_ARG, "heads_fused: 1..16 branches");
-    const int elems = d->dtype == MFX_BF16 ? 8 : 4;
-    if (d->K_pad % (4 * elems) != 0 || d->K_pad < 576) return mfx_fail(MFX_ERR_ARG, "heads_fused: K_pad must cover 9*64 and be a multiple of 64 bytes");
+    if (d->K_pad != 9 * kHeadC) return mfx_fail(MFX_ERR_ARG, "heads_fused: K_pad must be 576 (fragment-major packing)");
     for (int i = 0; i < d->nbranch; ++i)
         if (d->c_out[i] < 1 || d->c_out[i] > 32 || d->ch_off[i] < 0 || d->ch_off[i] + d->c_out[i] > d->ld_out)
             return mfx_fail(MFX_ERR_ARG, "heads_fused: branch output channels out of range");

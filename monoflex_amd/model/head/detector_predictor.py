@@ -103,14 +103,14 @@ class _predictor(nn.Module):
             w1.append(t[0].weight.detach().float().permute(0, 2, 3, 1).reshape(self.head_conv, -1))
             s, b = self._abn_fold(t[1])
             sc.append(s); sh.append(b)
-        bk = 4 * (4 if dtype == torch.float32 else 8)
         K = w1[0].shape[1]
-        K_pad = (K + bk - 1) // bk * bk
-        w1 = torch.cat(w1, 0)
-        if K_pad != K:
-            w1 = torch.cat((w1, w1.new_zeros(w1.shape[0], K_pad - K)), 1)
-        dev = w1.device
+        assert K == 576 and self.head_conv == 256
+        E = 4 if dtype == torch.float32 else 8
+        steps = K // (4 * E)
         nb = len(trunks)
+        dev = w1[0].device
+        # 3x3 weights, fragment-major: [branch][wave wn 4][step][frag j 4][k-group kq 4][row nl 16][E]  (lane = kq*16+nl)
+        W1 = torch.stack(w1, 0).view(nb, 4, 4, 16, steps, 4, E).permute(0, 1, 4, 2, 5, 3, 6).contiguous().to(dtype)
         w2 = torch.zeros(nb, 32, self.head_conv, device=dev)
         b2 = torch.zeros(nb, 32, device=dev)
         ch_off, c_out = [0], [self.num_classes]
@@ -127,8 +127,15 @@ class _predictor(nn.Module):
             ch_off.append(off); c_out.append(r)
             off += r
         assert off <= HM_LD
-        p = ops.PackedHeads(w1.to(dtype).contiguous(), torch.cat(sc).contiguous(), torch.cat(sh).contiguous(),
-                            w2.to(dtype).contiguous(), b2.contiguous(), K_pad, ch_off, c_out, HM_LD)
+        # 1x1 weights, fragment-major with the K order the kernel's accumulators arrive in (heads.hip TrunkPack):
+        #   bf16: [branch][wn][kb 2][of 2][g 4][o_l 16][half 2][q 4], trunk channel n = 64wn + 32kb + 16half + 4g + q
+        #   f32 : [branch][wn][kb 4][of 2][g 4][o_l 16][e 4],          n = 64wn + 16kb + 4g + e
+        if dtype == torch.float32:
+            W2 = w2.view(nb, 2, 16, 4, 4, 4, 4).permute(0, 3, 4, 1, 5, 2, 6).contiguous()
+        else:
+            W2 = w2.view(nb, 2, 16, 4, 2, 2, 4, 4).permute(0, 3, 4, 1, 6, 2, 5, 7).contiguous().to(dtype)
+        p = ops.PackedHeads(W1, torch.cat(sc).contiguous(), torch.cat(sh).contiguous(),
+                            W2, b2.contiguous(), K, ch_off, c_out, HM_LD)
         # edge fusion: trunks of the class branch and of the 3d_offset branch at the border points
         if self.enable_edge_fusion:
             oi = self.offset_index[0]
