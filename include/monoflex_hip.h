@@ -39,7 +39,7 @@ enum { MFX_OK = 0, MFX_ERR_ARG = -1, MFX_ERR_UNSUPPORTED = -2, MFX_ERR_LAUNCH = 
 int mfx_abi_version(void);
 const char* mfx_last_error(void);
 /* tuning/debug overrides: "conv_tile" | "dcn_tile" | "cat_tile" (tile id, 0 = automatic), "kc" (4 | 8 | 0),
- * "halo" (0 = generic kernel only, 1 = automatic, 2.. = force LDS-halo variant) */
+ * "halo" (0 = generic kernel only, 1 = automatic, 2.. = force LDS-halo variant), "halo_cg", "dcn_wave" (same convention) */
 int mfx_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------
@@ -82,6 +82,8 @@ int mfx_dcn_v2_backward(const float* input, const float* weight, const float* bi
 typedef struct {
     const void* x;            /* input [B][H][W][x_pixstride]                                  */
     const void* w;            /* packed weights [Cout_pad][K_pad], element type = dtype        */
+    const void* w_frag;       /* optional fragment-major copy [Cout_pad/16][K_pad/(64 B)][4 kq][16 n][16 B]: lets the
+                                 3x3/stride-1 LDS-halo kernel fetch each MFMA weight fragment as one contiguous KiB */
     const float* scale;       /* [Cout_pad] or NULL (=1)                                        */
     const float* shift;       /* [Cout_pad] or NULL (=0)                                        */
     const void* res;          /* residual [M][ldres] (element type = dtype) or NULL            */
@@ -121,6 +123,7 @@ int mfx_cat_conv1x1_nhwc(const mfx_cat_desc* d, void* stream);
  * offmask: fp32 [B*Ho*Wo][32]: ch 2k = dh, 2k+1 = dw, 18+k = mask (already sigmoided), kh*kw <= 9. */
 typedef struct {
     const void* x; const float* offmask; const void* w; const float* scale; const float* shift; void* y;
+    const void* w_frag;       /* optional fragment-major weights (see mfx_conv_desc.w_frag): enables the 2nd-generation kernel */
     int32_t B, H, W, C;       /* C: power of two >= 64 (bf16) / 16 (f32) elements                */
     int32_t kh, kw, stride, pad, dil;
     int32_t Ho, Wo, Cout, Cout_pad, K_pad, ldy, act, dtype;

@@ -40,7 +40,7 @@ template <typename T, int WN, int FN> struct HaloSmem {
 
 template <typename T, typename TO, int WN, int FN>
 __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __restrict__ x, const T* __restrict__ w,
-                                                                 HaloGeom g, EpiArgs ep) {
+                                                                 const u32x4* __restrict__ wfm, HaloGeom g, EpiArgs ep) {
     constexpr int NT = WN * 64, FM = kHaloRows;
     using SM = HaloSmem<T, WN, FN>;
     constexpr int ELEMS = ElemTraits<T>::ELEMS;
@@ -71,6 +71,33 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
     const int xl = lane & 15, kq = lane >> 4;
     const T* wrow = w + (size_t)(n0 + xl) * g.K_pad;         // this lane's weight row (fragment j adds 16 rows)
     const size_t wfrag = (size_t)16 * g.K_pad;
+    // fragment-major weights: fragment (nf, step) is one contiguous KiB, lane-linear
+    const int fsteps = g.K_pad / (4 * ELEMS);
+    const u32x4* wfl = wfm ? wfm + (size_t)(n0 >> 4) * fsteps * 64 + lane : nullptr;
+
+    // residual tile: fetched now, consumed in the epilogue (its latency hides behind the whole K loop)
+    constexpr int OE_ = ElemTraits<TO>::ELEMS;
+    constexpr int GPR_ = FN * 16 / OE_;
+    constexpr int RITEMS = (16 * GPR_ + 63) / 64;            // epilogue items per lane per output row
+    constexpr bool kResPrefetch = std::is_same<T, TO>::value && FN <= 2;
+    u32x4 rpre[kResPrefetch ? FM : 1][RITEMS];
+    if constexpr (kResPrefetch) {
+        if (ep.res) {
+            const T* res_ = reinterpret_cast<const T*>(ep.res);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int q = 0; q < RITEMS; ++q) {
+                    const int it = q * 64 + lane;
+                    const int px = it / GPR_, ng = it - px * GPR_;
+                    const int oy = y0 + i, ox = x0 + px, gn = n0 + ng * OE_;
+                    u32x4 z = {0u, 0u, 0u, 0u};
+                    if (it < 16 * GPR_ && oy < g.H && ox < g.W && gn < ep.Cout)
+                        z = *reinterpret_cast<const u32x4*>(res_ + (((size_t)b * g.H + oy) * g.W + ox) * ep.ldres + gn);
+                    rpre[i][q] = z;
+                }
+        }
+    }
 
     for (int grp = 0; grp < g.ngroups; ++grp) {
         if (grp > 0) __syncthreads();                         // every wave is done reading the previous patch
@@ -78,7 +105,7 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
         const T* xg = x + (size_t)b * g.H * g.W * g.C + grp * g.CG;
         const int nchunks = (kHaloRows + 2) * 18 * CPP;
         // batches of PU independent loads per lane (all in flight together), then the LDS writes
-        constexpr int PU = FN >= 4 ? 4 : 8;
+        constexpr int PU = FN >= 4 ? 4 : 12;
         for (int base = 0; base < nchunks; base += NT * PU) {
             u32x4 pr[PU];
 #pragma unroll
@@ -103,6 +130,20 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
         auto wfetch = [&](int s, u32x4 (&bf)[FN]) {
             const int e = s * (4 * ELEMS) + kq * ELEMS;
             const int tap = e >> g.lgCG, cl = e & (g.CG - 1);
+            if (wfl) {
+                // global K of this step's first chunk (kq = 0) -> 64-byte step index; wave-uniform
+                const int e0 = s * (4 * ELEMS);
+                const int tap0 = e0 >> g.lgCG;
+                const int st = (tap0 * g.C + grp * g.CG + (e0 & (g.CG - 1))) / (4 * ELEMS);
+                const bool ok = g.CG >= 4 * ELEMS ? tap0 < 9 : st < fsteps;     // K padding steps carry zeros / do not exist
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    u32x4 z = {0u, 0u, 0u, 0u};
+                    if (ok) z = wfl[((size_t)j * fsteps + st) * 64];
+                    bf[j] = z;
+                }
+                return;
+            }
             const T* p = wrow + tap * g.C + grp * g.CG + cl;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
@@ -169,7 +210,10 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
             for (int r = 0; r < 4; ++r) stage[((lane >> 4) * 4 + r) * LDS_ + j * 16 + xl] = acc[i][j][r] * sc[j] + sh[j];
         __builtin_amdgcn_wave_barrier();                      // same wave: DS ops complete in order
         const int oy = y0 + i;
-        for (int it = lane; it < 16 * GPR; it += 64) {
+#pragma unroll
+        for (int q = 0; q < RITEMS; ++q) {
+            const int it = q * 64 + lane;
+            if (it >= 16 * GPR) continue;
             const int px = it / GPR, ng = it - px * GPR;
             const int ox = x0 + px, gn = n0 + ng * OE;
             if (oy < g.H && ox < g.W && gn < ep.Cout) {
@@ -182,7 +226,12 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
                 }
                 if (res) {
                     const T* rp = res + gm * ep.ldres + gn;
-                    if constexpr (ElemTraits<T>::ELEMS == OE) {
+                    if constexpr (kResPrefetch) {
+                        float rv[OE];
+                        ElemTraits<T>::unpack(rpre[i][q], rv);
+#pragma unroll
+                        for (int e = 0; e < OE; ++e) v[e] += rv[e];
+                    } else if constexpr (ElemTraits<T>::ELEMS == OE) {
                         float rv[OE];
                         ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(rp), rv);
 #pragma unroll
@@ -230,7 +279,8 @@ static int launch_halo(const mfx_conv_desc* d, hipStream_t st) {
         attr_smem = smem;
     }
     const int tiles = g.tiles_n * g.tiles_x * g.tiles_y * d->B;
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(WN * 64), smem, st, reinterpret_cast<const T*>(d->x), reinterpret_cast<const T*>(d->w), g, ep);
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(WN * 64), smem, st, reinterpret_cast<const T*>(d->x), reinterpret_cast<const T*>(d->w),
+                       reinterpret_cast<const u32x4*>(d->w_frag), g, ep);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

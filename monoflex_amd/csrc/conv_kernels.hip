@@ -225,7 +225,8 @@ static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 int try_conv_halo(const mfx_conv_desc* d, hipStream_t st);   // conv_halo.hip
-extern int g_opt_halo, g_opt_halo_cg;
+extern int g_opt_halo, g_opt_halo_cg, g_opt_dcn_wave;
+int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st);      // dcn_wave.hip
 
 // tuning overrides (mfx_set_option): 0 = automatic
 int g_opt_conv_tile = 0, g_opt_dcn_tile = 0, g_opt_cat_tile = 0, g_opt_kc = 0;
@@ -321,6 +322,7 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "kc") g_opt_kc = value;
     else if (n == "halo") g_opt_halo = value;
     else if (n == "halo_cg") g_opt_halo_cg = value;
+    else if (n == "dcn_wave") g_opt_dcn_wave = value;
     else return mfx_fail(MFX_ERR_ARG, "set_option: unknown option");
     return MFX_OK;
 }
@@ -452,6 +454,10 @@ extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
     g.H = d->H; g.W = d->W; g.C = d->C; g.lgC = ilog2(d->C); g.Ho = d->Ho; g.Wo = d->Wo; g.kh = d->kh; g.kw = d->kw;
     g.inv_kw = (65536 + d->kw - 1) / d->kw; g.stride = d->stride; g.pad = d->pad; g.dil = d->dil; g.M = d->B * d->Ho * d->Wo;
     if (g.M <= 0) return MFX_OK;
+    {
+        const int h = try_dcn_wave(d, reinterpret_cast<hipStream_t>(stream));
+        if (h != 0) return h < 0 ? h : MFX_OK;
+    }
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = nullptr; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = 0;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = 1;

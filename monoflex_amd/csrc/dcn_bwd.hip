@@ -278,7 +278,7 @@ extern "C" int mfx_dcn_v2_backward(const float* input, const float* weight, cons
 
     // d(columns)[m][k] = sum_o go[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM
     mfx_conv_desc cd;
-    cd.x = go; cd.w = wT; cd.scale = nullptr; cd.shift = nullptr; cd.res = nullptr; cd.y = gcol; cd.rowmap = nullptr;
+    cd.x = go; cd.w = wT; cd.w_frag = nullptr; cd.scale = nullptr; cd.shift = nullptr; cd.res = nullptr; cd.y = gcol; cd.rowmap = nullptr;
     cd.B = 1; cd.H = 1; cd.W = g.M; cd.x_pixstride = g.Coutp; cd.Ck = g.Coutp; cd.kh = 1; cd.kw = 1; cd.stride = 1;
     cd.pad_h = 0; cd.pad_w = 0; cd.dil_w = 1; cd.Ho = 1; cd.Wo = g.M; cd.M = g.M; cd.Cout = g.Kp; cd.Cout_pad = g.Kp;
     cd.K_pad = g.Coutp; cd.ldy = g.Kp; cd.ldres = 0; cd.act = MFX_ACT_NONE; cd.dtype = MFX_F32; cd.out_dtype = MFX_F32;

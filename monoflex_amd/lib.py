@@ -17,7 +17,7 @@ c_int, c_void_p, c_float, c_size_t = ctypes.c_int32, ctypes.c_void_p, ctypes.c_f
 
 
 class ConvDesc(ctypes.Structure):
-    _fields_ = [("x", c_void_p), ("w", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("res", c_void_p),
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("w_frag", c_void_p), ("scale", c_void_p), ("shift", c_void_p), ("res", c_void_p),
                 ("y", c_void_p), ("rowmap", c_void_p),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("x_pixstride", c_int), ("Ck", c_int),
                 ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad_h", c_int), ("pad_w", c_int), ("dil_w", c_int),
@@ -35,7 +35,7 @@ class CatDesc(ctypes.Structure):
 
 class DcnDesc(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("offmask", c_void_p), ("w", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
-                ("y", c_void_p),
+                ("y", c_void_p), ("w_frag", c_void_p),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("C", c_int),
                 ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad", c_int), ("dil", c_int),
                 ("Ho", c_int), ("Wo", c_int), ("Cout", c_int), ("Cout_pad", c_int), ("K_pad", c_int),

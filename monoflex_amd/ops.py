@@ -73,6 +73,16 @@ class PackedConv:
     Cout_pad: int
     K_pad: int
     act: int
+    w_frag: Optional[torch.Tensor] = None   # fragment-major copy for the LDS-halo kernel (3x3 / stride 1)
+
+
+def fragment_major(w2d, dtype):
+    """[Cout_pad][K_pad] -> [Cout_pad/16][K_pad/(4E)][4 kq][16 n][E]: one MFMA weight fragment (16 rows x 64 bytes of K)
+    per contiguous KiB, lane (kq*16 + n) owning 16 bytes."""
+    E = _elems(dtype)
+    N, K = w2d.shape
+    assert N % 16 == 0 and K % (4 * E) == 0
+    return w2d.view(N // 16, 16, K // (4 * E), 4, E).permute(0, 2, 3, 1, 4).contiguous()
 
 
 def fold_bn(bn, conv_bias=None, cout_padded=None):
@@ -114,7 +124,8 @@ def pack_conv(weight, dtype, scale=None, shift=None, stride=1, pad=0, act=L.ACT_
         if v.numel() < cp:
             v = torch.cat((v, v.new_full((cp - v.numel(),), fill)))
         return v.contiguous()
-    return PackedConv(w2, padv(scale, 1.0), padv(shift, 0.0), kh, kw, stride, pad, pad, 1, Cin, cout, cp, K_pad, act)
+    wf = fragment_major(w2, dtype) if (kh == 3 and kw == 3 and stride == 1 and pad == 1) else None
+    return PackedConv(w2, padv(scale, 1.0), padv(shift, 0.0), kh, kw, stride, pad, pad, 1, Cin, cout, cp, K_pad, act, wf)
 
 
 # stem geometry: zero-padded NHWC4 image, 3 columns left / 5 right, 3 rows top/bottom
@@ -166,6 +177,7 @@ def conv2d(x, p: PackedConv, res=None, out_dtype=None, rowmap=None, x_channels=N
     d.x = x.data_ptr() + x_ch_off * x.element_size()
     d.w, d.scale, d.shift = p.w.data_ptr(), (p.scale.data_ptr() if p.scale is not None else None), \
         (p.shift.data_ptr() if p.shift is not None else None)
+    d.w_frag = p.w_frag.data_ptr() if p.w_frag is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.y = y.data_ptr()
     d.rowmap = rowmap.data_ptr() if rowmap is not None else None
@@ -227,6 +239,7 @@ def dcn(x, offmask, p: PackedConv):
     y = torch.empty((B, Ho, Wo, p.Cout), dtype=x.dtype, device=x.device)
     d = L.DcnDesc()
     d.x, d.offmask, d.w, d.y = x.data_ptr(), offmask.data_ptr(), p.w.data_ptr(), y.data_ptr()
+    d.w_frag = p.w_frag.data_ptr() if p.w_frag is not None else None
     d.scale = p.scale.data_ptr() if p.scale is not None else None
     d.shift = p.shift.data_ptr() if p.shift is not None else None
     d.B, d.H, d.W, d.C = B, H, W, C

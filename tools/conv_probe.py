@@ -93,6 +93,14 @@ if args.only in ("", "dcn"):
         M = B * H * W
         fl = 2.0 * M * Co * Ci * 9
         out = []
+        for wv in range(1, 9):
+            setopt("dcn_wave", wv)
+            try:
+                us = timeit(lambda: ops.dcn(x, om, p), args.reps)
+            except RuntimeError:
+                continue
+            out.append((us, "w%s" % ("auto" if wv == 1 else "V%d" % (wv - 1))))
+        setopt("dcn_wave", 0)
         for kc in (4, 8):
             setopt("kc", kc)
             for t in (0, 3, 4, 5, 6):
@@ -102,7 +110,7 @@ if args.only in ("", "dcn"):
                 except RuntimeError:
                     continue
                 out.append((us, "kc%d/%s" % (kc, TILES.get(t, "auto"))))
-        setopt("dcn_tile", 0); setopt("kc", 0)
+        setopt("dcn_tile", 0); setopt("kc", 0); setopt("dcn_wave", 1)
         out.sort()
         print("%-28s M=%-8d best %.1f us %.0f TF | " % (name, M, out[0][0], fl / out[0][0] / 1e6) +
               "  ".join("%s:%.0f" % (n, u) for u, n in out[:8]))
