@@ -79,7 +79,7 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
     constexpr int OE_ = ElemTraits<TO>::ELEMS;
     constexpr int GPR_ = FN * 16 / OE_;
     constexpr int RITEMS = (16 * GPR_ + 63) / 64;            // epilogue items per lane per output row
-    constexpr bool kResPrefetch = std::is_same<T, TO>::value && FN <= 2;
+    constexpr bool kResPrefetch = false;   // measured: the 32 extra VGPRs cost a wave of occupancy (3 -> 2 per SIMD), net loss
     u32x4 rpre[kResPrefetch ? FM : 1][RITEMS];
     if constexpr (kResPrefetch) {
         if (ep.res) {
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
         const T* xg = x + (size_t)b * g.H * g.W * g.C + grp * g.CG;
         const int nchunks = (kHaloRows + 2) * 18 * CPP;
         // batches of PU independent loads per lane (all in flight together), then the LDS writes
-        constexpr int PU = FN >= 4 ? 4 : 12;
+        constexpr int PU = FN >= 4 ? 4 : 8;
         for (int base = 0; base < nchunks; base += NT * PU) {
             u32x4 pr[PU];
 #pragma unroll

@@ -242,7 +242,8 @@ int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st) {
     // measured (tools/conv_probe.py, MI355X): every variant of both kernel generations lands within ~10 % -- the gather is
     // L1/texture-bandwidth bound (each input element is fetched ~36x; 64->64 @ B=8 moves 1.13 GB through L1 in 90 us =
     // 77 % of 64 B/clk/CU).  The 1-wave x 64-channel variant spills, so Cout = 64 stays on the first-generation kernel.
-    if (N % 128 != 0 && g_opt_dcn_wave < 2) return 0;
+    // Small maps (M/64 workgroups < 2 per CU) keep the first generation too: its 64x64 tiling has 2-4x more waves.
+    if (g_opt_dcn_wave < 2 && (N % 128 != 0 || (d->B * d->Ho * d->Wo / 64) * (N / 128) < 512)) return 0;
     int v = N % 256 == 0 ? 5 : N % 128 == 0 ? 3 : 6;
     if (g_opt_dcn_wave >= 2 && g_opt_dcn_wave - 1 <= 7 && N % bn[g_opt_dcn_wave - 1] == 0) v = g_opt_dcn_wave - 1;
     const int rc = d->dtype == MFX_F32 ? dcn_wave_variant<float>(v, d, st) : dcn_wave_variant<bf16_t>(v, d, st);
