@@ -158,6 +158,10 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r01_heads_traffic.json")       # PMC pass of the same kernel/config (rocprofv3 cannot run inside the bench)
+    if os.path.exists(tj) and args.dtype == "bf16" and B == 8:
+        traffic = json.load(open(tj))["traffic_bytes"]
     n_img = world * B * args.steps
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     achieved = HEADS_GFLOP_PER_IMG * B / heads_ms                # GFLOP / ms = TFLOP/s
@@ -172,7 +176,7 @@ def main():
                    "model_tflops_per_s": round(FWD_GFLOP_PER_IMG * n_img / elapsed / 1e3, 2),
                    "detections_last_step": int(valid.sum().item())},
         "roofline": {"kernel": "heads_fused_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                      "avg_launch_ms": round(heads_ms, 4),
                      "algorithmic_flops_per_launch": HEADS_GFLOP_PER_IMG * B * 1e9},
     }
