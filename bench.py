@@ -72,13 +72,11 @@ def cpu_baseline(sd, n_images):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from monoflex_amd import parallel
+    rank, world, local_rank = parallel.init_from_env(backend="nccl")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if args.gpus != world and rank == 0:
@@ -89,7 +87,7 @@ def main():
     lib.load()
     model, sd = build_model(args.dtype, device)
     B = args.batch
-    images = S.synthetic_images(B, 384, 1280, seed=1000 + rank * B).to(device)        # resident in HBM
+    images = S.synthetic_images(B, 384, 1280, seed=parallel.shard_seed(1000, rank, B)).to(device)   # resident in HBM
     targets = [make_test_target(S.synthetic_target(320, 96)) for _ in range(B)]
     ei, el, pad, calib, size = model.device_targets(targets, device)
 
@@ -134,10 +132,7 @@ def main():
         det, topk, valid, hm = out
         det_host = det.cpu()
 
-        if dist is not None:
-            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        rate, elapsed, n_img_total = parallel.aggregate_throughput(elapsed, B * args.steps, device=device)
 
         # ---- roofline of the dominant kernel (fused heads: 46 % of the forward FLOPs), HIP events on the launch stream
         feat = model.backbone.forward_nhwc(images)
@@ -162,7 +157,7 @@ def main():
     tj = os.path.join(ROOT, "profiles", "r01_heads_traffic.json")       # PMC pass of the same kernel/config (rocprofv3 cannot run inside the bench)
     if os.path.exists(tj) and args.dtype == "bf16" and B == 8:
         traffic = json.load(open(tj))["traffic_bytes"]
-    n_img = world * B * args.steps
+    n_img = n_img_total
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     achieved = HEADS_GFLOP_PER_IMG * B / heads_ms                # GFLOP / ms = TFLOP/s
     res = {

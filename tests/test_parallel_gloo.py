@@ -1,0 +1,52 @@
+"""N>1 path on CPU: two processes over gloo exercise the sharding and the max-over-ranks timing reduction
+bench.py uses (the data path itself has no collective: inference ranks are independent replicas)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from monoflex_amd import parallel, synthetic as S
+    r, w, lr = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    first, count = parallel.image_shard(rank, world, global_batch=5)
+    imgs = S.synthetic_images(count, 8, 16, seed=parallel.shard_seed(1000, rank, 3))
+    parallel.barrier()
+    rate, elapsed, total = parallel.aggregate_throughput(0.5 + rank, images_local=count)     # rank 1 is the slow one
+    out.put((rank, first, count, float(imgs.sum()), rate, elapsed, total))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_timing_reduction():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (_, f0, c0, s0, rate0, el0, tot0), (_, f1, c1, s1, rate1, el1, tot1) = res
+    assert (f0, c0, f1, c1) == (0, 3, 3, 2)                  # contiguous, disjoint, covers the 5 images
+    assert s0 != s1                                          # disjoint synthetic streams
+    assert el0 == el1 == 1.5 and tot0 == tot1 == 5           # max over ranks, sum over ranks
+    assert abs(rate0 - 5 / 1.5) < 1e-9 and rate0 == rate1
+
+
+def test_single_process_is_passthrough():
+    from monoflex_amd import parallel
+    assert parallel.image_shard(0, 1, 8) == (0, 8)
+    rate, el, tot = parallel.aggregate_throughput(2.0, 16)
+    assert (rate, el, tot) == (8.0, 2.0, 16)
