@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-images", type=int, default=2)
+    ap.add_argument("--cpu-baseline-images", type=int, default=6)
     return ap.parse_args()
 
 

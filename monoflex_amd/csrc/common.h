@@ -88,6 +88,22 @@ __device__ __forceinline__ float apply_act(float v, int act, int n) {
     return v;
 }
 
+// activation over one output chunk of OE channels starting at channel gn.  The DCN offset/mask conv needs a sigmoid on
+// channels 18..26 only: chunks outside that range skip the exp entirely (the epilogue is serial per wave, so 32 exp
+// per pixel cost as much as the whole K loop of a 64 -> 27 conv).
+template <int OE> __device__ __forceinline__ void apply_act_chunk(float (&v)[OE], int act, int gn) {
+    if (act == ACT_NONE) return;
+    if (act == ACT_DCN_OFFMASK) {
+        if (gn + OE <= 18 || gn >= 27) return;
+#pragma unroll
+        for (int e = 0; e < OE; ++e)
+            if (gn + e >= 18 && gn + e < 27) v[e] = 1.f / (1.f + __expf(-v[e]));
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < OE; ++e) v[e] = apply_act(v[e], act, gn + e);
+}
+
 // XCD-aware tile order: block b runs on XCD b%8 (observed, speed only); give every XCD a contiguous
 // range of tile ids so neighbouring tiles (shared halos / shared A rows) meet in one L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {

@@ -241,8 +241,7 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
                         for (int e = 0; e < OE; ++e) v[e] += ElemTraits<T>::load(rp + e);
                     }
                 }
-#pragma unroll
-                for (int e = 0; e < OE; ++e) v[e] = apply_act(v[e], ep.act, gn + e);
+apply_act_chunk<OE>(v, ep.act, gn);
                 *reinterpret_cast<u32x4*>(y + gm * ep.ldy + gn) = ElemTraits<TO>::pack(v);
             }
         }
@@ -321,7 +320,7 @@ int try_conv_halo(const mfx_conv_desc* d, hipStream_t st) {
     // 32 output channels per wave; narrow outputs on small maps split N further to get more waves in flight
     int v;
     if (N == 16) v = 1;
-    else if (N == 32) v = px_tiles >= 1024 ? 2 : 1;
+    else if (N == 32) v = px_tiles >= 256 ? 2 : 1;          // probe: BN32 wins down to 480 pixel tiles, BN16 below
     else if (N == 64) v = 6;
     else if (N % 128 == 0) {
         if (px_tiles * (N / 128) < 300) return 0;             // tiny maps (12x40): the generic 64x64 tiling has more parallelism

@@ -186,8 +186,7 @@ __global__ __launch_bounds__(WN * 64, 2) void dcn_wave_kernel(const T* __restric
                     const f32x4 t = *reinterpret_cast<const f32x4*>(stage + px * LDS_ + ng * OE + e);
                     v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
                 }
-#pragma unroll
-                for (int e = 0; e < OE; ++e) v[e] = apply_act(v[e], ep.act, gn + e);
+apply_act_chunk<OE>(v, ep.act, gn);
                 *reinterpret_cast<u32x4*>(y + (size_t)gm * ep.ldy + gn) = ElemTraits<T>::pack(v);
             }
         }

@@ -158,8 +158,7 @@ __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[BM / WM / 16][
                 for (int e = 0; e < OE; ++e) v[e] += ElemTraits<T>::load(rp + e);
             }
         }
-#pragma unroll
-        for (int e = 0; e < OE; ++e) v[e] = apply_act(v[e], act, gn + e);
+apply_act_chunk<OE>(v, act, gn);
         *reinterpret_cast<u32x4*>(y + (size_t)gm * ldy + gn) = ElemTraits<TO>::pack(v);
     }
 }
