@@ -89,10 +89,10 @@ def main():
     B = args.batch
     images = S.synthetic_images(B, 384, 1280, seed=parallel.shard_seed(1000, rank, B)).to(device)   # resident in HBM
     targets = [make_test_target(S.synthetic_target(320, 96)) for _ in range(B)]
-    ei, el, pad, calib, size = model.device_targets(targets, device)
+    tg = model.device_targets(targets, device)
 
     def step():
-        return model.detect_device(images, ei, el, pad, calib, size)
+        return model.detect_device(images, *tg)
 
     with torch.no_grad():
         for _ in range(max(args.warmup, 2)):

@@ -9,7 +9,7 @@ from ..structures.image_list import to_image_list
 from .backbone import build_backbone
 from .backbone.dla_dcn import invalidate_packs
 from .head.detector_head import bulid_head
-from .head.detector_predictor import stack_edge_fields
+from .head.detector_predictor import make_edge_rowmap, stack_edge_fields
 
 _DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
 
@@ -38,16 +38,18 @@ class KeypointDetector(nn.Module):
         return super().train(mode)
 
     # ---- device pipeline: no host sync, static shapes ------------------------------------------------
-    def detect_device(self, images, edge_indices, edge_lens, pad, calib, size):
+    def detect_device(self, images, edge_indices, edge_lens, pad, calib, size, edge_rowmap=None):
         feat = self.backbone.forward_nhwc(images)
-        hm = self.heads.predictor.forward_nhwc(feat, edge_indices, edge_lens)
+        hm = self.heads.predictor.forward_nhwc(feat, edge_indices, edge_lens, edge_rowmap)
         det, topk, valid = self.heads.post_processor.decode_device(hm, pad, calib, size, self.heads.predictor.last_cls_planar)
         return det, topk, valid, hm
 
     def device_targets(self, targets, device):
+        """Device-side view of the per-image targets: (edge_indices, edge_lens, pad, calib, size, edge_rowmap)."""
         ei, el = stack_edge_fields(targets, device)
         pad, calib, size = self.heads.post_processor.prepare_targets(targets, device)
-        return ei, el, pad, calib, size
+        pr = self.heads.predictor
+        return ei, el, pad, calib, size, make_edge_rowmap(ei, pr.output_height, pr.output_width)
 
     def forward(self, images, targets=None):
         if self.training and targets is None:

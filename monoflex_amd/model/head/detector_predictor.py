@@ -158,7 +158,7 @@ class _predictor(nn.Module):
         return p
 
     # ---- forward ---------------------------------------------------------------------------------
-    def forward_nhwc(self, features, edge_indices=None, edge_lens=None):
+    def forward_nhwc(self, features, edge_indices=None, edge_lens=None, edge_rowmap=None):
         """features (B,H,W,64) NHWC -> fp32 head map (B,H,W,64): [0:3] class logits (pre-sigmoid, after
         edge fusion), [8:58] the 50 regression channels.  edge_indices int32 (B,L,2) (x,y), edge_lens int32 (B,)."""
         _eval_only(self)
@@ -170,11 +170,8 @@ class _predictor(nn.Module):
                 raise ValueError("edge fusion is enabled: targets must carry edge_indices / edge_len")
             B, H, W, _ = features.shape
             Lmax = edge_indices.shape[1]
-            # sequence positions -1..L (replicate padding of the k=3 Conv1d) -> pixel rows
-            pos = torch.arange(-1, Lmax + 1, device=features.device).clamp(0, Lmax - 1)
-            xy = edge_indices[:, pos].long()
-            rowmap = (torch.arange(B, device=features.device).view(B, 1) * (H * W) + xy[..., 1] * W + xy[..., 0]).to(torch.int32)
-            trunk = ops.conv2d(features, p.edge_trunk, rowmap=rowmap.reshape(-1).contiguous())   # (B*(L+2), 512)
+            rowmap = edge_rowmap if edge_rowmap is not None else make_edge_rowmap(edge_indices, H, W)
+            trunk = ops.conv2d(features, p.edge_trunk, rowmap=rowmap)   # (B*(L+2), 512)
             trunk = trunk.view(B, 1, Lmax + 2, 2 * self.head_conv)
             for bi, (pk1, pk2, cout, choff) in enumerate(p.edge_branches):
                 f1 = ops.conv2d(trunk, pk1, x_ch_off=bi * self.head_conv)                  # (B,1,L,256)
@@ -189,6 +186,16 @@ class _predictor(nn.Module):
         hm = self.forward_nhwc(x, ei, el)
         cls = torch.sigmoid(hm[..., :self.num_classes]).clamp(min=1e-4, max=1 - 1e-4).permute(0, 3, 1, 2)
         return {'cls': cls, 'reg': hm[..., REG_OFF:REG_OFF + 50].permute(0, 3, 1, 2), 'hm_nhwc': hm, 'cls_planar': self.last_cls_planar}
+
+
+def make_edge_rowmap(edge_indices, H, W):
+    """int32 [B*(L+2)] pixel rows of the edge sequence positions -1..L (replicate padding of the k=3 Conv1d,
+    detector_predictor.py:111-119).  Depends on the targets only: computed once per batch, not per forward."""
+    B, Lmax = edge_indices.shape[0], edge_indices.shape[1]
+    pos = torch.arange(-1, Lmax + 1, device=edge_indices.device).clamp(0, Lmax - 1)
+    xy = edge_indices[:, pos].long()
+    rm = torch.arange(B, device=edge_indices.device).view(B, 1) * (H * W) + xy[..., 1] * W + xy[..., 0]
+    return rm.to(torch.int32).reshape(-1).contiguous()
 
 
 def stack_edge_fields(targets, device):

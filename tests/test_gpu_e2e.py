@@ -32,9 +32,9 @@ def _hip_model(cls_bias=-1.0, dtype="fp32", out_w=320, out_h=96):
 def _run(m, imgs, tgts):
     from monoflex_amd.structures.params_3d import make_test_target
     targets = [make_test_target(t) for t in tgts]
-    ei, el, pad, calib, size = m.device_targets(targets, DEV)
+    tg = m.device_targets(targets, DEV)
     with torch.no_grad():
-        det, topk, valid, hm = m.detect_device(imgs.to(DEV), ei, el, pad, calib, size)
+        det, topk, valid, hm = m.detect_device(imgs.to(DEV), *tg)
     torch.cuda.synchronize()
     return det.cpu(), topk.cpu(), valid.cpu(), hm.cpu()
 
