@@ -185,6 +185,40 @@ int mfx_decode_boxes(const float* hmap, int ld, int reg_off, const float* scores
                      const int32_t* img_size, float threshold, float* det, float* topk, int32_t* valid,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * (3) training path (reference: autograd over nn.Conv2d / BatchNorm2d / MaxPool2d / ConvTranspose2d and
+ *     `_ext.dcn_v2_backward`, driven by engine/trainer.py:116-117).  Data gradients of convolutions reuse
+ *     mfx_conv2d_nhwc with host-packed flipped/transposed weights; everything else is below.
+ * ------------------------------------------------------------------------------------------ */
+
+/* conv weight gradient dw fp32 [Cout][kh*kw][Ck] (overwritten): dw[o][tap][c] = sum_m dy[m][o] * x[pixel(m,tap)][c] */
+int mfx_conv_wgrad_nhwc(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
+                        int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
+                        int dtype, void* stream);
+/* out[c] = sum_m x[m*ld + c]  (bias gradients) */
+int mfx_colsum(const void* x, float* out, long M, int C, int ld, int dtype, void* stream);
+/* train-mode BatchNorm over [M][C]: per-channel sum and sum of squares (fp32, overwritten) */
+int mfx_bn_stats(const void* x, float* sum, float* sumsq, long M, int C, int dtype, void* stream);
+/* y = act(x*scale[c] + shift[c] (+ res)) */
+int mfx_bn_act_fwd(const void* x, const float* scale, const float* shift, const void* res, void* y,
+                   long M, int C, int act, int dtype, void* stream);
+/* backward of y = act(gamma*(x-mean)*rstd + beta (+res)) given da = dL/dy and the saved output a = y:
+ * sg[c] = sum g (= dbeta), sgx[c] = sum g*xhat (= dgamma), dx, and dres = g (optional); g = da * act'(a) */
+int mfx_bn_act_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
+                   float* sg, float* sgx, void* dx, void* dres, long M, int C, int act, int dtype, void* stream);
+int mfx_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream);
+/* depthwise deconv backward: dx (input-sized) and dw fp32 [2f*2f][C] (overwritten) */
+int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* dy, void* dx, float* dw,
+                          int B, int H, int W, int C, int f, int dtype, void* stream);
+/* up[b,2oh,2ow,:] = dy[b,oh,ow,:], zeros elsewhere (data gradient of a stride-2 conv = stride-1 conv of `up`) */
+int mfx_zero_insert2_nhwc(const void* dy, void* up, int B, int Ho, int Wo, int C, int H, int W, int dtype, void* stream);
+/* DCNv2 backward on NHWC fp32 activations (no layout transforms): see dcn_bwd.hip */
+size_t mfx_dcn_backward_nhwc_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil);
+int mfx_dcn_backward_nhwc(const float* x, const float* offmask, const float* weight, const float* dy,
+                          float* dx, float* d_offmask, float* dweight, float* dbias,
+                          int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

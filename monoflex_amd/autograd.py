@@ -1,0 +1,282 @@
+"""Differentiable NHWC operators for the training path (reference: torch autograd over nn.Conv2d, BatchNorm2d,
+MaxPool2d, ConvTranspose2d and the `_DCNv2` Function, engine/trainer.py:109-117).
+
+torch.autograd only records the graph and routes gradients; every forward and backward below runs in
+libmonoflex_hip.so.  Activations are NHWC (B,H,W,C) CUDA tensors; parameters keep the reference's shapes
+(conv OIHW, BN vectors, deconv (C,1,k,k)), so optimizers and checkpoints see the usual tensors.
+
+Gradient recipes:
+  conv      dx = conv(dy [zero-inserted when stride 2], W flipped + in/out swapped)   (forward MFMA kernels)
+            dW = mfx_conv_wgrad_nhwc, db = mfx_colsum
+  BN+act    mfx_bn_stats / mfx_bn_act_fwd / mfx_bn_act_bwd (train-mode statistics, running stats updated in place)
+  DCNv2     mfx_dcn_nhwc / mfx_dcn_backward_nhwc (offsets, modulation mask, input, weight, bias)
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import lib as L
+from . import ops
+from .ops import _dt, _ptr, _stream
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _wgrad(x, dy, kh, kw, stride, pad, Ho, Wo, Ck=None, x_pixstride=None, in_hw=None):
+    """fp32 (Cout, kh*kw, Ck) weight gradient."""
+    B, H, W, Cx = x.shape
+    if in_hw is not None:
+        H, W = in_hw
+    Ck = Ck or Cx
+    Cout = dy.shape[-1]
+    dw = torch.empty((Cout, kh * kw, Ck), dtype=torch.float32, device=x.device)
+    L.check(L.load().mfx_conv_wgrad_nhwc(_ptr(x), _ptr(dy), _ptr(dw), B, H, W, x_pixstride or Cx, Ck, kh, kw, stride, pad, pad,
+                                         Ho, Wo, Cout, Cout, _dt(x.dtype), _stream()), "mfx_conv_wgrad_nhwc")
+    return dw
+
+
+def _colsum(t):
+    C = t.shape[-1]
+    M = t.numel() // C
+    out = torch.empty(C, dtype=torch.float32, device=t.device)
+    L.check(L.load().mfx_colsum(_ptr(t), _ptr(out), M, C, C, _dt(t.dtype), _stream()), "mfx_colsum")
+    return out
+
+
+def _pad_channels(n, dtype):
+    """Output-channel padding: a power of two (>= one 16-byte chunk) so the padded map is a valid conv input."""
+    e = 4 if dtype == torch.float32 else 8
+    if n >= 64:
+        return (n + 63) // 64 * 64
+    p = e
+    while p < n:
+        p *= 2
+    return p
+
+
+class Conv2dFn(Function):
+    """y = conv2d(x, weight) (+ bias), k in {1,3}, stride in {1,2}, pad = k//2.  Output channels are padded up to a
+    multiple of the 16-byte chunk (extra channels are exactly zero); callers slice."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        x = _c(x)
+        Cout, Cin, kh, kw = weight.shape
+        cpad = _pad_channels(Cout, x.dtype)
+        p = ops.pack_conv(weight, x.dtype, None, bias, stride=stride, pad=pad, act=L.ACT_NONE, cout=cpad)
+        y = ops.conv2d(x, p)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, bias is not None, Cout)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, has_bias, Cout = ctx.cfg
+        dy = _c(dy)
+        B, H, W, Cin = x.shape
+        _, Ho, Wo, Cp = dy.shape
+        kh, kw = weight.shape[2], weight.shape[3]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # W^T flipped: (Cin, Cp, kh, kw), rows beyond Cout are zero (padded output channels carry no gradient)
+            wt = weight.detach().flip(2, 3).permute(1, 0, 2, 3)
+            if Cp != Cout:
+                wt = torch.cat((wt, wt.new_zeros(Cin, Cp - Cout, kh, kw)), dim=1)
+            cin_pad = _pad_channels(Cin, x.dtype)
+            pt = ops.pack_conv(wt.contiguous(), x.dtype, None, None, stride=1, pad=pad, act=L.ACT_NONE, cout=cin_pad)
+            g = dy
+            if stride == 2:
+                g = torch.empty((B, H, W, Cp), dtype=dy.dtype, device=dy.device)
+                L.check(L.load().mfx_zero_insert2_nhwc(_ptr(dy), _ptr(g), B, Ho, Wo, Cp, H, W, _dt(dy.dtype), _stream()),
+                        "mfx_zero_insert2_nhwc")
+            dx = ops.conv2d(g, pt)
+            if cin_pad != Cin:
+                dx = dx[..., :Cin]
+        if ctx.needs_input_grad[1]:
+            dwf = _wgrad(x, dy, kh, kw, stride, pad, Ho, Wo)                       # (Cp, taps, Cin)
+            dw = dwf[:Cout].view(Cout, kh, kw, Cin).permute(0, 3, 1, 2).contiguous().to(weight.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy)[:Cout]
+        return dx, dw, db, None, None
+
+
+class StemConvFn(Function):
+    """7x7 / stride 1 / pad 3 convolution of the NCHW fp32 image batch (dla_dcn.py:268-272); no data gradient."""
+
+    @staticmethod
+    def forward(ctx, images, weight, dtype):
+        B, _, H, W = images.shape
+        xp = ops.pack_image(images, dtype)
+        one = torch.ones(weight.shape[0], device=images.device)
+        p = ops.pack_stem(weight, dtype, one, torch.zeros_like(one), act=L.ACT_NONE)
+        y = ops.conv2d(xp, p, out_hw=(H, W))
+        ctx.save_for_backward(xp, weight)
+        ctx.hw = (H, W)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        xp, weight = ctx.saved_tensors
+        H, W = ctx.hw
+        if xp.dtype != torch.float32:
+            raise NotImplementedError("stem weight gradient: fp32 training mode only")
+        Cout = weight.shape[0]
+        dwf = _wgrad(xp, _c(dy), 7, 7, 1, 0, H, W, Ck=4, x_pixstride=4)          # padded image: pad 0 in padded coordinates
+        dw = dwf[:Cout].view(Cout, 7, 7, 4)[..., :3].permute(0, 3, 1, 2).contiguous()
+        return None, dw, None
+
+
+class BNActFn(Function):
+    """Train-mode BatchNorm (batch statistics, biased variance) + activation (+ residual before the activation)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, res, act, momentum, eps):
+        x = _c(x)
+        C = x.shape[-1]
+        M = x.numel() // C
+        s = torch.empty(C, dtype=torch.float32, device=x.device)
+        q = torch.empty_like(s)
+        lib_ = L.load()
+        L.check(lib_.mfx_bn_stats(_ptr(x), _ptr(s), _ptr(q), M, C, _dt(x.dtype), _stream()), "mfx_bn_stats")
+        mean = s / M
+        var = (q / M - mean * mean).clamp_(min=0.0)
+        rstd = torch.rsqrt(var + eps)
+        g32, b32 = gamma.detach().float(), beta.detach().float()
+        scale = (g32 * rstd).contiguous()
+        shift = (b32 - mean * scale).contiguous()
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var * (M / max(M - 1, 1)), alpha=momentum)
+        y = torch.empty_like(x)
+        res_c = _c(res) if res is not None else None
+        L.check(lib_.mfx_bn_act_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res_c), _ptr(y), M, C, act, _dt(x.dtype), _stream()),
+                "mfx_bn_act_fwd")
+        ctx.save_for_backward(x, y, mean.contiguous(), rstd.contiguous(), g32.contiguous())
+        ctx.cfg = (act, res is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, da):
+        x, y, mean, rstd, g32 = ctx.saved_tensors
+        act, has_res = ctx.cfg
+        da = _c(da)
+        C = x.shape[-1]
+        M = x.numel() // C
+        sg = torch.empty(C, dtype=torch.float32, device=x.device)
+        sgx = torch.empty_like(sg)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        L.check(L.load().mfx_bn_act_bwd(_ptr(x), _ptr(y), _ptr(da), _ptr(mean), _ptr(rstd), _ptr(g32), _ptr(sg), _ptr(sgx),
+                                        _ptr(dx), _ptr(dres), M, C, act, _dt(x.dtype), _stream()), "mfx_bn_act_bwd")
+        return dx, sgx, sg, None, None, dres, None, None, None
+
+
+class MaxPool2x2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return ops.maxpool2x2(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        L.check(L.load().mfx_maxpool2x2_bwd_nhwc(_ptr(x), _ptr(_c(dy)), _ptr(dx), B, H, W, C, _dt(x.dtype), _stream()),
+                "mfx_maxpool2x2_bwd_nhwc")
+        return dx
+
+
+class UpsampleAddFn(Function):
+    """y = depthwise ConvTranspose2d(x; k=2f, s=f, p=f/2) + skip   (dla_dcn.py:409-411, 419-425)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, skip, f):
+        x = _c(x)
+        wt = ops.pack_upsample(weight)
+        ctx.save_for_backward(x, wt)
+        ctx.f = f
+        ctx.wshape = weight.shape
+        return ops.upsample_add(x, wt, f, skip=_c(skip))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, wt = ctx.saved_tensors
+        f = ctx.f
+        dy = _c(dy)
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.empty((4 * f * f, C), dtype=torch.float32, device=x.device)
+        L.check(L.load().mfx_upsample_bwd_nhwc(_ptr(x), _ptr(wt), _ptr(dy), _ptr(dx), _ptr(dw), B, H, W, C, f, _dt(x.dtype), _stream()),
+                "mfx_upsample_bwd_nhwc")
+        return dx, dw.t().reshape(ctx.wshape).contiguous(), dy, None
+
+
+class DCNFn(Function):
+    """Modulated deformable conv on NHWC fp32: y = DCNv2(x; offsets, sigmoid(mask logits), weight) + bias.
+    `offmask_raw` is the (B,H,W,32) output of the 27-channel offset/mask conv (channels 0..17 offsets,
+    18..26 mask logits, reference dcn_v2.py:118-122)."""
+
+    @staticmethod
+    def forward(ctx, x, offmask_raw, weight, bias, stride, pad, dil):
+        if x.dtype != torch.float32:
+            raise NotImplementedError("DCN training path: fp32 mode only (the backward kernels are fp32)")
+        x, raw = _c(x), _c(offmask_raw)
+        om = raw.clone()
+        om[..., 18:27] = torch.sigmoid(raw[..., 18:27])
+        p = ops.pack_conv(weight, x.dtype, None, bias, stride=stride, pad=pad, act=L.ACT_NONE)
+        p.dil_w = dil
+        y = ops.dcn(x, om, p)
+        ctx.save_for_backward(x, om, weight)
+        ctx.cfg = (stride, pad, dil)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, om, weight = ctx.saved_tensors
+        stride, pad, dil = ctx.cfg
+        dy = _c(dy)
+        B, H, W, C = x.shape
+        Cout, _, kh, kw = weight.shape
+        lib_ = L.load()
+        nbytes = lib_.mfx_dcn_backward_nhwc_workspace_bytes(B, C, H, W, Cout, kh, kw, stride, pad, dil)
+        ws = ops._workspace(nbytes, x.device)
+        dx = torch.empty_like(x)
+        dom = torch.empty_like(om)
+        dw = torch.empty_like(weight)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+        wc = weight.detach().float().contiguous()
+        L.check(lib_.mfx_dcn_backward_nhwc(_ptr(x), _ptr(om), _ptr(wc), _ptr(dy), _ptr(dx), _ptr(dom), _ptr(dw), _ptr(db),
+                                           B, C, H, W, Cout, kh, kw, stride, pad, dil, _ptr(ws), ws.numel(), _stream()),
+                "mfx_dcn_backward_nhwc")
+        m = om[..., 18:27]
+        dom[..., 18:27] = dom[..., 18:27] * m * (1 - m)               # through the sigmoid
+        dom[..., 27:] = 0
+        return dx, dom, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0):
+    """Differentiable NHWC conv; returns exactly weight.shape[0] channels."""
+    y = Conv2dFn.apply(x, weight, bias, stride, pad)
+    return y if y.shape[-1] == weight.shape[0] else y[..., :weight.shape[0]]
+
+
+def bn_act(x, bn, act, res=None):
+    """Train-mode BN module `bn` (+act, +res) on an NHWC tensor; updates bn.running_* like nn.BatchNorm2d."""
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, act, mom, bn.eps)

@@ -236,6 +236,36 @@ static BwdGeom bwd_geom(int B, int C, int H, int W, int Cout, int kh, int kw, in
     return g;
 }
 
+// gradients of the NHWC fp32 problem: gcol scratch [M][Kp]; gx [B*H*W][Cp], gwp [Coutp][K], gb [Coutp] must be zeroed
+static int dcn_bwd_core(const float* x, const float* om, const float* wT, const float* go, float* gcol, float* gx, float* gom,
+                        float* gwp, float* gb, const BwdGeom& g, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // d(columns)[m][k] = sum_o go[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM
+    mfx_conv_desc cd;
+    cd.x = go; cd.w = wT; cd.w_frag = nullptr; cd.scale = nullptr; cd.shift = nullptr; cd.res = nullptr; cd.y = gcol; cd.rowmap = nullptr;
+    cd.B = 1; cd.H = 1; cd.W = g.M; cd.x_pixstride = g.Coutp; cd.Ck = g.Coutp; cd.kh = 1; cd.kw = 1; cd.stride = 1;
+    cd.pad_h = 0; cd.pad_w = 0; cd.dil_w = 1; cd.Ho = 1; cd.Wo = g.M; cd.M = g.M; cd.Cout = g.Kp; cd.Cout_pad = g.Kp;
+    cd.K_pad = g.Coutp; cd.ldy = g.Kp; cd.ldres = 0; cd.act = MFX_ACT_NONE; cd.dtype = MFX_F32; cd.out_dtype = MFX_F32;
+    int rc = mfx_conv2d_nhwc(&cd, stream);
+    if (rc) return rc;
+    {   // grad_offset, grad_mask, grad_input
+        const long pairs = (long)g.M * g.kk;
+        const int blocks = (int)((pairs + 3) / 4 < 65536 ? (pairs + 3) / 4 : 65536);
+        hipLaunchKernelGGL(dcn_bwd_sample_kernel, dim3(blocks), dim3(256), 0, st, x, om, gcol, g, gx, gom);
+    }
+    {   // grad_weight
+        const int m_per_block = 2048;
+        dim3 grid(g.Kp / 64, g.Coutp / 64, cdv(g.M, m_per_block));
+        hipLaunchKernelGGL(dcn_bwd_wgrad_kernel, grid, dim3(256), 0, st, x, om, go, g, m_per_block, gwp);
+    }
+    {   // grad_bias
+        const int rows = 1024;
+        hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3(cdv(g.M, rows), g.Coutp / 64), dim3(64, 4), 0, st, go, g.M, g.Coutp, rows, gb);
+    }
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
 extern "C" size_t mfx_dcn_v2_backward_workspace_bytes_(int B, int C, int H, int W, int Cout, int kh, int kw, int s, int p, int d) {
     return bwd_layout(bwd_geom(B, C, H, W, Cout, kh, kw, s, p, d)).total;
 }
@@ -276,36 +306,53 @@ extern "C" int mfx_dcn_v2_backward(const float* input, const float* weight, cons
     MFX_HIP_CHECK(hipMemsetAsync(gb, 0, (size_t)g.Coutp * 4, st));
     MFX_HIP_CHECK(hipGetLastError());
 
-    // d(columns)[m][k] = sum_o go[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM
-    mfx_conv_desc cd;
-    cd.x = go; cd.w = wT; cd.w_frag = nullptr; cd.scale = nullptr; cd.shift = nullptr; cd.res = nullptr; cd.y = gcol; cd.rowmap = nullptr;
-    cd.B = 1; cd.H = 1; cd.W = g.M; cd.x_pixstride = g.Coutp; cd.Ck = g.Coutp; cd.kh = 1; cd.kw = 1; cd.stride = 1;
-    cd.pad_h = 0; cd.pad_w = 0; cd.dil_w = 1; cd.Ho = 1; cd.Wo = g.M; cd.M = g.M; cd.Cout = g.Kp; cd.Cout_pad = g.Kp;
-    cd.K_pad = g.Coutp; cd.ldy = g.Kp; cd.ldres = 0; cd.act = MFX_ACT_NONE; cd.dtype = MFX_F32; cd.out_dtype = MFX_F32;
-    rc = mfx_conv2d_nhwc(&cd, stream);
+    rc = dcn_bwd_core(x, om, wT, go, gcol, gx, gom, gwp, gb, g, stream);
     if (rc) return rc;
-
-    {   // grad_offset, grad_mask, grad_input
-        const long pairs = (long)g.M * g.kk;
-        const int blocks = (int)((pairs + 3) / 4 < 65536 ? (pairs + 3) / 4 : 65536);
-        hipLaunchKernelGGL(dcn_bwd_sample_kernel, dim3(blocks), dim3(256), 0, st, x, om, gcol, g, gx, gom);
-    }
-    {   // grad_weight
-        const int m_per_block = 2048;
-        dim3 grid(g.Kp / 64, g.Coutp / 64, cdv(g.M, m_per_block));
-        hipLaunchKernelGGL(dcn_bwd_wgrad_kernel, grid, dim3(256), 0, st, x, om, go, g, m_per_block, gwp);
-    }
-    {   // grad_bias
-        const int rows = 1024;
-        hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3(cdv(g.M, rows), g.Coutp / 64), dim3(64, 4), 0, st, go, g.M, g.Coutp, rows, gb);
-    }
-    MFX_HIP_CHECK(hipGetLastError());
 
     rc = mfx_nhwc_to_nchw(gx, grad_input, B, C, H, W, g.Cp, MFX_F32, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(bwd_unpack_offmask, BWD_GRID((long)g.M * 3 * g.kk), dim3(256), 0, st, gom, grad_offset, grad_mask, B, HWo, g.kk);
     hipLaunchKernelGGL(bwd_unpack_weight, BWD_GRID((long)Cout * C * g.kk), dim3(256), 0, st, gwp, grad_weight, Cout, C, g.kk, g.Cp, g.K);
     MFX_HIP_CHECK(hipMemcpyAsync(grad_bias, gb, (size_t)Cout * 4, hipMemcpyDeviceToDevice, st));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+// Training entry (NHWC fp32 tensors straight from the model's activations; no layout transforms):
+//   x [B][H][W][C], offmask [M][32] (mask already sigmoided), weight (Cout,C,kh,kw) fp32, dy [M][Cout]
+//   -> dx [B][H][W][C], d_offmask [M][32] (grad wrt offsets and wrt the POST-sigmoid mask), dweight (Cout,C,kh,kw), dbias [Cout]
+// C and Cout must be powers of two (C >= 16, Cout >= 64).  workspace: mfx_dcn_backward_nhwc_workspace_bytes().
+extern "C" size_t mfx_dcn_backward_nhwc_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil) {
+    const BwdGeom g = bwd_geom(B, C, H, W, Cout, kh, kw, stride, pad, dil);
+    return al256((size_t)g.Kp * g.Coutp * 4) + al256((size_t)g.M * g.Kp * 4) + al256((size_t)g.Coutp * g.K * 4) + al256((size_t)g.Coutp * 4);
+}
+
+extern "C" int mfx_dcn_backward_nhwc(const float* x, const float* offmask, const float* weight, const float* dy,
+                                     float* dx, float* d_offmask, float* dweight, float* dbias,
+                                     int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !offmask || !weight || !dy || !dx || !d_offmask || !dweight || !dbias) return mfx_fail(MFX_ERR_ARG, "dcn_backward_nhwc: null pointer");
+    if (kh * kw > 9) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_backward_nhwc: at most 9 taps");
+    const BwdGeom g = bwd_geom(B, C, H, W, Cout, kh, kw, stride, pad, dil);
+    if (g.Cp != C || g.Coutp != Cout) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_backward_nhwc: C (>=16) and Cout (>=64) must be powers of two");
+    if (workspace_bytes < mfx_dcn_backward_nhwc_workspace_bytes(B, C, H, W, Cout, kh, kw, stride, pad, dil) || !workspace)
+        return mfx_fail(MFX_ERR_WORKSPACE, "dcn_backward_nhwc: workspace too small");
+    if (g.M == 0) return MFX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* wT = (float*)ws; ws += al256((size_t)g.Kp * g.Coutp * 4);
+    float* gcol = (float*)ws; ws += al256((size_t)g.M * g.Kp * 4);
+    float* gwp = (float*)ws; ws += al256((size_t)g.Coutp * g.K * 4);
+    float* gb = (float*)ws;
+    hipLaunchKernelGGL(bwd_pack_weight_t, BWD_GRID((long)g.Kp * g.Coutp), dim3(256), 0, st, weight, wT, Cout, C, g.kk, g.Cp, g.Kp, g.Coutp);
+    MFX_HIP_CHECK(hipMemsetAsync(dx, 0, (size_t)B * H * W * C * 4, st));
+    MFX_HIP_CHECK(hipMemsetAsync(d_offmask, 0, (size_t)g.M * 32 * 4, st));
+    MFX_HIP_CHECK(hipMemsetAsync(gwp, 0, (size_t)g.Coutp * g.K * 4, st));
+    MFX_HIP_CHECK(hipMemsetAsync(gb, 0, (size_t)g.Coutp * 4, st));
+    int rc = dcn_bwd_core(x, offmask, wT, dy, gcol, dx, d_offmask, gwp, gb, g, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bwd_unpack_weight, BWD_GRID((long)Cout * C * g.kk), dim3(256), 0, st, gwp, dweight, Cout, C, g.kk, g.Cp, g.K);
+    MFX_HIP_CHECK(hipMemcpyAsync(dbias, gb, (size_t)Cout * 4, hipMemcpyDeviceToDevice, st));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

@@ -1,0 +1,461 @@
+// Training-path kernels (NHWC): weight/bias gradients, train-mode BatchNorm (+activation, +residual) forward and
+// backward, max-pool / depthwise-deconv backward, zero-insertion for stride-2 data gradients.
+// Data gradients of convolutions reuse the forward implicit-GEMM kernels (flipped / transposed weights packed by the
+// host), so no separate dgrad kernel exists.  All reductions accumulate in fp32.
+#include "../../include/monoflex_hip.h"
+#include "common.h"
+#include "err.h"
+
+namespace mfx {
+
+static inline int cdivt(long a, long b) { return (int)((a + b - 1) / b); }
+#define TR_GRID(total) dim3((unsigned)(cdivt((total), 256) < 16384 ? cdivt((total), 256) : 16384))
+
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv weight gradient: dW[o][tap][c] = sum_m dy[m][o] * x[pixel(m,tap)][c]       (fp32 [Cout][taps][Ck])
+// Block = 64 k x 64 o tile over a slab of pixels; 256 threads x 4x4 register blocks; fp32 atomics on the small result.
+// ------------------------------------------------------------------------------------------------
+struct WgradGeom { int B, H, W, Ho, Wo, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, M, K, Cout, ldy, m_per_block; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, WgradGeom g, float* __restrict__ dw) {
+    constexpr int MCH = 16;
+    __shared__ float cs[MCH][64 + 4];
+    __shared__ float gs[MCH][64 + 4];
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+    const int m_begin = blockIdx.z * g.m_per_block, m_end = min(m_begin + g.m_per_block, g.M);
+    const int tk = (tid & 15) * 4, to = (tid >> 4) * 4;
+    const int sr = tid >> 4, sc = (tid & 15) * 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const int k = k0 + sc;
+    const bool k_ok = k < g.K;
+    const int tap = k_ok ? k / g.Ck : 0, c = k - tap * g.Ck;          // Ck % 4 == 0: the 4 k's share a tap
+    const int th = tap / g.kw, tw = tap - th * g.kw;
+    const bool o_ok = o0 + sc < g.Cout;
+    const int hw = g.Ho * g.Wo;
+    for (int mb = m_begin; mb < m_end; mb += MCH) {
+        const int m = mb + sr;
+        float cv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < m_end) {
+            if (o_ok) load4<T>(dy + (size_t)m * g.ldy + o0 + sc, gv);
+            if (k_ok) {
+                const int b = m / hw, rem = m - b * hw, oh = rem / g.Wo, ow = rem - oh * g.Wo;
+                const int ih = oh * g.stride - g.pad_h + th, iw = ow * g.stride - g.pad_w + tw;
+                if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+                    load4<T>(x + ((size_t)(b * g.H + ih) * g.W + iw) * g.x_pixstride + c, cv);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs[sr][sc + e] = cv[e]; gs[sr][sc + e] = gv[e]; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MCH; ++r) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&cs[r][tk]);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(&gs[r][to]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bb[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + tk + i < g.K && o0 + to + j < g.Cout) unsafeAtomicAdd(dw + (size_t)(o0 + to + j) * g.K + k0 + tk + i, acc[i][j]);
+}
+
+// column sums: out[c] += sum_m x[m][c]      (bias gradient)
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, int M, int C, int ld, int rows_per_block, float* __restrict__ out) {
+    const int c = blockIdx.y * 64 + threadIdx.x;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+    float s = 0.f;
+    if (c < C) for (int r = r0 + threadIdx.y; r < r1; r += blockDim.y) s += ElemTraits<T>::load(x + (size_t)r * ld + c);
+    __shared__ float red[4][64];
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < C) unsafeAtomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Train-mode BatchNorm over an [M][C] NHWC tensor
+// thread -> fixed 16-byte channel chunk column (cc = tid % CPR), rows strided: per-thread register accumulation, then
+// a short LDS + global atomic reduction per block.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, long M, int C, int rows_per_block,
+                                                       float* __restrict__ sum, float* __restrict__ sumsq) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    extern __shared__ float sred[];                          // [2][C]
+    const int CPR = C / E, tid = threadIdx.x;
+    const int cc = tid % CPR, rstep = 256 / CPR, roff = tid / CPR;
+    for (int i = tid; i < 2 * C; i += 256) sred[i] = 0.f;
+    __syncthreads();
+    float s[E], q[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(r0 + (long)rows_per_block, M);
+    if (roff < rstep)
+        for (long r = r0 + roff; r < r1; r += rstep) {
+            float v[E];
+            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + r * C + cc * E), v);
+#pragma unroll
+            for (int e = 0; e < E; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+        }
+#pragma unroll
+    for (int e = 0; e < E; ++e) { atomicAdd(&sred[cc * E + e], s[e]); atomicAdd(&sred[C + cc * E + e], q[e]); }
+    __syncthreads();
+    for (int i = tid; i < C; i += 256) { unsafeAtomicAdd(sum + i, sred[i]); unsafeAtomicAdd(sumsq + i, sred[C + i]); }
+}
+
+// y = act(x*scale[c] + shift[c] (+ res))
+template <typename T>
+__global__ void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                  const T* __restrict__ res, T* __restrict__ y, long total_chunks, int C, int act) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    const int CPR = C / E;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total_chunks; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % CPR) * E;
+        float v[E];
+        ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + i * E), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = v[e] * scale[c0 + e] + shift[c0 + e];
+        if (res) {
+            float r[E];
+            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(res + i * E), r);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] += r[e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = apply_act(v[e], act, 0);
+        *reinterpret_cast<u32x4*>(y + i * E) = ElemTraits<T>::pack(v);
+    }
+}
+
+__device__ __forceinline__ float act_grad(float a, int act) {    // derivative of the activation, from its OUTPUT a
+    if (act == ACT_RELU) return a > 0.f ? 1.f : 0.f;
+    if (act == ACT_LEAKY) return a > 0.f ? 1.f : 0.01f;
+    return 1.f;
+}
+
+// backward reductions: g = da * act'(a);  sg[c] = sum g,  sgx[c] = sum g * xhat,  xhat = (x - mean[c]) * rstd[c]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ da,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            long M, int C, int rows_per_block, int act,
+                                                            float* __restrict__ sg, float* __restrict__ sgx) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    extern __shared__ float sred[];
+    const int CPR = C / E, tid = threadIdx.x;
+    const int cc = tid % CPR, rstep = 256 / CPR, roff = tid / CPR;
+    for (int i = tid; i < 2 * C; i += 256) sred[i] = 0.f;
+    __syncthreads();
+    float s[E], q[E], mu[E], rs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { s[e] = 0.f; q[e] = 0.f; mu[e] = mean[cc * E + e]; rs[e] = rstd[cc * E + e]; }
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(r0 + (long)rows_per_block, M);
+    if (roff < rstep)
+        for (long r = r0 + roff; r < r1; r += rstep) {
+            float xv[E], av[E], dv[E];
+            const size_t o = (size_t)r * C + cc * E;
+            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + o), xv);
+            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(da + o), dv);
+            if (act != ACT_NONE) ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(a + o), av);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float gq = act != ACT_NONE ? dv[e] * act_grad(av[e], act) : dv[e];
+                s[e] += gq; q[e] += gq * (xv[e] - mu[e]) * rs[e];
+            }
+        }
+#pragma unroll
+    for (int e = 0; e < E; ++e) { atomicAdd(&sred[cc * E + e], s[e]); atomicAdd(&sred[C + cc * E + e], q[e]); }
+    __syncthreads();
+    for (int i = tid; i < C; i += 256) { unsafeAtomicAdd(sg + i, sred[i]); unsafeAtomicAdd(sgx + i, sred[C + i]); }
+}
+
+// dx = gamma*rstd * (g - sg/M - xhat*sgx/M);  dres = g (optional)
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ da,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sg, const float* __restrict__ sgx, float invM,
+                                    T* __restrict__ dx, T* __restrict__ dres, long total_chunks, int C, int act) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    const int CPR = C / E;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total_chunks; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % CPR) * E;
+        float xv[E], av[E], dv[E], gq[E], ov[E];
+        ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + i * E), xv);
+        ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(da + i * E), dv);
+        if (act != ACT_NONE) ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(a + i * E), av);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int c = c0 + e;
+            gq[e] = act != ACT_NONE ? dv[e] * act_grad(av[e], act) : dv[e];
+            const float xh = (xv[e] - mean[c]) * rstd[c];
+            ov[e] = gamma[c] * rstd[c] * (gq[e] - sg[c] * invM - xh * sgx[c] * invM);
+        }
+        *reinterpret_cast<u32x4*>(dx + i * E) = ElemTraits<T>::pack(ov);
+        if (dres) *reinterpret_cast<u32x4*>(dres + i * E) = ElemTraits<T>::pack(gq);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// max-pool 2x2 backward: gradient goes to the first maximum of each window (torch semantics)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    const int Ho = H / 2, Wo = W / 2, CG = C / E;
+    const long total = (long)B * Ho * Wo * CG;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        long p = i / CG;
+        const int ow = (int)(p % Wo); p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const size_t base = ((size_t)(b * H + oh * 2) * W + ow * 2) * C + cg * E;
+        const size_t offs[4] = {base, base + C, base + (size_t)W * C, base + (size_t)W * C + C};
+        float v[4][E], g[E], o[4][E];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + offs[q]), v[q]);
+        ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(dy + ((size_t)(b * Ho + oh) * Wo + ow) * C + cg * E), g);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            int best = 0; float bv = v[0][e];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) if (v[q][e] > bv) { bv = v[q][e]; best = q; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q][e] = q == best ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(dx + offs[q]) = ElemTraits<T>::pack(o[q]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise ConvTranspose2d(k=2f, s=f, p=f/2) backward:  dx[b,ih,iw,c] = sum_{kh,kw} dy[b, ih*f-p+kh, iw*f-p+kw, c] * w[kh*k+kw][c]
+//                                                         dw[kh*k+kw][c] = sum_{b,ih,iw} x[b,ih,iw,c] * dy[b, ih*f-p+kh, iw*f-p+kw, c]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void upsample_bwd_dx_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int B, int H, int W, int C, int f) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    const int Ho = H * f, Wo = W * f, CG = C / E, p_ = f / 2, k = 2 * f;
+    const long total = (long)B * H * W * CG;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        long p = i / CG;
+        const int iw = (int)(p % W); p /= W;
+        const int ih = (int)(p % H);
+        const int b = (int)(p / H);
+        float acc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.f;
+        for (int kh = 0; kh < k; ++kh) {
+            const int oh = ih * f - p_ + kh;
+            if (oh < 0 || oh >= Ho) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int ow = iw * f - p_ + kw;
+                if (ow < 0 || ow >= Wo) continue;
+                float g[E];
+                ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(dy + ((size_t)(b * Ho + oh) * Wo + ow) * C + cg * E), g);
+                const float* wp = w + (size_t)(kh * k + kw) * C + cg * E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] += g[e] * wp[e];
+            }
+        }
+        *reinterpret_cast<u32x4*>(dx + i * E) = ElemTraits<T>::pack(acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_dw_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
+                                                              int B, int H, int W, int C, int f, int pix_per_block) {
+    // thread -> (channel c = tid % C', tap subset); each block walks a slab of input pixels
+    const int k = 2 * f, p_ = f / 2, Ho = H * f, Wo = W * f, taps = k * k;
+    const long npix = (long)B * H * W;
+    const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(p0 + (long)pix_per_block, npix);
+    for (int item = threadIdx.x; item < taps * C; item += 256) {
+        const int c = item % C, tap = item / C, kh = tap / k, kw = tap - kh * k;
+        float s = 0.f;
+        for (long p = p0; p < p1; ++p) {
+            const int iw = (int)(p % W); const long q = p / W; const int ih = (int)(q % H); const int b = (int)(q / H);
+            const int oh = ih * f - p_ + kh, ow = iw * f - p_ + kw;
+            if (oh < 0 || oh >= Ho || ow < 0 || ow >= Wo) continue;
+            s += ElemTraits<T>::load(x + (size_t)p * C + c) * ElemTraits<T>::load(dy + ((size_t)(b * Ho + oh) * Wo + ow) * C + c);
+        }
+        unsafeAtomicAdd(dw + (size_t)tap * C + c, s);
+    }
+}
+
+// zero insertion for the data gradient of a stride-2 conv: up[b, 2*oh, 2*ow, :] = dy[b, oh, ow, :], zeros elsewhere
+template <typename T>
+__global__ void zero_insert2_kernel(const T* __restrict__ dy, T* __restrict__ up, int B, int Ho, int Wo, int C, int H, int W) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    const int CG = C / E;
+    const long total = (long)B * H * W * CG;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        long p = i / CG;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int b = (int)(p / H);
+        u32x4 z = {0u, 0u, 0u, 0u};
+        if (!(h & 1) && !(w & 1) && (h >> 1) < Ho && (w >> 1) < Wo)
+            z = *reinterpret_cast<const u32x4*>(dy + ((size_t)(b * Ho + (h >> 1)) * Wo + (w >> 1)) * C + cg * E);
+        *reinterpret_cast<u32x4*>(up + i * E) = z;
+    }
+}
+
+}  // namespace mfx
+using namespace mfx;
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == MFX_F32) { CALL_F32; } else if ((dtype) == MFX_BF16) { CALL_BF16; } else return mfx_fail(MFX_ERR_ARG, "bad dtype"); } while (0)
+
+extern "C" int mfx_conv_wgrad_nhwc(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
+                                   int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
+                                   int dtype, void* stream) {
+    if (!x || !dy || !dw) return mfx_fail(MFX_ERR_ARG, "conv_wgrad: null pointer");
+    if (Ck % 4 != 0 || Cout % 4 != 0) return mfx_fail(MFX_ERR_ARG, "conv_wgrad: Ck and Cout must be multiples of 4");
+    WgradGeom g;
+    g.B = B; g.H = H; g.W = W; g.Ho = Ho; g.Wo = Wo; g.x_pixstride = x_pixstride; g.Ck = Ck; g.kh = kh; g.kw = kw; g.stride = stride;
+    g.pad_h = pad_h; g.pad_w = pad_w; g.M = B * Ho * Wo; g.K = kh * kw * Ck; g.Cout = Cout; g.ldy = ldy; g.m_per_block = 2048;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)Cout * g.K * sizeof(float), st));
+    if (g.M == 0) return MFX_OK;
+    dim3 grid(cdivt(g.K, 64), cdivt(Cout, 64), cdivt(g.M, g.m_per_block));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, g, dw),
+                      hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int dtype, void* stream) {
+    if (!x || !out) return mfx_fail(MFX_ERR_ARG, "colsum: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MFX_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
+    if (M == 0) return MFX_OK;
+    const int rows = 2048;
+    dim3 grid(cdivt(M, rows), cdivt(C, 64)), block(64, 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)x, (int)M, C, ld, rows, out),
+                      hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (int)M, C, ld, rows, out));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+static int bn_check(int C, int dtype) {
+    const int E = dtype == MFX_BF16 ? 8 : 4;
+    if (C % E != 0 || C / E > 256 || (256 % (C / E)) != 0) return mfx_fail(MFX_ERR_ARG, "bn: C must be a power-of-two multiple of one 16-byte chunk (<= 256 chunks)");
+    return MFX_OK;
+}
+
+extern "C" int mfx_bn_stats(const void* x, float* sum, float* sumsq, long M, int C, int dtype, void* stream) {
+    if (!x || !sum || !sumsq) return mfx_fail(MFX_ERR_ARG, "bn_stats: null pointer");
+    int rc = bn_check(C, dtype); if (rc) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MFX_HIP_CHECK(hipMemsetAsync(sum, 0, (size_t)C * sizeof(float), st));
+    MFX_HIP_CHECK(hipMemsetAsync(sumsq, 0, (size_t)C * sizeof(float), st));
+    if (M == 0) return MFX_OK;
+    const int rows = 1024;
+    const size_t smem = (size_t)2 * C * sizeof(float);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, sum, sumsq),
+                      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, sum, sumsq));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_bn_act_fwd(const void* x, const float* scale, const float* shift, const void* res, void* y,
+                              long M, int C, int act, int dtype, void* stream) {
+    if (!x || !scale || !shift || !y) return mfx_fail(MFX_ERR_ARG, "bn_act_fwd: null pointer");
+    int rc = bn_check(C, dtype); if (rc) return rc;
+    if (M == 0) return MFX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long chunks = M * (C / (dtype == MFX_BF16 ? 8 : 4));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<float>, TR_GRID(chunks), dim3(256), 0, st, (const float*)x, scale, shift, (const float*)res, (float*)y, chunks, C, act),
+                      hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, TR_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (const bf16_t*)res, (bf16_t*)y, chunks, C, act));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_bn_act_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
+                              float* sg, float* sgx, void* dx, void* dres, long M, int C, int act, int dtype, void* stream) {
+    if (!x || !da || !mean || !rstd || !gamma || !sg || !sgx || !dx || (act != MFX_ACT_NONE && !a)) return mfx_fail(MFX_ERR_ARG, "bn_act_bwd: null pointer");
+    int rc = bn_check(C, dtype); if (rc) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MFX_HIP_CHECK(hipMemsetAsync(sg, 0, (size_t)C * sizeof(float), st));
+    MFX_HIP_CHECK(hipMemsetAsync(sgx, 0, (size_t)C * sizeof(float), st));
+    if (M == 0) return MFX_OK;
+    const int rows = 1024;
+    const size_t smem = (size_t)2 * C * sizeof(float);
+    const long chunks = M * (C / (dtype == MFX_BF16 ? 8 : 4));
+    const float invM = 1.f / (float)M;
+    DISPATCH_T(dtype,
+        { hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sg, sgx);
+          hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, TR_GRID(chunks), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, gamma, sg, sgx, invM, (float*)dx, (float*)dres, chunks, C, act); },
+        { hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, M, C, rows, act, sg, sgx);
+          hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, TR_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, gamma, sg, sgx, invM, (bf16_t*)dx, (bf16_t*)dres, chunks, C, act); });
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
+    if (!x || !dy || !dx) return mfx_fail(MFX_ERR_ARG, "maxpool_bwd: null pointer");
+    const int E = dtype == MFX_BF16 ? 8 : 4;
+    if (C % E != 0 || (H & 1) || (W & 1)) return mfx_fail(MFX_ERR_ARG, "maxpool_bwd: C must be a multiple of 16 bytes, H/W even");
+    const long total = (long)B * (H / 2) * (W / 2) * (C / E);
+    if (total == 0) return MFX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<float>, TR_GRID(total), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, B, H, W, C),
+                      hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* dy, void* dx, float* dw,
+                                     int B, int H, int W, int C, int f, int dtype, void* stream) {
+    if (!x || !w || !dy || !dx || !dw) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: null pointer");
+    const int E = dtype == MFX_BF16 ? 8 : 4;
+    if (C % E != 0 || f < 1) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: bad C or f");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)4 * f * f * C * sizeof(float), st));
+    const long total = (long)B * H * W * (C / E);
+    if (total == 0) return MFX_OK;
+    const int ppb = 256;
+    const long npix = (long)B * H * W;
+    DISPATCH_T(dtype,
+        { hipLaunchKernelGGL(upsample_bwd_dx_kernel<float>, TR_GRID(total), dim3(256), 0, st, (const float*)dy, w, (float*)dx, B, H, W, C, f);
+          hipLaunchKernelGGL(upsample_bwd_dw_kernel<float>, dim3(cdivt(npix, ppb)), dim3(256), 0, st, (const float*)x, (const float*)dy, dw, B, H, W, C, f, ppb); },
+        { hipLaunchKernelGGL(upsample_bwd_dx_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, (const bf16_t*)dy, w, (bf16_t*)dx, B, H, W, C, f);
+          hipLaunchKernelGGL(upsample_bwd_dw_kernel<bf16_t>, dim3(cdivt(npix, ppb)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, C, f, ppb); });
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_zero_insert2_nhwc(const void* dy, void* up, int B, int Ho, int Wo, int C, int H, int W, int dtype, void* stream) {
+    if (!dy || !up) return mfx_fail(MFX_ERR_ARG, "zero_insert2: null pointer");
+    const int E = dtype == MFX_BF16 ? 8 : 4;
+    if (C % E != 0) return mfx_fail(MFX_ERR_ARG, "zero_insert2: C must be a multiple of 16 bytes");
+    const long total = (long)B * H * W * (C / E);
+    if (total == 0) return MFX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(zero_insert2_kernel<float>, TR_GRID(total), dim3(256), 0, st, (const float*)dy, (float*)up, B, Ho, Wo, C, H, W),
+                      hipLaunchKernelGGL(zero_insert2_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)up, B, Ho, Wo, C, H, W));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}

@@ -69,6 +69,16 @@ SYMBOLS = {
     "mfx_heads_fused": (_I, [ctypes.POINTER(HeadsDesc), _P]),
     "mfx_edge_scatter_add": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
     "mfx_decode_topk": (_I, [_P, ctypes.c_long, ctypes.c_long, ctypes.c_long, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mfx_conv_wgrad_nhwc": (_I, [_P, _P, _P] + [_I] * 15 + [_P]),
+    "mfx_colsum": (_I, [_P, _P, ctypes.c_long, _I, _I, _I, _P]),
+    "mfx_bn_stats": (_I, [_P, _P, _P, ctypes.c_long, _I, _I, _P]),
+    "mfx_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P]),
+    "mfx_bn_act_bwd": (_I, [_P] * 10 + [ctypes.c_long, _I, _I, _I, _P]),
+    "mfx_maxpool2x2_bwd_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mfx_upsample_bwd_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mfx_zero_insert2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mfx_dcn_backward_nhwc_workspace_bytes": (_S, [_I] * 10),
+    "mfx_dcn_backward_nhwc": (_I, [_P] * 8 + [_I] * 10 + [_P, _S, _P]),
     "mfx_decode_boxes": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P]),
 }
 

@@ -111,6 +111,13 @@ class DCN(DCNv2):
         offmask = ops.conv2d(x, self.packed_offset(x.dtype), out_dtype=torch.float32)
         return ops.dcn(x, offmask, self.packed_main(x.dtype, bn, act))
 
+    def forward_nhwc_train(self, x):
+        """Differentiable NHWC form: offset/mask conv -> DCNv2 (gradients to x, offsets, mask logits, weight, bias)."""
+        from .... import autograd as AG
+        c = self.conv_offset_mask
+        raw = AG.Conv2dFn.apply(x, c.weight, c.bias, self.stride[0], self.padding[0])       # (B,H,W,32), 27 used
+        return AG.DCNFn.apply(x, raw, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
+
     def forward(self, input):
         if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad and self.training):
             raise NotImplementedError("DCN training path (offset conv backward) lands with the backward kernels; "

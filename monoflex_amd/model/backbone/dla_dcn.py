@@ -10,7 +10,9 @@ forward below runs NHWC through libmonoflex_hip.so:
   DeformConv: DCN + BN + ReLU                  -> offset conv + fused DCN kernel (DCN.forward_nhwc)
   up(proj(x)) + skip                           -> one depthwise-deconv launch    (ops.upsample_add)
 
-Eval mode only in this round (BN uses running statistics); training mode raises.
+Eval mode folds BN (running statistics) into the conv epilogues.  Training mode (module.training) runs the same
+graph unfused through the differentiable operators of monoflex_amd.autograd: conv -> train-mode BN(+act,+res),
+fp32 activations, gradients by the HIP backward kernels.
 """
 import math
 
@@ -18,6 +20,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from ... import autograd as AG
 from ... import lib as L
 from ... import ops
 from .DCNv2.dcn_v2 import DCN
@@ -43,6 +46,11 @@ def _eval_only(m):
                                   "call .eval() -- the training kernels are a later round" % type(m).__name__)
 
 
+def _train_conv_bn(x, conv, bn, act, res=None):
+    """Training form of conv -> BN(batch statistics) -> act (+res before the act)."""
+    return AG.bn_act(AG.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0]), bn, act, res)
+
+
 def _conv_bn(owner, key, conv, bn, dtype, act):
     packs = owner.__dict__.setdefault("_packs", {})
     k = (key, dtype)
@@ -63,9 +71,11 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x, residual=None):                      # x NHWC
-        _eval_only(self)
         if residual is None:
             residual = x
+        if self.training:
+            out = _train_conv_bn(x, self.conv1, self.bn1, L.ACT_RELU)
+            return _train_conv_bn(out, self.conv2, self.bn2, L.ACT_RELU, res=residual)
         out = ops.conv2d(x, _conv_bn(self, "c1", self.conv1, self.bn1, x.dtype, L.ACT_RELU))
         return ops.conv2d(out, _conv_bn(self, "c2", self.conv2, self.bn2, x.dtype, L.ACT_RELU), res=residual)
 
@@ -80,7 +90,8 @@ class Root(nn.Module):
         assert not residual, "dla34 uses residual_root=False (dla_dcn.py:264)"
 
     def forward(self, *xs):
-        _eval_only(self)
+        if self.training:
+            return _train_conv_bn(torch.cat(xs, dim=3), self.conv, self.bn, L.ACT_RELU)
         packs = self.__dict__.setdefault("_packs", {})
         chans = tuple(t.shape[3] for t in xs)
         k = (chans, xs[0].dtype)
@@ -116,14 +127,21 @@ class Tree(nn.Module):
                                          nn.BatchNorm2d(out_channels, momentum=BN_MOMENTUM))
 
     def forward(self, x, residual=None, children=None):       # dla_dcn.py:246-259
-        _eval_only(self)
         children = [] if children is None else children
-        bottom = ops.maxpool2x2(x) if self.downsample else x
+        if self.training:
+            bottom = AG.MaxPool2x2Fn.apply(x) if self.downsample else x
+        else:
+            bottom = ops.maxpool2x2(x) if self.downsample else x
         if self.levels == 1:
             # a levels>1 Tree hands `residual` to a nested Tree that recomputes its own:
-            # the outer level3/level4 `project` output is dead in the reference, so it is not computed here
-            residual = ops.conv2d(bottom, _conv_bn(self, "proj", self.project[0], self.project[1], x.dtype, L.ACT_NONE)) \
-                if self.project else bottom
+            # the outer level3/level4 `project` output is dead in the reference (its parameters never get a
+            # gradient), so it is not computed here
+            if not self.project:
+                residual = bottom
+            elif self.training:
+                residual = _train_conv_bn(bottom, self.project[0], self.project[1], L.ACT_NONE)
+            else:
+                residual = ops.conv2d(bottom, _conv_bn(self, "proj", self.project[0], self.project[1], x.dtype, L.ACT_NONE))
         if self.level_root:
             children.append(bottom)
         x1 = self.tree1(x, residual)
@@ -159,7 +177,8 @@ class DLA(nn.Module):
 
     def forward(self, images, dtype):
         """images: (B,3,H,W) fp32 NCHW -> list of 6 NHWC feature maps (strides 1..32)."""
-        _eval_only(self)
+        if self.training:
+            return self._forward_train(images, dtype)
         packs = self.__dict__.setdefault("_packs", {})
         if ("stem", dtype) not in packs:
             scale, shift = ops.fold_bn(self.base_layer[1])
@@ -176,6 +195,23 @@ class DLA(nn.Module):
                 x = lvl(x)
             y.append(x)
         return y
+
+
+def _dla_forward_train(self, images, dtype):
+    x = AG.bn_act(AG.StemConvFn.apply(images, self.base_layer[0].weight, dtype), self.base_layer[1], L.ACT_RELU)
+    y = []
+    for i in range(6):
+        lvl = getattr(self, "level{}".format(i))
+        if i < 2:
+            for j in range(0, len(lvl), 3):
+                x = _train_conv_bn(x, lvl[j], lvl[j + 1], L.ACT_RELU)
+        else:
+            x = lvl(x)
+        y.append(x)
+    return y
+
+
+DLA._forward_train = _dla_forward_train
 
 
 def dla34(pretrained=True, **kwargs):
@@ -203,7 +239,8 @@ class DeformConv(nn.Module):
         self.conv = DCN(chi, cho, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
 
     def forward(self, x):                                      # NHWC; DCN + BN + ReLU in one kernel epilogue
-        _eval_only(self)
+        if self.training:
+            return AG.bn_act(self.conv.forward_nhwc_train(x), self.actf[0], L.ACT_RELU)
         return self.conv.forward_nhwc(x, bn=self.actf[0], act=L.ACT_RELU)
 
 
@@ -226,6 +263,10 @@ class IDAUp(nn.Module):
             if k not in packs:
                 packs[k] = ops.pack_upsample(up.weight)
             t = getattr(self, "proj_" + str(k))(layers[i])
+            if self.training:
+                t = AG.UpsampleAddFn.apply(t, up.weight, layers[i - 1], up.stride[0])
+                layers[i] = getattr(self, "node_" + str(k))(t)
+                continue
             t = ops.upsample_add(t, packs[k], up.stride[0], skip=layers[i - 1])      # up(proj(x_i)) + x_{i-1}
             layers[i] = getattr(self, "node_" + str(k))(t)
 

@@ -44,6 +44,14 @@ class KeypointDetector(nn.Module):
         det, topk, valid = self.heads.post_processor.decode_device(hm, pad, calib, size, self.heads.predictor.last_cls_planar)
         return det, topk, valid, hm
 
+    def forward_train_maps(self, images, edge_indices, edge_lens):
+        """Training-mode network: (B,3,H,W) images -> (class logits (B,h,w,ncls), regression (B,h,w,50)), NHWC,
+        differentiable (HIP forward + backward kernels; BN on batch statistics)."""
+        if self.compute_dtype != torch.float32:
+            raise NotImplementedError("training runs in fp32 mode (MODEL.COMPUTE_DTYPE fp32); bf16 training is a later round")
+        feat = self.backbone.forward_nhwc(images)
+        return self.heads.predictor.forward_train(feat, edge_indices, edge_lens)
+
     def device_targets(self, targets, device):
         """Device-side view of the per-image targets: (edge_indices, edge_lens, pad, calib, size, edge_rowmap)."""
         ei, el = stack_edge_fields(targets, device)

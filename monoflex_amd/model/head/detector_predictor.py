@@ -14,9 +14,9 @@ import numpy as np
 import torch
 from torch import nn
 
+from ... import autograd as AG
 from ... import lib as L
 from ... import ops
-from ..backbone.dla_dcn import _eval_only
 
 HM_LD = 64          # fp32 head map row: [0:3] class logits, [8:58] regression channels
 REG_OFF = 8
@@ -161,7 +161,8 @@ class _predictor(nn.Module):
     def forward_nhwc(self, features, edge_indices=None, edge_lens=None, edge_rowmap=None):
         """features (B,H,W,64) NHWC -> fp32 head map (B,H,W,64): [0:3] class logits (pre-sigmoid, after
         edge fusion), [8:58] the 50 regression channels.  edge_indices int32 (B,L,2) (x,y), edge_lens int32 (B,)."""
-        _eval_only(self)
+        if self.training:
+            raise RuntimeError("forward_nhwc is the fused eval path; training goes through forward_train")
         p = self._pack(features.dtype)
         hm, planar = ops.heads_fused(features, p, planar_classes=self.num_classes)
         self.last_cls_planar = planar                               # (B,3,H*W) class logits for the top-K kernel
@@ -179,10 +180,55 @@ class _predictor(nn.Module):
                 ops.edge_scatter_add(hm, choff, cout, o, edge_indices, edge_lens, planar=planar if choff == 0 else None)
         return hm
 
+    def forward_train(self, features, edge_indices=None, edge_lens=None):
+        """Training form (detector_predictor.py:125-169), unfused and differentiable: per branch
+        conv3x3 -> ABN(batch statistics, leaky 0.01) -> one 1x1 conv over the branch's stacked heads; edge fusion
+        gathers the two trunks at the border points.  Returns (class logits (B,H,W,ncls), regression (B,H,W,50))."""
+        B, H, W, _ = features.shape
+        trunks = [self.class_head] + list(self.reg_features)
+        lasts = [[self.class_head[2]]] + [list(h) for h in self.reg_heads]
+        feats, outs = [], []
+        for t, heads in zip(trunks, lasts):
+            f = AG.bn_act(AG.conv2d(features, t[0].weight, None, 1, 1), t[1], L.ACT_LEAKY)
+            w = heads[0].weight if len(heads) == 1 else torch.cat([h.weight for h in heads], 0)
+            b = heads[0].bias if len(heads) == 1 else torch.cat([h.bias for h in heads], 0)
+            feats.append(f)
+            outs.append(AG.conv2d(f, w, b, 1, 0))
+        cls, regs = outs[0], outs[1:]
+        if self.enable_edge_fusion:
+            if edge_indices is None:
+                raise ValueError("edge fusion is enabled: targets must carry edge_indices / edge_len")
+            oi, oj = self.offset_index
+            Lmax = edge_indices.shape[1]
+            pos = torch.arange(-1, Lmax + 1, device=features.device).clamp(0, Lmax - 1)      # replicate padding, k=3
+            xy = edge_indices[:, pos].long()
+            bidx = torch.arange(B, device=features.device).view(B, 1).expand(B, Lmax + 2)
+            new = []
+            for f, seq, base in ((feats[0], self.trunc_heatmap_conv, cls), (feats[1 + oi], self.trunc_offset_conv, regs[oi])):
+                e = f[bidx, xy[..., 1], xy[..., 0]].view(B, 1, Lmax + 2, self.head_conv)      # grid_sample at integer points
+                c1, bn, c3 = seq[0], seq[1], seq[3]
+                h1 = AG.bn_act(AG.conv2d(e, c1.weight.unsqueeze(2), c1.bias, 1, 0), bn,
+                               L.ACT_RELU if self.edge_fusion_relu else L.ACT_NONE)
+                o = AG.conv2d(h1, c3.weight.unsqueeze(2), c3.bias, 1, 0).view(B, Lmax, -1)
+                lo = 0 if base is cls else sum(self.regression_channel_cfg[oi][:oj])
+                co = o.shape[-1]
+                valid = torch.arange(Lmax, device=features.device).view(1, Lmax) < edge_lens.view(B, 1).long()
+                bi, li = valid.nonzero(as_tuple=True)
+                ys, xs = edge_indices[bi, li, 1].long(), edge_indices[bi, li, 0].long()
+                add = torch.zeros_like(base)
+                add[bi, ys, xs, lo:lo + co] = o[bi, li]                                       # '+=' on unique border pixels
+                new.append(base + add)
+            cls, regs[oi] = new[0], new[1]
+        return cls, torch.cat(regs, dim=3)
+
     def forward(self, features, targets):
         """Reference surface: features (B,64,H,W) (any strides) + targets -> {'cls','reg'} NCHW views."""
         x = features.permute(0, 2, 3, 1).contiguous()
         ei, el = stack_edge_fields(targets, x.device)
+        if self.training:
+            cls, reg = self.forward_train(x, ei, el)
+            cls = torch.sigmoid(cls).clamp(min=1e-4, max=1 - 1e-4)
+            return {'cls': cls.permute(0, 3, 1, 2), 'reg': reg.permute(0, 3, 1, 2)}
         hm = self.forward_nhwc(x, ei, el)
         cls = torch.sigmoid(hm[..., :self.num_classes]).clamp(min=1e-4, max=1 - 1e-4).permute(0, 3, 1, 2)
         return {'cls': cls, 'reg': hm[..., REG_OFF:REG_OFF + 50].permute(0, 3, 1, 2), 'hm_nhwc': hm, 'cls_planar': self.last_cls_planar}

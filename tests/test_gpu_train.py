@@ -1,0 +1,240 @@
+"""GPU gradient parity of the training path: every differentiable HIP operator against torch CPU autograd of the
+reference's layer (nn.Conv2d / BatchNorm2d / MaxPool2d / ConvTranspose2d / the oracle's DCNv2 restatement), then the
+whole network (train-mode BN) against the CPU oracle under a fixed linear surrogate loss.  fp32; tolerances are
+relative to the largest gradient entry of each tensor."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-20))
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,bias", [(16, 32, 3, 1, False), (32, 64, 3, 2, False), (64, 128, 1, 1, False),
+                                                    (64, 27, 3, 1, True), (256, 3, 1, 1, True), (256, 20, 1, 1, True)])
+def test_conv_grads(cin, cout, k, stride, bias):
+    from monoflex_amd import autograd as AG
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, cin, 20, 36, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    b = torch.randn(cout, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=k // 2)
+    r = torch.randn(yr.shape, generator=g)
+    (yr * r).sum().backward()
+    xd = _nhwc(x).to(DEV).requires_grad_()
+    wd = w.to(DEV).requires_grad_()
+    bd = b.to(DEV).requires_grad_() if bias else None
+    yd = AG.conv2d(xd, wd, bd, stride, k // 2)
+    assert _rel(yd.permute(0, 3, 1, 2), yr) < 1e-5
+    (yd * _nhwc(r).to(DEV)).sum().backward()
+    assert _rel(xd.grad.permute(0, 3, 1, 2), xr.grad) < 1e-5
+    assert _rel(wd.grad, wr.grad) < 1e-5
+    if bias:
+        assert _rel(bd.grad, br.grad) < 1e-5
+
+
+def test_conv1d_as_conv_grads():
+    """Edge-fusion Conv1d k=3 over an explicitly replicate-padded sequence (pad 0 in the kernel)."""
+    from monoflex_amd import autograd as AG
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 64, 1, 50, generator=g)
+    w = torch.randn(64, 64, 1, 3, generator=g) * 0.1
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = F.conv2d(xr, wr)
+    r = torch.randn(yr.shape, generator=g)
+    (yr * r).sum().backward()
+    xd, wd = _nhwc(x).to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    yd = AG.conv2d(xd, wd, None, 1, 0)
+    (yd * _nhwc(r).to(DEV)).sum().backward()
+    assert _rel(yd.permute(0, 3, 1, 2), yr) < 1e-5
+    assert _rel(xd.grad.permute(0, 3, 1, 2), xr.grad) < 1e-5 and _rel(wd.grad, wr.grad) < 1e-5
+
+
+def test_stem_conv_wgrad():
+    from monoflex_amd import autograd as AG
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 32, 64, generator=g)
+    w = (torch.randn(16, 3, 7, 7, generator=g) * 0.1)
+    wr = w.clone().requires_grad_()
+    yr = F.conv2d(x, wr, padding=3)
+    r = torch.randn(yr.shape, generator=g)
+    (yr * r).sum().backward()
+    wd = w.to(DEV).requires_grad_()
+    yd = AG.StemConvFn.apply(x.to(DEV), wd, torch.float32)
+    (yd * _nhwc(r).to(DEV)).sum().backward()
+    assert _rel(yd.permute(0, 3, 1, 2), yr) < 1e-5 and _rel(wd.grad, wr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("act,res", [("relu", False), ("relu", True), ("leaky", False), ("none", False)])
+def test_bn_act_grads(act, res):
+    from monoflex_amd import autograd as AG
+    from monoflex_amd import lib as L
+    g = torch.Generator().manual_seed(4)
+    C = 64
+    x = torch.randn(3, C, 12, 20, generator=g) * 2 + 0.5
+    rs = torch.randn(3, C, 12, 20, generator=g) if res else None
+    bn_r, bn_d = torch.nn.BatchNorm2d(C, momentum=0.1), torch.nn.BatchNorm2d(C, momentum=0.1).to(DEV)
+    with torch.no_grad():
+        bn_r.weight.copy_(torch.rand(C, generator=g) + 0.5); bn_r.bias.copy_(torch.randn(C, generator=g))
+    bn_d.load_state_dict(bn_r.state_dict())
+    xr = x.clone().requires_grad_()
+    rr = rs.clone().requires_grad_() if res else None
+    t = bn_r(xr)
+    if res:
+        t = t + rr
+    yr = {"relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.01), "none": lambda v: v}[act](t)
+    r = torch.randn(yr.shape, generator=g)
+    (yr * r).sum().backward()
+    xd = _nhwc(x).to(DEV).requires_grad_()
+    rd = _nhwc(rs).to(DEV).requires_grad_() if res else None
+    yd = AG.bn_act(xd, bn_d, {"relu": L.ACT_RELU, "leaky": L.ACT_LEAKY, "none": L.ACT_NONE}[act], rd)
+    (yd * _nhwc(r).to(DEV)).sum().backward()
+    assert _rel(yd.permute(0, 3, 1, 2), yr) < 1e-5
+    assert _rel(xd.grad.permute(0, 3, 1, 2), xr.grad) < 1e-4
+    assert _rel(bn_d.weight.grad, bn_r.weight.grad) < 1e-4 and _rel(bn_d.bias.grad, bn_r.bias.grad) < 1e-4
+    assert _rel(bn_d.running_mean, bn_r.running_mean) < 1e-5 and _rel(bn_d.running_var, bn_r.running_var) < 1e-5
+    if res:
+        assert _rel(rd.grad.permute(0, 3, 1, 2), rr.grad) < 1e-5
+
+
+def test_maxpool_and_upsample_grads():
+    from monoflex_amd import autograd as AG
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 16, 24, generator=g)
+    xr = x.clone().requires_grad_()
+    yr = F.max_pool2d(xr, 2, 2)
+    r = torch.randn(yr.shape, generator=g)
+    (yr * r).sum().backward()
+    xd = _nhwc(x).to(DEV).requires_grad_()
+    yd = AG.MaxPool2x2Fn.apply(xd)
+    (yd * _nhwc(r).to(DEV)).sum().backward()
+    assert _rel(yd.permute(0, 3, 1, 2), yr) == 0 and _rel(xd.grad.permute(0, 3, 1, 2), xr.grad) == 0
+    for f in (2, 4, 8):
+        C = 64
+        x = torch.randn(2, C, 6, 10, generator=g)
+        w = torch.rand(C, 1, 2 * f, 2 * f, generator=g)
+        sk = torch.randn(2, C, 6 * f, 10 * f, generator=g)
+        xr, wr, sr = x.clone().requires_grad_(), w.clone().requires_grad_(), sk.clone().requires_grad_()
+        yr = F.conv_transpose2d(xr, wr, stride=f, padding=f // 2, groups=C) + sr
+        r = torch.randn(yr.shape, generator=g)
+        (yr * r).sum().backward()
+        xd, wd, sd = _nhwc(x).to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), _nhwc(sk).to(DEV).requires_grad_()
+        yd = AG.UpsampleAddFn.apply(xd, wd, sd, f)
+        (yd * _nhwc(r).to(DEV)).sum().backward()
+        assert _rel(yd.permute(0, 3, 1, 2), yr) < 1e-5
+        assert _rel(xd.grad.permute(0, 3, 1, 2), xr.grad) < 1e-5 and _rel(wd.grad, wr.grad) < 1e-5
+        assert _rel(sd.grad.permute(0, 3, 1, 2), sr.grad) == 0
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64), (512, 256)])
+def test_dcn_train_grads_vs_oracle(cin, cout):
+    """DCN module, training form: offset conv -> DCNv2, gradients to input and all four parameters, against the C
+    restatement of the reference's CPU backward (oracle/dcn_v2_ref.c)."""
+    from oracle import monoflex_ref as R
+    from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCN
+    g = torch.Generator().manual_seed(6)
+    ref = R.DCN(cin, cout)
+    dev = DCN(cin, cout, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(ref.weight.shape, generator=g) * 0.05)
+        ref.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        ref.conv_offset_mask.weight.copy_(torch.randn(ref.conv_offset_mask.weight.shape, generator=g) * 0.02)
+        ref.conv_offset_mask.bias.copy_(torch.randn(27, generator=g) * 0.5)
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.to(DEV).train()
+    x = torch.randn(2, cin, 12, 20, generator=g)
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    r = torch.randn(yr.shape, generator=g)
+    (yr * r).sum().backward()
+    xd = _nhwc(x).to(DEV).requires_grad_()
+    yd = dev.forward_nhwc_train(xd)
+    (yd * _nhwc(r).to(DEV)).sum().backward()
+    assert _rel(yd.permute(0, 3, 1, 2), yr) < 1e-4
+    assert _rel(xd.grad.permute(0, 3, 1, 2), xr.grad) < 2e-4
+    for n, p in dev.named_parameters():
+        pr = dict(ref.named_parameters())[n]
+        assert _rel(p.grad, pr.grad) < 2e-4, n
+
+
+def _models(out_w, out_h):
+    from monoflex_amd import synthetic as S
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.model.detector import KeypointDetector
+    from oracle import monoflex_ref as R
+    cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"))
+    cfg.MODEL.PRETRAIN = False
+    cfg.MODEL.COMPUTE_DTYPE = "fp32"
+    cfg.INPUT.WIDTH_TRAIN, cfg.INPUT.HEIGHT_TRAIN = out_w * 4, out_h * 4
+    m = KeypointDetector(cfg)
+    sd = S.synthetic_state_dict(m.state_dict(), seed=3, cls_bias=-1.0)
+    m.load_state_dict(sd)
+    ref = R.KeypointDetectorRef()
+    ref.load_state_dict(sd)
+    return m.to(DEV).train(), ref.train()
+
+
+def test_network_gradients_vs_oracle():
+    """Whole network in training mode (batch-statistics BN everywhere, DCN offsets learned): outputs, every parameter
+    gradient and the updated BN running statistics against the CPU oracle, linear surrogate loss."""
+    from monoflex_amd import synthetic as S
+    out_w, out_h = 64, 32
+    m, ref = _models(out_w, out_h)
+    B = 2
+    imgs = S.synthetic_images(B, out_h * 4, out_w * 4, seed=11)
+    eidx, elen = _edges(B, out_w, out_h)
+    g = torch.Generator().manual_seed(12)
+    rc = torch.randn(B, 3, out_h, out_w, generator=g)
+    rr = torch.randn(B, 50, out_h, out_w, generator=g)
+    taps = {}
+    om = ref.forward_maps(imgs, eidx.long(), elen.long(), taps)
+    loss_r = (taps['cls_logits'] * rc).sum() + (om['reg'] * rr).sum()
+    # oracle logits tap is a clone taken before the sigmoid: differentiable
+    loss_r.backward()
+    cls, reg = m.forward_train_maps(imgs.to(DEV), eidx.to(DEV), elen.to(DEV))
+    loss_d = (cls * _nhwc(rc).to(DEV)).sum() + (reg * _nhwc(rr).to(DEV)).sum()
+    loss_d.backward()
+    assert _rel(cls.permute(0, 3, 1, 2), taps['cls_logits']) < 1e-3
+    assert _rel(reg.permute(0, 3, 1, 2), om['reg']) < 1e-3
+    refp = dict(ref.named_parameters())
+    worst, dead = [], []
+    for n, p in m.named_parameters():
+        gr = refp[n].grad
+        if gr is None:
+            dead.append(n)
+            assert p.grad is None, n
+            continue
+        assert p.grad is not None, n
+        worst.append((_rel(p.grad, gr), n))
+    worst.sort(reverse=True)
+    assert len(dead) == 6, dead                      # outer level3/level4 project conv+BN
+    assert worst[0][0] < 5e-3, worst[:8]
+    refb = dict(ref.named_buffers())
+    for n, b in m.named_buffers():
+        if n.endswith("running_mean") or n.endswith("running_var"):
+            if any(n.startswith(d.rsplit(".", 1)[0]) for d in dead):
+                continue
+            assert _rel(b, refb[n]) < 1e-3, n
+
+
+def _edges(B, out_w, out_h):
+    from monoflex_amd import synthetic as S
+    ts = [S.synthetic_target(out_w, out_h, orig_size=(out_w * 4 - 8 * (i + 1), out_h * 4 - 4 * (i + 1))) for i in range(B)]
+    ei = torch.stack([torch.as_tensor(np.asarray(t["edge_indices"])) for t in ts]).to(torch.int32)
+    el = torch.as_tensor([int(t["edge_len"]) for t in ts], dtype=torch.int32)
+    return ei, el
