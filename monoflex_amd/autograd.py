@@ -90,6 +90,7 @@ class Conv2dFn(Function):
                 wt = torch.cat((wt, wt.new_zeros(Cin, Cp - Cout, kh, kw)), dim=1)
             cin_pad = _pad_channels(Cin, x.dtype)
             pt = ops.pack_conv(wt.contiguous(), x.dtype, None, None, stride=1, pad=pad, act=L.ACT_NONE, cout=cin_pad)
+            pt.pad_h, pt.pad_w = kh - 1 - pad, kw - 1 - pad                       # 'full' correlation of the flipped kernel
             g = dy
             if stride == 2:
                 g = torch.empty((B, H, W, Cp), dtype=dy.dtype, device=dy.device)
@@ -104,6 +105,43 @@ class Conv2dFn(Function):
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy)[:Cout]
         return dx, dw, db, None, None
+
+
+class CatConv1x1Fn(Function):
+    """Root (dla_dcn.py:203-220): y = conv1x1(cat(xs, channel axis), weight) without materialising the concat.
+    Backward per source i: dx_i = dy @ W[:, seg_i], dW[:, seg_i] = dy^T x_i."""
+
+    @staticmethod
+    def forward(ctx, weight, *xs):
+        xs = [_c(t) for t in xs]
+        chans = tuple(t.shape[3] for t in xs)
+        Cout = weight.shape[0]
+        one = torch.ones(Cout, device=weight.device)
+        p = ops.pack_cat(weight, xs[0].dtype, one, torch.zeros_like(one), chans, act=L.ACT_NONE)
+        ctx.save_for_backward(weight, *xs)
+        return ops.cat_conv1x1(xs, p)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        weight, *xs = ctx.saved_tensors
+        dy = _c(dy)
+        Cout = weight.shape[0]
+        w2 = weight.detach().reshape(Cout, -1)
+        dws, dxs, off = [], [], 0
+        for i, x in enumerate(xs):
+            C = x.shape[3]
+            seg = w2[:, off:off + C]
+            if ctx.needs_input_grad[1 + i]:
+                pt = ops.pack_conv(seg.t().reshape(C, Cout, 1, 1).contiguous(), x.dtype, None, None, stride=1, pad=0, act=L.ACT_NONE)
+                dxs.append(ops.conv2d(dy, pt))
+            else:
+                dxs.append(None)
+            if ctx.needs_input_grad[0]:
+                dws.append(_wgrad(x, dy, 1, 1, 1, 0, x.shape[1], x.shape[2]).view(Cout, C))
+            off += C
+        dw = torch.cat(dws, 1).view_as(weight).to(weight.dtype) if ctx.needs_input_grad[0] else None
+        return (dw, *dxs)
 
 
 class StemConvFn(Function):

@@ -91,7 +91,7 @@ class Root(nn.Module):
 
     def forward(self, *xs):
         if self.training:
-            return _train_conv_bn(torch.cat(xs, dim=3), self.conv, self.bn, L.ACT_RELU)
+            return AG.bn_act(AG.CatConv1x1Fn.apply(self.conv.weight, *xs), self.bn, L.ACT_RELU)
         packs = self.__dict__.setdefault("_packs", {})
         chans = tuple(t.shape[3] for t in xs)
         k = (chans, xs[0].dtype)

@@ -62,6 +62,8 @@ class DCN(nn.Module):
         out = self.conv_offset_mask(x)                          # dcn_v2.py:118-128
         offset = out[:, :18]                                    # chunk(3)+cat(o1,o2) == first 18 channels
         mask = torch.sigmoid(out[:, 18:27])
+        if getattr(self, "torch_form", False):                  # dtype-generic autograd form (fp64 ground truth in tests)
+            return dcn_ref.dcn_v2_torch(x, offset, mask, self.weight, self.bias, 1, 1, 1)
         return dcn_ref.dcn_v2_conv(x, offset, mask, self.weight, self.bias, 1, 1, 1, 1)
 
 
@@ -289,7 +291,7 @@ class Predictor(nn.Module):
             for j, out_head in enumerate(self.reg_heads[i]):
                 output_reg = out_head(reg_feature)
                 if [i, j] == self.offset_index:                              # :136-158
-                    grid = edge_indices.view(b, -1, 1, 2).float()
+                    grid = edge_indices.view(b, -1, 1, 2).to(features.dtype)
                     grid = torch.stack((grid[..., 0] / (w - 1) * 2 - 1, grid[..., 1] / (h - 1) * 2 - 1), -1)
                     fused = torch.cat((feature_cls, reg_feature), dim=1)
                     edge_feat = F.grid_sample(fused, grid, align_corners=True).squeeze(-1)

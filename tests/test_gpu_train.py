@@ -189,42 +189,67 @@ def _models(out_w, out_h):
     return m.to(DEV).train(), ref.train()
 
 
+def _oracle_grads(ref, imgs, eidx, elen, rc, rr):
+    taps = {}
+    om = ref.forward_maps(imgs, eidx.long(), elen.long(), taps)
+    ((taps['cls_logits'] * rc).sum() + (om['reg'] * rr).sum()).backward()      # logits tap: clone taken before the sigmoid
+    return taps['cls_logits'].detach(), om['reg'].detach(), {n: p.grad for n, p in ref.named_parameters()}
+
+
 def test_network_gradients_vs_oracle():
-    """Whole network in training mode (batch-statistics BN everywhere, DCN offsets learned): outputs, every parameter
-    gradient and the updated BN running statistics against the CPU oracle, linear surrogate loss."""
+    """Whole network in training mode (batch-statistics BN everywhere, DCN offsets learned) under a linear surrogate loss.
+
+    With ~100 ReLU/BN layers an fp32 gradient is only reproducible up to rounding-induced ReLU sign flips, so the bar is
+    set by measurement rather than by a constant: an fp64 evaluation of the oracle (autograd DCN form) is the ground
+    truth, the fp32 CPU oracle (C restatement of the reference backward) shows what fp32 rounding costs, and the HIP path
+    must be as close to the truth as that (within 3x, per-tensor error relative to the tensor's largest entry), with every
+    tensor's direction matching (cosine > 0.99)."""
+    import copy
     from monoflex_amd import synthetic as S
+    from oracle import monoflex_ref as R
     out_w, out_h = 64, 32
     m, ref = _models(out_w, out_h)
+    ref64 = copy.deepcopy(ref).double()
+    for mod in ref64.modules():
+        if isinstance(mod, R.DCN):
+            mod.torch_form = True
     B = 2
     imgs = S.synthetic_images(B, out_h * 4, out_w * 4, seed=11)
     eidx, elen = _edges(B, out_w, out_h)
     g = torch.Generator().manual_seed(12)
     rc = torch.randn(B, 3, out_h, out_w, generator=g)
     rr = torch.randn(B, 50, out_h, out_w, generator=g)
-    taps = {}
-    om = ref.forward_maps(imgs, eidx.long(), elen.long(), taps)
-    loss_r = (taps['cls_logits'] * rc).sum() + (om['reg'] * rr).sum()
-    # oracle logits tap is a clone taken before the sigmoid: differentiable
-    loss_r.backward()
+    c64, r64, g64 = _oracle_grads(ref64, imgs.double(), eidx, elen, rc.double(), rr.double())
+    c32, r32, g32 = _oracle_grads(ref, imgs, eidx, elen, rc, rr)
     cls, reg = m.forward_train_maps(imgs.to(DEV), eidx.to(DEV), elen.to(DEV))
-    loss_d = (cls * _nhwc(rc).to(DEV)).sum() + (reg * _nhwc(rr).to(DEV)).sum()
-    loss_d.backward()
-    assert _rel(cls.permute(0, 3, 1, 2), taps['cls_logits']) < 1e-3
-    assert _rel(reg.permute(0, 3, 1, 2), om['reg']) < 1e-3
-    refp = dict(ref.named_parameters())
-    worst, dead = [], []
+    ((cls * _nhwc(rc).to(DEV)).sum() + (reg * _nhwc(rr).to(DEV)).sum()).backward()
+    f_h = max(_rel(cls.permute(0, 3, 1, 2), c64), _rel(reg.permute(0, 3, 1, 2), r64))
+    f_32 = max(_rel(c32, c64), _rel(r32, r64))
+    e_h, e_32, cos, dead = [], [], [], []
     for n, p in m.named_parameters():
-        gr = refp[n].grad
-        if gr is None:
+        t = g64[n]
+        if t is None:
             dead.append(n)
-            assert p.grad is None, n
+            assert p.grad is None and g32[n] is None, n
             continue
         assert p.grad is not None, n
-        worst.append((_rel(p.grad, gr), n))
-    worst.sort(reverse=True)
+        t = t.float()
+        scale = float(t.abs().max())
+        if scale < 1e-2:            # conv bias feeding a batch-statistics BN: true gradient is exactly zero, both hold noise
+            assert float(p.grad.abs().max()) < 1e-1, n
+            continue
+        gh = p.grad.detach().cpu().float()
+        e_h.append(float((gh - t).abs().max()) / scale)
+        e_32.append(float((g32[n] - t).abs().max()) / scale)
+        cos.append((float(F.cosine_similarity(gh.flatten(), t.flatten(), dim=0)), n))
+    e_h, e_32 = np.array(e_h), np.array(e_32)
+    print("forward err vs fp64: hip %.2e cpu-fp32 %.2e | grad err vs fp64: hip max %.2e med %.2e, cpu-fp32 max %.2e med %.2e, "
+          "min cos %.5f" % (f_h, f_32, e_h.max(), np.median(e_h), e_32.max(), np.median(e_32), min(cos)[0]))
     assert len(dead) == 6, dead                      # outer level3/level4 project conv+BN (SURVEY App. C item 14)
-    assert worst[0][0] < 5e-3, worst[:8]
-    refb = dict(ref.named_buffers())
+    assert f_h <= max(3 * f_32, 1e-4), (f_h, f_32)
+    assert e_h.max() <= 3 * e_32.max() and np.median(e_h) <= 3 * np.median(e_32), (e_h.max(), e_32.max())
+    assert min(cos)[0] > 0.99, min(cos)
+    refb = dict(ref64.named_buffers())
     for n, b in m.named_buffers():
         if n.endswith("running_mean") or n.endswith("running_var"):
             if any(n.startswith(d.rsplit(".", 1)[0]) for d in dead):
