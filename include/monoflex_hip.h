@@ -206,6 +206,13 @@ int mfx_bn_act_fwd(const void* x, const float* scale, const float* shift, const 
  * sg[c] = sum g (= dbeta), sgx[c] = sum g*xhat (= dgamma), dx, and dres = g (optional); g = da * act'(a) */
 int mfx_bn_act_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
                    float* sg, float* sgx, void* dx, void* dres, long M, int C, int act, int dtype, void* stream);
+/* the two halves of mfx_bn_act_bwd, for synchronised BN (reference tools/plain_train_net.py:131-132, SyncBatchNorm):
+ * reduce -> all-reduce(sg, sgx) across ranks -> apply with M_total = rows summed over ranks */
+int mfx_bn_bwd_reduce(const void* x, const void* a, const void* da, const float* mean, const float* rstd,
+                      float* sg, float* sgx, long M, int C, int act, int dtype, void* stream);
+int mfx_bn_bwd_apply(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
+                     const float* sg, const float* sgx, void* dx, void* dres, long M, long M_total, int C, int act,
+                     int dtype, void* stream);
 int mfx_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream);
 /* depthwise deconv backward: dx (input-sized) and dw fp32 [2f*2f][C] (overwritten) */
 int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* dy, void* dx, float* dw,

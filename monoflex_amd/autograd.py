@@ -171,20 +171,37 @@ class StemConvFn(Function):
         return None, dw, None
 
 
+def _sync_group(sync):
+    """Process group for synchronised BN, or None (single process / local statistics)."""
+    import torch.distributed as dist
+    if sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.group.WORLD
+    return None
+
+
 class BNActFn(Function):
-    """Train-mode BatchNorm (batch statistics, biased variance) + activation (+ residual before the activation)."""
+    """Train-mode BatchNorm (batch statistics, biased variance) + activation (+ residual before the activation).
+    With `sync` and an initialised multi-rank process group the statistics are those of the global batch
+    (SyncBatchNorm, tools/plain_train_net.py:131-132): one all-reduce of [sum, sumsq, rows] forward and one of
+    [sum g, sum g*xhat] backward, 2C(+1) floats each over RCCL."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, res, act, momentum, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, res, act, momentum, eps, sync):
         x = _c(x)
         C = x.shape[-1]
         M = x.numel() // C
-        s = torch.empty(C, dtype=torch.float32, device=x.device)
-        q = torch.empty_like(s)
+        st = torch.empty(2 * C + 1, dtype=torch.float32, device=x.device)
         lib_ = L.load()
-        L.check(lib_.mfx_bn_stats(_ptr(x), _ptr(s), _ptr(q), M, C, _dt(x.dtype), _stream()), "mfx_bn_stats")
-        mean = s / M
-        var = (q / M - mean * mean).clamp_(min=0.0)
+        L.check(lib_.mfx_bn_stats(_ptr(x), _ptr(st), st.data_ptr() + 4 * C, M, C, _dt(x.dtype), _stream()), "mfx_bn_stats")
+        group = _sync_group(sync)
+        Mt = M
+        if group is not None:
+            import torch.distributed as dist
+            st[2 * C] = float(M)
+            dist.all_reduce(st, group=group)
+            Mt = M * dist.get_world_size(group)                # equal per-rank batches (weak scaling), no host sync
+        mean = st[:C] / Mt
+        var = (st[C:2 * C] / Mt - mean * mean).clamp_(min=0.0)
         rstd = torch.rsqrt(var + eps)
         g32, b32 = gamma.detach().float(), beta.detach().float()
         scale = (g32 * rstd).contiguous()
@@ -192,30 +209,39 @@ class BNActFn(Function):
         if running_mean is not None:
             with torch.no_grad():
                 running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var * (M / max(M - 1, 1)), alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var * (Mt / max(Mt - 1, 1)), alpha=momentum)
         y = torch.empty_like(x)
         res_c = _c(res) if res is not None else None
         L.check(lib_.mfx_bn_act_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res_c), _ptr(y), M, C, act, _dt(x.dtype), _stream()),
                 "mfx_bn_act_fwd")
         ctx.save_for_backward(x, y, mean.contiguous(), rstd.contiguous(), g32.contiguous())
-        ctx.cfg = (act, res is not None)
+        ctx.cfg = (act, res is not None, group, Mt)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, da):
         x, y, mean, rstd, g32 = ctx.saved_tensors
-        act, has_res = ctx.cfg
+        act, has_res, group, Mt = ctx.cfg
         da = _c(da)
         C = x.shape[-1]
         M = x.numel() // C
-        sg = torch.empty(C, dtype=torch.float32, device=x.device)
-        sgx = torch.empty_like(sg)
+        sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        sg, sgx = sums[:C], sums[C:]
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        L.check(L.load().mfx_bn_act_bwd(_ptr(x), _ptr(y), _ptr(da), _ptr(mean), _ptr(rstd), _ptr(g32), _ptr(sg), _ptr(sgx),
-                                        _ptr(dx), _ptr(dres), M, C, act, _dt(x.dtype), _stream()), "mfx_bn_act_bwd")
-        return dx, sgx, sg, None, None, dres, None, None, None
+        lib_ = L.load()
+        L.check(lib_.mfx_bn_bwd_reduce(_ptr(x), _ptr(y), _ptr(da), _ptr(mean), _ptr(rstd), _ptr(sg), sums.data_ptr() + 4 * C,
+                                       M, C, act, _dt(x.dtype), _stream()), "mfx_bn_bwd_reduce")
+        if group is not None:
+            import torch.distributed as dist
+            local = sums.clone()                                # parameter gradients stay rank-local: DDP averages them
+            dist.all_reduce(sums, group=group)
+        else:
+            local = sums
+        L.check(lib_.mfx_bn_bwd_apply(_ptr(x), _ptr(y), _ptr(da), _ptr(mean), _ptr(rstd), _ptr(g32), _ptr(sg), sums.data_ptr() + 4 * C,
+                                      _ptr(dx), _ptr(dres), M, Mt, C, act, _dt(x.dtype), _stream()), "mfx_bn_bwd_apply")
+        return dx, local[C:].clone(), local[:C].clone(), None, None, dres, None, None, None, None
 
 
 class MaxPool2x2Fn(Function):
@@ -312,9 +338,11 @@ def conv2d(x, weight, bias=None, stride=1, pad=0):
     return y if y.shape[-1] == weight.shape[0] else y[..., :weight.shape[0]]
 
 
-def bn_act(x, bn, act, res=None):
-    """Train-mode BN module `bn` (+act, +res) on an NHWC tensor; updates bn.running_* like nn.BatchNorm2d."""
+def bn_act(x, bn, act, res=None, sync=None):
+    """Train-mode BN module `bn` (+act, +res) on an NHWC tensor; updates bn.running_* like nn.BatchNorm2d.
+    sync=None follows the module's `sync_bn` attribute (set by engine.trainer.convert_sync_batchnorm)."""
     mom = bn.momentum if bn.momentum is not None else 0.1
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, act, mom, bn.eps)
+    return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, act, mom, bn.eps,
+                         bool(getattr(bn, 'sync_bn', False)) if sync is None else sync)

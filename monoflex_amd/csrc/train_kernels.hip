@@ -393,9 +393,9 @@ extern "C" int mfx_bn_act_fwd(const void* x, const float* scale, const float* sh
     return MFX_OK;
 }
 
-extern "C" int mfx_bn_act_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
-                              float* sg, float* sgx, void* dx, void* dres, long M, int C, int act, int dtype, void* stream) {
-    if (!x || !da || !mean || !rstd || !gamma || !sg || !sgx || !dx || (act != MFX_ACT_NONE && !a)) return mfx_fail(MFX_ERR_ARG, "bn_act_bwd: null pointer");
+extern "C" int mfx_bn_bwd_reduce(const void* x, const void* a, const void* da, const float* mean, const float* rstd,
+                                 float* sg, float* sgx, long M, int C, int act, int dtype, void* stream) {
+    if (!x || !da || !mean || !rstd || !sg || !sgx || (act != MFX_ACT_NONE && !a)) return mfx_fail(MFX_ERR_ARG, "bn_bwd_reduce: null pointer");
     int rc = bn_check(C, dtype); if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     MFX_HIP_CHECK(hipMemsetAsync(sg, 0, (size_t)C * sizeof(float), st));
@@ -403,15 +403,35 @@ extern "C" int mfx_bn_act_bwd(const void* x, const void* a, const void* da, cons
     if (M == 0) return MFX_OK;
     const int rows = 1024;
     const size_t smem = (size_t)2 * C * sizeof(float);
-    const long chunks = M * (C / (dtype == MFX_BF16 ? 8 : 4));
-    const float invM = 1.f / (float)M;
     DISPATCH_T(dtype,
-        { hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sg, sgx);
-          hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, TR_GRID(chunks), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, gamma, sg, sgx, invM, (float*)dx, (float*)dres, chunks, C, act); },
-        { hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, M, C, rows, act, sg, sgx);
-          hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, TR_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, gamma, sg, sgx, invM, (bf16_t*)dx, (bf16_t*)dres, chunks, C, act); });
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sg, sgx),
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, M, C, rows, act, sg, sgx));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
+}
+
+extern "C" int mfx_bn_bwd_apply(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
+                                const float* sg, const float* sgx, void* dx, void* dres, long M, long M_total, int C, int act,
+                                int dtype, void* stream) {
+    if (!x || !da || !mean || !rstd || !gamma || !sg || !sgx || !dx || (act != MFX_ACT_NONE && !a)) return mfx_fail(MFX_ERR_ARG, "bn_bwd_apply: null pointer");
+    int rc = bn_check(C, dtype); if (rc) return rc;
+    if (M == 0) return MFX_OK;
+    if (M_total < M) return mfx_fail(MFX_ERR_ARG, "bn_bwd_apply: M_total < M");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long chunks = M * (C / (dtype == MFX_BF16 ? 8 : 4));
+    const float invM = 1.f / (float)M_total;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, TR_GRID(chunks), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, gamma, sg, sgx, invM, (float*)dx, (float*)dres, chunks, C, act),
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, TR_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, gamma, sg, sgx, invM, (bf16_t*)dx, (bf16_t*)dres, chunks, C, act));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_bn_act_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
+                              float* sg, float* sgx, void* dx, void* dres, long M, int C, int act, int dtype, void* stream) {
+    int rc = mfx_bn_bwd_reduce(x, a, da, mean, rstd, sg, sgx, M, C, act, dtype, stream);
+    if (rc) return rc;
+    return mfx_bn_bwd_apply(x, a, da, mean, rstd, gamma, sg, sgx, dx, dres, M, M, C, act, dtype, stream);
 }
 
 extern "C" int mfx_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream) {

@@ -1,0 +1,55 @@
+"""One optimisation step and its data-parallel wrapping (reference engine/trainer.py:101-126,
+tools/plain_train_net.py:128-137).
+
+Data parallelism: one process per GPU, gradients averaged by torch DDP's bucketed all-reduce over RCCL, overlapped
+with the backward kernels.  The reference wraps with find_unused_parameters=True because six parameters (the outer
+level3/level4 `project` conv + BN, dead in DLA's Tree.forward) never receive a gradient, which makes DDP walk the
+autograd graph every iteration; here those six are excluded statically, so no per-iteration graph traversal happens
+and no bucket ever waits for them."""
+import torch
+
+DEAD_PARAMETER_SUFFIXES = ("base.level3.project.0.weight", "base.level3.project.1.weight", "base.level3.project.1.bias",
+                           "base.level4.project.0.weight", "base.level4.project.1.weight", "base.level4.project.1.bias")
+
+
+def dead_parameter_names(model):
+    """Names of the parameters that are unreachable from the loss, plus the buffers of their BN."""
+    names = [n for n, _ in model.named_parameters() if n.endswith(DEAD_PARAMETER_SUFFIXES)]
+    stems = {n.rsplit(".", 1)[0] for n in names}
+    names += [n for n, _ in model.named_buffers() if n.rsplit(".", 1)[0] in stems]
+    return names
+
+
+def convert_sync_batchnorm(model):
+    """Mark the BatchNorm modules the reference's SyncBatchNorm.convert_sync_batchnorm would convert
+    (tools/plain_train_net.py:131-132): every nn.BatchNorm1d/2d except the heads' InPlaceABN (upstream's InPlaceABN is
+    not a _BatchNorm subclass, so the nine head ABNs keep rank-local statistics)."""
+    from ..model.head.detector_predictor import InPlaceABN
+    n = 0
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and not isinstance(m, InPlaceABN):
+            m.sync_bn = True
+            n += 1
+    return n
+
+
+def wrap_data_parallel(model, device_ids=None, bucket_cap_mb=25):
+    """DistributedDataParallel(broadcast_buffers=False) with the dead parameters ignored instead of searched for."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    DDP._set_params_and_buffers_to_ignore_for_model(model, dead_parameter_names(model))
+    return DDP(model, device_ids=device_ids, broadcast_buffers=False, find_unused_parameters=False,
+               bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+
+
+def train_step(model, optimizer, images, targets, grad_norm_clip=-1.0, scheduler=None):
+    """trainer.py:109-126: forward -> summed loss -> zero_grad -> backward (+DDP all-reduce) -> clip -> step."""
+    loss_dict, log_loss_dict = model(images, targets)
+    losses = sum(loss_dict.values())
+    optimizer.zero_grad(set_to_none=True)
+    losses.backward()
+    if grad_norm_clip > 0:
+        torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], grad_norm_clip)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return losses.detach(), loss_dict, log_loss_dict

@@ -74,6 +74,8 @@ SYMBOLS = {
     "mfx_bn_stats": (_I, [_P, _P, _P, ctypes.c_long, _I, _I, _P]),
     "mfx_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_act_bwd": (_I, [_P] * 10 + [ctypes.c_long, _I, _I, _I, _P]),
+    "mfx_bn_bwd_reduce": (_I, [_P] * 7 + [ctypes.c_long, _I, _I, _I, _P]),
+    "mfx_bn_bwd_apply": (_I, [_P] * 10 + [ctypes.c_long, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_maxpool2x2_bwd_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mfx_upsample_bwd_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_zero_insert2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

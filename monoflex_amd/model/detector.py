@@ -65,8 +65,10 @@ class KeypointDetector(nn.Module):
         images = to_image_list(images)
         if not images.tensors.is_cuda:
             raise RuntimeError("KeypointDetector (HIP build) needs CUDA/HIP tensors: there is no CPU fallback")
-        if self.training:
-            raise NotImplementedError("training path (loss + backward kernels + DP all-reduce) is not built yet")
+        if self.training:                                           # detector.py:30-33 -> (loss_dict, log_loss_dict)
+            if self.compute_dtype != torch.float32:
+                raise NotImplementedError("training runs in fp32 mode (MODEL.COMPUTE_DTYPE fp32)")
+            return self.heads(self.backbone(images.tensors), targets)
         with torch.no_grad():
             features = self.backbone(images.tensors)
             return self.heads(features, targets, test=self.test)

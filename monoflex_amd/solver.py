@@ -1,0 +1,44 @@
+"""Optimizer / schedule of the training-step contract (reference solver/__init__.py:10-92, engine/trainer.py:109-126).
+
+AdamW(lr 3e-4, betas (0.9, 0.99), weight decay 1e-5); parameters whose name contains "bias" run at
+BASE_LR * BIAS_LR_FACTOR.  The reference builds one param-group per parameter (280 groups -> 280 separate foreach
+launches); groups with equal hyper-parameters are arithmetically identical when merged, so two groups are built
+(weights / biases), which lets torch run one fused multi-tensor AdamW kernel per group."""
+import torch
+
+
+def get_model_params(model, cfg, per_parameter_groups=False):
+    base_lr = cfg.SOLVER.BASE_LR
+    bias_lr = max(base_lr, base_lr * cfg.SOLVER.BIAS_LR_FACTOR)
+    if per_parameter_groups:                                         # the reference's literal layout
+        return [{"params": [p], "lr": bias_lr if "bias" in k else base_lr} for k, p in model.named_parameters() if p.requires_grad]
+    w = [p for k, p in model.named_parameters() if p.requires_grad and "bias" not in k]
+    b = [p for k, p in model.named_parameters() if p.requires_grad and "bias" in k]
+    return [{"params": w, "lr": base_lr}, {"params": b, "lr": bias_lr}]
+
+
+def build_optimizer(model, cfg, per_parameter_groups=False):
+    s = cfg.SOLVER
+    params = get_model_params(model, cfg, per_parameter_groups)
+    on_gpu = any(p.is_cuda for g in params for p in g["params"])
+    if s.OPTIMIZER == "adamw":
+        return torch.optim.AdamW(params, lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY, betas=(0.9, 0.99), fused=on_gpu or None)
+    if s.OPTIMIZER == "adam":
+        return torch.optim.Adam(params, lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY, betas=(0.9, 0.99), fused=on_gpu or None)
+    if s.OPTIMIZER == "sgd":
+        return torch.optim.SGD(params, lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY, momentum=s.get("MOMENTUM", 0.9))
+    raise NotImplementedError("SOLVER.OPTIMIZER %r (adam_onecycle's fastai wrapper is not part of the adamw training contract)" % s.OPTIMIZER)
+
+
+def build_scheduler(optimizer, cfg, iters_per_epoch=1, last_epoch=-1):
+    """Step decay by LR_DECAY at each epoch in DECAY_EPOCH_STEPS (solver/__init__.py:64-75, stepped per iteration)."""
+    steps = [e * iters_per_epoch for e in cfg.SOLVER.DECAY_EPOCH_STEPS]
+    decay = cfg.SOLVER.LR_DECAY
+
+    def factor(it):
+        f = 1.0
+        for s in steps:
+            if it >= s:
+                f *= decay
+        return f
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, factor, last_epoch=last_epoch)

@@ -66,3 +66,19 @@ def make_test_target(tgt):
     t.add_field("edge_len", tgt["edge_len"])
     t.add_field("edge_indices", tgt["edge_indices"])
     return t
+
+
+TRAIN_FIELDS = ("hm", "cls_ids", "target_centers", "reg_mask", "trunc_mask", "reg_weight", "offset_3D", "keypoints",
+                "keypoints_depth_mask", "dimensions", "locations", "rotys", "alphas", "orientations", "2d_bboxes", "gt_bboxes")
+
+
+def make_train_target(tgt):
+    """synthetic.synthetic_train_target() dict -> ParamsList with the training-split fields (kitti.py:302-333)."""
+    t = ParamsList(image_size=tgt["size"], is_train=True)
+    t.add_field("pad_size", tgt["pad_size"])
+    t.add_field("calib", Calibration(tgt["P"]))
+    t.add_field("edge_len", tgt["edge_len"])
+    t.add_field("edge_indices", tgt["edge_indices"])
+    for k in TRAIN_FIELDS:
+        t.add_field(k, tgt[k])
+    return t

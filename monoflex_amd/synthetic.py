@@ -116,3 +116,104 @@ def synthetic_state_dict(template_state, seed=0, cls_bias=-1.0, offset_std=1.5):
             raise KeyError("synthetic_state_dict: unhandled key %s %s" % (name, shape))
         out[name] = v.to(t.dtype).reshape(shape).contiguous()
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Training-split targets (reference data/datasets/kitti.py:302-333).  The dataset pipeline is out
+# of scope; this draws seeded 3D boxes in front of the KITTI camera and derives every field the loss consumes from
+# their projection, so the fields are mutually consistent (centres, offsets, keypoints, depths, multi-bin angles).
+# ------------------------------------------------------------------------------------------------
+_DIM_MEAN = np.array(((3.8840, 1.5261, 1.6286), (0.8423, 1.7607, 0.6602), (1.7635, 1.7372, 0.5968)))
+_DIM_STD = np.array(((0.4259, 0.1367, 0.1022), (0.2349, 0.1133, 0.1427), (0.1766, 0.0948, 0.1242)))
+
+
+def _multibin(alpha, num_bin=4, margin=1 / 6):
+    """4 bin flags + 4 residuals (kitti.py:181-200): bin centres 0, pi/2, pi, -pi/2, overlap margin pi/12."""
+    centers = np.array([0, np.pi / 2, np.pi, -np.pi / 2])
+    rng = np.pi / num_bin + 2 * np.pi / num_bin * margin
+    off = alpha - centers
+    off = np.where(off > np.pi, off - 2 * np.pi, off)
+    off = np.where(off < -np.pi, off + 2 * np.pi, off)
+    out = np.zeros(2 * num_bin)
+    hit = np.abs(off) < rng
+    out[:num_bin][hit] = 1
+    out[num_bin:][hit] = off[hit]
+    return out
+
+
+def synthetic_train_target(seed, out_w=320, out_h=96, down_ratio=4, n_obj=None, max_objs=40, P=KITTI_P2):
+    """One image's training `targets` fields as a dict (plus the test-split fields of synthetic_target)."""
+    rs = np.random.RandomState(seed)
+    base = synthetic_target(out_w, out_h, down_ratio, P=P)
+    W, H = out_w * down_ratio, out_h * down_ratio
+    pad = np.asarray(base["pad_size"], dtype=np.float64)
+    img_w, img_h = W - 2 * pad[0], H - 2 * pad[1]
+    Pm = np.asarray(P, dtype=np.float64).reshape(3, 4)
+    n = int(rs.randint(1, 9)) if n_obj is None else n_obj
+    f = dict(hm=np.zeros((3, out_h, out_w), np.float32), cls_ids=np.zeros(max_objs, np.int32),
+             target_centers=np.zeros((max_objs, 2), np.int32), reg_mask=np.zeros(max_objs, np.uint8),
+             trunc_mask=np.zeros(max_objs, np.uint8), reg_weight=np.zeros(max_objs, np.float32),
+             offset_3D=np.zeros((max_objs, 2), np.float32), keypoints=np.zeros((max_objs, 10, 3), np.float32),
+             keypoints_depth_mask=np.zeros((max_objs, 3), np.float32), dimensions=np.zeros((max_objs, 3), np.float32),
+             locations=np.zeros((max_objs, 3), np.float32), rotys=np.zeros(max_objs, np.float32),
+             alphas=np.zeros(max_objs, np.float32), orientations=np.zeros((max_objs, 8), np.float32))
+    f["2d_bboxes"] = np.zeros((max_objs, 4), np.float32)
+    f["gt_bboxes"] = np.zeros((max_objs, 4), np.float32)
+    # focal length / image size of the small test grids is not KITTI's: scale the scene so boxes land inside
+    sx = W / 1280.0
+
+    def project(p3):
+        q = Pm[:, :3] @ p3.T + Pm[:, 3:4]
+        uv = (q[:2] / q[2:]).T
+        uv[:, 0] = (uv[:, 0] - Pm[0, 2]) * sx + img_w / 2            # keep the principal point centred on small grids
+        uv[:, 1] = (uv[:, 1] - Pm[1, 2]) * sx + img_h / 2
+        return uv
+
+    ys, xs = np.mgrid[0:out_h, 0:out_w]
+    for i in range(n):
+        c = int(rs.randint(0, 3))
+        dims = _DIM_MEAN[c] + _DIM_STD[c] * rs.randn(3) * 0.5                       # (l, h, w)
+        z = rs.uniform(6, 55)
+        x = rs.uniform(-1.0, 1.0) * z * 1.1                                          # |x|/z > 0.86 leaves the image: truncated objects
+        yb = 1.65 + rs.randn() * 0.1                                               # bottom of the box on the road
+        ry = rs.uniform(-np.pi, np.pi)
+        l, h, w = dims
+        R = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+        cor = np.array([[l / 2, l / 2, -l / 2, -l / 2, l / 2, l / 2, -l / 2, -l / 2], [0, 0, 0, 0, -h, -h, -h, -h],
+                        [w / 2, -w / 2, -w / 2, w / 2, w / 2, -w / 2, -w / 2, w / 2]])
+        cor = (R @ cor).T + np.array([x, yb, z])
+        pts3 = np.vstack((cor, [[x, yb, z]], [[x, yb - h, z]]))                     # 8 corners, bottom centre, top centre
+        loc = np.array([x, yb - h / 2, z])
+        uv = project(pts3)
+        cuv = project(loc[None])[0]
+        box = np.array([uv[:8, 0].min(), uv[:8, 1].min(), uv[:8, 0].max(), uv[:8, 1].max()])
+        box = np.clip(box, 0, [img_w - 1, img_h - 1, img_w - 1, img_h - 1])
+        if box[2] - box[0] < 2 or box[3] - box[1] < 2:
+            continue
+        inside = 0 <= cuv[0] <= img_w - 1 and 0 <= cuv[1] <= img_h - 1
+        centre = cuv if inside else np.clip(cuv, 0, [img_w - 1, img_h - 1])        # truncated: nearest border point
+        cf = (centre + pad) / down_ratio
+        ci = np.floor(cf).astype(np.int32)
+        ci = np.clip(ci, 0, [out_w - 1, out_h - 1])
+        f["cls_ids"][i], f["target_centers"][i] = c, ci
+        f["reg_mask"][i], f["reg_weight"][i], f["trunc_mask"][i] = 1, 1.0, 0 if inside else 1
+        f["offset_3D"][i] = (cuv + pad) / down_ratio - ci
+        f["gt_bboxes"][i] = box
+        f["2d_bboxes"][i] = (box + np.tile(pad, 2)) / down_ratio
+        kf = (uv + pad) / down_ratio
+        vis = (uv[:, 0] >= 0) & (uv[:, 0] <= img_w - 1) & (uv[:, 1] >= 0) & (uv[:, 1] <= img_h - 1) & (pts3[:, 2] > 0)
+        f["keypoints"][i, :, :2] = kf - ci
+        f["keypoints"][i, :, 2] = vis
+        f["keypoints_depth_mask"][i] = (vis[8] & vis[9], vis[[0, 2, 4, 6]].all(), vis[[1, 3, 5, 7]].all())
+        f["dimensions"][i], f["locations"][i], f["rotys"][i] = dims, loc, ry
+        alpha = ry - np.arctan2(x, z)
+        alpha = alpha - 2 * np.pi if alpha > np.pi else alpha + 2 * np.pi if alpha < -np.pi else alpha
+        f["alphas"][i] = alpha
+        f["orientations"][i] = _multibin(alpha)
+        bw, bh = (box[2] - box[0]) / down_ratio, (box[3] - box[1]) / down_ratio
+        sigma = max(1.0, 0.1 * float(np.hypot(bw, bh))) / 1.5
+        gauss = np.exp(-((xs - ci[0]) ** 2 + (ys - ci[1]) ** 2) / (2 * sigma * sigma)).astype(np.float32)
+        gauss[ci[1], ci[0]] = 1.0
+        f["hm"][c] = np.maximum(f["hm"][c], gauss)
+    base.update(f)
+    return base

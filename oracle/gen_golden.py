@@ -219,10 +219,76 @@ def run_decode_cases():
     np.savez_compressed(os.path.join(GOLD, "decode_only.npz"), **out)
 
 
+def reference_train_target(tgt):
+    from monoflex_amd.structures.params_3d import TRAIN_FIELDS
+    t = reference_target(tgt)
+    t.is_train = True
+    for k in TRAIN_FIELDS:
+        t.add_field(k, np.asarray(tgt[k]))
+    t.add_field("ori_img", np.zeros((4, 4, 3), np.uint8))           # stacked by prepare_targets, visualisation only
+    return t
+
+
+LOSS_CASES = {   # name -> list of (target seed, n_obj or None, focal scale of P)
+    "b2": [(1, None, 1.0), (2, None, 1.0)],
+    "b3_empty_middle_mixed_calib": [(3, 5, 1.0), (4, 0, 1.1), (5, 7, 1.2)],
+    "b1_many": [(6, 30, 1.0)],
+}
+
+
+def loss_case_inputs(name):
+    """Seeded predictions + synthetic training targets of one loss case (shared with tests/test_loss_golden.py)."""
+    spec = LOSS_CASES[name]
+    tg = []
+    for seed, n_obj, fs in spec:
+        P = np.array(S.KITTI_P2, dtype=np.float64).reshape(3, 4).copy()
+        P[0, 0] *= fs; P[1, 1] *= fs
+        tg.append(S.synthetic_train_target(seed, n_obj=n_obj, P=P))
+    B = len(spec)
+    g = torch.Generator().manual_seed(100 + B)
+    reg = torch.randn(B, 50, 96, 320, generator=g) * 0.6
+    cls = torch.sigmoid(torch.randn(B, 3, 96, 320, generator=g) * 0.8 - 2.5).clamp(1e-4, 1 - 1e-4)
+    return tg, cls, reg
+
+
+def run_loss_cases():
+    """Reference Loss_Computation (model/head/detector_loss.py) on seeded predictions and synthetic training targets:
+    the 11 loss values, the log MAEs, and the gradient of the summed loss w.r.t. the regression map at the object
+    centres (it is zero elsewhere) and w.r.t. the heat map (checksums)."""
+    cfg, _ = build_reference(320, 96)
+    import model.head.detector_loss as dl
+    dl.get_iou_3d = lambda a, b: a.new_zeros(a.shape[0])            # shapely is absent; log-only (detector_loss.py:333)
+    out = {}
+    for name in LOSS_CASES:
+        tg, cls, reg = loss_case_inputs(name)
+        evaluator = dl.Loss_Computation(cfg)
+        cls, reg = cls.clone().requires_grad_(), reg.clone().requires_grad_()
+        loss_dict, log_dict = evaluator({"cls": cls, "reg": reg}, [reference_train_target(t) for t in tg])
+        sum(loss_dict.values()).backward()
+        for k, v in loss_dict.items():
+            out["%s/loss/%s" % (name, k)] = np.float64(v.item())
+        for k, v in log_dict.items():
+            out["%s/log/%s" % (name, k)] = np.float64(v)
+        cen = torch.stack([torch.as_tensor(t["target_centers"]) for t in tg]).long()          # (B,40,2)
+        gr = reg.grad.permute(0, 2, 3, 1)
+        bi = torch.arange(len(tg)).view(-1, 1).expand(cen.shape[:2])
+        out["%s/grad_reg_at_centres" % name] = gr[bi, cen[..., 1], cen[..., 0]].numpy()        # (B,40,50)
+        out["%s/grad_reg_abssum" % name] = np.float64(reg.grad.abs().double().sum())
+        cs = checksum(cls.grad)
+        out["%s/grad_cls_samples" % name], out["%s/grad_cls_idx" % name] = cs["samples"], cs["idx"]
+        out["%s/grad_cls_sum" % name] = np.float64(cs["sum"])
+        print("loss case", name, {k: round(v.item(), 4) for k, v in loss_dict.items()})
+    out["meta"] = np.array(repr(dict(case="loss", torch=torch.__version__, patches="get_iou_3d -> zeros (shapely absent)",
+                                     inputs="oracle/gen_golden.py:loss_case_inputs (seeded; regenerated by the test)")))
+    np.savez_compressed(os.path.join(GOLD, "loss.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     install_stubs()
-    which = sys.argv[1:] or ["small", "full", "decode"]
+    which = sys.argv[1:] or ["small", "full", "decode", "loss"]
+    if "loss" in which:
+        run_loss_cases()
     if "small" in which:
         run_case("e2e_small", 32, 16, seeds=(1000, 1001), cls_bias=-1.0, store_full=True)
     if "decode" in which:

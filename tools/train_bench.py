@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Training-step throughput: forward + loss + backward + AdamW on synthetic data,
+fp32, one process per GPU (launch under torch.distributed.run for N > 1: DDP over RCCL, optional SyncBN).
+Prints one JSON line; this is a secondary measurement, bench.py carries the headline (inference) metric."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--sync-bn", action="store_true")
+    ap.add_argument("--profile-sync", action="store_true", help="time forward/backward/step separately (adds syncs)")
+    a = ap.parse_args()
+    from monoflex_amd import parallel as par
+    from monoflex_amd import synthetic as S
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.engine.trainer import convert_sync_batchnorm, train_step, wrap_data_parallel
+    from monoflex_amd.model.detector import KeypointDetector
+    from monoflex_amd.solver import build_optimizer
+    from monoflex_amd.structures.params_3d import make_train_target
+    rank, world, local_rank = par.init_from_env()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_cfg(os.path.join(root, "runs", "monoflex.yaml"))
+    cfg.MODEL.PRETRAIN = False
+    cfg.MODEL.COMPUTE_DTYPE = "fp32"
+    model = KeypointDetector(cfg)
+    model.load_state_dict(S.synthetic_state_dict(model.state_dict(), seed=0))
+    model = model.to(dev).train()
+    model.heads.loss_evaluator.log_as_float = False                  # no host sync inside the step
+    if a.sync_bn and world > 1:
+        convert_sync_batchnorm(model)
+    opt = build_optimizer(model, cfg)
+    net = wrap_data_parallel(model, device_ids=[local_rank]) if world > 1 else model
+    seed = par.shard_seed(1000, rank, a.batch)
+    imgs = S.synthetic_images(a.batch, seed=seed).to(dev)
+    targets = [make_train_target(S.synthetic_train_target(seed + i)).to(dev) for i in range(a.batch)]
+    for _ in range(a.warmup):
+        train_step(net, opt, imgs, targets)
+    par.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        total, _, _ = train_step(net, opt, imgs, targets)
+    par.barrier(); torch.cuda.synchronize()
+    rate, dt, n_img = par.aggregate_throughput(time.perf_counter() - t0, a.batch * a.steps, device=dev)
+    if rank == 0:
+        print(json.dumps({"metric": "train_images_per_sec", "value": rate, "unit": "images/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+                          "dtype": "f32", "data": "synthetic", "loss": float(total),
+                          "config": {"workload": "MonoFlex DLA-34 1280x384 fwd+loss+bwd+AdamW", "batch_per_gpu": a.batch,
+                                     "sync_bn": bool(a.sync_bn and world > 1)}}))
+
+
+if __name__ == "__main__":
+    main()
