@@ -50,3 +50,57 @@ def test_single_process_is_passthrough():
     assert parallel.image_shard(0, 1, 8) == (0, 8)
     rate, el, tot = parallel.aggregate_throughput(2.0, 16)
     assert (rate, el, tot) == (8.0, 2.0, 16)
+
+
+class _Toy(torch.nn.Module):
+    """Stand-in with the reference's dead-parameter names (backbone.base.level{3,4}.project.*) next to live ones."""
+
+    def __init__(self):
+        super().__init__()
+        self.backbone = torch.nn.Module()
+        self.backbone.base = torch.nn.Module()
+        for lvl in ("level3", "level4"):
+            holder = torch.nn.Module()
+            holder.project = torch.nn.Sequential(torch.nn.Conv2d(4, 4, 1, bias=False), torch.nn.BatchNorm2d(4))
+            setattr(self.backbone.base, lvl, holder)
+        self.live = torch.nn.Linear(6, 3)
+
+    def forward(self, x):
+        return self.live(x).pow(2).sum()
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from monoflex_amd import parallel
+    from monoflex_amd.engine.trainer import dead_parameter_names, wrap_data_parallel
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    m = _Toy()
+    assert len(dead_parameter_names(m)) == 6 + 6                     # 6 parameters + their BN buffers
+    net = wrap_data_parallel(m)
+    xs = torch.arange(12, dtype=torch.float32).view(2, 6) / 10       # rank r trains on row r
+    grads = []
+    for it in range(2):          # with the dead parameters merely unused (not ignored) DDP raises on the 2nd iteration
+        m.zero_grad()
+        net(xs[rank:rank + 1]).backward()
+        grads.append(m.live.weight.grad.clone())
+    out.put((rank, grads[1].tolist(), [p.grad is None for n, p in m.named_parameters() if "project" in n]))
+    dist.destroy_process_group()
+
+
+def test_training_data_parallel_ignores_dead_parameters_and_averages():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted((q.get(timeout=120) for _ in ps), key=lambda t: t[0])
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    torch.manual_seed(0)
+    m = _Toy()
+    xs = torch.arange(12, dtype=torch.float32).view(2, 6) / 10
+    (m(xs[0:1]) + m(xs[1:2])).backward()
+    want = m.live.weight.grad / 2                                    # DDP averages over ranks
+    for rank, g, dead_none in res:
+        assert torch.allclose(torch.tensor(g), want, atol=1e-6) and all(dead_none)
