@@ -127,6 +127,8 @@ typedef struct {
     int32_t B, H, W, C;       /* C: power of two >= 64 (bf16) / 16 (f32) elements                */
     int32_t kh, kw, stride, pad, dil;
     int32_t Ho, Wo, Cout, Cout_pad, K_pad, ldy, act, dtype;
+    const void* w_frag_f16;   /* optional (bf16 mode): the fragment-major weights as IEEE fp16: enables the LDS-patch kernel,
+                                 which samples and multiplies in fp16 (3x3, stride 1, pad 1, C % 64 == 0)            */
 } mfx_dcn_desc;
 int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream);
 

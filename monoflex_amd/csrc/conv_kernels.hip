@@ -225,8 +225,9 @@ static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 int try_conv_halo(const mfx_conv_desc* d, hipStream_t st);   // conv_halo.hip
-extern int g_opt_halo, g_opt_halo_cg, g_opt_dcn_wave;
+extern int g_opt_halo, g_opt_halo_cg, g_opt_dcn_wave, g_opt_dcn_patch, g_opt_dcn_patch_fn8;
 int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st);      // dcn_wave.hip
+int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st);     // dcn_patch.hip
 
 // tuning overrides (mfx_set_option): 0 = automatic
 int g_opt_conv_tile = 0, g_opt_dcn_tile = 0, g_opt_cat_tile = 0, g_opt_kc = 0;
@@ -323,6 +324,8 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "halo") g_opt_halo = value;
     else if (n == "halo_cg") g_opt_halo_cg = value;
     else if (n == "dcn_wave") g_opt_dcn_wave = value;
+    else if (n == "dcn_patch") g_opt_dcn_patch = value;
+    else if (n == "dcn_patch_fn8") g_opt_dcn_patch_fn8 = value;
     else return mfx_fail(MFX_ERR_ARG, "set_option: unknown option");
     return MFX_OK;
 }
@@ -455,7 +458,9 @@ extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
     g.inv_kw = (65536 + d->kw - 1) / d->kw; g.stride = d->stride; g.pad = d->pad; g.dil = d->dil; g.M = d->B * d->Ho * d->Wo;
     if (g.M <= 0) return MFX_OK;
     {
-        const int h = try_dcn_wave(d, reinterpret_cast<hipStream_t>(stream));
+        int h = try_dcn_patch(d, reinterpret_cast<hipStream_t>(stream));
+        if (h != 0) return h < 0 ? h : MFX_OK;
+        h = try_dcn_wave(d, reinterpret_cast<hipStream_t>(stream));
         if (h != 0) return h < 0 ? h : MFX_OK;
     }
     EpiArgs ep;

@@ -102,6 +102,7 @@ class DCN(DCNv2):
                 scale, shift = None, self.bias
             p = ops.pack_conv(self.weight, dtype, scale, shift, stride=self.stride[0], pad=self.padding[0], act=act)
             p.dil_w = self.dilation[0]
+            ops.add_f16_fragments(p, self.weight)
             self._packs[key] = p
         return self._packs[key]
 

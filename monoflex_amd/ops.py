@@ -74,6 +74,7 @@ class PackedConv:
     K_pad: int
     act: int
     w_frag: Optional[torch.Tensor] = None   # fragment-major copy for the LDS-halo kernel (3x3 / stride 1)
+    w_frag_f16: Optional[torch.Tensor] = None   # same, IEEE fp16 (DCN LDS-patch kernel, bf16 mode)
 
 
 def fragment_major(w2d, dtype):
@@ -231,6 +232,15 @@ def cat_conv1x1(srcs, p: PackedCat):
     return y
 
 
+def add_f16_fragments(p: PackedConv, weight):
+    """Attach the fp16 fragment-major weights the DCN LDS-patch kernel multiplies with (bf16 mode, 3x3/s1/p1)."""
+    if p.w_frag is not None and p.w.dtype == torch.bfloat16:
+        Cout, Cin, kh, kw = weight.shape
+        w2 = _pad_rows_cols(weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, kh * kw * Cin), p.Cout_pad, p.K_pad)
+        p.w_frag_f16 = fragment_major(w2.to(device=p.w.device, dtype=torch.float16).contiguous(), torch.float16)
+    return p
+
+
 def dcn(x, offmask, p: PackedConv):
     """Fused DCNv2 + scale/shift + act.  x (B,H,W,C) NHWC, offmask fp32 (B,Ho,Wo,32)."""
     _need_cuda(x, offmask)
@@ -240,6 +250,7 @@ def dcn(x, offmask, p: PackedConv):
     d = L.DcnDesc()
     d.x, d.offmask, d.w, d.y = x.data_ptr(), offmask.data_ptr(), p.w.data_ptr(), y.data_ptr()
     d.w_frag = p.w_frag.data_ptr() if p.w_frag is not None else None
+    d.w_frag_f16 = p.w_frag_f16.data_ptr() if p.w_frag_f16 is not None else None
     d.scale = p.scale.data_ptr() if p.scale is not None else None
     d.shift = p.shift.data_ptr() if p.shift is not None else None
     d.B, d.H, d.W, d.C = B, H, W, C

@@ -295,3 +295,35 @@ def test_decode_vs_reference_goldens(golden_dir):
             assert np.allclose(res, want, rtol=1e-4, atol=2e-3), (n, np.abs(res - want).max())
         n += 1
     assert n >= 4
+
+
+@pytest.mark.parametrize("B,C,Cout,H,W,off_std", [(2, 64, 64, 20, 40, 1.5), (1, 128, 64, 33, 48, 1.0), (2, 64, 128, 16, 16, 4.0),
+                                                 (1, 256, 256, 12, 24, 2.0)])
+def test_dcn_patch_kernel_matches_first_generation(B, C, Cout, H, W, off_std):
+    """LDS-patch DCN kernel (dcn_patch.hip, all three tile heights) against the first-generation global-gather kernel on
+    the same bf16 inputs: same blend arithmetic and K order, so the results agree to accumulation rounding.  Ragged
+    tiles (H, W not multiples of the tile), two channel slices, several n-tiles, and offsets far outside the patch
+    (off_std 4: most samples take the global fallback; some leave the image)."""
+    from monoflex_amd import lib as L, ops
+    g = _g(31)
+    x = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV)
+    om = torch.zeros(B, H, W, 32)
+    om[..., :18] = torch.randn(B, H, W, 18, generator=g) * off_std
+    om[..., 18:27] = torch.rand(B, H, W, 9, generator=g)
+    om = om.to(DEV)
+    w = torch.randn(Cout, C, 3, 3, generator=g) * (1.0 / (3 * C ** 0.5))
+    p = ops.pack_conv(w.to(DEV), torch.bfloat16, torch.rand(Cout, generator=g).to(DEV) + 0.5, torch.randn(Cout, generator=g).to(DEV),
+                      stride=1, pad=1, act=L.ACT_RELU)
+    ops.add_f16_fragments(p, w)
+    lib_ = L.load()
+    try:
+        L.check(lib_.mfx_set_option(b"dcn_patch", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_wave", 0), "opt")
+        want = ops.dcn(x, om, p).float().cpu()
+        for v in (2, 3, 4):
+            L.check(lib_.mfx_set_option(b"dcn_patch", v), "opt")
+            got = ops.dcn(x, om, p).float().cpu()
+            err = float((got - want).abs().max())
+            assert err <= 2e-2 * max(1.0, float(want.abs().max())), (v, err)
+            assert float((got - want).abs().mean()) <= 1e-3 * max(1.0, float(want.abs().mean())), v
+    finally:
+        L.check(lib_.mfx_set_option(b"dcn_patch", 1), "opt"); L.check(lib_.mfx_set_option(b"dcn_wave", 1), "opt")
