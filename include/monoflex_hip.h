@@ -101,6 +101,8 @@ typedef struct {
     int32_t ldy, ldres;
     int32_t act;
     int32_t dtype, out_dtype;
+    void* workspace;          /* optional scratch for split-K (small-M / long-K layers): fp32, >= ksplit*M*Cout_pad*4 bytes  */
+    int64_t workspace_bytes;  /* 0 / NULL: never split                                           */
 } mfx_conv_desc;
 int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream);
 

@@ -63,12 +63,12 @@ class Conv2dFn(Function):
     multiple of the 16-byte chunk (extra channels are exactly zero); callers slice."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad):
+    def forward(ctx, x, weight, bias, stride, pad, out_dtype=None):
         x = _c(x)
         Cout, Cin, kh, kw = weight.shape
-        cpad = _pad_channels(Cout, x.dtype)
+        cpad = _pad_channels(Cout, out_dtype or x.dtype)
         p = ops.pack_conv(weight, x.dtype, None, bias, stride=stride, pad=pad, act=L.ACT_NONE, cout=cpad)
-        y = ops.conv2d(x, p)
+        y = ops.conv2d(x, p, out_dtype=out_dtype)             # bf16 mode: fp32 out for DCN offsets and the head maps
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, bias is not None, Cout)
         return y
@@ -79,6 +79,11 @@ class Conv2dFn(Function):
         x, weight = ctx.saved_tensors
         stride, pad, has_bias, Cout = ctx.cfg
         dy = _c(dy)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        emin = 4 if x.dtype == torch.float32 else 8
+        if dy.shape[-1] < emin:                                # fp32-out head conv in bf16 mode: 4 channels < one bf16 chunk
+            dy = torch.nn.functional.pad(dy, (0, emin - dy.shape[-1]))
         B, H, W, Cin = x.shape
         _, Ho, Wo, Cp = dy.shape
         kh, kw = weight.shape[2], weight.shape[3]
@@ -104,7 +109,7 @@ class Conv2dFn(Function):
             dw = dwf[:Cout].view(Cout, kh, kw, Cin).permute(0, 3, 1, 2).contiguous().to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy)[:Cout]
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class CatConv1x1Fn(Function):
@@ -163,8 +168,6 @@ class StemConvFn(Function):
     def backward(ctx, dy):
         xp, weight = ctx.saved_tensors
         H, W = ctx.hw
-        if xp.dtype != torch.float32:
-            raise NotImplementedError("stem weight gradient: fp32 training mode only")
         Cout = weight.shape[0]
         dwf = _wgrad(xp, _c(dy), 7, 7, 1, 0, H, W, Ck=4, x_pixstride=4)          # padded image: pad 0 in padded coordinates
         dw = dwf[:Cout].view(Cout, 7, 7, 4)[..., :3].permute(0, 3, 1, 2).contiguous()
@@ -295,9 +298,7 @@ class DCNFn(Function):
 
     @staticmethod
     def forward(ctx, x, offmask_raw, weight, bias, stride, pad, dil):
-        if x.dtype != torch.float32:
-            raise NotImplementedError("DCN training path: fp32 mode only (the backward kernels are fp32)")
-        x, raw = _c(x), _c(offmask_raw)
+        x, raw = _c(x), _c(offmask_raw).float()
         om = raw.clone()
         om[..., 18:27] = torch.sigmoid(raw[..., 18:27])
         p = ops.pack_conv(weight, x.dtype, None, bias, stride=stride, pad=pad, act=L.ACT_NONE)
@@ -318,9 +319,12 @@ class DCNFn(Function):
         lib_ = L.load()
         nbytes = lib_.mfx_dcn_backward_nhwc_workspace_bytes(B, C, H, W, Cout, kh, kw, stride, pad, dil)
         ws = ops._workspace(nbytes, x.device)
+        xdtype = x.dtype
+        if xdtype != torch.float32:                            # bf16 mode: the DCN backward kernels are fp32 (casts are transient)
+            x, dy = x.float(), dy.float()
         dx = torch.empty_like(x)
         dom = torch.empty_like(om)
-        dw = torch.empty_like(weight)
+        dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
         wc = weight.detach().float().contiguous()
         L.check(lib_.mfx_dcn_backward_nhwc(_ptr(x), _ptr(om), _ptr(wc), _ptr(dy), _ptr(dx), _ptr(dom), _ptr(dw), _ptr(db),
@@ -329,12 +333,12 @@ class DCNFn(Function):
         m = om[..., 18:27]
         dom[..., 18:27] = dom[..., 18:27] * m * (1 - m)               # through the sigmoid
         dom[..., 27:] = 0
-        return dx, dom, dw, db, None, None, None
+        return dx.to(xdtype), dom, dw.to(weight.dtype), db, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0):
+def conv2d(x, weight, bias=None, stride=1, pad=0, out_dtype=None):
     """Differentiable NHWC conv; returns exactly weight.shape[0] channels."""
-    y = Conv2dFn.apply(x, weight, bias, stride, pad)
+    y = Conv2dFn.apply(x, weight, bias, stride, pad, out_dtype)
     return y if y.shape[-1] == weight.shape[0] else y[..., :weight.shape[0]]
 
 

@@ -184,9 +184,51 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const T* x, co
     ConvALoader<T, BM, WM * WN * 64, KC> al; al.init(x, g, rowmap, m0, threadIdx.x);
     WeightLoader<T, BN, WM * WN * 64, KC> bl; bl.init(w, n0, ep.K_pad, threadIdx.x);
     f32x4 acc[BM / WM / 16][BN / WN / 16];
+    if (ep.ksplit > 1) {                                      // this workgroup's slice of K; fp32 partial tile to the workspace
+        const int per = (ep.nk + ep.ksplit - 1) / ep.ksplit, k0 = blockIdx.y * per;
+        gemm_mainloop<T, BM, BN, WM, WN, KC>(al, bl, min(per, ep.nk - k0), smem, acc, k0);
+        epilogue_store<T, float, BM, BN, WM, WN>(acc, smem, nullptr, nullptr, nullptr, 0,
+                                                 ep.ws + (size_t)blockIdx.y * g.M * ep.ws_ld, ep.ws_ld, m0, n0, g.M, ep.ws_ld, ACT_NONE);
+        return;
+    }
     gemm_mainloop<T, BM, BN, WM, WN, KC>(al, bl, ep.nk, smem, acc);
     epilogue_store<T, TO, BM, BN, WM, WN>(acc, smem, ep.scale, ep.shift, reinterpret_cast<const T*>(ep.res), ep.ldres,
                                           reinterpret_cast<TO*>(ep.y), ep.ldy, m0, n0, g.M, ep.Cout, ep.act);
+}
+
+// y = act((sum_s ws[s][m][n]) * scale[n] + shift[n] (+ res)): the epilogue of a split-K convolution
+template <typename TO>
+__global__ void splitk_finalize_kernel(const float* __restrict__ ws, int ksplit, size_t split_stride, int ws_ld,
+                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                       const TO* __restrict__ res, int ldres, TO* __restrict__ y, int ldy, int M, int Cout, int act) {
+    constexpr int OE = ElemTraits<TO>::ELEMS;
+    const int gpr = Cout / OE;
+    const long total = (long)M * gpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / gpr), n = (int)(i - (long)m * gpr) * OE;
+        float v[OE];
+#pragma unroll
+        for (int e = 0; e < OE; ++e) v[e] = 0.f;
+        for (int s = 0; s < ksplit; ++s) {
+            const float* p = ws + s * split_stride + (size_t)m * ws_ld + n;
+#pragma unroll
+            for (int e = 0; e < OE; e += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p + e);
+                v[e] += t[0]; v[e + 1] += t[1]; v[e + 2] += t[2]; v[e + 3] += t[3];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < OE; ++e) v[e] = v[e] * (scale ? scale[n + e] : 1.f) + (shift ? shift[n + e] : 0.f);
+        if (res) {
+            float rv[OE];
+            ElemTraits<TO>::unpack(*reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n), rv);
+#pragma unroll
+            for (int e = 0; e < OE; ++e) v[e] += rv[e];
+        }
+#pragma unroll
+        for (int e = 0; e < OE; ++e) v[e] = apply_act(v[e], act, n + e);
+        *reinterpret_cast<u32x4*>(y + (size_t)m * ldy + n) = ElemTraits<TO>::pack(v);
+    }
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KC>
@@ -231,6 +273,7 @@ int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st);     // dcn_patch.hip
 
 // tuning overrides (mfx_set_option): 0 = automatic
 int g_opt_conv_tile = 0, g_opt_dcn_tile = 0, g_opt_cat_tile = 0, g_opt_kc = 0;
+int g_opt_ksplit = 0;        // 0 = automatic, 1 = never split, n = force n splits where legal
 
 template <typename K> static int set_smem(K k, int smem) {
     if (smem > 64 * 1024) MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -246,6 +289,31 @@ static int launch_conv(const mfx_conv_desc* d, const ConvGeom& g, EpiArgs ep, hi
     constexpr int smem = TileSmem<BM, BN, KC>::bytes;
     static bool attr_set = false;
     if (!attr_set) { int rc = set_smem(k, smem); if (rc) return rc; attr_set = true; }
+    // split-K (option "ksplit" = n): shares each output tile among n workgroups.  Built for the level4/level5 layers
+    // (M = 15360 / 3840 rows, K = 2304 / 4608: < 2 workgroups per CU), but measured neutral-to-slower there (54 -> 49..58 us,
+    // 43 -> 64..80 us): those layers are bound by the L2->LDS operand traffic of the 64-wide tiles, not by occupancy.
+    int ksplit = 1;
+    if constexpr (std::is_same<T, TO>::value) {
+        if (d->workspace && !d->rowmap && g_opt_ksplit != 1 && d->Cout == d->Cout_pad) {
+            ksplit = g_opt_ksplit > 1 ? g_opt_ksplit : 1;      // measured (tools/splitk_probe.sh): no gain on DLA level4/5 -> opt-in only
+            ksplit = std::min(ksplit, std::min(8, ep.nk / 6));
+            while (ksplit > 1 && ((ep.nk + ksplit - 1) / ksplit) * (ksplit - 1) >= ep.nk) --ksplit;     // no empty split
+            if ((size_t)ksplit * d->M * d->Cout_pad * sizeof(float) > (size_t)d->workspace_bytes) ksplit = 1;
+        }
+    }
+    if (ksplit > 1) {
+        ep.ksplit = ksplit; ep.ws = reinterpret_cast<float*>(d->workspace); ep.ws_ld = d->Cout_pad;
+        hipLaunchKernelGGL(k, dim3(tiles, ksplit), dim3(WM * WN * 64), smem, st, reinterpret_cast<const T*>(d->x),
+                           reinterpret_cast<const T*>(d->w), g, d->rowmap, ep);
+        MFX_HIP_CHECK(hipGetLastError());
+        const long chunks = (long)d->M * (d->Cout / ElemTraits<TO>::ELEMS);
+        const int blocks = (int)std::min<long>((chunks + 255) / 256, 4096);
+        hipLaunchKernelGGL(splitk_finalize_kernel<TO>, dim3(blocks), dim3(256), 0, st, ep.ws, ksplit, (size_t)d->M * d->Cout_pad, d->Cout_pad,
+                           d->scale, d->shift, reinterpret_cast<const TO*>(d->res), d->ldres, reinterpret_cast<TO*>(d->y), d->ldy,
+                           d->M, d->Cout, d->act);
+        MFX_HIP_CHECK(hipGetLastError());
+        return MFX_OK;
+    }
     hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), smem, st, reinterpret_cast<const T*>(d->x),
                        reinterpret_cast<const T*>(d->w), g, d->rowmap, ep);
     MFX_HIP_CHECK(hipGetLastError());
@@ -321,6 +389,7 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "dcn_tile") g_opt_dcn_tile = value;
     else if (n == "cat_tile") g_opt_cat_tile = value;
     else if (n == "kc") g_opt_kc = value;
+    else if (n == "ksplit") g_opt_ksplit = value;
     else if (n == "halo") g_opt_halo = value;
     else if (n == "halo_cg") g_opt_halo_cg = value;
     else if (n == "dcn_wave") g_opt_dcn_wave = value;

@@ -246,6 +246,7 @@ static int dcn_bwd_core(const float* x, const float* om, const float* wT, const 
     cd.B = 1; cd.H = 1; cd.W = g.M; cd.x_pixstride = g.Coutp; cd.Ck = g.Coutp; cd.kh = 1; cd.kw = 1; cd.stride = 1;
     cd.pad_h = 0; cd.pad_w = 0; cd.dil_w = 1; cd.Ho = 1; cd.Wo = g.M; cd.M = g.M; cd.Cout = g.Kp; cd.Cout_pad = g.Kp;
     cd.K_pad = g.Coutp; cd.ldy = g.Kp; cd.ldres = 0; cd.act = MFX_ACT_NONE; cd.dtype = MFX_F32; cd.out_dtype = MFX_F32;
+    cd.workspace = nullptr; cd.workspace_bytes = 0;
     int rc = mfx_conv2d_nhwc(&cd, stream);
     if (rc) return rc;
     {   // grad_offset, grad_mask, grad_input

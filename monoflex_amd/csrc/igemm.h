@@ -30,6 +30,10 @@ template <int BM, int BN, int KC = 4> struct TileSmem {
 struct EpiArgs {
     const float* scale; const float* shift; const void* res; void* y;
     int ldy, ldres, Cout, act, tiles_n, K_pad, nk;
+    // split-K (conv_igemm only): gridDim.y = ksplit workgroups share one output tile, each writes its fp32 partial
+    // sums to ws[split][M][ws_ld]; splitk_finalize_kernel adds them and applies the real epilogue
+    int ksplit = 1, ws_ld = 0;
+    float* ws = nullptr;
 };
 
 // Weight (B operand) loader: rows n0.. of a [N_pad][K_pad] K-contiguous matrix.
@@ -64,7 +68,7 @@ template <typename T, int BN, int NT = 256, int KC = 4> struct WeightLoader {
 // acc[FM][FN] += A-tile x B-tile over nk k-iterations.  ALoader provides load(kiter)/store(As).
 template <typename T, int BM, int BN, int WM, int WN, int KC, typename ALoader>
 __device__ __forceinline__ void gemm_mainloop(ALoader& al, WeightLoader<T, BN, WM * WN * 64, KC>& bl, int nk, char* smem,
-                                              f32x4 (&acc)[BM / WM / 16][BN / WN / 16]) {
+                                              f32x4 (&acc)[BM / WM / 16][BN / WN / 16], int k0 = 0) {
     constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
     constexpr int STAGE = TileSmem<BM, BN, KC>::stage_bytes;
     constexpr int kRowBytes = RowGeom<KC>::bytes;
@@ -79,8 +83,8 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, WeightLoader<T, BN, W
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    al.load(0);
-    bl.load(0);
+    al.load(k0);
+    bl.load(k0);
     al.store(smem);
     bl.store(smem + BM * kRowBytes);
     __syncthreads();
@@ -89,7 +93,7 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, WeightLoader<T, BN, W
         char* cur = smem + (k & 1) * STAGE;
         char* nxt = smem + ((k + 1) & 1) * STAGE;
         const bool more = (k + 1) < nk;
-        if (more) { al.load(k + 1); bl.load(k + 1); }
+        if (more) { al.load(k0 + k + 1); bl.load(k0 + k + 1); }
 
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks) {               // 64 bytes of K per sub-step

@@ -22,7 +22,8 @@ class ConvDesc(ctypes.Structure):
                 ("B", c_int), ("H", c_int), ("W", c_int), ("x_pixstride", c_int), ("Ck", c_int),
                 ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad_h", c_int), ("pad_w", c_int), ("dil_w", c_int),
                 ("Ho", c_int), ("Wo", c_int), ("M", c_int), ("Cout", c_int), ("Cout_pad", c_int), ("K_pad", c_int),
-                ("ldy", c_int), ("ldres", c_int), ("act", c_int), ("dtype", c_int), ("out_dtype", c_int)]
+                ("ldy", c_int), ("ldres", c_int), ("act", c_int), ("dtype", c_int), ("out_dtype", c_int),
+                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64)]
 
 
 class CatDesc(ctypes.Structure):

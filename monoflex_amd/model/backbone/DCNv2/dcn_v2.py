@@ -116,7 +116,7 @@ class DCN(DCNv2):
         """Differentiable NHWC form: offset/mask conv -> DCNv2 (gradients to x, offsets, mask logits, weight, bias)."""
         from .... import autograd as AG
         c = self.conv_offset_mask
-        raw = AG.Conv2dFn.apply(x, c.weight, c.bias, self.stride[0], self.padding[0])       # (B,H,W,32), 27 used
+        raw = AG.Conv2dFn.apply(x, c.weight, c.bias, self.stride[0], self.padding[0], torch.float32)   # (B,H,W,32), 27 used
         return AG.DCNFn.apply(x, raw, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
 
     def forward(self, input):

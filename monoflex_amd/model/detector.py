@@ -47,8 +47,6 @@ class KeypointDetector(nn.Module):
     def forward_train_maps(self, images, edge_indices, edge_lens):
         """Training-mode network: (B,3,H,W) images -> (class logits (B,h,w,ncls), regression (B,h,w,50)), NHWC,
         differentiable (HIP forward + backward kernels; BN on batch statistics)."""
-        if self.compute_dtype != torch.float32:
-            raise NotImplementedError("training runs in fp32 mode (MODEL.COMPUTE_DTYPE fp32); bf16 training is a later round")
         feat = self.backbone.forward_nhwc(images)
         return self.heads.predictor.forward_train(feat, edge_indices, edge_lens)
 
@@ -66,8 +64,6 @@ class KeypointDetector(nn.Module):
         if not images.tensors.is_cuda:
             raise RuntimeError("KeypointDetector (HIP build) needs CUDA/HIP tensors: there is no CPU fallback")
         if self.training:                                           # detector.py:30-33 -> (loss_dict, log_loss_dict)
-            if self.compute_dtype != torch.float32:
-                raise NotImplementedError("training runs in fp32 mode (MODEL.COMPUTE_DTYPE fp32)")
             return self.heads(self.backbone(images.tensors), targets)
         with torch.no_grad():
             features = self.backbone(images.tensors)

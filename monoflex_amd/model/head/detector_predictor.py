@@ -193,7 +193,7 @@ class _predictor(nn.Module):
             w = heads[0].weight if len(heads) == 1 else torch.cat([h.weight for h in heads], 0)
             b = heads[0].bias if len(heads) == 1 else torch.cat([h.bias for h in heads], 0)
             feats.append(f)
-            outs.append(AG.conv2d(f, w, b, 1, 0))
+            outs.append(AG.conv2d(f, w, b, 1, 0, out_dtype=torch.float32))
         cls, regs = outs[0], outs[1:]
         if self.enable_edge_fusion:
             if edge_indices is None:
@@ -209,7 +209,7 @@ class _predictor(nn.Module):
                 c1, bn, c3 = seq[0], seq[1], seq[3]
                 h1 = AG.bn_act(AG.conv2d(e, c1.weight.unsqueeze(2), c1.bias, 1, 0), bn,
                                L.ACT_RELU if self.edge_fusion_relu else L.ACT_NONE)
-                o = AG.conv2d(h1, c3.weight.unsqueeze(2), c3.bias, 1, 0).view(B, Lmax, -1)
+                o = AG.conv2d(h1, c3.weight.unsqueeze(2), c3.bias, 1, 0, out_dtype=torch.float32).view(B, Lmax, -1)
                 lo = 0 if base is cls else sum(self.regression_channel_cfg[oi][:oj])
                 co = o.shape[-1]
                 valid = torch.arange(Lmax, device=features.device).view(1, Lmax) < edge_lens.view(B, 1).long()

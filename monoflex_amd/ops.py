@@ -187,6 +187,9 @@ def conv2d(x, p: PackedConv, res=None, out_dtype=None, rowmap=None, x_channels=N
     d.Ho, d.Wo, d.M, d.Cout, d.Cout_pad, d.K_pad = Ho, Wo, M, p.Cout, p.Cout_pad, p.K_pad
     d.ldy, d.ldres = p.Cout, (res.shape[-1] if res is not None else 0)
     d.act, d.dtype, d.out_dtype = p.act, _dt(x.dtype), _dt(out_dtype)
+    if rowmap is None and M * p.Cout_pad <= SPLITK_MAX_ELEMS and p.K_pad * x.element_size() >= 2048:
+        ws = _splitk_workspace(x.device)                      # small-M / long-K layers: lets the library split K
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     L.check(L.load().mfx_conv2d_nhwc(ctypes.byref(d), _stream()), "mfx_conv2d_nhwc")
     return y
 
@@ -384,6 +387,19 @@ def decode_boxes(hmap, reg_off, scores, index, calib, pad, img_size, threshold):
 
 # ---- reference `_ext` boundary (NCHW fp32) ---------------------------------------------------------
 _ws_cache = {}
+
+
+SPLITK_MAX_ELEMS = 4 * 1024 * 1024          # output elements (M * Cout_pad) up to which split-K is offered
+_splitk_ws = {}
+
+
+def _splitk_workspace(device):
+    """One persistent fp32 scratch per device (8 splits x SPLITK_MAX_ELEMS): stable address, so captured graphs stay valid;
+    launches on one stream are ordered, so consecutive layers can share it."""
+    key = (device.type, device.index)
+    if key not in _splitk_ws:
+        _splitk_ws[key] = torch.empty(8 * SPLITK_MAX_ELEMS, dtype=torch.float32, device=device)
+    return _splitk_ws[key]
 
 
 def _workspace(nbytes, device):

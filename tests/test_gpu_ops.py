@@ -327,3 +327,31 @@ def test_dcn_patch_kernel_matches_first_generation(B, C, Cout, H, W, off_std):
             assert float((got - want).abs().mean()) <= 1e-3 * max(1.0, float(want.abs().mean())), v
     finally:
         L.check(lib_.mfx_set_option(b"dcn_patch", 1), "opt"); L.check(lib_.mfx_set_option(b"dcn_wave", 1), "opt")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 12, 40, 512, 512, 3, 1, True), (2, 24, 80, 256, 256, 3, 1, False), (2, 24, 80, 128, 256, 3, 2, False),
+                                   (1, 12, 40, 256, 512, 1, 1, False)])
+def test_conv_split_k_matches_single_pass(dtype, shape):
+    """Split-K path of the generic conv (small-M / long-K layers of DLA level4/level5): every legal split count against
+    the single-pass kernel with the same epilogue (BN scale/shift, residual, ReLU)."""
+    from monoflex_amd import lib as L, ops
+    B, H, W, Ci, Co, k, s, with_res = shape
+    g = _g(41)
+    x = torch.randn(B, H, W, Ci, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / (k * Ci ** 0.5)).to(DEV)
+    p = ops.pack_conv(w, dtype, (torch.rand(Co, generator=g) + 0.5).to(DEV), torch.randn(Co, generator=g).to(DEV), stride=s, pad=k // 2,
+                      act=L.ACT_RELU)
+    p.w_frag = None                                            # keep the layer on the generic kernel
+    res = torch.randn(B, H // s, W // s, Co, generator=g).to(dtype).to(DEV) if with_res else None
+    lib_ = L.load()
+    try:
+        L.check(lib_.mfx_set_option(b"ksplit", 1), "opt")
+        want = ops.conv2d(x, p, res=res).float().cpu()
+        for ks in (0, 2, 3, 8):
+            L.check(lib_.mfx_set_option(b"ksplit", ks), "opt")
+            got = ops.conv2d(x, p, res=res).float().cpu()
+            tol = 2e-5 if dtype == torch.float32 else 2e-2
+            assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), ks
+    finally:
+        L.check(lib_.mfx_set_option(b"ksplit", 0), "opt")

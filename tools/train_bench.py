@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sync-bn", action="store_true")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="activation dtype (parameters and their gradients stay fp32)")
     ap.add_argument("--profile-sync", action="store_true", help="time forward/backward/step separately (adds syncs)")
     a = ap.parse_args()
     from monoflex_amd import parallel as par
@@ -34,7 +35,7 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = get_cfg(os.path.join(root, "runs", "monoflex.yaml"))
     cfg.MODEL.PRETRAIN = False
-    cfg.MODEL.COMPUTE_DTYPE = "fp32"
+    cfg.MODEL.COMPUTE_DTYPE = a.dtype
     model = KeypointDetector(cfg)
     model.load_state_dict(S.synthetic_state_dict(model.state_dict(), seed=0))
     model = model.to(dev).train()
@@ -57,7 +58,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "train_images_per_sec", "value": rate, "unit": "images/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-                          "dtype": "f32", "data": "synthetic", "loss": float(total),
+                          "dtype": "f32" if a.dtype == "fp32" else "bf16", "data": "synthetic", "loss": float(total),
                           "config": {"workload": "MonoFlex DLA-34 1280x384 fwd+loss+bwd+AdamW", "batch_per_gpu": a.batch,
                                      "sync_bn": bool(a.sync_bn and world > 1)}}))
 
