@@ -81,6 +81,110 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
             if (k0 + tk + i < g.K && o0 + to + j < g.Cout) unsafeAtomicAdd(dw + (size_t)(o0 + to + j) * g.K + k0 + tk + i, acc[i][j]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv weight gradient on the matrix cores (bf16 activations): dW[o][k] = sum_m dy[m][o] * A[m][k], A = implicit im2col.
+// The reduction runs over pixels, which is the SLOW axis of both NHWC operands, while an MFMA fragment wants 8
+// consecutive reduction elements per lane.  Each k-step therefore stages 32 pixels of both operands in LDS TRANSPOSED
+// ([channel][pixel]): a thread loads the same 8-channel chunk of two adjacent pixels (2 x 16 B, coalesced along channels)
+// and writes eight 4-byte (pixel, pixel+1) pairs; fragments are then plain ds_read_b128.  Workgroup = 4 waves (2 x 2),
+// tile 64 o x 64 k, slab of m_per_block pixels, fp32 atomics on the small result.  Needs Ck % 8 == 0.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWgRow = 80;                                   // LDS row: 32 pixels x 2 B + 16 B pad
+
+__global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, WgradGeom g,
+                                                              float* __restrict__ dw) {
+    __shared__ __attribute__((aligned(16))) char lds[2][2][64 * kWgRow];      // [buffer][0 = dy^T, 1 = A^T][64 rows]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wo = wave >> 1, wk = wave & 1;
+    const int k0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+    const int m_begin = blockIdx.z * g.m_per_block, m_end = min(m_begin + g.m_per_block, g.M);
+
+    // loader role: threads 0..127 transpose dy, 128..255 the im2col operand; thread = (pixel pair pp, 8-channel chunk c)
+    const bool is_a = tid >= 128;
+    const int lt = tid & 127, pp = lt >> 3, c8 = (lt & 7) * 8;
+    const int kk = k0 + c8;                                   // first of this thread's 8 consecutive k (one tap: Ck % 8 == 0)
+    const bool col_ok = is_a ? kk < g.K : o0 + c8 < g.Cout;
+    const int tap = (is_a && col_ok) ? kk / g.Ck : 0, ch = kk - tap * g.Ck;
+    const int th = tap / g.kw, tw = tap - th * g.kw;
+    const int hw = g.Ho * g.Wo;
+    // (b, oh, ow) of this thread's first pixel, advanced incrementally by 32 pixels per step
+    int m = m_begin + 2 * pp;
+    int pb = m / hw, rem = m - pb * hw, poh = rem / g.Wo, pow_ = rem - poh * g.Wo;
+    auto advance = [&](int& b_, int& oh_, int& ow_, int n) {
+        ow_ += n;
+        while (ow_ >= g.Wo) { ow_ -= g.Wo; if (++oh_ == g.Ho) { oh_ = 0; ++b_; } }
+    };
+    u32x4 r0, r1;
+    auto gload = [&]() {                                      // this thread's chunk of pixels m and m+1 (zero when masked)
+        r0 = u32x4{0u, 0u, 0u, 0u}; r1 = r0;
+        if (!col_ok) return;
+        if (!is_a) {
+            if (m < m_end) r0 = *reinterpret_cast<const u32x4*>(dy + (size_t)m * g.ldy + o0 + c8);
+            if (m + 1 < m_end) r1 = *reinterpret_cast<const u32x4*>(dy + (size_t)(m + 1) * g.ldy + o0 + c8);
+        } else {
+            int b2 = pb, oh2 = poh, ow2 = pow_;
+            if (m < m_end) {
+                const int ih = poh * g.stride - g.pad_h + th, iw = pow_ * g.stride - g.pad_w + tw;
+                if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+                    r0 = *reinterpret_cast<const u32x4*>(x + ((size_t)(pb * g.H + ih) * g.W + iw) * g.x_pixstride + ch);
+            }
+            if (m + 1 < m_end) {
+                advance(b2, oh2, ow2, 1);
+                const int ih = oh2 * g.stride - g.pad_h + th, iw = ow2 * g.stride - g.pad_w + tw;
+                if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+                    r1 = *reinterpret_cast<const u32x4*>(x + ((size_t)(b2 * g.H + ih) * g.W + iw) * g.x_pixstride + ch);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {                              // transposed: row = channel, 4-byte (pixel, pixel+1) pairs
+        char* base = lds[buf][is_a ? 1 : 0] + c8 * kWgRow + pp * 4;
+        const uint32_t a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<uint32_t*>(base + (2 * q) * kWgRow) = (a[q] & 0xffffu) | (b[q] << 16);
+            *reinterpret_cast<uint32_t*>(base + (2 * q + 1) * kWgRow) = (a[q] >> 16) | (b[q] & 0xffff0000u);
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frag = (lane & 15) * kWgRow + (lane >> 4) * 16;
+
+    gload();
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int mb = m_begin; mb < m_end; mb += 32) {
+        const bool more = mb + 32 < m_end;
+        if (more) { m += 32; advance(pb, poh, pow_, 32); gload(); }
+        u32x4 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(lds[buf][0] + (wo * 32 + i * 16) * kWgRow + frag);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const u32x4*>(lds[buf][1] + (wk * 32 + j * 16) * kWgRow + frag);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma_chunk<bf16_t>(af[i], bf[j], acc[i][j]);
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // D: col (lane&15) = k, row (lane>>4)*4 + r = o
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + wo * 32 + i * 16 + (lane >> 4) * 4 + r, k = k0 + wk * 32 + j * 16 + (lane & 15);
+                if (o < g.Cout && k < g.K) unsafeAtomicAdd(dw + (size_t)o * g.K + k, acc[i][j][r]);
+            }
+}
+
 // column sums: out[c] += sum_m x[m][c]      (bias gradient)
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ x, int M, int C, int ld, int rows_per_block, float* __restrict__ out) {
@@ -326,6 +430,8 @@ __global__ void zero_insert2_kernel(const T* __restrict__ dy, T* __restrict__ up
 }  // namespace mfx
 using namespace mfx;
 
+int g_opt_wgrad_mfma = 1;     // option "wgrad_mfma": 0 = VALU kernel for bf16 too
+
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == MFX_F32) { CALL_F32; } else if ((dtype) == MFX_BF16) { CALL_BF16; } else return mfx_fail(MFX_ERR_ARG, "bad dtype"); } while (0)
 
 extern "C" int mfx_conv_wgrad_nhwc(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
@@ -339,6 +445,13 @@ extern "C" int mfx_conv_wgrad_nhwc(const void* x, const void* dy, float* dw, int
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)Cout * g.K * sizeof(float), st));
     if (g.M == 0) return MFX_OK;
+    if (dtype == MFX_BF16 && Ck % 8 == 0 && x_pixstride % 8 == 0 && ldy % 8 == 0 && g_opt_wgrad_mfma) {
+        g.m_per_block = g.M >= (1 << 20) ? 8192 : g.M >= (1 << 16) ? 4096 : 1024;
+        dim3 grid(cdivt(g.K, 64), cdivt(Cout, 64), cdivt(g.M, g.m_per_block));
+        hipLaunchKernelGGL(conv_wgrad_mfma_kernel, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
+        MFX_HIP_CHECK(hipGetLastError());
+        return MFX_OK;
+    }
     dim3 grid(cdivt(g.K, 64), cdivt(Cout, 64), cdivt(g.M, g.m_per_block));
     DISPATCH_T(dtype, hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, g, dw),
                       hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw));
