@@ -229,6 +229,33 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
     for (int i = tid; i < C; i += 256) { unsafeAtomicAdd(sum + i, sred[i]); unsafeAtomicAdd(sumsq + i, sred[C + i]); }
 }
 
+// column sums with the bn_stats thread mapping (16-byte chunks along channels, rows strided): used for bias gradients when
+// the row is a power-of-two number of chunks (every padded output map is)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_chunk_kernel(const T* __restrict__ x, long M, int C, int ld, int rows_per_block, float* __restrict__ out) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    extern __shared__ float sred[];                          // [C]
+    const int CPR = C / E, tid = threadIdx.x;
+    const int cc = tid % CPR, rstep = 256 / CPR, roff = tid / CPR;
+    for (int i = tid; i < C; i += 256) sred[i] = 0.f;
+    __syncthreads();
+    float s[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(r0 + (long)rows_per_block, M);
+    if (roff < rstep)
+        for (long r = r0 + roff; r < r1; r += rstep) {
+            float v[E];
+            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + r * ld + cc * E), v);
+#pragma unroll
+            for (int e = 0; e < E; ++e) s[e] += v[e];
+        }
+#pragma unroll
+    for (int e = 0; e < E; ++e) atomicAdd(&sred[cc * E + e], s[e]);
+    __syncthreads();
+    for (int i = tid; i < C; i += 256) unsafeAtomicAdd(out + i, sred[i]);
+}
+
 // y = act(x*scale[c] + shift[c] (+ res))
 template <typename T>
 __global__ void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -395,7 +422,8 @@ __global__ __launch_bounds__(256) void upsample_bwd_dw_kernel(const T* __restric
     const int k = 2 * f, p_ = f / 2, Ho = H * f, Wo = W * f, taps = k * k;
     const long npix = (long)B * H * W;
     const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(p0 + (long)pix_per_block, npix);
-    for (int item = threadIdx.x; item < taps * C; item += 256) {
+    // blockIdx.y selects a 256-wide slice of the (tap, channel) items: a wave reads 64 consecutive channels of one tap
+    for (int item = blockIdx.y * 256 + threadIdx.x; item < taps * C; item += 256 * gridDim.y) {
         const int c = item % C, tap = item / C, kh = tap / k, kw = tap - kh * k;
         float s = 0.f;
         for (long p = p0; p < p1; ++p) {
@@ -464,7 +492,18 @@ extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     MFX_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
     if (M == 0) return MFX_OK;
-    const int rows = 2048;
+    {
+        const int E = dtype == MFX_BF16 ? 8 : 4;
+        if (C % E == 0 && ld % E == 0 && C / E <= 256 && 256 % (C / E) == 0) {
+            const int rows2 = M >= (1 << 20) ? 2048 : 512;
+            const size_t smem = (size_t)C * sizeof(float);
+            DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_chunk_kernel<float>, dim3(cdivt(M, rows2)), dim3(256), smem, st, (const float*)x, M, C, ld, rows2, out),
+                              hipLaunchKernelGGL(colsum_chunk_kernel<bf16_t>, dim3(cdivt(M, rows2)), dim3(256), smem, st, (const bf16_t*)x, M, C, ld, rows2, out));
+            MFX_HIP_CHECK(hipGetLastError());
+            return MFX_OK;
+        }
+    }
+    const int rows = M >= (1 << 18) ? 1024 : 128;             // >= ~2 workgroups per CU also on the small head maps
     dim3 grid(cdivt(M, rows), cdivt(C, 64)), block(64, 4);
     DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)x, (int)M, C, ld, rows, out),
                       hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (int)M, C, ld, rows, out));
@@ -573,9 +612,9 @@ extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* 
     const long npix = (long)B * H * W;
     DISPATCH_T(dtype,
         { hipLaunchKernelGGL(upsample_bwd_dx_kernel<float>, TR_GRID(total), dim3(256), 0, st, (const float*)dy, w, (float*)dx, B, H, W, C, f);
-          hipLaunchKernelGGL(upsample_bwd_dw_kernel<float>, dim3(cdivt(npix, ppb)), dim3(256), 0, st, (const float*)x, (const float*)dy, dw, B, H, W, C, f, ppb); },
+          hipLaunchKernelGGL(upsample_bwd_dw_kernel<float>, dim3(cdivt(npix, ppb), cdivt(4 * f * f * C, 256)), dim3(256), 0, st, (const float*)x, (const float*)dy, dw, B, H, W, C, f, ppb); },
         { hipLaunchKernelGGL(upsample_bwd_dx_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, (const bf16_t*)dy, w, (bf16_t*)dx, B, H, W, C, f);
-          hipLaunchKernelGGL(upsample_bwd_dw_kernel<bf16_t>, dim3(cdivt(npix, ppb)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, C, f, ppb); });
+          hipLaunchKernelGGL(upsample_bwd_dw_kernel<bf16_t>, dim3(cdivt(npix, ppb), cdivt(4 * f * f * C, 256)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, C, f, ppb); });
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

@@ -41,6 +41,20 @@ def wrap_data_parallel(model, device_ids=None, bucket_cap_mb=25):
                bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
 
 
+class PreparedTargets(list):
+    """The per-image targets of one batch plus their device-side stacked form, built once per batch (outside any graph
+    capture): `.edge` = (edge_indices, edge_lens) for the predictor, `.loss` = (heat maps, stacked fields) for the loss."""
+
+
+def prepare_targets(model, targets, device):
+    from ..model.head.detector_predictor import stack_edge_fields
+    m = model.module if hasattr(model, "module") else model
+    pt = PreparedTargets(targets)
+    pt.edge = stack_edge_fields(targets, device)
+    pt.loss = m.heads.loss_evaluator.prepare_targets(targets, device)
+    return pt
+
+
 def train_step(model, optimizer, images, targets, grad_norm_clip=-1.0, scheduler=None):
     """trainer.py:109-126: forward -> summed loss -> zero_grad -> backward (+DDP all-reduce) -> clip -> step."""
     loss_dict, log_loss_dict = model(images, targets)

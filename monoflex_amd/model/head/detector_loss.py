@@ -73,6 +73,14 @@ class Loss_Computation:
         self.down_ratio = cfg.MODEL.BACKBONE.DOWN_RATIO
         self.EPS = 1e-3
         self.log_as_float = True          # reference returns python floats in log_loss_dict; False keeps 0-d tensors
+        self._consts = {}
+
+    def _const(self, name, values, device, dtype=torch.float32):
+        """Small constant tables live on the device once (no host-to-device copy per step: those cannot be graph-captured)."""
+        key = (name, str(device), dtype)
+        if key not in self._consts:
+            self._consts[key] = torch.as_tensor(values, dtype=dtype).to(device)
+        return self._consts[key]
 
     # ---------------------------------------------------------------------------------------------
     def prepare_targets(self, targets, device=None):
@@ -107,11 +115,11 @@ class Loss_Computation:
         return d
 
     def _decode_dimension(self, cls_id, off):                                     # anno_encoder.py:217-239
-        mean = self.dim_mean.to(off.device)[cls_id]
+        mean = self._const("dim_mean", self.dim_mean, off.device)[cls_id]
         if self.dim_modes[0] == 'exp':
             off = off.exp()
         if self.dim_modes[2]:
-            return off * self.dim_std.to(off.device)[cls_id] + mean
+            return off * self._const("dim_std", self.dim_std, off.device)[cls_id] + mean
         return off * mean
 
     def _decode_location(self, points, offsets, depths, cal, pad):                # anno_encoder.py:142-156 + kitti_utils.py:350-369
@@ -123,8 +131,8 @@ class Loss_Computation:
     def _keypoint_depths(self, kpts, dims, f_u):                                  # anno_encoder.py:185-215
         h3d = dims[:, 1]
         center_h = kpts[:, -2, 1] - kpts[:, -1, 1]
-        c02 = kpts[:, [0, 2], 1] - kpts[:, [4, 6], 1]
-        c13 = kpts[:, [1, 3], 1] - kpts[:, [5, 7], 1]
+        c02 = kpts[:, 0:3:2, 1] - kpts[:, 4:7:2, 1]                               # corners (0,2) - (4,6); slices, not index lists
+        c13 = kpts[:, 1:4:2, 1] - kpts[:, 5:8:2, 1]
         dc = f_u * h3d / (F.relu(center_h) * self.down_ratio + self.EPS)
         d02 = (f_u.unsqueeze(-1) * h3d.unsqueeze(-1) / (F.relu(c02) * self.down_ratio + self.EPS)).mean(dim=1)
         d13 = (f_u.unsqueeze(-1) * h3d.unsqueeze(-1) / (F.relu(c13) * self.down_ratio + self.EPS)).mean(dim=1)
@@ -135,20 +143,19 @@ class Loss_Computation:
         conf = torch.softmax(vec[:, :nb * 2].reshape(-1, nb, 2), dim=2)[..., 1]
         best = conf.argmax(dim=1, keepdim=True)
         off = vec[:, nb * 2:].reshape(-1, nb, 2)
-        centers = torch.tensor([0, PI / 2, PI, -PI / 2], device=vec.device, dtype=vec.dtype)[:nb]
+        centers = self._const("alpha_centers", [0, PI / 2, PI, -PI / 2], vec.device, vec.dtype)[:nb]
         alpha_all = torch.atan2(off[..., 0], off[..., 1]) + centers
         alphas = alpha_all.gather(1, best).squeeze(1)
         rotys = alphas + torch.atan2(locs[:, 0], locs[:, 2])
         rotys = torch.where(rotys > PI, rotys - 2 * PI, rotys)
         return torch.where(rotys < -PI, rotys + 2 * PI, rotys)
 
-    @staticmethod
-    def encode_box3d(rotys, dims, locs):                                          # anno_encoder.py:88-122
+    def encode_box3d(self, rotys, dims, locs):                                    # anno_encoder.py:88-122
         c, s = rotys.cos(), rotys.sin()
         l, h, w = dims[:, 0:1] * 0.5, dims[:, 1:2] * 0.5, dims[:, 2:3] * 0.5
-        sx = torch.tensor([-1, -1, 1, 1, -1, -1, 1, 1], device=dims.device, dtype=dims.dtype)       # -l/2 .. l/2 per corner
-        sy = torch.tensor([1, 1, 1, 1, -1, -1, -1, -1], device=dims.device, dtype=dims.dtype)
-        sz = torch.tensor([-1, 1, 1, -1, -1, 1, 1, -1], device=dims.device, dtype=dims.dtype)
+        sx = self._const("corner_sx", [-1, -1, 1, 1, -1, -1, 1, 1], dims.device, dims.dtype)        # -l/2 .. l/2 per corner
+        sy = self._const("corner_sy", [1, 1, 1, 1, -1, -1, -1, -1], dims.device, dims.dtype)
+        sz = self._const("corner_sz", [-1, 1, 1, -1, -1, 1, 1, -1], dims.device, dims.dtype)
         x, y, z = l * sx, h * sy, w * sz
         X = c[:, None] * x + s[:, None] * z + locs[:, 0:1]
         Y = y + locs[:, 1:2]
@@ -273,7 +280,8 @@ class Loss_Computation:
 
     def __call__(self, predictions, targets):
         dev = predictions['reg'].device
-        heat, tv = targets if isinstance(targets, tuple) else self.prepare_targets(targets, dev)
+        prepared = targets if isinstance(targets, tuple) else getattr(targets, "loss", None)
+        heat, tv = prepared if prepared is not None else self.prepare_targets(targets, dev)
         T, P, sel, _ = self.prepare_predictions(tv, predictions)
         W = self.loss_weights
         valid, v = sel['valid'], sel['valid'].float()
@@ -306,7 +314,7 @@ class Loss_Computation:
             offset_loss = W['offset_loss'] * _wmean(off_l1, v)
 
         orien_loss = W['orien_loss'] * self._multibin(P['orien_3D'], T['orien_3D'], v)
-        dims_l1 = (P['dims_3D'] - T['dims_3D']).abs() * self.dim_weight.to(dev)
+        dims_l1 = (P['dims_3D'] - T['dims_3D']).abs() * self._const('dim_weight', self.dim_weight, dev)
         dims_loss = W['dims_loss'] * _wmean(dims_l1.sum(dim=1), v)
         # (N,8) per-corner L1 sums averaged over all N*8 entries (detector_loss.py:338-339: `.sum(dim=2).mean()`)
         corner_loss = W['corner_loss'] * _wmean((P['corners_3D'] - T['corners_3D']).abs().sum(dim=2).mean(dim=1), v)

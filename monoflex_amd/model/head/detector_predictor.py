@@ -212,11 +212,14 @@ class _predictor(nn.Module):
                 o = AG.conv2d(h1, c3.weight.unsqueeze(2), c3.bias, 1, 0, out_dtype=torch.float32).view(B, Lmax, -1)
                 lo = 0 if base is cls else sum(self.regression_channel_cfg[oi][:oj])
                 co = o.shape[-1]
-                valid = torch.arange(Lmax, device=features.device).view(1, Lmax) < edge_lens.view(B, 1).long()
-                bi, li = valid.nonzero(as_tuple=True)
-                ys, xs = edge_indices[bi, li, 1].long(), edge_indices[bi, li, 0].long()
-                add = torch.zeros_like(base)
-                add[bi, ys, xs, lo:lo + co] = o[bi, li]                                       # '+=' on unique border pixels
+                # static-shape scatter (no nonzero()/host sync, graph-capturable): positions >= edge_len contribute zeros;
+                # the valid border pixels are unique, so accumulate == the reference's '+='
+                valid = (torch.arange(Lmax, device=features.device).view(1, Lmax) < edge_lens.view(B, 1).long()).to(o.dtype)
+                ys, xs = edge_indices[..., 1].long(), edge_indices[..., 0].long()
+                bl = torch.arange(B, device=features.device).view(B, 1).expand(B, Lmax)
+                add = torch.zeros(B, H, W, co, dtype=o.dtype, device=o.device).index_put((bl, ys, xs), o * valid.unsqueeze(-1), accumulate=True)
+                if co != base.shape[-1]:
+                    add = torch.nn.functional.pad(add, (lo, base.shape[-1] - lo - co))
                 new.append(base + add)
             cls, regs[oi] = new[0], new[1]
         return cls, torch.cat(regs, dim=3)
@@ -224,7 +227,7 @@ class _predictor(nn.Module):
     def forward(self, features, targets):
         """Reference surface: features (B,64,H,W) (any strides) + targets -> {'cls','reg'} NCHW views."""
         x = features.permute(0, 2, 3, 1).contiguous()
-        ei, el = stack_edge_fields(targets, x.device)
+        ei, el = getattr(targets, "edge", None) or stack_edge_fields(targets, x.device)
         if self.training:
             cls, reg = self.forward_train(x, ei, el)
             cls = torch.sigmoid(cls).clamp(min=1e-4, max=1 - 1e-4)

@@ -17,12 +17,13 @@ def get_model_params(model, cfg, per_parameter_groups=False):
     return [{"params": w, "lr": base_lr}, {"params": b, "lr": bias_lr}]
 
 
-def build_optimizer(model, cfg, per_parameter_groups=False):
+def build_optimizer(model, cfg, per_parameter_groups=False, capturable=False):
     s = cfg.SOLVER
     params = get_model_params(model, cfg, per_parameter_groups)
     on_gpu = any(p.is_cuda for g in params for p in g["params"])
     if s.OPTIMIZER == "adamw":
-        return torch.optim.AdamW(params, lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY, betas=(0.9, 0.99), fused=on_gpu or None)
+        return torch.optim.AdamW(params, lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY, betas=(0.9, 0.99), fused=on_gpu or None,
+                                 capturable=capturable)
     if s.OPTIMIZER == "adam":
         return torch.optim.Adam(params, lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY, betas=(0.9, 0.99), fused=on_gpu or None)
     if s.OPTIMIZER == "sgd":
