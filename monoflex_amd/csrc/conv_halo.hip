@@ -30,24 +30,32 @@ struct HaloGeom {
 
 constexpr int kHaloRows = 8;               // output rows per workgroup (FM)
 
-template <typename T, int WN, int FN> struct HaloSmem {
+template <typename T, int WN, int FN, int WK = 1> struct HaloSmem {
     static constexpr int stage_ld = FN * 16 + 4;                              // fp32 words per staged pixel row
     static constexpr int stage_bytes = 16 * stage_ld * 4;                     // per wave
+    static constexpr int reduce_bytes = WK > 1 ? WN * WK * kHaloRows * FN * 64 * 16 : 0;   // split-K partial accumulators
     static __host__ __device__ constexpr int patch_stride(int CG) { return CG * (int)sizeof(T) + 16; }
     static __host__ __device__ constexpr int patch_bytes(int CG) { return (kHaloRows + 2) * 18 * patch_stride(CG); }
-    static __host__ __device__ constexpr int total(int CG) { return patch_bytes(CG) + WN * stage_bytes; }
+    // the K-split reduction reuses the patch memory once the K loop is over
+    static __host__ __device__ constexpr int main_bytes(int CG) { return patch_bytes(CG) > reduce_bytes ? patch_bytes(CG) : reduce_bytes; }
+    static __host__ __device__ constexpr int total(int CG) { return main_bytes(CG) + WN * WK * stage_bytes; }
 };
 
-template <typename T, typename TO, int WN, int FN>
-__global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __restrict__ x, const T* __restrict__ w,
-                                                                 const u32x4* __restrict__ wfm, HaloGeom g, EpiArgs ep) {
-    constexpr int NT = WN * 64, FM = kHaloRows;
-    using SM = HaloSmem<T, WN, FN>;
+// WK > 1: WK waves share each output slice and split the K steps among themselves (step s belongs to wave s % WK); their
+// partial accumulators meet in LDS after the K loop and each wave finishes FM / WK output rows.  For narrow outputs
+// (the 27-channel DCN offset/mask conv: N = 32) a workgroup would otherwise be ONE wave walking the whole K alone.
+template <typename T, typename TO, int WN, int FN, int WK = 1>
+__global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                                      const u32x4* __restrict__ wfm, HaloGeom g, EpiArgs ep) {
+    constexpr int NT = WN * WK * 64, FM = kHaloRows;
+    static_assert(FM % WK == 0, "rows must split evenly over the K-split waves");
+    using SM = HaloSmem<T, WN, FN, WK>;
     constexpr int ELEMS = ElemTraits<T>::ELEMS;
     constexpr int BN = WN * FN * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wk = wave / WN;
 
     // tile decode: n-tile fastest, then x, y, image -> neighbours share halos in one XCD's L2
     int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
 
     const int PS = SM::patch_stride(g.CG);
     char* patch = smem;
-    float* stage = reinterpret_cast<float*>(smem + SM::patch_bytes(g.CG) + wn * SM::stage_bytes);
+    float* stage = reinterpret_cast<float*>(smem + SM::main_bytes(g.CG) + wave * SM::stage_bytes);
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -152,11 +160,14 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
                 bf[j] = z;
             }
         };
-        // weight fragments: ring of 3 register buffers, fetched two steps ahead of their use
+        // weight fragments: ring of 3 register buffers, fetched two steps ahead of their use.  This wave's steps are
+        // S(j) = wk + j*WK, j < nl
         u32x4 wb[3][FN];
         const int ns = g.steps_per_group;
-        wfetch(0, wb[0]);
-        if (ns > 1) wfetch(1, wb[1]);
+        const int nl = ns > wk ? (ns - wk + WK - 1) / WK : 0;
+        auto S = [&](int j) { return wk + j * WK; };
+        if (nl > 0) wfetch(S(0), wb[0]);
+        if (nl > 1) wfetch(S(1), wb[1]);
         __syncthreads();                                      // patch visible to all waves
 
         auto compute = [&](int s, const u32x4 (&bf)[FN]) {
@@ -174,19 +185,40 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
             }
         };
         int s = 0;
-        for (; s + 3 <= ns; s += 3) {                         // unrolled by 3 so the ring indices are static
-            if (s + 2 < ns) wfetch(s + 2, wb[2]);
-            compute(s, wb[0]);
-            if (s + 3 < ns) wfetch(s + 3, wb[0]);
-            compute(s + 1, wb[1]);
-            if (s + 4 < ns) wfetch(s + 4, wb[1]);
-            compute(s + 2, wb[2]);
+        for (; s + 3 <= nl; s += 3) {                         // unrolled by 3 so the ring indices are static
+            if (s + 2 < nl) wfetch(S(s + 2), wb[2]);
+            compute(S(s), wb[0]);
+            if (s + 3 < nl) wfetch(S(s + 3), wb[0]);
+            compute(S(s + 1), wb[1]);
+            if (s + 4 < nl) wfetch(S(s + 4), wb[1]);
+            compute(S(s + 2), wb[2]);
         }
-        if (s < ns) {                                         // 1 or 2 steps left; their fragments are already in flight
-            if (s + 2 < ns) wfetch(s + 2, wb[2]);
-            compute(s, wb[0]);
-            if (s + 1 < ns) compute(s + 1, wb[1]);
+        if (s < nl) {                                         // 1 or 2 steps left; their fragments are already in flight
+            if (s + 2 < nl) wfetch(S(s + 2), wb[2]);
+            compute(S(s), wb[0]);
+            if (s + 1 < nl) compute(S(s + 1), wb[1]);
         }
+    }
+
+    // ---- K-split: partial accumulators -> LDS (the patch is dead), wave wk sums and finishes rows wk*RW .. +RW
+    constexpr int RW = FM / WK;
+    if constexpr (WK > 1) {
+        __syncthreads();                                      // every wave is done reading the patch
+        f32x4* red = reinterpret_cast<f32x4*>(smem);          // [wn][wk][i][j][lane]
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) red[(((wn * WK + wk) * FM + i) * FN + j) * 64 + lane] = acc[i][j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < WK; ++q) t += red[(((wn * WK + q) * FM + wk * RW + r) * FN + j) * 64 + lane];
+                acc[r][j] = t;                                // row wk*RW + r now lives in slot r
+            }
     }
 
     // ---- epilogue, wave-private: acc row-fragment i (16 pixels of output row y0+i) -> stage -> 16-byte stores
@@ -202,12 +234,13 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
         sh[j] = ep.shift ? ep.shift[n0 + j * 16 + xl] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
+    for (int ii = 0; ii < RW; ++ii) {
+        const int i = WK > 1 ? wk * RW + ii : ii;             // output row of accumulator slot ii
         // D layout: col n = lane&15, row (pixel x) = (lane>>4)*4 + r
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[((lane >> 4) * 4 + r) * LDS_ + j * 16 + xl] = acc[i][j][r] * sc[j] + sh[j];
+            for (int r = 0; r < 4; ++r) stage[((lane >> 4) * 4 + r) * LDS_ + j * 16 + xl] = acc[ii][j][r] * sc[j] + sh[j];
         __builtin_amdgcn_wave_barrier();                      // same wave: DS ops complete in order
         const int oy = y0 + i;
 #pragma unroll
@@ -228,7 +261,7 @@ __global__ __launch_bounds__(WN * 64, 2) void conv3x3_wave_kernel(const T* __res
                     const T* rp = res + gm * ep.ldres + gn;
                     if constexpr (kResPrefetch) {
                         float rv[OE];
-                        ElemTraits<T>::unpack(rpre[i][q], rv);
+                        ElemTraits<T>::unpack(rpre[ii][q], rv);
 #pragma unroll
                         for (int e = 0; e < OE; ++e) v[e] += rv[e];
                     } else if constexpr (ElemTraits<T>::ELEMS == OE) {
@@ -255,9 +288,9 @@ static inline int ilog2h(int v) { int l = 0; while ((1 << l) < v) ++l; return l;
 int g_opt_halo = 1;          // 0 = generic kernel only, 1 = automatic, >= 2 = force variant (value - 1)
 int g_opt_halo_cg = 0;       // max channels per patch pass (0 = default)
 
-template <typename T, typename TO, int WN, int FN>
+template <typename T, typename TO, int WN, int FN, int WK = 1>
 static int launch_halo(const mfx_conv_desc* d, hipStream_t st) {
-    using SM = HaloSmem<T, WN, FN>;
+    using SM = HaloSmem<T, WN, FN, WK>;
     constexpr int ELEMS = ElemTraits<T>::ELEMS;
     constexpr int BN = WN * FN * 16;
     HaloGeom g;
@@ -271,14 +304,14 @@ static int launch_halo(const mfx_conv_desc* d, hipStream_t st) {
     ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
     const int smem = SM::total(g.CG);
-    auto k = conv3x3_wave_kernel<T, TO, WN, FN>;
+    auto k = conv3x3_wave_kernel<T, TO, WN, FN, WK>;
     static int attr_smem = 0;
     if (smem > 64 * 1024 && smem > attr_smem) {
         MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_smem = smem;
     }
     const int tiles = g.tiles_n * g.tiles_x * g.tiles_y * d->B;
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(WN * 64), smem, st, reinterpret_cast<const T*>(d->x), reinterpret_cast<const T*>(d->w),
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(WN * WK * 64), smem, st, reinterpret_cast<const T*>(d->x), reinterpret_cast<const T*>(d->w),
                        reinterpret_cast<const u32x4*>(d->w_frag), g, ep);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -290,6 +323,9 @@ template <typename T, typename TO> static int halo_variant(int v, const mfx_conv
     switch (v) {
         case 1: return launch_halo<T, TO, 1, 1>(d, st);
         case 2: return launch_halo<T, TO, 1, 2>(d, st);
+        case 8: return launch_halo<T, TO, 1, 2, 4>(d, st);    // BN32, 4 waves split K
+        case 9: return launch_halo<T, TO, 1, 2, 2>(d, st);    // BN32, 2 waves split K
+        case 10: return launch_halo<T, TO, 1, 1, 4>(d, st);   // BN16, 4 waves split K
         default: break;
     }
     if constexpr (std::is_same<T, TO>::value) {
@@ -305,7 +341,7 @@ template <typename T, typename TO> static int halo_variant(int v, const mfx_conv
     return mfx_fail(MFX_ERR_UNSUPPORTED, "conv halo: no such variant");
 }
 
-static int variant_bn(int v) { const int bn[8] = {0, 16, 32, 64, 128, 256, 64, 128}; return (v >= 1 && v <= 7) ? bn[v] : 0; }
+static int variant_bn(int v) { const int bn[11] = {0, 16, 32, 64, 128, 256, 64, 128, 32, 32, 16}; return (v >= 1 && v <= 10) ? bn[v] : 0; }
 
 // returns 1 if the halo kernel handled the convolution, 0 if the caller should use the generic kernel, <0 on error
 int try_conv_halo(const mfx_conv_desc* d, hipStream_t st) {
@@ -320,7 +356,9 @@ int try_conv_halo(const mfx_conv_desc* d, hipStream_t st) {
     // 32 output channels per wave; narrow outputs on small maps split N further to get more waves in flight
     int v;
     if (N == 16) v = 1;
-    else if (N == 32) v = px_tiles >= 256 ? 2 : 1;          // probe: BN32 wins down to 480 pixel tiles, BN16 below
+    // N = 32 is the DCN offset/mask conv: one or two waves per pixel tile cannot hide anything, so the waves split K
+    // (tools/layer_bench.py, B=8: 512ch@12x40 83 -> 34 us, 256ch@24x80 50 -> 23, 128ch@48x160 43 -> 24, 64ch@96x320 49 -> 37)
+    else if (N == 32) v = (px_tiles >= 300 && px_tiles < 1500) ? 8 : 10;
     else if (N == 64) v = 6;
     else if (N % 128 == 0) {
         if (px_tiles * (N / 128) < 300) return 0;             // tiny maps (12x40): the generic 64x64 tiling has more parallelism

@@ -355,3 +355,27 @@ def test_conv_split_k_matches_single_pass(dtype, shape):
             assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), ks
     finally:
         L.check(lib_.mfx_set_option(b"ksplit", 0), "opt")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 20, 40, 64), (1, 12, 40, 512), (2, 9, 17, 128)])
+def test_offset_conv_k_split_waves(dtype, B, H, W, C):
+    """3x3 conv with a narrow output (the 27-channel DCN offset/mask conv, fp32 out, sigmoid on the mask channels):
+    halo-kernel variants whose waves split K (8: 4 waves, 9: 2 waves, 10: BN16 x 4 waves) against the generic kernel."""
+    from monoflex_amd import lib as L, ops
+    g = _g(51)
+    x = torch.randn(B, H, W, C, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(27, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+    bias = torch.randn(27, generator=g).to(DEV)
+    p = ops.pack_conv(w, dtype, None, bias, stride=1, pad=1, act=L.ACT_DCN_OFFMASK, cout=32)
+    lib_ = L.load()
+    try:
+        L.check(lib_.mfx_set_option(b"halo", 0), "opt")
+        want = ops.conv2d(x, p, out_dtype=torch.float32).cpu()
+        for v in (8, 9, 10):
+            L.check(lib_.mfx_set_option(b"halo", v + 1), "opt")
+            got = ops.conv2d(x, p, out_dtype=torch.float32).cpu()
+            tol = 2e-5 if dtype == torch.float32 else 2e-3
+            assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), v
+    finally:
+        L.check(lib_.mfx_set_option(b"halo", 1), "opt")
