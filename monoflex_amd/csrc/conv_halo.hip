@@ -33,7 +33,7 @@ constexpr int kHaloRows = 8;               // output rows per workgroup (FM)
 template <typename T, int WN, int FN, int WK = 1> struct HaloSmem {
     static constexpr int stage_ld = FN * 16 + 4;                              // fp32 words per staged pixel row
     static constexpr int stage_bytes = 16 * stage_ld * 4;                     // per wave
-    static constexpr int reduce_bytes = WK > 1 ? WN * WK * kHaloRows * FN * 64 * 16 : 0;   // split-K partial accumulators
+    static constexpr int reduce_bytes = WN * (WK - 1) * kHaloRows * FN * 64 * 16;          // split-K: partials of the rows a wave does not finish itself
     static __host__ __device__ constexpr int patch_stride(int CG) { return CG * (int)sizeof(T) + 16; }
     static __host__ __device__ constexpr int patch_bytes(int CG) { return (kHaloRows + 2) * 18 * patch_stride(CG); }
     // the K-split reduction reuses the patch memory once the K loop is over
@@ -204,21 +204,36 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
     constexpr int RW = FM / WK;
     if constexpr (WK > 1) {
         __syncthreads();                                      // every wave is done reading the patch
-        f32x4* red = reinterpret_cast<f32x4*>(smem);          // [wn][wk][i][j][lane]
+        // red[wn][dst][slot][r][j][lane]: what wave `src` accumulated for the RW rows finished by wave `dst`
+        // (slot = src with dst skipped): a wave never writes the rows it finishes itself
+        f32x4* red = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+        for (int dst = 0; dst < WK; ++dst) {
+            if (dst == wk) continue;
+            const int slot = wk < dst ? wk : wk - 1;
 #pragma unroll
-            for (int j = 0; j < FN; ++j) red[(((wn * WK + wk) * FM + i) * FN + j) * 64 + lane] = acc[i][j];
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    red[((((wn * WK + dst) * (WK - 1) + slot) * RW + r) * FN + j) * 64 + lane] = acc[dst * RW + r][j];
+        }
         __syncthreads();
+        f32x4 own[RW][FN];
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < WK; ++q) t += red[(((wn * WK + q) * FM + wk * RW + r) * FN + j) * 64 + lane];
-                acc[r][j] = t;                                // row wk*RW + r now lives in slot r
+                for (int q = 0; q < WK; ++q) if (q == wk) t = acc[q * RW + r][j];       // own partial (static register index)
+#pragma unroll
+                for (int slot = 0; slot < WK - 1; ++slot) t += red[((((wn * WK + wk) * (WK - 1) + slot) * RW + r) * FN + j) * 64 + lane];
+                own[r][j] = t;
             }
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[r][j] = own[r][j];       // row wk*RW + r now lives in slot r
     }
 
     // ---- epilogue, wave-private: acc row-fragment i (16 pixels of output row y0+i) -> stage -> 16-byte stores
@@ -335,13 +350,17 @@ template <typename T, typename TO> static int halo_variant(int v, const mfx_conv
             case 5: return launch_halo<T, TO, 4, 4>(d, st);
             case 6: return launch_halo<T, TO, 2, 2>(d, st);
             case 7: return launch_halo<T, TO, 4, 2>(d, st);
+            case 11: return launch_halo<T, TO, 4, 2, 2>(d, st);   // BN128, 2-way K split (8 waves)
+            case 12: return launch_halo<T, TO, 2, 2, 2>(d, st);   // BN64, 2-way K split
+            case 13: return launch_halo<T, TO, 2, 2, 4>(d, st);   // BN64, 4-way K split (8 waves)
+            case 14: return launch_halo<T, TO, 2, 4, 2>(d, st);   // BN128 (2 x FN4), 2-way K split
             default: break;
         }
     }
     return mfx_fail(MFX_ERR_UNSUPPORTED, "conv halo: no such variant");
 }
 
-static int variant_bn(int v) { const int bn[11] = {0, 16, 32, 64, 128, 256, 64, 128, 32, 32, 16}; return (v >= 1 && v <= 10) ? bn[v] : 0; }
+static int variant_bn(int v) { const int bn[15] = {0, 16, 32, 64, 128, 256, 64, 128, 32, 32, 16, 128, 64, 64, 128}; return (v >= 1 && v <= 14) ? bn[v] : 0; }
 
 // returns 1 if the halo kernel handled the convolution, 0 if the caller should use the generic kernel, <0 on error
 int try_conv_halo(const mfx_conv_desc* d, hipStream_t st) {
@@ -359,10 +378,11 @@ int try_conv_halo(const mfx_conv_desc* d, hipStream_t st) {
     // N = 32 is the DCN offset/mask conv: one or two waves per pixel tile cannot hide anything, so the waves split K
     // (tools/layer_bench.py, B=8: 512ch@12x40 83 -> 34 us, 256ch@24x80 50 -> 23, 128ch@48x160 43 -> 24, 64ch@96x320 49 -> 37)
     else if (N == 32) v = (px_tiles >= 300 && px_tiles < 1500) ? 8 : 10;
-    else if (N == 64) v = 6;
+    else if (N == 64) v = px_tiles >= 1500 ? 12 : 6;        // 64ch@96x320: 2-way K split 35 us vs 38.6
     else if (N % 128 == 0) {
-        if (px_tiles * (N / 128) < 300) return 0;             // tiny maps (12x40): the generic 64x64 tiling has more parallelism
-        v = 7;
+        // few pixel tiles (level4 24x80: 240, level5 12x40: 192 workgroups): 8 waves with a 2-way K split keep the CUs busy
+        // (256ch@24x80: 27 us vs 43 generic / 38 unsplit; 512ch@12x40: 50 vs 54 generic)
+        v = px_tiles * (N / 128) < 300 ? 11 : 7;
     } else v = 6;
     if (g_opt_halo >= 2) {
         const int f = g_opt_halo - 1, bn = variant_bn(f);
