@@ -131,6 +131,8 @@ typedef struct {
     int32_t Ho, Wo, Cout, Cout_pad, K_pad, ldy, act, dtype;
     const void* w_frag_f16;   /* optional (bf16 mode): the fragment-major weights as IEEE fp16: enables the LDS-patch kernel,
                                  which samples and multiplies in fp16 (3x3, stride 1, pad 1, C % 64 == 0)            */
+    void* workspace;          /* optional fp32 scratch for split-K on small maps (>= 9*M*Cout_pad*4 bytes to allow every split) */
+    int64_t workspace_bytes;
 } mfx_dcn_desc;
 int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream);
 

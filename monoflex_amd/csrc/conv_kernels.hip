@@ -106,12 +106,12 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
     static constexpr int R = BM / RPP;
     static constexpr int kRowBytes = RowGeom<KC>::bytes;
     static_assert(BM % RPP == 0, "BM must be a multiple of the rows covered per pass");
-    const T* x; const float* om; DcnGeom g; int c, r0;
+    const T* x; const float* om; DcnGeom g; int c, r0, cur_tap;
     int oh_[R], ow_[R], pix0[R], mrow[R]; bool ok[R];
     int coff[R][4]; float cw[R][4];
     u32x4 regs[R][4];
     __device__ __forceinline__ void init(const T* x_, const float* om_, const DcnGeom& g_, int m0, int tid) {
-        x = x_; om = om_; g = g_; c = tid % KC; r0 = tid / KC;
+        x = x_; om = om_; g = g_; c = tid % KC; r0 = tid / KC; cur_tap = -1;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int m = m0 + r0 + RPP * i;
@@ -149,7 +149,8 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
     __device__ __forceinline__ void load(int kiter) {
         const int e = kiter * (KC * ELEMS);
         const int ci = (e & (g.C - 1)) + c * ELEMS;
-        if ((e & (g.C - 1)) == 0) tap_setup(e >> g.lgC);      // wave-uniform: a new tap starts
+        const int tap = e >> g.lgC;
+        if (tap != cur_tap) { tap_setup(tap); cur_tap = tap; } // wave-uniform: a new tap starts (or a K split starts mid-way)
 #pragma unroll
         for (int i = 0; i < R; ++i)
 #pragma unroll
@@ -254,6 +255,13 @@ __global__ __launch_bounds__(WM * WN * 64) void dcn_igemm_kernel(const T* x, con
     DcnALoader<T, BM, WM * WN * 64, KC> al; al.init(x, om, g, m0, threadIdx.x);
     WeightLoader<T, BN, WM * WN * 64, KC> bl; bl.init(w, n0, ep.K_pad, threadIdx.x);
     f32x4 acc[BM / WM / 16][BN / WN / 16];
+    if (ep.ksplit > 1) {          // split-K: the gather (the expensive part) is split with it, nothing is duplicated
+        const int per = (ep.nk + ep.ksplit - 1) / ep.ksplit, k0 = blockIdx.y * per;
+        gemm_mainloop<T, BM, BN, WM, WN, KC>(al, bl, min(per, ep.nk - k0), smem, acc, k0);
+        epilogue_store<T, float, BM, BN, WM, WN>(acc, smem, nullptr, nullptr, nullptr, 0,
+                                                 ep.ws + (size_t)blockIdx.y * g.M * ep.ws_ld, ep.ws_ld, m0, n0, g.M, ep.ws_ld, ACT_NONE);
+        return;
+    }
     gemm_mainloop<T, BM, BN, WM, WN, KC>(al, bl, ep.nk, smem, acc);
     epilogue_store<T, T, BM, BN, WM, WN>(acc, smem, ep.scale, ep.shift, nullptr, 0,
                                          reinterpret_cast<T*>(ep.y), ep.ldy, m0, n0, g.M, ep.Cout, ep.act);
@@ -277,6 +285,7 @@ int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st);     // dcn_patch.hip
 // tuning overrides (mfx_set_option): 0 = automatic
 int g_opt_conv_tile = 0, g_opt_dcn_tile = 0, g_opt_cat_tile = 0, g_opt_kc = 0;
 int g_opt_ksplit = 0;        // 0 = automatic, 1 = never split, n = force n splits where legal
+int g_opt_dcn_ksplit = 0;    // same for the fused DCN kernel
 
 template <typename K> static int set_smem(K k, int smem) {
     if (smem > 64 * 1024) MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -393,6 +402,7 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "cat_tile") g_opt_cat_tile = value;
     else if (n == "kc") g_opt_kc = value;
     else if (n == "ksplit") g_opt_ksplit = value;
+    else if (n == "dcn_ksplit") g_opt_dcn_ksplit = value;
     else if (n == "wgrad_mfma") g_opt_wgrad_mfma = value;
     else if (n == "halo") g_opt_halo = value;
     else if (n == "halo_cg") g_opt_halo_cg = value;
@@ -497,6 +507,26 @@ static int launch_dcn(const mfx_dcn_desc* d, const DcnGeom& g, EpiArgs ep, hipSt
     constexpr int smem = TileSmem<BM, BN, KC>::bytes;
     static bool attr_set = false;
     if (!attr_set) { int rc = set_smem(k, smem); if (rc) return rc; attr_set = true; }
+    // split-K on small maps (12x40 .. 24x80: 60 .. 480 tiles with K = 2304 .. 4608): more workgroups, same gather work
+    int ksplit = 1;
+    if (d->workspace && g_opt_dcn_ksplit != 1 && d->Cout == d->Cout_pad) {
+        ksplit = g_opt_dcn_ksplit > 1 ? g_opt_dcn_ksplit : (tiles <= 256 ? 3 : 1);   // layer_bench: 512->256@12x40 83 -> 58 us, 256->64@24x80 49 -> 39; 480-tile layers lose
+        ksplit = std::min(ksplit, std::min(9, ep.nk / 4));
+        while (ksplit > 1 && ((ep.nk + ksplit - 1) / ksplit) * (ksplit - 1) >= ep.nk) --ksplit;
+        if ((size_t)ksplit * g.M * d->Cout_pad * sizeof(float) > (size_t)d->workspace_bytes) ksplit = 1;
+    }
+    if (ksplit > 1) {
+        ep.ksplit = ksplit; ep.ws = reinterpret_cast<float*>(d->workspace); ep.ws_ld = d->Cout_pad;
+        hipLaunchKernelGGL(k, dim3(tiles, ksplit), dim3(WM * WN * 64), smem, st, reinterpret_cast<const T*>(d->x), d->offmask,
+                           reinterpret_cast<const T*>(d->w), g, ep);
+        MFX_HIP_CHECK(hipGetLastError());
+        const long chunks = (long)g.M * (d->Cout / ElemTraits<T>::ELEMS);
+        const int blocks = (int)std::min<long>((chunks + 255) / 256, 4096);
+        hipLaunchKernelGGL(splitk_finalize_kernel<T>, dim3(blocks), dim3(256), 0, st, ep.ws, ksplit, (size_t)g.M * d->Cout_pad, d->Cout_pad,
+                           d->scale, d->shift, (const T*)nullptr, 0, reinterpret_cast<T*>(d->y), d->ldy, g.M, d->Cout, d->act);
+        MFX_HIP_CHECK(hipGetLastError());
+        return MFX_OK;
+    }
     hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), smem, st, reinterpret_cast<const T*>(d->x), d->offmask,
                        reinterpret_cast<const T*>(d->w), g, ep);
     MFX_HIP_CHECK(hipGetLastError());

@@ -241,7 +241,7 @@ static int dcn_bwd_core(const float* x, const float* om, const float* wT, const 
                         float* gwp, float* gb, const BwdGeom& g, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // d(columns)[m][k] = sum_o go[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM
-    mfx_conv_desc cd;
+    mfx_conv_desc cd = {};
     cd.x = go; cd.w = wT; cd.w_frag = nullptr; cd.scale = nullptr; cd.shift = nullptr; cd.res = nullptr; cd.y = gcol; cd.rowmap = nullptr;
     cd.B = 1; cd.H = 1; cd.W = g.M; cd.x_pixstride = g.Coutp; cd.Ck = g.Coutp; cd.kh = 1; cd.kw = 1; cd.stride = 1;
     cd.pad_h = 0; cd.pad_w = 0; cd.dil_w = 1; cd.Ho = 1; cd.Wo = g.M; cd.M = g.M; cd.Cout = g.Kp; cd.Cout_pad = g.Kp;

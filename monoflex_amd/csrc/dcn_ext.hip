@@ -115,7 +115,7 @@ extern "C" int mfx_dcn_v2_forward(const float* input, const float* weight, const
     hipLaunchKernelGGL(pad_copy_kernel, dim3(cdivi(d.Coutp, 256)), dim3(256), 0, st, bias, shift, Cout, d.Coutp);
     MFX_HIP_CHECK(hipGetLastError());
 
-    mfx_dcn_desc dd;
+    mfx_dcn_desc dd = {};
     dd.x = x_nhwc; dd.offmask = om; dd.w = wp; dd.w_frag = nullptr; dd.scale = nullptr; dd.shift = shift; dd.y = y_nhwc;
     dd.B = B; dd.H = H; dd.W = W; dd.C = d.Cp; dd.kh = kh; dd.kw = kw; dd.stride = stride_h; dd.pad = pad_h; dd.dil = dil_h;
     dd.Ho = d.Ho; dd.Wo = d.Wo; dd.Cout = d.Coutp; dd.Cout_pad = d.Coutp; dd.K_pad = d.K; dd.ldy = d.Coutp;

@@ -40,7 +40,8 @@ class DcnDesc(ctypes.Structure):
                 ("B", c_int), ("H", c_int), ("W", c_int), ("C", c_int),
                 ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad", c_int), ("dil", c_int),
                 ("Ho", c_int), ("Wo", c_int), ("Cout", c_int), ("Cout_pad", c_int), ("K_pad", c_int),
-                ("ldy", c_int), ("act", c_int), ("dtype", c_int), ("w_frag_f16", c_void_p)]
+                ("ldy", c_int), ("act", c_int), ("dtype", c_int), ("w_frag_f16", c_void_p),
+                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64)]
 
 
 class HeadsDesc(ctypes.Structure):

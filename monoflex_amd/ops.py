@@ -259,6 +259,9 @@ def dcn(x, offmask, p: PackedConv):
     d.B, d.H, d.W, d.C = B, H, W, C
     d.kh, d.kw, d.stride, d.pad, d.dil = p.kh, p.kw, p.stride, p.pad_h, p.dil_w
     d.Ho, d.Wo, d.Cout, d.Cout_pad, d.K_pad, d.ldy, d.act, d.dtype = Ho, Wo, p.Cout, p.Cout_pad, p.K_pad, p.Cout, p.act, _dt(x.dtype)
+    if B * Ho * Wo * p.Cout_pad <= SPLITK_MAX_ELEMS:           # small maps: lets the library split K over workgroups
+        ws = _splitk_workspace(x.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     L.check(L.load().mfx_dcn_nhwc(ctypes.byref(d), _stream()), "mfx_dcn_nhwc")
     return y
 
@@ -394,11 +397,11 @@ _splitk_ws = {}
 
 
 def _splitk_workspace(device):
-    """One persistent fp32 scratch per device (8 splits x SPLITK_MAX_ELEMS): stable address, so captured graphs stay valid;
+    """One persistent fp32 scratch per device (9 splits x SPLITK_MAX_ELEMS): stable address, so captured graphs stay valid;
     launches on one stream are ordered, so consecutive layers can share it."""
     key = (device.type, device.index)
     if key not in _splitk_ws:
-        _splitk_ws[key] = torch.empty(8 * SPLITK_MAX_ELEMS, dtype=torch.float32, device=device)
+        _splitk_ws[key] = torch.empty(9 * SPLITK_MAX_ELEMS, dtype=torch.float32, device=device)
     return _splitk_ws[key]
 
 

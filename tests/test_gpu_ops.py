@@ -379,3 +379,35 @@ def test_offset_conv_k_split_waves(dtype, B, H, W, C):
             assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), v
     finally:
         L.check(lib_.mfx_set_option(b"halo", 1), "opt")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,Cout,H,W", [(2, 512, 256, 12, 40), (2, 256, 128, 24, 40), (1, 128, 64, 17, 23)])
+def test_dcn_split_k_matches_single_pass(dtype, B, C, Cout, H, W):
+    """Split-K of the fused DCN kernel (small maps): forced split counts incl. ones that start in the middle of a tap,
+    against the single-pass kernel with the same BN/ReLU epilogue."""
+    from monoflex_amd import lib as L, ops
+    g = _g(61)
+    x = torch.randn(B, H, W, C, generator=g).to(dtype).to(DEV)
+    om = torch.zeros(B, H, W, 32)
+    om[..., :18] = torch.randn(B, H, W, 18, generator=g) * 2.0
+    om[..., 18:27] = torch.rand(B, H, W, 9, generator=g)
+    om = om.to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+    p = ops.pack_conv(w, dtype, (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV), stride=1, pad=1,
+                      act=L.ACT_RELU)
+    lib_ = L.load()
+    try:
+        for o in (b"dcn_patch", b"dcn_wave"):
+            L.check(lib_.mfx_set_option(o, 0), "opt")
+        L.check(lib_.mfx_set_option(b"dcn_ksplit", 1), "opt")
+        want = ops.dcn(x, om, p).float().cpu()
+        for ks in (0, 2, 5, 9):
+            L.check(lib_.mfx_set_option(b"dcn_ksplit", ks), "opt")
+            got = ops.dcn(x, om, p).float().cpu()
+            tol = 2e-5 if dtype == torch.float32 else 2e-2
+            assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), ks
+    finally:
+        L.check(lib_.mfx_set_option(b"dcn_ksplit", 0), "opt")
+        for o in (b"dcn_patch", b"dcn_wave"):
+            L.check(lib_.mfx_set_option(o, 1), "opt")

@@ -28,7 +28,7 @@ def test_ctypes_struct_layout_matches_header_sizes():
     # sizes of the descriptor structs as laid out by the C compiler for this ABI (LP64)
     from monoflex_amd import lib as L
     assert ctypes.sizeof(L.ConvDesc) == 8 * 8 + 22 * 4 + 16
-    assert ctypes.sizeof(L.DcnDesc) == 7 * 8 + 17 * 4 + 4 + 8    # 4 bytes of padding before the trailing pointer
+    assert ctypes.sizeof(L.DcnDesc) == 7 * 8 + 17 * 4 + 4 + 8 + 16   # 4 bytes of padding before the trailing pointers
     assert ctypes.sizeof(L.CatDesc) == 9 * 8 + 18 * 4 + 2 * 4 + 5 * 8 + 8 * 4
     assert ctypes.sizeof(L.HeadsDesc) == 8 * 8 + 8 * 4 + 32 * 4
 
