@@ -136,6 +136,12 @@ typedef struct {
 } mfx_dcn_desc;
 int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream);
 
+/* DLA stem in bf16 mode: 7x7 / stride 1 / pad 3 conv of the fp32 NCHW image batch (B,3,H,W) -> NHWC (B,H,W,16) bf16 with
+ * scale/shift (folded BN) + activation (dla_dcn.py:268-272).  Reads the image planes directly (no padded NHWC copy);
+ * w: bf16 [16][K_pad], K = 7 rows x 4 super-taps x (2 pixels x 4 channels) as built by the host packer. */
+int mfx_stem_conv7x7_nchw(const float* images, const void* w, const float* scale, const float* shift, void* y,
+                          int B, int H, int W, int Cout, int K_pad, int act, int dtype, void* stream);
+
 /* 2x2/stride-2 max pooling (dla_dcn.py:237-238), NHWC, C % (16 bytes) == 0 */
 int mfx_maxpool2x2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 

@@ -321,6 +321,18 @@ def pack_image(images, dtype):
     return y
 
 
+def stem_conv(images, p: PackedConv):
+    """bf16 stem: (B,3,H,W) fp32 NCHW -> (B,H,W,16) bf16 NHWC, conv7x7 + scale/shift + act in one kernel."""
+    _need_cuda(images)
+    images = images.float().contiguous()
+    B, C, H, W = images.shape
+    assert C == 3 and p.w.dtype == torch.bfloat16 and p.Cout == 16
+    y = torch.empty((B, H, W, 16), dtype=torch.bfloat16, device=images.device)
+    L.check(L.load().mfx_stem_conv7x7_nchw(_ptr(images), _ptr(p.w), _ptr(p.scale), _ptr(p.shift), _ptr(y), B, H, W, 16, p.K_pad, p.act,
+                                           L.MFX_BF16, _stream()), "mfx_stem_conv7x7_nchw")
+    return y
+
+
 @dataclass
 class PackedHeads:
     w1: torch.Tensor

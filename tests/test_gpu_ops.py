@@ -411,3 +411,21 @@ def test_dcn_split_k_matches_single_pass(dtype, B, C, Cout, H, W):
         L.check(lib_.mfx_set_option(b"dcn_ksplit", 0), "opt")
         for o in (b"dcn_patch", b"dcn_wave"):
             L.check(lib_.mfx_set_option(o, 1), "opt")
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (1, 37, 70), (2, 9, 130)])
+def test_stem_kernel_matches_generic_path(B, H, W):
+    """Dedicated bf16 stem kernel (reads the NCHW planes, weights in registers) against the generic implicit-GEMM path
+    over the padded NHWC4 image, same packed weights, BN + ReLU; and against F.conv2d in fp32."""
+    from monoflex_amd import lib as L, ops
+    g = _g(71)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(16, 3, 7, 7, generator=g) * 0.1
+    scale, shift = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g)
+    p = ops.pack_stem(w.to(DEV), torch.bfloat16, scale.to(DEV), shift.to(DEV), act=L.ACT_RELU)
+    want = ops.conv2d(ops.pack_image(img.to(DEV), torch.bfloat16), p, out_hw=(H, W)).float().cpu()
+    got = ops.stem_conv(img.to(DEV), p).float().cpu()
+    assert got.shape == (B, H, W, 16)
+    assert float((got - want).abs().max()) <= 1e-2 * max(1.0, float(want.abs().max()))
+    ref = torch.relu(torch.nn.functional.conv2d(img, w, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    assert float((got - ref).abs().max()) <= 3e-2 * max(1.0, float(ref.abs().max()))
