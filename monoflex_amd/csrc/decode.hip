@@ -109,11 +109,25 @@ __global__ __launch_bounds__(kTopkThreads) void decode_topk_kernel(const float* 
     __syncthreads();
     i = 0;
     for (int p = tid; p < HW; p += kTopkThreads, ++i) nm[p] = ((keepmask >> i) & 1ull) ? sigmoid_clamp(nm[p]) : 0.f;
-    if (tid == 0) cnt = 0;
+    if (tid == 0) { cnt = 0; sh[0] = 0; }
+    __syncthreads();
+    // ~90 % of the map is exactly 0 after the NMS: histogramming those would serialise ~27 k LDS atomics on one bin per
+    // radix level (that was 80 % of this kernel's time).  Count the survivors; when at least K exist the zeros cannot be
+    // among the top K and are left out of the selection.
+    {
+        int nz = 0;
+        for (int p = tid; p < HW; p += kTopkThreads) nz += nm[p] != 0.f ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nz += __shfl_xor(nz, off);
+        if ((tid & 63) == 0 && nz) atomicAdd(&sh[0], nz);
+    }
+    __syncthreads();
+    const bool skip_zero = sh[0] >= K;
     __syncthreads();
     // K-th largest heat T; take_eq = how many of the elements equal to T are in the top K
     int take_eq = 0;
-    const uint32_t T = select_kth([&](int p) { return __float_as_uint(nm[p]); }, [&](int) { return true; }, HW, K, hist, sh, &take_eq);
+    const uint32_t T = select_kth([&](int p) { return __float_as_uint(nm[p]); }, [&](int p) { return !skip_zero || nm[p] != 0.f; },
+                                  HW, K, hist, sh, &take_eq);
     // among the elements equal to T keep the take_eq lowest flat indices: k-th largest of (HW-1-p)
     int dummy = 0;
     const uint32_t I = select_kth([&](int p) { return (uint32_t)(HW - 1 - p); },

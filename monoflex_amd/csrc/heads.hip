@@ -124,11 +124,24 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
             const int tap = e >> 6, cl = e & 63;
             const int th = (tap * 21846) >> 16, tw = tap - th * 3;
             const char* ap = patch + (th * 18 + xl + tw) * PS + cl * (int)sizeof(T);
+            // pixel fragments two rows ahead of the MFMAs that consume them: left to itself the scheduler (at 250+ VGPRs) sinks
+            // each ds_read pair right in front of its 8 MFMAs and every pair then exposes a full LDS round trip
+            u32x4 pf[2][2];
+            pf[0][0] = *reinterpret_cast<const u32x4*>(ap);
+            pf[0][1] = *reinterpret_cast<const u32x4*>(ap + 18 * PS);
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const u32x4 pf = *reinterpret_cast<const u32x4*>(ap + i * 18 * PS);
+            for (int i = 0; i < FM; i += 2) {
+                const int cur = (i >> 1) & 1;
+                if (i + 2 < FM) {
+                    pf[cur ^ 1][0] = *reinterpret_cast<const u32x4*>(ap + (i + 2) * 18 * PS);
+                    pf[cur ^ 1][1] = *reinterpret_cast<const u32x4*>(ap + (i + 3) * 18 * PS);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < FN; ++j) mma_chunk<T>(wf[j], pf, acc[i][j]);
+                for (int j = 0; j < FN; ++j) mma_chunk<T>(wf[j], pf[cur][0], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma_chunk<T>(wf[j], pf[cur][1], acc[i + 1][j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         u32x4 wb[3][FN];
