@@ -429,3 +429,29 @@ def test_stem_kernel_matches_generic_path(B, H, W):
     assert float((got - want).abs().max()) <= 1e-2 * max(1.0, float(want.abs().max()))
     ref = torch.relu(torch.nn.functional.conv2d(img, w, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
     assert float((got - ref).abs().max()) <= 3e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,Cout,variants", [(64, 64, (6, 12, 13)), (128, 128, (7, 11, 14)), (256, 256, (5, 11)), (512, 512, (11,))])
+def test_halo_conv_k_split_wide_variants(dtype, C, Cout, variants):
+    """Halo-kernel variants for wide outputs, with and without K-split waves (11: BN128 x 2-way, 12/13: BN64 x 2/4-way,
+    14: 2 x FN4 x 2-way), forced one by one against the generic kernel, BN + residual + ReLU epilogue, ragged tile edges."""
+    from monoflex_amd import lib as L, ops
+    g = _g(91)
+    B, H, W = 2, 13, 37
+    x = torch.randn(B, H, W, C, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+    p = ops.pack_conv(w, dtype, (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV), stride=1, pad=1,
+                      act=L.ACT_RELU)
+    res = torch.randn(B, H, W, Cout, generator=g).to(dtype).to(DEV)
+    lib_ = L.load()
+    try:
+        L.check(lib_.mfx_set_option(b"halo", 0), "opt")
+        want = ops.conv2d(x, p, res=res).float().cpu()
+        for v in variants:
+            L.check(lib_.mfx_set_option(b"halo", v + 1), "opt")
+            got = ops.conv2d(x, p, res=res).float().cpu()
+            tol = 2e-5 if dtype == torch.float32 else 2e-2
+            assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), v
+    finally:
+        L.check(lib_.mfx_set_option(b"halo", 1), "opt")
