@@ -411,7 +411,7 @@ _splitk_ws = {}
 def _splitk_workspace(device):
     """One persistent fp32 scratch per device (9 splits x SPLITK_MAX_ELEMS): stable address, so captured graphs stay valid;
     launches on one stream are ordered, so consecutive layers can share it."""
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)      # concurrent streams must not share it
     if key not in _splitk_ws:
         _splitk_ws[key] = torch.empty(9 * SPLITK_MAX_ELEMS, dtype=torch.float32, device=device)
     return _splitk_ws[key]
