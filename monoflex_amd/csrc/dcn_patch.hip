@@ -31,12 +31,14 @@ namespace mfx {
 
 struct DcnPGeom { int B, H, W, C, tiles_x, tiles_y, tiles_n, fsteps, cpt; };   // cpt = C/32: k-steps per tap
 
-constexpr int kPW = 24;                                       // patch width in pixels (16 + 2*4)
-
-template <int FM> struct DcnPSmem {
-    static constexpr int rows = 4 * FM + 8;
-    static constexpr int pix = rows * kPW;
-    static constexpr int bytes = pix * 128;
+// patch = output tile grown by R+1 pixels on every side (1 for the 3x3 taps, R for the offsets), CS channels per slice
+template <int FM, int R, int CS> struct DcnPSmem {
+    static constexpr int PW = 16 + 2 * (R + 1);
+    static constexpr int rows = 4 * FM + 2 * (R + 1);
+    static constexpr int pix = rows * PW;
+    static constexpr int PB = CS * 2;                        // bytes per patch pixel (fp16)
+    static constexpr int NC = CS / 8;                        // 16-byte columns per pixel
+    static constexpr int bytes = pix * PB;
 };
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
@@ -48,10 +50,11 @@ __device__ __forceinline__ uint32_t bf2_to_h2(uint32_t d) {
 }
 __device__ __forceinline__ u32x4 bf8_to_h8(const u32x4& v) { return u32x4{bf2_to_h2(v.x), bf2_to_h2(v.y), bf2_to_h2(v.z), bf2_to_h2(v.w)}; }
 
-template <int FN, int FM>
+template <int FN, int FM, int R = 3, int CS = 64>
 __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
                                                           const u32x4* __restrict__ wfm, DcnPGeom g, EpiArgs ep) {
-    using SM = DcnPSmem<FM>;
+    using SM = DcnPSmem<FM, R, CS>;
+    constexpr int kPW = SM::PW, PB = SM::PB, NC = SM::NC, KS = CS / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
     const int tx = tile % g.tiles_x; tile /= g.tiles_x;
     const int ty = tile % g.tiles_y, b = tile / g.tiles_y;
     const int ty0 = ty * (4 * FM), tx0 = tx * 16, n0 = tn * (FN * 16);
-    const int py0 = ty0 - 4, px0 = tx0 - 4;                    // image coordinates of patch pixel (0,0)
+    const int py0 = ty0 - (R + 1), px0 = tx0 - (R + 1);        // image coordinates of patch pixel (0,0)
     const bf16_t* xb = x + (size_t)b * g.H * g.W * g.C;
 
     // ---- sampling geometry is computed ONCE per pixel: lane l owns pixel (tile row wv*FM + (l>>4) % FM, column l&15) and
@@ -104,10 +107,10 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
         const float lh = h - hf, lw = w - wf_, hh = 1.f - lh, hw_ = 1.f - lw;
         const float m_ = inside ? mk : 0.f;
         // clamp before the int conversion: a wild offset must not overflow (the sample is outside the image then: weight 0)
-        const int h0 = (int)fminf(fmaxf(hf, -8.f), 30000.f), w0 = (int)fminf(fmaxf(wf_, -8.f), 30000.f);
+        const int h0 = (int)fminf(fmaxf(hf, -24.f), 30000.f), w0 = (int)fminf(fmaxf(wf_, -24.f), 30000.f);
         const uint32_t wa = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(hh * hw_ * m_, hh * lw * m_));
         const uint32_t wb_ = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lh * hw_ * m_, lh * lw * m_));
-        const int hw = (h0 + 16) | ((w0 + 16) << 16);
+        const int hw = (h0 + 32) | ((w0 + 32) << 16);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int src = (i * 16 + xl) << 2;
@@ -117,13 +120,13 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
         }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int ry = (chw[i] & 0xffff) - 16 - py0, rx = (chw[i] >> 16) - 16 - px0;
+            const int ry = (chw[i] & 0xffff) - 32 - py0, rx = (chw[i] >> 16) - 32 - px0;
             inp[i] = ry >= 0 && ry + 1 < SM::rows && rx >= 0 && rx + 1 < kPW;
             const int p = ry * kPW + rx;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int pq = p + (q >> 1) * kPW + (q & 1);
-                cb[i][q] = (pq << 7) | ((pq & 7) << 4);
+                cb[i][q] = pq * PB + ((pq & (NC - 1)) << 4);
             }
         }
     };
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(smem + (cb[i][q] ^ (col << 4)));
         } else {                                              // rare: sample left the patch -> exact global gather
-            const int h0 = (chw[i] & 0xffff) - 16, w0 = (chw[i] >> 16) - 16;
+            const int h0 = (chw[i] & 0xffff) - 32, w0 = (chw[i] >> 16) - 32;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int hc = h0 + (q >> 1), wc = w0 + (q & 1);
@@ -159,34 +162,35 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
         return o;
     };
 
-    const int nslice = g.C >> 6;
+    const int nslice = g.C / CS;
     for (int sl = 0; sl < nslice; ++sl) {
-        const int c0 = sl * 64;
+        const int c0 = sl * CS;
         if (sl) __syncthreads();                              // previous slice fully consumed
         // ---- patch load: pix x 8 columns of 16 bytes (bf16 -> fp16), zero outside the image
-        for (int idx = tid; idx < SM::pix * 8; idx += 256) {
-            const int p = idx >> 3, col = idx & 7;
+        for (int idx = tid; idx < SM::pix * NC; idx += 256) {
+            const int p = idx / NC, col = idx % NC;
             const int ry = p / kPW, rx = p - ry * kPW;
             const int gy = py0 + ry, gx = px0 + rx;
             u32x4 v = u32x4{0u, 0u, 0u, 0u};
             if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
                 v = bf8_to_h8(*reinterpret_cast<const u32x4*>(xb + ((size_t)gy * g.W + gx) * g.C + c0 + col * 8));
-            *reinterpret_cast<u32x4*>(smem + (((p << 7) | ((p & 7) << 4)) ^ (col << 4))) = v;
+            *reinterpret_cast<u32x4*>(smem + ((p * PB + ((p & (NC - 1)) << 4)) ^ (col << 4))) = v;
         }
         // weights of the slice's first two steps while the patch lands
         constexpr int RD = FN >= 8 ? 2 : 3;                   // weight ring depth (registers: RD*FN*4)
         u32x4 wb[RD][FN];
-        auto sidx = [&](int t, int ks) { return t * g.cpt + sl * 2 + ks; };       // fragment step of (tap, k-step)
+        auto sidx = [&](int t, int ks) { return t * g.cpt + sl * KS + ks; };      // fragment step of (tap, k-step)
         wfetch(sidx(0, 0), wb[0]);
-        if (RD > 2) wfetch(sidx(0, 1), wb[1]);
+        if (RD > 2) wfetch(sidx(1 / KS, 1 % KS), wb[1]);
         __syncthreads();
 
-        // 18 steps per slice: (tap, ks), fully unrolled (static ring slots and static indices into the offset registers)
+        // 9*KS steps per slice: (tap, ks), fully unrolled (static ring slots and static indices into the offset registers)
+        constexpr int NS = 9 * KS;
 #pragma unroll
-        for (int u = 0; u < 18; ++u) {
-            const int tap = u >> 1, ks = u & 1;
+        for (int u = 0; u < NS; ++u) {
+            const int tap = u / KS, ks = u % KS;
             if (ks == 0) geom(tap);
-            if (u + RD - 1 < 18) wfetch(sidx((u + RD - 1) >> 1, (u + RD - 1) & 1), wb[(u + RD - 1) % RD]);
+            if (u + RD - 1 < NS) wfetch(sidx((u + RD - 1) / KS, (u + RD - 1) % KS), wb[(u + RD - 1) % RD]);
             const int col = ks * 4 + kq;
             u32x4 v[2][4];
             corners(0, col, c0, v[0]);
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
 int g_opt_dcn_patch_fn8 = 1;
 int g_opt_dcn_patch = 1;     // 0 = off, 1 = automatic, 2 = force (FM 4), 3 = force FM 2, 4 = force FM 1
 
-template <int FN, int FM>
+template <int FN, int FM, int R = 3, int CS = 64>
 static int launch_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
     DcnPGeom g;
     g.B = d->B; g.H = d->H; g.W = d->W; g.C = d->C;
@@ -253,13 +257,13 @@ static int launch_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
     ep.scale = d->scale; ep.shift = d->shift; ep.res = nullptr; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = 0;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
     const int tiles = d->B * g.tiles_y * g.tiles_x * g.tiles_n;
-    constexpr int smem = DcnPSmem<FM>::bytes;
+    constexpr int smem = DcnPSmem<FM, R, CS>::bytes;
     static bool attr_done = false;
     if (!attr_done) {
-        MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_patch_kernel<FN, FM>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_patch_kernel<FN, FM, R, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    hipLaunchKernelGGL((dcn_patch_kernel<FN, FM>), dim3(tiles), dim3(256), smem, st, reinterpret_cast<const bf16_t*>(d->x), d->offmask,
+    hipLaunchKernelGGL((dcn_patch_kernel<FN, FM, R, CS>), dim3(tiles), dim3(256), smem, st, reinterpret_cast<const bf16_t*>(d->x), d->offmask,
                        reinterpret_cast<const u32x4*>(d->w_frag_f16), g, ep);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -271,14 +275,24 @@ int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dil != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
     if (d->C % 64 != 0 || d->K_pad != 9 * d->C || d->Cout_pad % 64 != 0) return 0;
     const long px = (long)d->B * d->H * d->W;
+    if (g_opt_dcn_patch >= 5 && g_opt_dcn_patch <= 7) {       // wide-margin variants: +-7 pixel offsets in range, 32-channel slices
+        const int rc = g_opt_dcn_patch == 5 ? launch_dcn_patch<4, 4, 7, 32>(d, st)
+                     : g_opt_dcn_patch == 6 ? launch_dcn_patch<4, 2, 7, 32>(d, st) : launch_dcn_patch<4, 1, 7, 32>(d, st);
+        return rc == MFX_OK ? 1 : rc;
+    }
     int fm = g_opt_dcn_patch == 2 ? 4 : g_opt_dcn_patch == 3 ? 2 : g_opt_dcn_patch == 4 ? 1 : 0;
     if (!fm) {
-        // automatic choice, measured in the full network at B=8 (tools/layer_bench.py --opts dcn_patch=..): the LDS path
-        // wins when most samples stay inside the patch (64->64 @ 96x320, offset std 1.5: 75 us vs 118 us; std 0: 73 us).
-        // The synthetic benchmark weights produce offsets of std 2.2 .. 7 px (15 .. 70 % of the samples leave the +-3 px
-        // patch and take the global path, one L2 round trip per fragment), which leaves ~10 % on the single-slice
-        // 64-channel layers and a loss on the multi-slice ones -- so only the former are routed here by default.
-        if (d->C == 64 && d->Cout_pad == 64 && px >= 65536) fm = 1; else return 0;
+        // automatic choice, measured in the full network at B=8 (tools/layer_bench.py --opts dcn_patch=..).  The synthetic
+        // benchmark weights produce offsets of std 2.2 .. 7 px: with the +-3 px patch 15 .. 70 % of the samples take the global
+        // path and the gain over the first generation is gone (64->64 @ 96x320: 73 us at std 0, 147 us at std 2.5).  The
+        // +-7 px patch over 32-channel slices keeps ~99 % of the samples of the 64-channel layers in LDS (std 2.5: 84 us;
+        // in the network 86-88 us vs 102-117) and is what those layers use; the multi-slice layers (C >= 128, smaller maps,
+        // larger offsets) stay on the first-generation kernel, which measured faster there.
+        if (d->C == 64 && d->Cout_pad == 64 && px >= 65536) {
+            const int rc0 = launch_dcn_patch<4, 4, 7, 32>(d, st);
+            return rc0 == MFX_OK ? 1 : rc0;
+        }
+        return 0;
     }
     int rc;
     const bool wide = d->Cout_pad % 128 == 0 && g_opt_dcn_patch_fn8;      // one workgroup covers 128 output channels

@@ -319,7 +319,7 @@ def test_dcn_patch_kernel_matches_first_generation(B, C, Cout, H, W, off_std):
     try:
         L.check(lib_.mfx_set_option(b"dcn_patch", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_wave", 0), "opt")
         want = ops.dcn(x, om, p).float().cpu()
-        for v in (2, 3, 4):
+        for v in (2, 3, 4, 5, 6, 7):                         # 5..7: +-7 pixel margin, 32-channel slices
             L.check(lib_.mfx_set_option(b"dcn_patch", v), "opt")
             got = ops.dcn(x, om, p).float().cpu()
             err = float((got - want).abs().max())
