@@ -207,10 +207,26 @@ int mfx_decode_boxes(const float* hmap, int ld, int reg_off, const float* scores
 int mfx_conv_wgrad_nhwc(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
                         int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
                         int dtype, void* stream);
+/* same, written straight in the parameter's layout: dw fp32 (Cout_real, Cin_real, kh, kw); channels of dy beyond Cout_real
+ * and of x beyond Cin_real (padding) are dropped */
+int mfx_conv_wgrad_oihw(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
+                        int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
+                        int Cout_real, int Cin_real, int dtype, void* stream);
+/* fp32 OIHW parameter -> packed operand [rows_pad][K_pad] of `dtype` (+ optional fragment-major copy, see mfx_conv_desc.w_frag).
+ * mode 0: forward weights, row = o, k = tap*ck + c (ck >= Cin).  mode 1: data-gradient weights (kernel rotated by 180 degrees,
+ * in/out swapped): row = c, k = tap'*ck + o (ck >= Cout = channels of dy).  Padding rows/columns are zero. */
+int mfx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int kh, int kw, int mode, void* packed, void* frag,
+                         int rows_pad, int K_pad, int ck, int dtype, void* stream);
 /* out[c] = sum_m x[m*ld + c]  (bias gradients) */
 int mfx_colsum(const void* x, float* out, long M, int C, int ld, int dtype, void* stream);
 /* train-mode BatchNorm over [M][C]: per-channel sum and sum of squares (fp32, overwritten) */
 int mfx_bn_stats(const void* x, float* sum, float* sumsq, long M, int C, int dtype, void* stream);
+/* per-channel epilogue of mfx_bn_stats: mean = sum/count, biased var, rstd, scale = gamma*rstd, shift = beta - mean*scale, and
+ * (optional) running_mean/var <- (1-momentum)*old + momentum*(mean / unbiased var), like nn.BatchNorm2d in training mode.
+ * gamma/beta fp32.  count = rows that entered the sums (all ranks when the sums were all-reduced). */
+int mfx_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, long count, float* mean, float* rstd, float* scale,
+                    float* shift, int C, void* stream);
 /* y = act(x*scale[c] + shift[c] (+ res)) */
 int mfx_bn_act_fwd(const void* x, const float* scale, const float* shift, const void* res, void* y,
                    long M, int C, int act, int dtype, void* stream);

@@ -58,6 +58,23 @@ def _pad_channels(n, dtype):
     return p
 
 
+def _pack_weight(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, shift=None):
+    """One-launch packing of an fp32 OIHW parameter into the conv operand (mode 0 forward, 1 data gradient)."""
+    Cout, Cin, kh, kw = weight.shape
+    E = 4 if dtype == torch.float32 else 8
+    if ck & (ck - 1) or ck < E:
+        raise ValueError("conv operand: channels per tap must be a power of two >= %d (got %d)" % (E, ck))
+    K_pad = (kh * kw * ck + 8 * E - 1) // (8 * E) * (8 * E)
+    cp = ops.cout_pad(rows)
+    w32 = weight.detach()
+    w32 = _c(w32 if w32.dtype == torch.float32 else w32.float())
+    packed = torch.empty((cp, K_pad), dtype=dtype, device=weight.device)
+    frag = torch.empty_like(packed) if (kh == 3 and kw == 3 and stride == 1 and pad_h == 1 and pad_w == 1) else None
+    L.check(L.load().mfx_pack_conv_weight(_ptr(w32), Cout, Cin, kh, kw, mode, _ptr(packed), _ptr(frag), cp, K_pad, ck, _dt(dtype), _stream()),
+            "mfx_pack_conv_weight")
+    return ops.PackedConv(packed, None, shift, kh, kw, stride, pad_h, pad_w, 1, ck, rows, cp, K_pad, L.ACT_NONE, frag)
+
+
 class Conv2dFn(Function):
     """y = conv2d(x, weight) (+ bias), k in {1,3}, stride in {1,2}, pad = k//2.  Output channels are padded up to a
     multiple of the 16-byte chunk (extra channels are exactly zero); callers slice."""
@@ -67,7 +84,12 @@ class Conv2dFn(Function):
         x = _c(x)
         Cout, Cin, kh, kw = weight.shape
         cpad = _pad_channels(Cout, out_dtype or x.dtype)
-        p = ops.pack_conv(weight, x.dtype, None, bias, stride=stride, pad=pad, act=L.ACT_NONE, cout=cpad)
+        shift = None
+        if bias is not None:
+            cp = ops.cout_pad(cpad)
+            shift = torch.zeros(cp, dtype=torch.float32, device=x.device)
+            shift[:Cout] = bias.detach()
+        p = _pack_weight(weight, x.dtype, 0, cpad, Cin, stride, pad, pad, shift)
         y = ops.conv2d(x, p, out_dtype=out_dtype)             # bf16 mode: fp32 out for DCN offsets and the head maps
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, bias is not None, Cout)
@@ -89,13 +111,9 @@ class Conv2dFn(Function):
         kh, kw = weight.shape[2], weight.shape[3]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            # W^T flipped: (Cin, Cp, kh, kw), rows beyond Cout are zero (padded output channels carry no gradient)
-            wt = weight.detach().flip(2, 3).permute(1, 0, 2, 3)
-            if Cp != Cout:
-                wt = torch.cat((wt, wt.new_zeros(Cin, Cp - Cout, kh, kw)), dim=1)
+            # the kernel rotated by 180 degrees with in/out swapped, as the operand of a stride-1 'full' correlation
             cin_pad = _pad_channels(Cin, x.dtype)
-            pt = ops.pack_conv(wt.contiguous(), x.dtype, None, None, stride=1, pad=pad, act=L.ACT_NONE, cout=cin_pad)
-            pt.pad_h, pt.pad_w = kh - 1 - pad, kw - 1 - pad                       # 'full' correlation of the flipped kernel
+            pt = _pack_weight(weight, x.dtype, 1, cin_pad, Cp, 1, kh - 1 - pad, kw - 1 - pad)
             g = dy
             if stride == 2:
                 g = torch.empty((B, H, W, Cp), dtype=dy.dtype, device=dy.device)
@@ -105,8 +123,10 @@ class Conv2dFn(Function):
             if cin_pad != Cin:
                 dx = dx[..., :Cin]
         if ctx.needs_input_grad[1]:
-            dwf = _wgrad(x, dy, kh, kw, stride, pad, Ho, Wo)                       # (Cp, taps, Cin)
-            dw = dwf[:Cout].view(Cout, kh, kw, Cin).permute(0, 3, 1, 2).contiguous().to(weight.dtype)
+            dwf = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            L.check(L.load().mfx_conv_wgrad_oihw(_ptr(x), _ptr(dy), _ptr(dwf), B, H, W, Cin, Cin, kh, kw, stride, pad, pad, Ho, Wo, Cp, Cp,
+                                                 Cout, Cin, _dt(x.dtype), _stream()), "mfx_conv_wgrad_oihw")
+            dw = dwf if weight.dtype == torch.float32 else dwf.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy)[:Cout]
         return dx, dw, db, None, None, None
@@ -203,21 +223,18 @@ class BNActFn(Function):
             st[2 * C] = float(M)
             dist.all_reduce(st, group=group)
             Mt = M * dist.get_world_size(group)                # equal per-rank batches (weak scaling), no host sync
-        mean = st[:C] / Mt
-        var = (st[C:2 * C] / Mt - mean * mean).clamp_(min=0.0)
-        rstd = torch.rsqrt(var + eps)
-        g32, b32 = gamma.detach().float(), beta.detach().float()
-        scale = (g32 * rstd).contiguous()
-        shift = (b32 - mean * scale).contiguous()
-        if running_mean is not None:
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var * (Mt / max(Mt - 1, 1)), alpha=momentum)
+        g32 = gamma.detach() if gamma.dtype == torch.float32 else gamma.detach().float()
+        b32 = beta.detach() if beta.dtype == torch.float32 else beta.detach().float()
+        out = torch.empty(4 * C, dtype=torch.float32, device=x.device)          # mean | rstd | scale | shift
+        mean, rstd, scale, shift = out[:C], out[C:2 * C], out[2 * C:3 * C], out[3 * C:]
+        L.check(lib_.mfx_bn_finalize(_ptr(st), st.data_ptr() + 4 * C, _ptr(_c(g32)), _ptr(_c(b32)), _ptr(running_mean), _ptr(running_var),
+                                     ctypes.c_float(momentum), ctypes.c_float(eps), Mt, _ptr(mean), out.data_ptr() + 4 * C,
+                                     out.data_ptr() + 8 * C, out.data_ptr() + 12 * C, C, _stream()), "mfx_bn_finalize")
         y = torch.empty_like(x)
         res_c = _c(res) if res is not None else None
         L.check(lib_.mfx_bn_act_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res_c), _ptr(y), M, C, act, _dt(x.dtype), _stream()),
                 "mfx_bn_act_fwd")
-        ctx.save_for_backward(x, y, mean.contiguous(), rstd.contiguous(), g32.contiguous())
+        ctx.save_for_backward(x, y, mean, rstd, _c(g32))
         ctx.cfg = (act, res is not None, group, Mt)
         return y
 

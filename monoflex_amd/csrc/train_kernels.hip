@@ -25,7 +25,14 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
 // conv weight gradient: dW[o][tap][c] = sum_m dy[m][o] * x[pixel(m,tap)][c]       (fp32 [Cout][taps][Ck])
 // Block = 64 k x 64 o tile over a slab of pixels; 256 threads x 4x4 register blocks; fp32 atomics on the small result.
 // ------------------------------------------------------------------------------------------------
-struct WgradGeom { int B, H, W, Ho, Wo, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, M, K, Cout, ldy, m_per_block; };
+struct WgradGeom { int B, H, W, Ho, Wo, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, M, K, Cout, ldy, m_per_block;
+                   int oihw, Cin_out, Cout_out; };   // oihw: write dW as (Cout_out, Cin_out, kh, kw), dropping padded channels
+
+__device__ __forceinline__ void wgrad_add(float* dw, const WgradGeom& g, int o, int k, float v) {
+    if (!g.oihw) { unsafeAtomicAdd(dw + (size_t)o * g.K + k, v); return; }
+    const int tap = k / g.Ck, c = k - tap * g.Ck;
+    if (o < g.Cout_out && c < g.Cin_out) unsafeAtomicAdd(dw + ((size_t)o * g.Cin_out + c) * (g.kh * g.kw) + tap, v);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, WgradGeom g, float* __restrict__ dw) {
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (k0 + tk + i < g.K && o0 + to + j < g.Cout) unsafeAtomicAdd(dw + (size_t)(o0 + to + j) * g.K + k0 + tk + i, acc[i][j]);
+            if (k0 + tk + i < g.K && o0 + to + j < g.Cout) wgrad_add(dw, g, o0 + to + j, k0 + tk + i, acc[i][j]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -181,8 +188,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const bf16_t* __re
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = o0 + wo * 32 + i * 16 + (lane >> 4) * 4 + r, k = k0 + wk * 32 + j * 16 + (lane & 15);
-                if (o < g.Cout && k < g.K) unsafeAtomicAdd(dw + (size_t)o * g.K + k, acc[i][j][r]);
+                if (o < g.Cout && k < g.K) wgrad_add(dw, g, o, k, acc[i][j][r]);
             }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing for the training step: fp32 OIHW parameter -> K-contiguous [rows_pad][K_pad] (+ fragment-major copy) of the
+// compute dtype in one launch.  mode 0: forward operand, row = o, k = tap*Cin + c.  mode 1: data-gradient operand (the
+// flipped, in/out-swapped kernel): row = c, k = tap'*ck + o with tap' the 180-degree rotated tap, ck = channels of dy.
+// (As torch ops this was ~8 small launches per conv in forward and ~12 in backward, 60 convs per step.)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int kh, int kw, int mode, T* __restrict__ packed,
+                                        T* __restrict__ frag, int rows_pad, int K_pad, int ck) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    const long total = (long)rows_pad * K_pad;
+    const int taps = kh * kw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / K_pad), k = (int)(i - (long)n * K_pad);
+        const int tap = k / ck, cc = k - tap * ck;
+        float v = 0.f;
+        if (tap < taps) {
+            if (mode == 0) { if (n < Cout && cc < Cin) v = w[((size_t)n * Cin + cc) * taps + tap]; }
+            else if (n < Cin && cc < Cout) v = w[((size_t)cc * Cin + n) * taps + (taps - 1 - tap)];
+        }
+        ElemTraits<T>::store(packed + i, v);
+        if (frag) {
+            const size_t f = (((size_t)(n >> 4) * (K_pad / (4 * E)) + k / (4 * E)) * 4 + (k % (4 * E)) / E) * (16 * E) + (n & 15) * E + k % E;
+            ElemTraits<T>::store(frag + f, v);
+        }
+    }
 }
 
 // column sums: out[c] += sum_m x[m][c]      (bias gradient)
@@ -254,6 +289,25 @@ __global__ __launch_bounds__(256) void colsum_chunk_kernel(const T* __restrict__
     for (int e = 0; e < E; ++e) atomicAdd(&sred[cc * E + e], s[e]);
     __syncthreads();
     for (int i = tid; i < C; i += 256) unsafeAtomicAdd(out + i, sred[i]);
+}
+
+// per-channel epilogue of the statistics pass: mean / rstd / folded scale+shift and the running-statistics update in ONE
+// launch (as separate tensor ops this was ~10 tiny launches per BN layer, 66 layers per step)
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+                                   float inv_count, float unbias, float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float m = sum[c] * inv_count;
+    const float v = fmaxf(sumsq[c] * inv_count - m * m, 0.f);
+    const float r = rsqrtf(v + eps);
+    const float sc = gamma[c] * r;
+    mean[c] = m; rstd[c] = r; scale[c] = sc; shift[c] = beta[c] - m * sc;
+    if (running_mean) {
+        running_mean[c] = running_mean[c] * (1.f - momentum) + m * momentum;
+        running_var[c] = running_var[c] * (1.f - momentum) + v * unbias * momentum;
+    }
 }
 
 // y = act(x*scale[c] + shift[c] (+ res))
@@ -462,16 +516,17 @@ int g_opt_wgrad_mfma = 1;     // option "wgrad_mfma": 0 = VALU kernel for bf16 t
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == MFX_F32) { CALL_F32; } else if ((dtype) == MFX_BF16) { CALL_BF16; } else return mfx_fail(MFX_ERR_ARG, "bad dtype"); } while (0)
 
-extern "C" int mfx_conv_wgrad_nhwc(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
-                                   int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
-                                   int dtype, void* stream) {
+static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
+                           int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
+                           int dtype, int oihw, int Cin_out, int Cout_out, void* stream) {
     if (!x || !dy || !dw) return mfx_fail(MFX_ERR_ARG, "conv_wgrad: null pointer");
     if (Ck % 4 != 0 || Cout % 4 != 0) return mfx_fail(MFX_ERR_ARG, "conv_wgrad: Ck and Cout must be multiples of 4");
     WgradGeom g;
     g.B = B; g.H = H; g.W = W; g.Ho = Ho; g.Wo = Wo; g.x_pixstride = x_pixstride; g.Ck = Ck; g.kh = kh; g.kw = kw; g.stride = stride;
     g.pad_h = pad_h; g.pad_w = pad_w; g.M = B * Ho * Wo; g.K = kh * kw * Ck; g.Cout = Cout; g.ldy = ldy; g.m_per_block = 2048;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)Cout * g.K * sizeof(float), st));
+    g.oihw = oihw; g.Cin_out = Cin_out; g.Cout_out = Cout_out;
+    MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (oihw ? (size_t)Cout_out * Cin_out * kh * kw : (size_t)Cout * g.K) * sizeof(float), st));
     if (g.M == 0) return MFX_OK;
     if (dtype == MFX_BF16 && Ck % 8 == 0 && x_pixstride % 8 == 0 && ldy % 8 == 0 && g_opt_wgrad_mfma) {
         g.m_per_block = g.M >= (1 << 20) ? 8192 : g.M >= (1 << 16) ? 4096 : 1024;
@@ -483,6 +538,34 @@ extern "C" int mfx_conv_wgrad_nhwc(const void* x, const void* dy, float* dw, int
     dim3 grid(cdivt(g.K, 64), cdivt(Cout, 64), cdivt(g.M, g.m_per_block));
     DISPATCH_T(dtype, hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, g, dw),
                       hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_conv_wgrad_nhwc(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
+                                   int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
+                                   int dtype, void* stream) {
+    return conv_wgrad_impl(x, dy, dw, B, H, W, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, Ho, Wo, Cout, ldy, dtype, 0, 0, 0, stream);
+}
+
+extern "C" int mfx_conv_wgrad_oihw(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
+                                   int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
+                                   int Cout_real, int Cin_real, int dtype, void* stream) {
+    if (Cout_real < 1 || Cout_real > Cout || Cin_real < 1 || Cin_real > Ck) return mfx_fail(MFX_ERR_ARG, "conv_wgrad_oihw: bad real channel counts");
+    return conv_wgrad_impl(x, dy, dw, B, H, W, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, Ho, Wo, Cout, ldy, dtype, 1, Cin_real, Cout_real, stream);
+}
+
+extern "C" int mfx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int kh, int kw, int mode, void* packed, void* frag,
+                                    int rows_pad, int K_pad, int ck, int dtype, void* stream) {
+    if (!w_oihw || !packed) return mfx_fail(MFX_ERR_ARG, "pack_conv_weight: null pointer");
+    const int E = dtype == MFX_BF16 ? 8 : 4;
+    if (mode < 0 || mode > 1 || ck < 1 || K_pad < kh * kw * ck || K_pad % (4 * E) != 0 || rows_pad % 16 != 0 ||
+        rows_pad < (mode == 0 ? Cout : Cin) || ck < (mode == 0 ? Cin : Cout))
+        return mfx_fail(MFX_ERR_ARG, "pack_conv_weight: bad geometry");
+    const long total = (long)rows_pad * K_pad;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_kernel<float>, TR_GRID(total), dim3(256), 0, st, w_oihw, Cout, Cin, kh, kw, mode, (float*)packed, (float*)frag, rows_pad, K_pad, ck),
+                      hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, w_oihw, Cout, Cin, kh, kw, mode, (bf16_t*)packed, (bf16_t*)frag, rows_pad, K_pad, ck));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -528,6 +611,19 @@ extern "C" int mfx_bn_stats(const void* x, float* sum, float* sumsq, long M, int
     const size_t smem = (size_t)2 * C * sizeof(float);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, sum, sumsq),
                       hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, sum, sumsq));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float momentum, float eps, long count, float* mean, float* rstd, float* scale,
+                               float* shift, int C, void* stream) {
+    if (!sum || !sumsq || !gamma || !beta || !mean || !rstd || !scale || !shift) return mfx_fail(MFX_ERR_ARG, "bn_finalize: null pointer");
+    if ((running_mean == nullptr) != (running_var == nullptr)) return mfx_fail(MFX_ERR_ARG, "bn_finalize: running_mean/var must come together");
+    if (C <= 0 || count <= 0) return MFX_OK;
+    const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdivt(C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sum, sumsq, gamma, beta,
+                       running_mean, running_var, momentum, eps, (float)(1.0 / (double)count), unbias, mean, rstd, scale, shift, C);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

@@ -73,8 +73,11 @@ SYMBOLS = {
     "mfx_edge_scatter_add": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
     "mfx_decode_topk": (_I, [_P, ctypes.c_long, ctypes.c_long, ctypes.c_long, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mfx_conv_wgrad_nhwc": (_I, [_P, _P, _P] + [_I] * 15 + [_P]),
+    "mfx_conv_wgrad_oihw": (_I, [_P, _P, _P] + [_I] * 17 + [_P]),
+    "mfx_pack_conv_weight": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
     "mfx_colsum": (_I, [_P, _P, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_stats": (_I, [_P, _P, _P, ctypes.c_long, _I, _I, _P]),
+    "mfx_bn_finalize": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, ctypes.c_long, _P, _P, _P, _P, _I, _P]),
     "mfx_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_act_bwd": (_I, [_P] * 10 + [ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_bwd_reduce": (_I, [_P] * 7 + [ctypes.c_long, _I, _I, _I, _P]),
