@@ -5,6 +5,7 @@
 #include "../../include/monoflex_hip.h"
 #include "common.h"
 #include "err.h"
+#include <algorithm>
 
 namespace mfx {
 
@@ -98,53 +99,60 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
 // ------------------------------------------------------------------------------------------------
 constexpr int kWgRow = 80;                                   // LDS row: 32 pixels x 2 B + 16 B pad
 
+// BT = 64: tile 64 o x 64 k, threads 0..127 stage dy and 128..255 the im2col operand, 4 MFMAs per wave and step.
+// BT = 128: tile 128 x 128, every thread stages one chunk pair of each operand, 16 MFMAs per wave and step: with 64-wide tiles
+// the head-trunk weight gradients alone re-read ~20 GB of operand tiles from L2 per step; 128-wide tiles halve that.
+// Global loads run TWO steps ahead of their LDS store (two register sets): one step of MFMAs is far shorter than an L2 round
+// trip and the large tiles leave only a few waves per SIMD to hide it.
+template <int BT>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, WgradGeom g,
                                                               float* __restrict__ dw) {
-    __shared__ __attribute__((aligned(16))) char lds[2][2][64 * kWgRow];      // [buffer][0 = dy^T, 1 = A^T][64 rows]
+    constexpr int NCH = BT / 8, FR = BT / 32;                 // 16-byte chunks per tile row; 16-row fragments per wave and operand
+    __shared__ __attribute__((aligned(16))) char lds[2][2][BT * kWgRow];      // [buffer][0 = dy^T, 1 = A^T][BT rows]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wo = wave >> 1, wk = wave & 1;
-    const int k0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+    const int k0 = blockIdx.x * BT, o0 = blockIdx.y * BT;
     const int m_begin = blockIdx.z * g.m_per_block, m_end = min(m_begin + g.m_per_block, g.M);
 
-    // loader role: threads 0..127 transpose dy, 128..255 the im2col operand; thread = (pixel pair pp, 8-channel chunk c)
-    const bool is_a = tid >= 128;
-    const int lt = tid & 127, pp = lt >> 3, c8 = (lt & 7) * 8;
+    // loader roles; item = (pixel pair pp, 8-channel chunk c8)
+    const bool do_dy = BT == 128 || tid < 128, do_a = BT == 128 || tid >= 128;
+    const int lt = BT == 128 ? tid : (tid & 127), pp = lt / NCH, c8 = (lt % NCH) * 8;
     const int kk = k0 + c8;                                   // first of this thread's 8 consecutive k (one tap: Ck % 8 == 0)
-    const bool col_ok = is_a ? kk < g.K : o0 + c8 < g.Cout;
-    const int tap = (is_a && col_ok) ? kk / g.Ck : 0, ch = kk - tap * g.Ck;
+    const bool a_ok = do_a && kk < g.K, d_ok = do_dy && o0 + c8 < g.Cout;
+    const int tap = a_ok ? kk / g.Ck : 0, ch = kk - tap * g.Ck;
     const int th = tap / g.kw, tw = tap - th * g.kw;
     const int hw = g.Ho * g.Wo;
-    // (b, oh, ow) of this thread's first pixel, advanced incrementally by 32 pixels per step
+    // (b, oh, ow) of the pixel pair this thread loads next, advanced by 32 pixels per load
     int m = m_begin + 2 * pp;
     int pb = m / hw, rem = m - pb * hw, poh = rem / g.Wo, pow_ = rem - poh * g.Wo;
     auto advance = [&](int& b_, int& oh_, int& ow_, int n) {
         ow_ += n;
         while (ow_ >= g.Wo) { ow_ -= g.Wo; if (++oh_ == g.Ho) { oh_ = 0; ++b_; } }
     };
-    u32x4 r0, r1;
-    auto gload = [&]() {                                      // this thread's chunk of pixels m and m+1 (zero when masked)
-        r0 = u32x4{0u, 0u, 0u, 0u}; r1 = r0;
-        if (!col_ok) return;
-        if (!is_a) {
-            if (m < m_end) r0 = *reinterpret_cast<const u32x4*>(dy + (size_t)m * g.ldy + o0 + c8);
-            if (m + 1 < m_end) r1 = *reinterpret_cast<const u32x4*>(dy + (size_t)(m + 1) * g.ldy + o0 + c8);
-        } else {
+    struct Regs { u32x4 d0, d1, a0, a1; };
+    auto gload = [&](Regs& r) {                               // chunks of pixels m and m+1 (zero when masked), then m += 32
+        r.d0 = u32x4{0u, 0u, 0u, 0u}; r.d1 = r.d0; r.a0 = r.d0; r.a1 = r.d0;
+        if (d_ok) {
+            if (m < m_end) r.d0 = *reinterpret_cast<const u32x4*>(dy + (size_t)m * g.ldy + o0 + c8);
+            if (m + 1 < m_end) r.d1 = *reinterpret_cast<const u32x4*>(dy + (size_t)(m + 1) * g.ldy + o0 + c8);
+        }
+        if (a_ok) {
             int b2 = pb, oh2 = poh, ow2 = pow_;
             if (m < m_end) {
                 const int ih = poh * g.stride - g.pad_h + th, iw = pow_ * g.stride - g.pad_w + tw;
                 if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
-                    r0 = *reinterpret_cast<const u32x4*>(x + ((size_t)(pb * g.H + ih) * g.W + iw) * g.x_pixstride + ch);
+                    r.a0 = *reinterpret_cast<const u32x4*>(x + ((size_t)(pb * g.H + ih) * g.W + iw) * g.x_pixstride + ch);
             }
             if (m + 1 < m_end) {
                 advance(b2, oh2, ow2, 1);
                 const int ih = oh2 * g.stride - g.pad_h + th, iw = ow2 * g.stride - g.pad_w + tw;
                 if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
-                    r1 = *reinterpret_cast<const u32x4*>(x + ((size_t)(b2 * g.H + ih) * g.W + iw) * g.x_pixstride + ch);
+                    r.a1 = *reinterpret_cast<const u32x4*>(x + ((size_t)(b2 * g.H + ih) * g.W + iw) * g.x_pixstride + ch);
             }
         }
+        m += 32; advance(pb, poh, pow_, 32);
     };
-    auto lstore = [&](int buf) {                              // transposed: row = channel, 4-byte (pixel, pixel+1) pairs
-        char* base = lds[buf][is_a ? 1 : 0] + c8 * kWgRow + pp * 4;
+    auto tstore = [&](char* base, const u32x4& r0, const u32x4& r1) {       // transposed: row = channel, (pixel, pixel+1) pairs
         const uint32_t a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -152,42 +160,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const bf16_t* __re
             *reinterpret_cast<uint32_t*>(base + (2 * q + 1) * kWgRow) = (a[q] >> 16) | (b[q] & 0xffff0000u);
         }
     };
+    auto lstore = [&](int buf, const Regs& r) {
+        if (do_dy) tstore(lds[buf][0] + c8 * kWgRow + pp * 4, r.d0, r.d1);
+        if (do_a) tstore(lds[buf][1] + c8 * kWgRow + pp * 4, r.a0, r.a1);
+    };
 
-    f32x4 acc[2][2];
+    f32x4 acc[FR][FR];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FR; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int frag = (lane & 15) * kWgRow + (lane >> 4) * 16;
+    auto compute = [&](int buf) {
+        u32x4 af[FR], bf[FR];
+#pragma unroll
+        for (int i = 0; i < FR; ++i) af[i] = *reinterpret_cast<const u32x4*>(lds[buf][0] + (wo * (BT / 2) + i * 16) * kWgRow + frag);
+#pragma unroll
+        for (int j = 0; j < FR; ++j) bf[j] = *reinterpret_cast<const u32x4*>(lds[buf][1] + (wk * (BT / 2) + j * 16) * kWgRow + frag);
+#pragma unroll
+        for (int i = 0; i < FR; ++i)
+#pragma unroll
+            for (int j = 0; j < FR; ++j) mma_chunk<bf16_t>(af[i], bf[j], acc[i][j]);
+    };
 
-    gload();
-    lstore(0);
+    // steps s = 0 .. ns-1; registers R[s & 1] hold the data of step s once loaded (two steps ahead of its LDS store)
+    const int ns = (m_end - m_begin + 31) / 32;
+    Regs R0, R1;
+    gload(R0);                                               // step 0
+    lstore(0, R0);
+    if (ns > 1) gload(R1);                                   // step 1
+    if (ns > 2) gload(R0);                                   // step 2
     __syncthreads();
-    int buf = 0;
-    for (int mb = m_begin; mb < m_end; mb += 32) {
-        const bool more = mb + 32 < m_end;
-        if (more) { m += 32; advance(pb, poh, pow_, 32); gload(); }
-        u32x4 af[2], bf[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(lds[buf][0] + (wo * 32 + i * 16) * kWgRow + frag);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const u32x4*>(lds[buf][1] + (wk * 32 + j * 16) * kWgRow + frag);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_chunk<bf16_t>(af[i], bf[j], acc[i][j]);
-        if (more) lstore(buf ^ 1);
+    int s = 0;
+    for (; s + 2 <= ns; s += 2) {                            // unrolled by two: static register sets
+        compute(0);                                          // step s   (buffer 0)
+        if (s + 1 < ns) lstore(1, R1);                       // step s+1 -> buffer 1
+        if (s + 3 < ns) gload(R1);                           // step s+3
         __syncthreads();
-        buf ^= 1;
+        if (s + 1 < ns) compute(1);                          // step s+1 (buffer 1)
+        if (s + 2 < ns) lstore(0, R0);                       // step s+2 -> buffer 0
+        if (s + 4 < ns) gload(R0);                           // step s+4
+        __syncthreads();
     }
+    if (s < ns) compute(0);                                  // odd tail
     // D: col (lane&15) = k, row (lane>>4)*4 + r = o
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FR; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FR; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = o0 + wo * 32 + i * 16 + (lane >> 4) * 4 + r, k = k0 + wk * 32 + j * 16 + (lane & 15);
+                const int o = o0 + wo * (BT / 2) + i * 16 + (lane >> 4) * 4 + r, k = k0 + wk * (BT / 2) + j * 16 + (lane & 15);
                 if (o < g.Cout && k < g.K) wgrad_add(dw, g, o, k, acc[i][j][r]);
             }
 }
@@ -512,7 +535,10 @@ __global__ void zero_insert2_kernel(const T* __restrict__ dy, T* __restrict__ up
 }  // namespace mfx
 using namespace mfx;
 
-int g_opt_wgrad_mfma = 1;     // option "wgrad_mfma": 0 = VALU kernel for bf16 too
+int g_opt_wgrad_blocks = 600;   // option "wgrad_blocks": target workgroup count of the MFMA weight-gradient kernel (measured, B=8 step:
+                                // 64 -> 146 ms, 150 -> 90, 300 -> 78, 600 -> 73, 2048 -> 75, 8192 -> 81: the tile atomics of every slab cost
+                                // more than the extra workgroups hide)
+int g_opt_wgrad_mfma = 1;     // option "wgrad_mfma": 0 = VALU kernel for bf16 too, 1 = 64x64 MFMA tiles, 3 = 128x128 where they fit
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == MFX_F32) { CALL_F32; } else if ((dtype) == MFX_BF16) { CALL_BF16; } else return mfx_fail(MFX_ERR_ARG, "bad dtype"); } while (0)
 
@@ -529,9 +555,15 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
     MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (oihw ? (size_t)Cout_out * Cin_out * kh * kw : (size_t)Cout * g.K) * sizeof(float), st));
     if (g.M == 0) return MFX_OK;
     if (dtype == MFX_BF16 && Ck % 8 == 0 && x_pixstride % 8 == 0 && ldy % 8 == 0 && g_opt_wgrad_mfma) {
-        g.m_per_block = g.M >= (1 << 20) ? 8192 : g.M >= (1 << 16) ? 4096 : 1024;
-        dim3 grid(cdivt(g.K, 64), cdivt(Cout, 64), cdivt(g.M, g.m_per_block));
-        hipLaunchKernelGGL(conv_wgrad_mfma_kernel, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
+        const int bt = (Cout >= 128 && g.K >= 128 && g_opt_wgrad_mfma == 3) ? 128 : 64;     // 128-wide tiles measured slower (83 vs 78 ms)
+        const int tiles = cdivt(g.K, bt) * cdivt(Cout, bt);
+        // pixel slabs: enough workgroups to fill the chip (~8 per CU), but at least 1024 pixels each (the fp32 atomics of the
+        // tile are paid once per slab)
+        int slabs = std::max(1, g_opt_wgrad_blocks / tiles);
+        g.m_per_block = std::max(1024, (int)(((long)g.M / slabs + 31) / 32 * 32));
+        dim3 grid(cdivt(g.K, bt), cdivt(Cout, bt), cdivt(g.M, g.m_per_block));
+        if (bt == 128) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<128>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
+        else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
         MFX_HIP_CHECK(hipGetLastError());
         return MFX_OK;
     }

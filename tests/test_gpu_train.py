@@ -331,7 +331,9 @@ def test_train_steps_update_parameters():
 
 # ---- bf16 training mode (activations bf16, fp32 master weights / statistics / gradients of parameters) ------------------
 @pytest.mark.parametrize("cin,cout,k,stride,bias,f32out", [(16, 32, 3, 1, False, False), (32, 64, 3, 2, False, False),
-                                                           (64, 27, 3, 1, True, True), (256, 3, 1, 1, True, True)])
+                                                           (64, 27, 3, 1, True, True), (256, 3, 1, 1, True, True),
+                                                           (64, 256, 3, 1, False, False), (128, 128, 3, 2, False, False),
+                                                           (256, 512, 1, 1, False, False)])
 def test_conv_grads_bf16(cin, cout, k, stride, bias, f32out):
     from monoflex_amd import autograd as AG
     g = torch.Generator().manual_seed(1)

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="activation dtype (parameters and their gradients stay fp32)")
+    ap.add_argument("--opts", default="", help="library options k=v,... (mfx_set_option)")
     ap.add_argument("--graph", action="store_true", help="capture forward+loss+backward+optimizer in one hipGraph and replay it")
     a = ap.parse_args()
     from monoflex_amd import parallel as par
@@ -29,6 +30,10 @@ def main():
     from monoflex_amd.model.detector import KeypointDetector
     from monoflex_amd.solver import build_optimizer
     from monoflex_amd.structures.params_3d import make_train_target
+    from monoflex_amd import lib as _lib
+    for kv in filter(None, a.opts.split(",")):
+        k_, v_ = kv.split("=")
+        _lib.check(_lib.load().mfx_set_option(k_.encode(), int(v_)), "set_option")
     rank, world, local_rank = par.init_from_env()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
