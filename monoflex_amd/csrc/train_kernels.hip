@@ -10,6 +10,8 @@
 namespace mfx {
 
 static inline int cdivt(long a, long b) { return (int)((a + b - 1) / b); }
+// elementwise BN passes: at most ~8 workgroups per CU, each streaming many chunks (amortises the per-workgroup table)
+#define BN_APPLY_GRID(total) dim3((unsigned)(cdivt((total), 256) < 2048 ? cdivt((total), 256) : 2048))
 #define TR_GRID(total) dim3((unsigned)(cdivt((total), 256) < 16384 ? cdivt((total), 256) : 16384))
 
 template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
@@ -333,7 +335,16 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
     }
 }
 
-// y = act(x*scale[c] + shift[c] (+ res))
+// y = act(x*scale[c] + shift[c] (+ res)); per-channel parameters are fetched as 16-byte vectors (8 scalar loads per
+// parameter and chunk made these streaming kernels instruction-bound at ~1.2 TB/s)
+template <int E> __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + e);
+        v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+    }
+}
+
 template <typename T>
 __global__ void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                   const T* __restrict__ res, T* __restrict__ y, long total_chunks, int C, int act) {
@@ -341,10 +352,11 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restri
     const int CPR = C / E;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total_chunks; i += (long)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % CPR) * E;
-        float v[E];
+        float v[E], sc[E], sh[E];
         ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + i * E), v);
+        load_vec<E>(scale + c0, sc); load_vec<E>(shift + c0, sh);
 #pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = v[e] * scale[c0 + e] + shift[c0 + e];
+        for (int e = 0; e < E; ++e) v[e] = v[e] * sc[e] + sh[e];
         if (res) {
             float r[E];
             ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(res + i * E), r);
@@ -398,26 +410,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     for (int i = tid; i < C; i += 256) { unsafeAtomicAdd(sg + i, sred[i]); unsafeAtomicAdd(sgx + i, sred[C + i]); }
 }
 
-// dx = gamma*rstd * (g - sg/M - xhat*sgx/M);  dres = g (optional)
+// dx = gamma*rstd * (g - sg/M - xhat*sgx/M) = A[c]*g + B[c]*x + D[c];  dres = g (optional).  Every workgroup first builds the
+// [A | B | D] table (3*C floats) in LDS, then streams: three 16-byte table reads per chunk instead of 40 scalar loads.
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ da,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ da,
                                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ sg, const float* __restrict__ sgx, float invM,
                                     T* __restrict__ dx, T* __restrict__ dres, long total_chunks, int C, int act) {
     constexpr int E = ElemTraits<T>::ELEMS;
+    extern __shared__ float coef[];                          // [3][C]
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float ca = gamma[c] * rstd[c], cb = -ca * rstd[c] * sgx[c] * invM;
+        coef[c] = ca; coef[C + c] = cb; coef[2 * C + c] = -cb * mean[c] - ca * sg[c] * invM;
+    }
+    __syncthreads();
     const int CPR = C / E;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total_chunks; i += (long)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % CPR) * E;
-        float xv[E], av[E], dv[E], gq[E], ov[E];
+        float xv[E], av[E], dv[E], gq[E], ov[E], ca[E], cb[E], cd[E];
         ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + i * E), xv);
         ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(da + i * E), dv);
         if (act != ACT_NONE) ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(a + i * E), av);
+        load_vec<E>(coef + c0, ca); load_vec<E>(coef + C + c0, cb); load_vec<E>(coef + 2 * C + c0, cd);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int c = c0 + e;
             gq[e] = act != ACT_NONE ? dv[e] * act_grad(av[e], act) : dv[e];
-            const float xh = (xv[e] - mean[c]) * rstd[c];
-            ov[e] = gamma[c] * rstd[c] * (gq[e] - sg[c] * invM - xh * sgx[c] * invM);
+            ov[e] = ca[e] * gq[e] + cb[e] * xv[e] + cd[e];
         }
         *reinterpret_cast<u32x4*>(dx + i * E) = ElemTraits<T>::pack(ov);
         if (dres) *reinterpret_cast<u32x4*>(dres + i * E) = ElemTraits<T>::pack(gq);
@@ -626,6 +644,16 @@ extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int 
     return MFX_OK;
 }
 
+// rows per workgroup of the two reductions: ~2048 workgroups (240 one-per-CU workgroups left these passes latency-bound at
+// a quarter of the HBM rate), a multiple of the rows one pass of the 256 threads covers
+static int bn_rows_per_block(long M, int C, int dtype) {
+    const int E = dtype == MFX_BF16 ? 8 : 4, rstep = std::max(1, 256 / (C / E));
+    long rows = (M + 2047) / 2048;
+    rows = std::max<long>(rows, 4L * rstep);
+    rows = (rows + rstep - 1) / rstep * rstep;
+    return (int)std::min<long>(rows, 1 << 20);
+}
+
 static int bn_check(int C, int dtype) {
     const int E = dtype == MFX_BF16 ? 8 : 4;
     if (C % E != 0 || C / E > 256 || (256 % (C / E)) != 0) return mfx_fail(MFX_ERR_ARG, "bn: C must be a power-of-two multiple of one 16-byte chunk (<= 256 chunks)");
@@ -639,7 +667,7 @@ extern "C" int mfx_bn_stats(const void* x, float* sum, float* sumsq, long M, int
     MFX_HIP_CHECK(hipMemsetAsync(sum, 0, (size_t)C * sizeof(float), st));
     MFX_HIP_CHECK(hipMemsetAsync(sumsq, 0, (size_t)C * sizeof(float), st));
     if (M == 0) return MFX_OK;
-    const int rows = 1024;
+    const int rows = bn_rows_per_block(M, C, dtype);
     const size_t smem = (size_t)2 * C * sizeof(float);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, sum, sumsq),
                       hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, sum, sumsq));
@@ -681,7 +709,7 @@ extern "C" int mfx_bn_bwd_reduce(const void* x, const void* a, const void* da, c
     MFX_HIP_CHECK(hipMemsetAsync(sg, 0, (size_t)C * sizeof(float), st));
     MFX_HIP_CHECK(hipMemsetAsync(sgx, 0, (size_t)C * sizeof(float), st));
     if (M == 0) return MFX_OK;
-    const int rows = 1024;
+    const int rows = bn_rows_per_block(M, C, dtype);
     const size_t smem = (size_t)2 * C * sizeof(float);
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sg, sgx),
@@ -701,8 +729,8 @@ extern "C" int mfx_bn_bwd_apply(const void* x, const void* a, const void* da, co
     const long chunks = M * (C / (dtype == MFX_BF16 ? 8 : 4));
     const float invM = 1.f / (float)M_total;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, TR_GRID(chunks), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, gamma, sg, sgx, invM, (float*)dx, (float*)dres, chunks, C, act),
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, TR_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, gamma, sg, sgx, invM, (bf16_t*)dx, (bf16_t*)dres, chunks, C, act));
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, BN_APPLY_GRID(chunks), dim3(256), (size_t)3 * C * sizeof(float), st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, gamma, sg, sgx, invM, (float*)dx, (float*)dres, chunks, C, act),
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, BN_APPLY_GRID(chunks), dim3(256), (size_t)3 * C * sizeof(float), st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, gamma, sg, sgx, invM, (bf16_t*)dx, (bf16_t*)dres, chunks, C, act));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
