@@ -207,6 +207,11 @@ int mfx_decode_boxes(const float* hmap, int ld, int reg_off, const float* scores
 int mfx_conv_wgrad_nhwc(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
                         int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
                         int dtype, void* stream);
+/* same with a tap dilation along W (the bf16 stem: 8-element super-taps = two 4-channel pixels, kw = 4, dil_w = 2, pixel
+ * stride 4 elements -- see mfx_stem_conv7x7_nchw / the host packer) */
+int mfx_conv_wgrad_nhwc_dil(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
+                            int kh, int kw, int stride, int pad_h, int pad_w, int dil_w, int Ho, int Wo, int Cout, int ldy,
+                            int dtype, void* stream);
 /* same, written straight in the parameter's layout: dw fp32 (Cout_real, Cin_real, kh, kw); channels of dy beyond Cout_real
  * and of x beyond Cin_real (padding) are dropped */
 int mfx_conv_wgrad_oihw(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,

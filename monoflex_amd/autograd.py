@@ -189,8 +189,18 @@ class StemConvFn(Function):
         xp, weight = ctx.saved_tensors
         H, W = ctx.hw
         Cout = weight.shape[0]
-        dwf = _wgrad(xp, _c(dy), 7, 7, 1, 0, H, W, Ck=4, x_pixstride=4)          # padded image: pad 0 in padded coordinates
-        dw = dwf[:Cout].view(Cout, 7, 7, 4)[..., :3].permute(0, 3, 1, 2).contiguous()
+        dy = _c(dy)
+        if xp.dtype == torch.bfloat16:
+            # bf16: the matrix-core kernel needs 16-byte K chunks -> 8-element super-taps (two 4-channel pixels), kw = 4, dilation 2
+            # (the layout the forward stem uses); dW[o][th*4 + j][u*4 + c] is the gradient of w[o][c][th][2j + u]
+            B, Hp, Wp, _ = xp.shape
+            dws = torch.empty((dy.shape[-1], 28, 8), dtype=torch.float32, device=xp.device)
+            L.check(L.load().mfx_conv_wgrad_nhwc_dil(_ptr(xp), _ptr(dy), _ptr(dws), B, Hp, Wp, 4, 8, 7, 4, 1, 0, 0, 2, H, W, dy.shape[-1],
+                                                     dy.shape[-1], _dt(xp.dtype), _stream()), "mfx_conv_wgrad_nhwc_dil")
+            dw = dws[:Cout].view(Cout, 7, 4, 2, 4).reshape(Cout, 7, 8, 4)[:, :, :7, :3].permute(0, 3, 1, 2).contiguous()
+        else:
+            dwf = _wgrad(xp, dy, 7, 7, 1, 0, H, W, Ck=4, x_pixstride=4)      # padded image: pad 0 in padded coordinates
+            dw = dwf[:Cout].view(Cout, 7, 7, 4)[..., :3].permute(0, 3, 1, 2).contiguous()
         return None, dw, None
 
 

@@ -262,7 +262,7 @@ static int dcn_bwd_core(const float* x, const float* om, const float* wT, const 
         hipLaunchKernelGGL(dcn_bwd_wgrad_kernel, grid, dim3(256), 0, st, x, om, go, g, m_per_block, gwp);
     }
     {   // grad_bias
-        const int rows = 1024;
+        const int rows = g.M >= (1 << 18) ? 256 : 128;          // ~1000+ workgroups (240 left this pass latency-bound)
         hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3(cdv(g.M, rows), g.Coutp / 64), dim3(64, 4), 0, st, go, g.M, g.Coutp, rows, gb);
     }
     MFX_HIP_CHECK(hipGetLastError());

@@ -28,7 +28,7 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
 // conv weight gradient: dW[o][tap][c] = sum_m dy[m][o] * x[pixel(m,tap)][c]       (fp32 [Cout][taps][Ck])
 // Block = 64 k x 64 o tile over a slab of pixels; 256 threads x 4x4 register blocks; fp32 atomics on the small result.
 // ------------------------------------------------------------------------------------------------
-struct WgradGeom { int B, H, W, Ho, Wo, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, M, K, Cout, ldy, m_per_block;
+struct WgradGeom { int B, H, W, Ho, Wo, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, dil_w, M, K, Cout, ldy, m_per_block;
                    int oihw, Cin_out, Cout_out; };   // oihw: write dW as (Cout_out, Cin_out, kh, kw), dropping padded channels
 
 __device__ __forceinline__ void wgrad_add(float* dw, const WgradGeom& g, int o, int k, float v) {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
             if (o_ok) load4<T>(dy + (size_t)m * g.ldy + o0 + sc, gv);
             if (k_ok) {
                 const int b = m / hw, rem = m - b * hw, oh = rem / g.Wo, ow = rem - oh * g.Wo;
-                const int ih = oh * g.stride - g.pad_h + th, iw = ow * g.stride - g.pad_w + tw;
+                const int ih = oh * g.stride - g.pad_h + th, iw = ow * g.stride - g.pad_w + tw * g.dil_w;
                 if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
                     load4<T>(x + ((size_t)(b * g.H + ih) * g.W + iw) * g.x_pixstride + c, cv);
             }
@@ -141,13 +141,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const bf16_t* __re
         if (a_ok) {
             int b2 = pb, oh2 = poh, ow2 = pow_;
             if (m < m_end) {
-                const int ih = poh * g.stride - g.pad_h + th, iw = pow_ * g.stride - g.pad_w + tw;
+                const int ih = poh * g.stride - g.pad_h + th, iw = pow_ * g.stride - g.pad_w + tw * g.dil_w;
                 if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
                     r.a0 = *reinterpret_cast<const u32x4*>(x + ((size_t)(pb * g.H + ih) * g.W + iw) * g.x_pixstride + ch);
             }
             if (m + 1 < m_end) {
                 advance(b2, oh2, ow2, 1);
-                const int ih = oh2 * g.stride - g.pad_h + th, iw = ow2 * g.stride - g.pad_w + tw;
+                const int ih = oh2 * g.stride - g.pad_h + th, iw = ow2 * g.stride - g.pad_w + tw * g.dil_w;
                 if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
                     r.a1 = *reinterpret_cast<const u32x4*>(x + ((size_t)(b2 * g.H + ih) * g.W + iw) * g.x_pixstride + ch);
             }
@@ -562,17 +562,18 @@ int g_opt_wgrad_mfma = 1;     // option "wgrad_mfma": 0 = VALU kernel for bf16 t
 
 static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
                            int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
-                           int dtype, int oihw, int Cin_out, int Cout_out, void* stream) {
+                           int dtype, int oihw, int Cin_out, int Cout_out, void* stream, int dil_w = 1) {
     if (!x || !dy || !dw) return mfx_fail(MFX_ERR_ARG, "conv_wgrad: null pointer");
     if (Ck % 4 != 0 || Cout % 4 != 0) return mfx_fail(MFX_ERR_ARG, "conv_wgrad: Ck and Cout must be multiples of 4");
     WgradGeom g;
     g.B = B; g.H = H; g.W = W; g.Ho = Ho; g.Wo = Wo; g.x_pixstride = x_pixstride; g.Ck = Ck; g.kh = kh; g.kw = kw; g.stride = stride;
-    g.pad_h = pad_h; g.pad_w = pad_w; g.M = B * Ho * Wo; g.K = kh * kw * Ck; g.Cout = Cout; g.ldy = ldy; g.m_per_block = 2048;
+    g.pad_h = pad_h; g.pad_w = pad_w; g.dil_w = dil_w; g.M = B * Ho * Wo; g.K = kh * kw * Ck; g.Cout = Cout; g.ldy = ldy; g.m_per_block = 2048;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     g.oihw = oihw; g.Cin_out = Cin_out; g.Cout_out = Cout_out;
     MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (oihw ? (size_t)Cout_out * Cin_out * kh * kw : (size_t)Cout * g.K) * sizeof(float), st));
     if (g.M == 0) return MFX_OK;
-    if (dtype == MFX_BF16 && Ck % 8 == 0 && x_pixstride % 8 == 0 && ldy % 8 == 0 && g_opt_wgrad_mfma) {
+    // (x chunks only need 4-byte alignment: the stem reads 8-element super-taps at a pixel stride of 4 elements)
+    if (dtype == MFX_BF16 && Ck % 8 == 0 && x_pixstride % 2 == 0 && ldy % 8 == 0 && g_opt_wgrad_mfma) {
         const int bt = (Cout >= 128 && g.K >= 128 && g_opt_wgrad_mfma == 3) ? 128 : 64;     // 128-wide tiles measured slower (83 vs 78 ms)
         const int tiles = cdivt(g.K, bt) * cdivt(Cout, bt);
         // pixel slabs: enough workgroups to fill the chip (~8 per CU), but at least 1024 pixels each (the fp32 atomics of the
@@ -596,6 +597,13 @@ extern "C" int mfx_conv_wgrad_nhwc(const void* x, const void* dy, float* dw, int
                                    int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
                                    int dtype, void* stream) {
     return conv_wgrad_impl(x, dy, dw, B, H, W, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, Ho, Wo, Cout, ldy, dtype, 0, 0, 0, stream);
+}
+
+extern "C" int mfx_conv_wgrad_nhwc_dil(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
+                                       int kh, int kw, int stride, int pad_h, int pad_w, int dil_w, int Ho, int Wo, int Cout, int ldy,
+                                       int dtype, void* stream) {
+    if (dil_w < 1) return mfx_fail(MFX_ERR_ARG, "conv_wgrad: dil_w must be >= 1");
+    return conv_wgrad_impl(x, dy, dw, B, H, W, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, Ho, Wo, Cout, ldy, dtype, 0, 0, 0, stream, dil_w);
 }
 
 extern "C" int mfx_conv_wgrad_oihw(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
@@ -664,8 +672,11 @@ extern "C" int mfx_bn_stats(const void* x, float* sum, float* sumsq, long M, int
     if (!x || !sum || !sumsq) return mfx_fail(MFX_ERR_ARG, "bn_stats: null pointer");
     int rc = bn_check(C, dtype); if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    MFX_HIP_CHECK(hipMemsetAsync(sum, 0, (size_t)C * sizeof(float), st));
-    MFX_HIP_CHECK(hipMemsetAsync(sumsq, 0, (size_t)C * sizeof(float), st));
+    if (sumsq == sum + C) { MFX_HIP_CHECK(hipMemsetAsync(sum, 0, (size_t)2 * C * sizeof(float), st)); }      // one fill for the usual packed pair
+    else {
+        MFX_HIP_CHECK(hipMemsetAsync(sum, 0, (size_t)C * sizeof(float), st));
+        MFX_HIP_CHECK(hipMemsetAsync(sumsq, 0, (size_t)C * sizeof(float), st));
+    }
     if (M == 0) return MFX_OK;
     const int rows = bn_rows_per_block(M, C, dtype);
     const size_t smem = (size_t)2 * C * sizeof(float);
@@ -706,8 +717,11 @@ extern "C" int mfx_bn_bwd_reduce(const void* x, const void* a, const void* da, c
     if (!x || !da || !mean || !rstd || !sg || !sgx || (act != MFX_ACT_NONE && !a)) return mfx_fail(MFX_ERR_ARG, "bn_bwd_reduce: null pointer");
     int rc = bn_check(C, dtype); if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    MFX_HIP_CHECK(hipMemsetAsync(sg, 0, (size_t)C * sizeof(float), st));
-    MFX_HIP_CHECK(hipMemsetAsync(sgx, 0, (size_t)C * sizeof(float), st));
+    if (sgx == sg + C) { MFX_HIP_CHECK(hipMemsetAsync(sg, 0, (size_t)2 * C * sizeof(float), st)); }
+    else {
+        MFX_HIP_CHECK(hipMemsetAsync(sg, 0, (size_t)C * sizeof(float), st));
+        MFX_HIP_CHECK(hipMemsetAsync(sgx, 0, (size_t)C * sizeof(float), st));
+    }
     if (M == 0) return MFX_OK;
     const int rows = bn_rows_per_block(M, C, dtype);
     const size_t smem = (size_t)2 * C * sizeof(float);

@@ -379,3 +379,19 @@ def test_train_steps_bf16_mode():
     opt = build_optimizer(m16, cfg)
     losses = [float(train_step(m16, opt, imgs, targets)[0]) for _ in range(3)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_stem_conv_wgrad_bf16():
+    """bf16 stem weight gradient: matrix-core kernel over 8-element super-taps with dilation 2, mapped back to (16,3,7,7)."""
+    from monoflex_amd import autograd as AG
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 32, 64, generator=g).bfloat16().float()
+    w = (torch.randn(16, 3, 7, 7, generator=g) * 0.1)
+    wr = w.clone().requires_grad_()
+    yr = F.conv2d(x, wr, padding=3)
+    r = torch.randn(yr.shape, generator=g).bfloat16().float()
+    (yr * r).sum().backward()
+    wd = w.to(DEV).requires_grad_()
+    yd = AG.StemConvFn.apply(x.to(DEV), wd, torch.bfloat16)
+    (yd.float() * _nhwc(r).to(DEV)).sum().backward()
+    assert _rel(yd.permute(0, 3, 1, 2), yr) < 2e-2 and _rel(wd.grad, wr.grad) < 2e-2
