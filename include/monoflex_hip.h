@@ -258,6 +258,12 @@ int mfx_dcn_backward_nhwc(const float* x, const float* offmask, const float* wei
                           float* dx, float* d_offmask, float* dweight, float* dbias,
                           int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* bf16 activations (x, dy bf16): d(columns) by the bf16 MFMA GEMM; all gradient outputs fp32 (dx is accumulated with fp32
+ * atomics; the caller narrows it).  Same workspace size.  C >= 64. */
+int mfx_dcn_backward_nhwc_bf16(const void* x, const float* offmask, const float* weight_oihw, const void* dy,
+                               float* dx, float* d_offmask, float* dweight, float* dbias,
+                               int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -347,14 +347,16 @@ class DCNFn(Function):
         nbytes = lib_.mfx_dcn_backward_nhwc_workspace_bytes(B, C, H, W, Cout, kh, kw, stride, pad, dil)
         ws = ops._workspace(nbytes, x.device)
         xdtype = x.dtype
-        if xdtype != torch.float32:                            # bf16 mode: the DCN backward kernels are fp32 (casts are transient)
+        bf16_path = xdtype == torch.bfloat16 and C >= 64
+        if xdtype != torch.float32 and not bf16_path:
             x, dy = x.float(), dy.float()
-        dx = torch.empty_like(x)
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         dom = torch.empty_like(om)
         dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
         wc = weight.detach().float().contiguous()
-        L.check(lib_.mfx_dcn_backward_nhwc(_ptr(x), _ptr(om), _ptr(wc), _ptr(dy), _ptr(dx), _ptr(dom), _ptr(dw), _ptr(db),
+        entry = lib_.mfx_dcn_backward_nhwc_bf16 if bf16_path else lib_.mfx_dcn_backward_nhwc
+        L.check(entry(_ptr(x), _ptr(om), _ptr(wc), _ptr(dy if dy.dtype == x.dtype else dy.to(x.dtype)), _ptr(dx), _ptr(dom), _ptr(dw), _ptr(db),
                                            B, C, H, W, Cout, kh, kw, stride, pad, dil, _ptr(ws), ws.numel(), _stream()),
                 "mfx_dcn_backward_nhwc")
         m = om[..., 18:27]

@@ -12,12 +12,20 @@
 #include "../../include/monoflex_hip.h"
 #include "common.h"
 #include "err.h"
+#include <type_traits>
 
 namespace mfx {
 
 static inline int next_pow2_(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static inline int cdv(long a, long b) { return (int)((a + b - 1) / b); }
+
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t* p) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    return f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+}
 
 struct BwdGeom { int B, H, W, Cp, lgC, Ho, Wo, kh, kw, kk, stride, pad, dil, M, K, Kp, Coutp; };
 
@@ -51,7 +59,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // grad wrt offsets, mask and input from d(columns).  One wavefront per (pixel m, tap).
-__global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const float* x, const float* om, const float* gcol, BwdGeom g,
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const T* x, const float* om, const T* gcol, BwdGeom g,
                                                              float* gx, float* gom) {
     const int lane = threadIdx.x & 63;
     const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
@@ -65,10 +74,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const float* x, con
         float gm = 0.f, gh = 0.f, gw = 0.f;
         if (t.inside) {
             for (int c = lane; c < g.Cp; c += 64) {
-                const float gc = gcol[(size_t)m * g.Kp + tap * g.Cp + c];
+                const float gc = ElemTraits<T>::load(gcol + (size_t)m * g.Kp + tap * g.Cp + c);
                 float v[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = t.cv[q] ? x[(size_t)t.off[q] * g.Cp + c] : 0.f;
+                for (int q = 0; q < 4; ++q) v[q] = t.cv[q] ? ElemTraits<T>::load(x + (size_t)t.off[q] * g.Cp + c) : 0.f;
                 gm += gc * (t.w[0] * v[0] + t.w[1] * v[1] + t.w[2] * v[2] + t.w[3] * v[3]);
                 // dmcn_get_coordinate_weight (dcn_v2_im2col_cuda.cu:82-122)
                 gh += (-t.hw * v[0] - t.lw * v[1] + t.hw * v[2] + t.lw * v[3]) * gc * mask;
@@ -92,7 +101,8 @@ int g_opt_dcn_wgrad_m = 512;    // option "dcn_wgrad_m": pixels per workgroup sl
 // grad_weight[o][k] += sum over a slab of pixels of go[m][o] * col[m][k]; col re-sampled into LDS.
 // Block = 64 k x 64 o output tile, 256 threads each owning a 4x4 register block.
 constexpr int WG_MCH = 16;     // pixels staged per step
-__global__ __launch_bounds__(256) void dcn_bwd_wgrad_kernel(const float* x, const float* om, const float* go, BwdGeom g,
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_bwd_wgrad_kernel(const T* x, const float* om, const T* go, BwdGeom g,
                                                             int m_per_block, float* gw) {
     __shared__ float cs[WG_MCH][64 + 4];     // col chunk  [m][k]
     __shared__ float gs[WG_MCH][64 + 4];     // grad chunk [m][o]
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_wgrad_kernel(const float* x, cons
         const int m = mb + sr;
         float cv4[4] = {0.f, 0.f, 0.f, 0.f}, gv4[4] = {0.f, 0.f, 0.f, 0.f};
         if (m < m_end) {
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(go + (size_t)m * g.Coutp + o0 + sc);
+            const f32x4 gg = ld4<T>(go + (size_t)m * g.Coutp + o0 + sc);
             gv4[0] = gg[0]; gv4[1] = gg[1]; gv4[2] = gg[2]; gv4[3] = gg[3];
             const int k = k0 + sc;
             if (k < g.K) {                                   // Cp >= 16 -> the 4 k's share one tap
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_wgrad_kernel(const float* x, cons
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (t.cv[q]) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)t.off[q] * g.Cp + c);
+                        const f32x4 v = ld4<T>(x + (size_t)t.off[q] * g.Cp + c);
                         const float wq = t.w[q] * mask;
                         cv4[0] += wq * v[0]; cv4[1] += wq * v[1]; cv4[2] += wq * v[2]; cv4[3] += wq * v[3];
                     }
@@ -152,11 +162,12 @@ __global__ __launch_bounds__(256) void dcn_bwd_wgrad_kernel(const float* x, cons
 }
 
 // grad_bias[o] = sum_m go[m][o]
-__global__ void dcn_bwd_bias_kernel(const float* go, int M, int Coutp, int rows_per_block, float* gb) {
+template <typename T>
+__global__ void dcn_bwd_bias_kernel(const T* go, int M, int Coutp, int rows_per_block, float* gb) {
     const int o = blockIdx.y * 64 + threadIdx.x;
     const int r0 = blockIdx.x * rows_per_block;
     float s = 0.f;
-    for (int r = r0 + threadIdx.y; r < min(r0 + rows_per_block, M); r += blockDim.y) s += go[(size_t)r * Coutp + o];
+    for (int r = r0 + threadIdx.y; r < min(r0 + rows_per_block, M); r += blockDim.y) s += ElemTraits<T>::load(go + (size_t)r * Coutp + o);
     __shared__ float red[4][64];
     red[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
@@ -188,13 +199,14 @@ __global__ void bwd_unpack_offmask(const float* gom, float* goff, float* gmask, 
     }
 }
 // weight (Cout,C,kk) -> transposed pack wT[Kp][Coutp]: wT[tap*Cp+c][o]
-__global__ void bwd_pack_weight_t(const float* w, float* wT, int Cout, int C, int kk, int Cp, int Kp, int Coutp) {
+template <typename T>
+__global__ void bwd_pack_weight_t(const float* w, T* wT, int Cout, int C, int kk, int Cp, int Kp, int Coutp) {
     const long total = (long)Kp * Coutp;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int o = (int)(i % Coutp);
         const int k = (int)(i / Coutp);
         const int tap = k / Cp, c = k - tap * Cp;
-        wT[i] = (o < Cout && c < C && tap < kk) ? w[((size_t)o * C + c) * kk + tap] : 0.f;
+        ElemTraits<T>::store(wT + i, (o < Cout && c < C && tap < kk) ? w[((size_t)o * C + c) * kk + tap] : 0.f);
     }
 }
 // packed grad [Coutp][K] (k = tap*Cp+c) -> (Cout,C,kk)
@@ -239,7 +251,8 @@ static BwdGeom bwd_geom(int B, int C, int H, int W, int Cout, int kh, int kw, in
 }
 
 // gradients of the NHWC fp32 problem: gcol scratch [M][Kp]; gx [B*H*W][Cp], gwp [Coutp][K], gb [Coutp] must be zeroed
-static int dcn_bwd_core(const float* x, const float* om, const float* wT, const float* go, float* gcol, float* gx, float* gom,
+template <typename T>
+static int dcn_bwd_core(const T* x, const float* om, const T* wT, const T* go, T* gcol, float* gx, float* gom,
                         float* gwp, float* gb, const BwdGeom& g, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // d(columns)[m][k] = sum_o go[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM
@@ -247,23 +260,23 @@ static int dcn_bwd_core(const float* x, const float* om, const float* wT, const 
     cd.x = go; cd.w = wT; cd.w_frag = nullptr; cd.scale = nullptr; cd.shift = nullptr; cd.res = nullptr; cd.y = gcol; cd.rowmap = nullptr;
     cd.B = 1; cd.H = 1; cd.W = g.M; cd.x_pixstride = g.Coutp; cd.Ck = g.Coutp; cd.kh = 1; cd.kw = 1; cd.stride = 1;
     cd.pad_h = 0; cd.pad_w = 0; cd.dil_w = 1; cd.Ho = 1; cd.Wo = g.M; cd.M = g.M; cd.Cout = g.Kp; cd.Cout_pad = g.Kp;
-    cd.K_pad = g.Coutp; cd.ldy = g.Kp; cd.ldres = 0; cd.act = MFX_ACT_NONE; cd.dtype = MFX_F32; cd.out_dtype = MFX_F32;
+    cd.K_pad = g.Coutp; cd.ldy = g.Kp; cd.ldres = 0; cd.act = MFX_ACT_NONE; cd.dtype = std::is_same<T, float>::value ? MFX_F32 : MFX_BF16; cd.out_dtype = cd.dtype;
     cd.workspace = nullptr; cd.workspace_bytes = 0;
     int rc = mfx_conv2d_nhwc(&cd, stream);
     if (rc) return rc;
     {   // grad_offset, grad_mask, grad_input
         const long pairs = (long)g.M * g.kk;
         const int blocks = (int)((pairs + 3) / 4 < 65536 ? (pairs + 3) / 4 : 65536);
-        hipLaunchKernelGGL(dcn_bwd_sample_kernel, dim3(blocks), dim3(256), 0, st, x, om, gcol, g, gx, gom);
+        hipLaunchKernelGGL(dcn_bwd_sample_kernel<T>, dim3(blocks), dim3(256), 0, st, x, om, gcol, g, gx, gom);
     }
     {   // grad_weight
         const int m_per_block = g_opt_dcn_wgrad_m;
         dim3 grid(g.Kp / 64, g.Coutp / 64, cdv(g.M, m_per_block));
-        hipLaunchKernelGGL(dcn_bwd_wgrad_kernel, grid, dim3(256), 0, st, x, om, go, g, m_per_block, gwp);
+        hipLaunchKernelGGL(dcn_bwd_wgrad_kernel<T>, grid, dim3(256), 0, st, x, om, go, g, m_per_block, gwp);
     }
     {   // grad_bias
         const int rows = g.M >= (1 << 18) ? 256 : 128;          // ~1000+ workgroups (240 left this pass latency-bound)
-        hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3(cdv(g.M, rows), g.Coutp / 64), dim3(64, 4), 0, st, go, g.M, g.Coutp, rows, gb);
+        hipLaunchKernelGGL(dcn_bwd_bias_kernel<T>, dim3(cdv(g.M, rows), g.Coutp / 64), dim3(64, 4), 0, st, go, g.M, g.Coutp, rows, gb);
     }
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -303,13 +316,13 @@ extern "C" int mfx_dcn_v2_backward(const float* input, const float* weight, cons
     rc = mfx_nchw_to_nhwc(grad_output, go, B, Cout, g.Ho, g.Wo, g.Coutp, MFX_F32, stream);   // .contiguous() is the caller's job (App. C item 18)
     if (rc) return rc;
     hipLaunchKernelGGL(bwd_pack_offmask, BWD_GRID((long)g.M * 32), dim3(256), 0, st, offset, mask, om, B, HWo, g.kk);
-    hipLaunchKernelGGL(bwd_pack_weight_t, BWD_GRID((long)g.Kp * g.Coutp), dim3(256), 0, st, weight, wT, Cout, C, g.kk, g.Cp, g.Kp, g.Coutp);
+    hipLaunchKernelGGL(bwd_pack_weight_t<float>, BWD_GRID((long)g.Kp * g.Coutp), dim3(256), 0, st, weight, wT, Cout, C, g.kk, g.Cp, g.Kp, g.Coutp);
     MFX_HIP_CHECK(hipMemsetAsync(gx, 0, (size_t)B * H * W * g.Cp * 4, st));
     MFX_HIP_CHECK(hipMemsetAsync(gwp, 0, (size_t)g.Coutp * g.K * 4, st));
     MFX_HIP_CHECK(hipMemsetAsync(gb, 0, (size_t)g.Coutp * 4, st));
     MFX_HIP_CHECK(hipGetLastError());
 
-    rc = dcn_bwd_core(x, om, wT, go, gcol, gx, gom, gwp, gb, g, stream);
+    rc = dcn_bwd_core<float>(x, om, wT, go, gcol, gx, gom, gwp, gb, g, stream);
     if (rc) return rc;
 
     rc = mfx_nhwc_to_nchw(gx, grad_input, B, C, H, W, g.Cp, MFX_F32, stream);
@@ -330,10 +343,11 @@ extern "C" size_t mfx_dcn_backward_nhwc_workspace_bytes(int B, int C, int H, int
     return al256((size_t)g.Kp * g.Coutp * 4) + al256((size_t)g.M * g.Kp * 4) + al256((size_t)g.Coutp * g.K * 4) + al256((size_t)g.Coutp * 4);
 }
 
-extern "C" int mfx_dcn_backward_nhwc(const float* x, const float* offmask, const float* weight, const float* dy,
-                                     float* dx, float* d_offmask, float* dweight, float* dbias,
-                                     int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+template <typename T>
+static int dcn_backward_nhwc_impl(const T* x, const float* offmask, const float* weight, const T* dy,
+                                  float* dx, float* d_offmask, float* dweight, float* dbias,
+                                  int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !offmask || !weight || !dy || !dx || !d_offmask || !dweight || !dbias) return mfx_fail(MFX_ERR_ARG, "dcn_backward_nhwc: null pointer");
     if (kh * kw > 9) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_backward_nhwc: at most 9 taps");
     const BwdGeom g = bwd_geom(B, C, H, W, Cout, kh, kw, stride, pad, dil);
@@ -342,20 +356,39 @@ extern "C" int mfx_dcn_backward_nhwc(const float* x, const float* offmask, const
         return mfx_fail(MFX_ERR_WORKSPACE, "dcn_backward_nhwc: workspace too small");
     if (g.M == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    char* ws = reinterpret_cast<char*>(workspace);
-    float* wT = (float*)ws; ws += al256((size_t)g.Kp * g.Coutp * 4);
-    float* gcol = (float*)ws; ws += al256((size_t)g.M * g.Kp * 4);
+    char* ws = reinterpret_cast<char*>(workspace);                     // regions sized for fp32 (the bf16 build uses half of two of them)
+    T* wT = (T*)ws; ws += al256((size_t)g.Kp * g.Coutp * 4);
+    T* gcol = (T*)ws; ws += al256((size_t)g.M * g.Kp * 4);
     float* gwp = (float*)ws; ws += al256((size_t)g.Coutp * g.K * 4);
     float* gb = (float*)ws;
-    hipLaunchKernelGGL(bwd_pack_weight_t, BWD_GRID((long)g.Kp * g.Coutp), dim3(256), 0, st, weight, wT, Cout, C, g.kk, g.Cp, g.Kp, g.Coutp);
+    hipLaunchKernelGGL(bwd_pack_weight_t<T>, BWD_GRID((long)g.Kp * g.Coutp), dim3(256), 0, st, weight, wT, Cout, C, g.kk, g.Cp, g.Kp, g.Coutp);
     MFX_HIP_CHECK(hipMemsetAsync(dx, 0, (size_t)B * H * W * C * 4, st));
     MFX_HIP_CHECK(hipMemsetAsync(d_offmask, 0, (size_t)g.M * 32 * 4, st));
     MFX_HIP_CHECK(hipMemsetAsync(gwp, 0, (size_t)g.Coutp * g.K * 4, st));
     MFX_HIP_CHECK(hipMemsetAsync(gb, 0, (size_t)g.Coutp * 4, st));
-    int rc = dcn_bwd_core(x, offmask, wT, dy, gcol, dx, d_offmask, gwp, gb, g, stream);
+    int rc = dcn_bwd_core<T>(x, offmask, wT, dy, gcol, dx, d_offmask, gwp, gb, g, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(bwd_unpack_weight, BWD_GRID((long)Cout * C * g.kk), dim3(256), 0, st, gwp, dweight, Cout, C, g.kk, g.Cp, g.K);
     MFX_HIP_CHECK(hipMemcpyAsync(dbias, gb, (size_t)Cout * 4, hipMemcpyDeviceToDevice, st));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
+}
+
+extern "C" int mfx_dcn_backward_nhwc(const float* x, const float* offmask, const float* weight, const float* dy,
+                                     float* dx, float* d_offmask, float* dweight, float* dbias,
+                                     int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    return dcn_backward_nhwc_impl<float>(x, offmask, weight, dy, dx, d_offmask, dweight, dbias, B, C, H, W, Cout, kh, kw, stride, pad, dil,
+                                         workspace, workspace_bytes, stream);
+}
+
+// bf16 activations: x and dy bf16; d(columns) is produced by the bf16 MFMA GEMM and kept in bf16; every gradient output
+// (dx included: it is accumulated with fp32 atomics) stays fp32
+extern "C" int mfx_dcn_backward_nhwc_bf16(const void* x, const float* offmask, const float* weight, const void* dy,
+                                          float* dx, float* d_offmask, float* dweight, float* dbias,
+                                          int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (C < 64) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_backward_nhwc_bf16: C >= 64");
+    return dcn_backward_nhwc_impl<bf16_t>((const bf16_t*)x, offmask, weight, (const bf16_t*)dy, dx, d_offmask, dweight, dbias,
+                                          B, C, H, W, Cout, kh, kw, stride, pad, dil, workspace, workspace_bytes, stream);
 }

@@ -88,6 +88,7 @@ SYMBOLS = {
     "mfx_zero_insert2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_dcn_backward_nhwc_workspace_bytes": (_S, [_I] * 10),
     "mfx_dcn_backward_nhwc": (_I, [_P] * 8 + [_I] * 10 + [_P, _S, _P]),
+    "mfx_dcn_backward_nhwc_bf16": (_I, [_P] * 8 + [_I] * 10 + [_P, _S, _P]),
     "mfx_decode_boxes": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P]),
 }
 

@@ -395,3 +395,34 @@ def test_stem_conv_wgrad_bf16():
     yd = AG.StemConvFn.apply(x.to(DEV), wd, torch.bfloat16)
     (yd.float() * _nhwc(r).to(DEV)).sum().backward()
     assert _rel(yd.permute(0, 3, 1, 2), yr) < 2e-2 and _rel(wd.grad, wr.grad) < 2e-2
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64)])
+def test_dcn_train_grads_bf16_vs_oracle(cin, cout):
+    """bf16 DCN backward (bf16 x / dy / d(columns), fp32 accumulation of every gradient) against the C oracle's fp32
+    gradients on bf16-representable inputs; tolerance of a bf16 pipeline."""
+    from oracle import monoflex_ref as R
+    from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCN
+    g = torch.Generator().manual_seed(8)
+    ref = R.DCN(cin, cout)
+    dev = DCN(cin, cout, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
+    with torch.no_grad():
+        ref.weight.copy_((torch.randn(ref.weight.shape, generator=g) * 0.05).bfloat16().float())
+        ref.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        ref.conv_offset_mask.weight.copy_((torch.randn(ref.conv_offset_mask.weight.shape, generator=g) * 0.02).bfloat16().float())
+        ref.conv_offset_mask.bias.copy_(torch.randn(27, generator=g) * 0.5)
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.to(DEV).train()
+    x = torch.randn(2, cin, 12, 20, generator=g).bfloat16().float()
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    r = torch.randn(yr.shape, generator=g).bfloat16().float()
+    (yr * r).sum().backward()
+    xd = _nhwc(x).to(DEV).bfloat16().requires_grad_()
+    yd = dev.forward_nhwc_train(xd)
+    (yd.float() * _nhwc(r).to(DEV)).sum().backward()
+    assert _rel(yd.permute(0, 3, 1, 2), yr) < 2e-2
+    assert _rel(xd.grad.permute(0, 3, 1, 2), xr.grad) < 3e-2
+    refp = dict(ref.named_parameters())
+    for n, p in dev.named_parameters():
+        assert _rel(p.grad, refp[n].grad) < 4e-2, n
