@@ -216,7 +216,9 @@ int mfx_conv_wgrad_nhwc_dil(const void* x, const void* dy, float* dw, int B, int
  * and of x beyond Cin_real (padding) are dropped */
 int mfx_conv_wgrad_oihw(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
                         int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
-                        int Cout_real, int Cin_real, int dtype, void* stream);
+                        int Cout_real, int Cin_real, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* (workspace: optional fp32 scratch; with it the bf16 kernel writes per-slab partial tiles and sums them in a second pass
+ *  instead of accumulating with atomics, which lets it use 4x more workgroups) */
 /* fp32 OIHW parameter -> packed operand [rows_pad][K_pad] of `dtype` (+ optional fragment-major copy, see mfx_conv_desc.w_frag).
  * mode 0: forward weights, row = o, k = tap*ck + c (ck >= Cin).  mode 1: data-gradient weights (kernel rotated by 180 degrees,
  * in/out swapped): row = c, k = tap'*ck + o (ck >= Cout = channels of dy).  Padding rows/columns are zero. */

@@ -124,8 +124,9 @@ class Conv2dFn(Function):
                 dx = dx[..., :Cin]
         if ctx.needs_input_grad[1]:
             dwf = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            ws = ops._splitk_workspace(x.device)                 # per-slab partial tiles (bf16 path), shared per stream
             L.check(L.load().mfx_conv_wgrad_oihw(_ptr(x), _ptr(dy), _ptr(dwf), B, H, W, Cin, Cin, kh, kw, stride, pad, pad, Ho, Wo, Cp, Cp,
-                                                 Cout, Cin, _dt(x.dtype), _stream()), "mfx_conv_wgrad_oihw")
+                                                 Cout, Cin, _dt(x.dtype), _ptr(ws), ws.numel() * 4, _stream()), "mfx_conv_wgrad_oihw")
             dw = dwf if weight.dtype == torch.float32 else dwf.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy)[:Cout]

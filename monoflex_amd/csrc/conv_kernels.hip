@@ -277,7 +277,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 int try_conv_halo(const mfx_conv_desc* d, hipStream_t st);   // conv_halo.hip
 extern int g_opt_halo, g_opt_halo_cg, g_opt_dcn_wave, g_opt_dcn_patch, g_opt_dcn_patch_fn8, g_opt_dcn_wgrad_m;
 }
-extern int g_opt_wgrad_mfma, g_opt_wgrad_blocks;                                   // train_kernels.hip (global namespace)
+extern int g_opt_wgrad_mfma, g_opt_wgrad_blocks, g_opt_wgrad_ws, g_opt_wgrad_ws_blocks;                                   // train_kernels.hip (global namespace)
 namespace mfx {
 int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st);      // dcn_wave.hip
 int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st);     // dcn_patch.hip
@@ -405,6 +405,8 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "dcn_ksplit") g_opt_dcn_ksplit = value;
     else if (n == "wgrad_mfma") g_opt_wgrad_mfma = value;
     else if (n == "wgrad_blocks") g_opt_wgrad_blocks = value;
+    else if (n == "wgrad_ws") g_opt_wgrad_ws = value;
+    else if (n == "wgrad_ws_blocks") g_opt_wgrad_ws_blocks = value;
     else if (n == "dcn_wgrad_m") g_opt_dcn_wgrad_m = value < 64 ? 64 : value;
     else if (n == "halo") g_opt_halo = value;
     else if (n == "halo_cg") g_opt_halo_cg = value;

@@ -29,9 +29,11 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
 // Block = 64 k x 64 o tile over a slab of pixels; 256 threads x 4x4 register blocks; fp32 atomics on the small result.
 // ------------------------------------------------------------------------------------------------
 struct WgradGeom { int B, H, W, Ho, Wo, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, dil_w, M, K, Cout, ldy, m_per_block;
-                   int oihw, Cin_out, Cout_out; };   // oihw: write dW as (Cout_out, Cin_out, kh, kw), dropping padded channels
+                   int oihw, Cin_out, Cout_out;
+                   float* ws; int ws_ld; long ws_slab; };    // ws != null: partial tiles go to ws[slab][o][k] with plain stores   // oihw: write dW as (Cout_out, Cin_out, kh, kw), dropping padded channels
 
 __device__ __forceinline__ void wgrad_add(float* dw, const WgradGeom& g, int o, int k, float v) {
+    if (g.ws) { g.ws[(size_t)blockIdx.z * g.ws_slab + (size_t)o * g.ws_ld + k] = v; return; }
     if (!g.oihw) { unsafeAtomicAdd(dw + (size_t)o * g.K + k, v); return; }
     const int tap = k / g.Ck, c = k - tap * g.Ck;
     if (o < g.Cout_out && c < g.Cin_out) unsafeAtomicAdd(dw + ((size_t)o * g.Cin_out + c) * (g.kh * g.kw) + tap, v);
@@ -215,6 +217,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const bf16_t* __re
                 const int o = o0 + wo * (BT / 2) + i * 16 + (lane >> 4) * 4 + r, k = k0 + wk * (BT / 2) + j * 16 + (lane & 15);
                 if (o < g.Cout && k < g.K) wgrad_add(dw, g, o, k, acc[i][j][r]);
             }
+}
+
+// sums the per-slab partial tiles of conv_wgrad_mfma_kernel and writes the gradient in its final layout
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int slabs, long ws_slab, int ws_ld, WgradGeom g, float* __restrict__ dw) {
+    const long total = (long)g.Cout * g.K;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i / g.K), k = (int)(i - (long)o * g.K);
+        float s = 0.f;
+        for (int z = 0; z < slabs; ++z) s += ws[(size_t)z * ws_slab + (size_t)o * ws_ld + k];
+        if (!g.oihw) { dw[(size_t)o * g.K + k] = s; continue; }
+        const int tap = k / g.Ck, c = k - tap * g.Ck;
+        if (o < g.Cout_out && c < g.Cin_out) dw[((size_t)o * g.Cin_out + c) * (g.kh * g.kw) + tap] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -556,33 +571,49 @@ using namespace mfx;
 int g_opt_wgrad_blocks = 600;   // option "wgrad_blocks": target workgroup count of the MFMA weight-gradient kernel (measured, B=8 step:
                                 // 64 -> 146 ms, 150 -> 90, 300 -> 78, 600 -> 73, 2048 -> 75, 8192 -> 81: the tile atomics of every slab cost
                                 // more than the extra workgroups hide)
+int g_opt_wgrad_ws = 1;        // option "wgrad_ws": 0 = always accumulate the tiles with atomics
+int g_opt_wgrad_ws_blocks = 1200;  // option "wgrad_ws_blocks": target workgroup count when partial tiles go to the workspace (step: 1200 -> 58.0 ms, 2400 -> 58.3, 4800 -> 58.6; atomics: 59.6)
 int g_opt_wgrad_mfma = 1;     // option "wgrad_mfma": 0 = VALU kernel for bf16 too, 1 = 64x64 MFMA tiles, 3 = 128x128 where they fit
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == MFX_F32) { CALL_F32; } else if ((dtype) == MFX_BF16) { CALL_BF16; } else return mfx_fail(MFX_ERR_ARG, "bad dtype"); } while (0)
 
 static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
                            int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
-                           int dtype, int oihw, int Cin_out, int Cout_out, void* stream, int dil_w = 1) {
+                           int dtype, int oihw, int Cin_out, int Cout_out, void* stream, int dil_w = 1,
+                           void* workspace = nullptr, size_t workspace_bytes = 0) {
     if (!x || !dy || !dw) return mfx_fail(MFX_ERR_ARG, "conv_wgrad: null pointer");
     if (Ck % 4 != 0 || Cout % 4 != 0) return mfx_fail(MFX_ERR_ARG, "conv_wgrad: Ck and Cout must be multiples of 4");
     WgradGeom g;
     g.B = B; g.H = H; g.W = W; g.Ho = Ho; g.Wo = Wo; g.x_pixstride = x_pixstride; g.Ck = Ck; g.kh = kh; g.kw = kw; g.stride = stride;
     g.pad_h = pad_h; g.pad_w = pad_w; g.dil_w = dil_w; g.M = B * Ho * Wo; g.K = kh * kw * Ck; g.Cout = Cout; g.ldy = ldy; g.m_per_block = 2048;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    g.oihw = oihw; g.Cin_out = Cin_out; g.Cout_out = Cout_out;
+    g.oihw = oihw; g.Cin_out = Cin_out; g.Cout_out = Cout_out; g.ws = nullptr; g.ws_ld = 0; g.ws_slab = 0;
     MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (oihw ? (size_t)Cout_out * Cin_out * kh * kw : (size_t)Cout * g.K) * sizeof(float), st));
     if (g.M == 0) return MFX_OK;
     // (x chunks only need 4-byte alignment: the stem reads 8-element super-taps at a pixel stride of 4 elements)
     if (dtype == MFX_BF16 && Ck % 8 == 0 && x_pixstride % 2 == 0 && ldy % 8 == 0 && g_opt_wgrad_mfma) {
         const int bt = (Cout >= 128 && g.K >= 128 && g_opt_wgrad_mfma == 3) ? 128 : 64;     // 128-wide tiles measured slower (83 vs 78 ms)
         const int tiles = cdivt(g.K, bt) * cdivt(Cout, bt);
-        // pixel slabs: enough workgroups to fill the chip (~8 per CU), but at least 1024 pixels each (the fp32 atomics of the
-        // tile are paid once per slab)
-        int slabs = std::max(1, g_opt_wgrad_blocks / tiles);
+        // pixel slabs.  With a workspace every slab writes its partial tile with plain stores and wgrad_reduce_kernel sums them,
+        // so the slab count only has to fill the chip; without one the tile is accumulated with fp32 atomics, which bounds it
+        // (measured optimum ~600 workgroups: the atomics of every extra slab cost more than the extra workgroups hide).
+        const int ws_ld = cdivt(g.K, bt) * bt;
+        const long ws_slab = (long)cdivt(Cout, bt) * bt * ws_ld;
+        const bool use_ws = workspace && g_opt_wgrad_ws;
+        int slabs = std::max(1, (use_ws ? g_opt_wgrad_ws_blocks : g_opt_wgrad_blocks) / tiles);
+        if (use_ws) slabs = (int)std::min<long>(slabs, (long)(workspace_bytes / sizeof(float)) / ws_slab);
+        if (use_ws && slabs < 1) slabs = 1;
         g.m_per_block = std::max(1024, (int)(((long)g.M / slabs + 31) / 32 * 32));
-        dim3 grid(cdivt(g.K, bt), cdivt(Cout, bt), cdivt(g.M, g.m_per_block));
+        const int nslab = cdivt(g.M, g.m_per_block);
+        const bool ws_ok = use_ws && (size_t)nslab * ws_slab * sizeof(float) <= workspace_bytes;
+        if (ws_ok) { g.ws = reinterpret_cast<float*>(workspace); g.ws_ld = ws_ld; g.ws_slab = ws_slab; }
+        dim3 grid(cdivt(g.K, bt), cdivt(Cout, bt), nslab);
         if (bt == 128) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<128>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
         else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
+        if (ws_ok) {
+            const long total = (long)Cout * g.K;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, TR_GRID(total), dim3(256), 0, st, g.ws, nslab, ws_slab, ws_ld, g, dw);
+        }
         MFX_HIP_CHECK(hipGetLastError());
         return MFX_OK;
     }
@@ -608,9 +639,10 @@ extern "C" int mfx_conv_wgrad_nhwc_dil(const void* x, const void* dy, float* dw,
 
 extern "C" int mfx_conv_wgrad_oihw(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
                                    int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
-                                   int Cout_real, int Cin_real, int dtype, void* stream) {
+                                   int Cout_real, int Cin_real, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (Cout_real < 1 || Cout_real > Cout || Cin_real < 1 || Cin_real > Ck) return mfx_fail(MFX_ERR_ARG, "conv_wgrad_oihw: bad real channel counts");
-    return conv_wgrad_impl(x, dy, dw, B, H, W, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, Ho, Wo, Cout, ldy, dtype, 1, Cin_real, Cout_real, stream);
+    return conv_wgrad_impl(x, dy, dw, B, H, W, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, Ho, Wo, Cout, ldy, dtype, 1, Cin_real, Cout_real, stream, 1,
+                           workspace, workspace_bytes);
 }
 
 extern "C" int mfx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int kh, int kw, int mode, void* packed, void* frag,

@@ -74,7 +74,7 @@ SYMBOLS = {
     "mfx_decode_topk": (_I, [_P, ctypes.c_long, ctypes.c_long, ctypes.c_long, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mfx_conv_wgrad_nhwc": (_I, [_P, _P, _P] + [_I] * 15 + [_P]),
     "mfx_conv_wgrad_nhwc_dil": (_I, [_P, _P, _P] + [_I] * 16 + [_P]),
-    "mfx_conv_wgrad_oihw": (_I, [_P, _P, _P] + [_I] * 17 + [_P]),
+    "mfx_conv_wgrad_oihw": (_I, [_P, _P, _P] + [_I] * 17 + [_P, _S, _P]),
     "mfx_pack_conv_weight": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
     "mfx_colsum": (_I, [_P, _P, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_stats": (_I, [_P, _P, _P, ctypes.c_long, _I, _I, _P]),
