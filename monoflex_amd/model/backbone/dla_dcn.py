@@ -15,6 +15,7 @@ graph unfused through the differentiable operators of monoflex_amd.autograd: con
 fp32 activations, gradients by the HIP backward kernels.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -218,10 +219,18 @@ DLA._forward_train = _dla_forward_train
 
 
 def dla34(pretrained=True, **kwargs):
+    """DLA-34 trunk. `pretrained`: False = random init; a path = ImageNet weights from that file; True = the file named
+    by $MONOFLEX_DLA34_WEIGHTS (the reference downloads dla34-ba72cf86.pth, dla_dcn.py:333-344 -- there is no network here)."""
+    model = DLA([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], block=BasicBlock, **kwargs)
     if pretrained:
-        raise RuntimeError("dla34(pretrained=True) needs http://dl.yf.io/dla/models/imagenet/dla34-ba72cf86.pth "
-                           "(dla_dcn.py:333-344); no network here -- set MODEL.PRETRAIN False and load a checkpoint")
-    return DLA([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], block=BasicBlock, **kwargs)
+        path = pretrained if isinstance(pretrained, str) else os.environ.get("MONOFLEX_DLA34_WEIGHTS", "")
+        if not path or not os.path.exists(path):
+            raise RuntimeError("dla34(pretrained=True) needs the ImageNet weights http://dl.yf.io/dla/models/imagenet/"
+                               "dla34-ba72cf86.pth as a local file: set MONOFLEX_DLA34_WEIGHTS=<path> or MODEL.PRETRAIN "
+                               "to the path (no network in this build), or set MODEL.PRETRAIN False and load a checkpoint")
+        from ...utils.model_serialization import load_dla_imagenet
+        load_dla_imagenet(model, path)
+    return model
 
 
 def fill_up_weights(up):                                       # dla_dcn.py:372-381

@@ -283,10 +283,56 @@ def run_loss_cases():
     np.savez_compressed(os.path.join(GOLD, "loss.npz"), **out)
 
 
+
+def serialization_cases():
+    """(model keys, loaded keys) pairs for the checkpoint key-alignment golden: the HIP model's real key list against
+    (a) itself, (b) a DDP-saved copy, (c) a trunk-only ImageNet file with its classifier, (d) a file carrying the
+    pretrain-grown `backbone.base.fc.*`, (e) ambiguous suffixes (longest wins), (f) suffixes that cut a component."""
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.model.detector import KeypointDetector
+    cfg = get_cfg(os.path.join(REPO, "runs", "monoflex.yaml"))
+    cfg.MODEL.PRETRAIN = False
+    keys = list(KeypointDetector(cfg).state_dict().keys())
+    trunk = [k[len("backbone.base."):] for k in keys if k.startswith("backbone.base.")]
+    return {
+        "self": (keys, keys),
+        "ddp": (keys, ["module." + k for k in keys]),
+        "imagenet_trunk": (keys, trunk + ["fc.weight", "fc.bias"]),
+        "with_fc": (keys[:40], keys[:40] + ["backbone.base.fc.weight", "backbone.base.fc.bias"]),
+        "longest_wins": (["a.b.conv1.weight", "a.c.conv1.weight", "conv1.weight", "x.bias"],
+                         ["conv1.weight", "b.conv1.weight", "weight", "y.bias", "ias"]),
+        "cut_component": (["m.bn1.weight", "m.1.weight", "m.bn1.bias"], ["1.weight", "n1.bias"]),
+        "partial_prefix": (["p.q.w", "p.r.w"], ["module.q.w", "module.r.w", "s.w"]),
+    }
+
+
+def run_serialization_cases():
+    """Mapping produced by the reference's own loader (utils/model_serialization.py:8-78) -> tests/golden/serialization.json.gz.
+    Values are the loaded key names, so after the call each model entry names the loaded key it took (or None)."""
+    import json
+    from collections import OrderedDict
+    sys.path.insert(0, REF)
+    from utils import model_serialization as ref_ms
+    out = {}
+    for name, (mk, lk) in serialization_cases().items():
+        model_sd = OrderedDict((k, None) for k in mk)
+        loaded = ref_ms.strip_prefix_if_present(OrderedDict((k, k) for k in lk), prefix="module.")
+        stripped = {v: k for k, v in loaded.items()}             # original name -> name after the prefix strip
+        ref_ms.align_and_update_state_dicts(model_sd, loaded)
+        out[name] = {"model_keys": mk, "loaded_keys": lk, "taken": [model_sd[k] for k in mk],
+                     "stripped": [stripped[k] for k in lk]}
+    import gzip
+    with gzip.GzipFile(os.path.join(GOLD, "serialization.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(out).encode())
+    print("serialization.json.gz:", {k: sum(t is not None for t in v["taken"]) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     install_stubs()
     which = sys.argv[1:] or ["small", "full", "decode", "loss"]
+    if "serialization" in which:
+        run_serialization_cases()
     if "loss" in which:
         run_loss_cases()
     if "small" in which:
