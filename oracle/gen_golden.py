@@ -327,10 +327,143 @@ def run_serialization_cases():
     print("serialization.json.gz:", {k: sum(t is not None for t in v["taken"]) for k, v in out.items()})
 
 
+
+# ---- KITTI input pipeline + training-target encoding -----------------------------------------------
+KITTI_SIZES = [(1242, 375), (1224, 370), (1238, 374), (1241, 376)]
+KITTI_FIELDS = ["hm", "cls_ids", "target_centers", "keypoints", "keypoints_depth_mask", "dimensions", "locations", "reg_mask",
+                "reg_weight", "offset_3D", "2d_bboxes", "pad_size", "rotys", "trunc_mask", "alphas", "orientations", "gt_bboxes",
+                "occlusions", "truncations", "edge_len", "edge_indices"]
+
+
+def kitti_label_lines(seed, img_w, img_h, n_obj):
+    """KITTI-format label lines (2-decimal text, like label_2/*.txt) for seeded boxes in front of (and around) the camera:
+    in-image objects, objects whose 3D centre projects outside the image, objects straddling or behind the camera
+    plane, over-truncated small boxes (annotation filter), and classes outside DETECT_CLASSES."""
+    rs = np.random.RandomState(seed)
+    P = np.asarray(S.KITTI_P2, dtype=np.float64).reshape(3, 4)
+    dims = {"Car": (1.53, 1.63, 3.88), "Pedestrian": (1.76, 0.66, 0.84), "Cyclist": (1.74, 0.60, 1.76),
+            "Van": (2.2, 1.9, 5.1), "Truck": (3.2, 2.6, 10.0), "Misc": (1.9, 1.5, 3.5)}                # (h, w, l)
+    names = ["Car"] * 5 + ["Pedestrian"] * 2 + ["Cyclist"] * 2 + ["Van", "Truck", "Misc", "DontCare"]
+    lines = []
+    for k in range(n_obj):
+        typ = names[rs.randint(len(names))]
+        if typ == "DontCare":
+            x1, y1 = rs.uniform(0, img_w - 60), rs.uniform(0, img_h - 40)
+            lines.append("DontCare -1 -1 -10 %.2f %.2f %.2f %.2f -1 -1 -1 -1000 -1000 -1000 -10"
+                         % (x1, y1, x1 + rs.uniform(5, 50), y1 + rs.uniform(5, 30)))
+            continue
+        h, w, l = np.array(dims[typ]) * (1 + 0.1 * rs.randn(3))
+        mode = rs.randint(10)
+        z = rs.uniform(4, 60)
+        x = rs.uniform(-0.75, 0.75) * z
+        if mode == 0:
+            x = np.sign(rs.randn()) * rs.uniform(0.82, 1.0) * z          # centre projects beyond the left/right border
+        elif mode == 1:
+            z, x = rs.uniform(1.2, 3.0), rs.uniform(-2.5, 2.5)            # box straddles the camera plane
+        elif mode == 2 and k % 2 == 0:
+            z = -rs.uniform(2, 20)                                        # behind the camera
+        y = 1.65 + 0.1 * rs.randn()
+        ry = rs.uniform(-np.pi, np.pi)
+        c, s_ = np.cos(ry), np.sin(ry)
+        xs = np.array([l / 2, l / 2, -l / 2, -l / 2] * 2)
+        ys = np.array([0, 0, 0, 0, -h, -h, -h, -h])
+        zs = np.array([w / 2, -w / 2, -w / 2, w / 2] * 2)
+        X, Y, Z = c * xs + s_ * zs + x, ys + y, -s_ * xs + c * zs + z
+        Zc = np.maximum(Z, 0.1)
+        u = (P[0, 0] * X + P[0, 2] * Zc + P[0, 3]) / Zc
+        v = (P[1, 1] * Y + P[1, 2] * Zc + P[1, 3]) / Zc
+        full = np.array([u.min(), v.min(), u.max(), v.max()])
+        box = np.array([max(full[0], 0), max(full[1], 0), min(full[2], img_w - 1), min(full[3], img_h - 1)])
+        if box[2] - box[0] < 1 or box[3] - box[1] < 1:                    # not visible at all: KITTI would not label it
+            box = np.array([rs.uniform(0, img_w - 30), rs.uniform(0, img_h - 30), 0, 0])
+            box[2:] = box[:2] + rs.uniform(3, 25, 2)
+        area_full = max((full[2] - full[0]) * (full[3] - full[1]), 1e-6)
+        trunc = float(np.clip(1 - (box[2] - box[0]) * (box[3] - box[1]) / area_full, 0, 1))
+        if mode == 3:
+            trunc = 0.95                                                  # annotation filter: dropped when the box is <= 20 px
+        alpha = ry - np.arctan2(x, z)
+        lines.append("%s %.2f %d %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f"
+                     % (typ, trunc, rs.randint(0, 4), alpha, box[0], box[1], box[2], box[3], h, w, l, x, y, z, ry))
+    return lines
+
+
+def kitti_cases():
+    """(name, image size, #label lines, flip, label seed, image seed)."""
+    cases = []
+    for i in range(12):
+        w, h = KITTI_SIZES[i % 4]
+        n = [6, 0, 14, 28, 9, 1, 40, 11, 3, 22, 8, 17][i]
+        cases.append(("s%02d" % i, w, h, n, i % 2 == 1 or i == 6, 500 + i, 900 + i))
+    return cases
+
+
+def run_kitti_cases():
+    """Runs the reference's KITTIDataset.__getitem__ (+ its flip augmentation, transforms) on a generated KITTI directory
+    -> tests/golden/kitti_encode.npz. torchvision is absent: `data.transforms.transforms.F` is a two-function stand-in with
+    torchvision's documented semantics (to_tensor: HWC uint8 -> CHW float32 / 255; normalize: (x - mean) / std) -- the
+    image half of the fixture is pinned to that, not to torchvision itself."""
+    import random
+    from PIL import Image
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    np.int = int                                                        # kitti.py:434,436 under numpy >= 1.24
+    from config import cfg
+    cfg.merge_from_file(os.path.join(REF, "runs", "monoflex.yaml"))
+    import data.transforms.transforms as T
+    T.F = types.SimpleNamespace(
+        to_tensor=lambda img: torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255),
+        normalize=lambda t, mean, std: (t - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1))
+    from data.transforms import build_transforms
+    from data.datasets.kitti import KITTIDataset
+    from data.augmentations.augmentations import Compose, RandomHorizontallyFlip
+    root = tempfile.mkdtemp(prefix="kitti_fake_")
+    for d in ("image_2", "label_2", "calib", "ImageSets"):
+        os.makedirs(os.path.join(root, d))
+    cases = kitti_cases()
+    P = np.asarray(S.KITTI_P2, dtype=np.float64).reshape(-1)
+    out = dict(names=np.array([c[0] for c in cases]))
+    for i, (name, w, h, n, flip, lseed, iseed) in enumerate(cases):
+        img = np.random.RandomState(iseed).randint(0, 256, (h, w, 3)).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(root, "image_2", "%06d.png" % i))
+        lines = kitti_label_lines(lseed, w, h, n)
+        with open(os.path.join(root, "label_2", "%06d.txt" % i), "w") as f:
+            f.write("".join(l + "\n" for l in lines))
+        with open(os.path.join(root, "calib", "%06d.txt" % i), "w") as f:
+            f.write("P2: " + " ".join("%.12e" % v for v in P) + "\n")
+            f.write("P3: " + " ".join("%.12e" % v for v in P) + "\n")
+            f.write("R0_rect: 1 0 0 0 1 0 0 0 1\nTr_velo_to_cam: 1 0 0 0 0 1 0 0 0 0 1 0\n")
+        out[name + "_labels"] = np.array("\n".join(lines))
+        out[name + "_meta"] = np.array([w, h, int(flip), iseed])
+    with open(os.path.join(root, "ImageSets", "train.txt"), "w") as f:
+        f.write("".join("%06d\n" % i for i in range(len(cases))))
+    ds = KITTIDataset(cfg, root, is_train=True, transforms=build_transforms(cfg, True), augment=True)
+    kept = []
+    for i, (name, w, h, n, flip, lseed, iseed) in enumerate(cases):
+        ds.augmentation = Compose([RandomHorizontallyFlip(1.0 if flip else 0.0)])
+        random.seed(i)
+        img, target, idx = ds[i]
+        assert idx == "%06d" % i and tuple(img.shape) == (3, 384, 1280)
+        for k in KITTI_FIELDS:
+            out[name + "_" + k] = np.asarray(target.get_field(k))
+        out[name + "_P"] = np.asarray(target.get_field("calib").P, dtype=np.float64)
+        cs = checksum(img)
+        out[name + "_img_sum"] = np.array([cs["sum"], cs["abssum"], cs["sq"]])
+        out[name + "_img_idx"], out[name + "_img_samples"] = cs["idx"], cs["samples"]
+        kept.append(int(target.get_field("reg_mask").sum()))
+    out["meta"] = np.array("reference KITTIDataset.__getitem__ (data/datasets/kitti.py) + RandomHorizontallyFlip + "
+                           "ToTensor/Normalize stand-in; numpy %s; P2 = monoflex_amd.synthetic.KITTI_P2" % np.__version__)
+    np.savez_compressed(os.path.join(GOLD, "kitti_encode.npz"), **out)
+    import shutil
+    shutil.rmtree(root)
+    print("kitti_encode.npz: objects kept per sample", kept)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     install_stubs()
     which = sys.argv[1:] or ["small", "full", "decode", "loss"]
+    if "kitti" in which:
+        run_kitti_cases()
     if "serialization" in which:
         run_serialization_cases()
     if "loss" in which:
