@@ -267,6 +267,59 @@ int mfx_dcn_backward_nhwc_bf16(const void* x, const float* offmask, const float*
                                int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- (4) input pipeline: KITTI sample -> network input + training targets, on the device ------------------------------
+ * Replaces the per-sample numpy/PIL work of the reference's dataset (data/datasets/kitti.py:231-525 __getitem__,
+ * data/augmentations/augmentations.py:33-78 flip, data/transforms/transforms.py:15-31 ToTensor+Normalize,
+ * model/heatmap_coder.py:37-124 Gaussian rasterisation). The host only parses the text files. */
+
+/* Batch of raw samples -> every field of the reference's training `target` (kitti.py:496-523), batch-stacked.
+ * records: one row per object of the DETECT_CLASSES, in label order (kitti_utils.py:64-92):
+ *   [cls_id, truncation, occlusion, xmin, ymin, xmax, ymax, h, w, l, tx, ty, tz, ry]  (float64, the parsed text values)
+ * Arithmetic follows the reference's dtypes: float64 throughout, float32 where its numpy code is float32 (location,
+ * label 2D box and everything derived from it). Objects the reference skips leave all-zero rows. All outputs are
+ * fully overwritten. status[b] != 0 flags inputs on which the reference raises (bit 0: n_obj > max_objs, bit 1: truncated
+ * object whose 2D-box centre lies outside the image, bit 2: no border intersection, bit 3: both boundary radii > 0). */
+typedef struct {
+  const double* records;     /* (B, max_objs, 14) */
+  const int32_t* n_obj;      /* (B) */
+  const double* P;           /* (B, 3, 4) camera matrix as read from calib (kitti_utils.py:186-187) */
+  const int32_t* img_wh;     /* (B, 2) original image width, height */
+  const int32_t* flip;       /* (B) 1 = apply the horizontal flip augmentation */
+  float* hm;                 /* (B, num_classes, out_h, out_w) */
+  int32_t* cls_ids;          /* (B, max_objs) */
+  int32_t* target_centers;   /* (B, max_objs, 2) */
+  float* keypoints;          /* (B, max_objs, 10, 3) */
+  float* keypoints_depth_mask; /* (B, max_objs, 3) */
+  float* dimensions;         /* (B, max_objs, 3) l, h, w */
+  float* locations;          /* (B, max_objs, 3) */
+  uint8_t* reg_mask;         /* (B, max_objs) */
+  float* reg_weight;         /* (B, max_objs) */
+  float* offset_3D;          /* (B, max_objs, 2) */
+  float* bboxes;             /* (B, max_objs, 4) field "2d_bboxes" */
+  float* gt_bboxes;          /* (B, max_objs, 4) */
+  float* rotys;              /* (B, max_objs) */
+  uint8_t* trunc_mask;       /* (B, max_objs) */
+  float* alphas;             /* (B, max_objs) */
+  float* orientations;       /* (B, max_objs, 8) multi-bin: 4 flags + 4 residuals */
+  double* occlusions;        /* (B, max_objs) */
+  double* truncations;       /* (B, max_objs) */
+  int64_t* pad_size;         /* (B, 2) */
+  int64_t* edge_indices;     /* (B, 2*(out_w+out_h), 2) */
+  int64_t* edge_len;         /* (B) point count - 1 (kitti.py:284) */
+  double* P_out;             /* (B, 3, 4) P after the flip */
+  int32_t* heat_radius;      /* (B, max_objs, 4) auxiliary: rx, ry, circular(1)/boundary(0), drawn(1) */
+  int32_t* status;           /* (B) */
+  int32_t B, max_objs, in_w, in_h, down, num_classes;
+  double filter_trunc, filter_size;   /* DATASETS.FILTER_ANNOS; filter_trunc < 0 disables the filter */
+  double edge_ratio;                  /* INPUT.HEATMAP_RATIO */
+} mfx_kitti_desc;
+int mfx_kitti_encode_targets(const mfx_kitti_desc* d, void* stream);
+
+/* uint8 RGB images of different sizes (packed back to back, HWC) -> (B,3,in_h,in_w) float32 NCHW: optional left-right
+ * flip, centre zero padding, /255, (x-mean)/std; the padding is zero BEFORE normalisation (kitti.py:218-228). */
+int mfx_kitti_preprocess_u8(const uint8_t* pixels, const int64_t* offsets, const int32_t* img_wh, const int32_t* flip,
+                            float* out, int B, int in_w, int in_h, const float* mean3, const float* std3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

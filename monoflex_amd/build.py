@@ -13,8 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libmonoflex_hip.so")
-SOURCES = ["capi.hip", "conv_kernels.hip", "conv_halo.hip", "misc_kernels.hip", "stem.hip", "heads.hip", "decode.hip", "dcn_wave.hip", "dcn_patch.hip", "dcn_ext.hip", "dcn_bwd.hip", "train_kernels.hip"]
+SOURCES = ["capi.hip", "conv_kernels.hip", "conv_halo.hip", "misc_kernels.hip", "stem.hip", "heads.hip", "decode.hip", "dcn_wave.hip", "dcn_patch.hip", "dcn_ext.hip", "dcn_bwd.hip", "train_kernels.hip", "kitti_encode.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# the target encoder reproduces numpy's twice-rounded float32/float64 arithmetic: no fused multiply-add there
+EXTRA_FLAGS = {"kitti_encode.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc():
@@ -28,7 +30,7 @@ def _stamp():
             if fn.endswith((".hip", ".h")):
                 with open(os.path.join(root, fn), "rb") as f:
                     h.update(fn.encode() + f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
@@ -42,7 +44,7 @@ def build_lib(force=False, verbose=False):
 
     def compile_one(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))

@@ -121,7 +121,8 @@ def _defaults():
     C.INPUT = CfgNode(dict(
         HEIGHT_TRAIN=384, WIDTH_TRAIN=1280, HEIGHT_TEST=384, WIDTH_TEST=1280,
         PIXEL_MEAN=[0.485, 0.456, 0.406], PIXEL_STD=[0.229, 0.224, 0.225], TO_BGR=False,
-        MODIFY_ALPHA=False, HEATMAP_CENTER='3D', ADJUST_BOUNDARY_HEATMAP=False,
+        MODIFY_ALPHA=False, USE_APPROX_CENTER=False, HEATMAP_CENTER='3D', ADJUST_DIM_HEATMAP=False, ADJUST_BOUNDARY_HEATMAP=False,
+        HEATMAP_RATIO=0.5, ELLIP_GAUSSIAN=False, IGNORE_DONT_CARE=False, ALLOW_OUTSIDE_CENTER=False,
         KEYPOINT_VISIBLE_MODIFY=False, APPROX_3D_CENTER='intersect',
         ORIENTATION='head-axis', ORIENTATION_BIN_SIZE=4, AUG_PARAMS=[[0.5]],
     ))

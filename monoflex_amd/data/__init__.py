@@ -1,0 +1,4 @@
+"""Input pipeline (reference data/): KITTI files -> raw samples on the host, everything numeric on the device."""
+from .collate_batch import DeviceBatchCollator, DeviceLoader   # noqa: F401
+from .datasets.kitti import KITTIDataset                  # noqa: F401
+from .encode import encode_targets, preprocess_images     # noqa: F401

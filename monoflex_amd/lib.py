@@ -51,6 +51,15 @@ class HeadsDesc(ctypes.Structure):
                 ("dtype", c_int), ("planar_c", c_int), ("ch_off", c_int * 16), ("c_out", c_int * 16)]
 
 
+class KittiDesc(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "records", "n_obj", "P", "img_wh", "flip", "hm", "cls_ids", "target_centers", "keypoints", "keypoints_depth_mask",
+        "dimensions", "locations", "reg_mask", "reg_weight", "offset_3D", "bboxes", "gt_bboxes", "rotys", "trunc_mask", "alphas",
+        "orientations", "occlusions", "truncations", "pad_size", "edge_indices", "edge_len", "P_out", "heat_radius", "status")] + \
+        [(n, c_int) for n in ("B", "max_objs", "in_w", "in_h", "down", "num_classes")] + \
+        [(n, ctypes.c_double) for n in ("filter_trunc", "filter_size", "edge_ratio")]
+
+
 # every symbol include/monoflex_hip.h declares: name -> (restype, argtypes)
 _P, _I, _F, _S = c_void_p, c_int, c_float, c_size_t
 SYMBOLS = {
@@ -89,6 +98,8 @@ SYMBOLS = {
     "mfx_dcn_backward_nhwc_workspace_bytes": (_S, [_I] * 10),
     "mfx_dcn_backward_nhwc": (_I, [_P] * 8 + [_I] * 10 + [_P, _S, _P]),
     "mfx_dcn_backward_nhwc_bf16": (_I, [_P] * 8 + [_I] * 10 + [_P, _S, _P]),
+    "mfx_kitti_encode_targets": (_I, [ctypes.POINTER(KittiDesc), _P]),
+    "mfx_kitti_preprocess_u8": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P]),
     "mfx_decode_boxes": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P]),
 }
 

@@ -217,3 +217,58 @@ def synthetic_train_target(seed, out_w=320, out_h=96, down_ratio=4, n_obj=None, 
         f["hm"][c] = np.maximum(f["hm"][c], gauss)
     base.update(f)
     return base
+
+
+# ------------------------------------------------------------------------------------------------
+# KITTI label text for the input-pipeline tests and benchmarks (data/datasets/kitti.py consumes label_2/*.txt lines).
+# ------------------------------------------------------------------------------------------------
+def synthetic_kitti_labels(seed, img_w, img_h, n_obj):
+    """KITTI-format label lines (2-decimal text, like label_2/*.txt) for seeded boxes in front of (and around) the camera:
+    in-image objects, objects whose 3D centre projects outside the image, objects straddling or behind the camera
+    plane, over-truncated small boxes (annotation filter), and classes outside DETECT_CLASSES."""
+    rs = np.random.RandomState(seed)
+    P = np.asarray(KITTI_P2, dtype=np.float64).reshape(3, 4)
+    dims = {"Car": (1.53, 1.63, 3.88), "Pedestrian": (1.76, 0.66, 0.84), "Cyclist": (1.74, 0.60, 1.76),
+            "Van": (2.2, 1.9, 5.1), "Truck": (3.2, 2.6, 10.0), "Misc": (1.9, 1.5, 3.5)}                # (h, w, l)
+    names = ["Car"] * 5 + ["Pedestrian"] * 2 + ["Cyclist"] * 2 + ["Van", "Truck", "Misc", "DontCare"]
+    lines = []
+    for k in range(n_obj):
+        typ = names[rs.randint(len(names))]
+        if typ == "DontCare":
+            x1, y1 = rs.uniform(0, img_w - 60), rs.uniform(0, img_h - 40)
+            lines.append("DontCare -1 -1 -10 %.2f %.2f %.2f %.2f -1 -1 -1 -1000 -1000 -1000 -10"
+                         % (x1, y1, x1 + rs.uniform(5, 50), y1 + rs.uniform(5, 30)))
+            continue
+        h, w, l = np.array(dims[typ]) * (1 + 0.1 * rs.randn(3))
+        mode = rs.randint(10)
+        z = rs.uniform(4, 60)
+        x = rs.uniform(-0.75, 0.75) * z
+        if mode == 0:
+            x = np.sign(rs.randn()) * rs.uniform(0.82, 1.0) * z          # centre projects beyond the left/right border
+        elif mode == 1:
+            z, x = rs.uniform(1.2, 3.0), rs.uniform(-2.5, 2.5)            # box straddles the camera plane
+        elif mode == 2 and k % 2 == 0:
+            z = -rs.uniform(2, 20)                                        # behind the camera
+        y = 1.65 + 0.1 * rs.randn()
+        ry = rs.uniform(-np.pi, np.pi)
+        c, s_ = np.cos(ry), np.sin(ry)
+        xs = np.array([l / 2, l / 2, -l / 2, -l / 2] * 2)
+        ys = np.array([0, 0, 0, 0, -h, -h, -h, -h])
+        zs = np.array([w / 2, -w / 2, -w / 2, w / 2] * 2)
+        X, Y, Z = c * xs + s_ * zs + x, ys + y, -s_ * xs + c * zs + z
+        Zc = np.maximum(Z, 0.1)
+        u = (P[0, 0] * X + P[0, 2] * Zc + P[0, 3]) / Zc
+        v = (P[1, 1] * Y + P[1, 2] * Zc + P[1, 3]) / Zc
+        full = np.array([u.min(), v.min(), u.max(), v.max()])
+        box = np.array([max(full[0], 0), max(full[1], 0), min(full[2], img_w - 1), min(full[3], img_h - 1)])
+        if box[2] - box[0] < 1 or box[3] - box[1] < 1:                    # not visible at all: KITTI would not label it
+            box = np.array([rs.uniform(0, img_w - 30), rs.uniform(0, img_h - 30), 0, 0])
+            box[2:] = box[:2] + rs.uniform(3, 25, 2)
+        area_full = max((full[2] - full[0]) * (full[3] - full[1]), 1e-6)
+        trunc = float(np.clip(1 - (box[2] - box[0]) * (box[3] - box[1]) / area_full, 0, 1))
+        if mode == 3:
+            trunc = 0.95                                                  # annotation filter: dropped when the box is <= 20 px
+        alpha = ry - np.arctan2(x, z)
+        lines.append("%s %.2f %d %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f"
+                     % (typ, trunc, rs.randint(0, 4), alpha, box[0], box[1], box[2], box[3], h, w, l, x, y, z, ry))
+    return lines
