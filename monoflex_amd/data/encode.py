@@ -93,22 +93,37 @@ def pack_inputs(records, Ps, sizes, flips, params):
                 img_wh=np.asarray(sizes, dtype=np.int32).reshape(B, 2).copy(), flip=np.asarray(flips, dtype=np.int32).reshape(B).copy())
 
 
+def _align16(n):
+    return (n + 15) // 16 * 16
+
+
 def _upload(arrays, device):
     """Several small numpy arrays -> one pinned buffer -> one async copy; returns device views in the original dtypes."""
-    total = sum((a.nbytes + 15) // 16 * 16 for a in arrays.values())
+    total = sum(_align16(a.nbytes) for a in arrays.values())
     host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
-    views, off = {}, 0
+    hn, views, off = host.numpy(), {}, 0
     for k, a in arrays.items():
-        n = a.nbytes
-        host[off:off + n] = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
+        hn[off:off + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
         views[k] = (off, a.shape, a.dtype)
-        off += (n + 15) // 16 * 16
+        off += _align16(a.nbytes)
     dev = host.to(device, non_blocking=True)
-    out = {}
-    for k, (o, shape, dt) in views.items():
-        n = int(np.prod(shape)) * np.dtype(dt).itemsize
-        out[k] = dev[o:o + n].view(getattr(torch, np.dtype(dt).name)).view(*shape)
-    return out
+    return {k: _view(dev, o, shape, getattr(torch, np.dtype(dt).name)) for k, (o, shape, dt) in views.items()}
+
+
+def _view(buf, offset, shape, dtype):
+    n = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+    return buf[offset:offset + n].view(dtype).view(*shape)
+
+
+def _alloc_outputs(B, dims, device):
+    """All output fields as views of one device allocation (one allocator call per batch instead of 24)."""
+    specs, total = {}, 0
+    for name, (_, shape, dt) in TARGET_FIELDS.items():
+        full = (B,) + tuple(dims.get(s, s) for s in shape)
+        specs[name] = (total, full, dt)
+        total += _align16(int(np.prod(full, dtype=np.int64)) * torch.empty((), dtype=dt).element_size())
+    buf = torch.empty(total, dtype=torch.uint8, device=device)
+    return {name: _view(buf, o, full, dt) for name, (o, full, dt) in specs.items()}
 
 
 def encode_targets(records, Ps, sizes, flips, params, device, check=True):
@@ -120,9 +135,7 @@ def encode_targets(records, Ps, sizes, flips, params, device, check=True):
     lib = L.load()
     inp = _upload(pack_inputs(records, Ps, sizes, flips, params), device)
     B, dims = len(records), params.dims()
-    out = {}
-    for name, (_, shape, dt) in TARGET_FIELDS.items():
-        out[name] = torch.empty((B,) + tuple(dims.get(s, s) for s in shape), dtype=dt, device=device)
+    out = _alloc_outputs(B, dims, device)
     d = L.KittiDesc()
     for k, t in inp.items():
         setattr(d, k, t.data_ptr())
@@ -164,10 +177,11 @@ def preprocess_images(frames, flips, params, device, mean=(0.485, 0.456, 0.406),
                              % (b, f.shape[1], f.shape[0], params.in_w, params.in_h))
         sizes[b] = (f.shape[1], f.shape[0])
         offsets[b] = total
-        total += (f.size + 15) // 16 * 16
+        total += _align16(f.size)
     host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+    hn = host.numpy()
     for b, f in enumerate(frames):
-        host[offsets[b]:offsets[b] + f.size] = torch.from_numpy(np.ascontiguousarray(f).reshape(-1))
+        hn[offsets[b]:offsets[b] + f.size] = f.reshape(-1)
     pixels = host.to(device, non_blocking=True)
     meta = _upload(dict(offsets=offsets, img_wh=sizes, flip=np.asarray(flips, dtype=np.int32).reshape(B).copy()), device)
     out = torch.empty((B, 3, params.in_h, params.in_w), dtype=torch.float32, device=device)
