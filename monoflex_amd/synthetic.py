@@ -222,7 +222,7 @@ def synthetic_train_target(seed, out_w=320, out_h=96, down_ratio=4, n_obj=None, 
 # ------------------------------------------------------------------------------------------------
 # KITTI label text for the input-pipeline tests and benchmarks (data/datasets/kitti.py consumes label_2/*.txt lines).
 # ------------------------------------------------------------------------------------------------
-def synthetic_kitti_labels(seed, img_w, img_h, n_obj):
+def synthetic_kitti_labels(seed, img_w, img_h, n_obj, z_range=(4, 60), occl_max=3):
     """KITTI-format label lines (2-decimal text, like label_2/*.txt) for seeded boxes in front of (and around) the camera:
     in-image objects, objects whose 3D centre projects outside the image, objects straddling or behind the camera
     plane, over-truncated small boxes (annotation filter), and classes outside DETECT_CLASSES."""
@@ -241,7 +241,7 @@ def synthetic_kitti_labels(seed, img_w, img_h, n_obj):
             continue
         h, w, l = np.array(dims[typ]) * (1 + 0.1 * rs.randn(3))
         mode = rs.randint(10)
-        z = rs.uniform(4, 60)
+        z = rs.uniform(*z_range)
         x = rs.uniform(-0.75, 0.75) * z
         if mode == 0:
             x = np.sign(rs.randn()) * rs.uniform(0.82, 1.0) * z          # centre projects beyond the left/right border
@@ -270,5 +270,37 @@ def synthetic_kitti_labels(seed, img_w, img_h, n_obj):
             trunc = 0.95                                                  # annotation filter: dropped when the box is <= 20 px
         alpha = ry - np.arctan2(x, z)
         lines.append("%s %.2f %d %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f"
-                     % (typ, trunc, rs.randint(0, 4), alpha, box[0], box[1], box[2], box[3], h, w, l, x, y, z, ry))
+                     % (typ, trunc, rs.randint(0, occl_max + 1), alpha, box[0], box[1], box[2], box[3], h, w, l, x, y, z, ry))
     return lines
+
+
+def synthetic_detections(seed, label_lines, img_w, img_h, recall=0.8, n_false=3):
+    """(N,14) float32 detection rows in the detector's output format [cls, alpha, x1, y1, x2, y2, h, w, l, x, y, z, ry,
+    score] (detector_infer.py:215-218) derived from KITTI label lines: most labelled Car/Pedestrian/Cyclist objects are
+    detected with perturbed boxes, a few are missed or mis-classified, and some false positives are added."""
+    rs = np.random.RandomState(seed)
+    ids = {"Car": 0, "Pedestrian": 1, "Cyclist": 2}
+    rows = []
+    for line in label_lines:
+        d = line.split(" ")
+        if d[0] not in ids or rs.rand() > recall:
+            continue
+        v = np.array([float(x) for x in d[1:15]])
+        box, hwl, loc, ry = v[3:7].copy(), v[7:10].copy(), v[10:13].copy(), v[13]
+        if loc[2] <= 0:
+            continue
+        q = rs.choice([0.3, 1.0, 3.0])                                    # detection quality: tight, typical, sloppy
+        box += rs.randn(4) * 2.0 * q
+        hwl *= 1 + 0.04 * q * rs.randn(3)
+        loc += rs.randn(3) * np.array([0.05, 0.03, 0.02 * loc[2]]) * q
+        ry = ry + 0.08 * q * rs.randn()
+        cls = ids[d[0]] if rs.rand() > 0.05 else int(rs.randint(0, 3))
+        alpha = ry - np.arctan2(loc[0], loc[2])
+        rows.append([cls, alpha, box[0], box[1], box[2], box[3], hwl[0], hwl[1], hwl[2], loc[0], loc[1], loc[2], ry, rs.uniform(0.2, 1.0)])
+    for _ in range(int(rs.randint(0, n_false + 1))):
+        cls = int(rs.randint(0, 3))
+        x1, y1 = rs.uniform(0, img_w - 80), rs.uniform(0, img_h - 60)
+        z = rs.uniform(5, 60)
+        rows.append([cls, rs.uniform(-3, 3), x1, y1, x1 + rs.uniform(10, 80), y1 + rs.uniform(10, 60), 1.5, 1.6, 3.9,
+                     rs.uniform(-0.5, 0.5) * z, 1.7, z, rs.uniform(-3, 3), rs.uniform(0.2, 0.7)])
+    return np.asarray(rows, dtype=np.float32).reshape(-1, 14)

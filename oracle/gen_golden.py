@@ -406,10 +406,150 @@ def run_kitti_cases():
     print("kitti_encode.npz: objects kept per sample", kept)
 
 
+
+# ---- KITTI result files + AP evaluation -------------------------------------------------------------
+def install_numba_emulation():
+    """numba is absent: `numba.jit` becomes the identity (the reference's CPU loops run as plain Python) and `numba.cuda`
+    a small SIMT emulator -- every CUDA thread of a block is a Python thread, `syncthreads` a barrier, `shared.array` one
+    array per block and call site, `local.array` a fresh array -- so the reference's own rotate_iou.py kernels execute
+    unmodified. Arithmetic then follows numpy's scalar rules (float32 op python-float stays float32) where numba would
+    widen to float64: overlaps agree with a real numba run to float32 round-off, which the fixture's metadata states."""
+    import threading
+
+    def jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+    numba = types.ModuleType("numba")
+    numba.jit = jit
+    numba.float32, numba.float64, numba.int32, numba.int64 = np.float32, np.float64, np.int32, np.int64
+    tls = threading.local()
+
+    class Dim:
+        def __init__(self, which):
+            self.which = which
+        x = property(lambda self: getattr(tls, self.which)[0])
+        y = property(lambda self: getattr(tls, self.which)[1])
+
+    class Dev(np.ndarray):
+        def copy_to_host(self, dst, stream=None):
+            dst[...] = self
+
+    class Stream:
+        def auto_synchronize(self):
+            import contextlib
+            return contextlib.nullcontext()
+
+    class Kernel:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def __getitem__(self, cfg):
+            grid, block = cfg[0], cfg[1]
+            grid = tuple(grid) if isinstance(grid, (tuple, list)) else (grid,)
+            grid = grid + (1,) * (2 - len(grid))
+
+            def launch(*args):
+                for bx in range(int(grid[0])):
+                    for by in range(int(grid[1])):
+                        shared, barrier, errs = [], threading.Barrier(block), []
+
+                        def run(tx):
+                            tls.blockIdx, tls.threadIdx, tls.shared, tls.nshared, tls.barrier = (bx, by), (tx, 0), shared, 0, barrier
+                            try:
+                                self.fn(*args)
+                            except BaseException as e:          # noqa: BLE001
+                                errs.append(e); barrier.abort()
+                        ts = [threading.Thread(target=run, args=(t,)) for t in range(block)]
+                        [t.start() for t in ts]; [t.join() for t in ts]
+                        if errs:
+                            raise errs[0]
+            return launch
+
+    lock = threading.Lock()
+
+    def shared_array(shape, dtype):
+        with lock:
+            if tls.nshared == len(tls.shared):
+                tls.shared.append(np.zeros(shape, dtype=dtype))
+            a = tls.shared[tls.nshared]
+        tls.nshared += 1
+        return a
+
+    def cuda_jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return Kernel(a[0])
+        device = k.get("device", False)
+        return (lambda f: f) if device else (lambda f: Kernel(f))
+    cuda = types.ModuleType("numba.cuda")
+    cuda.jit = cuda_jit
+    cuda.local = types.SimpleNamespace(array=lambda shape, dtype: np.zeros(shape, dtype=dtype))
+    cuda.shared = types.SimpleNamespace(array=shared_array)
+    cuda.syncthreads = lambda: tls.barrier.wait()
+    cuda.blockIdx, cuda.threadIdx = Dim("blockIdx"), Dim("threadIdx")
+    cuda.select_device = lambda i: None
+    cuda.stream = lambda: Stream()
+    cuda.to_device = lambda arr, stream=None: np.array(arr).view(Dev)
+    numba.cuda = cuda
+    sys.modules["numba"], sys.modules["numba.cuda"] = numba, cuda
+
+
+def eval_cases():
+    """(image size, label seed, #label lines, detection seed) per image of the evaluation fixture."""
+    return [((1242, 375), 700 + i, [10, 14, 6, 12, 9, 16, 0, 11, 13, 8, 15, 12][i], 800 + i) for i in range(12)]
+
+
+def run_eval_cases():
+    """The reference's result writer (evaluate.py:34-54) and its R40 / R11 evaluation (evaluate.py:17-32, eval.py,
+    rotate_iou.py, kitti_common.py:294-349) on a generated label_2 folder and synthetic detections
+    -> tests/golden/kitti_eval.npz."""
+    install_numba_emulation()
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    from data.datasets.evaluation.kitti_object_eval_python import evaluate as ref_eval
+    root = tempfile.mkdtemp(prefix="kitti_eval_")
+    label_dir, result_dir = os.path.join(root, "label_2"), os.path.join(root, "data")
+    os.makedirs(label_dir); os.makedirs(result_dir)
+    out = {}
+    cases = eval_cases()
+    for i, ((w, h), lseed, n, dseed) in enumerate(cases):
+        lines = S.synthetic_kitti_labels(lseed, w, h, n, z_range=(5, 38), occl_max=1)    # mostly easy/moderate objects
+        with open(os.path.join(label_dir, "%06d.txt" % i), "w") as f:
+            f.write("\n".join(lines))
+        det = S.synthetic_detections(dseed, lines, w, h, recall=0.9) if i != 3 else np.zeros((0, 14), np.float32)    # one image without detections
+        ref_eval.generate_kitti_3d_detection(torch.from_numpy(det), os.path.join(result_dir, "%06d.txt" % i))
+        out["labels_%d" % i] = np.array("\n".join(lines))
+        out["det_%d" % i] = det
+        out["txt_%d" % i] = np.array(open(os.path.join(result_dir, "%06d.txt" % i)).read())
+    split = os.path.join(root, "val.txt")
+    with open(split, "w") as f:
+        f.write("".join("%06d\n" % i for i in range(len(cases))))
+    from data.datasets.evaluation.kitti_object_eval_python import kitti_common as ref_kc
+    from data.datasets.evaluation.kitti_object_eval_python import eval as ref_ev
+    dt_annos, gt_annos = ref_kc.get_label_annos(result_dir), ref_kc.get_label_annos(label_dir, list(range(len(cases))))
+    for m in range(3):                                                  # per-image (num_dt, num_gt) overlaps: bbox, bev, 3d
+        ovs = ref_ev.calculate_iou_partly(dt_annos, gt_annos, m)[0]
+        for i, o in enumerate(ovs):
+            out["ov%d_%d" % (m, i)] = np.asarray(o, dtype=np.float64)
+    for metric in ("R40", "R11"):
+        result, ret = ref_eval.evaluate(label_dir, result_dir, split, current_class=["Car", "Pedestrian", "Cyclist"], metric=metric)
+        out["result_" + metric] = np.array(result)
+        out["keys_" + metric] = np.array(sorted(ret.keys()))
+        out["values_" + metric] = np.array([float(ret[k]) for k in sorted(ret.keys())])
+        print(metric, {k: round(float(v), 3) for k, v in sorted(ret.items()) if "moderate" in k})
+    out["meta"] = np.array("reference evaluate.py/eval.py/rotate_iou.py/kitti_common.py executed with numba emulated in Python "
+                           "(identity jit; SIMT emulation of numba.cuda; numpy scalar arithmetic); numpy %s" % np.__version__)
+    np.savez_compressed(os.path.join(GOLD, "kitti_eval.npz"), **out)
+    import shutil
+    shutil.rmtree(root)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     install_stubs()
     which = sys.argv[1:] or ["small", "full", "decode", "loss"]
+    if "eval" in which:
+        run_eval_cases()
     if "kitti" in which:
         run_kitti_cases()
     if "serialization" in which:
