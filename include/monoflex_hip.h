@@ -320,6 +320,46 @@ int mfx_kitti_encode_targets(const mfx_kitti_desc* d, void* stream);
 int mfx_kitti_preprocess_u8(const uint8_t* pixels, const int64_t* offsets, const int32_t* img_wh, const int32_t* flip,
                             float* out, int B, int in_w, int in_h, const float* mean3, const float* std3, void* stream);
 
+/* ---- (5) KITTI AP evaluation on the device -----------------------------------------------------------------------------
+ * Replaces the numba CPU loops and the numba.cuda rotated-IoU kernel of the reference's evaluator
+ * (data/datasets/evaluation/kitti_object_eval_python/eval.py:27-286,448-570, rotate_iou.py:17-333). The host parses the
+ * label / result text, sorts nothing and decides nothing: it ships one record per box, calls the four entries in order and
+ * turns the accumulated (tp, fp, fn, similarity) table into precision curves and AP numbers.
+ *
+ * Box record (MFX_EVAL_REC doubles): [name code, truncated, occluded, alpha, x1, y1, x2, y2, l, h, w, x, y, z, ry, score].
+ * Name codes: 0 car, 1 pedestrian, 2 cyclist, 3 van, 4 person_sitting, 5 truck, 6 DontCare, 7 anything else.
+ * Images are ragged: boxes of image b are rows [off[b], off[b+1]) of `gt` / `dt`; its overlap block starts at pair_off[b]
+ * and is laid out [detection][ground truth]. At most 64 detections per image.
+ * A "combination" c indexes (class m, difficulty l, metric, overlap set k) as ((m*3 + l)*3 + metric)*num_k + k. */
+#define MFX_EVAL_REC 16
+#define MFX_EVAL_PTS 41
+typedef struct {
+  const double* gt;            /* (n_gt, 16) */
+  const double* dt;            /* (n_dt, 16) */
+  const int32_t* gt_off;       /* (B+1) */
+  const int32_t* dt_off;       /* (B+1) */
+  const int64_t* pair_off;     /* (B+1) */
+  const int32_t* classes;      /* (num_classes) evaluated name codes, e.g. {0,1,2} */
+  const double* min_overlaps;  /* (num_k, 3 metrics, num_classes) */
+  double* overlaps;            /* (3, n_pairs): bbox IoU, BEV rotated IoU, 3D IoU */
+  double* tp_scores;           /* (n_comb, n_gt): score of the detection matched to that ground truth, -1 if none */
+  int32_t* num_valid_gt;       /* (num_classes, 3) */
+  double* thresholds;          /* (n_comb, 41) */
+  int32_t* num_thresholds;     /* (n_comb) */
+  double* pr;                  /* (n_comb, 41, 4): tp, fp, fn, orientation similarity; zeroed by mfx_kitti_eval_match_pass1 */
+  int32_t B, n_gt, n_dt, num_classes, num_k, compute_aos;
+  int64_t n_pairs;
+} mfx_kitti_eval_desc;
+/* 1: all three overlap matrices (eval.py:83-153, rotate_iou.py). */
+int mfx_kitti_eval_overlaps(const mfx_kitti_eval_desc* d, void* stream);
+/* 2: matching without score threshold -> tp_scores, num_valid_gt (eval.py:497-512 first loop); zeroes pr. */
+int mfx_kitti_eval_match_pass1(const mfx_kitti_eval_desc* d, void* stream);
+/* 3: `sorted_scores` = tp_scores sorted descending per combination (the caller sorts: any device sort) ->
+ *    the <= 41 recall sample thresholds per combination (eval.py:8-24). */
+int mfx_kitti_eval_thresholds(const mfx_kitti_eval_desc* d, const double* sorted_scores, void* stream);
+/* 4: matching at every threshold with false-positive / DontCare / orientation accounting -> pr (eval.py:289-326). */
+int mfx_kitti_eval_match_pass2(const mfx_kitti_eval_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,12 @@ class KittiDesc(ctypes.Structure):
         [(n, ctypes.c_double) for n in ("filter_trunc", "filter_size", "edge_ratio")]
 
 
+class KittiEvalDesc(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("gt", "dt", "gt_off", "dt_off", "pair_off", "classes", "min_overlaps", "overlaps", "tp_scores",
+                                        "num_valid_gt", "thresholds", "num_thresholds", "pr")] + \
+        [(n, c_int) for n in ("B", "n_gt", "n_dt", "num_classes", "num_k", "compute_aos")] + [("n_pairs", ctypes.c_int64)]
+
+
 # every symbol include/monoflex_hip.h declares: name -> (restype, argtypes)
 _P, _I, _F, _S = c_void_p, c_int, c_float, c_size_t
 SYMBOLS = {
@@ -100,6 +106,10 @@ SYMBOLS = {
     "mfx_dcn_backward_nhwc_bf16": (_I, [_P] * 8 + [_I] * 10 + [_P, _S, _P]),
     "mfx_kitti_encode_targets": (_I, [ctypes.POINTER(KittiDesc), _P]),
     "mfx_kitti_preprocess_u8": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P]),
+    "mfx_kitti_eval_overlaps": (_I, [ctypes.POINTER(KittiEvalDesc), _P]),
+    "mfx_kitti_eval_match_pass1": (_I, [ctypes.POINTER(KittiEvalDesc), _P]),
+    "mfx_kitti_eval_thresholds": (_I, [ctypes.POINTER(KittiEvalDesc), _P, _P]),
+    "mfx_kitti_eval_match_pass2": (_I, [ctypes.POINTER(KittiEvalDesc), _P]),
     "mfx_decode_boxes": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P]),
 }
 

@@ -52,9 +52,10 @@ def test_official_result_matches_reference(metric):
 
 
 def test_fixture_has_no_borderline_overlaps():
-    """No overlap within 1e-4 of a matching threshold: GPU float round-off cannot flip a match on this fixture."""
+    """No overlap within 2e-4 of a matching threshold: the float32 round-off of the device's rotated-box arithmetic (<= 1e-4
+    on this fixture) cannot flip a match, so AP values must agree to round-off."""
     for m in range(3):
         for i in range(N_IMG):
             o = GOLD["ov%d_%d" % (m, i)]
             for th in (0.25, 0.5, 0.7):
-                assert not ((np.abs(o - th) < 1e-4) & (o > 0)).any(), (m, i, th)
+                assert not ((np.abs(o - th) < 2e-4) & (o > 0)).any(), (m, i, th)

@@ -1,0 +1,118 @@
+"""CPU check of the evaluator's device functions (monoflex_amd/csrc/kitti_eval_math.h compiled for the host by the test-only
+tests/shim/kitti_eval_host.cpp) and of the host half of monoflex_amd/data/evaluation.py: result files byte-identical to the
+reference's, parsing, packing, curve / AP arithmetic and the report text against the reference goldens."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from monoflex_amd import lib as L
+from monoflex_amd.data import evaluation as EV
+from oracle import kitti_eval_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "kitti_eval.npz"))
+N_IMG = len([k for k in GOLD.files if k.startswith("det_")])
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("shim") / "libkitti_eval_shim.so")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", so,
+                        os.path.join(ROOT, "tests", "shim", "kitti_eval_host.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lib = ctypes.CDLL(so)
+    lib.shim_kitti_eval.argtypes = [ctypes.POINTER(L.KittiEvalDesc)]
+    lib.shim_kitti_eval.restype = None
+    return lib
+
+
+def records():
+    gts = [EV.parse_label_text(str(GOLD["labels_%d" % i])) for i in range(N_IMG)]
+    dts = [EV.parse_label_text(str(GOLD["txt_%d" % i])) for i in range(N_IMG)]
+    return gts, dts
+
+
+def shim_pr_table(shim, gts, dts, classes, mo):
+    arrays, sz, aos = EV.pack_eval_inputs(gts, dts, classes, mo)
+    n_comb = sz["num_classes"] * 9 * sz["num_k"]
+    out = dict(overlaps=np.zeros((3, max(sz["n_pairs"], 1))), tp_scores=np.zeros((n_comb, max(sz["n_gt"], 1))),
+               thresholds=np.zeros((n_comb, 41)), pr=np.full((n_comb, 41, 4), 7.0), num_valid_gt=np.zeros((sz["num_classes"], 3), np.int32),
+               num_thresholds=np.zeros(n_comb, np.int32))
+    d = L.KittiEvalDesc()
+    for k, a in list(arrays.items()) + list(out.items()):
+        setattr(d, k, a.ctypes.data)
+    for k, v in sz.items():
+        setattr(d, k, v)
+    d.compute_aos = int(aos)
+    shim.shim_kitti_eval(ctypes.byref(d))
+    shape = (sz["num_classes"], 3, 3, sz["num_k"])
+    return out["pr"].reshape(shape + (41, 4)), out["num_thresholds"].reshape(shape), out["overlaps"][:, :sz["n_pairs"]], arrays["pair_off"], aos
+
+
+def test_result_writer_is_byte_identical(tmp_path):
+    for i in range(N_IMG):
+        f = tmp_path / ("%06d.txt" % i)
+        EV.generate_kitti_3d_detection(torch.from_numpy(GOLD["det_%d" % i]), str(f))
+        assert f.read_text() == str(GOLD["txt_%d" % i]), i
+    got = EV.read_label_folder(str(tmp_path))
+    assert len(got) == N_IMG and got[3].shape == (0, 16)
+    assert np.allclose(got[0][:, 15], GOLD["det_0"][:, 13].round(4))
+
+
+def test_parsing_matches_oracle():
+    text = str(GOLD["labels_1"])
+    rec, a = EV.parse_label_text(text), R.parse_annos(text)
+    assert rec.shape == (len(a["name"]), 16)
+    codes = {"car": 0, "pedestrian": 1, "cyclist": 2, "van": 3, "person_sitting": 4, "truck": 5}
+    for r, name in zip(rec, a["name"]):
+        assert r[0] == (6 if name == "DontCare" else codes.get(name.lower(), 7))
+    assert np.array_equal(rec[:, 1], a["truncated"]) and np.array_equal(rec[:, 2], a["occluded"]) and np.array_equal(rec[:, 3], a["alpha"])
+    assert np.array_equal(rec[:, 4:8], a["bbox"]) and np.array_equal(rec[:, 8:11], a["dimensions"])
+    assert np.array_equal(rec[:, 11:14], a["location"]) and np.array_equal(rec[:, 14], a["rotation_y"]) and (rec[:, 15] == 0).all()
+    assert EV.parse_label_text("\n").shape == (0, 16) and EV.parse_label_text("").shape == (0, 16)
+    with pytest.raises(ValueError):
+        EV.pack_eval_inputs([np.zeros((0, 16))], [np.zeros((65, 16))], [0], np.zeros((1, 3, 1)))
+
+
+def test_shim_overlaps_match_reference(shim):
+    gts, dts = records()
+    _, _, ov, pair_off, _ = shim_pr_table(shim, gts, dts, [0, 1, 2], np.full((2, 3, 3), 0.5))
+    for m in range(3):
+        for i in range(N_IMG):
+            ref = GOLD["ov%d_%d" % (m, i)]
+            got = ov[m, pair_off[i]:pair_off[i + 1]].reshape(ref.shape)
+            # rotated boxes: float32 arithmetic with cosf/sinf/sqrtf instead of the double-precision libm calls of the emulated
+            # reference run -> near-parallel edge crossings move by a few 1e-5
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4 if m else 0, err_msg="metric %d image %d" % (m, i))
+
+
+@pytest.mark.parametrize("metric", ["R40", "R11"])
+def test_shim_result_matches_reference(shim, metric, monkeypatch):
+    gts, dts = records()
+    monkeypatch.setattr(EV, "pr_table", lambda g, d, c, mo, device="cuda": shim_pr_table(shim, g, d, c, mo))
+    text, ret = EV.get_official_eval_result(gts, dts, ["Car", "Pedestrian", "Cyclist"], metric=metric)
+    keys = [str(k) for k in GOLD["keys_" + metric]]
+    assert sorted(ret.keys()) == keys
+    np.testing.assert_allclose(np.array([float(ret[k]) for k in keys]), GOLD["values_" + metric], rtol=1e-12, atol=1e-12)
+    assert text == str(GOLD["result_" + metric])
+
+
+def test_shim_subset_of_classes_and_no_orientation(shim, monkeypatch):
+    gts, dts = records()
+    monkeypatch.setattr(EV, "pr_table", lambda g, d, c, mo, device="cuda": shim_pr_table(shim, g, d, c, mo))
+    _, car = EV.get_official_eval_result(gts, dts, "Car", metric="R40")
+    i = [str(k) for k in GOLD["keys_R40"]].index("Car_3d_0.70/moderate")
+    assert abs(car["Car_3d_0.70/moderate"] - GOLD["values_R40"][i]) < 1e-9 and not any(k.startswith("Ped") for k in car)
+    for d in dts:
+        d[:, 3] = -10
+    text, ret = EV.get_official_eval_result(gts, dts, [0], metric="R40")
+    assert "aos" not in text and not any("aos" in k for k in ret)
+    ga, da = [R.parse_annos(str(GOLD["labels_%d" % i])) for i in range(N_IMG)], [R.parse_annos(str(GOLD["txt_%d" % i])) for i in range(N_IMG)]
+    for a in da:
+        a["alpha"][:] = -10
+    otext, oret = R.official_result(ga, da, (0,), "R40")
+    assert text == otext and all(abs(ret[k] - oret[k]) < 1e-9 for k in oret)
