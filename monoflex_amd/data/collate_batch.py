@@ -48,6 +48,7 @@ class DeviceLoader:
                                                                                       shuffle=shuffle and sampler is None)
         self.loader = torch.utils.data.DataLoader(RawView(dataset), num_workers=num_workers, collate_fn=_as_list, **kw)
         self.collate = DeviceBatchCollator(dataset, check=check)
+        self.dataset = dataset
 
     def __len__(self):
         return len(self.loader)

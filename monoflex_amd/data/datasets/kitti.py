@@ -40,7 +40,7 @@ class KITTIDataset(torch.utils.data.Dataset):
         self.split = cfg.DATASETS.TRAIN_SPLIT if is_train else cfg.DATASETS.TEST_SPLIT
         self.is_train = is_train
         self.transforms = transforms                 # kept for signature parity; normalisation runs in the frame kernel
-        imageset = os.path.join(root, "ImageSets", "{}.txt".format(self.split))
+        imageset = self.imageset_txt = os.path.join(root, "ImageSets", "{}.txt".format(self.split))
         if not os.path.exists(imageset):
             raise FileNotFoundError("ImageSets file not exist, dir = {}".format(imageset))
         with open(imageset) as f:

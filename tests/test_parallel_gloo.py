@@ -104,3 +104,45 @@ def test_training_data_parallel_ignores_dead_parameters_and_averages():
     want = m.live.weight.grad / 2                                    # DDP averages over ranks
     for rank, g, dead_none in res:
         assert torch.allclose(torch.tensor(g), want, atol=1e-6) and all(dead_none)
+
+
+def _sampler_worker(rank, world, port, out):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from monoflex_amd.data.samplers import InferenceSampler, IterationBatchSampler, TrainingSampler, shared_random_seed
+    torch.manual_seed(100 + rank)                                  # ranks have different local RNG states ...
+    seed = shared_random_seed()                                    # ... and still agree on the seed
+    tr = TrainingSampler(10)                                       # seed=None: agreed through the broadcast
+    batches = list(IterationBatchSampler(TrainingSampler(10, seed=7), batch_size=3, num_iterations=4))
+    out.put((rank, seed, list(__import__("itertools").islice(iter(tr), 15)), batches, list(InferenceSampler(7)), tr._seed))
+    dist.destroy_process_group()
+
+
+def test_samplers_shard_one_shared_stream_over_two_ranks():
+    """distributed_sampler.py:43-54,193-196: rank r sees entries r, r+2, ... of one endless seeded permutation stream; the
+    inference sampler cuts contiguous shards."""
+    import itertools
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    ps = [ctx.Process(target=_sampler_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    (_, s0, t0, b0, i0, ts0), (_, s1, t1, b1, i1, ts1) = res
+    assert s0 == s1 and ts0 == ts1
+    merged = [v for pair in zip(t0, t1) for v in pair]             # interleaving the two ranks restores the stream
+    g = torch.Generator(); g.manual_seed(ts0)
+    stream = torch.randperm(10, generator=g).tolist() + torch.randperm(10, generator=g).tolist() + torch.randperm(10, generator=g).tolist()
+    assert merged == stream[:30] and sorted(merged[:10]) == list(range(10))
+    assert len(b0) == 4 and all(len(b) == 3 for b in b0) and not set(map(tuple, b0)) & set(map(tuple, b1))
+    g.manual_seed(7)
+    s7 = torch.randperm(10, generator=g).tolist() + torch.randperm(10, generator=g).tolist() + torch.randperm(10, generator=g).tolist()
+    assert [v for b in b0 for v in b] == s7[0:24:2] and [v for b in b1 for v in b] == s7[1:24:2]
+    assert i0 == [0, 1, 2, 3] and i1 == [4, 5, 6]
+
+
+def test_samplers_single_process():
+    from monoflex_amd.data.samplers import InferenceSampler, TrainingSampler
+    import itertools
+    assert list(InferenceSampler(5)) == [0, 1, 2, 3, 4] and len(InferenceSampler(5)) == 5
+    assert list(itertools.islice(iter(TrainingSampler(4, shuffle=False, seed=0)), 9)) == [0, 1, 2, 3, 0, 1, 2, 3, 0]
