@@ -131,3 +131,32 @@ def test_synthetic_train_targets_are_consistent():
         for j in np.nonzero(o[:4])[0]:
             d = (centers[j] + o[4 + j] - a["alphas"][i] + np.pi) % (2 * np.pi) - np.pi
             assert abs(d) < 1e-5
+
+
+def test_ctypes_layouts_equal_the_c_compilers(tmp_path):
+    """Every descriptor struct of include/monoflex_hip.h: sizeof and the offset of each member as laid out by gcc must
+    equal the ctypes mirror in monoflex_amd/lib.py (a silent mismatch would hand kernels the wrong pointers)."""
+    import subprocess
+    from monoflex_amd import lib as L
+    pairs = {"mfx_conv_desc": L.ConvDesc, "mfx_cat_desc": L.CatDesc, "mfx_dcn_desc": L.DcnDesc, "mfx_heads_desc": L.HeadsDesc,
+             "mfx_kitti_desc": L.KittiDesc, "mfx_kitti_eval_desc": L.KittiEvalDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "monoflex_hip.h"', 'int main(void) {']
+    for cname, ct in pairs.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for field, _ in ct._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, field, cname, field))
+    lines.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    r = subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr                              # also proves the header is plain C and names every member
+    out = subprocess.run([exe], capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for line in filter(None, out):
+        cname, field, value = line.split(" ")
+        ct = pairs[cname]
+        expect = ctypes.sizeof(ct) if field == "sizeof" else getattr(ct, field).offset
+        assert int(value) == expect, (cname, field, value, expect)
+        seen += 1
+    assert seen == sum(len(ct._fields_) + 1 for ct in pairs.values())
