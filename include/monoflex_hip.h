@@ -183,9 +183,12 @@ int mfx_edge_scatter_add(float* out, int ld_out, int ch_off, int C, const float*
  * Class logit of (image b, class c, pixel p) is hmap[b*b_stride + c*c_stride + p*p_stride] (elements): either the
  * NHWC head map (c_stride 1, p_stride ld) or a planar (B,ncls,H*W) copy (c_stride H*W, p_stride 1: coalesced).
  * Outputs [B][ncls][K], sorted by descending score.  Ties are broken towards the lower flat index
- * (torch.topk leaves the order unspecified). */
+ * (torch.topk leaves the order unspecified).
+ * With a workspace of mfx_decode_topk_workspace_bytes() each map is cut into row strips reduced by separate workgroups and
+ * merged by a second launch (same result, ~4x shorter on a 256-CU device); without one a single workgroup per map does it. */
+size_t mfx_decode_topk_workspace_bytes(int ncls, int B, int K);
 int mfx_decode_topk(const float* hmap, long b_stride, long c_stride, long p_stride, int ncls, int B, int H, int W, int K,
-                    float* scores, int32_t* index, void* stream);
+                    float* scores, int32_t* index, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Decode stage 2 (layers/utils.py:88-100,120-145; detector_infer.py:96-232; anno_encoder.py:69-295):
  * merge ncls*K -> K, gather the 50 regression channels, 3D box recovery.

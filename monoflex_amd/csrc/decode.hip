@@ -23,12 +23,15 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { retur
 // Among the elements p in [0,n) with `pred(p)`, returns the key of rank `need` (1 = largest) and writes how many
 // of the elements EQUAL to that key belong to the top `need` into *take_eq.  keys are < 2^32, examined in
 // three digit levels (12 + 10 + 10 bits).  One workgroup; hist has 4096 ints; sh[0..1] is scratch.
-template <class KeyF, class PredF>
+// NLEV = 3: digits of 12 + 10 + 10 bits (few passes over many keys); NLEV = 4: four 8-bit digits (small key sets: the
+// per-level cost is then the 256-bin scan, not the 4096-bin one).
+template <int NLEV = 3, class KeyF, class PredF>
 __device__ uint32_t select_kth(KeyF key, PredF pred, int n, int need, int* hist, int* sh, int* take_eq) {
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
-    const int shifts[3] = {20, 10, 0}, nbits[3] = {12, 10, 10};
+    const int shifts[4] = {NLEV == 3 ? 20 : 24, NLEV == 3 ? 10 : 16, NLEV == 3 ? 0 : 8, 0};
+    const int nbits[4] = {NLEV == 3 ? 12 : 8, NLEV == 3 ? 10 : 8, NLEV == 3 ? 10 : 8, 8};
     uint32_t prefix = 0;
-    for (int lev = 0; lev < 3; ++lev) {
+    for (int lev = 0; lev < NLEV; ++lev) {
         const int nb = 1 << nbits[lev], sft = shifts[lev];
         for (int i = tid; i < nb; i += nthreads) hist[i] = 0;
         __syncthreads();
@@ -150,6 +153,103 @@ __global__ __launch_bounds__(kTopkThreads) void decode_topk_kernel(const float* 
     }
 }
 
+// ---- strip-parallel form of stage 1 ---------------------------------------------------------------------------------
+// The single-workgroup kernel above keeps one (class, image) map in one CU's LDS: 24 workgroups for B=8, i.e. a 256-CU
+// device runs a chain of serial radix passes on 9 % of its CUs (79 us).  Here each map is cut into row strips; every strip
+// (its rows + one halo row each side for the NMS) is reduced to its own exact top-K by one small workgroup, and a second
+// tiny kernel merges the S*K candidates.  Any element of the global top-K is in the top-K of its strip under the same total
+// order (value desc, flat index asc), so the result is identical.
+constexpr int kStripThreads = 256;
+
+__global__ __launch_bounds__(kStripThreads) void decode_topk_strip_kernel(const float* hmap, long b_stride, long c_stride, long p_stride,
+                                                                          int H, int W, int K, int rows_per, float* cand_v, int* cand_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int strip = blockIdx.x, S = gridDim.x, cls = blockIdx.y, ncls = gridDim.y, b = blockIdx.z;
+    const int r0 = strip * rows_per, r1 = min(H, r0 + rows_per);
+    const int ylo = max(r0 - 1, 0), yhi = min(r1 + 1, H);
+    const int nloc = (r1 - r0) * W, nstage = (yhi - ylo) * W;
+    float* lg = reinterpret_cast<float*>(smem_raw);                 // [(rows_per+2)*W] logits of rows ylo..yhi
+    float* nm = lg + (rows_per + 2) * W;                            // [rows_per*W] heat after NMS
+    __shared__ int hist[256];
+    __shared__ int sh[2];
+    __shared__ int cnt;
+    __shared__ float cv[256];
+    __shared__ int ci[256];
+    const int tid = threadIdx.x;
+    const float* src = hmap + (size_t)b * b_stride + (size_t)cls * c_stride;
+    for (int q = tid; q < nstage; q += kStripThreads) lg[q] = src[(size_t)(ylo * W + q) * p_stride];
+    if (tid == 0) { cnt = 0; sh[0] = 0; }
+    __syncthreads();
+    int nz = 0;
+    for (int q = tid; q < nloc; q += kStripThreads) {               // nms_hm (layers/utils.py:45-58), same tie rule as above
+        const int y = r0 + q / W, x = q % W;
+        const float xv = lg[(y - ylo) * W + x];
+        float xm = -3.0e38f;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W || (dx == 0 && dy == 0)) continue;
+                xm = fmaxf(xm, lg[(yy - ylo) * W + xx]);
+            }
+        }
+        const bool keep = xv >= xm || sigmoid_clamp(xv) == sigmoid_clamp(xm);
+        const float h = keep ? sigmoid_clamp(xv) : 0.f;
+        nm[q] = h;
+        nz += h != 0.f ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nz += __shfl_xor(nz, off);
+    if ((tid & 63) == 0 && nz) atomicAdd(&sh[0], nz);
+    __syncthreads();
+    const int need = K < nloc ? K : nloc;
+    const bool skip_zero = sh[0] >= need;
+    __syncthreads();
+    int take_eq = 0, dummy = 0;
+    const uint32_t T = select_kth<4>([&](int q) { return __float_as_uint(nm[q]); }, [&](int q) { return !skip_zero || nm[q] != 0.f; },
+                                     nloc, need, hist, sh, &take_eq);
+    const uint32_t I = select_kth<4>([&](int q) { return (uint32_t)(nloc - 1 - q); },
+                                  [&](int q) { return __float_as_uint(nm[q]) == T; }, nloc, take_eq, hist, sh, &dummy);
+    for (int q = tid; q < nloc; q += kStripThreads) {
+        const uint32_t kb = __float_as_uint(nm[q]);
+        if (kb > T || (kb == T && (uint32_t)(nloc - 1 - q) >= I)) {
+            const int slot = atomicAdd(&cnt, 1);
+            if (slot < 256) { cv[slot] = nm[q]; ci[slot] = r0 * W + q; }
+        }
+    }
+    __syncthreads();
+    float* ov = cand_v + (((size_t)b * ncls + cls) * S + strip) * K;
+    int* oi = cand_i + (((size_t)b * ncls + cls) * S + strip) * K;
+    const int n = cnt < need ? cnt : need;                          // == need by construction
+    for (int t = tid; t < K; t += kStripThreads) {
+        if (t < n) { ov[t] = cv[t]; oi[t] = ci[t]; }
+        else { ov[t] = -1.f; oi[t] = 0x7fffffff; }                   // padding: below every heat value (heat >= 0)
+    }
+}
+
+// Rank of every candidate among the S*K candidates of its map.  One wave per candidate: the lanes split the comparison
+// range (independent LDS reads, a few per lane) and add their counts; a thread-per-candidate loop over all n candidates is a
+// chain of ~2n dependent LDS round trips and took longer than the whole single-workgroup selection.
+__global__ __launch_bounds__(512) void decode_topk_merge_kernel(const float* cand_v, const int* cand_i, int n, int K, float* scores, int* index) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* v = reinterpret_cast<float*>(smem_raw);
+    int* ix = reinterpret_cast<int*>(v + n);
+    const size_t map = (size_t)blockIdx.y * gridDim.x + blockIdx.x;   // (image, class)
+    for (int t = threadIdx.x; t < n; t += blockDim.x) { v[t] = cand_v[map * n + t]; ix[t] = cand_i[map * n + t]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, nwaves = (blockDim.x >> 6) * gridDim.z, wave = blockIdx.z * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (int c = wave; c < n; c += nwaves) {                        // the candidates are dealt to the waves of gridDim.z workgroups
+        const float mv = v[c]; const int mi = ix[c];
+        int rank = 0;
+#pragma unroll 4
+        for (int u = lane; u < n; u += 64) rank += better(v[u], ix[u], mv, mi) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rank += __shfl_xor(rank, off);
+        if (lane == 0 && rank < K) { scores[map * K + rank] = mv; index[map * K + rank] = mi; }
+    }
+}
+
 struct DecodeConst {
     float dim_mean[3][3];     // (l,h,w) per class, config/defaults.py:206-208
     float depth_min, depth_max;
@@ -265,18 +365,40 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(const float* hmap, in
 }  // namespace mfx
 using namespace mfx;
 
+int g_opt_topk_strips = 8;       // row strips per (class, image) map when a workspace is supplied; 1 = single-workgroup kernel
+
+extern "C" size_t mfx_decode_topk_workspace_bytes(int ncls, int B, int K) {
+    return (size_t)B * ncls * 16 * K * 8;                           // up to 16 strips of K (value, index) pairs
+}
+
 extern "C" int mfx_decode_topk(const float* hmap, long b_stride, long c_stride, long p_stride, int ncls, int B, int H, int W, int K,
-                               float* scores, int32_t* index, void* stream) {
+                               float* scores, int32_t* index, void* workspace, size_t workspace_bytes, void* stream) {
     if (!hmap || !scores || !index) return mfx_fail(MFX_ERR_ARG, "decode_topk: null pointer");
     if (K < 1 || K > H * W || K > 256) return mfx_fail(MFX_ERR_ARG, "decode_topk: need 1 <= K <= min(H*W, 256)");
+    if (B * ncls == 0) return MFX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int S = g_opt_topk_strips < 1 ? 1 : (g_opt_topk_strips > 16 ? 16 : g_opt_topk_strips);
+    while (S > 1 && ((H + S - 1) / S) * W < K) --S;                 // every strip must be able to hold K candidates ...
+    while (S > 1 && (S - 1) * ((H + S - 1) / S) >= H) --S;          // ... and no strip may be empty
+    if (workspace && S > 1 && workspace_bytes >= (size_t)B * ncls * S * K * 8) {
+        const int rows_per = (H + S - 1) / S;
+        float* cand_v = reinterpret_cast<float*>(workspace);
+        int* cand_i = reinterpret_cast<int*>(cand_v + (size_t)B * ncls * S * K);
+        const size_t smem = (size_t)(2 * rows_per + 2) * W * sizeof(float);
+        if (smem <= 48 * 1024) {
+            hipLaunchKernelGGL(decode_topk_strip_kernel, dim3(S, ncls, B), dim3(kStripThreads), smem, st,
+                               hmap, b_stride, c_stride, p_stride, H, W, K, rows_per, cand_v, cand_i);
+            hipLaunchKernelGGL(decode_topk_merge_kernel, dim3(ncls, B, 4), dim3(512), (size_t)S * K * 8, st, cand_v, cand_i, S * K, K, scores, index);
+            MFX_HIP_CHECK(hipGetLastError());
+            return MFX_OK;
+        }
+    }
     const size_t smem = (size_t)H * W * sizeof(float);
     if (smem > 136 * 1024) return mfx_fail(MFX_ERR_UNSUPPORTED, "decode_topk: heat map larger than LDS (H*W <= 34816)");
-    if (B * ncls == 0) return MFX_OK;
     auto k = decode_topk_kernel;
     static size_t attr_smem = 0;
     if (smem > attr_smem) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr_smem = smem; }
-    hipLaunchKernelGGL(k, dim3(ncls, B), dim3(kTopkThreads), smem, reinterpret_cast<hipStream_t>(stream),
-                       hmap, b_stride, c_stride, p_stride, H, W, K, scores, index);
+    hipLaunchKernelGGL(k, dim3(ncls, B), dim3(kTopkThreads), smem, st, hmap, b_stride, c_stride, p_stride, H, W, K, scores, index);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

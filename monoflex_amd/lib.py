@@ -86,7 +86,8 @@ SYMBOLS = {
     "mfx_pack_image_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_heads_fused": (_I, [ctypes.POINTER(HeadsDesc), _P]),
     "mfx_edge_scatter_add": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
-    "mfx_decode_topk": (_I, [_P, ctypes.c_long, ctypes.c_long, ctypes.c_long, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mfx_decode_topk_workspace_bytes": (_S, [_I, _I, _I]),
+    "mfx_decode_topk": (_I, [_P, ctypes.c_long, ctypes.c_long, ctypes.c_long, _I, _I, _I, _I, _I, _P, _P, _P, _S, _P]),
     "mfx_conv_wgrad_nhwc": (_I, [_P, _P, _P] + [_I] * 15 + [_P]),
     "mfx_conv_wgrad_nhwc_dil": (_I, [_P, _P, _P] + [_I] * 16 + [_P]),
     "mfx_conv_wgrad_oihw": (_I, [_P, _P, _P] + [_I] * 17 + [_P, _S, _P]),

@@ -382,8 +382,10 @@ def decode_topk(hmap, ch_off, ncls, K, planar=None):
         src, bs, cs, ps = planar.data_ptr(), ncls * H * W, H * W, 1
     else:
         src, bs, cs, ps = hmap.data_ptr() + 4 * ch_off, H * W * ld, 1, ld
-    L.check(L.load().mfx_decode_topk(ctypes.c_void_p(src), bs, cs, ps, ncls, B, H, W, K, _ptr(scores), _ptr(index), _stream()),
-            "mfx_decode_topk")
+    lib = L.load()
+    ws = torch.empty(int(lib.mfx_decode_topk_workspace_bytes(ncls, B, K)), dtype=torch.uint8, device=hmap.device)
+    L.check(lib.mfx_decode_topk(ctypes.c_void_p(src), bs, cs, ps, ncls, B, H, W, K, _ptr(scores), _ptr(index), _ptr(ws), ws.numel(),
+                                _stream()), "mfx_decode_topk")
     return scores, index
 
 

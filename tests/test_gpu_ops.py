@@ -297,6 +297,53 @@ def test_decode_vs_reference_goldens(golden_dir):
     assert n >= 4
 
 
+def _topk_reference(logits, K):
+    """torch restatement of nms_hm + per-class top-K with ties toward the lower flat index (layers/utils.py:39-77)."""
+    heat = torch.sigmoid(logits).clamp(1e-4, 1 - 1e-4)
+    keep = torch.nn.functional.max_pool2d(heat, 3, 1, 1) == heat
+    flat = (heat * keep).flatten(2)                                              # (B, C, H*W)
+    # a stable descending sort on the value alone keeps equal values in ascending index order
+    order = torch.sort(flat, dim=-1, descending=True, stable=True).indices[..., :K]
+    return torch.gather(flat, 2, order), order
+
+
+@pytest.mark.parametrize("B,H,W,K,kind", [(2, 96, 320, 50, "dense"), (1, 96, 320, 50, "sparse"), (2, 37, 50, 50, "ties"),
+                                          (1, 96, 320, 100, "plateau"), (3, 20, 24, 50, "dense")])
+def test_decode_topk_strip_kernel_equals_single_workgroup(B, H, W, K, kind):
+    """Stage 1 of the decode, strip-parallel form (row strips + merge) against the single-workgroup kernel and a torch
+    restatement: identical scores and indices for every strip count, with ties, plateaus and fewer than K survivors."""
+    ops, L = _ops()
+    lib_ = L.load()
+    g = _g(5)
+    logits = torch.randn(B, 3, H, W, generator=g) * 1.5 - 2.0
+    if kind == "sparse":                                                        # fewer than K non-zero survivors in one class
+        logits[:, 0] = -30.0
+        logits[:, 0, 10, 11], logits[:, 0, 50, 200], logits[:, 0, 95, 319] = 2.0, 1.0, 3.0
+    elif kind == "ties":                                                        # many exactly equal heat values
+        logits = (logits * 2).round() / 2
+    elif kind == "plateau":                                                     # constant regions survive the NMS as a whole
+        logits[:, 1, 20:40, 100:140] = 1.25
+        logits[:, 2] = 0.5
+    hm = torch.zeros(B, H, W, 64)
+    hm[..., :3] = logits.permute(0, 2, 3, 1)
+    hm = hm.to(DEV)
+    want_s, want_i = _topk_reference(logits.to(DEV), K)
+    try:
+        outs = {}
+        for strips in (1, 2, 3, 8, 16):
+            L.check(lib_.mfx_set_option(b"topk_strips", strips), "opt")
+            s_, i_ = ops.decode_topk(hm, 0, 3, K)
+            outs[strips] = (s_.clone(), i_.clone())
+        planar = logits.to(DEV).flatten(2).contiguous()
+        L.check(lib_.mfx_set_option(b"topk_strips", 8), "opt")
+        outs["planar"] = ops.decode_topk(hm, 0, 3, K, planar=planar)
+    finally:
+        L.check(lib_.mfx_set_option(b"topk_strips", 8), "opt")
+    for k, (s_, i_) in outs.items():
+        assert torch.equal(s_, outs[1][0]) and torch.equal(i_, outs[1][1]), k
+    assert torch.allclose(outs[8][0], want_s, rtol=0, atol=1e-6) and torch.equal(outs[8][1].long(), want_i)
+
+
 @pytest.mark.parametrize("B,C,Cout,H,W,off_std", [(2, 64, 64, 20, 40, 1.5), (1, 128, 64, 33, 48, 1.0), (2, 64, 128, 16, 16, 4.0),
                                                  (1, 256, 256, 12, 24, 2.0)])
 def test_dcn_patch_kernel_matches_first_generation(B, C, Cout, H, W, off_std):
