@@ -544,10 +544,65 @@ def run_eval_cases():
     shutil.rmtree(root)
 
 
+
+# ---- G6: one training step of the reference model -----------------------------------------------------------
+TRAIN_STEP = dict(out_w=96, out_h=32, batch=2, weight_seed=3, seed0=20)
+TRAIN_GRAD_KEYS = ["backbone.base.base_layer.0.weight", "backbone.base.level2.tree1.conv1.weight", "backbone.base.level3.tree2.root.bn.weight",
+                   "backbone.base.level5.root.conv.weight", "backbone.dla_up.ida_0.proj_1.conv.weight",
+                   "backbone.dla_up.ida_0.proj_1.conv.conv_offset_mask.weight", "backbone.dla_up.ida_2.node_3.conv.bias",
+                   "backbone.ida_up.up_1.weight", "backbone.ida_up.node_2.actf.0.bias", "heads.predictor.class_head.0.weight",
+                   "heads.predictor.class_head.2.bias", "heads.predictor.reg_heads.2.0.weight", "heads.predictor.reg_features.7.1.weight",
+                   "heads.predictor.trunc_heatmap_conv.0.weight", "heads.predictor.trunc_offset_conv.3.bias"]
+
+
+def train_step_inputs():
+    """Seeded images + synthetic training targets of the train-step fixture (same generator as tests/test_gpu_train.py)."""
+    c = TRAIN_STEP
+    tg = [S.synthetic_train_target(c["seed0"] + i, out_w=c["out_w"], out_h=c["out_h"], n_obj=3 + i) for i in range(c["batch"])]
+    imgs = S.synthetic_images(c["batch"], c["out_h"] * 4, c["out_w"] * 4, seed=c["seed0"])
+    return imgs, tg
+
+
+def run_train_step_case():
+    """The reference KeypointDetector in training mode (tools/plain_train_net.py path: model(images, targets) -> loss dict ->
+    summed loss -> backward) on a 128x384 input, B=2: the 11 losses, the global gradient norm, the parameters without
+    gradient, and checksums + strided samples of 15 parameter gradients spanning trunk, DCN, up-sampling and heads."""
+    c = TRAIN_STEP
+    cfg, model = build_reference(c["out_w"], c["out_h"])
+    import model.head.detector_loss as dl
+    dl.get_iou_3d = lambda a, b: a.new_zeros(a.shape[0])
+    model.load_state_dict(S.synthetic_state_dict(model.state_dict(), seed=c["weight_seed"], cls_bias=-1.0))
+    model.train()
+    imgs, tg = train_step_inputs()
+    loss_dict, log_dict = model(imgs, [reference_train_target(t) for t in tg])
+    total = sum(loss_dict.values())
+    total.backward()
+    out = {"loss/" + k: np.float64(v.item()) for k, v in loss_dict.items()}
+    out["total"] = np.float64(total.item())
+    grads = {n: p.grad for n, p in model.named_parameters()}
+    out["no_grad"] = np.array(sorted(n for n, g in grads.items() if g is None))
+    out["grad_norm"] = np.float64(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values() if g is not None)).item())
+    out["norms"] = np.array([float(grads[n].double().norm()) if grads[n] is not None else -1.0 for n in sorted(grads)])
+    out["norm_names"] = np.array(sorted(grads))
+    for n in TRAIN_GRAD_KEYS:
+        cs = checksum(grads[n])
+        out["g/%s/samples" % n], out["g/%s/idx" % n] = cs["samples"], cs["idx"]
+        out["g/%s/sum" % n], out["g/%s/abssum" % n] = np.float64(cs["sum"]), np.float64(cs["abssum"])
+    bn = model.backbone.base.base_layer[1]
+    out["bn/base_layer.running_mean"], out["bn/base_layer.running_var"] = bn.running_mean.numpy().copy(), bn.running_var.numpy().copy()
+    out["meta"] = np.array(repr(dict(case="train_step", torch=torch.__version__, config=c,
+                                     patches="get_iou_3d -> zeros; _ext = oracle/dcn_v2_ref.c; InPlaceABN = BN + leaky_relu(0.01)")))
+    np.savez_compressed(os.path.join(GOLD, "train_step.npz"), **out)
+    print("train step:", {k[5:]: round(float(v), 4) for k, v in out.items() if k.startswith("loss/")}, "grad norm", float(out["grad_norm"]),
+          "no grad:", len(out["no_grad"]))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     install_stubs()
     which = sys.argv[1:] or ["small", "full", "decode", "loss"]
+    if "train" in which:
+        run_train_step_case()
     if "eval" in which:
         run_eval_cases()
     if "kitti" in which:
