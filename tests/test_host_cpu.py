@@ -160,3 +160,29 @@ def test_ctypes_layouts_equal_the_c_compilers(tmp_path):
         assert int(value) == expect, (cname, field, value, expect)
         seen += 1
     assert seen == sum(len(ct._fields_) + 1 for ct in pairs.values())
+
+
+def test_c_abi_argument_errors_need_no_gpu():
+    """Error behaviour of the C boundary: bad arguments are rejected before any device work, with a code and a message
+    (the reference raises through AT_ASSERTM / python asserts, SURVEY 8b 'Errors')."""
+    from monoflex_amd import lib as L
+    lib = L.load()
+    null = ctypes.c_void_p(None)
+    assert lib.mfx_set_option(b"no_such_option", 1) != 0 and b"unknown option" in lib.mfx_last_error()
+    assert lib.mfx_kitti_encode_targets(None, null) != 0 and b"null descriptor" in lib.mfx_last_error()
+    d = L.KittiDesc()
+    d.B, d.max_objs, d.in_w, d.in_h, d.down, d.num_classes = 1, 40, 1281, 384, 4, 3         # width not divisible by the stride
+    assert lib.mfx_kitti_encode_targets(ctypes.byref(d), null) != 0 and b"bad sizes" in lib.mfx_last_error()
+    d.in_w = 1280                                                                             # sizes fine, pointers missing
+    assert lib.mfx_kitti_encode_targets(ctypes.byref(d), null) != 0 and b"pointer" in lib.mfx_last_error()
+    assert lib.mfx_kitti_preprocess_u8(None, None, None, None, None, 1, 1280, 384, None, None, null) != 0
+    e = L.KittiEvalDesc()
+    for fn in (lib.mfx_kitti_eval_overlaps, lib.mfx_kitti_eval_match_pass1, lib.mfx_kitti_eval_match_pass2):
+        assert fn(None, null) != 0
+        assert fn(ctypes.byref(e), null) != 0 and b"bad sizes" in lib.mfx_last_error()      # B == 0
+    e.B, e.num_classes, e.num_k = 1, 3, 2
+    assert lib.mfx_kitti_eval_overlaps(ctypes.byref(e), null) != 0 and b"pointer" in lib.mfx_last_error()
+    assert lib.mfx_decode_topk(None, 0, 0, 0, 3, 1, 96, 320, 50, None, None, None, 0, null) != 0
+    assert lib.mfx_heads_fused(None, null) != 0 and lib.mfx_conv2d_nhwc(None, null) != 0 and lib.mfx_dcn_nhwc(None, null) != 0
+    with pytest.raises(RuntimeError, match="mfx_conv2d_nhwc failed"):
+        L.check(lib.mfx_conv2d_nhwc(None, null), "mfx_conv2d_nhwc")
