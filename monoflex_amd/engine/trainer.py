@@ -46,12 +46,26 @@ class PreparedTargets(list):
     capture): `.edge` = (edge_indices, edge_lens) for the predictor, `.loss` = (heat maps, stacked fields) for the loss."""
 
 
-def prepare_targets(model, targets, device):
+def prepare_targets(model, targets, device, fields=None):
+    """Per-image targets -> PreparedTargets. `fields`: the batch-stacked device tensors a DeviceLoader batch carries
+    (`batch["fields"]`, produced by the target-encoding kernels): with them nothing is re-stacked per image."""
     from ..model.head.detector_predictor import stack_edge_fields
     m = model.module if hasattr(model, "module") else model
     pt = PreparedTargets(targets)
-    pt.edge = stack_edge_fields(targets, device)
-    pt.loss = m.heads.loss_evaluator.prepare_targets(targets, device)
+    if fields is None:
+        pt.edge = stack_edge_fields(targets, device)
+        pt.loss = m.heads.loss_evaluator.prepare_targets(targets, device)
+        return pt
+    dev = torch.device(device)
+    pt.edge = (fields["edge_indices"].to(device=dev, dtype=torch.int32).contiguous(), fields["edge_len"].to(device=dev, dtype=torch.int32).contiguous())
+    names = ("cls_ids", "target_centers", "keypoints", "keypoints_depth_mask", "dimensions", "locations", "rotys", "alphas",
+             "orientations", "pad_size", "reg_mask", "reg_weight", "offset_3D", "trunc_mask")
+    d = {n: fields[n].to(dev) for n in names}
+    d["bboxes"] = fields["2d_bboxes"].to(dev)
+    calibs = [t.get_field("calib") for t in targets]
+    d["calib"] = calibs
+    d["calib_f32"] = torch.tensor([[c.f_u, c.f_v, c.c_u, c.c_v, c.b_x, c.b_y] for c in calibs], dtype=torch.float32).to(dev)
+    pt.loss = (fields["hm"].to(dev), d)
     return pt
 
 

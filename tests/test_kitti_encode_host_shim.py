@@ -182,3 +182,40 @@ def test_dataset_front_on_generated_directory(tmp_path):
         KITTIDataset(cfg, str(tmp_path), is_train=False)                     # no ImageSets/val.txt
     with pytest.raises(RuntimeError):
         ds.encode_batch([raw]) if not torch.cuda.is_available() else (_ for _ in ()).throw(RuntimeError("gpu present"))
+
+
+def test_prepared_targets_from_stacked_fields_equal_the_per_image_path(shim):
+    """engine.trainer.prepare_targets(fields=...) (the DeviceLoader fast path) builds the same loss / edge inputs as
+    stacking the per-image ParamsLists, and the loss evaluated on both is identical (CPU tensors; no GPU work)."""
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.data.datasets.kitti_utils import Calibration
+    from monoflex_amd.engine.trainer import prepare_targets
+    from monoflex_amd.model.head.detector_loss import make_loss_evaluator
+    from monoflex_amd.structures.params_3d import ParamsList
+    samples = [golden_sample(n)[:4] for n in ("s00", "s03", "s07")]
+    fields = {k: torch.from_numpy(v) for k, v in run_shim(shim, samples).items()}
+    targets = []
+    for b, (_, w, h, flip) in enumerate(samples):
+        t = ParamsList(image_size=(1280, 384), is_train=True)
+        for k in ("cls_ids", "target_centers", "keypoints", "keypoints_depth_mask", "dimensions", "locations", "reg_mask", "reg_weight",
+                  "offset_3D", "2d_bboxes", "pad_size", "rotys", "trunc_mask", "alphas", "orientations", "hm", "edge_len", "edge_indices"):
+            t.add_field(k, fields[k][b])
+        c = Calibration.from_matrix(S.KITTI_P2)
+        t.add_field("calib", c.flipped(w) if flip else c)
+        targets.append(t)
+
+    class _M:                                                      # the two attributes prepare_targets touches
+        pass
+    m = _M(); m.heads = _M()
+    m.heads.loss_evaluator = make_loss_evaluator(get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml")))
+    slow, fast = prepare_targets(m, targets, "cpu"), prepare_targets(m, targets, "cpu", fields=fields)
+    assert torch.equal(slow.edge[0], fast.edge[0]) and torch.equal(slow.edge[1], fast.edge[1])
+    assert torch.equal(slow.loss[0], fast.loss[0]) and set(slow.loss[1]) - {"ori_imgs"} == set(fast.loss[1])
+    for k, v in fast.loss[1].items():
+        if torch.is_tensor(v):
+            assert torch.equal(v, slow.loss[1][k]) and v.dtype == slow.loss[1][k].dtype, k
+    g = torch.Generator().manual_seed(0)
+    pred = {"cls": torch.rand(3, 3, 96, 320, generator=g).clamp(1e-4, 1 - 1e-4), "reg": torch.randn(3, 50, 96, 320, generator=g) * 0.1}
+    a, _ = m.heads.loss_evaluator(pred, slow)
+    b, _ = m.heads.loss_evaluator(pred, fast)
+    assert all(float(a[k]) == float(b[k]) for k in a)
