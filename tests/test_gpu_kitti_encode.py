@@ -117,7 +117,12 @@ def test_dataset_loader_feeds_a_training_step(tmp_path):
     model = KeypointDetector(cfg).cuda().train()
     loss_dict, log = model(batch["images"], list(batch["targets"]))
     total = sum(loss_dict.values())
-    assert torch.isfinite(total) and float(total) > 0
+    assert torch.isfinite(total) and float(total.detach()) > 0
+    from monoflex_amd.engine.trainer import prepare_targets
+    fast = prepare_targets(model, batch["targets"], "cuda", fields=batch["fields"])        # no per-image re-stacking
+    slow = prepare_targets(model, batch["targets"], "cuda")
+    assert torch.equal(fast.edge[0], slow.edge[0]) and torch.equal(fast.loss[0], slow.loss[0])
+    assert all(torch.equal(v, slow.loss[1][k]) for k, v in fast.loss[1].items() if torch.is_tensor(v))
     total.backward()
     g = model.backbone.base.base_layer[0].weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
