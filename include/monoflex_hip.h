@@ -38,8 +38,13 @@ enum { MFX_OK = 0, MFX_ERR_ARG = -1, MFX_ERR_UNSUPPORTED = -2, MFX_ERR_LAUNCH = 
 
 int mfx_abi_version(void);
 const char* mfx_last_error(void);
-/* tuning/debug overrides: "conv_tile" | "dcn_tile" | "cat_tile" (tile id, 0 = automatic), "kc" (4 | 8 | 0),
- * "halo" (0 = generic kernel only, 1 = automatic, 2.. = force LDS-halo variant), "halo_cg", "dcn_wave" (same convention) */
+/* Threading: one host thread per process drives the library, like the reference (one process per GPU). Entry points
+ * only enqueue work on the stream they are given and never synchronise; mfx_last_error() is thread-local; the options below and
+ * the one-time kernel attribute setup are process-wide and unsynchronised -- set options before concurrent use.
+ * Tuning/debug overrides: "conv_tile" | "dcn_tile" | "cat_tile" (tile id, 0 = automatic), "kc" (4 | 8 | 0),
+ * "halo" (0 = generic kernel only, 1 = automatic, 2.. = force LDS-halo variant), "halo_cg", "dcn_wave", "dcn_patch" (same
+ * convention), "ksplit" / "dcn_ksplit" (split-K factor), "topk_strips" (row strips of the top-K stage, 1 = single workgroup),
+ * "wgrad_*" / "dcn_wgrad_m" (training GEMM partitioning). Unknown names return MFX_ERR_ARG. */
 int mfx_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------
