@@ -298,9 +298,10 @@ def sample_thresholds(scores, num_gt, npts=41):
     return out
 
 
-def precision_curves(gts, dts, classes, metric, min_overlaps, aos=False):
-    """eval.py:448-570 -> precision, recall, aos arrays [class, level, overlap set, 41]."""
-    ovs = [image_overlaps(d, g, metric) for g, d in zip(gts, dts)]
+def precision_curves(gts, dts, classes, metric, min_overlaps, aos=False, overlaps=None, tables=None):
+    """eval.py:448-570 -> precision, recall, aos arrays [class, level, overlap set, 41].  `overlaps`: per-image (num_dt, num_gt)
+    matrices to use instead of computing them; `tables`: dict that receives {(m, level, k): (thresholds, pr)}."""
+    ovs = overlaps if overlaps is not None else [image_overlaps(d, g, metric) for g, d in zip(gts, dts)]
     nc, nk = len(classes), len(min_overlaps)
     prec, rec, ori = (np.zeros((nc, 3, nk, 41)) for _ in range(3))
     for m, cls in enumerate(classes):
@@ -320,6 +321,8 @@ def precision_curves(gts, dts, classes, metric, min_overlaps, aos=False):
                         pr[t, :3] += (tp, fp, fn)
                         if sim != -1:
                             pr[t, 3] += sim
+                if tables is not None:
+                    tables[(m, level, k)] = (list(ths), pr.copy(), total_valid)
                 with np.errstate(divide="ignore", invalid="ignore"):
                     for t in range(len(ths)):
                         rec[m, level, k, t] = pr[t, 0] / (pr[t, 0] + pr[t, 2])

@@ -8,14 +8,23 @@
 
 using namespace mfx::keval;
 
+static void matching_steps(const mfx_kitti_eval_desc& d);
+
 extern "C" void shim_kitti_eval(const mfx_kitti_eval_desc* dp) {
   const mfx_kitti_eval_desc& d = *dp;
-  const int n_comb = d.num_classes * 9 * d.num_k;
   for (int b = 0; b < d.B; ++b) {
     const int ng = d.gt_off[b + 1] - d.gt_off[b], nd = d.dt_off[b + 1] - d.dt_off[b];
     for (int j = 0; j < nd; ++j)
       for (int i = 0; i < ng; ++i) pair_overlaps(d, b, j, i);
   }
+  matching_steps(d);
+}
+
+// steps 2-4 on overlap matrices supplied by the caller (lets a test feed arbitrary overlaps to the matching logic)
+extern "C" void shim_kitti_eval_match_only(const mfx_kitti_eval_desc* dp) { matching_steps(*dp); }
+
+static void matching_steps(const mfx_kitti_eval_desc& d) {
+  const int n_comb = d.num_classes * 9 * d.num_k;
   for (long i = 0; i < (long)n_comb * PTS * 4; ++i) d.pr[i] = 0.0;
   for (int i = 0; i < d.num_classes * 3; ++i) d.num_valid_gt[i] = 0;
   for (int b = 0; b < d.B; ++b)

@@ -116,3 +116,75 @@ def test_shim_subset_of_classes_and_no_orientation(shim, monkeypatch):
         a["alpha"][:] = -10
     otext, oret = R.official_result(ga, da, (0,), "R40")
     assert text == otext and all(abs(ret[k] - oret[k]) < 1e-9 for k in oret)
+
+
+def _random_records(rs, n, with_score):
+    """Random box records that exercise every ignore rule: all name codes, heights around the 25/40 px limits, occlusion
+    0..3, truncation around 0.15/0.3/0.5, scores on a coarse grid (ties)."""
+    r = np.zeros((n, 16))
+    r[:, 0] = rs.choice([0, 0, 0, 1, 1, 2, 2, 3, 4, 5, 6, 7], n) if not with_score else rs.choice([0, 0, 1, 2], n)
+    r[:, 1] = rs.choice([0.0, 0.1, 0.15, 0.2, 0.3, 0.4, 0.5, 0.6], n)
+    r[:, 2] = rs.randint(0, 4, n)
+    r[:, 3] = rs.uniform(-3, 3, n)
+    r[:, 4], r[:, 5] = rs.uniform(0, 1000, n), rs.uniform(0, 300, n)
+    r[:, 6] = r[:, 4] + rs.uniform(5, 120, n)
+    r[:, 7] = r[:, 5] + rs.choice([20.0, 25.0, 25.5, 39.0, 40.0, 40.5, 60.0], n)
+    r[:, 8:11] = rs.uniform(0.5, 4, (n, 3))
+    r[:, 11:14] = rs.uniform(-20, 60, (n, 3))
+    r[:, 14] = rs.uniform(-3, 3, n)
+    r[:, 15] = np.round(rs.uniform(0.05, 1.0, n), 2) if with_score else 0.0
+    return r
+
+
+def _as_annos(rec):
+    names = np.array(["Car", "Pedestrian", "Cyclist", "Van", "Person_sitting", "Truck", "DontCare", "Tram"])
+    return dict(name=names[rec[:, 0].astype(int)], truncated=rec[:, 1], occluded=rec[:, 2].astype(int), alpha=rec[:, 3], bbox=rec[:, 4:8],
+                dimensions=rec[:, 8:11], location=rec[:, 11:14], rotation_y=rec[:, 14], score=rec[:, 15])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_matching_logic_on_arbitrary_overlaps(shim, seed):
+    """Steps 2-4 (ignore rules, both greedy passes, threshold sampling, PR accumulation) on random boxes and RANDOM overlap
+    matrices -- including values exactly at the matching thresholds and tied scores -- against the oracle's restatement of
+    the reference loops: thresholds, tp, fp, fn identical, orientation similarity to 1e-12, for all 54 combinations."""
+    rs = np.random.RandomState(seed)
+    B = 120
+    gts = [_random_records(rs, int(rs.randint(0, 12)), False) for _ in range(B)]
+    dts = [_random_records(rs, int(rs.randint(0, 15)), True) for _ in range(B)]
+    grid = np.array([0.0, 0.1, 0.25, 0.3, 0.5, 0.6, 0.7, 0.9])
+    ovs = [[rs.choice(grid, (len(d), len(g))) * (rs.rand(len(d), len(g)) < 0.7) for g, d in zip(gts, dts)] for _ in range(3)]
+    classes = [0, 1, 2]
+    mo = np.stack([np.array([[0.7, 0.5, 0.5]] * 3), np.array([[0.7, 0.5, 0.5], [0.5, 0.25, 0.25], [0.5, 0.25, 0.25]])], 0)
+    arrays, sz, aos = EV.pack_eval_inputs(gts, dts, classes, mo)
+    assert aos
+    n_comb = 54
+    flat = np.zeros((3, max(sz["n_pairs"], 1)))
+    for m in range(3):
+        for b in range(B):
+            flat[m, arrays["pair_off"][b]:arrays["pair_off"][b + 1]] = ovs[m][b].reshape(-1)
+    out = dict(overlaps=flat, tp_scores=np.zeros((n_comb, max(sz["n_gt"], 1))), thresholds=np.zeros((n_comb, 41)),
+               pr=np.zeros((n_comb, 41, 4)), num_valid_gt=np.zeros((3, 3), np.int32), num_thresholds=np.zeros(n_comb, np.int32))
+    d = L.KittiEvalDesc()
+    for k, a in list(arrays.items()) + list(out.items()):
+        setattr(d, k, a.ctypes.data)
+    for k, v in sz.items():
+        setattr(d, k, v)
+    d.compute_aos = 1
+    shim.shim_kitti_eval_match_only.argtypes = [ctypes.POINTER(L.KittiEvalDesc)]
+    shim.shim_kitti_eval_match_only.restype = None
+    shim.shim_kitti_eval_match_only(ctypes.byref(d))
+    ga, da = [_as_annos(g) for g in gts], [_as_annos(x) for x in dts]
+    checked = 0
+    for metric in range(3):
+        tables = {}
+        R.precision_curves(ga, da, classes, metric, mo, aos=(metric == 0), overlaps=ovs[metric], tables=tables)
+        for (m, level, k), (ths, pr, nvalid) in tables.items():
+            comb = ((m * 3 + level) * 3 + metric) * 2 + k
+            assert out["num_valid_gt"][m, level] == nvalid
+            assert out["num_thresholds"][comb] == len(ths), (metric, m, level, k)
+            assert np.array_equal(out["thresholds"][comb, :len(ths)], np.array(ths))
+            got = out["pr"][comb, :len(ths)]
+            assert np.array_equal(got[:, :3], pr[:, :3]), (metric, m, level, k)
+            assert np.allclose(got[:, 3], pr[:, 3], rtol=0, atol=1e-12)
+            checked += len(ths)
+    assert checked > 300
