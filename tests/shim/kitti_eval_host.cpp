@@ -53,3 +53,8 @@ static void matching_steps(const mfx_kitti_eval_desc& d) {
         if (s.sim != -1.0) pr[3] += s.sim;
       }
 }
+
+// intersection areas of box pairs (cx, cy, dx, dy, angle), for the geometric property test
+extern "C" void shim_rotated_intersections(const float* a, const float* b, int n, float* out) {
+  for (int i = 0; i < n; ++i) out[i] = rotated_intersection(a + 5 * i, b + 5 * i);
+}
