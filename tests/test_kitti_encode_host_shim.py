@@ -219,3 +219,88 @@ def test_prepared_targets_from_stacked_fields_equal_the_per_image_path(shim):
     a, _ = m.heads.loss_evaluator(pred, slow)
     b, _ = m.heads.loss_evaluator(pred, fast)
     assert all(float(a[k]) == float(b[k]) for k in a)
+
+
+@pytest.fixture
+def cpu_encoders(shim, monkeypatch):
+    """Stand in for the two GPU launches with the host build of the same device functions, so that the dataset / loader
+    front (field lists, splits, calibration flips, batching, worker processes) can be exercised end to end on CPU."""
+    import monoflex_amd.data.datasets.kitti as DK
+
+    def encode(records, Ps, sizes, flips, params, device, check=True):
+        inp = E.pack_inputs(records, Ps, sizes, flips, params)
+        dims, B = params.dims(), len(records)
+        out = {n: np.zeros((B,) + tuple(dims.get(s, s) for s in sh), dtype=NP_DTYPES[dt]) for n, (_, sh, dt) in E.TARGET_FIELDS.items()}
+        d = L.KittiDesc()
+        for k, a in inp.items():
+            setattr(d, k, a.ctypes.data)
+        for n, (member, _, _) in E.TARGET_FIELDS.items():
+            setattr(d, member, out[n].ctypes.data)
+        d.B, d.max_objs, d.in_w, d.in_h, d.down, d.num_classes = B, params.max_objs, params.in_w, params.in_h, params.down, params.num_classes
+        d.filter_trunc, d.filter_size, d.edge_ratio = params.filter_trunc, params.filter_size, params.edge_ratio
+        shim.shim_kitti_encode(ctypes.byref(d))
+        return {k: torch.from_numpy(v) for k, v in out.items()}
+
+    def frames(fr, flips, params, device, mean, std):
+        return torch.from_numpy(np.stack([K.transform_image(f, bool(fl)) for f, fl in zip(fr, flips)]))
+    monkeypatch.setattr(DK, "encode_targets", encode)
+    monkeypatch.setattr(DK, "preprocess_images", frames)
+
+
+def _kitti_dir(tmp_path, n=3, splits=("train", "val", "test")):
+    from PIL import Image
+    for d in ("image_2", "label_2", "calib", "ImageSets"):
+        (tmp_path / d).mkdir()
+    P = np.asarray(S.KITTI_P2).reshape(-1)
+    sizes = [(1242, 375), (1224, 370), (1238, 374)]
+    for i in range(n):
+        w, h = sizes[i % 3]
+        Image.fromarray(np.random.RandomState(i).randint(0, 256, (h, w, 3)).astype(np.uint8)).save(tmp_path / "image_2" / ("%06d.png" % i))
+        (tmp_path / "label_2" / ("%06d.txt" % i)).write_text("".join(l + "\n" for l in S.synthetic_kitti_labels(40 + i, w, h, 9)))
+        (tmp_path / "calib" / ("%06d.txt" % i)).write_text("P2: " + " ".join("%.12e" % v for v in P) + "\nP3: " + " ".join("%.12e" % v for v in P) + "\n")
+    for s in splits:
+        (tmp_path / "ImageSets" / (s + ".txt")).write_text("".join("%06d\n" % i for i in range(n)))
+    return sizes
+
+
+def test_dataset_and_loader_front_end_to_end_on_cpu(tmp_path, cpu_encoders):
+    import random
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.data import DeviceLoader, InferenceSampler, IterationBatchSampler, KITTIDataset, TrainingSampler
+    sizes = _kitti_dir(tmp_path)
+    cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"))
+    train = KITTIDataset(cfg, str(tmp_path), is_train=True, device="cpu")
+    img, tgt, idx = train[1]
+    want = ["cls_ids", "target_centers", "keypoints", "keypoints_depth_mask", "dimensions", "locations", "calib", "reg_mask", "reg_weight",
+            "offset_3D", "2d_bboxes", "pad_size", "rotys", "trunc_mask", "alphas", "orientations", "hm", "gt_bboxes", "occlusions",
+            "truncations", "edge_len", "edge_indices"]
+    assert tgt.fields() == want and img.shape == (3, 384, 1280) and idx == "000001" and tgt.size == (1280, 384)   # kitti.py:496-523 order
+    # the flip coin flips image, labels and calibration together
+    random.seed(3)
+    raws = [train.load_raw(0) for _ in range(12)]
+    assert {r.flip for r in raws} == {True, False}
+    flipped = next(r for r in raws if r.flip)
+    _, (t,), _, fields = train.encode_batch([flipped])
+    ref = K.encode_sample(S.synthetic_kitti_labels(40, *sizes[0], 9), S.KITTI_P2, *sizes[0], do_flip=True)
+    compare_fields({k: t.get_field(k).numpy() for k in ref if k in want and k != "calib"}, ref, "flipped")
+    assert np.isclose(t.get_field("calib").c_u, sizes[0][0] - S.KITTI_P2[0][2] - 1) and np.allclose(fields["P"][0].numpy(), ref["P"])
+    # val split: labels, no augmentation; test split: four fields only (kitti.py:287-299)
+    val = KITTIDataset(cfg, str(tmp_path), is_train=False, device="cpu")
+    want_objects = int(K.encode_sample(S.synthetic_kitti_labels(40, *sizes[0], 9), S.KITTI_P2, *sizes[0])["reg_mask"].sum())
+    assert val.split == "val" and val.flip_p == 0 and int(val[0][1].get_field("reg_mask").sum()) == want_objects
+    assert len(val[0][1]) == 0 and len(train[0][1]) in (want_objects, len(train[0][1]))    # ParamsList.__len__ counts objects in training mode only
+    cfg2 = cfg.clone(); cfg2.DATASETS.TEST_SPLIT = "test"
+    test = KITTIDataset(cfg2, str(tmp_path), is_train=False, device="cpu")
+    assert test[2][1].fields() == ["pad_size", "calib", "edge_len", "edge_indices"] and int(test[2][1].get_field("edge_len")) == K.edge_indices(*sizes[2], K.pad_size(*sizes[2]))[1]
+    # loaders: inference shard in order, iteration-based training batches from worker processes
+    batches = list(DeviceLoader(val, batch_size=2, sampler=InferenceSampler(len(val))))
+    assert [b["img_ids"] for b in batches] == [("000000", "000001"), ("000002",)] and batches[0]["images"].tensors.shape == (2, 3, 384, 1280)
+    bs = IterationBatchSampler(TrainingSampler(len(train), seed=5), batch_size=2, num_iterations=3)
+    out = list(DeviceLoader(train, batch_sampler=bs, num_workers=2))
+    assert len(out) == 3 and all(len(b["targets"]) == 2 and b["fields"]["hm"].shape == (2, 3, 96, 320) for b in out)
+    g = torch.Generator(); g.manual_seed(5)
+    stream = torch.randperm(3, generator=g).tolist() + torch.randperm(3, generator=g).tolist()
+    assert [i for b in out for i in b["img_ids"]] == ["%06d" % i for i in stream]
+    with pytest.raises(NotImplementedError):
+        c3 = cfg.clone(); c3.INPUT.HEATMAP_CENTER = "2D"
+        KITTIDataset(c3, str(tmp_path), is_train=True)
