@@ -186,3 +186,23 @@ def test_c_abi_argument_errors_need_no_gpu():
     assert lib.mfx_heads_fused(None, null) != 0 and lib.mfx_conv2d_nhwc(None, null) != 0 and lib.mfx_dcn_nhwc(None, null) != 0
     with pytest.raises(RuntimeError, match="mfx_conv2d_nhwc failed"):
         L.check(lib.mfx_conv2d_nhwc(None, null), "mfx_conv2d_nhwc")
+
+
+def test_product_code_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import oracle/; the package itself must not."""
+    import re
+    imp = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b|from\s+\.+\s*oracle\b)|importlib\.import_module\([\"\']oracle", re.M)
+    offenders = []
+    for d, _, files in os.walk(os.path.join(ROOT, "monoflex_amd")):
+        for f in files:
+            if f.endswith(".py") and imp.search(open(os.path.join(d, f), errors="ignore").read()):
+                offenders.append(os.path.relpath(os.path.join(d, f), ROOT))
+    assert offenders == [], offenders
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    start = bench.index("def cpu_baseline")
+    end = bench.index("\ndef ", start + 10)
+    hits = [m.start() for m in imp.finditer(bench)]
+    assert hits and all(start <= h < end for h in hits), "bench.py may use the oracle only inside cpu_baseline()"
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    s0 = entry.index("def smoke")
+    assert all(h >= s0 or "dcn_ref" in entry[h:h + 80] for h in [m.start() for m in imp.finditer(entry)])   # build() only compiles the checker
