@@ -183,10 +183,13 @@ def get_official_eval_result(gts, dts, current_classes, metric="R40", device="cu
     return text, ret
 
 
-def evaluate_python(label_path, result_path, label_split_file, current_class, metric="R40", device="cuda"):
-    """data/datasets/evaluation/__init__.py:31-34 -> evaluate.py:17-32."""
+def evaluate_python(label_path, result_path, label_split_file, current_class, metric="R40", score_thresh=-1, device="cuda"):
+    """data/datasets/evaluation/__init__.py:31-34 -> evaluate.py:17-32. `score_thresh` > 0 drops detections scoring below it
+    before the evaluation (kitti_common.py:191-202)."""
     with open(label_split_file) as f:
         ids = [int(line) for line in f.readlines()]
     dts = read_label_folder(result_path)
+    if score_thresh > 0:
+        dts = [d[d[:, 15] >= score_thresh] for d in dts]
     gts = read_label_folder(label_path, ids)
     return get_official_eval_result(gts, dts, current_class, metric=metric, device=device)

@@ -537,6 +537,10 @@ def run_eval_cases():
         out["keys_" + metric] = np.array(sorted(ret.keys()))
         out["values_" + metric] = np.array([float(ret[k]) for k in sorted(ret.keys())])
         print(metric, {k: round(float(v), 3) for k, v in sorted(ret.items()) if "moderate" in k})
+    # (the COCO-style path of the reference, get_coco_eval_result, passes a float `num` to np.linspace and fails on numpy >= 1.18)
+    result, ret = ref_eval.evaluate(label_dir, result_dir, split, current_class=["Car"], score_thresh=0.5, metric="R40")
+    out["result_thresh"], out["keys_thresh"] = np.array(result), np.array(sorted(ret.keys()))
+    out["values_thresh"] = np.array([float(ret[k]) for k in sorted(ret.keys())])
     out["meta"] = np.array("reference evaluate.py/eval.py/rotate_iou.py/kitti_common.py executed with numba emulated in Python "
                            "(identity jit; SIMT emulation of numba.cuda; numpy scalar arithmetic); numpy %s" % np.__version__)
     np.savez_compressed(os.path.join(GOLD, "kitti_eval.npz"), **out)

@@ -235,3 +235,20 @@ def test_rotated_intersection_is_geometrically_right(shim):
     assert np.percentile(err, 99) < 1e-4 and err.max() < 5e-3, (float(np.percentile(err, 99)), float(err.max()))
     ora = np.array([R.rotated_intersection(a[i], b[i]) for i in range(300)])       # and the oracle agrees with the device functions
     assert np.abs(ora - out[:300]).max() < 1e-4
+
+
+def test_evaluate_python_with_score_threshold(shim, monkeypatch, tmp_path):
+    """The file-level entry point with score_thresh (evaluate.py:17-32, kitti_common.py:191-202) against the reference run."""
+    monkeypatch.setattr(EV, "pr_table", lambda g, d, c, mo, device="cuda": shim_pr_table(shim, g, d, c, mo))
+    label_dir, result_dir = tmp_path / "label_2", tmp_path / "data"
+    label_dir.mkdir(); result_dir.mkdir()
+    for i in range(N_IMG):
+        (label_dir / ("%06d.txt" % i)).write_text(str(GOLD["labels_%d" % i]))
+        EV.generate_kitti_3d_detection(GOLD["det_%d" % i], str(result_dir / ("%06d.txt" % i)))
+    (tmp_path / "val.txt").write_text("".join("%06d\n" % i for i in range(N_IMG)))
+    text, ret = EV.evaluate_python(str(label_dir), str(result_dir), str(tmp_path / "val.txt"), ["Car"], metric="R40", score_thresh=0.5)
+    keys = [str(k) for k in GOLD["keys_thresh"]]
+    assert sorted(ret) == keys and text == str(GOLD["result_thresh"])
+    np.testing.assert_allclose(np.array([float(ret[k]) for k in keys]), GOLD["values_thresh"], rtol=1e-12, atol=1e-12)
+    full, _ = EV.evaluate_python(str(label_dir), str(result_dir), str(tmp_path / "val.txt"), ("Car", "Pedestrian", "Cyclist"))
+    assert full == str(GOLD["result_R40"])
