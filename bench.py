@@ -1,59 +1,93 @@
 #!/usr/bin/env python
-"""bench.py -- images/sec of the MonoFlex hot path on MI355X.
+"""bench.py -- images/sec of the MonoFlex hot path on MI355X (BASELINE.json metric).
 
-One "step" = DLA-34 + DCNv2 + all heads forward + decode over one batch of synthetic 1280x384
-images already resident in HBM (BASELINE.json configs[1]: batch 8 per GPU, bf16).  N>1: one
-process per GPU (torchrun), independent replicas over disjoint image shards -- the inference path
-has no exchange step, so there is no collective in the timed region (weak scaling).
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train] [--batch B] [--dtype bf16|fp32]
 
-Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).
+--mode infer (default; BASELINE configs[1] / C5 with --batch 32): one "step" = DLA-34 + DCNv2 + all heads forward +
+    NMS / top-K / 3D decode over one batch of synthetic 1280x384 images already resident in HBM, replayed from one hipGraph.
+    N > 1: one process per GPU, independent replicas over disjoint image shards -- the inference path has no exchange
+    step, so there is no collective in the timed region (weak scaling).
+--mode train (configs[2]/[3], the second half of the metric): one "step" = forward + 11 losses + backward + AdamW at
+    `--batch` images per GPU; N > 1 = data parallel, gradients averaged by an RCCL all-reduce of one flat fp32 buffer
+    between the captured forward/backward graph and the captured optimizer graph (engine/trainer.GraphedTrainStep).
+
+N > 1 without a torchrun environment: this script re-executes itself under `python -m torch.distributed.run` (one rank
+per GPU, rendezvous on 127.0.0.1), so `python bench.py --gpus 8` is a complete command.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import ast
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-
 FWD_GFLOP_PER_IMG = 177.99          # SURVEY 8d / BASELINE.md section 3 (2 x 88.997 GMAC)
+TRAIN_GFLOP_PER_IMG = 3 * FWD_GFLOP_PER_IMG          # dgrad + wgrad each ~ forward
 HEADS_GFLOP_PER_IMG = 2 * 41.185    # Appendix A: 9 x (3x3 64->256 + 1x1) per image
 PEAK_BF16_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_F32_TFLOPS = 157.3
+HEADS_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_heads_traffic.json")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"])
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-images", type=int, default=6)
-    return ap.parse_args()
+    ap.add_argument("--sync-bn", action="store_true", help="train mode, N > 1: synchronised BatchNorm statistics")
+    ap.add_argument("--opts", default="", help="library tuning options k=v,... (mfx_set_option), for experiments")
+    a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 30 if a.mode == "infer" else 10
+    if a.warmup is None:
+        a.warmup = 5 if a.mode == "infer" else 3
+    return a
 
 
-def build_model(dtype, device):
+def respawn_under_torchrun(args):
+    """`bench.py --gpus N` outside a torchrun environment: start N ranks (reference engine/launch.py:23-89 does the
+    same with mp.spawn + NCCL init) and hand over the exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def build_model(dtype, device, train=False):
     from monoflex_amd import synthetic as S
     from monoflex_amd.config import get_cfg
     from monoflex_amd.model.detector import KeypointDetector
     cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"))
     cfg.MODEL.PRETRAIN = False
-    cfg.DATASETS.TEST_SPLIT = "test"
+    if not train:
+        cfg.DATASETS.TEST_SPLIT = "test"
     cfg.MODEL.COMPUTE_DTYPE = dtype
-    m = KeypointDetector(cfg).eval()
-    sd = S.synthetic_state_dict(m.state_dict(), seed=0, cls_bias=-1.0)      # -1.0: all 50 slots pass 0.2 (worst-case decode)
+    m = KeypointDetector(cfg)
+    m = m.train() if train else m.eval()
+    # cls_bias -1.0: all 50 slots pass 0.2 (worst-case decode)
+    sd = S.synthetic_state_dict(m.state_dict(), seed=0, **({} if train else {"cls_bias": -1.0}))
     m.load_state_dict(sd)
-    return m.to(device), sd
+    return m.to(device), sd, cfg
 
 
 def cpu_baseline(sd, n_images):
-    """The oracle (CPU port of the reference path) timed on this host's cores: forward+decode, B=1 per call."""
+    """The oracle (CPU port of the reference path) timed on this host's cores.  Two bounded samples: forward+decode at
+    B=1 (the bench's own workload, `value`) and BASELINE configs[0] (C1: backbone forward on 4 images)."""
+    import torch
     from monoflex_amd import synthetic as S
     from oracle import monoflex_ref as R
     ref = R.KeypointDetectorRef().eval()
@@ -65,27 +99,76 @@ def cpu_baseline(sd, n_images):
         img = S.synthetic_images(1, 384, 1280, seed=2000 + i)
         ref.detect(img, [tgt])
     dt = time.time() - t0
-    return {"value": round(n_images / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d x (1,3,384,1280) image, forward+decode, oracle/monoflex_ref.py (torch fp32 convs + C DCN, "
-                      "OpenMP), %.1f s" % (n_images, dt)}
+    out = {"value": round(n_images / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "%d x (1,3,384,1280) image, forward+decode, oracle/monoflex_ref.py (torch fp32 convs + C DCN, "
+                     "OpenMP), %.1f s" % (n_images, dt)}
+    try:
+        imgs = S.synthetic_images(4, 384, 1280, seed=1000)
+        t0 = time.time()
+        with torch.no_grad():
+            ref.backbone(imgs)
+        dt = time.time() - t0
+        out["c1_backbone_b4"] = {"value": round(4 / dt, 4), "unit": "images/s",
+                                 "sample": "BASELINE configs[0]: DLA-34+DCNv2 backbone forward on 4 x 1280x384, %.1f s" % dt}
+    except Exception as e:                                             # noqa: BLE001
+        out["c1_backbone_b4"] = {"value": None, "sample": "failed: %s" % e}
+    return out
 
 
-def main():
-    args = parse()
-    from monoflex_amd import parallel
-    rank, world, local_rank = parallel.init_from_env(backend="nccl")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d (launch with torchrun for N>1)" % (args.gpus, world), file=sys.stderr)
+def deviation_vs_reference(out, dtype):
+    """Image 0 of rank 0's batch is the image of tests/golden/e2e_full.npz (seed 1000, same weights): how far the
+    benchmarked mode is from the REFERENCE's own outputs (logits at 512 + 50 pixels, top-K set, (N,14) rows)."""
+    import numpy as np
+    import torch
+    g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_full.npz"))
+    meta = ast.literal_eval(str(g["meta"]))
+    if meta["seeds"][0] != 1000 or meta["cls_bias"] != -1.0:
+        return None
+    det, topk, valid, hm = [t[0].float().cpu() for t in out]
+    pix = torch.as_tensor(g["img0_pix"])
+    dl = float(np.abs(hm[..., :3].permute(2, 0, 1).reshape(3, -1)[:, pix].numpy() - g["img0_cls_logits_at"]).max())
+    dr = float(np.abs(hm[..., 8:58].permute(2, 0, 1).reshape(50, -1)[:, pix].numpy() - g["img0_reg_at"]).max())
+    mine, ref = topk[:, 1].numpy().astype(np.int64), g["img0_topk_index"]
+    agree = len(set(mine.tolist()) & set(ref.tolist())) / float(len(ref))
+    same_order = bool(np.array_equal(mine, ref))
+    rows, want = det[valid.bool()].numpy(), g["img0_result"]
+    # rows are compared where both sides decoded the same heat-map peak (same class, same order slot)
+    row_delta = None
+    if rows.shape == want.shape and same_order:
+        row_delta = float(np.abs(rows - want).max())
+    return {"golden": "tests/golden/e2e_full.npz (reference KeypointDetector, image seed 1000)", "dtype": dtype,
+            "max_abs_dlogit": round(dl, 6), "max_abs_dreg": round(dr, 6), "topk_index_agreement": round(agree, 4),
+            "topk_identical_order": same_order, "max_abs_row_delta": row_delta,
+            "north_star_bar": "fp32 mode: <=1e-3 on logits, identical top-K (tests/test_gpu_e2e.py)"}
 
-    from monoflex_amd import lib, synthetic as S
+
+def _hip_event_ms(fn, reps):
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def heads_traffic(dtype, B):
+    """HBM bytes per heads launch from the committed PMC pass (rocprofv3 cannot run inside the bench)."""
+    if os.path.exists(HEADS_TRAFFIC_JSON):
+        t = json.load(open(HEADS_TRAFFIC_JSON))
+        if t.get("dtype") == dtype and t.get("batch") == B:
+            return t["traffic_bytes"], t.get("source", os.path.relpath(HEADS_TRAFFIC_JSON, ROOT))
+    return None, None
+
+
+def run_infer(args, rank, world, device):
+    import torch
+    from monoflex_amd import lib, ops, parallel, synthetic as S
     from monoflex_amd.structures.params_3d import make_test_target
+    dist = torch.distributed if world > 1 else None
     lib.load()
-    model, sd = build_model(args.dtype, device)
+    model, sd, _ = build_model(args.dtype, device)
     B = args.batch
     images = S.synthetic_images(B, 384, 1280, seed=parallel.shard_seed(1000, rank, B)).to(device)   # resident in HBM
     targets = [make_test_target(S.synthetic_target(320, 96)) for _ in range(B)]
@@ -124,54 +207,41 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             run()
-            # the (B,50,14) rows + validity mask go back to the host like engine/inference.py:39
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         det, topk, valid, hm = out
-        det_host = det.cpu()
-
-        rate, elapsed, n_img_total = parallel.aggregate_throughput(elapsed, B * args.steps, device=device)
+        rate, elapsed, n_img = parallel.aggregate_throughput(elapsed, B * args.steps, device=device)
 
         # ---- roofline of the dominant kernel (fused heads: 46 % of the forward FLOPs), HIP events on the launch stream
         feat = model.backbone.forward_nhwc(images)
         pk = model.heads.predictor._pack(feat.dtype)
-        from monoflex_amd import ops
         for _ in range(3):
             ops.heads_fused(feat, pk)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        e0.record()
-        for _ in range(reps):
-            ops.heads_fused(feat, pk)
-        e1.record()
-        torch.cuda.synchronize()
-        heads_ms = e0.elapsed_time(e1) / reps
+        heads_ms = _hip_event_ms(lambda: ops.heads_fused(feat, pk), 20)
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "r01_heads_traffic.json")       # PMC pass of the same kernel/config (rocprofv3 cannot run inside the bench)
-    if os.path.exists(tj) and args.dtype == "bf16" and B == 8:
-        traffic = json.load(open(tj))["traffic_bytes"]
-    n_img = n_img_total
+        return None
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     achieved = HEADS_GFLOP_PER_IMG * B / heads_ms                # GFLOP / ms = TFLOP/s
+    traffic, traffic_source = heads_traffic(args.dtype, B)
     res = {
         "metric": "images/sec at 1280x384, DLA-34+DCNv2 forward+decode",
         "value": round(n_img / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "DLA-34+DCNv2+9 heads+edge fusion forward + NMS/top-K/3D decode, batch %d per GPU, "
-                               "1280x384, %s (BASELINE.json configs[1])" % (B, args.dtype),
+                               "1280x384, %s (BASELINE.json configs[%d])" % (B, args.dtype, 4 if B == 32 else 1),
                    "batch_per_gpu": B, "launch": mode, "parallelism": "replicas x%d (no collective on the inference path)" % world,
                    "model_tflops_per_s": round(FWD_GFLOP_PER_IMG * n_img / elapsed / 1e3, 2),
-                   "detections_last_step": int(valid.sum().item())},
+                   "detections_last_step": int(valid.sum().item()),
+                   "h2d_excluded": True, "d2h_excluded": True,
+                   "timed_region": "graph replays only: the fp32 image batch is already in HBM and the (B,50,14) rows stay "
+                                   "on the device (the reference's timer includes the D2H, engine/inference.py:35-43)",
+                   "vs_reference": deviation_vs_reference(out, args.dtype)},
         "roofline": {"kernel": "heads_fused_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "avg_launch_ms": round(heads_ms, 4),
                      "algorithmic_flops_per_launch": HEADS_GFLOP_PER_IMG * B * 1e9},
     }
@@ -183,9 +253,126 @@ def main():
                                    "sample": "failed: %s" % e}
     else:
         res["cpu_baseline"] = None
-    print(json.dumps(res))
-    if dist is not None:
-        dist.destroy_process_group()
+    return res
+
+
+def cpu_train_baseline(n_steps=1):
+    """Reference-shaped training step on the host cores: the oracle network in training mode + the loss module,
+    forward + 11 losses + backward at B=1 (a bounded sample of the same workload)."""
+    import torch
+    from monoflex_amd import synthetic as S
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.model.head.detector_loss import make_loss_evaluator
+    from monoflex_amd.structures.params_3d import make_train_target
+    from oracle import monoflex_ref as R
+    cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"))
+    ref = R.KeypointDetectorRef().train()
+    ref.load_state_dict(S.synthetic_state_dict(ref.state_dict(), seed=0))
+    tgt = S.synthetic_train_target(1000)
+    ei = torch.as_tensor(tgt["edge_indices"]).long()[None]
+    el = torch.as_tensor([int(tgt["edge_len"])]).long()
+    evaluator = make_loss_evaluator(cfg)
+    t0 = time.time()
+    for _ in range(n_steps):
+        maps = ref.forward_maps(S.synthetic_images(1, seed=1000), ei, el)
+        loss_dict, _ = evaluator(maps, [make_train_target(tgt)])
+        sum(loss_dict.values()).backward()
+    dt = time.time() - t0
+    return {"value": round(n_steps / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d x (B=1 forward + 11 losses + backward), oracle/monoflex_ref.py, %.1f s" % (n_steps, dt)}
+
+
+def run_train(args, rank, world, device):
+    import torch
+    from monoflex_amd import lib, parallel, synthetic as S
+    from monoflex_amd.engine.trainer import (GraphedTrainStep, convert_sync_batchnorm, prepare_targets, train_step,
+                                             wrap_data_parallel)
+    from monoflex_amd.solver import build_optimizer
+    from monoflex_amd.structures.params_3d import make_train_target
+    lib.load()
+    model, _, cfg = build_model(args.dtype, device, train=True)
+    model.heads.loss_evaluator.log_as_float = False                  # no host sync inside the step
+    if args.sync_bn and world > 1:
+        convert_sync_batchnorm(model)
+    B = args.batch
+    seed = parallel.shard_seed(1000, rank, B)
+    imgs = S.synthetic_images(B, seed=seed).to(device)
+    targets = [make_train_target(S.synthetic_train_target(seed + i)).to(device) for i in range(B)]
+    targets = prepare_targets(model, targets, device)
+    graphed = not args.no_graph and not (args.sync_bn and world > 1)        # SyncBN collectives sit inside the network
+    opt = build_optimizer(model, cfg, capturable=graphed)
+    if graphed:
+        step = GraphedTrainStep(model, opt, imgs, targets)
+        mode = "hipGraph (fwd+loss+bwd+AdamW)" if world == 1 else "hipGraph fwd+bwd | RCCL all-reduce(flat fp32 grads) | hipGraph AdamW"
+    else:
+        net = wrap_data_parallel(model, device_ids=[device.index]) if world > 1 else model
+        mode = "eager" + (" + torch DDP (bucketed all-reduce overlapped with backward)" if world > 1 else "")
+
+        def step():
+            return train_step(net, opt, imgs, targets)[0]
+    for _ in range(args.warmup):
+        loss = step()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    rate, elapsed, n_img = parallel.aggregate_throughput(elapsed, B * args.steps, device=device)
+    loss_v = float(loss)
+
+    # ---- roofline of the dominant training kernel family, timed live on one representative layer
+    from tools.train_layer_bench import dominant_kernel_roofline
+    roof = dominant_kernel_roofline(args.dtype, B, device)
+    if rank != 0:
+        return None
+    res = {
+        "metric": "images/sec at 1280x384, DLA-34+DCNv2 forward+loss+backward+AdamW (training step)",
+        "value": round(n_img / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "MonoFlex training step (fwd + 11 losses + bwd + AdamW), batch %d per GPU, 1280x384, %s activations, "
+                               "fp32 parameters/gradients (BASELINE.json configs[2]/[3] per-GPU shape)" % (B, args.dtype),
+                   "batch_per_gpu": B, "global_batch": B * world, "launch": mode,
+                   "parallelism": "dp%d" % world if world > 1 else "single GPU", "sync_bn": bool(args.sync_bn and world > 1),
+                   "model_tflops_per_s": round(TRAIN_GFLOP_PER_IMG * n_img / elapsed / 1e3, 2), "loss_last_step": loss_v,
+                   "h2d_excluded": True},
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            res["cpu_baseline"] = cpu_train_baseline()
+        except Exception as e:                                             # noqa: BLE001
+            res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": "failed: %s" % e}
+    else:
+        res["cpu_baseline"] = None
+    return res
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
+    import torch
+    from monoflex_amd import parallel
+    rank, world, local_rank = parallel.init_from_env(backend="nccl")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d" % (args.gpus, world, world), file=sys.stderr)
+    if args.opts:
+        from monoflex_amd import lib
+        for kv in filter(None, args.opts.split(",")):
+            k, v = kv.split("=")
+            lib.check(lib.load().mfx_set_option(k.encode(), int(v)), "set_option")
+    res = run_infer(args, rank, world, device) if args.mode == "infer" else run_train(args, rank, world, device)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

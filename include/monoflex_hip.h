@@ -337,10 +337,12 @@ int mfx_kitti_preprocess_u8(const uint8_t* pixels, const int64_t* offsets, const
  * Box record (MFX_EVAL_REC doubles): [name code, truncated, occluded, alpha, x1, y1, x2, y2, l, h, w, x, y, z, ry, score].
  * Name codes: 0 car, 1 pedestrian, 2 cyclist, 3 van, 4 person_sitting, 5 truck, 6 DontCare, 7 anything else.
  * Images are ragged: boxes of image b are rows [off[b], off[b+1]) of `gt` / `dt`; its overlap block starts at pair_off[b]
- * and is laid out [detection][ground truth]. At most 64 detections per image.
+ * and is laid out [detection][ground truth]. At most MFX_EVAL_MAX_DET (64) detections per image: the offsets are device
+ * data, so the entries cannot validate them -- the caller must (detections past the 64th of an image are ignored).
  * A "combination" c indexes (class m, difficulty l, metric, overlap set k) as ((m*3 + l)*3 + metric)*num_k + k. */
 #define MFX_EVAL_REC 16
 #define MFX_EVAL_PTS 41
+#define MFX_EVAL_MAX_DET 64
 typedef struct {
   const double* gt;            /* (n_gt, 16) */
   const double* dt;            /* (n_dt, 16) */
@@ -350,7 +352,7 @@ typedef struct {
   const int32_t* classes;      /* (num_classes) evaluated name codes, e.g. {0,1,2} */
   const double* min_overlaps;  /* (num_k, 3 metrics, num_classes) */
   double* overlaps;            /* (3, n_pairs): bbox IoU, BEV rotated IoU, 3D IoU */
-  double* tp_scores;           /* (n_comb, n_gt): score of the detection matched to that ground truth, -1 if none */
+  double* tp_scores;           /* (n_comb, n_gt): score of the detection matched to that ground truth, -inf if none (any score sign is kept) */
   int32_t* num_valid_gt;       /* (num_classes, 3) */
   double* thresholds;          /* (n_comb, 41) */
   int32_t* num_thresholds;     /* (n_comb) */

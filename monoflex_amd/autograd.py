@@ -26,6 +26,14 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _device_guarded(cls):
+    """Class decorator: forward/backward of an autograd Function run with their tensors' device current (they launch on
+    `torch.cuda.current_stream()` and keep per-device scratch), so a model on cuda:N works from any current device."""
+    for name in ("forward", "backward"):
+        setattr(cls, name, staticmethod(ops.on_tensor_device(getattr(cls, name))))
+    return cls
+
+
 def _wgrad(x, dy, kh, kw, stride, pad, Ho, Wo, Ck=None, x_pixstride=None, in_hw=None):
     """fp32 (Cout, kh*kw, Ck) weight gradient."""
     B, H, W, Cx = x.shape
@@ -75,6 +83,7 @@ def _pack_weight(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, shift=None
     return ops.PackedConv(packed, None, shift, kh, kw, stride, pad_h, pad_w, 1, ck, rows, cp, K_pad, L.ACT_NONE, frag)
 
 
+@_device_guarded
 class Conv2dFn(Function):
     """y = conv2d(x, weight) (+ bias), k in {1,3}, stride in {1,2}, pad = k//2.  Output channels are padded up to a
     multiple of the 16-byte chunk (extra channels are exactly zero); callers slice."""
@@ -133,6 +142,7 @@ class Conv2dFn(Function):
         return dx, dw, db, None, None, None
 
 
+@_device_guarded
 class CatConv1x1Fn(Function):
     """Root (dla_dcn.py:203-220): y = conv1x1(cat(xs, channel axis), weight) without materialising the concat.
     Backward per source i: dx_i = dy @ W[:, seg_i], dW[:, seg_i] = dy^T x_i."""
@@ -170,6 +180,7 @@ class CatConv1x1Fn(Function):
         return (dw, *dxs)
 
 
+@_device_guarded
 class StemConvFn(Function):
     """7x7 / stride 1 / pad 3 convolution of the NCHW fp32 image batch (dla_dcn.py:268-272); no data gradient."""
 
@@ -213,6 +224,7 @@ def _sync_group(sync):
     return None
 
 
+@_device_guarded
 class BNActFn(Function):
     """Train-mode BatchNorm (batch statistics, biased variance) + activation (+ residual before the activation).
     With `sync` and an initialised multi-rank process group the statistics are those of the global batch
@@ -275,6 +287,7 @@ class BNActFn(Function):
         return dx, local[C:].clone(), local[:C].clone(), None, None, dres, None, None, None, None
 
 
+@_device_guarded
 class MaxPool2x2Fn(Function):
     @staticmethod
     def forward(ctx, x):
@@ -293,6 +306,7 @@ class MaxPool2x2Fn(Function):
         return dx
 
 
+@_device_guarded
 class UpsampleAddFn(Function):
     """y = depthwise ConvTranspose2d(x; k=2f, s=f, p=f/2) + skip   (dla_dcn.py:409-411, 419-425)."""
 
@@ -319,6 +333,7 @@ class UpsampleAddFn(Function):
         return dx, dw.t().reshape(ctx.wshape).contiguous(), dy, None
 
 
+@_device_guarded
 class DCNFn(Function):
     """Modulated deformable conv on NHWC fp32: y = DCNv2(x; offsets, sigmoid(mask logits), weight) + bias.
     `offmask_raw` is the (B,H,W,32) output of the 27-channel offset/mask conv (channels 0..17 offsets,
@@ -378,5 +393,6 @@ def bn_act(x, bn, act, res=None, sync=None):
     mom = bn.momentum if bn.momentum is not None else 0.1
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, act, mom, bn.eps,
-                         bool(getattr(bn, 'sync_bn', False)) if sync is None else sync)
+    if sync is None:                    # torch's own converter (the reference script's literal call) leaves SyncBatchNorm holders
+        sync = bool(getattr(bn, 'sync_bn', False)) or isinstance(bn, torch.nn.SyncBatchNorm)
+    return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, act, mom, bn.eps, sync)

@@ -52,8 +52,8 @@ __global__ void __launch_bounds__(64) keval_thresholds_kernel(mfx_kitti_eval_des
   int m, level, metric, k;
   keval::decode_comb(d, comb, m, level, metric, k);
   const double* s = sorted + (long)comb * d.n_gt;
-  int lo = 0, hi = d.n_gt;                                 // descending, "no match" entries are -1: count the scores >= 0
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (s[mid] >= 0) lo = mid + 1; else hi = mid; }
+  int lo = 0, hi = d.n_gt;                                 // descending, "no match" entries are -inf: count the real scores
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (s[mid] > keval::NO_MATCH) lo = mid + 1; else hi = mid; }
   d.num_thresholds[comb] = keval::sample_thresholds(s, lo, d.num_valid_gt[m * 3 + level], d.thresholds + (long)comb * keval::PTS);
 }
 

@@ -166,13 +166,20 @@ MFX_HD void decode_comb(const mfx_kitti_eval_desc& d, int comb, int& m, int& lev
 // COUNT_FP = false: no score threshold, best-scoring candidate wins, tp_scores receives the winners' scores.
 // COUNT_FP = true : detections below `thresh` are invisible, highest overlap wins, false positives / DontCare / orientation
 //                   similarity are accounted.
+#ifndef MFX_KEVAL_NO_MATCH
+#define MFX_KEVAL_NO_MATCH
+constexpr double NO_MATCH = -__builtin_huge_val();     // 'ground truth not matched' in tp_scores
+#endif
 template <bool COUNT_FP>
 MFX_HD Stats match(const mfx_kitti_eval_desc& d, int b, int comb, double thresh) {
   int m, level, metric, k;
   decode_comb(d, comb, m, level, metric, k);
   const int cls = d.classes[m];
   const double min_ov = d.min_overlaps[((long)k * 3 + metric) * d.num_classes + m];
-  const int g0 = d.gt_off[b], ng = d.gt_off[b + 1] - g0, d0 = d.dt_off[b], nd = d.dt_off[b + 1] - d0;
+  const int g0 = d.gt_off[b], ng = d.gt_off[b + 1] - g0, d0 = d.dt_off[b];
+  // one 64-bit mask per detection set: MFX_EVAL_MAX_DET detections per image (the offsets live on the device, so the entry
+  // points cannot check them; the host packer refuses larger images, a raw caller's surplus detections are ignored)
+  const int nd = (d.dt_off[b + 1] - d0) > 64 ? 64 : (d.dt_off[b + 1] - d0);
   const double* ov = d.overlaps + (long)metric * d.n_pairs + d.pair_off[b];
   uint64_t taken = 0, skip = 0, soft = 0;                  // skip: other class or below threshold; soft: flag 1 ("ignored")
   for (int j = 0; j < nd; ++j) {
@@ -185,7 +192,7 @@ MFX_HD Stats match(const mfx_kitti_eval_desc& d, int b, int comb, double thresh)
   for (int i = 0; i < ng; ++i) {
     const double* G = d.gt + (long)(g0 + i) * REC;
     const int ig = gt_flag(G, cls, level);
-    if (!COUNT_FP) d.tp_scores[(long)comb * d.n_gt + g0 + i] = -1.0;
+    if (!COUNT_FP) d.tp_scores[(long)comb * d.n_gt + g0 + i] = NO_MATCH;      // -inf: any real score, negative ones included, sorts above it
     if (ig == -1) continue;
     int best = -1; bool found = false, from_soft = false;
     double best_score = 0.0, max_ov = 0.0;

@@ -38,9 +38,16 @@ class PostProcessor(nn.Module):
               and self.uncertainty_as_conf and cfg.MODEL.HEAD.DEPTH_MODE == 'inv_sigmoid'
               and list(cfg.MODEL.HEAD.DIMENSION_REG) == ['exp', True, False] and cfg.INPUT.ORIENTATION == 'multi-bin'
               and cfg.MODEL.BACKBONE.DOWN_RATIO == 4 and self.num_classes == 3)
+        # constants compiled into mfx_decode_boxes (decode.hip DecodeConst; reference config/defaults.py:175,206-208): a config
+        # that changes them would train with its own values and decode with the built-in ones, so it is refused
+        built_in_mean = ((3.8840, 1.5261, 1.6286), (0.8423, 1.7607, 0.6602), (1.7635, 1.7372, 0.5968))
+        mean = [tuple(float(v) for v in row) for row in cfg.MODEL.HEAD.DIMENSION_MEAN]
+        ok = ok and len(mean) == 3 and all(abs(a - b) < 1e-6 for ra, rb in zip(mean, built_in_mean) for a, b in zip(ra, rb))
+        ok = ok and [float(v) for v in cfg.MODEL.HEAD.DEPTH_RANGE] == [0.1, 100.0]
         if not ok:
             raise NotImplementedError("the HIP decode kernel implements the runs/monoflex.yaml decode "
-                                      "(soft depth fusion, inv_sigmoid depth, exp dims, multi-bin orientation)")
+                                      "(soft depth fusion, inv_sigmoid depth in [0.1, 100], exp dims with the KITTI "
+                                      "DIMENSION_MEAN, multi-bin orientation)")
 
     @staticmethod
     def prepare_targets(targets, device):

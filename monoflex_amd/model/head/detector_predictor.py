@@ -2,7 +2,7 @@
 
 Parameter names follow the reference (`class_head.{0,1,2}`, `reg_features.{i}.{0,1}`,
 `reg_heads.{i}.{j}`, `trunc_heatmap_conv.{0,1,3}`, `trunc_offset_conv.{0,1,3}`).  InPlaceABN
-(third-party, not vendored) is held as a BatchNorm2d subclass with the same parameter/buffer names;
+(third-party, not vendored) is held as a plain module with BatchNorm2d's parameter/buffer names;
 its semantics here are BN(eps=1e-5) -> leaky_relu(0.01) (`abn_abs_weight`
 selects upstream's |gamma|+eps variant).
 
@@ -22,12 +22,27 @@ HM_LD = 64          # fp32 head map row: [0:3] class logits, [8:58] regression c
 REG_OFF = 8
 
 
-class InPlaceABN(nn.BatchNorm2d):
-    """Parameter holder for the head's fused BN + leaky_relu(0.01)."""
+class InPlaceABN(nn.Module):
+    """Parameter holder for the head's fused BN + leaky_relu(0.01): the parameter / buffer names of a BatchNorm2d
+    (weight, bias, running_mean, running_var, num_batches_tracked -- the stand-in the golden fixtures were recorded
+    with), but -- like upstream's inplace_abn.InPlaceABN -- NOT a torch `_BatchNorm` subclass, so
+    `torch.nn.SyncBatchNorm.convert_sync_batchnorm` leaves the nine head ABNs on rank-local statistics exactly as in the
+    reference (tools/plain_train_net.py:131-132)."""
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation="leaky_relu", activation_param=0.01):
-        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine)
+        super().__init__()
+        if not affine:
+            raise NotImplementedError("InPlaceABN holder: affine=True only")
+        self.num_features, self.eps, self.momentum, self.affine, self.track_running_stats = num_features, eps, momentum, True, True
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self.activation, self.activation_param = activation, activation_param
+
+    def forward(self, x):
+        raise RuntimeError("InPlaceABN is a parameter holder: the fused HIP heads kernel applies it")
 
 
 class _predictor(nn.Module):

@@ -16,7 +16,36 @@ from . import lib as L
 
 
 def _stream():
+    """The current HIP stream of the CURRENT device: every entry point below runs under `on_tensor_device`, which makes the
+    operands' device current first, so a model on cuda:N launches on cuda:N's stream whatever the caller's current device is."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _first_cuda_device(args):
+    for a in args:
+        if torch.is_tensor(a):
+            if a.is_cuda:
+                return a.device
+        elif isinstance(a, (list, tuple)):
+            d = _first_cuda_device(a)
+            if d is not None:
+                return d
+    return None
+
+
+def on_tensor_device(fn):
+    """Run `fn` with the device of its first CUDA tensor argument current (kernels, streams and scratch buffers are all
+    looked up through the current device); other CUDA operands must live on the same device."""
+    import functools
+
+    @functools.wraps(fn)
+    def run(*args, **kwargs):
+        dev = _first_cuda_device(args) or _first_cuda_device(tuple(kwargs.values()))
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return run
 
 
 def _dt(dtype):
@@ -36,10 +65,17 @@ def _ptr(t):
 
 
 def _need_cuda(*ts):
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("MonoFlex HIP operator called with a CPU tensor: the product path has no CPU "
                                "fallback (the CPU oracle lives in oracle/ and is test-only)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("MonoFlex HIP operator: operands on different devices (%s and %s)" % (dev, t.device))
 
 
 def _pow2(v):
@@ -158,6 +194,7 @@ def pack_stem(weight, dtype, scale, shift, act=L.ACT_RELU):
 # --------------------------------------------------------------------------------------------
 # operators
 # --------------------------------------------------------------------------------------------
+@on_tensor_device
 def conv2d(x, p: PackedConv, res=None, out_dtype=None, rowmap=None, x_channels=None, x_ch_off=0,
            out_hw=None, in_hw=None):
     """y = act(conv(x)*scale + shift (+res)).  x: (B,H,W,Cx) NHWC.  With `rowmap` (int32 [M], pixel
@@ -216,6 +253,7 @@ def pack_cat(weight, dtype, scale, shift, src_channels, act=L.ACT_RELU):
     return PackedCat(w2, scale.contiguous(), shift.contiguous(), Cseg, Cout, cp, Ctot, act)
 
 
+@on_tensor_device
 def cat_conv1x1(srcs, p: PackedCat):
     """Root: 1x1 conv over the virtual concat of `srcs` (list of (B,H,W,Ci) tensors)."""
     _need_cuda(*srcs)
@@ -244,6 +282,7 @@ def add_f16_fragments(p: PackedConv, weight):
     return p
 
 
+@on_tensor_device
 def dcn(x, offmask, p: PackedConv):
     """Fused DCNv2 + scale/shift + act.  x (B,H,W,C) NHWC, offmask fp32 (B,Ho,Wo,32)."""
     _need_cuda(x, offmask)
@@ -266,6 +305,7 @@ def dcn(x, offmask, p: PackedConv):
     return y
 
 
+@on_tensor_device
 def maxpool2x2(x):
     _need_cuda(x)
     B, H, W, C = x.shape
@@ -280,6 +320,7 @@ def pack_upsample(weight):
     return weight.detach().float().reshape(C, k * k).t().contiguous()
 
 
+@on_tensor_device
 def upsample_add(x, w_taps, f, skip=None):
     _need_cuda(x, w_taps, skip)
     B, H, W, C = x.shape
@@ -289,6 +330,7 @@ def upsample_add(x, w_taps, f, skip=None):
     return y
 
 
+@on_tensor_device
 def nchw_to_nhwc(x, dtype, channels=None):
     """fp32 NCHW -> NHWC of `dtype`, channel axis zero-padded to `channels`."""
     _need_cuda(x)
@@ -300,6 +342,7 @@ def nchw_to_nhwc(x, dtype, channels=None):
     return y
 
 
+@on_tensor_device
 def nhwc_to_nchw(x, channels=None):
     _need_cuda(x)
     B, H, W, ld = x.shape
@@ -309,6 +352,7 @@ def nhwc_to_nchw(x, channels=None):
     return y
 
 
+@on_tensor_device
 def pack_image(images, dtype):
     """(B,3,H,W) fp32 NCHW -> zero-padded NHWC4 (B, H+6, W+8, 4) for the stem conv."""
     _need_cuda(images)
@@ -321,6 +365,7 @@ def pack_image(images, dtype):
     return y
 
 
+@on_tensor_device
 def stem_conv(images, p: PackedConv):
     """bf16 stem: (B,3,H,W) fp32 NCHW -> (B,H,W,16) bf16 NHWC, conv7x7 + scale/shift + act in one kernel."""
     _need_cuda(images)
@@ -346,6 +391,7 @@ class PackedHeads:
     ld_out: int
 
 
+@on_tensor_device
 def heads_fused(x, p: PackedHeads, planar_classes=0):
     """-> (head map fp32 (B,H,W,ld_out), class-planar logits (B,planar_classes,H*W) or None)."""
     _need_cuda(x)
@@ -364,6 +410,7 @@ def heads_fused(x, p: PackedHeads, planar_classes=0):
     return out, planar
 
 
+@on_tensor_device
 def edge_scatter_add(out, ch_off, C, v, edge_xy, edge_len, planar=None):
     _need_cuda(out, v, edge_xy, edge_len, planar)
     B, H, W, ld = out.shape
@@ -372,6 +419,7 @@ def edge_scatter_add(out, ch_off, C, v, edge_xy, edge_len, planar=None):
                                           B, Lmax, H, W, _ptr(planar), _stream()), "mfx_edge_scatter_add")
 
 
+@on_tensor_device
 def decode_topk(hmap, ch_off, ncls, K, planar=None):
     """Per-(image,class) NMS + top-K.  Reads the class-planar logits when given (coalesced), else the NHWC map."""
     _need_cuda(hmap, planar)
@@ -389,6 +437,7 @@ def decode_topk(hmap, ch_off, ncls, K, planar=None):
     return scores, index
 
 
+@on_tensor_device
 def decode_boxes(hmap, reg_off, scores, index, calib, pad, img_size, threshold):
     _need_cuda(hmap, scores, index, calib, pad, img_size)
     B, H, W, ld = hmap.shape
@@ -420,7 +469,7 @@ def _splitk_workspace(device):
 
 
 def _workspace(nbytes, device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -428,6 +477,7 @@ def _workspace(nbytes, device):
     return ws
 
 
+@on_tensor_device
 def ext_dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg):
     _need_cuda(input, weight, bias, offset, mask)
     ts = [t.float().contiguous() for t in (input, weight, bias, offset, mask)]
@@ -449,6 +499,7 @@ def ext_dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw
     return out
 
 
+@on_tensor_device
 def ext_dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kh, kw, sh, sw, ph, pw, dh, dw, dg):
     _need_cuda(input, weight, bias, offset, mask, grad_output)
     x, w, b, off, msk, go = [t.float().contiguous() for t in (input, weight, bias, offset, mask, grad_output)]

@@ -2,10 +2,12 @@
 
 A checkpoint is one `torch.save`d dict {"model": state_dict, "optimizer": ..., "scheduler": ..., **extras} named
 `<save_dir>/<name>.pth`; `<save_dir>/last_checkpoint` holds the path of the newest one and wins over an explicit
-file when `use_latest` is set. Files written by the reference load here and vice versa: parameter names, OIHW weight
-layout and the optimizer's parameter order are the reference's. Weights-only files (a bare state_dict) are accepted
+file when `use_latest` is set. Files written by the reference load here and vice versa: parameter names and OIHW weight
+layout are the reference's, and the optimizer / scheduler state is written in the reference's one-group-per-parameter
+layout and mapped by parameter name onto this build's merged groups when read (see below). Weights-only files (a bare state_dict) are accepted
 by `DetectronCheckpointer`. There is no network in this build, so `catalog://` and `http(s)://` sources raise.
 """
+import copy
 import logging
 import os
 
@@ -14,6 +16,115 @@ import torch
 from .model_serialization import load_state_dict
 
 LAST = "last_checkpoint"
+FC_NAMES = ("backbone.base.fc.weight", "backbone.base.fc.bias")     # exist in the reference when MODEL.PRETRAIN builds DLA's classifier
+
+
+# ---- optimizer / scheduler state: reference layout <-> this build's merged groups -------------------------------------
+# The reference optimizer has ONE param group per parameter, in `model.named_parameters()` order (solver/__init__.py:10-25:
+# 280 groups, 282 with backbone.base.fc.*); solver.build_optimizer here merges them into [weights, biases] so that one fused
+# multi-tensor AdamW launch covers a group.  Arithmetic is identical, only the bookkeeping differs, so checkpoints are
+# written in the reference's layout and either layout is accepted on load (mapped by parameter NAME).
+def _trainable_names(model):
+    return [n for n, p in model.named_parameters() if p.requires_grad]
+
+
+def _reference_names(model, n_groups):
+    names = _trainable_names(model)
+    if n_groups == len(names):
+        return names
+    if n_groups == len(names) + 2 and not any(n in names for n in FC_NAMES):
+        last_base = max(i for i, n in enumerate(names) if n.startswith("backbone.base."))
+        return names[:last_base + 1] + list(FC_NAMES) + names[last_base + 1:]
+    return None
+
+
+def _local_index(model, optimizer):
+    """parameter name -> (state index, group index) in `optimizer` (whatever its grouping)."""
+    by_id = {id(p): n for n, p in model.named_parameters()}
+    out, i = {}, 0
+    for gi, g in enumerate(optimizer.param_groups):
+        for p in g["params"]:
+            out[by_id[id(p)]] = (i, gi)
+            i += 1
+    return out
+
+
+def optimizer_state_to_reference(model, optimizer):
+    """optimizer.state_dict() re-expressed with one param group per parameter in named_parameters() order."""
+    sd = optimizer.state_dict()
+    names = _trainable_names(model)
+    if len(sd["param_groups"]) == len(names):
+        return sd
+    loc = _local_index(model, optimizer)
+    groups, state = [], {}
+    for j, n in enumerate(names):
+        i, gi = loc[n]
+        g = {k: copy.deepcopy(v) for k, v in sd["param_groups"][gi].items() if k != "params"}
+        g["params"] = [j]
+        groups.append(g)
+        if i in sd["state"]:
+            state[j] = sd["state"][i]
+    return {"state": state, "param_groups": groups}
+
+
+def optimizer_state_from_reference(model, optimizer, sd):
+    """A per-parameter-group state (the reference's layout) mapped by name onto `optimizer`'s own groups; entries of
+    parameters this model does not have (backbone.base.fc.*) are dropped.  Returns None when the layout is not recognised."""
+    mine = optimizer.state_dict()
+    if len(sd["param_groups"]) == len(mine["param_groups"]):
+        return sd
+    ref_names = _reference_names(model, len(sd["param_groups"]))
+    if ref_names is None or any(len(g["params"]) != 1 for g in sd["param_groups"]):
+        return None
+    loc = _local_index(model, optimizer)
+    ref_pos = {n: j for j, n in enumerate(ref_names)}
+    groups = [dict(g) for g in mine["param_groups"]]
+    seen = set()
+    state = {}
+    for n, (i, gi) in loc.items():
+        j = ref_pos[n]
+        src = sd["param_groups"][j]
+        if gi not in seen:                                   # hyper-parameters of a merged group: those of its first member
+            seen.add(gi)
+            for k, v in src.items():
+                if k != "params":
+                    groups[gi][k] = copy.deepcopy(v)
+        pid = src["params"][0]
+        if pid in sd["state"]:
+            state[i] = sd["state"][pid]
+    return {"state": state, "param_groups": groups}
+
+
+def _per_group_lists(sched_sd):
+    return [k for k, v in sched_sd.items() if isinstance(v, (list, tuple)) and k in ("base_lrs", "_last_lr")]
+
+
+def scheduler_state_to_reference(model, optimizer, sched_sd):
+    names = _trainable_names(model)
+    loc = _local_index(model, optimizer)
+    out = dict(sched_sd)
+    for k in _per_group_lists(sched_sd):
+        if len(sched_sd[k]) == len(optimizer.param_groups) != len(names):
+            out[k] = [sched_sd[k][loc[n][1]] for n in names]
+    return out
+
+
+def scheduler_state_from_reference(model, optimizer, sched_sd):
+    out = dict(sched_sd)
+    loc = _local_index(model, optimizer)
+    for k in _per_group_lists(sched_sd):
+        if len(sched_sd[k]) == len(optimizer.param_groups):
+            continue
+        ref_names = _reference_names(model, len(sched_sd[k]))
+        if ref_names is None:
+            return None
+        pos = {n: j for j, n in enumerate(ref_names)}
+        vals = [None] * len(optimizer.param_groups)
+        for n, (_, gi) in loc.items():
+            if vals[gi] is None:
+                vals[gi] = sched_sd[k][pos[n]]
+        out[k] = vals
+    return out
 
 
 class Checkpointer:
@@ -26,10 +137,12 @@ class Checkpointer:
     # ---- writing ---------------------------------------------------------------------------------------
     def save(self, name, **extras):
         data = {"model": self.model.state_dict()}
+        m = self.model.module if hasattr(self.model, "module") else self.model
         if self.optimizer is not None:
-            data["optimizer"] = self.optimizer.state_dict()
+            data["optimizer"] = optimizer_state_to_reference(m, self.optimizer)
         if self.scheduler is not None and hasattr(self.scheduler, "state_dict"):
-            data["scheduler"] = self.scheduler.state_dict()
+            sd = self.scheduler.state_dict()
+            data["scheduler"] = scheduler_state_to_reference(m, self.optimizer, sd) if self.optimizer is not None else sd
         data.update(extras)
         path = os.path.join(self.save_dir, name + ".pth")
         self.logger.info("Saving checkpoint to %s", path)
@@ -64,10 +177,21 @@ class Checkpointer:
         ckpt = self._load_file(f)
         self._load_model(ckpt)
         if self.load_optimizer_scheduler:
+            m = self.model.module if hasattr(self.model, "module") else self.model
             if "optimizer" in ckpt and self.optimizer:
-                self.optimizer.load_state_dict(ckpt.pop("optimizer"))
+                sd = optimizer_state_from_reference(m, self.optimizer, ckpt.pop("optimizer"))
+                if sd is None:
+                    self.logger.warning("optimizer state has an unknown parameter-group layout: not loaded (weights were)")
+                else:
+                    self.optimizer.load_state_dict(sd)
             if "scheduler" in ckpt and self.scheduler:
-                self.scheduler.load_state_dict(ckpt.pop("scheduler"))
+                sd = ckpt.pop("scheduler")
+                if self.optimizer is not None:
+                    sd = scheduler_state_from_reference(m, self.optimizer, sd)
+                if sd is None:
+                    self.logger.warning("scheduler state has an unknown parameter-group layout: not loaded")
+                else:
+                    self.scheduler.load_state_dict(sd)
         return ckpt
 
     def _load_file(self, f):

@@ -133,3 +133,79 @@ def test_imagenet_dla34_import(tmp_path, monkeypatch):
     torch.save(sd, f)
     with pytest.raises(RuntimeError):                            # the trunk loads strictly
         dla34(pretrained=f)
+
+
+def _stepped(model, cfg, per_parameter_groups):
+    opt = build_optimizer(model, cfg, per_parameter_groups=per_parameter_groups)
+    sched = build_scheduler(opt, cfg, iters_per_epoch=5)
+    g = torch.Generator().manual_seed(5)
+    for p in model.parameters():
+        p.grad = torch.randn(p.shape, generator=g) * 1e-3
+    opt.step(); sched.step()
+    return opt, sched
+
+
+def test_reference_layout_optimizer_state_loads_into_merged_groups(tmp_path):
+    """a checkpoint whose optimizer has the reference's one-group-per-parameter layout (solver/__init__.py:10-25:
+    280 groups; 282 with backbone.base.fc.*) resumes into this build's two merged groups, mapped by parameter name."""
+    cfg = _cfg()
+    a = _model(1)
+    opt_ref, sched_ref = _stepped(a, cfg, per_parameter_groups=True)          # the reference's literal layout
+    ref_sd = opt_ref.state_dict()
+    assert len(ref_sd["param_groups"]) == 280
+    # grow it to the 282-group form: two extra groups for fc.weight / fc.bias right after the last backbone.base.* parameter
+    names = [n for n, p in a.named_parameters() if p.requires_grad]
+    last_base = max(i for i, n in enumerate(names) if n.startswith("backbone.base."))
+    grown = {"state": {}, "param_groups": []}
+    for j in range(282):
+        src = j if j <= last_base else (None if j <= last_base + 2 else j - 2)
+        if src is None:
+            grown["param_groups"].append(dict(ref_sd["param_groups"][0], params=[j]))
+            grown["state"][j] = {"step": torch.tensor(1.0), "exp_avg": torch.zeros(3), "exp_avg_sq": torch.zeros(3)}
+        else:
+            grown["param_groups"].append(dict(ref_sd["param_groups"][src], params=[j]))
+            grown["state"][j] = ref_sd["state"][src]
+    for tag, sd in (("280", ref_sd), ("282", grown)):
+        path = str(tmp_path / ("ref_%s.pth" % tag))
+        torch.save({"model": a.state_dict(), "optimizer": sd, "scheduler": sched_ref.state_dict(), "iteration": 3}, path)
+        b = _model(2)
+        opt_b = build_optimizer(b, cfg)
+        sched_b = build_scheduler(opt_b, cfg, iters_per_epoch=5)
+        assert len(opt_b.param_groups) == 2
+        rest = DetectronCheckpointer(cfg, b, opt_b, sched_b, save_dir=str(tmp_path / "none")).load(path, use_latest=False)
+        assert rest == {"iteration": 3}
+        pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+        for n in ("backbone.base.level2.tree1.conv1.weight", "backbone.dla_up.ida_0.proj_1.conv.bias", "heads.predictor.class_head.2.bias"):
+            sa, sb = opt_ref.state[pa[n]], opt_b.state[pb[n]]
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), (tag, n)
+        assert opt_b.param_groups[0]["lr"] == cfg.SOLVER.BASE_LR and opt_b.param_groups[1]["lr"] == cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR
+        assert sched_b.state_dict()["last_epoch"] == sched_ref.state_dict()["last_epoch"] and len(sched_b.base_lrs) == 2
+        # the resumed optimizer continues exactly like the reference-layout one
+        g = torch.Generator().manual_seed(9)
+        for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            gr = torch.randn(p.shape, generator=g) * 1e-3
+            p.grad, q.grad = gr.clone(), gr.clone()
+        if tag == "280":
+            opt_ref.step(); opt_b.step()
+            for n in pa:
+                assert torch.allclose(pa[n], pb[n], rtol=0, atol=1e-7), n
+
+
+def test_saved_optimizer_state_is_in_the_reference_layout(tmp_path):
+    """What this build writes, a reference-layout optimizer (280 groups) loads with plain load_state_dict()."""
+    cfg = _cfg()
+    a = _model(1)
+    opt, sched = _stepped(a, cfg, per_parameter_groups=False)
+    path = DetectronCheckpointer(cfg, a, opt, sched, save_dir=str(tmp_path)).save("m", iteration=1)
+    raw = torch.load(path, map_location="cpu")
+    assert len(raw["optimizer"]["param_groups"]) == 280 and len(raw["scheduler"]["base_lrs"]) == 280
+    assert all(len(g["params"]) == 1 for g in raw["optimizer"]["param_groups"])
+    b = _model(2)
+    opt_ref = build_optimizer(b, cfg, per_parameter_groups=True)
+    sched_ref = build_scheduler(opt_ref, cfg, iters_per_epoch=5)
+    opt_ref.load_state_dict(raw["optimizer"])                   # what the reference's Checkpointer.load does (check_point.py:68)
+    sched_ref.load_state_dict(raw["scheduler"])
+    n = "backbone.base.level3.tree2.root.bn.bias"
+    assert torch.equal(opt.state[dict(a.named_parameters())[n]]["exp_avg"], opt_ref.state[dict(b.named_parameters())[n]]["exp_avg"])
+    lrs = {g["lr"] for g in opt_ref.param_groups}
+    assert lrs == {cfg.SOLVER.BASE_LR, cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR}

@@ -1,9 +1,12 @@
 """GPU parity tests, end to end: the HIP KeypointDetector against (a) fixtures captured from the
 reference's own Python (tests/golden) and (b) the CPU oracle on the same seeded inputs.
 
-fp32 mode carries the north-star gate: |logits - reference| <= 1e-3 and identical top-K indices.
-bf16 mode (the perf mode) reports its own deviation; asserted loosely."""
+fp32 mode carries the north-star gate: |logits - reference| <= 1e-3 and identical top-K indices, plus the per-stage
+goldens (six DLA levels, four DLAUp outputs, the 64-channel feature).  bf16 mode (the benchmarked mode) is run at the
+benchmarked shape (B=8, 1280x384) against the same reference goldens with measured bounds; what it measures is written to
+gpurun_out/bf16_vs_reference.json (committed as profiles/r02_bf16_vs_reference.json) and repeated in the bench line."""
 import ast
+import json
 import os
 
 import numpy as np
@@ -39,6 +42,39 @@ def _run(m, imgs, tgts):
     return det.cpu(), topk.cpu(), valid.cpu(), hm.cpu()
 
 
+def _stages(m, imgs):
+    """The tensors the reference's forward hooks recorded (oracle/gen_golden.py:run_case): base level outputs, DLAUp outputs,
+    the backbone feature -- as NHWC device tensors of the whole batch."""
+    bb = m.backbone
+    with torch.no_grad():
+        base = bb.base(imgs.to(DEV), bb.compute_dtype)
+        up = bb.dla_up(list(base))
+        y = [up[i] for i in range(bb.last_level - bb.first_level)]
+        bb.ida_up(y, 0, len(y))
+    torch.cuda.synchronize()
+    out = {"base%d" % i: t for i, t in enumerate(base)}
+    out.update({"dlaup%d" % i: t for i, t in enumerate(up)})
+    out["feature"] = y[-1]
+    return out
+
+
+def _stage_errors(g, n, stages, image=0):
+    """Per stage: max |sample - golden sample| / max |golden sample| over the 256 strided samples, and the relative error
+    of the absolute sum over the whole map (image `image` of the batch against golden image n)."""
+    errs = {}
+    for name, t in stages.items():
+        p = "img%d_%s_" % (n, name)
+        if p + "samples" not in g:
+            continue
+        flat = t[image].float().permute(2, 0, 1).reshape(-1).cpu().double()            # the golden indexes the NCHW map
+        assert int(np.prod(g[p + "shape"])) == flat.numel(), name
+        want = g[p + "samples"].astype(np.float64)
+        got = flat[torch.as_tensor(g[p + "idx"])].numpy()
+        errs[name] = (float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6)),
+                      abs(float(flat.abs().sum()) - float(g[p + "abssum"])) / float(g[p + "abssum"]))
+    return errs
+
+
 def _check_against_golden(g, n, meta, hm, topk, det, valid, full):
     p = "img%d_" % n
     logits = hm[..., :3].permute(2, 0, 1)
@@ -70,8 +106,11 @@ def test_e2e_small_vs_reference_golden_fp32():
     # both images in ONE batch: batched decode must equal the reference's per-image (B=1) decode
     imgs = torch.cat([S.synthetic_images(1, oh * 4, ow * 4, seed=s) for s in meta["seeds"]])
     det, topk, valid, hm = _run(m, imgs, [S.synthetic_target(ow, oh)] * len(meta["seeds"]))
+    stages = _stages(m, imgs)
     for n in range(len(meta["seeds"])):
         _check_against_golden(g, n, meta, hm[n], topk[n], det[n], valid[n], full=True)
+        errs = _stage_errors(g, n, stages, image=n)
+        assert len(errs) == 11 and all(e[0] <= 2e-4 and e[1] <= 1e-4 for e in errs.values()), errs
 
 
 def test_e2e_full_vs_reference_golden_fp32():
@@ -82,7 +121,45 @@ def test_e2e_full_vs_reference_golden_fp32():
     imgs = S.synthetic_images(1, 384, 1280, seed=meta["seeds"][0])
     det, topk, valid, hm = _run(m, imgs, [S.synthetic_target(320, 96)])
     dl, dr = _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False)
-    print("full-size fp32 vs reference: max |dlogit| %.2e, max |dreg| %.2e" % (dl, dr))
+    errs = _stage_errors(g, 0, _stages(m, imgs))
+    print("full-size fp32 vs reference: max |dlogit| %.2e, max |dreg| %.2e; stages %s" % (
+        dl, dr, {k: "%.1e/%.1e" % v for k, v in errs.items()}))
+    assert len(errs) == 11 and all(e[0] <= 2e-4 and e[1] <= 1e-4 for e in errs.values()), errs
+    pix = torch.as_tensor(g["img0_pix"])
+    feat = _stages(m, imgs)["feature"][0].float().permute(2, 0, 1).reshape(64, -1)[:, pix].cpu().numpy()
+    assert np.abs(feat - g["img0_feature_at"]).max() <= 2e-4 * max(1.0, np.abs(g["img0_feature_at"]).max())
+
+
+def test_c5_batch32_hipgraph_fp32_rows_equal_reference_golden():
+    """BASELINE configs[4] per-GPU shape: batch 32 captured in ONE hipGraph (DLA + DCN + heads + top-K + decode), replayed;
+    image 0 of the batch is the golden image: logits <= 1e-3, identical top-K, (N,14) rows -- the batched, graphed decode
+    equals the reference's batch-1 eager decode.  Two further images of the batch are checked against their own B=1 run."""
+    from monoflex_amd import synthetic as S
+    from monoflex_amd.structures.params_3d import make_test_target
+    g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_full.npz"))
+    meta = ast.literal_eval(str(g["meta"]))
+    m = _hip_model(meta["cls_bias"], "fp32")
+    B = 32
+    imgs = S.synthetic_images(B, 384, 1280, seed=meta["seeds"][0]).to(DEV)
+    tg = m.device_targets([make_test_target(S.synthetic_target(320, 96)) for _ in range(B)], DEV)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m.detect_device(imgs, *tg)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = m.detect_device(imgs, *tg)
+        graph.replay(); graph.replay()
+    torch.cuda.synchronize()
+    det, topk, valid, hm = [t.cpu() for t in out]
+    _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False)
+    for n in (13, 31):
+        d1, t1, v1, h1 = _run(m, imgs[n:n + 1].cpu(), [S.synthetic_target(320, 96)])
+        assert torch.equal(topk[n][:, 1], t1[0][:, 1]) and torch.equal(valid[n], v1[0])
+        assert torch.allclose(det[n], d1[0], rtol=1e-5, atol=1e-5)
 
 
 def test_e2e_vs_oracle_other_seeds_fp32():
@@ -105,21 +182,51 @@ def test_e2e_vs_oracle_other_seeds_fp32():
         assert torch.allclose(res, dec[b]["result"], rtol=2e-3, atol=2e-2)
 
 
-def test_e2e_bf16_perf_mode_deviation():
-    """bf16 perf mode: not a parity gate (SURVEY section 7 'hard parts'); report and bound the deviation."""
+def test_e2e_bf16_benchmarked_shape_vs_reference_golden():
+    """The benchmarked mode at the benchmarked shape (BASELINE configs[1]: B=8, 1280x384, bf16) against the REFERENCE's
+    goldens: image 0 of the batch is the golden image.  bf16 is not the north-star parity mode (that is fp32, above); this
+    pins how far it is from the reference, stage by stage, with bounds of ~2x the deviation measured on MI355X, and writes the
+    measured numbers out.  Also: the batched result of image 0 equals its B=1 result (no cross-image leakage)."""
     from monoflex_amd import synthetic as S
     g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_full.npz"))
     meta = ast.literal_eval(str(g["meta"]))
     m = _hip_model(meta["cls_bias"], "bf16")
-    imgs = S.synthetic_images(1, 384, 1280, seed=meta["seeds"][0])
-    det, topk, valid, hm = _run(m, imgs, [S.synthetic_target(320, 96)])
+    imgs = S.synthetic_images(8, 384, 1280, seed=meta["seeds"][0])
+    tgts = [S.synthetic_target(320, 96)] * 8
+    det, topk, valid, hm = _run(m, imgs, tgts)
+    errs = _stage_errors(g, 0, _stages(m, imgs))
     pix = torch.as_tensor(g["img0_pix"])
     logits = hm[0][..., :3].permute(2, 0, 1).reshape(3, -1)[:, pix].numpy()
-    dl = np.abs(logits - g["img0_cls_logits_at"]).max()
-    agree = len(set(topk[0][:, 1].numpy().astype(np.int64).tolist()) & set(g["img0_topk_index"].tolist())) / 50.0
-    print("bf16 vs reference: max |dlogit| %.3e, top-K index agreement %.0f%%" % (dl, 100 * agree))
-    assert np.isfinite(hm[..., :3].numpy()).all() and np.isfinite(hm[..., 8:58].numpy()).all()
-    assert dl < 0.25 and agree >= 0.6
+    reg = hm[0][..., 8:58].permute(2, 0, 1).reshape(50, -1)[:, pix].numpy()
+    dl = float(np.abs(logits - g["img0_cls_logits_at"]).max())
+    dr = float(np.abs(reg - g["img0_reg_at"]).max() / max(1.0, np.abs(g["img0_reg_at"]).max()))
+    mine, ref = topk[0][:, 1].numpy().astype(np.int64), g["img0_topk_index"]
+    agree = len(set(mine.tolist()) & set(ref.tolist())) / 50.0
+    # decoded rows of the peaks both sides found (matched by heat-map index), relative to the row magnitudes
+    ref_rows = {int(i): r for i, r in zip(ref[:len(g["img0_result"])], g["img0_result"])}
+    rows = det[0][valid[0].bool()].numpy()
+    deltas = [np.abs(r - ref_rows[int(i)]) / np.maximum(np.abs(ref_rows[int(i)]), 1.0) for i, r in zip(mine, rows) if int(i) in ref_rows]
+    row_delta = float(np.max(deltas)) if deltas else float("nan")
+    report = {"shape": "B=8, 1280x384, bf16, image 0 = tests/golden/e2e_full.npz (reference KeypointDetector)",
+              "stage_sample_rel_err": {k: v[0] for k, v in errs.items()}, "stage_abssum_rel_err": {k: v[1] for k, v in errs.items()},
+              "max_abs_dlogit": dl, "max_rel_dreg": dr, "topk_index_agreement": agree, "matched_rows": len(deltas),
+              "max_rel_row_delta_matched": row_delta}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bf16_vs_reference.json"), "w") as f:
+        json.dump(report, f, indent=1, sort_keys=True)
+    print("bf16 B=8 vs reference:", json.dumps(report))
+    assert np.isfinite(hm.numpy()).all()
+    assert len(errs) == 11
+    assert all(e[0] <= BF16_STAGE_BOUND and e[1] <= BF16_ABSSUM_BOUND for e in errs.values()), errs
+    assert dl <= BF16_DLOGIT_BOUND and dr <= BF16_DREG_BOUND and agree >= BF16_TOPK_AGREE, (dl, dr, agree)
+    assert len(deltas) >= 25 and row_delta <= BF16_ROW_BOUND
+    d1, t1, v1, h1 = _run(m, imgs[:1], tgts[:1])
+    assert torch.equal(topk[0][:, 1], t1[0][:, 1]) and torch.allclose(hm[0], h1[0], rtol=0, atol=1e-6)
+
+
+# bounds of the bf16 mode against the reference goldens: ~2x the deviation measured on MI355X (profiles/r02_bf16_vs_reference.json)
+BF16_STAGE_BOUND, BF16_ABSSUM_BOUND = 0.12, 0.02
+BF16_DLOGIT_BOUND, BF16_DREG_BOUND, BF16_TOPK_AGREE, BF16_ROW_BOUND = 0.25, 0.25, 0.6, 0.5
 
 
 def test_forward_surface_matches_reference_contract():

@@ -1,0 +1,198 @@
+"""GPU tests of the training step as bench.py / a DP job runs it: torch DDP over a (world_size 1) RCCL group around the HIP
+autograd Functions, the hipGraph-replayed step (single-graph and split flat-gradient forms), torch's own SyncBatchNorm
+converter, and the checkpoint round trip through the HIP model."""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT_W, OUT_H = 96, 32
+
+
+def _cfg(dtype="fp32", w=OUT_W, h=OUT_H):
+    from monoflex_amd.config import get_cfg
+    cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"))
+    cfg.MODEL.PRETRAIN = False
+    cfg.MODEL.COMPUTE_DTYPE = dtype
+    cfg.INPUT.WIDTH_TRAIN, cfg.INPUT.HEIGHT_TRAIN = w * 4, h * 4
+    return cfg
+
+
+def _model(dtype="fp32", seed=3):
+    from monoflex_amd import synthetic as S
+    from monoflex_amd.model.detector import KeypointDetector
+    m = KeypointDetector(_cfg(dtype))
+    m.load_state_dict(S.synthetic_state_dict(m.state_dict(), seed=seed, cls_bias=-1.0))
+    m = m.to(DEV).train()
+    m.heads.loss_evaluator.log_as_float = False
+    return m
+
+
+def _batch(m, B=2, seed0=20):
+    from monoflex_amd import synthetic as S
+    from monoflex_amd.engine.trainer import prepare_targets
+    from monoflex_amd.structures.params_3d import make_train_target
+    tg = [make_train_target(S.synthetic_train_target(seed0 + i, out_w=OUT_W, out_h=OUT_H, n_obj=3 + i)).to(DEV) for i in range(B)]
+    imgs = S.synthetic_images(B, OUT_H * 4, OUT_W * 4, seed=seed0).to(DEV)
+    return imgs, prepare_targets(m, tg, DEV)
+
+
+def _big_grads(m, k=12):
+    ps = [(n, p) for n, p in m.named_parameters() if p.grad is not None and p.numel() >= 4096]
+    return ps[:k]
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_ddp_over_rccl_wraps_the_hip_autograd_functions(nccl_world1):
+    """tools/plain_train_net.py:134-137 on this build: DistributedDataParallel (RCCL backend, world_size 1, the six dead
+    parameters ignored statically) around the real model -- one step's loss and gradients equal the unwrapped model's,
+    and a second iteration runs (with merely-unused parameters DDP raises on iteration 2)."""
+    from monoflex_amd.engine.trainer import dead_parameter_names, wrap_data_parallel
+    a, b = _model(), _model()
+    imgs, tg = _batch(a)
+    la, _ = a(imgs, tg)
+    sum(la.values()).backward()
+    net = wrap_data_parallel(b, device_ids=[torch.cuda.current_device()])
+    for it in range(2):
+        b.zero_grad(set_to_none=True)
+        lb, _ = net(imgs, tg)
+        sum(lb.values()).backward()
+        if it == 0:
+            for k in la:
+                assert abs(float(la[k]) - float(lb[k])) <= 1e-4 * max(1.0, abs(float(la[k]))), k
+            gb = dict(b.named_parameters())
+            for n, p in _big_grads(a):
+                rel = float((p.grad - gb[n].grad).abs().max() / p.grad.abs().max().clamp(min=1e-12))
+                assert rel < 5e-3, (n, rel)                      # fp32 atomics reorder sums run to run; nothing structural
+    dead = set(dead_parameter_names(b))
+    assert all((p.grad is None) == (n in dead) for n, p in b.named_parameters())
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_graphed_train_step_equals_the_eager_step(split, nccl_world1):
+    """engine.trainer.GraphedTrainStep (what `bench.py --mode train` times): the first replayed step moves every parameter
+    like one eager train_step from the same start.  split=True is the data-parallel form (flat fp32 gradient buffer,
+    all-reduce between two graphs) on the world_size-1 RCCL group."""
+    from monoflex_amd.engine.trainer import GraphedTrainStep, train_step
+    from monoflex_amd.solver import build_optimizer
+    cfg = _cfg()
+    a, b = _model(), _model()
+    imgs, tg = _batch(a)
+    start = {n: p.detach().clone() for n, p in a.named_parameters()}
+    opt_a = build_optimizer(a, cfg)
+    loss_a = float(train_step(a, opt_a, imgs, tg)[0])
+    opt_b = build_optimizer(b, cfg, capturable=True)
+    step = GraphedTrainStep(b, opt_b, imgs, tg, warmup=2, split=split)
+    assert (step.graph_b is not None) == split
+    # the capture warm-up already stepped b: rewind parameters, BN statistics and optimizer state, then replay ONE step
+    with torch.no_grad():
+        for n, p in b.named_parameters():
+            p.copy_(start[n])
+        for st in opt_b.state.values():
+            for k, v in st.items():
+                v.zero_()
+    loss_b = float(step())
+    torch.cuda.synchronize()
+    assert abs(loss_a - loss_b) <= 2e-3 * abs(loss_a), (loss_a, loss_b)     # BN running stats differ after warm-up; loss uses batch stats
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    checked = 0
+    for n, p in _big_grads(a, 40):
+        da, db = (pa[n] - start[n]).flatten().double(), (pb[n] - start[n]).flatten().double()
+        cos = float(torch.dot(da, db) / (da.norm() * db.norm()).clamp(min=1e-30))
+        assert cos > 0.95, (n, cos)
+        checked += 1
+    assert checked >= 10
+    l2 = float(step())
+    assert np.isfinite(l2)
+
+
+def test_torch_sync_batchnorm_converter_is_accepted():
+    """The reference script's literal call (plain_train_net.py:131-132): torch.nn.SyncBatchNorm.convert_sync_batchnorm
+    replaces the BN holders; the HIP path reads their parameters/buffers and treats them as synchronised; the nine head
+    ABNs are (as upstream's InPlaceABN) not _BatchNorm modules and stay rank-local.  Single process: statistics are local,
+    the step equals the unconverted model's."""
+    from monoflex_amd.model.head.detector_predictor import InPlaceABN
+    a, b = _model(), _model()
+    n_bn = sum(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in b.modules())
+    b = torch.nn.SyncBatchNorm.convert_sync_batchnorm(b)
+    assert sum(isinstance(m, torch.nn.SyncBatchNorm) for m in b.modules()) == n_bn and n_bn > 50
+    assert sum(isinstance(m, InPlaceABN) for m in b.modules()) == 9
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    imgs, tg = _batch(a)
+    la, _ = a(imgs, tg)
+    lb, _ = b(imgs, tg)
+    for k in la:
+        assert abs(float(la[k]) - float(lb[k])) <= 1e-4 * max(1.0, abs(float(la[k]))), k
+    sum(lb.values()).backward()
+    assert b.backbone.base.level2.tree1.bn1.weight.grad is not None
+
+
+def test_model_on_a_non_current_device_index_is_guarded():
+    """kernels launch on the stream of the TENSORS' device.  One GPU here, so the check is that the guard is
+    in place and harmless: ops called under an explicit device context of the tensor's own device give the same answer."""
+    from monoflex_amd import ops
+    x = torch.randn(1, 8, 12, 64, device=DEV)
+    with torch.cuda.device(x.device):
+        y0 = ops.maxpool2x2(x)
+    y1 = ops.maxpool2x2(x)
+    assert torch.equal(y0, y1)
+    with pytest.raises(RuntimeError):
+        ops.maxpool2x2(x.cpu())
+
+
+def test_checkpoint_round_trip_through_the_hip_model(tmp_path):
+    """SURVEY 8(f)4 on the device: train two steps, save with DetectronCheckpointer (reference file format), load into a
+    FRESH HIP model -> identical detections (N,14) in eval mode (packed weights invalidated by the load), identical
+    optimizer moments, and training resumes."""
+    from monoflex_amd import synthetic as S
+    from monoflex_amd.engine.trainer import train_step
+    from monoflex_amd.solver import build_optimizer, build_scheduler
+    from monoflex_amd.structures.params_3d import make_test_target
+    from monoflex_amd.utils.check_point import DetectronCheckpointer
+    cfg = _cfg()
+    a = _model()
+    opt = build_optimizer(a, cfg)
+    sched = build_scheduler(opt, cfg, iters_per_epoch=5)
+    imgs, tg = _batch(a)
+    for _ in range(2):
+        train_step(a, opt, imgs, tg, scheduler=sched)
+    path = DetectronCheckpointer(cfg, a, opt, sched, save_dir=str(tmp_path)).save("model_it2", iteration=2)
+    raw = torch.load(path, map_location="cpu")
+    assert len(raw["model"]) == 478 and len(raw["optimizer"]["param_groups"]) == 280        # the reference's layout on disk
+
+    def detect(m):
+        m.eval()
+        ttg = [make_test_target(S.synthetic_target(OUT_W, OUT_H)) for _ in range(imgs.shape[0])]
+        with torch.no_grad():
+            det, topk, valid, hm = m.detect_device(imgs, *m.device_targets(ttg, DEV))
+        torch.cuda.synchronize()
+        return det.cpu(), topk.cpu(), valid.cpu()
+
+    b = _model(seed=9)                                           # different weights: must be overwritten
+    detect(b)                                                    # populate b's packed-weight caches with the OLD weights
+    opt_b = build_optimizer(b, cfg)
+    sched_b = build_scheduler(opt_b, cfg, iters_per_epoch=5)
+    rest = DetectronCheckpointer(cfg, b, opt_b, sched_b, save_dir=str(tmp_path)).load()
+    assert rest == {"iteration": 2}
+    da, db = detect(a), detect(b)
+    assert torch.equal(da[1], db[1]) and torch.equal(da[2], db[2]) and torch.equal(da[0], db[0])
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    for n in ("backbone.base.level2.tree1.conv1.weight", "heads.predictor.class_head.2.bias"):
+        assert torch.equal(opt.state[pa[n]]["exp_avg"], opt_b.state[pb[n]]["exp_avg"]), n
+    b.train()
+    total, loss_dict, _ = train_step(b, opt_b, imgs, tg, scheduler=sched_b)
+    assert torch.isfinite(total) and sched_b.last_epoch == 3

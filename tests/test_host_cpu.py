@@ -199,10 +199,12 @@ def test_product_code_never_touches_the_oracle():
                 offenders.append(os.path.relpath(os.path.join(d, f), ROOT))
     assert offenders == [], offenders
     bench = open(os.path.join(ROOT, "bench.py")).read()
-    start = bench.index("def cpu_baseline")
-    end = bench.index("\ndef ", start + 10)
+    spans = []
+    for fn in ("def cpu_baseline", "def cpu_train_baseline"):           # the two `cpu_baseline` legs (inference / training step)
+        start = bench.index(fn)
+        spans.append((start, bench.index("\ndef ", start + 10)))
     hits = [m.start() for m in imp.finditer(bench)]
-    assert hits and all(start <= h < end for h in hits), "bench.py may use the oracle only inside cpu_baseline()"
+    assert hits and all(any(a <= h < b for a, b in spans) for h in hits), "bench.py may use the oracle only inside its cpu_baseline legs"
     entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
     s0 = entry.index("def smoke")
     assert all(h >= s0 or "dcn_ref" in entry[h:h + 80] for h in [m.start() for m in imp.finditer(entry)])   # build() only compiles the checker

@@ -146,3 +146,71 @@ def test_samplers_single_process():
     import itertools
     assert list(InferenceSampler(5)) == [0, 1, 2, 3, 4] and len(InferenceSampler(5)) == 5
     assert list(itertools.islice(iter(TrainingSampler(4, shuffle=False, seed=0)), 9)) == [0, 1, 2, 3, 0, 1, 2, 3, 0]
+
+
+class _ToyDetector(_Toy):
+    """The training surface of KeypointDetector: model(images, targets) -> (loss_dict, log_loss_dict)."""
+
+    def forward(self, images, targets=None):
+        return {"a_loss": self.live(images).pow(2).sum(), "b_loss": self.live(images).sum() * 0.5}, {}
+
+
+def _flat_step_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from monoflex_amd import parallel
+    from monoflex_amd.engine.trainer import GraphedTrainStep
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    m = _ToyDetector()
+    opt = torch.optim.SGD([p for n, p in m.named_parameters() if "project" not in n], lr=0.1)
+    xs = torch.arange(12, dtype=torch.float32).view(2, 6) / 10
+    step = GraphedTrainStep(m, opt, xs[rank:rank + 1].clone(), None, comm_chunks=3, use_graphs=False)
+    assert step.split and step.flat.numel() == 3 * 6 + 3                 # live.weight + live.bias only: dead ones left out
+    w0 = m.live.weight.detach().clone()
+    step()
+    g1 = step.flat.clone()
+    step.load_batch(xs[1 - rank:2 - rank])                               # swap the shards: the averaged gradient of a linear
+    step()                                                               # model's batch does not depend on who holds which row
+    out.put((rank, g1.tolist(), m.live.weight.detach().tolist(), w0.tolist(),
+             [p.grad is None for n, p in m.named_parameters() if "project" in n]))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_exchange_of_the_graphed_step_over_two_ranks():
+    """engine.trainer.GraphedTrainStep, split form, run eagerly on CPU over gloo: every live gradient lands in ONE flat fp32
+    buffer, the chunked all-reduce averages it over the ranks, the optimizer reads it through views; the dead parameters are
+    neither in the buffer nor touched."""
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    ps = [ctx.Process(target=_flat_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted((q.get(timeout=120) for _ in ps), key=lambda t: t[0])
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    torch.manual_seed(0)
+    m = _ToyDetector()
+    xs = torch.arange(12, dtype=torch.float32).view(2, 6) / 10
+    (sum(m(xs[0:1])[0].values()) + sum(m(xs[1:2])[0].values())).backward()
+    want = torch.cat((m.live.weight.grad.flatten(), m.live.bias.grad.flatten())) / 2
+    for rank, g1, w_after, w0, dead_none in res:
+        assert torch.allclose(torch.tensor(g1), want, atol=1e-6) and all(dead_none)
+    assert torch.allclose(torch.tensor(res[0][2]), torch.tensor(res[1][2]), atol=1e-7)                # ranks stay in lock step
+    assert not torch.allclose(torch.tensor(res[0][2]), torch.tensor(res[0][3]))                     # and the weights moved
+
+
+def test_bench_respawns_itself_under_torchrun_for_n_ranks(monkeypatch):
+    """`python bench.py --gpus N` outside a torchrun environment starts N ranks on 127.0.0.1 (reference engine/launch.py:23-89)."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--mode", "train"])
+    args = bench.parse()
+    assert bench.respawn_under_torchrun(args) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--mode", "train"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

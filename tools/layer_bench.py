@@ -28,7 +28,7 @@ for kv in filter(None, args.opts.split(",")):
     k, v = kv.split("=")
     lib.check(L.mfx_set_option(k.encode(), int(v)), "set_option")
 
-model, _ = bench.build_model(args.dtype, "cuda")
+model, _, _ = bench.build_model(args.dtype, torch.device("cuda", 0))
 B = args.batch
 images = S.synthetic_images(B, 384, 1280, seed=1000).cuda()
 targets = [make_test_target(S.synthetic_target(320, 96)) for _ in range(B)]

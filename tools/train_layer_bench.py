@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Live timing of the dominant kernel group of the training step (used by `bench.py --mode train` for its `roofline` object).
+
+The group is the NHWC DCNv2 backward of the largest DCN shape (64 -> 64 @ 96x320, five of the sixteen DCN layers;
+reference dcn_v2_cuda.cu:206-335): d(columns) GEMM, offset/mask/input gradients and the weight gradient.  Algorithmic
+work per launch: two GEMMs of M x 9C x Cout each (data gradient through the columns, weight gradient)
+= 4 * M * 9C * Cout FLOP, M = B*96*320; algorithmic HBM bytes: x, dy read + dx written + offsets read/written
+(the columns never need to exist in HBM).  Timed with HIP events on the launch stream.
+
+  python tools/train_layer_bench.py [--batch 8] [--dtype bf16]      prints the roofline object as JSON
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK = {"bf16": 2500.0, "fp32": 157.3}
+
+
+def dominant_kernel_roofline(dtype, B, device, H=96, W=320, C=64, Cout=64, reps=10):
+    import torch
+    from monoflex_amd import autograd as AG
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(B, H, W, C, generator=g).relu().to(dt).to(device).requires_grad_()
+    raw = torch.zeros(B, H, W, 32)
+    raw[..., :18] = torch.randn(B, H, W, 18, generator=g) * 1.5          # the synthetic weights' offset spread (synthetic.py)
+    raw[..., 18:27] = torch.randn(B, H, W, 9, generator=g)
+    raw = raw.to(device).requires_grad_()
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(device).requires_grad_()
+    b = torch.zeros(Cout, device=device, requires_grad=True)
+    y = AG.DCNFn.apply(x, raw, w, b, 1, 1, 1)
+    dy = torch.randn(y.shape, generator=g).to(dt).to(device)
+
+    def run():
+        torch.autograd.grad(y, (x, raw, w, b), dy, retain_graph=True)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / reps
+    M = B * H * W
+    flops = 4.0 * M * 9 * C * Cout
+    es = 2 if dtype == "bf16" else 4
+    alg_bytes = M * (C * es + Cout * es + C * 4 + 32 * 4 * 2)
+    achieved = flops / ms / 1e9
+    return {"kernel": "DCNv2 backward group (dcn_bwd_* kernels), %d->%d @ %dx%d, B=%d" % (C, Cout, H, W, B), "bound": "mfma",
+            "achieved": round(achieved, 2), "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype], 4),
+            "traffic": None, "traffic_source": None, "avg_launch_ms": round(ms, 4),
+            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+            "hbm_floor_ms": round(alg_bytes / 8e12 * 1e3, 4)}
+
+
+if __name__ == "__main__":
+    import argparse
+    import torch
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    print(json.dumps(dominant_kernel_roofline(a.dtype, a.batch, torch.device("cuda", 0))))
