@@ -1,0 +1,4 @@
+"""`import data` == `import monoflex_amd.data` (the reference's top-level name, tools/plain_train_net.py:9-26)."""
+from monoflex_amd._alias import install
+
+install(__name__)

@@ -138,7 +138,11 @@ def _defaults():
         BIAS_LR_FACTOR=2.0, BACKBONE_LR_FACTOR=1.0, IMS_PER_BATCH=32, EVAL_INTERVAL=2000,
         EVAL_AND_SAVE_EPOCH=False, EVAL_EPOCH_INTERVAL=2, SAVE_CHECKPOINT_EPOCH_INTERVAL=5,
         SAVE_CHECKPOINT_INTERVAL=1000, LOAD_OPTIMIZER_SCHEDULER=True,
+        # keys the reference's entry script / scheduler read (config/defaults.py:256-299)
+        MOMS=[0.95, 0.85], PCT_START=0.4, DIV_FACTOR=10, STEPS=(20000, 25000), LR_CLIP=0.0000001, WARMUP_EPOCH=1,
+        GRAD_CLIP_FACTOR=99, GRAD_ALPHA=0.9, MASTER_BATCH=-1, MOMENTUM=0.9,
     ))
+    C.DATALOADER = CfgNode(dict(NUM_WORKERS=8, SIZE_DIVISIBILITY=0, ASPECT_RATIO_GROUPING=False))
     C.TEST = CfgNode(dict(
         SINGLE_GPU_TEST=True, IMS_PER_BATCH=1, PRED_2D=True, UNCERTAINTY_AS_CONFIDENCE=False,
         METRIC=['R40'], EVAL_DIS_IOUS=False, EVAL_DEPTH=False, DETECTIONS_PER_IMG=50,
@@ -146,6 +150,7 @@ def _defaults():
     ))
     C.OUTPUT_DIR = "./tools/logs"
     C.SEED = -1
+    C.START_TIME = 0
     return C
 
 

@@ -201,3 +201,48 @@ def train_step(model, optimizer, images, targets, grad_norm_clip=-1.0, scheduler
     if scheduler is not None:
         scheduler.step()
     return losses.detach(), loss_dict, log_loss_dict
+
+
+def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, scheduler, warmup_scheduler, checkpointer, device,
+             arguments):
+    """The reference's training loop (engine/trainer.py:62-230) over this build's loaders: forward -> summed loss -> backward
+    (+ gradient all-reduce when `model` is DDP-wrapped) -> optional clip -> AdamW -> per-iteration scheduler, periodic
+    checkpoints (rank 0) and validation.  TensorBoard logging and best-mAP bookkeeping are not reproduced."""
+    import logging
+    import time
+    from ..utils import comm
+    logger = logging.getLogger("monoflex.trainer")
+    max_iter, start_iter = cfg.SOLVER.MAX_ITERATION, arguments["iteration"]
+    warmup_iters = cfg.SOLVER.WARMUP_STEPS if (cfg.SOLVER.LR_WARMUP and warmup_scheduler is not None) else -1
+    clip = cfg.SOLVER.GRAD_NORM_CLIP
+    net = model.module if hasattr(model, "module") else model
+    model.train()
+    t0 = time.time()
+    loss_v = None
+    for data, iteration in zip(data_loader, range(start_iter, max_iter)):
+        images = data["images"].to(device) if hasattr(data["images"], "to") else data["images"]
+        targets = [t.to(device) for t in data["targets"]]
+        if data.get("fields") is not None:
+            targets = prepare_targets(net, targets, device, fields=data["fields"])
+        losses, loss_dict, log_loss_dict = train_step(model, optimizer, images, targets, grad_norm_clip=clip)
+        (warmup_scheduler if iteration < warmup_iters else scheduler).step()
+        iteration += 1
+        arguments["iteration"] = iteration
+        if iteration % 10 == 0 or iteration == max_iter:
+            loss_v = float(losses)
+            logger.info("iter: %d  loss: %.4f  lr: %.8f  %.3f s/iter", iteration, loss_v, optimizer.param_groups[0]["lr"],
+                        (time.time() - t0) / (iteration - start_iter))
+        if comm.get_rank() == 0 and checkpointer is not None:
+            if iteration % cfg.SOLVER.SAVE_CHECKPOINT_INTERVAL == 0:
+                checkpointer.save("model_checkpoint", **arguments)
+            if iteration == max_iter:
+                checkpointer.save("model_final", **arguments)
+        if data_loaders_val and cfg.SOLVER.EVAL_INTERVAL > 0 and iteration % cfg.SOLVER.EVAL_INTERVAL == 0:
+            from .inference import inference
+            import os
+            for name, loader in zip(cfg.DATASETS.TEST, data_loaders_val):
+                inference(model, loader, dataset_name=name, device=cfg.MODEL.DEVICE, metrics=cfg.TEST.METRIC,
+                          output_folder=os.path.join(cfg.OUTPUT_DIR, "inference_{}".format(iteration), name))
+            model.train()
+            comm.synchronize()
+    return loss_v

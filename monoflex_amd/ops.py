@@ -462,6 +462,11 @@ _splitk_ws = {}
 def _splitk_workspace(device):
     """One persistent fp32 scratch per device (9 splits x SPLITK_MAX_ELEMS): stable address, so captured graphs stay valid;
     launches on one stream are ordered, so consecutive layers can share it."""
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture the scratch must come from THAT graph's memory pool and live exactly as long as the ops
+        # that use it (an entry cached from an earlier capture would belong to another graph's pool): allocate per call, the
+        # pool reuses the block for the next layer in stream order, which replays faithfully
+        return torch.empty(9 * SPLITK_MAX_ELEMS, dtype=torch.float32, device=device)
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)      # concurrent streams must not share it
     if key not in _splitk_ws:
         _splitk_ws[key] = torch.empty(9 * SPLITK_MAX_ELEMS, dtype=torch.float32, device=device)
@@ -469,6 +474,8 @@ def _splitk_workspace(device):
 
 
 def _workspace(nbytes, device):
+    if torch.cuda.is_current_stream_capturing():                # see _splitk_workspace
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:

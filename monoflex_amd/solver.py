@@ -31,8 +31,29 @@ def build_optimizer(model, cfg, per_parameter_groups=False, capturable=False):
     raise NotImplementedError("SOLVER.OPTIMIZER %r (adam_onecycle's fastai wrapper is not part of the adamw training contract)" % s.OPTIMIZER)
 
 
-def build_scheduler(optimizer, cfg, iters_per_epoch=1, last_epoch=-1):
-    """Step decay by LR_DECAY at each epoch in DECAY_EPOCH_STEPS (solver/__init__.py:64-75, stepped per iteration)."""
+def build_scheduler(optimizer, cfg=None, iters_per_epoch=1, last_epoch=-1, total_iters_each_epoch=None, optim_cfg=None):
+    """Step decay by LR_DECAY (solver/__init__.py:64-92), stepped per iteration.
+
+    Two call forms: this build's `build_scheduler(optimizer, cfg, iters_per_epoch)` -> LambdaLR decaying at
+    DECAY_EPOCH_STEPS * iters_per_epoch; and the reference's `build_scheduler(optimizer, total_iters_each_epoch=...,
+    optim_cfg=cfg.SOLVER)` -> `(scheduler, warmup_scheduler)` decaying at optim_cfg.STEPS (iterations, set by the entry
+    script from the epochs), clipped at LR_CLIP / BASE_LR, with the cosine warm-up when LR_WARMUP is on."""
+    if optim_cfg is not None:
+        steps, decay = list(optim_cfg.STEPS), optim_cfg.LR_DECAY
+        floor = optim_cfg.LR_CLIP / optim_cfg.BASE_LR
+
+        def lr_lbmd(it):
+            f = 1.0
+            for s in steps:
+                if it >= s:
+                    f *= decay
+            return max(f, floor)
+        sched = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lbmd, last_epoch=last_epoch)
+        warm = None
+        if optim_cfg.LR_WARMUP:
+            warm = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=optim_cfg.WARMUP_STEPS,
+                                                              eta_min=optim_cfg.BASE_LR / optim_cfg.DIV_FACTOR)
+        return sched, warm
     steps = [e * iters_per_epoch for e in cfg.SOLVER.DECAY_EPOCH_STEPS]
     decay = cfg.SOLVER.LR_DECAY
 

@@ -1,0 +1,4 @@
+"""`import solver` == `import monoflex_amd.solver` (the reference's top-level name, tools/plain_train_net.py:9-26)."""
+from monoflex_amd._alias import install
+
+install(__name__)

@@ -77,7 +77,7 @@ def test_dcn_patch_kernel_vs_c_oracle_real_shapes(B, C, Co, H, W, std, variants)
             got = ops.dcn(xd, om.to(DEV), p).float().cpu().permute(0, 3, 1, 2)
             emax, emean = _errs(got, want)
             worst = (max(worst[0], emax), max(worst[1], emean))
-            assert emax <= 1.2e-2 and emean <= 4e-3, (v, emax, emean)
+            assert emax <= 7.5e-3 and emean <= 4.5e-3, (v, emax, emean)        # observed 3.5e-3 / 2.2e-3
     finally:
         L.check(lib_.mfx_set_option(b"dcn_patch", 1), "opt")
     print("dcn_patch %d->%d@%dx%d std %.1f: worst max-rel %.2e mean-rel %.2e" % (C, Co, H, W, std, *worst))
@@ -106,7 +106,7 @@ def test_dcn_generic_and_wave_kernels_vs_c_oracle_real_shapes(B, C, Co, H, W):
     emax, emean = _errs(got, want)
     print("dcn %d->%d@%dx%d: max-rel %.2e mean-rel %.2e" % (C, Co, H, W, emax, emean))
     _record("dcn_auto_%d_%d_%dx%d" % (C, Co, H, W), max_rel=emax, mean_rel=emean)
-    assert emax <= 1.2e-2 and emean <= 4e-3
+    assert emax <= 7.5e-3 and emean <= 4.5e-3                  # observed <= 3.6e-3 / 2.2e-3
 
 
 def test_stem_kernel_vs_torch_full_resolution():
@@ -123,7 +123,7 @@ def test_stem_kernel_vs_torch_full_resolution():
     emax, emean = _errs(got, ref)
     print("stem 384x1280: max-rel %.2e mean-rel %.2e" % (emax, emean))
     _record("stem_384x1280", max_rel=emax, mean_rel=emean)
-    assert emax <= 6e-3 and emean <= 3e-3
+    assert emax <= 4e-3 and emean <= 2.9e-3                    # observed 2.0e-3 / 1.4e-3
 
 
 CONV_VARIANT_CASES = [
@@ -173,7 +173,7 @@ def test_conv3x3_kernel_variants_vs_torch_real_shapes(name, shape, opt, values, 
             got = y.float().cpu().permute(0, 3, 1, 2)[:, :Co]
             emax, emean = _errs(got, ref)
             worst = (max(worst[0], emax), max(worst[1], emean))
-            bound = (2e-4, 1e-4) if f32out else (6e-3, 3e-3)            # fp32 out: accumulation order only
+            bound = (2e-6, 5e-7) if f32out else (6e-3, 2.9e-3)          # observed 3.9e-7 / 1.1e-7 (fp32 out: accumulation order only) and 3.0e-3 / 1.4e-3
             assert emax <= bound[0] and emean <= bound[1], (name, v, emax, emean)
     finally:
         L.check(lib_.mfx_set_option(opt, 1 if opt == b"halo" else 0), "opt")
