@@ -274,6 +274,16 @@ int mfx_dcn_backward_nhwc_bf16(const void* x, const float* offmask, const float*
                                float* dx, float* d_offmask, float* dweight, float* dbias,
                                int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* Second-generation DCNv2 backward (dcn_bwd_tile.hip): 3x3 / stride 1 / pad 1 / dilation 1, C and Cout powers of two >= 64,
+ * x / dy / dx in `dtype` (MFX_F32 or MFX_BF16).  grad_input is accumulated per tile in LDS and written once in the
+ * activation dtype (no global atomics for offsets within 8 pixels of the sampling pixel's tile); `d_raw` is the fp32
+ * gradient of the RAW 27(32)-channel offset/mask conv output (B,H,W,32): offsets 0..17, mask LOGITS 18..26 (the sigmoid
+ * derivative is applied here), channels 27..31 zero.  `offmask` holds the offsets and the POST-sigmoid mask, as the forward
+ * kernel consumed them.  dweight fp32 (Cout,C,3,3), dbias fp32 (Cout); all outputs overwritten. */
+size_t mfx_dcn_backward_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int dtype);
+int mfx_dcn_backward_v2(const void* x, const float* offmask, const float* weight_oihw, const void* dy, void* dx,
+                        float* d_raw, float* dweight, float* dbias, int B, int C, int H, int W, int Cout, int dtype,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- (4) input pipeline: KITTI sample -> network input + training targets, on the device ------------------------------
  * Replaces the per-sample numpy/PIL work of the reference's dataset (data/datasets/kitti.py:231-525 __getitem__,

@@ -360,6 +360,19 @@ class DCNFn(Function):
         B, H, W, C = x.shape
         Cout, _, kh, kw = weight.shape
         lib_ = L.load()
+        pow2 = lambda v: v >= 64 and (v & (v - 1)) == 0
+        if (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1) and pow2(C) and pow2(Cout) and not _DCN_BWD_V1[0]:
+            # tile-owned backward (dcn_bwd_tile.hip): dx in the activation dtype, gradient of the RAW offset/mask conv output
+            dt = _dt(x.dtype)
+            ws = ops._workspace(lib_.mfx_dcn_backward_v2_workspace_bytes(B, C, H, W, Cout, dt), x.device)
+            dx = torch.empty_like(x)
+            draw = torch.empty_like(om)
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+            wc = _c(weight.detach() if weight.dtype == torch.float32 else weight.detach().float())
+            L.check(lib_.mfx_dcn_backward_v2(_ptr(x), _ptr(om), _ptr(wc), _ptr(dy if dy.dtype == x.dtype else dy.to(x.dtype)), _ptr(dx), _ptr(draw),
+                                             _ptr(dw), _ptr(db), B, C, H, W, Cout, dt, _ptr(ws), ws.numel(), _stream()), "mfx_dcn_backward_v2")
+            return dx, draw, dw if weight.dtype == torch.float32 else dw.to(weight.dtype), db, None, None, None
         nbytes = lib_.mfx_dcn_backward_nhwc_workspace_bytes(B, C, H, W, Cout, kh, kw, stride, pad, dil)
         ws = ops._workspace(nbytes, x.device)
         xdtype = x.dtype
@@ -379,6 +392,9 @@ class DCNFn(Function):
         dom[..., 18:27] = dom[..., 18:27] * m * (1 - m)               # through the sigmoid
         dom[..., 27:] = 0
         return dx.to(xdtype), dom, dw.to(weight.dtype), db, None, None, None
+
+
+_DCN_BWD_V1 = [False]          # tests: force the first-generation (global-atomics) backward for comparison
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, out_dtype=None):

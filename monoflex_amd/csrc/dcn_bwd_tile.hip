@@ -1,0 +1,454 @@
+// DCNv2 backward, second generation (training path, NHWC, 3x3 / stride 1 / pad 1 / dilation 1, C a multiple of 64).
+// Reference math: model/backbone/DCNv2/src/cuda/dcn_v2_cuda.cu:206-335 and dcn_v2_im2col_cuda.cu:197-327
+// (col2im for grad_input, col2im_coord for grad_offset / grad_mask, im2col + GEMM for grad_weight).
+//
+// The first generation (dcn_bwd.hip) scattered every (pixel, tap) sample's four corners into grad_input with global fp32
+// atomics -- 36 atomic bursts per input element, 2.5 ms for one 64->64 @ 96x320 layer at B=8, 100x its HBM floor -- and
+// re-sampled the columns a second time on the vector ALUs for grad_weight.  Here the INPUT gradient is owned by tiles:
+//
+//   * one workgroup owns an 8 x 16 tile of grad_input pixels (x a slice of <= 128 channels) and accumulates it in LDS
+//     (ds_add_f32, lanes = consecutive channels: conflict-free), then writes it ONCE with plain coalesced stores in the
+//     activation dtype -- no global atomics, no fp32 grad_input buffer, no zero-fill, no narrowing pass;
+//   * contributions come from the tile's own samples (phase S) and from the samples of the surrounding D = 8 pixel ring
+//     whose corners fall into the tile (phase A): the ring's sampling geometry is evaluated lane-parallel (one lane per
+//     (pixel, tap)), hits are compacted into an LDS work list, and only hits re-read their d(columns) row;
+//   * a corner further than D pixels from its sample's tile ("far": offsets beyond ~8 px) is added to an fp32 side buffer
+//     with global atomics and merged afterwards (dcn_bwd_far_merge_kernel, skipped when no far corner occurred), so every
+//     offset stays exact: a corner (sample m, pixel p) is handled by the owner of tile(p) iff m lies in tile(p) grown by D,
+//     and by the side buffer otherwise -- exactly once;
+//   * phase S also produces grad_offset / grad_mask (wave reduction over channels; the sigmoid derivative of the mask logit
+//     is folded in, so the result is the gradient of the raw 27-channel offset/mask conv output) and writes the modulated
+//     columns col[m][tap*C + c] in the activation dtype, which turns grad_weight into a plain MFMA GEMM
+//     (conv_wgrad_mfma_kernel, "direct" operand mode) instead of a second VALU re-sampling pass.
+#include "../../include/monoflex_hip.h"
+#include "common.h"
+#include "err.h"
+#include <type_traits>
+
+// train_kernels.hip: weight gradient with a dense [M][K] A operand (direct = 1), written as (Cout, Cin, kh, kw)
+int mfx_internal_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
+                            int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
+                            int dtype, int oihw, int Cin_out, int Cout_out, void* stream, int dil_w,
+                            void* workspace, size_t workspace_bytes, int direct);
+
+int g_opt_dcn_bt_dbg = 0;      // option "dcn_bt_dbg": experiment switches of dcn_bwd_tile_kernel (0 in production)
+
+namespace mfx {
+
+constexpr int BT_TH = 8, BT_TW = 16, BT_D = 8, BT_NPIX = BT_TH * BT_TW;
+constexpr int BT_LCAP = 47, BT_FCAP = 512;   // BT_FCAP: far corners staged per workgroup before one global reservation
+            // list entries per target pixel (mean 36 = 9 taps x 4 corners); overflow takes the exact far path
+constexpr int BT_CH = BT_TH + 2 * BT_D, BT_CW = BT_TW + 2 * BT_D;        // candidate window (24 x 32 pixels)
+
+struct BtGeom { int B, H, W, C, tiles_x, tiles_y, Kp, CS, nslices, dbg; };
+
+struct SampGeo { int h0, w0; float lh, lw, mask; int inside; };
+
+// sampling geometry of (pixel (my,mx), tap): same rules as the forward sampler (dcn_v2_im2col_cuda.cu:25-54,178-189)
+__device__ __forceinline__ SampGeo samp_geo(const BtGeom& g, const float* __restrict__ om_row, int my, int mx, int tap) {
+    SampGeo s;
+    const int th = (tap * 11) >> 5, tw = tap - th * 3;        // tap / 3 for 0..8
+    const float h = (float)(my - 1 + th) + om_row[2 * tap];
+    const float w = (float)(mx - 1 + tw) + om_row[2 * tap + 1];
+    s.inside = (h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W) ? 1 : 0;
+    const float hf = floorf(h), wf = floorf(w);
+    s.lh = h - hf; s.lw = w - wf;
+    // clamp before the int conversion: a wild (or NaN) offset must not overflow; such a sample is not `inside` anyway
+    s.h0 = (int)fminf(fmaxf(hf, -4.f), 32000.f);
+    s.w0 = (int)fminf(fmaxf(wf, -4.f), 32000.f);
+    s.mask = om_row[18 + tap];
+    return s;
+}
+
+// sum over the LPS (8 or 16) consecutive lanes that share one sample, on the VALU's DPP path (no LDS crossbar):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+template <int LPS> __device__ __forceinline__ float bt_group_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+    if (LPS == 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ void bt_load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void bt_load8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <> __device__ __forceinline__ void bt_load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    ElemTraits<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(p), v);
+}
+template <typename T> __device__ __forceinline__ void bt_store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void bt_store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void bt_store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    *reinterpret_cast<u32x4*>(p) = ElemTraits<bf16_t>::pack(v);
+}
+
+template <typename T> __device__ __forceinline__ void bt_store4(T* p, const f32x4& v);
+template <> __device__ __forceinline__ void bt_store4<float>(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void bt_store4<bf16_t>(bf16_t* p, const f32x4& v) {
+    uint2 o;
+    o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2));
+    o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2));
+    *reinterpret_cast<uint2*>(p) = o;
+}
+
+// LPS = lanes per pixel / sample: every lane owns 8 consecutive channels (one 16-byte chunk in bf16), so a channel slice is
+// CS = 8 * LPS channels and a wavefront works on 64 / LPS samples (or target pixels) at once.
+//
+// Measured dead ends (MI355X, 64 -> 64 @ 96x320, B=8; profiles/r02_dcn_bwd.md): one sample per wavefront with lanes over
+// channels is latency-bound (five 128-byte loads in flight per wave: 4.7 ms); accumulating the tile with ds_add_f32 costs
+// ~140 cycles per wave instruction (the LDS float-atomic unit retires about one lane per clock: 2.0 ms for the 566 M lane
+// adds of this layer).  So the tile is not accumulated by atomics at all: phase 1 BINS every (sample, corner) pair that
+// lands in the tile into a per-pixel list (one integer LDS atomic per pair, 64x fewer than per channel), and phase 3 lets
+// each target pixel's lane group walk its list and accumulate in registers.
+template <typename T, int LPS>
+__global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const T* __restrict__ x, const float* __restrict__ om,
+                                                          const T* __restrict__ gcol, BtGeom g, T* __restrict__ dx,
+                                                          float* __restrict__ dx_far, int* __restrict__ far_count,
+                                                          u32x4* __restrict__ far_list, int far_cap,
+                                                          float* __restrict__ graw, T* __restrict__ col) {
+    constexpr int CS = 8 * LPS, SPW = 64 / LPS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2* lists = reinterpret_cast<uint2*>(smem);                             // [BT_NPIX][BT_LCAP] (sample id, weight bits)
+    int* counts = reinterpret_cast<int*>(smem + BT_NPIX * BT_LCAP * 8);        // [BT_NPIX]
+    uint2* fstage = reinterpret_cast<uint2*>(smem + BT_NPIX * BT_LCAP * 8 + BT_NPIX * 4);   // [BT_FCAP] (sample id | corner << 28, weight)
+    __shared__ int fcount, fbase;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sl = lane / LPS, cl = lane % LPS;                               // sample / pixel slot in the wave, 8-channel group
+    int tile = blockIdx.x;
+    const int tx = tile % g.tiles_x; tile /= g.tiles_x;
+    const int ty = tile % g.tiles_y; const int b = tile / g.tiles_y;
+    const int ty0 = ty * BT_TH, tx0 = tx * BT_TW;
+    const int cs0 = blockIdx.y * CS, c0 = cs0 + cl * 8;                        // slice start, this lane's first channel
+    const int HW = g.H * g.W;
+    const T* xb = x + (size_t)b * HW * g.C;
+    const long mb = (long)b * HW;                                              // first sample index of image b
+
+    for (int i = tid; i < BT_NPIX; i += 256) counts[i] = 0;
+    if (tid == 0) fcount = 0;
+    __syncthreads();
+
+    // a corner that cannot go through the tile lists (far from its sample's tile, or a full list) is staged in LDS and, after
+    // phase 1, appended to a global list with ONE counter reservation per workgroup (a per-corner atomic on the single global
+    // counter serialised at ~12 ns each: +1 ms at 10 % far corners); dcn_bwd_far_kernel scatters that list into the fp32 side
+    // buffer with 8 lanes per entry.  If a stage or the global list is full, the lane walks the slice's channels itself.
+    auto to_far = [&](size_t m, int my, int mx, int tap, int q, int hc, int wc, float w) {
+        const int fs = atomicAdd(&fcount, 1);
+        if (fs < BT_FCAP) { fstage[fs] = uint2{((uint32_t)q << 28) | ((uint32_t)my << 16) | ((uint32_t)mx << 4) | (uint32_t)tap, __float_as_uint(w)}; return; }
+        const T* gp = gcol + m * g.Kp + tap * g.C + cs0;
+        float* f = dx_far + ((size_t)b * HW + (size_t)hc * g.W + wc) * g.C + cs0;
+        for (int c = 0; c < CS; ++c) unsafeAtomicAdd(f + c, w * ElemTraits<T>::load(gp + c));
+        if (fs == BT_FCAP) atomicAdd(far_count + 1, 1);                       // "side buffer touched" flag for the merge pass
+    };
+
+    // ---------------- phase 1: bin the (sample, corner) pairs of the candidate window by target pixel ----------------
+    // window = tile grown by D pixels (BT_CH x BT_CW = 3 x 256 pixels): one thread per pixel, its 9 taps from registers.
+    // Own samples (window pixel inside the tile): corners in the tile are listed; corners elsewhere are left to the owner of
+    // their tile unless this pixel lies outside that tile's window ("far").  Ring samples: only corners inside the tile.
+    static_assert(BT_CH * BT_CW == 3 * 256, "three candidate pixels per thread");
+    for (int round = 0; round < ((g.dbg & 4) ? 0 : 3); ++round) {
+        const int cp = round * 256 + tid;
+        const int wy = cp / BT_CW, wx = cp - wy * BT_CW;
+        const int my = ty0 - BT_D + wy, mx = tx0 - BT_D + wx;
+        const bool own = wy >= BT_D && wy < BT_D + BT_TH && wx >= BT_D && wx < BT_D + BT_TW;
+        if (my < 0 || my >= g.H || mx < 0 || mx >= g.W) continue;
+        const size_t m = (size_t)(mb + (long)my * g.W + mx);
+        const float* r = om + m * 32;
+        float o[28];
+#pragma unroll
+        for (int q4 = 0; q4 < 28; q4 += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(r + q4);
+            o[q4] = t[0]; o[q4 + 1] = t[1]; o[q4 + 2] = t[2]; o[q4 + 3] = t[3];
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int th = tap / 3, tw = tap - th * 3;
+            const float h = (float)(my - 1 + th) + o[2 * tap], w = (float)(mx - 1 + tw) + o[2 * tap + 1];
+            const float mask = o[18 + tap];
+            if (!(h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W) || mask == 0.f) continue;
+            const float hf = floorf(h), wf = floorf(w);
+            const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const int h0 = (int)hf, w0 = (int)wf;                             // inside => -1 <= h0 < H: no overflow
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int hc = h0 + (q >> 1), wc = w0 + (q & 1);
+                const float wq = ((q >> 1) ? lh : hh) * ((q & 1) ? lw : hw) * mask;
+                if (hc < 0 || hc >= g.H || wc < 0 || wc >= g.W || wq == 0.f) continue;
+                const int ly = hc - ty0, lx = wc - tx0;
+                if (ly >= 0 && ly < BT_TH && lx >= 0 && lx < BT_TW) {
+                    const int p = ly * BT_TW + lx;
+                    const int slot = atomicAdd(&counts[p], 1);
+                    if (slot < BT_LCAP) lists[p * BT_LCAP + slot] = uint2{((uint32_t)my << 16) | ((uint32_t)mx << 4) | (uint32_t)tap, __float_as_uint(wq)};
+                    else to_far(m, my, mx, tap, q, hc, wc, wq);               // list full: exact fallback
+                } else if (own) {
+                    const int cty0 = (hc / BT_TH) * BT_TH, ctx0 = (wc / BT_TW) * BT_TW;
+                    const bool near = my >= cty0 - BT_D && my < cty0 + BT_TH + BT_D && mx >= ctx0 - BT_D && mx < ctx0 + BT_TW + BT_D;
+                    if (!near) to_far(m, my, mx, tap, q, hc, wc, wq);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {   // flush the staged far corners: one reservation on the global counter for the whole workgroup
+        const int nf = min(fcount, BT_FCAP);
+        if (nf > 0) {
+            if (tid == 0) fbase = atomicAdd(far_count, nf);
+            __syncthreads();
+            for (int i = tid; i < nf; i += 256) {
+                const uint2 en = fstage[i];
+                const int q = (int)(en.x >> 28), emy = (int)((en.x >> 16) & 0xfff), emx = (int)((en.x >> 4) & 0xfff), etap = (int)(en.x & 15);
+                const size_t m = (size_t)(mb + (long)emy * g.W + emx);
+                const SampGeo sg = samp_geo(g, om + m * 32, emy, emx, etap);
+                const int hc = sg.h0 + (q >> 1), wc = sg.w0 + (q & 1);
+                const int slot = fbase + i;
+                if (slot < far_cap) far_list[slot] = u32x4{(uint32_t)m, ((uint32_t)hc << 16) | ((uint32_t)wc << 4) | (uint32_t)etap, en.y, (uint32_t)cs0};
+                else {
+                    const T* gp = gcol + m * g.Kp + etap * g.C + cs0;
+                    float* f = dx_far + ((size_t)b * HW + (size_t)hc * g.W + wc) * g.C + cs0;
+                    const float w = __uint_as_float(en.y);
+                    for (int c = 0; c < CS; ++c) unsafeAtomicAdd(f + c, w * ElemTraits<T>::load(gp + c));
+                }
+            }
+        }
+    }
+
+    // ---------------- phase 2: the tile's own samples: grad_offset / grad_mask and the modulated columns ----------------
+    constexpr int NS = BT_NPIX * 9;
+    if (!(g.dbg & 8) && (g.nslices == 1 || true)) {
+        for (int base = wv * SPW; base < NS; base += 4 * SPW) {
+            const int s = base + sl;
+            const int lp = s / 9, tap = s - lp * 9;
+            const int my = ty0 + lp / BT_TW, mx = tx0 + (lp % BT_TW);
+            const bool ok = s < NS && my < g.H && mx < g.W;
+            const size_t m = (size_t)(mb + (long)my * g.W + mx);
+            SampGeo sg = {0, 0, 0.f, 0.f, 0.f, 0};
+            if (ok) sg = samp_geo(g, om + m * 32, my, mx, tap);
+            float gh = 0.f, gw = 0.f, gm = 0.f;
+            if (ok) {
+                float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (sg.inside) {
+                    const float lh = sg.lh, lw = sg.lw, hh = 1.f - lh, hw = 1.f - lw, mask = sg.mask;
+                    float gc[8], v[4][8];
+                    bt_load8<T>(gcol + m * g.Kp + tap * g.C + c0, gc);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int hc = sg.h0 + (q >> 1), wc = sg.w0 + (q & 1);
+                        if (hc >= 0 && hc < g.H && wc >= 0 && wc < g.W) bt_load8<T>(xb + ((size_t)hc * g.W + wc) * g.C + c0, v[q]);
+                        else {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[q][k] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float val = hh * hw * v[0][k] + hh * lw * v[1][k] + lh * hw * v[2][k] + lh * lw * v[3][k];
+                        cv[k] = mask * val;
+                        gm += gc[k] * val;
+                        // dmcn_get_coordinate_weight (dcn_v2_im2col_cuda.cu:82-122)
+                        gh += (-hw * v[0][k] - lw * v[1][k] + hw * v[2][k] + lw * v[3][k]) * gc[k] * mask;
+                        gw += (-hh * v[0][k] + hh * v[1][k] - lh * v[2][k] + lh * v[3][k]) * gc[k] * mask;
+                    }
+                }
+                bt_store8<T>(col + m * g.Kp + tap * g.C + c0, cv);
+            }
+            gh = bt_group_sum<LPS>(gh); gw = bt_group_sum<LPS>(gw); gm = bt_group_sum<LPS>(gm);
+            if (cl == 0 && ok && sg.inside) {
+                float* o = graw + m * 32;
+                const float gmr = gm * sg.mask * (1.f - sg.mask);              // through the sigmoid of the mask logit
+                if (g.nslices == 1) { o[2 * tap] = gh; o[2 * tap + 1] = gw; o[18 + tap] = gmr; }
+                else { unsafeAtomicAdd(o + 2 * tap, gh); unsafeAtomicAdd(o + 2 * tap + 1, gw); unsafeAtomicAdd(o + 18 + tap, gmr); }
+            }
+        }
+    }
+
+    // ---------------- phase 3: every target pixel's lane group walks its list, accumulates in registers, stores once ----------------
+    for (int p = wv * SPW + sl; p < ((g.dbg & 1) ? 0 : BT_NPIX); p += 4 * SPW) {
+        const int y = ty0 + p / BT_TW, xx = tx0 + (p % BT_TW);
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int n = min(counts[p], BT_LCAP);
+        const uint2* lp = lists + p * BT_LCAP;
+        int e = 0;
+        for (; e + 4 <= n; e += 4) {                                          // four rows in flight per lane group
+            uint2 en[4]; float gq[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) en[u] = lp[e + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t m = (size_t)(mb + (long)(en[u].x >> 16) * g.W + ((en[u].x >> 4) & 0xfff));
+                bt_load8<T>(gcol + m * g.Kp + (en[u].x & 15) * g.C + c0, gq[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float w = __uint_as_float(en[u].y);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] += w * gq[u][k];
+            }
+        }
+        for (; e < n; ++e) {
+            const uint2 en = lp[e];
+            const size_t m = (size_t)(mb + (long)(en.x >> 16) * g.W + ((en.x >> 4) & 0xfff));
+            float gq[8];
+            bt_load8<T>(gcol + m * g.Kp + (en.x & 15) * g.C + c0, gq);
+            const float w = __uint_as_float(en.y);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += w * gq[k];
+        }
+        if (y < g.H && xx < g.W) bt_store8<T>(dx + ((size_t)b * HW + (size_t)y * g.W + xx) * g.C + c0, a);
+    }
+}
+
+// far corners (rare: offsets beyond the 8-pixel ring, or an over-full tile list): entry = (sample m, corner pixel, tap,
+// weight, first channel of the slice); 8 lanes per entry x 8 channels per lane per pass, fp32 atomics on the side buffer
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_bwd_far_kernel(const T* __restrict__ gcol, const u32x4* __restrict__ far_list,
+                                                         const int* __restrict__ far_count, int far_cap, BtGeom g,
+                                                         float* __restrict__ dx_far) {
+    const int n = min(*far_count, far_cap);
+    const int HW = g.H * g.W, cl = threadIdx.x & 7;
+    for (long e = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 3; e < n; e += ((long)gridDim.x * blockDim.x) >> 3) {
+        const u32x4 en = far_list[e];
+        const size_t m = en.x;
+        const int hc = (int)(en.y >> 16), wc = (int)((en.y >> 4) & 0xfff), tap = (int)(en.y & 15), cs0 = (int)en.w;
+        const float w = __uint_as_float(en.z);
+        const size_t bimg = m / HW;
+        const T* gp = gcol + m * g.Kp + tap * g.C + cs0;
+        float* f = dx_far + (bimg * HW + (size_t)hc * g.W + wc) * g.C + cs0;
+        for (int c = cl * 8; c < g.CS; c += 64) {
+            float gq[8];
+            bt_load8<T>(gp + c, gq);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) unsafeAtomicAdd(f + c + k, w * gq[k]);
+        }
+    }
+}
+
+// dx += dx_far where far corners occurred; nothing to do otherwise
+template <typename T>
+__global__ void dcn_bwd_far_merge_kernel(T* __restrict__ dx, const float* __restrict__ dx_far, const int* __restrict__ far_count, long n4) {
+    if (far_count[0] == 0 && far_count[1] == 0) return;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 f = *reinterpret_cast<const f32x4*>(dx_far + i * 4);
+        if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f && f[3] == 0.f) continue;
+        f32x4 v;
+        if constexpr (std::is_same<T, float>::value) {
+            v = *reinterpret_cast<const f32x4*>(dx + i * 4);
+        } else {
+            const uint2 t = *reinterpret_cast<const uint2*>(dx + i * 4);
+            v = f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+        }
+        v[0] += f[0]; v[1] += f[1]; v[2] += f[2]; v[3] += f[3];
+        bt_store4<T>(dx + i * 4, v);
+    }
+}
+
+// weight (Cout,C,9) fp32 -> wT[K][Cout] (k = tap*C + c), compute dtype: the B operand of d(columns) = dy x W
+template <typename T>
+__global__ void bt_pack_weight_t(const float* __restrict__ w, T* __restrict__ wT, int Cout, int C) {
+    const long total = (long)9 * C * Cout;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % Cout);
+        const int k = (int)(i / Cout);
+        const int tap = k / C, c = k - tap * C;
+        ElemTraits<T>::store(wT + i, w[((size_t)o * C + c) * 9 + tap]);
+    }
+}
+
+static inline size_t bt_al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct BtLayout { size_t wT, gcol, col, far, cnt, flist, wg, total; long far_cap; };
+static BtLayout bt_layout(int B, int C, int H, int W, int Cout, int es) {
+    BtLayout L; size_t o = 0;
+    const size_t M = (size_t)B * H * W, K = (size_t)9 * C;
+    L.wT = o;   o += bt_al(K * Cout * es);
+    L.gcol = o; o += bt_al(M * K * es);
+    L.col = o;  o += bt_al(M * K * es);
+    L.far = o;  o += bt_al(M * C * 4);
+    L.cnt = o;  o += 256;
+    L.far_cap = (long)M * 9;                                  // one far corner per sample on average before the serial fallback
+    L.flist = o; o += bt_al((size_t)L.far_cap * 16);
+    L.wg = o;   o += bt_al((size_t)24 * 1024 * 1024);         // partial tiles of the MFMA weight-gradient slabs
+    L.total = o;
+    return L;
+}
+
+template <typename T>
+static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* weight, const T* dy, T* dx, float* d_raw,
+                                float* dweight, float* dbias, int B, int C, int H, int W, int Cout, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    constexpr int es = (int)sizeof(T);
+    constexpr int dt = std::is_same<T, float>::value ? MFX_F32 : MFX_BF16;
+    const BtLayout L = bt_layout(B, C, H, W, Cout, es);
+    if (!workspace || workspace_bytes < L.total) return mfx_fail(MFX_ERR_WORKSPACE, "dcn_backward_v2: workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(workspace);
+    T* wT = (T*)(ws + L.wT); T* gcol = (T*)(ws + L.gcol); T* col = (T*)(ws + L.col);
+    float* dx_far = (float*)(ws + L.far); int* cnt = (int*)(ws + L.cnt);
+    u32x4* flist = (u32x4*)(ws + L.flist);
+    const int far_cap = (int)L.far_cap;
+    const long M = (long)B * H * W;
+    const int K = 9 * C;
+    {
+        const long total = (long)K * Cout;
+        hipLaunchKernelGGL(bt_pack_weight_t<T>, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, weight, wT, Cout, C);
+    }
+    MFX_HIP_CHECK(hipMemsetAsync(d_raw, 0, (size_t)M * 32 * 4, st));
+    MFX_HIP_CHECK(hipMemsetAsync(dx_far, 0, (size_t)M * C * 4, st));
+    MFX_HIP_CHECK(hipMemsetAsync(cnt, 0, 8, st));
+    // d(columns)[m][k] = sum_o dy[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM on the matrix cores
+    mfx_conv_desc cd = {};
+    cd.x = dy; cd.w = wT; cd.y = gcol;
+    cd.B = 1; cd.H = 1; cd.W = (int)M; cd.x_pixstride = Cout; cd.Ck = Cout; cd.kh = 1; cd.kw = 1; cd.stride = 1; cd.dil_w = 1;
+    cd.Ho = 1; cd.Wo = (int)M; cd.M = (int)M; cd.Cout = K; cd.Cout_pad = K; cd.K_pad = Cout; cd.ldy = K;
+    cd.act = MFX_ACT_NONE; cd.dtype = dt; cd.out_dtype = dt;
+    int rc = mfx_conv2d_nhwc(&cd, stream);
+    if (rc) return rc;
+    BtGeom g;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.tiles_x = (W + BT_TW - 1) / BT_TW; g.tiles_y = (H + BT_TH - 1) / BT_TH; g.Kp = K;
+    g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg;
+    const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * B), (unsigned)g.nslices);
+    const size_t smem = (size_t)BT_NPIX * BT_LCAP * 8 + (size_t)BT_NPIX * 4 + (size_t)BT_FCAP * 8;
+    if (g.CS == 64) {
+        hipLaunchKernelGGL((dcn_bwd_tile_kernel<T, 8>), grid, dim3(256), smem, st, x, offmask, (const T*)gcol, g, dx, dx_far, cnt, flist, far_cap, d_raw, col);
+    } else {
+        auto k = dcn_bwd_tile_kernel<T, 16>;
+        hipLaunchKernelGGL(k, grid, dim3(256), smem, st, x, offmask, (const T*)gcol, g, dx, dx_far, cnt, flist, far_cap, d_raw, col);
+    }
+    hipLaunchKernelGGL(dcn_bwd_far_kernel<T>, dim3(1024), dim3(256), 0, st, (const T*)gcol, (const u32x4*)flist, (const int*)cnt, far_cap, g, dx_far);
+    {
+        const long n4 = M * C / 4;
+        hipLaunchKernelGGL(dcn_bwd_far_merge_kernel<T>, dim3((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0, st, dx, (const float*)dx_far, (const int*)cnt, n4);
+    }
+    MFX_HIP_CHECK(hipGetLastError());
+    // grad_weight[o][c][tap] = sum_m dy[m][o] * col[m][tap*C + c]: MFMA GEMM over the pixels, written as (Cout, C, 3, 3)
+    rc = mfx_internal_conv_wgrad(col, dy, dweight, 1, 1, (int)M, K, C, 3, 3, 1, 0, 0, 1, (int)M, Cout, Cout, dt, 1, C, Cout, stream, 1,
+                                 ws + L.wg, L.total - L.wg, 1);
+    if (rc) return rc;
+    return mfx_colsum(dy, dbias, M, Cout, Cout, dt, stream);                    // grad_bias[o] = sum_m dy[m][o]
+}
+
+}  // namespace mfx
+using namespace mfx;
+
+extern "C" size_t mfx_dcn_backward_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int dtype) {
+    return bt_layout(B, C, H, W, Cout, dtype == MFX_BF16 ? 2 : 4).total;
+}
+
+extern "C" int mfx_dcn_backward_v2(const void* x, const float* offmask, const float* weight_oihw, const void* dy, void* dx,
+                                   float* d_raw, float* dweight, float* dbias, int B, int C, int H, int W, int Cout, int dtype,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !offmask || !weight_oihw || !dy || !dx || !d_raw || !dweight || !dbias) return mfx_fail(MFX_ERR_ARG, "dcn_backward_v2: null pointer");
+    if (C < 64 || (C & (C - 1)) || Cout < 64 || (Cout & (Cout - 1))) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_backward_v2: C and Cout must be powers of two >= 64");
+    if (H >= 4096 || W >= 4096 || (long)B * H * W >= (1L << 31) / 32) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_backward_v2: map too large");
+    if (B * H * W == 0) return MFX_OK;
+    if (dtype == MFX_F32)
+        return dcn_backward_v2_impl<float>((const float*)x, offmask, weight_oihw, (const float*)dy, (float*)dx, d_raw, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream);
+    if (dtype == MFX_BF16)
+        return dcn_backward_v2_impl<bf16_t>((const bf16_t*)x, offmask, weight_oihw, (const bf16_t*)dy, (bf16_t*)dx, d_raw, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream);
+    return mfx_fail(MFX_ERR_ARG, "dcn_backward_v2: bad dtype");
+}

@@ -30,7 +30,8 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
 // ------------------------------------------------------------------------------------------------
 struct WgradGeom { int B, H, W, Ho, Wo, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, dil_w, M, K, Cout, ldy, m_per_block;
                    int oihw, Cin_out, Cout_out;
-                   float* ws; int ws_ld; long ws_slab; };    // ws != null: partial tiles go to ws[slab][o][k] with plain stores   // oihw: write dW as (Cout_out, Cin_out, kh, kw), dropping padded channels
+                   float* ws; int ws_ld; long ws_slab;
+                   int direct; };                            // direct: the A operand is a dense [M][K] matrix (row stride x_pixstride), no im2col addressing    // ws != null: partial tiles go to ws[slab][o][k] with plain stores   // oihw: write dW as (Cout_out, Cin_out, kh, kw), dropping padded channels
 
 __device__ __forceinline__ void wgrad_add(float* dw, const WgradGeom& g, int o, int k, float v) {
     if (g.ws) { g.ws[(size_t)blockIdx.z * g.ws_slab + (size_t)o * g.ws_ld + k] = v; return; }
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
         float cv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f};
         if (m < m_end) {
             if (o_ok) load4<T>(dy + (size_t)m * g.ldy + o0 + sc, gv);
-            if (k_ok) {
+            if (k_ok && g.direct) load4<T>(x + (size_t)m * g.x_pixstride + k, cv);
+            else if (k_ok) {
                 const int b = m / hw, rem = m - b * hw, oh = rem / g.Wo, ow = rem - oh * g.Wo;
                 const int ih = oh * g.stride - g.pad_h + th, iw = ow * g.stride - g.pad_w + tw * g.dil_w;
                 if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
@@ -140,7 +142,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const bf16_t* __re
             if (m < m_end) r.d0 = *reinterpret_cast<const u32x4*>(dy + (size_t)m * g.ldy + o0 + c8);
             if (m + 1 < m_end) r.d1 = *reinterpret_cast<const u32x4*>(dy + (size_t)(m + 1) * g.ldy + o0 + c8);
         }
-        if (a_ok) {
+        if (a_ok && g.direct) {
+            if (m < m_end) r.a0 = *reinterpret_cast<const u32x4*>(x + (size_t)m * g.x_pixstride + kk);
+            if (m + 1 < m_end) r.a1 = *reinterpret_cast<const u32x4*>(x + (size_t)(m + 1) * g.x_pixstride + kk);
+        } else if (a_ok) {
             int b2 = pb, oh2 = poh, ow2 = pow_;
             if (m < m_end) {
                 const int ih = poh * g.stride - g.pad_h + th, iw = pow_ * g.stride - g.pad_w + tw * g.dil_w;
@@ -580,14 +585,14 @@ int g_opt_wgrad_mfma = 1;     // option "wgrad_mfma": 0 = VALU kernel for bf16 t
 static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
                            int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
                            int dtype, int oihw, int Cin_out, int Cout_out, void* stream, int dil_w = 1,
-                           void* workspace = nullptr, size_t workspace_bytes = 0) {
+                           void* workspace = nullptr, size_t workspace_bytes = 0, int direct = 0) {
     if (!x || !dy || !dw) return mfx_fail(MFX_ERR_ARG, "conv_wgrad: null pointer");
     if (Ck % 4 != 0 || Cout % 4 != 0) return mfx_fail(MFX_ERR_ARG, "conv_wgrad: Ck and Cout must be multiples of 4");
     WgradGeom g;
     g.B = B; g.H = H; g.W = W; g.Ho = Ho; g.Wo = Wo; g.x_pixstride = x_pixstride; g.Ck = Ck; g.kh = kh; g.kw = kw; g.stride = stride;
     g.pad_h = pad_h; g.pad_w = pad_w; g.dil_w = dil_w; g.M = B * Ho * Wo; g.K = kh * kw * Ck; g.Cout = Cout; g.ldy = ldy; g.m_per_block = 2048;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    g.oihw = oihw; g.Cin_out = Cin_out; g.Cout_out = Cout_out; g.ws = nullptr; g.ws_ld = 0; g.ws_slab = 0;
+    g.oihw = oihw; g.Cin_out = Cin_out; g.Cout_out = Cout_out; g.ws = nullptr; g.ws_ld = 0; g.ws_slab = 0; g.direct = direct;
     MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (oihw ? (size_t)Cout_out * Cin_out * kh * kw : (size_t)Cout * g.K) * sizeof(float), st));
     if (g.M == 0) return MFX_OK;
     // (x chunks only need 4-byte alignment: the stem reads 8-element super-taps at a pixel stride of 4 elements)
@@ -622,6 +627,15 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
                       hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
+}
+
+// library-internal (dcn_bwd_tile.hip): the DCN weight gradient is a weight gradient over the dense columns matrix
+int mfx_internal_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
+                            int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
+                            int dtype, int oihw, int Cin_out, int Cout_out, void* stream, int dil_w,
+                            void* workspace, size_t workspace_bytes, int direct) {
+    return conv_wgrad_impl(x, dy, dw, B, H, W, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, Ho, Wo, Cout, ldy, dtype, oihw, Cin_out, Cout_out,
+                           stream, dil_w, workspace, workspace_bytes, direct);
 }
 
 extern "C" int mfx_conv_wgrad_nhwc(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
