@@ -5,6 +5,7 @@
 #include "../../include/monoflex_hip.h"
 #include "common.h"
 #include "err.h"
+#include "wgrad.h"
 #include <algorithm>
 
 namespace mfx {
@@ -28,11 +29,6 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
 // conv weight gradient: dW[o][tap][c] = sum_m dy[m][o] * x[pixel(m,tap)][c]       (fp32 [Cout][taps][Ck])
 // Block = 64 k x 64 o tile over a slab of pixels; 256 threads x 4x4 register blocks; fp32 atomics on the small result.
 // ------------------------------------------------------------------------------------------------
-struct WgradGeom { int B, H, W, Ho, Wo, x_pixstride, Ck, kh, kw, stride, pad_h, pad_w, dil_w, M, K, Cout, ldy, m_per_block;
-                   int oihw, Cin_out, Cout_out;
-                   float* ws; int ws_ld; long ws_slab;
-                   int direct; };                            // direct: the A operand is a dense [M][K] matrix (row stride x_pixstride), no im2col addressing    // ws != null: partial tiles go to ws[slab][o][k] with plain stores   // oihw: write dW as (Cout_out, Cin_out, kh, kw), dropping padded channels
-
 __device__ __forceinline__ void wgrad_add(float* dw, const WgradGeom& g, int o, int k, float v) {
     if (g.ws) { g.ws[(size_t)blockIdx.z * g.ws_slab + (size_t)o * g.ws_ld + k] = v; return; }
     if (!g.oihw) { unsafeAtomicAdd(dw + (size_t)o * g.K + k, v); return; }
@@ -596,6 +592,17 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
     MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (oihw ? (size_t)Cout_out * Cin_out * kh * kw : (size_t)Cout * g.K) * sizeof(float), st));
     if (g.M == 0) return MFX_OK;
     // (x chunks only need 4-byte alignment: the stem reads 8-element super-taps at a pixel stride of 4 elements)
+    if (dtype == MFX_BF16 && g_opt_wgrad_mfma) {
+        int nslab_tr = 0;
+        const int rc_tr = try_conv_wgrad_tr(x, dy, g, workspace, workspace_bytes, &nslab_tr, st);
+        if (rc_tr == 1) {
+            const long total = (long)Cout * g.K;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, TR_GRID(total), dim3(256), 0, st, g.ws, nslab_tr, g.ws_slab, g.ws_ld, g, dw);
+            MFX_HIP_CHECK(hipGetLastError());
+            return MFX_OK;
+        }
+        g.ws = nullptr; g.ws_ld = 0; g.ws_slab = 0; g.m_per_block = 2048;
+    }
     if (dtype == MFX_BF16 && Ck % 8 == 0 && x_pixstride % 2 == 0 && ldy % 8 == 0 && g_opt_wgrad_mfma) {
         const int bt = (Cout >= 128 && g.K >= 128 && g_opt_wgrad_mfma == 3) ? 128 : 64;     // 128-wide tiles measured slower (83 vs 78 ms)
         const int tiles = cdivt(g.K, bt) * cdivt(Cout, bt);

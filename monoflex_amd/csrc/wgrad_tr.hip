@@ -1,0 +1,200 @@
+// Convolution weight gradient on the matrix cores, second generation (bf16 activations):
+//     dW[o][k] = sum_m dy[m][o] * A[m][k],   A = implicit im2col of x (k = tap * Ck + c) or a dense [M][K] matrix
+// (reference: torch autograd of nn.Conv2d, engine/trainer.py:116-117; DCN: dcn_v2_cuda.cu:292-318).
+//
+// The reduction runs over pixels, the SLOW axis of both NHWC operands, while an MFMA fragment wants 8 consecutive reduction
+// elements per lane.  The first generation (train_kernels.hip, conv_wgrad_mfma_kernel) transposed on the way INTO LDS: sixteen
+// 4-byte ds_write per thread and step for four MFMAs per wave -- 170 TFLOP/s over the step's 1.4 PFLOP of weight gradients,
+// the largest line of the training profile (profiles/r02_b_train_step_kernel_stats.md).  Here the tiles go into LDS in their
+// natural layout with 16-byte stores and are transposed on the way OUT by ds_read_b64_tr_b16 (gfx950): within a 16-lane group
+// lanes 4j..4j+3 supply row j (4 x 8 bytes) and lane l receives column l of rows 0..3 (semantics probed on the device,
+// tools/probes/tr_probe.hip).  LDS image per operand and step: 16-channel sub-tiles of 32 pixel rows x 32 bytes, rows stored
+// at position p(r) = r with bits 2 and 3 swapped, so that the two 16-lane groups of a 32-lane LDS pass (pixel rows 8g..8g+3
+// and 8g+8..8g+11) read eight consecutive 32-byte rows = all 64 banks once.
+//
+// Workgroup = WO x 3 waves; every wave owns a 64 (o) x 64 (k) block = 4 x 4 MFMA fragments: 16 MFMAs per 16 transposed reads
+// and step.  BK = 192 divides K = 9 * Ck exactly for every 3x3 convolution with Ck a multiple of 64.  The pixel range is
+// split into slabs over blockIdx.z; partial tiles go to the workspace with plain stores (wgrad_reduce_kernel sums them).
+#include "../../include/monoflex_hip.h"
+#include "common.h"
+#include "err.h"
+#include "wgrad.h"
+#include <algorithm>
+
+namespace mfx {
+
+constexpr int TR_BK = 192, TR_STEP = 32;
+
+__device__ __forceinline__ int tr_rowpos(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+// four 16x(8 rows) fragments of one operand: sub-tiles at byte offsets 0 / 1024 / 2048 / 3072 from the two lane addresses
+// (rows 8g..8g+3 and 8g+4..8g+7); ONE asm block so that the wait sits behind all eight reads and nothing that consumes the
+// results can be scheduled in front of it
+__device__ __forceinline__ void tr_read4(uint32_t alo, uint32_t ahi, u32x4 (&f)[4]) {
+    uint64_t l0, h0, l1, h1, l2, h2, l3, h3;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\t"
+        "ds_read_b64_tr_b16 %1, %9\n\t"
+        "ds_read_b64_tr_b16 %2, %8 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %5, %9 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %6, %8 offset:3072\n\t"
+        "ds_read_b64_tr_b16 %7, %9 offset:3072\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+        : "v"(alo), "v"(ahi)
+        : "memory");
+    f[0] = u32x4{(uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)h0, (uint32_t)(h0 >> 32)};
+    f[1] = u32x4{(uint32_t)l1, (uint32_t)(l1 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32)};
+    f[2] = u32x4{(uint32_t)l2, (uint32_t)(l2 >> 32), (uint32_t)h2, (uint32_t)(h2 >> 32)};
+    f[3] = u32x4{(uint32_t)l3, (uint32_t)(l3 >> 32), (uint32_t)h3, (uint32_t)(h3 >> 32)};
+}
+
+template <int WO>
+__global__ __launch_bounds__(WO * 192) void conv_wgrad_tr_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, WgradGeom g) {
+    constexpr int NT = WO * 192, BO = WO * 64, BK = TR_BK;
+    constexpr int OB = BO / 16, KB = BK / 16;                 // 16-channel sub-tiles per operand
+    constexpr int SUB = TR_STEP * 32;                         // bytes per sub-tile (32 rows x 32 B)
+    constexpr int DY_BYTES = OB * SUB, A_BYTES = KB * SUB, STAGE = DY_BYTES + A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char lds[];        // [2][STAGE]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave / 3, wk = wave - wo * 3;
+    const int k0 = blockIdx.x * BK, o0 = blockIdx.y * BO;
+    const int m_begin = blockIdx.z * g.m_per_block, m_end = min(m_begin + g.m_per_block, g.M);
+
+    // ---- loader roles.  A tile: 32 pixel rows x 24 chunks of 8 channels; thread -> fixed chunk column, rows r0 + j * (NT / 24)
+    constexpr int A_RPP = NT / 24, A_N = TR_STEP / A_RPP;     // rows per pass (8 or 16), passes (4 or 2)
+    const int a_kc = tid % 24, a_r0 = tid / 24;
+    const int a_kk = k0 + a_kc * 8;
+    const bool a_ok = a_kk < g.K;
+    const int a_tap = a_ok ? a_kk / g.Ck : 0, a_ch = a_kk - a_tap * g.Ck;
+    const int a_th = a_tap / g.kw, a_tw = a_tap - a_th * g.kw;
+    // dy tile: 32 rows x OB*2 chunks; item id = tid + j * NT, row = id / (2 * OB), chunk = id % (2 * OB)
+    constexpr int D_CPR = 2 * OB, D_ITEMS = TR_STEP * D_CPR, D_N = (D_ITEMS + NT - 1) / NT;
+    const int hw = g.Ho * g.Wo;
+
+    struct Regs { u32x4 a[A_N]; u32x4 d[D_N]; };
+    auto gload = [&](Regs& r, int m0) {                        // tiles of pixels m0 .. m0 + 31
+#pragma unroll
+        for (int j = 0; j < A_N; ++j) {
+            r.a[j] = u32x4{0u, 0u, 0u, 0u};
+            const int m = m0 + a_r0 + j * A_RPP;
+            if (a_ok && m < m_end) {
+                if (g.direct) r.a[j] = *reinterpret_cast<const u32x4*>(x + (size_t)m * g.x_pixstride + a_kk);
+                else {
+                    const int b = m / hw, rem = m - b * hw, oh = rem / g.Wo, ow = rem - oh * g.Wo;
+                    const int ih = oh * g.stride - g.pad_h + a_th, iw = ow * g.stride - g.pad_w + a_tw * g.dil_w;
+                    if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
+                        r.a[j] = *reinterpret_cast<const u32x4*>(x + ((size_t)(b * g.H + ih) * g.W + iw) * g.x_pixstride + a_ch);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < D_N; ++j) {
+            r.d[j] = u32x4{0u, 0u, 0u, 0u};
+            const int id = tid + j * NT;
+            const int row = id / D_CPR, ch = id - row * D_CPR;
+            const int m = m0 + row;
+            if ((D_ITEMS % NT == 0 || id < D_ITEMS) && m < m_end && o0 + ch * 8 < g.Cout)
+                r.d[j] = *reinterpret_cast<const u32x4*>(dy + (size_t)m * g.ldy + o0 + ch * 8);
+        }
+    };
+    auto lstore = [&](int buf, const Regs& r) {
+        char* base = lds + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < A_N; ++j) {
+            const int row = a_r0 + j * A_RPP;
+            *reinterpret_cast<u32x4*>(base + DY_BYTES + (a_kc >> 1) * SUB + tr_rowpos(row) * 32 + (a_kc & 1) * 16) = r.a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < D_N; ++j) {
+            const int id = tid + j * NT;
+            const int row = id / D_CPR, ch = id - row * D_CPR;
+            if (D_ITEMS % NT == 0 || id < D_ITEMS)
+                *reinterpret_cast<u32x4*>(base + (ch >> 1) * SUB + tr_rowpos(row) * 32 + (ch & 1) * 16) = r.d[j];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed fragment reads: lane l of 16-lane group gq supplies 8 bytes of row 8*gq + (l16 >> 2) (+4 for the second
+    // half), channels (l16 & 3) * 4 .. +3 of the sub-tile, and receives channel l16, rows 8*gq .. 8*gq+3 (+4)
+    const int l16 = lane & 15, gq = lane >> 4;
+    const int frag_lo = tr_rowpos(8 * gq + (l16 >> 2)) * 32 + (l16 & 3) * 8;
+    const int frag_hi = tr_rowpos(8 * gq + 4 + (l16 >> 2)) * 32 + (l16 & 3) * 8;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    static_assert(SUB == 1024, "tr_read4 immediates");
+    auto compute = [&](int buf) {
+        const uint32_t sb = lds_base + buf * STAGE;
+        u32x4 af[4], bf[4];
+        tr_read4(sb + wo * 4 * SUB + frag_lo, sb + wo * 4 * SUB + frag_hi, af);
+        tr_read4(sb + DY_BYTES + wk * 4 * SUB + frag_lo, sb + DY_BYTES + wk * 4 * SUB + frag_hi, bf);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma_chunk<bf16_t>(af[i], bf[j], acc[i][j]);
+    };
+
+    const int ns = (m_end - m_begin + TR_STEP - 1) / TR_STEP;
+    Regs R;
+    gload(R, m_begin);
+    lstore(0, R);
+    __syncthreads();
+    for (int s = 0; s < ns; ++s) {
+        const bool more = s + 1 < ns;
+        if (more) gload(R, m_begin + (s + 1) * TR_STEP);       // global loads of the next step fly during the MFMAs
+        compute(s & 1);
+        if (more) lstore((s + 1) & 1, R);
+        __syncthreads();
+    }
+
+    // D: col (lane & 15) = k, row (lane >> 4) * 4 + r = o; partial tile -> workspace slab (plain stores)
+    float* wsb = g.ws + (size_t)blockIdx.z * g.ws_slab;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + wo * 64 + i * 16 + (lane >> 4) * 4 + r, k = k0 + wk * 64 + j * 16 + (lane & 15);
+                if (o < g.Cout && k < g.K) wsb[(size_t)o * g.ws_ld + k] = acc[i][j][r];
+            }
+}
+
+}  // namespace mfx
+using namespace mfx;
+
+int g_opt_wgrad_tr = 1;          // option "wgrad_tr": 0 = first-generation kernel everywhere
+int g_opt_wgrad_tr_blocks = 1024;   // option "wgrad_tr_blocks": target workgroup count (tiles x pixel slabs)
+
+// returns 1 if handled (partial tiles are in g.ws: the caller runs wgrad_reduce_kernel), 0 to fall through
+int try_conv_wgrad_tr(const void* x, const void* dy, WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st) {
+    if (!g_opt_wgrad_tr || !workspace) return 0;
+    if (g.K % TR_BK != 0 || g.Cout % 64 != 0 || g.Ck % 8 != 0 || g.x_pixstride % 8 != 0 || g.ldy % 8 != 0 || g.M < 4096) return 0;
+    const int wo = g.Cout % 128 == 0 ? 2 : 1, bo = wo * 64;
+    const int tiles = (g.K / TR_BK) * (g.Cout / bo);
+    const int ws_ld = g.K;
+    const long ws_slab = (long)g.Cout * ws_ld;
+    int slabs = std::max(1, g_opt_wgrad_tr_blocks / tiles);
+    slabs = (int)std::min<long>(slabs, (long)(workspace_bytes / sizeof(float)) / ws_slab);
+    if (slabs < 1) return 0;
+    g.m_per_block = std::max(512, (int)(((long)g.M / slabs + TR_STEP - 1) / TR_STEP * TR_STEP));
+    const int nslab = (g.M + g.m_per_block - 1) / g.m_per_block;
+    g.ws = reinterpret_cast<float*>(workspace); g.ws_ld = ws_ld; g.ws_slab = ws_slab;
+    const dim3 grid(g.K / TR_BK, g.Cout / bo, nslab);
+    if (wo == 2) {
+        constexpr int smem = 2 * ((128 / 16) + (TR_BK / 16)) * TR_STEP * 32;
+        hipLaunchKernelGGL(conv_wgrad_tr_kernel<2>, grid, dim3(384), smem, st, (const bf16_t*)x, (const bf16_t*)dy, g);
+    } else {
+        constexpr int smem = 2 * ((64 / 16) + (TR_BK / 16)) * TR_STEP * 32;
+        hipLaunchKernelGGL(conv_wgrad_tr_kernel<1>, grid, dim3(192), smem, st, (const bf16_t*)x, (const bf16_t*)dy, g);
+    }
+    *nslab_out = nslab;
+    return 1;
+}

@@ -482,3 +482,35 @@ def test_dcn_tile_owned_backward_vs_oracle(cin, cout, H, W, off_std, dtype):
     if not bf:                                                   # fp32: both generations are exact up to summation order
         for n, a, b_ in zip(names, got["v2"], got["v1"]):
             assert _rel(a, b_) < 3e-4, (n, _rel(a, b_))
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,H,W", [(64, 256, 3, 1, 48, 96), (64, 64, 3, 1, 40, 72), (128, 128, 3, 2, 64, 80),
+                                                   (256, 256, 3, 1, 24, 80), (512, 512, 3, 1, 12, 40), (64, 192, 3, 1, 33, 47)])
+def test_conv_wgrad_transposed_read_kernel_vs_torch(cin, cout, k, stride, H, W):
+    """Second-generation weight-gradient kernel (wgrad_tr.hip: natural-layout LDS tiles + ds_read_b64_tr_b16, 64x64 wave
+    blocks, BK = 192) against torch autograd of F.conv2d on bf16-representable operands, and against the first-generation
+    kernel; ragged pixel slabs, stride 2, Cout not a multiple of 128."""
+    from monoflex_amd import autograd as AG, lib as L
+    g = torch.Generator().manual_seed(31)
+    B = 3
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.05
+    wr = w.clone().requires_grad_()
+    yr = F.conv2d(x, wr, None, stride=stride, padding=k // 2)
+    r = torch.randn(yr.shape, generator=g).bfloat16().float()
+    (yr * r).sum().backward()
+    lib_ = L.load()
+    got = {}
+    try:
+        for tr in (1, 0):
+            L.check(lib_.mfx_set_option(b"wgrad_tr", tr), "opt")
+            xd = _nhwc(x).to(DEV).bfloat16()
+            wd = w.to(DEV).requires_grad_()
+            yd = AG.conv2d(xd, wd, None, stride, k // 2)
+            (yd.float() * _nhwc(r).to(DEV)).sum().backward()
+            got[tr] = wd.grad.detach().cpu()
+    finally:
+        L.check(lib_.mfx_set_option(b"wgrad_tr", 1), "opt")
+    # dy is rounded to bf16 by the conv's output dtype on both sides; fp32 accumulation: only summation order differs
+    assert _rel(got[1], got[0]) < 2e-3, _rel(got[1], got[0])
+    assert _rel(got[1], wr.grad) < 1.5e-2, _rel(got[1], wr.grad)
