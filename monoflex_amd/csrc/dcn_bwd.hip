@@ -12,6 +12,7 @@
 #include "../../include/monoflex_hip.h"
 #include "common.h"
 #include "err.h"
+#include "fill.h"
 #include <type_traits>
 
 namespace mfx {
@@ -317,9 +318,9 @@ extern "C" int mfx_dcn_v2_backward(const float* input, const float* weight, cons
     if (rc) return rc;
     hipLaunchKernelGGL(bwd_pack_offmask, BWD_GRID((long)g.M * 32), dim3(256), 0, st, offset, mask, om, B, HWo, g.kk);
     hipLaunchKernelGGL(bwd_pack_weight_t<float>, BWD_GRID((long)g.Kp * g.Coutp), dim3(256), 0, st, weight, wT, Cout, C, g.kk, g.Cp, g.Kp, g.Coutp);
-    MFX_HIP_CHECK(hipMemsetAsync(gx, 0, (size_t)B * H * W * g.Cp * 4, st));
-    MFX_HIP_CHECK(hipMemsetAsync(gwp, 0, (size_t)g.Coutp * g.K * 4, st));
-    MFX_HIP_CHECK(hipMemsetAsync(gb, 0, (size_t)g.Coutp * 4, st));
+    MFX_HIP_CHECK(mfx::zero_async(gx, (size_t)B * H * W * g.Cp * 4, st));
+    MFX_HIP_CHECK(mfx::zero_async(gwp, (size_t)g.Coutp * g.K * 4, st));
+    MFX_HIP_CHECK(mfx::zero_async(gb, (size_t)g.Coutp * 4, st));
     MFX_HIP_CHECK(hipGetLastError());
 
     rc = dcn_bwd_core<float>(x, om, wT, go, gcol, gx, gom, gwp, gb, g, stream);
@@ -329,7 +330,7 @@ extern "C" int mfx_dcn_v2_backward(const float* input, const float* weight, cons
     if (rc) return rc;
     hipLaunchKernelGGL(bwd_unpack_offmask, BWD_GRID((long)g.M * 3 * g.kk), dim3(256), 0, st, gom, grad_offset, grad_mask, B, HWo, g.kk);
     hipLaunchKernelGGL(bwd_unpack_weight, BWD_GRID((long)Cout * C * g.kk), dim3(256), 0, st, gwp, grad_weight, Cout, C, g.kk, g.Cp, g.K);
-    MFX_HIP_CHECK(hipMemcpyAsync(grad_bias, gb, (size_t)Cout * 4, hipMemcpyDeviceToDevice, st));
+    MFX_HIP_CHECK(mfx::copy_async(grad_bias, gb, (size_t)Cout * 4, st));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -362,14 +363,14 @@ static int dcn_backward_nhwc_impl(const T* x, const float* offmask, const float*
     float* gwp = (float*)ws; ws += al256((size_t)g.Coutp * g.K * 4);
     float* gb = (float*)ws;
     hipLaunchKernelGGL(bwd_pack_weight_t<T>, BWD_GRID((long)g.Kp * g.Coutp), dim3(256), 0, st, weight, wT, Cout, C, g.kk, g.Cp, g.Kp, g.Coutp);
-    MFX_HIP_CHECK(hipMemsetAsync(dx, 0, (size_t)B * H * W * C * 4, st));
-    MFX_HIP_CHECK(hipMemsetAsync(d_offmask, 0, (size_t)g.M * 32 * 4, st));
-    MFX_HIP_CHECK(hipMemsetAsync(gwp, 0, (size_t)g.Coutp * g.K * 4, st));
-    MFX_HIP_CHECK(hipMemsetAsync(gb, 0, (size_t)g.Coutp * 4, st));
+    MFX_HIP_CHECK(mfx::zero_async(dx, (size_t)B * H * W * C * 4, st));
+    MFX_HIP_CHECK(mfx::zero_async(d_offmask, (size_t)g.M * 32 * 4, st));
+    MFX_HIP_CHECK(mfx::zero_async(gwp, (size_t)g.Coutp * g.K * 4, st));
+    MFX_HIP_CHECK(mfx::zero_async(gb, (size_t)g.Coutp * 4, st));
     int rc = dcn_bwd_core<T>(x, offmask, wT, dy, gcol, dx, d_offmask, gwp, gb, g, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(bwd_unpack_weight, BWD_GRID((long)Cout * C * g.kk), dim3(256), 0, st, gwp, dweight, Cout, C, g.kk, g.Cp, g.K);
-    MFX_HIP_CHECK(hipMemcpyAsync(dbias, gb, (size_t)Cout * 4, hipMemcpyDeviceToDevice, st));
+    MFX_HIP_CHECK(mfx::copy_async(dbias, gb, (size_t)Cout * 4, st));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

@@ -23,6 +23,7 @@
 #include "../../include/monoflex_hip.h"
 #include "common.h"
 #include "err.h"
+#include "fill.h"
 #include <type_traits>
 
 // train_kernels.hip: weight gradient with a dense [M][K] A operand (direct = 1), written as (Cout, Cin, kh, kw)
@@ -397,9 +398,9 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
         const long total = (long)K * Cout;
         hipLaunchKernelGGL(bt_pack_weight_t<T>, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, weight, wT, Cout, C);
     }
-    MFX_HIP_CHECK(hipMemsetAsync(d_raw, 0, (size_t)M * 32 * 4, st));
-    MFX_HIP_CHECK(hipMemsetAsync(dx_far, 0, (size_t)M * C * 4, st));
-    MFX_HIP_CHECK(hipMemsetAsync(cnt, 0, 8, st));
+    MFX_HIP_CHECK(mfx::zero_async(d_raw, (size_t)M * 32 * 4, st));
+    MFX_HIP_CHECK(mfx::zero_async(dx_far, (size_t)M * C * 4, st));
+    MFX_HIP_CHECK(mfx::zero_async(cnt, 8, st));
     // d(columns)[m][k] = sum_o dy[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM on the matrix cores
     mfx_conv_desc cd = {};
     cd.x = dy; cd.w = wT; cd.y = gcol;

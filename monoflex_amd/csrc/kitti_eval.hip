@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "err.h"
+#include "fill.h"
 #include "kitti_eval_math.h"
 
 namespace mfx {
@@ -99,8 +100,8 @@ extern "C" int mfx_kitti_eval_match_pass1(const mfx_kitti_eval_desc* d, void* st
   if (int rc = check_desc(d, "pass1")) return rc;
   const int n_comb = d->num_classes * 9 * d->num_k;
   hipStream_t st = (hipStream_t)stream;
-  MFX_HIP_CHECK(hipMemsetAsync(d->pr, 0, sizeof(double) * n_comb * keval::PTS * 4, st));
-  MFX_HIP_CHECK(hipMemsetAsync(d->num_valid_gt, 0, sizeof(int32_t) * d->num_classes * 3, st));
+  MFX_HIP_CHECK(mfx::zero_async(d->pr, sizeof(double) * n_comb * keval::PTS * 4, st));
+  MFX_HIP_CHECK(mfx::zero_async(d->num_valid_gt, sizeof(int32_t) * d->num_classes * 3, st));
   hipLaunchKernelGGL(keval_pass1_kernel, dim3(blocks((long)d->B * n_comb, 256)), dim3(256), 0, st, *d, n_comb);
   MFX_HIP_CHECK(hipGetLastError());
   return MFX_OK;

@@ -5,6 +5,7 @@
 #include "../../include/monoflex_hip.h"
 #include "common.h"
 #include "err.h"
+#include "fill.h"
 #include "wgrad.h"
 #include <algorithm>
 
@@ -279,30 +280,63 @@ __global__ void colsum_kernel(const T* __restrict__ x, int M, int C, int ld, int
 // thread -> fixed 16-byte channel chunk column (cc = tid % CPR), rows strided: per-thread register accumulation, then
 // a short LDS + global atomic reduction per block.
 // ------------------------------------------------------------------------------------------------
+// Block reduction of per-thread column partials: thread (roff, cc) holds NV vectors of E floats for the 16-byte channel chunk
+// cc; partials with equal cc are summed over roff through LDS with plain stores (LDS float atomics retire about one lane per
+// clock on gfx950 -- sixteen of them per thread made these kernels atomic-bound), then ONE global atomic per column and block.
+template <int E, int NV>
+__device__ __forceinline__ void block_reduce_columns(const float (&v)[NV][E], float* sred, int C, int CPR, int tid, float* const (&out)[NV]) {
+    const int cc = tid % CPR, roff = tid / CPR, rstep = 256 / CPR;
+    const int ld = NV * C;
+    if (roff < rstep) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n)
+#pragma unroll
+            for (int e = 0; e < E; e += 4)
+                *reinterpret_cast<f32x4*>(sred + roff * ld + n * C + cc * E + e) = f32x4{v[n][e], v[n][e + 1], v[n][e + 2], v[n][e + 3]};
+    }
+    __syncthreads();
+    for (int i = tid; i < ld; i += 256) {
+        float t = 0.f;
+        for (int r = 0; r < rstep; ++r) t += sred[r * ld + i];
+        unsafeAtomicAdd(out[i / C] + (i % C), t);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, long M, int C, int rows_per_block,
                                                        float* __restrict__ sum, float* __restrict__ sumsq) {
     constexpr int E = ElemTraits<T>::ELEMS;
-    extern __shared__ float sred[];                          // [2][C]
+    extern __shared__ float sred[];                          // [256 / CPR][2 * C]
     const int CPR = C / E, tid = threadIdx.x;
     const int cc = tid % CPR, rstep = 256 / CPR, roff = tid / CPR;
-    for (int i = tid; i < 2 * C; i += 256) sred[i] = 0.f;
-    __syncthreads();
-    float s[E], q[E];
+    float acc[2][E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int e = 0; e < E; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(r0 + (long)rows_per_block, M);
-    if (roff < rstep)
-        for (long r = r0 + roff; r < r1; r += rstep) {
-            float v[E];
-            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + r * C + cc * E), v);
+    if (roff < rstep) {
+        const T* px = x + cc * E;
+        long r = r0 + roff;
+        for (; r + 3L * rstep < r1; r += 4L * rstep) {       // four independent 16-byte loads in flight per thread
+            u32x4 c4[4];
 #pragma unroll
-            for (int e = 0; e < E; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+            for (int u = 0; u < 4; ++u) c4[u] = *reinterpret_cast<const u32x4*>(px + (r + (long)u * rstep) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[E];
+                ElemTraits<T>::unpack(c4[u], v);
+#pragma unroll
+                for (int e = 0; e < E; ++e) { acc[0][e] += v[e]; acc[1][e] += v[e] * v[e]; }
+            }
         }
+        for (; r < r1; r += rstep) {
+            float v[E];
+            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(px + r * C), v);
 #pragma unroll
-    for (int e = 0; e < E; ++e) { atomicAdd(&sred[cc * E + e], s[e]); atomicAdd(&sred[C + cc * E + e], q[e]); }
-    __syncthreads();
-    for (int i = tid; i < C; i += 256) { unsafeAtomicAdd(sum + i, sred[i]); unsafeAtomicAdd(sumsq + i, sred[C + i]); }
+            for (int e = 0; e < E; ++e) { acc[0][e] += v[e]; acc[1][e] += v[e] * v[e]; }
+        }
+    }
+    float* const outs[2] = {sum, sumsq};
+    block_reduce_columns<E, 2>(acc, sred, C, CPR, tid, outs);
 }
 
 // column sums with the bn_stats thread mapping (16-byte chunks along channels, rows strided): used for bias gradients when
@@ -310,26 +344,37 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_chunk_kernel(const T* __restrict__ x, long M, int C, int ld, int rows_per_block, float* __restrict__ out) {
     constexpr int E = ElemTraits<T>::ELEMS;
-    extern __shared__ float sred[];                          // [C]
+    extern __shared__ float sred[];                          // [256 / CPR][C]
     const int CPR = C / E, tid = threadIdx.x;
     const int cc = tid % CPR, rstep = 256 / CPR, roff = tid / CPR;
-    for (int i = tid; i < C; i += 256) sred[i] = 0.f;
-    __syncthreads();
-    float s[E];
+    float acc[1][E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) s[e] = 0.f;
+    for (int e = 0; e < E; ++e) acc[0][e] = 0.f;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(r0 + (long)rows_per_block, M);
-    if (roff < rstep)
-        for (long r = r0 + roff; r < r1; r += rstep) {
-            float v[E];
-            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + r * ld + cc * E), v);
+    if (roff < rstep) {
+        const T* px = x + cc * E;
+        long r = r0 + roff;
+        for (; r + 3L * rstep < r1; r += 4L * rstep) {
+            u32x4 c4[4];
 #pragma unroll
-            for (int e = 0; e < E; ++e) s[e] += v[e];
+            for (int u = 0; u < 4; ++u) c4[u] = *reinterpret_cast<const u32x4*>(px + (r + (long)u * rstep) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[E];
+                ElemTraits<T>::unpack(c4[u], v);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[0][e] += v[e];
+            }
         }
+        for (; r < r1; r += rstep) {
+            float v[E];
+            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(px + r * ld), v);
 #pragma unroll
-    for (int e = 0; e < E; ++e) atomicAdd(&sred[cc * E + e], s[e]);
-    __syncthreads();
-    for (int i = tid; i < C; i += 256) unsafeAtomicAdd(out + i, sred[i]);
+            for (int e = 0; e < E; ++e) acc[0][e] += v[e];
+        }
+    }
+    float* const outs[1] = {out};
+    block_reduce_columns<E, 1>(acc, sred, C, CPR, tid, outs);
 }
 
 // per-channel epilogue of the statistics pass: mean / rstd / folded scale+shift and the running-statistics update in ONE
@@ -398,32 +443,43 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             long M, int C, int rows_per_block, int act,
                                                             float* __restrict__ sg, float* __restrict__ sgx) {
     constexpr int E = ElemTraits<T>::ELEMS;
-    extern __shared__ float sred[];
+    extern __shared__ float sred[];                          // [256 / CPR][2 * C]
     const int CPR = C / E, tid = threadIdx.x;
     const int cc = tid % CPR, rstep = 256 / CPR, roff = tid / CPR;
-    for (int i = tid; i < 2 * C; i += 256) sred[i] = 0.f;
-    __syncthreads();
-    float s[E], q[E], mu[E], rs[E];
+    float acc[2][E], mu[E], rs[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { s[e] = 0.f; q[e] = 0.f; mu[e] = mean[cc * E + e]; rs[e] = rstd[cc * E + e]; }
+    for (int e = 0; e < E; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; mu[e] = mean[cc * E + e]; rs[e] = rstd[cc * E + e]; }
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(r0 + (long)rows_per_block, M);
-    if (roff < rstep)
-        for (long r = r0 + roff; r < r1; r += rstep) {
-            float xv[E], av[E], dv[E];
-            const size_t o = (size_t)r * C + cc * E;
-            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + o), xv);
-            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(da + o), dv);
-            if (act != ACT_NONE) ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(a + o), av);
+    auto fold = [&](const u32x4& cx, const u32x4& cd, const u32x4& ca) {
+        float xv[E], av[E], dv[E];
+        ElemTraits<T>::unpack(cx, xv); ElemTraits<T>::unpack(cd, dv);
+        if (act != ACT_NONE) ElemTraits<T>::unpack(ca, av);
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const float gq = act != ACT_NONE ? dv[e] * act_grad(av[e], act) : dv[e];
-                s[e] += gq; q[e] += gq * (xv[e] - mu[e]) * rs[e];
-            }
+        for (int e = 0; e < E; ++e) {
+            const float gq = act != ACT_NONE ? dv[e] * act_grad(av[e], act) : dv[e];
+            acc[0][e] += gq; acc[1][e] += gq * (xv[e] - mu[e]) * rs[e];
         }
-#pragma unroll
-    for (int e = 0; e < E; ++e) { atomicAdd(&sred[cc * E + e], s[e]); atomicAdd(&sred[C + cc * E + e], q[e]); }
-    __syncthreads();
-    for (int i = tid; i < C; i += 256) { unsafeAtomicAdd(sg + i, sred[i]); unsafeAtomicAdd(sgx + i, sred[C + i]); }
+    };
+    if (roff < rstep) {
+        long r = r0 + roff;
+        for (; r + rstep < r1; r += 2L * rstep) {            // two rows = six 16-byte loads in flight per thread
+            const size_t o0 = (size_t)r * C + cc * E, o1 = (size_t)(r + rstep) * C + cc * E;
+            const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + o0), x1 = *reinterpret_cast<const u32x4*>(x + o1);
+            const u32x4 d0 = *reinterpret_cast<const u32x4*>(da + o0), d1 = *reinterpret_cast<const u32x4*>(da + o1);
+            u32x4 a0 = x0, a1 = x1;
+            if (act != ACT_NONE) { a0 = *reinterpret_cast<const u32x4*>(a + o0); a1 = *reinterpret_cast<const u32x4*>(a + o1); }
+            fold(x0, d0, a0); fold(x1, d1, a1);
+        }
+        for (; r < r1; r += rstep) {
+            const size_t o = (size_t)r * C + cc * E;
+            const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + o), d0 = *reinterpret_cast<const u32x4*>(da + o);
+            u32x4 a0 = x0;
+            if (act != ACT_NONE) a0 = *reinterpret_cast<const u32x4*>(a + o);
+            fold(x0, d0, a0);
+        }
+    }
+    float* const outs[2] = {sg, sgx};
+    block_reduce_columns<E, 2>(acc, sred, C, CPR, tid, outs);
 }
 
 // dx = gamma*rstd * (g - sg/M - xhat*sgx/M) = A[c]*g + B[c]*x + D[c];  dres = g (optional).  Every workgroup first builds the
@@ -589,7 +645,7 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
     g.pad_h = pad_h; g.pad_w = pad_w; g.dil_w = dil_w; g.M = B * Ho * Wo; g.K = kh * kw * Ck; g.Cout = Cout; g.ldy = ldy; g.m_per_block = 2048;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     g.oihw = oihw; g.Cin_out = Cin_out; g.Cout_out = Cout_out; g.ws = nullptr; g.ws_ld = 0; g.ws_slab = 0; g.direct = direct;
-    MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (oihw ? (size_t)Cout_out * Cin_out * kh * kw : (size_t)Cout * g.K) * sizeof(float), st));
+    MFX_HIP_CHECK(mfx::zero_async(dw, (oihw ? (size_t)Cout_out * Cin_out * kh * kw : (size_t)Cout * g.K) * sizeof(float), st));
     if (g.M == 0) return MFX_OK;
     // (x chunks only need 4-byte alignment: the stem reads 8-element super-taps at a pixel stride of 4 elements)
     if (dtype == MFX_BF16 && g_opt_wgrad_mfma) {
@@ -681,16 +737,18 @@ extern "C" int mfx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int 
     return MFX_OK;
 }
 
+static int bn_rows_per_block(long M, int C, int dtype);
+
 extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int dtype, void* stream) {
     if (!x || !out) return mfx_fail(MFX_ERR_ARG, "colsum: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    MFX_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
+    MFX_HIP_CHECK(mfx::zero_async(out, (size_t)C * sizeof(float), st));
     if (M == 0) return MFX_OK;
     {
         const int E = dtype == MFX_BF16 ? 8 : 4;
         if (C % E == 0 && ld % E == 0 && C / E <= 256 && 256 % (C / E) == 0) {
-            const int rows2 = M >= (1 << 20) ? 2048 : 512;
-            const size_t smem = (size_t)C * sizeof(float);
+            const int rows2 = bn_rows_per_block(M, C, dtype);
+            const size_t smem = (size_t)(256 / (C / E)) * C * sizeof(float);
             DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_chunk_kernel<float>, dim3(cdivt(M, rows2)), dim3(256), smem, st, (const float*)x, M, C, ld, rows2, out),
                               hipLaunchKernelGGL(colsum_chunk_kernel<bf16_t>, dim3(cdivt(M, rows2)), dim3(256), smem, st, (const bf16_t*)x, M, C, ld, rows2, out));
             MFX_HIP_CHECK(hipGetLastError());
@@ -705,12 +763,16 @@ extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int 
     return MFX_OK;
 }
 
-// rows per workgroup of the two reductions: ~2048 workgroups (240 one-per-CU workgroups left these passes latency-bound at
-// a quarter of the HBM rate), a multiple of the rows one pass of the 256 threads covers
+int g_opt_bn_blocks = 768;     // option "bn_blocks": target workgroup count of the column reductions (BN statistics / backward sums / bias sums)
+
+// rows per workgroup of the column reductions: every workgroup ends with one global atomic per column, all workgroups on the
+// same 2C addresses (~12 ns each when they collide), so the count is bounded (~3 per CU, 4+ rows in flight per thread hide the
+// latency instead of more workgroups); a multiple of the rows one pass of the 256 threads covers
 static int bn_rows_per_block(long M, int C, int dtype) {
     const int E = dtype == MFX_BF16 ? 8 : 4, rstep = std::max(1, 256 / (C / E));
-    long rows = (M + 2047) / 2048;
-    rows = std::max<long>(rows, 4L * rstep);
+    const int target = g_opt_bn_blocks > 0 ? g_opt_bn_blocks : 768;
+    long rows = (M + target - 1) / target;
+    rows = std::max<long>(rows, 8L * rstep);
     rows = (rows + rstep - 1) / rstep * rstep;
     return (int)std::min<long>(rows, 1 << 20);
 }
@@ -725,14 +787,14 @@ extern "C" int mfx_bn_stats(const void* x, float* sum, float* sumsq, long M, int
     if (!x || !sum || !sumsq) return mfx_fail(MFX_ERR_ARG, "bn_stats: null pointer");
     int rc = bn_check(C, dtype); if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (sumsq == sum + C) { MFX_HIP_CHECK(hipMemsetAsync(sum, 0, (size_t)2 * C * sizeof(float), st)); }      // one fill for the usual packed pair
+    if (sumsq == sum + C) { MFX_HIP_CHECK(mfx::zero_async(sum, (size_t)2 * C * sizeof(float), st)); }      // one fill for the usual packed pair
     else {
-        MFX_HIP_CHECK(hipMemsetAsync(sum, 0, (size_t)C * sizeof(float), st));
-        MFX_HIP_CHECK(hipMemsetAsync(sumsq, 0, (size_t)C * sizeof(float), st));
+        MFX_HIP_CHECK(mfx::zero_async(sum, (size_t)C * sizeof(float), st));
+        MFX_HIP_CHECK(mfx::zero_async(sumsq, (size_t)C * sizeof(float), st));
     }
     if (M == 0) return MFX_OK;
     const int rows = bn_rows_per_block(M, C, dtype);
-    const size_t smem = (size_t)2 * C * sizeof(float);
+    const size_t smem = (size_t)(256 / (C / (dtype == MFX_BF16 ? 8 : 4))) * 2 * C * sizeof(float);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, sum, sumsq),
                       hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, sum, sumsq));
     MFX_HIP_CHECK(hipGetLastError());
@@ -770,14 +832,14 @@ extern "C" int mfx_bn_bwd_reduce(const void* x, const void* a, const void* da, c
     if (!x || !da || !mean || !rstd || !sg || !sgx || (act != MFX_ACT_NONE && !a)) return mfx_fail(MFX_ERR_ARG, "bn_bwd_reduce: null pointer");
     int rc = bn_check(C, dtype); if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (sgx == sg + C) { MFX_HIP_CHECK(hipMemsetAsync(sg, 0, (size_t)2 * C * sizeof(float), st)); }
+    if (sgx == sg + C) { MFX_HIP_CHECK(mfx::zero_async(sg, (size_t)2 * C * sizeof(float), st)); }
     else {
-        MFX_HIP_CHECK(hipMemsetAsync(sg, 0, (size_t)C * sizeof(float), st));
-        MFX_HIP_CHECK(hipMemsetAsync(sgx, 0, (size_t)C * sizeof(float), st));
+        MFX_HIP_CHECK(mfx::zero_async(sg, (size_t)C * sizeof(float), st));
+        MFX_HIP_CHECK(mfx::zero_async(sgx, (size_t)C * sizeof(float), st));
     }
     if (M == 0) return MFX_OK;
     const int rows = bn_rows_per_block(M, C, dtype);
-    const size_t smem = (size_t)2 * C * sizeof(float);
+    const size_t smem = (size_t)(256 / (C / (dtype == MFX_BF16 ? 8 : 4))) * 2 * C * sizeof(float);
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sg, sgx),
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, M, C, rows, act, sg, sgx));
@@ -828,7 +890,7 @@ extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* 
     const int E = dtype == MFX_BF16 ? 8 : 4;
     if (C % E != 0 || f < 1) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: bad C or f");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    MFX_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)4 * f * f * C * sizeof(float), st));
+    MFX_HIP_CHECK(mfx::zero_async(dw, (size_t)4 * f * f * C * sizeof(float), st));
     const long total = (long)B * H * W * (C / E);
     if (total == 0) return MFX_OK;
     const int ppb = 256;

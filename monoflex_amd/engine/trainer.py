@@ -117,16 +117,16 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
         if not self.split:
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):     # (an RCCL watchdog thread may poll events meanwhile)
                 self.loss = self._fwd_bwd()
                 optimizer.step()
             return
-        with torch.cuda.graph(self.graph_a):
+        with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
             self.loss = self._fwd_bwd()
             self._flatten()
         self._point_grads_at_views()
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
             optimizer.step()
 
     def _fwd_bwd(self):

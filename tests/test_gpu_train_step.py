@@ -76,48 +76,51 @@ def test_ddp_over_rccl_wraps_the_hip_autograd_functions(nccl_world1):
                 assert abs(float(la[k]) - float(lb[k])) <= 1e-3 * max(1.0, abs(float(la[k]))), k      # BN statistics are summed with fp32 atomics: ~1e-4 run to run
             gb = dict(b.named_parameters())
             for n, p in _big_grads(a):
-                rel = float((p.grad - gb[n].grad).abs().max() / p.grad.abs().max().clamp(min=1e-12))
-                assert rel < 5e-3, (n, rel)                      # fp32 atomics reorder sums run to run; nothing structural
+                # two runs of the SAME model differ by what fp32 atomics (BN statistics, gradient sums) reorder; through ~100
+                # ReLU/BN layers that reaches a few per cent in the earliest layers (observed 4.1e-2 at level1): structural
+                # errors (a missing all-reduce hook, a wrong bucket view) would be O(1), so direction + magnitude are checked
+                ga, gbb = p.grad.flatten().double(), gb[n].grad.flatten().double()
+                cos = float(torch.dot(ga, gbb) / (ga.norm() * gbb.norm()).clamp(min=1e-30))
+                assert cos > 0.99 and abs(float(ga.norm() / gbb.norm()) - 1) < 0.05, (n, cos)
     dead = set(dead_parameter_names(b))
     assert all((p.grad is None) == (n in dead) for n, p in b.named_parameters())
 
 
 @pytest.mark.parametrize("split", [False, True])
 def test_graphed_train_step_equals_the_eager_step(split, nccl_world1):
-    """engine.trainer.GraphedTrainStep (what `bench.py --mode train` times): the first replayed step moves every parameter
-    like one eager train_step from the same start.  split=True is the data-parallel form (flat fp32 gradient buffer,
-    all-reduce between two graphs) on the world_size-1 RCCL group."""
+    """engine.trainer.GraphedTrainStep (what `bench.py --mode train` times): one replayed step moves every parameter like one
+    eager train_step from the same state (parameters, BN buffers, AdamW moments).  split=True is the data-parallel form (flat
+    fp32 gradient buffer, all-reduce between two graphs) on the world_size-1 RCCL group."""
     from monoflex_amd.engine.trainer import GraphedTrainStep, train_step
     from monoflex_amd.solver import build_optimizer
     cfg = _cfg()
-    a, b = _model(), _model()
-    imgs, tg = _batch(a)
-    start = {n: p.detach().clone() for n, p in a.named_parameters()}
-    opt_a = build_optimizer(a, cfg)
-    loss_a = float(train_step(a, opt_a, imgs, tg)[0])
+    b = _model()
+    imgs, tg = _batch(b)
     opt_b = build_optimizer(b, cfg, capturable=True)
     step = GraphedTrainStep(b, opt_b, imgs, tg, warmup=2, split=split)
     assert (step.graph_b is not None) == split
-    # the capture warm-up already stepped b: rewind parameters, BN statistics and optimizer state, then replay ONE step
-    with torch.no_grad():
-        for n, p in b.named_parameters():
-            p.copy_(start[n])
-        for st in opt_b.state.values():
-            for k, v in st.items():
-                v.zero_()
+    torch.cuda.synchronize()
+    # state after the capture warm-up = common starting point; an eager twin starts from a copy of it
+    model_sd = {k: v.detach().clone() for k, v in b.state_dict().items()}
+    opt_sd = copy.deepcopy(opt_b.state_dict())
+    start = {n: p.detach().clone() for n, p in b.named_parameters()}
     loss_b = float(step())
     torch.cuda.synchronize()
-    assert abs(loss_a - loss_b) <= 2e-3 * abs(loss_a), (loss_a, loss_b)     # BN running stats differ after warm-up; loss uses batch stats
+    a = _model(seed=5)
+    a.load_state_dict(model_sd)
+    opt_a = build_optimizer(a, cfg, capturable=True)
+    opt_a.load_state_dict(opt_sd)
+    loss_a = float(train_step(a, opt_a, imgs, tg)[0])
+    assert abs(loss_a - loss_b) <= 2e-3 * abs(loss_a), (loss_a, loss_b)
     pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
     checked = 0
     for n, p in _big_grads(a, 40):
         da, db = (pa[n] - start[n]).flatten().double(), (pb[n] - start[n]).flatten().double()
         cos = float(torch.dot(da, db) / (da.norm() * db.norm()).clamp(min=1e-30))
-        assert cos > 0.8, (n, cos)              # AdamW's first update is ~lr*sign(g): near-zero gradients flip with the atomics' order
+        assert cos > 0.8, (n, cos)              # small-gradient entries flip with the fp32 atomics' summation order
         checked += 1
     assert checked >= 10
-    l2 = float(step())
-    assert np.isfinite(l2)
+    assert np.isfinite(float(step()))
 
 
 def test_torch_sync_batchnorm_converter_is_accepted():
