@@ -89,7 +89,9 @@ class Conv2dFn(Function):
     multiple of the 16-byte chunk (extra channels are exactly zero); callers slice."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, out_dtype=None):
+    def forward(ctx, x, weight, bias, stride, pad, out_dtype=None, act=L.ACT_NONE):
+        """`act` = ACT_DCN_OFFMASK fuses the sigmoid of the DCN mask channels into the epilogue; the CONSUMER (DCNFn with
+        post_sigmoid=True) then hands back the gradient of the pre-activation, which is what backward() below expects."""
         x = _c(x)
         Cout, Cin, kh, kw = weight.shape
         cpad = _pad_channels(Cout, out_dtype or x.dtype)
@@ -99,6 +101,7 @@ class Conv2dFn(Function):
             shift = torch.zeros(cp, dtype=torch.float32, device=x.device)
             shift[:Cout] = bias.detach()
         p = _pack_weight(weight, x.dtype, 0, cpad, Cin, stride, pad, pad, shift)
+        p.act = act
         y = ops.conv2d(x, p, out_dtype=out_dtype)             # bf16 mode: fp32 out for DCN offsets and the head maps
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, bias is not None, Cout)
@@ -139,7 +142,7 @@ class Conv2dFn(Function):
             dw = dwf if weight.dtype == torch.float32 else dwf.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy)[:Cout]
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 @_device_guarded
@@ -340,10 +343,13 @@ class DCNFn(Function):
     18..26 mask logits, reference dcn_v2.py:118-122)."""
 
     @staticmethod
-    def forward(ctx, x, offmask_raw, weight, bias, stride, pad, dil):
+    def forward(ctx, x, offmask_raw, weight, bias, stride, pad, dil, post_sigmoid=False):
         x, raw = _c(x), _c(offmask_raw).float()
-        om = raw.clone()
-        om[..., 18:27] = torch.sigmoid(raw[..., 18:27])
+        if post_sigmoid:                                       # the offset/mask conv already applied the sigmoid (fused epilogue)
+            om = raw
+        else:
+            om = raw.clone()
+            om[..., 18:27] = torch.sigmoid(raw[..., 18:27])
         p = ops.pack_conv(weight, x.dtype, None, bias, stride=stride, pad=pad, act=L.ACT_NONE)
         p.dil_w = dil
         y = ops.dcn(x, om, p)
@@ -372,7 +378,7 @@ class DCNFn(Function):
             wc = _c(weight.detach() if weight.dtype == torch.float32 else weight.detach().float())
             L.check(lib_.mfx_dcn_backward_v2(_ptr(x), _ptr(om), _ptr(wc), _ptr(dy if dy.dtype == x.dtype else dy.to(x.dtype)), _ptr(dx), _ptr(draw),
                                              _ptr(dw), _ptr(db), B, C, H, W, Cout, dt, _ptr(ws), ws.numel(), _stream()), "mfx_dcn_backward_v2")
-            return dx, draw, dw if weight.dtype == torch.float32 else dw.to(weight.dtype), db, None, None, None
+            return dx, draw, dw if weight.dtype == torch.float32 else dw.to(weight.dtype), db, None, None, None, None
         nbytes = lib_.mfx_dcn_backward_nhwc_workspace_bytes(B, C, H, W, Cout, kh, kw, stride, pad, dil)
         ws = ops._workspace(nbytes, x.device)
         xdtype = x.dtype
@@ -391,7 +397,7 @@ class DCNFn(Function):
         m = om[..., 18:27]
         dom[..., 18:27] = dom[..., 18:27] * m * (1 - m)               # through the sigmoid
         dom[..., 27:] = 0
-        return dx.to(xdtype), dom, dw.to(weight.dtype), db, None, None, None
+        return dx.to(xdtype), dom, dw.to(weight.dtype), db, None, None, None, None
 
 
 _DCN_BWD_V1 = [False]          # tests: force the first-generation (global-atomics) backward for comparison

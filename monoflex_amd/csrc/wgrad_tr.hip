@@ -27,7 +27,7 @@ constexpr int TR_BK = 192, TR_STEP = 32;
 
 __device__ __forceinline__ int tr_rowpos(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-// four 16x(8 rows) fragments of one operand: sub-tiles at byte offsets 0 / 1024 / 2048 / 3072 from the two lane addresses
+// four 16x(8 rows) fragments of one operand: sub-tiles at byte offsets 0 / 1056 / 2112 / 3168 from the two lane addresses
 // (rows 8g..8g+3 and 8g+4..8g+7); ONE asm block so that the wait sits behind all eight reads and nothing that consumes the
 // results can be scheduled in front of it
 __device__ __forceinline__ void tr_read4(uint32_t alo, uint32_t ahi, u32x4 (&f)[4]) {
@@ -35,12 +35,12 @@ __device__ __forceinline__ void tr_read4(uint32_t alo, uint32_t ahi, u32x4 (&f)[
     asm volatile(
         "ds_read_b64_tr_b16 %0, %8\n\t"
         "ds_read_b64_tr_b16 %1, %9\n\t"
-        "ds_read_b64_tr_b16 %2, %8 offset:1024\n\t"
-        "ds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
-        "ds_read_b64_tr_b16 %4, %8 offset:2048\n\t"
-        "ds_read_b64_tr_b16 %5, %9 offset:2048\n\t"
-        "ds_read_b64_tr_b16 %6, %8 offset:3072\n\t"
-        "ds_read_b64_tr_b16 %7, %9 offset:3072\n\t"
+        "ds_read_b64_tr_b16 %2, %8 offset:1056\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:1056\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:2112\n\t"
+        "ds_read_b64_tr_b16 %5, %9 offset:2112\n\t"
+        "ds_read_b64_tr_b16 %6, %8 offset:3168\n\t"
+        "ds_read_b64_tr_b16 %7, %9 offset:3168\n\t"
         "s_waitcnt lgkmcnt(0)"
         : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
         : "v"(alo), "v"(ahi)
@@ -55,7 +55,8 @@ template <int WO>
 __global__ __launch_bounds__(WO * 192) void conv_wgrad_tr_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, WgradGeom g) {
     constexpr int NT = WO * 192, BO = WO * 64, BK = TR_BK;
     constexpr int OB = BO / 16, KB = BK / 16;                 // 16-channel sub-tiles per operand
-    constexpr int SUB = TR_STEP * 32;                         // bytes per sub-tile (32 rows x 32 B)
+    constexpr int SUB = TR_STEP * 32 + 32;                    // bytes per sub-tile: 32 rows x 32 B, + 32 so that the sub-tiles of one
+                                                              // pixel (the 16-byte stores of 8 neighbouring lanes) start 8 banks apart
     constexpr int DY_BYTES = OB * SUB, A_BYTES = KB * SUB, STAGE = DY_BYTES + A_BYTES;
     extern __shared__ __attribute__((aligned(16))) char lds[];        // [2][STAGE]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -76,6 +77,15 @@ __global__ __launch_bounds__(WO * 192) void conv_wgrad_tr_kernel(const bf16_t* _
     const int hw = g.Ho * g.Wo;
 
     struct Regs { u32x4 a[A_N]; u32x4 d[D_N]; };
+    // (b, oh, ow) of this thread's A rows, advanced by 32 pixels per load: integer divisions per chunk made the first version
+    // VALU-bound (12.5 VALU instructions per MFMA, PMC in profiles/r02_wgrad_tr_pmc.md)
+    int pb[A_N], poh[A_N], pow_[A_N];
+#pragma unroll
+    for (int j = 0; j < A_N; ++j) {
+        const int m = m_begin + a_r0 + j * A_RPP;
+        pb[j] = m / hw; const int rem = m - pb[j] * hw; poh[j] = rem / g.Wo; pow_[j] = rem - poh[j] * g.Wo;
+    }
+    int m_next = m_begin;                                      // first pixel of the next tile to load (loads are issued in order)
     auto gload = [&](Regs& r, int m0) {                        // tiles of pixels m0 .. m0 + 31
 #pragma unroll
         for (int j = 0; j < A_N; ++j) {
@@ -84,13 +94,15 @@ __global__ __launch_bounds__(WO * 192) void conv_wgrad_tr_kernel(const bf16_t* _
             if (a_ok && m < m_end) {
                 if (g.direct) r.a[j] = *reinterpret_cast<const u32x4*>(x + (size_t)m * g.x_pixstride + a_kk);
                 else {
-                    const int b = m / hw, rem = m - b * hw, oh = rem / g.Wo, ow = rem - oh * g.Wo;
-                    const int ih = oh * g.stride - g.pad_h + a_th, iw = ow * g.stride - g.pad_w + a_tw * g.dil_w;
+                    const int ih = poh[j] * g.stride - g.pad_h + a_th, iw = pow_[j] * g.stride - g.pad_w + a_tw * g.dil_w;
                     if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)
-                        r.a[j] = *reinterpret_cast<const u32x4*>(x + ((size_t)(b * g.H + ih) * g.W + iw) * g.x_pixstride + a_ch);
+                        r.a[j] = *reinterpret_cast<const u32x4*>(x + ((size_t)(pb[j] * g.H + ih) * g.W + iw) * g.x_pixstride + a_ch);
                 }
             }
+            pow_[j] += TR_STEP;                                // next tile: 32 pixels further (row-major over (b, oh, ow))
+            while (pow_[j] >= g.Wo) { pow_[j] -= g.Wo; if (++poh[j] == g.Ho) { poh[j] = 0; ++pb[j]; } }
         }
+        (void)m_next;
 #pragma unroll
         for (int j = 0; j < D_N; ++j) {
             r.d[j] = u32x4{0u, 0u, 0u, 0u};
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(WO * 192) void conv_wgrad_tr_kernel(const bf16_t* _
     const int frag_lo = tr_rowpos(8 * gq + (l16 >> 2)) * 32 + (l16 & 3) * 8;
     const int frag_hi = tr_rowpos(8 * gq + 4 + (l16 >> 2)) * 32 + (l16 & 3) * 8;
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
-    static_assert(SUB == 1024, "tr_read4 immediates");
+    static_assert(SUB == 1056, "tr_read4 immediates");
     auto compute = [&](int buf) {
         const uint32_t sb = lds_base + buf * STAGE;
         u32x4 af[4], bf[4];
@@ -141,18 +153,27 @@ __global__ __launch_bounds__(WO * 192) void conv_wgrad_tr_kernel(const bf16_t* _
             for (int j = 0; j < 4; ++j) mma_chunk<bf16_t>(af[i], bf[j], acc[i][j]);
     };
 
+    // steps s = 0 .. ns-1; register set R[s & 1] holds the data of step s.  Global loads run TWO steps ahead of their LDS
+    // store (one step of 16 MFMAs per wave is far shorter than an L2 / HBM round trip): iteration s issues the loads of step
+    // s+2 into the set that step s has just vacated, computes step s, then stores step s+1 (loaded one iteration ago).
     const int ns = (m_end - m_begin + TR_STEP - 1) / TR_STEP;
-    Regs R;
-    gload(R, m_begin);
-    lstore(0, R);
+    Regs R0, R1;
+    gload(R0, m_begin);
+    lstore(0, R0);
+    if (ns > 1) gload(R1, m_begin + TR_STEP);
     __syncthreads();
-    for (int s = 0; s < ns; ++s) {
-        const bool more = s + 1 < ns;
-        if (more) gload(R, m_begin + (s + 1) * TR_STEP);       // global loads of the next step fly during the MFMAs
-        compute(s & 1);
-        if (more) lstore((s + 1) & 1, R);
+    int s = 0;
+    for (; s + 2 <= ns; s += 2) {                             // unrolled by two: static register sets
+        if (s + 2 < ns) gload(R0, m_begin + (s + 2) * TR_STEP);
+        compute(0);
+        if (s + 1 < ns) lstore(1, R1);
+        __syncthreads();
+        if (s + 3 < ns) gload(R1, m_begin + (s + 3) * TR_STEP);
+        compute(1);
+        if (s + 2 < ns) lstore(0, R0);
         __syncthreads();
     }
+    if (s < ns) compute(0);                                   // odd tail (its data was stored by the last iteration)
 
     // D: col (lane & 15) = k, row (lane >> 4) * 4 + r = o; partial tile -> workspace slab (plain stores)
     float* wsb = g.ws + (size_t)blockIdx.z * g.ws_slab;
@@ -171,11 +192,14 @@ __global__ __launch_bounds__(WO * 192) void conv_wgrad_tr_kernel(const bf16_t* _
 using namespace mfx;
 
 int g_opt_wgrad_tr = 1;          // option "wgrad_tr": 0 = first-generation kernel everywhere
-int g_opt_wgrad_tr_blocks = 1024;   // option "wgrad_tr_blocks": target workgroup count (tiles x pixel slabs)
+int g_opt_wgrad_tr_blocks = 512;   // option "wgrad_tr_blocks": target workgroup count (tiles x pixel slabs)
 
 // returns 1 if handled (partial tiles are in g.ws: the caller runs wgrad_reduce_kernel), 0 to fall through
 int try_conv_wgrad_tr(const void* x, const void* dy, WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st) {
     if (!g_opt_wgrad_tr || !workspace) return 0;
+    // Cout = 64: the 64 x 192 workgroup tile (49 FLOP per L1 byte) measured slower than the first-generation kernel
+    // (188 vs 137 us on 64->64 @ 96x320, B=8), so those layers fall through unless option wgrad_tr = 2 forces it
+    if (g.Cout % 128 != 0 && g_opt_wgrad_tr != 2) return 0;
     if (g.K % TR_BK != 0 || g.Cout % 64 != 0 || g.Ck % 8 != 0 || g.x_pixstride % 8 != 0 || g.ldy % 8 != 0 || g.M < 4096) return 0;
     const int wo = g.Cout % 128 == 0 ? 2 : 1, bo = wo * 64;
     const int tiles = (g.K / TR_BK) * (g.Cout / bo);
@@ -189,10 +213,10 @@ int try_conv_wgrad_tr(const void* x, const void* dy, WgradGeom& g, void* workspa
     g.ws = reinterpret_cast<float*>(workspace); g.ws_ld = ws_ld; g.ws_slab = ws_slab;
     const dim3 grid(g.K / TR_BK, g.Cout / bo, nslab);
     if (wo == 2) {
-        constexpr int smem = 2 * ((128 / 16) + (TR_BK / 16)) * TR_STEP * 32;
+        constexpr int smem = 2 * ((128 / 16) + (TR_BK / 16)) * (TR_STEP * 32 + 32);
         hipLaunchKernelGGL(conv_wgrad_tr_kernel<2>, grid, dim3(384), smem, st, (const bf16_t*)x, (const bf16_t*)dy, g);
     } else {
-        constexpr int smem = 2 * ((64 / 16) + (TR_BK / 16)) * TR_STEP * 32;
+        constexpr int smem = 2 * ((64 / 16) + (TR_BK / 16)) * (TR_STEP * 32 + 32);
         hipLaunchKernelGGL(conv_wgrad_tr_kernel<1>, grid, dim3(192), smem, st, (const bf16_t*)x, (const bf16_t*)dy, g);
     }
     *nslab_out = nslab;

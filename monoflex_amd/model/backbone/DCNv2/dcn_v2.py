@@ -116,8 +116,10 @@ class DCN(DCNv2):
         """Differentiable NHWC form: offset/mask conv -> DCNv2 (gradients to x, offsets, mask logits, weight, bias)."""
         from .... import autograd as AG
         c = self.conv_offset_mask
-        raw = AG.Conv2dFn.apply(x, c.weight, c.bias, self.stride[0], self.padding[0], torch.float32)   # (B,H,W,32), 27 used
-        return AG.DCNFn.apply(x, raw, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
+        # (B,H,W,32), 27 used; the sigmoid of the 9 mask channels runs in the conv epilogue, and DCNFn returns the gradient
+        # of the pre-activation (both generations of the backward fold the sigmoid derivative in)
+        om = AG.Conv2dFn.apply(x, c.weight, c.bias, self.stride[0], self.padding[0], torch.float32, L.ACT_DCN_OFFMASK)
+        return AG.DCNFn.apply(x, om, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0], True)
 
     def forward(self, input):
         if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad and self.training):

@@ -1,3 +1,2 @@
-echo "== tr on (blocks 512)"; python tools/wgrad_bench.py --opts wgrad_tr_blocks=512
-echo "== tr on (blocks 256)"; python tools/wgrad_bench.py --opts wgrad_tr_blocks=256
-echo "== tr off"; python tools/wgrad_bench.py --opts wgrad_tr=0
+python -m pytest tests/test_gpu_train.py -q -m gpu -p no:cacheprovider 2>&1 | tail -3 | cut -c1-200
+python bench.py --mode train --no-cpu-baseline --steps 5 2>&1 | tail -1 | cut -c90-200

@@ -14,6 +14,7 @@ from monoflex_amd import lib as L, ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--opts", default="")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--only", default="", help="substring of the shape name")
 a = ap.parse_args()
 lib = L.load()
 for kv in filter(None, a.opts.split(",")):
@@ -30,6 +31,8 @@ dev = torch.device("cuda", 0)
 ws = ops._splitk_workspace(dev)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for name, B, H, W, Ci, Co, k, s in SHAPES:
+    if a.only and a.only not in name:
+        continue
     Ho, Wo = H // s, W // s
     x = torch.randn(B, H, W, Ci, device=dev).bfloat16()
     dy = torch.randn(B, Ho, Wo, Co, device=dev).bfloat16()
@@ -48,4 +51,4 @@ for name, B, H, W, Ci, Co, k, s in SHAPES:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.reps
     gf = 2.0 * B * Ho * Wo * Co * Ci * k * k / 1e9
-    print("%-28s %8.1f us  %7.1f GF  %7.1f TF/s" % (name, us, gf, gf / us * 1e3 / 1e3))
+    print("%-28s %8.1f us  %7.1f GF  %7.1f TF/s" % (name, us, gf, gf / us))
