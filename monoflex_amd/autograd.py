@@ -70,8 +70,8 @@ def _pack_weight(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, shift=None
     """One-launch packing of an fp32 OIHW parameter into the conv operand (mode 0 forward, 1 data gradient)."""
     Cout, Cin, kh, kw = weight.shape
     E = 4 if dtype == torch.float32 else 8
-    if ck & (ck - 1) or ck < E:
-        raise ValueError("conv operand: channels per tap must be a power of two >= %d (got %d)" % (E, ck))
+    if (ck & (ck - 1) and kh * kw > 1) or ck < E or ck % E:
+        raise ValueError("conv operand: channels per tap must be a power of two >= %d (any multiple of %d for 1x1), got %d" % (E, E, ck))
     K_pad = (kh * kw * ck + 8 * E - 1) // (8 * E) * (8 * E)
     cp = ops.cout_pad(rows)
     w32 = weight.detach()
@@ -98,8 +98,7 @@ class Conv2dFn(Function):
         shift = None
         if bias is not None:
             cp = ops.cout_pad(cpad)
-            shift = torch.zeros(cp, dtype=torch.float32, device=x.device)
-            shift[:Cout] = bias.detach()
+            shift = bias.detach().float() if cp == Cout else torch.nn.functional.pad(bias.detach().float(), (0, cp - Cout))
         p = _pack_weight(weight, x.dtype, 0, cpad, Cin, stride, pad, pad, shift)
         p.act = act
         y = ops.conv2d(x, p, out_dtype=out_dtype)             # bf16 mode: fp32 out for DCN offsets and the head maps
@@ -154,9 +153,11 @@ class CatConv1x1Fn(Function):
     def forward(ctx, weight, *xs):
         xs = [_c(t) for t in xs]
         chans = tuple(t.shape[3] for t in xs)
-        Cout = weight.shape[0]
-        one = torch.ones(Cout, device=weight.device)
-        p = ops.pack_cat(weight, xs[0].dtype, one, torch.zeros_like(one), chans, act=L.ACT_NONE)
+        Cout, Ctot = weight.shape[0], weight.shape[1]
+        pk = _pack_weight(weight, xs[0].dtype, 0, Cout, Ctot, 1, 0, 0)          # one launch: [Cout_pad][Ctot], K-contiguous
+        Cseg = min(chans)
+        assert sum(chans) == Ctot and all(c % Cseg == 0 for c in chans) and Cseg & (Cseg - 1) == 0 and pk.K_pad == Ctot
+        p = ops.PackedCat(pk.w, None, None, Cseg, Cout, pk.Cout_pad, Ctot, L.ACT_NONE)
         ctx.save_for_backward(weight, *xs)
         return ops.cat_conv1x1(xs, p)
 
@@ -165,14 +166,15 @@ class CatConv1x1Fn(Function):
     def backward(ctx, dy):
         weight, *xs = ctx.saved_tensors
         dy = _c(dy)
-        Cout = weight.shape[0]
-        w2 = weight.detach().reshape(Cout, -1)
+        Cout, Ctot = weight.shape[0], weight.shape[1]
+        need_dx = any(ctx.needs_input_grad[1 + i] for i in range(len(xs)))
+        # data-gradient operand of the whole Root in one launch: WT[c][o] = W[o][c]; source i uses rows [off, off + C_i)
+        wt = _pack_weight(weight, dy.dtype, 1, Ctot, Cout, 1, 0, 0) if need_dx else None
         dws, dxs, off = [], [], 0
         for i, x in enumerate(xs):
             C = x.shape[3]
-            seg = w2[:, off:off + C]
             if ctx.needs_input_grad[1 + i]:
-                pt = ops.pack_conv(seg.t().reshape(C, Cout, 1, 1).contiguous(), x.dtype, None, None, stride=1, pad=0, act=L.ACT_NONE)
+                pt = ops.PackedConv(wt.w[off:off + C], None, None, 1, 1, 1, 0, 0, 1, Cout, C, C, wt.K_pad, L.ACT_NONE, None)
                 dxs.append(ops.conv2d(dy, pt))
             else:
                 dxs.append(None)

@@ -267,7 +267,9 @@ def cat_conv1x1(srcs, p: PackedCat):
             d.src[n], d.stride[n], d.off[n] = s.data_ptr(), C, part * p.Cseg
             n += 1
     d.nseg, d.Cseg = n, p.Cseg
-    d.w, d.scale, d.shift, d.res, d.y = p.w.data_ptr(), p.scale.data_ptr(), p.shift.data_ptr(), None, y.data_ptr()
+    d.w, d.res, d.y = p.w.data_ptr(), None, y.data_ptr()
+    d.scale = p.scale.data_ptr() if p.scale is not None else None
+    d.shift = p.shift.data_ptr() if p.shift is not None else None
     d.M, d.Cout, d.Cout_pad, d.K_pad, d.ldy, d.ldres, d.act, d.dtype = B * H * W, p.Cout, p.Cout_pad, p.K_pad, p.Cout, 0, p.act, _dt(y.dtype)
     L.check(L.load().mfx_cat_conv1x1_nhwc(ctypes.byref(d), _stream()), "mfx_cat_conv1x1_nhwc")
     return y
