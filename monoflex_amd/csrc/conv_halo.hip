@@ -160,14 +160,17 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
                 bf[j] = z;
             }
         };
-        // weight fragments: ring of 3 register buffers, fetched two steps ahead of their use.  This wave's steps are
-        // S(j) = wk + j*WK, j < nl
-        u32x4 wb[3][FN];
+        // weight fragments: ring of RING register buffers, fetched RING-1 steps ahead of their use.  A step is FM*FN MFMAs
+        // = 107 ns (FN 2) .. 213 ns (FN 4) of matrix-pipe time per wave, an L2 round trip is ~400-500 ns: narrow waves need a
+        // deeper ring than wide ones (option "halo_ring" to compare).  This wave's steps are S(j) = wk + j*WK, j < nl
+        constexpr int RING = FN >= 4 ? 3 : 5;
+        u32x4 wb[RING][FN];
         const int ns = g.steps_per_group;
         const int nl = ns > wk ? (ns - wk + WK - 1) / WK : 0;
         auto S = [&](int j) { return wk + j * WK; };
-        if (nl > 0) wfetch(S(0), wb[0]);
-        if (nl > 1) wfetch(S(1), wb[1]);
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u)
+            if (u < nl) wfetch(S(u), wb[u]);
         __syncthreads();                                      // patch visible to all waves
 
         auto compute = [&](int s, const u32x4 (&bf)[FN]) {
@@ -185,19 +188,16 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
             }
         };
         int s = 0;
-        for (; s + 3 <= nl; s += 3) {                         // unrolled by 3 so the ring indices are static
-            if (s + 2 < nl) wfetch(S(s + 2), wb[2]);
-            compute(S(s), wb[0]);
-            if (s + 3 < nl) wfetch(S(s + 3), wb[0]);
-            compute(S(s + 1), wb[1]);
-            if (s + 4 < nl) wfetch(S(s + 4), wb[1]);
-            compute(S(s + 2), wb[2]);
+        for (; s + RING <= nl; s += RING) {                   // unrolled by RING so the ring indices are static
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                if (s + u + RING - 1 < nl) wfetch(S(s + u + RING - 1), wb[(u + RING - 1) % RING]);
+                compute(S(s + u), wb[u]);
+            }
         }
-        if (s < nl) {                                         // 1 or 2 steps left; their fragments are already in flight
-            if (s + 2 < nl) wfetch(S(s + 2), wb[2]);
-            compute(S(s), wb[0]);
-            if (s + 1 < nl) compute(S(s + 1), wb[1]);
-        }
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u)                    // < RING steps left; their fragments are already in flight
+            if (s + u < nl) compute(S(s + u), wb[u]);
     }
 
     // ---- K-split: partial accumulators -> LDS (the patch is dead), wave wk sums and finishes rows wk*RW .. +RW
