@@ -284,6 +284,11 @@ size_t mfx_dcn_backward_v2_workspace_bytes(int B, int C, int H, int W, int Cout,
 int mfx_dcn_backward_v2(const void* x, const float* offmask, const float* weight_oihw, const void* dy, void* dx,
                         float* d_raw, float* dweight, float* dbias, int B, int C, int H, int W, int Cout, int dtype,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* Heat-map loss (penalty-reduced focal loss, model/layers/focal_loss.py:29-55 on sigmoid_hm(logits), layers/utils.py:39-42)
+ * in one pass: logits fp32 NHWC (B,H,W,ncls), target fp32 NCHW (B,ncls,H,W) -> sums2 = [loss_sum, num_pos] (overwritten) and
+ * dlogits (B,H,W,ncls) = d(loss_sum)/d(logit), the clamp of the sigmoid included. */
+int mfx_focal_loss(const float* logits_nhwc, const float* heat_nchw, int B, int H, int W, int ncls, float alpha, float beta,
+                   float* sums2, float* dlogits_nhwc, void* stream);
 
 /* ---- (4) input pipeline: KITTI sample -> network input + training targets, on the device ------------------------------
  * Replaces the per-sample numpy/PIL work of the reference's dataset (data/datasets/kitti.py:231-525 __getitem__,

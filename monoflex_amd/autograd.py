@@ -405,6 +405,31 @@ class DCNFn(Function):
 _DCN_BWD_V1 = [False]          # tests: force the first-generation (global-atomics) backward for comparison
 
 
+@_device_guarded
+class FocalLossFn(Function):
+    """Penalty-reduced focal loss of the class heat map in one kernel (csrc/loss_kernels.hip): fp32 NHWC logits (B,H,W,C) and
+    the NCHW Gaussian target map -> (loss_sum, num_pos); sigmoid + clamp(1e-4, 1-1e-4) are part of the kernel, and
+    d(loss_sum)/d(logit) is written in the same pass, so backward is one scale."""
+
+    @staticmethod
+    def forward(ctx, logits, heat, alpha, beta):
+        z, t = _c(logits).float(), _c(heat).float()
+        B, H, W, C = z.shape
+        sums = torch.empty(2, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        L.check(L.load().mfx_focal_loss(_ptr(z), _ptr(t), B, H, W, C, ctypes.c_float(alpha), ctypes.c_float(beta), _ptr(sums), _ptr(dz),
+                                        _stream()), "mfx_focal_loss")
+        ctx.save_for_backward(dz)
+        ctx.mark_non_differentiable(sums[1:])
+        return sums[0], sums[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_loss, g_np):
+        (dz,) = ctx.saved_tensors
+        return dz * g_loss, None, None, None
+
+
 def conv2d(x, weight, bias=None, stride=1, pad=0, out_dtype=None):
     """Differentiable NHWC conv; returns exactly weight.shape[0] channels."""
     y = Conv2dFn.apply(x, weight, bias, stride, pad, out_dtype)

@@ -1,0 +1,70 @@
+// Fused loss kernels of the training step (reference model/head/detector_loss.py:267-300, model/layers/focal_loss.py:29-55).
+//
+// Heat-map term (penalty-reduced focal loss of CenterNet) over the (B, classes, H, W) class map: the reference runs
+//   sigmoid -> clamp(1e-4, 1-1e-4) -> eq/lt/ge masks -> pow -> log -> mul ... -> two sums -> backward of all of it,
+// ~35 elementwise passes over 737 k elements per step.  Here ONE pass reads the NHWC logits and the NCHW target map,
+// accumulates [loss_sum, num_pos] and writes d(loss_sum)/d(logit) for the backward pass (which is then a single scale).
+#include "../../include/monoflex_hip.h"
+#include "common.h"
+#include "err.h"
+#include "fill.h"
+
+namespace mfx {
+
+__global__ __launch_bounds__(256) void focal_loss_kernel(const float* __restrict__ logits, const float* __restrict__ heat,
+                                                        int B, int HW, int ncls, float alpha, float beta,
+                                                        float* __restrict__ sums, float* __restrict__ dz) {
+    const long total = (long)B * HW * ncls;
+    float ls = 0.f, np = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // i indexes the NHWC logits: (b, p, c); the target is NCHW: (b, c, p)
+        const int c = (int)(i % ncls);
+        const long bp = i / ncls;
+        const int p = (int)(bp % HW), b = (int)(bp / HW);
+        const float z = logits[i], t = heat[((size_t)b * ncls + c) * HW + p];
+        const float s = 1.f / (1.f + expf(-z));
+        const bool clamped = s < 1e-4f || s > 1.f - 1e-4f;           // sigmoid_hm: clamp(min=1e-4, max=1-1e-4) (layers/utils.py:39-42)
+        const float pr = fminf(fmaxf(s, 1e-4f), 1.f - 1e-4f);
+        const float dpdz = clamped ? 0.f : pr * (1.f - pr);
+        float l = 0.f, dldp = 0.f;
+        if (t == 1.f) {                                              // positive: log(p) * (1-p)^alpha
+            const float q = 1.f - pr, qa = powf(q, alpha);
+            l = logf(pr) * qa;
+            dldp = qa / pr - alpha * powf(q, alpha - 1.f) * logf(pr);
+            np += 1.f;
+        } else if (t < 1.f && t >= 0.f) {                            // negative: log(1-p) * p^alpha * (1-t)^beta
+            const float nw = powf(1.f - t, beta), pa = powf(pr, alpha), q = 1.f - pr;
+            l = logf(q) * pa * nw;
+            dldp = nw * (alpha * powf(pr, alpha - 1.f) * logf(q) - pa / q);
+        }
+        ls -= l;                                                     // loss_sum = -sum(pos) - sum(neg)
+        dz[i] = -dldp * dpdz;
+    }
+    // block reduction -> two global atomics per block
+    __shared__ float red[2][4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ls += __shfl_xor(ls, off); np += __shfl_xor(np, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ls; red[1][threadIdx.x >> 6] = np; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(sums, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        unsafeAtomicAdd(sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+}  // namespace mfx
+using namespace mfx;
+
+extern "C" int mfx_focal_loss(const float* logits_nhwc, const float* heat_nchw, int B, int H, int W, int ncls, float alpha, float beta,
+                              float* sums2, float* dlogits_nhwc, void* stream) {
+    if (!logits_nhwc || !heat_nchw || !sums2 || !dlogits_nhwc) return mfx_fail(MFX_ERR_ARG, "focal_loss: null pointer");
+    if (ncls < 1 || B < 0 || H < 0 || W < 0) return mfx_fail(MFX_ERR_ARG, "focal_loss: bad sizes");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MFX_HIP_CHECK(mfx::zero_async(sums2, 8, st));
+    const long total = (long)B * H * W * ncls;
+    if (total == 0) return MFX_OK;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(focal_loss_kernel, dim3(blocks), dim3(256), 0, st, logits_nhwc, heat_nchw, B, H * W, ncls, alpha, beta, sums2, dlogits_nhwc);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}

@@ -107,6 +107,7 @@ SYMBOLS = {
     "mfx_dcn_backward_nhwc_bf16": (_I, [_P] * 8 + [_I] * 10 + [_P, _S, _P]),
     "mfx_dcn_backward_v2_workspace_bytes": (_S, [_I] * 6),
     "mfx_dcn_backward_v2": (_I, [_P] * 8 + [_I] * 6 + [_P, _S, _P]),
+    "mfx_focal_loss": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "mfx_kitti_encode_targets": (_I, [ctypes.POINTER(KittiDesc), _P]),
     "mfx_kitti_preprocess_u8": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P]),
     "mfx_kitti_eval_overlaps": (_I, [ctypes.POINTER(KittiEvalDesc), _P]),

@@ -288,7 +288,12 @@ class Loss_Computation:
         v2 = sel['reg_2D'].float()
         one = torch.ones((), device=dev)
 
-        hm_loss, num_pos = self._focal(predictions['cls'], heat.to(dev))
+        if predictions.get('cls_logits_nhwc') is not None and predictions['cls_logits_nhwc'].is_cuda:
+            # fused heat-map term: the predictor hands over its fp32 NHWC logits; sigmoid + clamp + focal + gradient in one pass
+            from ... import autograd as AG
+            hm_loss, num_pos = AG.FocalLossFn.apply(predictions['cls_logits_nhwc'], heat.to(dev), float(self.focal_alpha), float(self.focal_beta))
+        else:
+            hm_loss, num_pos = self._focal(predictions['cls'], heat.to(dev))
         hm_loss = W['hm_loss'] * hm_loss / torch.clamp(num_pos, 1)
 
         # 2D box (GIoU); unselected rows get a unit box on both sides

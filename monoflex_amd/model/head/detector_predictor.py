@@ -244,9 +244,11 @@ class _predictor(nn.Module):
         x = features.permute(0, 2, 3, 1).contiguous()
         ei, el = getattr(targets, "edge", None) or stack_edge_fields(targets, x.device)
         if self.training:
-            cls, reg = self.forward_train(x, ei, el)
-            cls = torch.sigmoid(cls).clamp(min=1e-4, max=1 - 1e-4)
-            return {'cls': cls.permute(0, 3, 1, 2), 'reg': reg.permute(0, 3, 1, 2)}
+            logits, reg = self.forward_train(x, ei, el)
+            # 'cls' keeps the reference's contract (sigmoid_hm of the logits, NCHW); the loss uses the raw NHWC logits and does
+            # sigmoid + clamp + focal + its gradient in one kernel, so this view stays a detached by-product
+            cls = torch.sigmoid(logits.detach()).clamp(min=1e-4, max=1 - 1e-4)
+            return {'cls': cls.permute(0, 3, 1, 2), 'reg': reg.permute(0, 3, 1, 2), 'cls_logits_nhwc': logits}
         hm = self.forward_nhwc(x, ei, el)
         cls = torch.sigmoid(hm[..., :self.num_classes]).clamp(min=1e-4, max=1 - 1e-4).permute(0, 3, 1, 2)
         return {'cls': cls, 'reg': hm[..., REG_OFF:REG_OFF + 50].permute(0, 3, 1, 2), 'hm_nhwc': hm, 'cls_planar': self.last_cls_planar}

@@ -514,3 +514,38 @@ def test_conv_wgrad_transposed_read_kernel_vs_torch(cin, cout, k, stride, H, W):
     # dy is rounded to bf16 by the conv's output dtype on both sides; fp32 accumulation: only summation order differs
     assert _rel(got[1], got[0]) < 2e-3, _rel(got[1], got[0])
     assert _rel(got[1], wr.grad) < 1.5e-2, _rel(got[1], wr.grad)
+
+
+@pytest.mark.parametrize("name", ["b2", "b3_empty_middle_mixed_calib", "b1_many"])
+def test_fused_focal_loss_kernel_vs_reference_golden(name):
+    """csrc/loss_kernels.hip (sigmoid + clamp + penalty-reduced focal loss + gradient, one pass) against the fixture recorded
+    from the reference's Loss_Computation (tests/golden/loss.npz): the heat-map loss value, and the gradient with respect to
+    the class map -- the golden holds dL/dp for p = sigmoid_hm(logits); the kernel returns dL/dz = dL/dp * p(1-p)."""
+    from test_loss_golden import case_inputs, evaluator
+    from monoflex_amd.structures.params_3d import make_train_target
+    g = np.load(os.path.join(ROOT, "tests", "golden", "loss.npz"), allow_pickle=True)
+    tg, cls, reg = case_inputs(name)
+    p = cls.double()
+    logits = torch.log(p / (1 - p)).float()                                    # sigmoid_hm(logits) == cls up to fp32 rounding
+    z = logits.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_()
+    ev = evaluator()
+    preds = {"cls": cls.to(DEV), "reg": reg.to(DEV).requires_grad_(), "cls_logits_nhwc": z}
+    loss_dict, _ = ev(preds, [make_train_target(t).to(DEV) for t in tg])
+    ref = float(g["%s/loss/hm_loss" % name])
+    assert abs(float(loss_dict["hm_loss"]) - ref) <= 3e-5 * max(1.0, abs(ref)), (float(loss_dict["hm_loss"]), ref)
+    for k in loss_dict:                                                        # the other ten terms are untouched by the fused path
+        r = float(g["%s/loss/%s" % (name, k)])
+        assert abs(float(loss_dict[k]) - r) <= 3e-5 * max(1.0, abs(r)), k
+    sum(loss_dict.values()).backward()
+    dz = z.grad.detach().cpu().permute(0, 3, 1, 2).double().flatten()          # NCHW order like the golden's flat index
+    idx = torch.as_tensor(g["%s/grad_cls_idx" % name])
+    pp = p.flatten()[idx]
+    want = torch.as_tensor(g["%s/grad_cls_samples" % name]).double() * pp * (1 - pp)
+    inside = (pp > 1.0001e-4) & (pp < 1 - 1.0001e-4)                           # on the clamp the reference's autograd passes 0 too
+    assert float((dz[idx][inside] - want[inside]).abs().max()) <= 2e-5 * max(1e-3, float(want.abs().max()))
+    # and against the unfused torch path on the device (same inputs): total gradient mass
+    cls_d = cls.to(DEV).requires_grad_()
+    ld2, _ = ev({"cls": cls_d, "reg": reg.to(DEV)}, [make_train_target(t).to(DEV) for t in tg])
+    ld2["hm_loss"].backward()
+    full = (cls_d.grad.double() * p.to(DEV) * (1 - p.to(DEV))).cpu().flatten()
+    assert float((dz - full).abs().max()) <= 2e-5 * max(1e-3, float(full.abs().max()))
