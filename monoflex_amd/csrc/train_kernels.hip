@@ -688,7 +688,8 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
     // (x chunks only need 4-byte alignment: the stem reads 8-element super-taps at a pixel stride of 4 elements)
     if (dtype == MFX_BF16 && g_opt_wgrad_mfma) {
         int nslab_tr = 0;
-        const int rc_tr = try_conv_wgrad_tr(x, dy, g, workspace, workspace_bytes, &nslab_tr, st);
+        int rc_tr = try_conv_wgrad_patch(x, dy, g, workspace, workspace_bytes, &nslab_tr, st);
+        if (rc_tr != 1) rc_tr = try_conv_wgrad_tr(x, dy, g, workspace, workspace_bytes, &nslab_tr, st);
         if (rc_tr == 1) {
             const long total = (long)Cout * g.K;
             hipLaunchKernelGGL(wgrad_reduce_kernel, TR_GRID(total), dim3(256), 0, st, g.ws, nslab_tr, g.ws_slab, g.ws_ld, g, dw);

@@ -222,3 +222,254 @@ int try_conv_wgrad_tr(const void* x, const void* dy, WgradGeom& g, void* workspa
     *nslab_out = nslab;
     return 1;
 }
+
+// ======================================================================================================================
+// Third form, for 3x3 / stride 1 / pad 1 convolutions (the heads' nine 64->256 trunks, the DLA trunk, the DCN offset/mask
+// convs): the implicit-im2col operand is NOT re-read from memory once per tap.  A workgroup stages the input PATCH of a
+// 4 x 32 pixel tile (6 x 34 pixels x 64 channels, 26 KB) and the tile's dy rows (128 pixels x 64 output channels, 16 KB) in
+// LDS once and derives all nine taps' operand fragments from the patch with shifted transposed reads -- 225 FLOP per byte
+// staged instead of 49-77 -- while the whole (64 o) x (9 taps x 64 c) gradient block stays in the accumulators of its six
+// waves across ALL tiles of the workgroup's pixel slab.
+//
+// Transposed reads (ds_read_b64_tr_b16) need no row permutation here: the MFMA k index is mapped to pixels as
+// k-group g <-> pixels {4g..4g+3} and {16+4g..16+4g+3} of a 32-pixel row segment, for BOTH operands, so the two 16-lane
+// groups of an LDS pass read eight consecutive 32-byte pixel rows (all 64 banks once) at any pixel shift.
+// ======================================================================================================================
+namespace mfx {
+
+constexpr int WP_TH = 4, WP_TW = 32, WP_PW = WP_TW + 2, WP_PPIX = (WP_TH + 2) * WP_PW;      // patch 6 x 34 pixels
+constexpr int WP_XSUB = WP_PPIX * 32 + 32, WP_DSUB = WP_TH * WP_TW * 32 + 32;              // sub-tile strides (+32: banks)
+
+
+struct WpGeom { int B, H, W, Cin, Cout, ldy, tiles_x, tiles_y, ntiles, tiles_per_slab, K; float* ws; long ws_slab; };
+
+// OS = 16-channel sub-tiles of dy handled by the workgroup (4: 64 output channels, 2: 32); NW = waves (6 or 12), each
+// owning JW = 36 / NW of the 36 (tap, 16-channel) operand sub-tiles
+template <int OS, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_patch_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, WpGeom g) {
+    constexpr int WP_NT = 64 * NW, JW = 36 / NW;
+    constexpr int XCH = WP_PPIX * 8, DCH = WP_TH * WP_TW * 2 * OS;           // 16-byte chunks per tile: x patch, dy
+    constexpr int XN = (XCH + WP_NT - 1) / WP_NT, DN = (DCH + WP_NT - 1) / WP_NT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int STAGE = 4 * WP_XSUB + OS * WP_DSUB;                        // x patch [4 sub][204 px][32 B] | dy [OS sub][128 px][32 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               // k sub-tiles JW*wave .. JW*wave+JW-1 of 36
+    const int o0 = blockIdx.x * (16 * OS), cs = blockIdx.y;                  // first output channel, 64-channel input slice
+    const int t_begin = blockIdx.z * g.tiles_per_slab, t_end = min(t_begin + g.tiles_per_slab, g.ntiles);
+
+    struct Regs { u32x4 xr[XN]; u32x4 dr[DN]; };
+    auto gload = [&](Regs& r, int t) {
+        const int tx = t % g.tiles_x; int q = t / g.tiles_x;
+        const int ty = q % g.tiles_y, b = q / g.tiles_y;
+        const int x0 = tx * WP_TW, y0 = ty * WP_TH;
+        const bf16_t* xb = x + (size_t)b * g.H * g.W * g.Cin + cs * 64;
+        const bf16_t* db = dy + (size_t)b * g.H * g.W * g.ldy + o0;
+#pragma unroll
+        for (int u = 0; u < XN; ++u) {
+            const int id = tid + u * WP_NT;
+            const int p = id >> 3, c8 = id & 7;
+            const int pr = p / WP_PW, pc = p - pr * WP_PW;
+            const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if ((XCH % WP_NT == 0 || id < XCH) && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                z = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * g.W + ix) * g.Cin + c8 * 8);
+            r.xr[u] = z;
+        }
+#pragma unroll
+        for (int u = 0; u < DN; ++u) {
+            const int id = tid + u * WP_NT;
+            const int px = id / (2 * OS), c8 = id - px * (2 * OS);
+            const int oy = y0 + px / WP_TW, ox = x0 + (px % WP_TW);
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if ((DCH % WP_NT == 0 || id < DCH) && oy < g.H && ox < g.W && o0 + c8 * 8 < g.Cout)
+                z = *reinterpret_cast<const u32x4*>(db + ((size_t)oy * g.W + ox) * g.ldy + c8 * 8);
+            r.dr[u] = z;
+        }
+    };
+    auto lstore = [&](int buf, const Regs& r) {
+        char* xs = lds + buf * STAGE;
+        char* ds = xs + 4 * WP_XSUB;
+#pragma unroll
+        for (int u = 0; u < XN; ++u) {
+            const int id = tid + u * WP_NT;
+            if (XCH % WP_NT == 0 || id < XCH)
+                *reinterpret_cast<u32x4*>(xs + ((id & 7) >> 1) * WP_XSUB + (id >> 3) * 32 + (id & 1) * 16) = r.xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < DN; ++u) {
+            const int id = tid + u * WP_NT;
+            const int px = id / (2 * OS), c8 = id - px * (2 * OS);
+            if (DCH % WP_NT == 0 || id < DCH)
+                *reinterpret_cast<u32x4*>(ds + (c8 >> 1) * WP_DSUB + px * 32 + (c8 & 1) * 16) = r.dr[u];
+        }
+    };
+
+    f32x4 acc[OS][JW];
+#pragma unroll
+    for (int i = 0; i < OS; ++i)
+#pragma unroll
+        for (int j = 0; j < JW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // lane part of every transposed read: pixel 4*gq + (l16 >> 2) of the 32-pixel segment, 8-byte quarter (l16 & 3)
+    const int l16 = lane & 15, gq = lane >> 4;
+    const uint32_t lane_off = (uint32_t)((4 * gq + (l16 >> 2)) * 32 + (l16 & 3) * 8);
+    const uint32_t xs_a = (uint32_t)(uintptr_t)lds, ds_a = xs_a + 4 * WP_XSUB;
+    uint32_t xoff[JW];                                                       // this wave's (tap, channel sub-tile) operands
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+        const int ks = wave * JW + j, tap = ks >> 2, sub = ks & 3, th = tap / 3, tw = tap - th * 3;
+        xoff[j] = xs_a + (uint32_t)(sub * WP_XSUB + (th * WP_PW + tw) * 32) + lane_off;
+    }
+    auto compute = [&](int buf) {
+        const uint32_t sb = (uint32_t)(buf * STAGE);
+#pragma unroll
+        for (int r = 0; r < WP_TH; ++r) {
+            u32x4 df[OS], xf[JW];
+            {
+                const uint32_t da = ds_a + sb + (uint32_t)(r * WP_TW * 32) + lane_off;
+                uint64_t l0, h0, l1, h1, l2 = 0, h2 = 0, l3 = 0, h3 = 0;
+                if constexpr (OS == 4) {
+                    asm volatile(
+                        "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:512\n\t"
+                        "ds_read_b64_tr_b16 %2, %8 offset:4128\n\tds_read_b64_tr_b16 %3, %8 offset:4640\n\t"
+                        "ds_read_b64_tr_b16 %4, %8 offset:8256\n\tds_read_b64_tr_b16 %5, %8 offset:8768\n\t"
+                        "ds_read_b64_tr_b16 %6, %8 offset:12384\n\tds_read_b64_tr_b16 %7, %8 offset:12896\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3) : "v"(da) : "memory");
+                } else {
+                    asm volatile(
+                        "ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                        "ds_read_b64_tr_b16 %2, %4 offset:4128\n\tds_read_b64_tr_b16 %3, %4 offset:4640\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1) : "v"(da) : "memory");
+                }
+                df[0] = u32x4{(uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)h0, (uint32_t)(h0 >> 32)};
+                df[1] = u32x4{(uint32_t)l1, (uint32_t)(l1 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32)};
+                if constexpr (OS == 4) {
+                    df[2] = u32x4{(uint32_t)l2, (uint32_t)(l2 >> 32), (uint32_t)h2, (uint32_t)(h2 >> 32)};
+                    df[3] = u32x4{(uint32_t)l3, (uint32_t)(l3 >> 32), (uint32_t)h3, (uint32_t)(h3 >> 32)};
+                }
+            }
+            {
+                const uint32_t ro = sb + (uint32_t)(r * WP_PW * 32);
+                if constexpr (JW == 6) {
+                    const uint32_t a0 = xoff[0] + ro, a1 = xoff[1] + ro, a2 = xoff[2] + ro, a3 = xoff[3] + ro, a4 = xoff[4] + ro, a5 = xoff[5] + ro;
+                    uint64_t l0, h0, l1, h1, l2, h2, l3, h3, l4, h4, l5, h5;
+                    asm volatile(
+                        "ds_read_b64_tr_b16 %0, %12\n\tds_read_b64_tr_b16 %1, %12 offset:512\n\t"
+                        "ds_read_b64_tr_b16 %2, %13\n\tds_read_b64_tr_b16 %3, %13 offset:512\n\t"
+                        "ds_read_b64_tr_b16 %4, %14\n\tds_read_b64_tr_b16 %5, %14 offset:512\n\t"
+                        "ds_read_b64_tr_b16 %6, %15\n\tds_read_b64_tr_b16 %7, %15 offset:512\n\t"
+                        "ds_read_b64_tr_b16 %8, %16\n\tds_read_b64_tr_b16 %9, %16 offset:512\n\t"
+                        "ds_read_b64_tr_b16 %10, %17\n\tds_read_b64_tr_b16 %11, %17 offset:512\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3), "=&v"(l4), "=&v"(h4), "=&v"(l5), "=&v"(h5)
+                        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5) : "memory");
+                    xf[0] = u32x4{(uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)h0, (uint32_t)(h0 >> 32)};
+                    xf[1] = u32x4{(uint32_t)l1, (uint32_t)(l1 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32)};
+                    xf[2] = u32x4{(uint32_t)l2, (uint32_t)(l2 >> 32), (uint32_t)h2, (uint32_t)(h2 >> 32)};
+                    xf[3 % JW] = u32x4{(uint32_t)l3, (uint32_t)(l3 >> 32), (uint32_t)h3, (uint32_t)(h3 >> 32)};
+                    xf[4 % JW] = u32x4{(uint32_t)l4, (uint32_t)(l4 >> 32), (uint32_t)h4, (uint32_t)(h4 >> 32)};
+                    xf[5 % JW] = u32x4{(uint32_t)l5, (uint32_t)(l5 >> 32), (uint32_t)h5, (uint32_t)(h5 >> 32)};
+                } else {
+                    const uint32_t a0 = xoff[0] + ro, a1 = xoff[1 % JW] + ro, a2 = xoff[2 % JW] + ro;
+                    uint64_t l0, h0, l1, h1, l2, h2;
+                    asm volatile(
+                        "ds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %6 offset:512\n\t"
+                        "ds_read_b64_tr_b16 %2, %7\n\tds_read_b64_tr_b16 %3, %7 offset:512\n\t"
+                        "ds_read_b64_tr_b16 %4, %8\n\tds_read_b64_tr_b16 %5, %8 offset:512\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2)
+                        : "v"(a0), "v"(a1), "v"(a2) : "memory");
+                    xf[0] = u32x4{(uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)h0, (uint32_t)(h0 >> 32)};
+                    xf[1 % JW] = u32x4{(uint32_t)l1, (uint32_t)(l1 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32)};
+                    xf[2 % JW] = u32x4{(uint32_t)l2, (uint32_t)(l2 >> 32), (uint32_t)h2, (uint32_t)(h2 >> 32)};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < OS; ++i)
+#pragma unroll
+                for (int j = 0; j < JW; ++j) mma_chunk<bf16_t>(df[i], xf[j], acc[i][j]);
+        }
+    };
+
+    // two LDS stages: the next tile is stored while the other stage is being read, one barrier per tile
+    Regs R;
+    if (t_begin < t_end) {
+        gload(R, t_begin);
+        lstore(0, R);
+        __syncthreads();
+        for (int t = t_begin; t < t_end; ++t) {
+            const bool more = t + 1 < t_end;
+            const int cur = (t - t_begin) & 1;
+            if (more) gload(R, t + 1);                        // next tile's global loads fly during this tile's MFMAs
+            compute(cur);
+            if (more) lstore(cur ^ 1, R);
+            __syncthreads();
+        }
+    }
+    // partial gradient block -> workspace slab [Cout][K]: row o, column k = tap * Cin + cs * 64 + sub * 16 + (lane & 15)
+    float* wsb = g.ws + (size_t)blockIdx.z * g.ws_slab;
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+        const int ks = wave * JW + j, tap = ks >> 2, sub = ks & 3;
+        const int k = tap * g.Cin + cs * 64 + sub * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < OS; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + i * 16 + (lane >> 4) * 4 + r;
+                if (o < g.Cout) wsb[(size_t)o * g.K + k] = acc[i][j][r];
+            }
+    }
+}
+
+}  // namespace mfx
+using namespace mfx;
+
+int g_opt_wgrad_patch = 1;          // option "wgrad_patch": 0 = off
+int g_opt_wgrad_patch_blocks = 256; // option "wgrad_patch_blocks": target workgroup count
+int g_opt_wgrad_patch_waves = 12;   // option "wgrad_patch_waves": 6 (64 x 96 block per wave) or 12 (64 x 48)
+
+// 3x3 / s1 / p1, Cin % 64 == 0: returns 1 if launched (partials in g.ws, *nslab slabs), 0 to fall through
+int try_conv_wgrad_patch(const void* x, const void* dy, WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st) {
+    if (!g_opt_wgrad_patch || !workspace || g.direct) return 0;
+    if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.pad_h != 1 || g.pad_w != 1 || g.dil_w != 1 || g.Ho != g.H || g.Wo != g.W) return 0;
+    if (g.Ck % 64 != 0 || g.x_pixstride != g.Ck || g.ldy % 8 != 0 || g.Cout % 8 != 0 || g.M < 2048) return 0;
+    WpGeom w;
+    w.B = g.B; w.H = g.H; w.W = g.W; w.Cin = g.Ck; w.Cout = g.Cout; w.ldy = g.ldy; w.K = g.K;
+    w.tiles_x = (g.W + WP_TW - 1) / WP_TW; w.tiles_y = (g.H + WP_TH - 1) / WP_TH; w.ntiles = w.tiles_x * w.tiles_y * g.B;
+    const int os = g.Cout > 32 ? 4 : 2;
+    const int otiles = (g.Cout + 16 * os - 1) / (16 * os), slices = g.Ck / 64;
+    const long ws_slab = (long)g.Cout * g.K;
+    int nslab = std::max(1, g_opt_wgrad_patch_blocks / (otiles * slices));
+    nslab = (int)std::min<long>(nslab, (long)(workspace_bytes / sizeof(float)) / ws_slab);
+    nslab = std::min(nslab, std::max(1, w.ntiles / 4));       // at least four tiles per slab: the 147 KB epilogue must amortise
+    if (nslab < 1) return 0;
+    w.tiles_per_slab = (w.ntiles + nslab - 1) / nslab;
+    nslab = (w.ntiles + w.tiles_per_slab - 1) / w.tiles_per_slab;
+    w.ws = reinterpret_cast<float*>(workspace); w.ws_slab = ws_slab;
+    g.ws = w.ws; g.ws_ld = g.K; g.ws_slab = ws_slab;
+    const dim3 grid(otiles, slices, nslab);
+    const int nw = g_opt_wgrad_patch_waves == 12 ? 12 : 6;
+    if (os == 4) {
+        constexpr int smem = 2 * (4 * WP_XSUB + 4 * WP_DSUB);
+        if (nw == 12) {
+            auto k = conv_wgrad_patch_kernel<4, 12>;
+            static bool a12 = false; if (!a12) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); a12 = true; }
+            hipLaunchKernelGGL(k, grid, dim3(768), smem, st, (const bf16_t*)x, (const bf16_t*)dy, w);
+        } else {
+            auto k = conv_wgrad_patch_kernel<4, 6>;
+            static bool a6 = false; if (!a6) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); a6 = true; }
+            hipLaunchKernelGGL(k, grid, dim3(384), smem, st, (const bf16_t*)x, (const bf16_t*)dy, w);
+        }
+    } else {
+        constexpr int smem = 2 * (4 * WP_XSUB + 2 * WP_DSUB);
+        auto k = conv_wgrad_patch_kernel<2, 6>;
+        static bool a2 = false; if (!a2) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); a2 = true; }
+        hipLaunchKernelGGL(k, grid, dim3(384), smem, st, (const bf16_t*)x, (const bf16_t*)dy, w);
+    }
+    MFX_HIP_CHECK(hipGetLastError());
+    *nslab_out = nslab;
+    return 1;
+}

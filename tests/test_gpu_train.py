@@ -485,7 +485,8 @@ def test_dcn_tile_owned_backward_vs_oracle(cin, cout, H, W, off_std, dtype):
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,H,W", [(64, 256, 3, 1, 48, 96), (64, 64, 3, 1, 40, 72), (128, 128, 3, 2, 64, 80),
-                                                   (256, 256, 3, 1, 24, 80), (512, 512, 3, 1, 12, 40), (64, 192, 3, 1, 33, 47)])
+                                                   (256, 256, 3, 1, 24, 80), (512, 512, 3, 1, 12, 40), (64, 192, 3, 1, 33, 47),
+                                                   (128, 27, 3, 1, 48, 96), (64, 27, 3, 1, 37, 75), (64, 64, 3, 1, 96, 40)])
 def test_conv_wgrad_transposed_read_kernel_vs_torch(cin, cout, k, stride, H, W):
     """Second-generation weight-gradient kernel (wgrad_tr.hip: natural-layout LDS tiles + ds_read_b64_tr_b16, 64x64 wave
     blocks, BK = 192) against torch autograd of F.conv2d on bf16-representable operands, and against the first-generation
@@ -502,8 +503,9 @@ def test_conv_wgrad_transposed_read_kernel_vs_torch(cin, cout, k, stride, H, W):
     lib_ = L.load()
     got = {}
     try:
-        for tr in (1, 0):
-            L.check(lib_.mfx_set_option(b"wgrad_tr", tr), "opt")
+        for tr in (1, 2, 0):                                     # 1: LDS-patch form where it applies, 2: plain transposed-read form, 0: first generation
+            L.check(lib_.mfx_set_option(b"wgrad_tr", 1 if tr else 0), "opt")
+            L.check(lib_.mfx_set_option(b"wgrad_patch", 1 if tr == 1 else 0), "opt")
             xd = _nhwc(x).to(DEV).bfloat16()
             wd = w.to(DEV).requires_grad_()
             yd = AG.conv2d(xd, wd, None, stride, k // 2)
@@ -511,9 +513,11 @@ def test_conv_wgrad_transposed_read_kernel_vs_torch(cin, cout, k, stride, H, W):
             got[tr] = wd.grad.detach().cpu()
     finally:
         L.check(lib_.mfx_set_option(b"wgrad_tr", 1), "opt")
+        L.check(lib_.mfx_set_option(b"wgrad_patch", 1), "opt")
     # dy is rounded to bf16 by the conv's output dtype on both sides; fp32 accumulation: only summation order differs
-    assert _rel(got[1], got[0]) < 2e-3, _rel(got[1], got[0])
-    assert _rel(got[1], wr.grad) < 1.5e-2, _rel(got[1], wr.grad)
+    for v in (1, 2):
+        assert _rel(got[v], got[0]) < 2e-3, (v, _rel(got[v], got[0]))
+        assert _rel(got[v], wr.grad) < 1.5e-2, (v, _rel(got[v], wr.grad))
 
 
 @pytest.mark.parametrize("name", ["b2", "b3_empty_middle_mixed_calib", "b1_many"])
