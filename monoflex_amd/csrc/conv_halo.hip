@@ -163,7 +163,7 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
         // weight fragments: ring of RING register buffers, fetched RING-1 steps ahead of their use.  A step is FM*FN MFMAs
         // = 107 ns (FN 2) .. 213 ns (FN 4) of matrix-pipe time per wave, an L2 round trip is ~400-500 ns: narrow waves need a
         // deeper ring than wide ones (option "halo_ring" to compare).  This wave's steps are S(j) = wk + j*WK, j < nl
-        constexpr int RING = FN >= 4 ? 3 : 5;
+        constexpr int RING = FN == 2 ? 5 : 3;               // FN 1 (the offset/mask convs, K-split over 4 waves) measured slower with 5
         u32x4 wb[RING][FN];
         const int ns = g.steps_per_group;
         const int nl = ns > wk ? (ns - wk + WK - 1) / WK : 0;
