@@ -290,6 +290,39 @@ int mfx_dcn_backward_v2(const void* x, const float* offmask, const float* weight
 int mfx_focal_loss(const float* logits_nhwc, const float* heat_nchw, int B, int H, int W, int ncls, float alpha, float beta,
                    float* sums2, float* dlogits_nhwc, void* stream);
 
+/* Per-object regression losses and their gradient (model/head/detector_loss.py:116-482: prepare_predictions, the nine
+ * regression terms, the logged MAEs; decoders model/anno_encoder.py:88-295, model/layers/iou_loss.py:7-49).  One wavefront per
+ * object row; lane c carries d/d(channel c) through the expression in forward mode, so the value of every term and its
+ * gradient row come out of the same launch.
+ *   rows  fp32 [N][MFX_OBJ_ROW]: one row per (image, object slot), N = B * MAX_OBJECTS (layout: csrc/object_loss_math.h R_*)
+ *   reg   fp32 NHWC map, pixel stride `ld`, the 50 regression channels at [ch_off, ch_off + 50) of every pixel
+ *   vals  fp32 [MFX_OBJ_VALUES] (overwritten): [0, MFX_OBJ_TERMS) the weighted loss terms bbox, depth, offset, trunc_offset, orien,
+ *         dims, corner, keypoint, keypoint_depth, weighted_avg_depth; then the logged means (2D_IoU, depth_loss, keypoint_depth_loss,
+ *         depth / center / 02 / 13 / lower / hard / soft / mean MAE)
+ *   G     fp32 [N][MFX_OBJ_TERMS][64] (overwritten): d(term)/d(channel) at the object's pixel
+ * mfx_object_loss_backward ADDS sum_t gout[t] * G[n][t][c] into dreg (same geometry as reg; the caller zero-fills it): objects
+ * sharing a centre pixel accumulate, as the gather's backward does. */
+#define MFX_OBJ_ROW 72
+#define MFX_OBJ_TERMS 10
+#define MFX_OBJ_VALUES 24
+typedef struct mfx_object_loss_cfg {
+    float w[MFX_OBJ_TERMS];               /* INIT_LOSS_WEIGHT of the ten terms, in the order above */
+    float dim_mean[9], dim_std[9], dim_weight[3];
+    float depth_ref[2], depth_range[2];
+    float unc_lo, unc_hi, down_ratio, eps;
+    int depth_mode;                       /* 0 exp, 1 linear, 2 inv_sigmoid */
+    int has_depth_range, dim_exp, dim_use_std;
+    int iou_type;                         /* 0 giou, 1 iou, 2 linear_iou */
+    int corner_depth_mode;                /* 0 direct, 1 keypoint_mean, 2 soft_combine, 3 hard_combine */
+    int separate_trunc, trunc_log, modify_invalid;
+    int ch[9];                            /* first channel of 2d_dim, 3d_offset, corner_offset, corner_uncertainty, 3d_dim, ori_cls,
+                                             ori_offset, depth, depth_uncertainty within the 50 */
+} mfx_object_loss_cfg;
+int mfx_object_loss(const float* reg_nhwc, int B, int H, int W, int ld, int ch_off, const float* rows, int N,
+                    const mfx_object_loss_cfg* cfg, float* vals, float* G, void* stream);
+int mfx_object_loss_backward(const float* G, const float* gout_terms, const float* rows, int N, int B, int H, int W,
+                             float* dreg_nhwc, int ld, int ch_off, void* stream);
+
 /* ---- (4) input pipeline: KITTI sample -> network input + training targets, on the device ------------------------------
  * Replaces the per-sample numpy/PIL work of the reference's dataset (data/datasets/kitti.py:231-525 __getitem__,
  * data/augmentations/augmentations.py:33-78 flip, data/transforms/transforms.py:15-31 ToTensor+Normalize,

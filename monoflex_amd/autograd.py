@@ -430,6 +430,43 @@ class FocalLossFn(Function):
         return dz * g_loss, None, None, None
 
 
+@_device_guarded
+class ObjectLossFn(Function):
+    """The nine per-object regression terms (detector_loss.py:116-482) in one launch (csrc/object_loss_math.h): fp32 NHWC map
+    with the 50 regression channels at [ch_off, ch_off+50) of each pixel + the packed target rows -> (terms[10], logged[14]);
+    the gradient row of every term is produced by the same launch (forward-mode tangents, one lane per channel), backward is a
+    scatter-add of sum_t gout[t] * G[n][t][:] into a zero map."""
+
+    @staticmethod
+    def forward(ctx, reg_nhwc, rows, cfg, ch_off):
+        reg = _c(reg_nhwc)
+        if reg.dtype != torch.float32 or rows.dtype != torch.float32:
+            raise TypeError("object loss: fp32 regression map and fp32 target rows")
+        rows = _c(rows)
+        B, H, W, ld = reg.shape
+        N = rows.shape[0]
+        vals = torch.empty(L.OBJ_VALUES, dtype=torch.float32, device=reg.device)
+        G = torch.empty(N, L.OBJ_TERMS, 64, dtype=torch.float32, device=reg.device)
+        L.check(L.load().mfx_object_loss(_ptr(reg), B, H, W, ld, ch_off, _ptr(rows), N, ctypes.byref(cfg), _ptr(vals), _ptr(G), _stream()),
+                "mfx_object_loss")
+        ctx.save_for_backward(G, rows)
+        ctx.geom = (B, H, W, ld, ch_off)
+        terms, logged = vals[:L.OBJ_TERMS], vals[L.OBJ_TERMS:]
+        ctx.mark_non_differentiable(logged)
+        return terms, logged
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_terms, g_logged):
+        G, rows = ctx.saved_tensors
+        B, H, W, ld, ch_off = ctx.geom
+        dreg = torch.zeros(B, H, W, ld, dtype=torch.float32, device=G.device)
+        g = _c(g_terms.float())
+        L.check(L.load().mfx_object_loss_backward(_ptr(G), _ptr(g), _ptr(rows), rows.shape[0], B, H, W, _ptr(dreg), ld, ch_off, _stream()),
+                "mfx_object_loss_backward")
+        return dreg, None, None, None
+
+
 def conv2d(x, weight, bias=None, stride=1, pad=0, out_dtype=None):
     """Differentiable NHWC conv; returns exactly weight.shape[0] channels."""
     y = Conv2dFn.apply(x, weight, bias, stride, pad, out_dtype)

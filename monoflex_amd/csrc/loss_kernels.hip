@@ -68,3 +68,88 @@ extern "C" int mfx_focal_loss(const float* logits_nhwc, const float* heat_nchw, 
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Per-object regression terms: one wavefront per object row (object_loss_math.h)
+// ------------------------------------------------------------------------------------------------
+#include "object_loss_math.h"
+
+namespace mfx {
+using namespace oloss;
+
+struct PixelReader {                                        // channel ch of the object's pixel; lane `seed` differentiates w.r.t. its own channel
+    const float* p; int seed;
+    __device__ Dual operator()(int ch) const { return Dual{p[ch], ch == seed ? 1.f : 0.f}; }
+};
+
+__device__ __forceinline__ const float* object_pixel(const float* base, const float* t, int B, int H, int W, int ld, int ch_off) {
+    const int b = min(max((int)t[R_B], 0), B - 1), cx = min(max((int)t[R_CX], 0), W - 1), cy = min(max((int)t[R_CY], 0), H - 1);
+    return base + ((size_t)(b * H + cy) * W + cx) * ld + ch_off;
+}
+
+__global__ __launch_bounds__(64) void object_loss_kernel(const float* __restrict__ reg, int B, int H, int W, int ld, int ch_off,
+                                                         const float* __restrict__ rows, int N, mfx_object_loss_cfg c,
+                                                         float* __restrict__ vals, float* __restrict__ G) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    float cn[NNORM];
+#pragma unroll
+    for (int i = 0; i < NNORM; ++i) cn[i] = 0.f;
+    for (int r = lane; r < N; r += 64) {                    // the batch-wide selection counts: every wave recounts them (N <= a few hundred rows)
+        float q[NNORM];
+        row_counts(rows + (size_t)r * ROW, q);
+#pragma unroll
+        for (int i = 0; i < NNORM; ++i) cn[i] += q[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NNORM; ++i)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cn[i] += __shfl_xor(cn[i], off);
+    const float* t = rows + (size_t)n * ROW;
+    Dual out[NVAL];
+    const PixelReader X{object_pixel(reg, t, B, H, W, ld, ch_off), lane};
+    object_terms(X, t, c, cn, out);
+#pragma unroll
+    for (int k = 0; k < NTERM; ++k) G[((size_t)n * NTERM + k) * 64 + lane] = out[k].d;
+    if (lane == 0 && t[R_VALID] != 0.f)
+        for (int k = 0; k < NVAL; ++k) unsafeAtomicAdd(vals + k, out[k].v);
+}
+
+__global__ __launch_bounds__(64) void object_loss_bwd_kernel(const float* __restrict__ G, const float* __restrict__ gout,
+                                                             const float* __restrict__ rows, int B, int H, int W,
+                                                             float* __restrict__ dreg, int ld, int ch_off) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const float* t = rows + (size_t)n * ROW;
+    if (t[R_VALID] == 0.f || lane >= 50) return;
+    float g = 0.f;
+#pragma unroll
+    for (int k = 0; k < NTERM; ++k) g += gout[k] * G[((size_t)n * NTERM + k) * 64 + lane];
+    float* p = const_cast<float*>(object_pixel(dreg, t, B, H, W, ld, ch_off));
+    unsafeAtomicAdd(p + lane, g);
+}
+
+}  // namespace mfx
+
+extern "C" int mfx_object_loss(const float* reg_nhwc, int B, int H, int W, int ld, int ch_off, const float* rows, int N,
+                               const mfx_object_loss_cfg* cfg, float* vals, float* G, void* stream) {
+    if (!reg_nhwc || !rows || !cfg || !vals || !G) return mfx_fail(MFX_ERR_ARG, "object_loss: null pointer");
+    if (B < 1 || H < 1 || W < 1 || N < 0 || ch_off < 0 || ch_off + 50 > ld) return mfx_fail(MFX_ERR_ARG, "object_loss: bad sizes");
+    for (int i = 0; i < 9; ++i)
+        if (cfg->ch[i] < 0 || cfg->ch[i] >= 50) return mfx_fail(MFX_ERR_ARG, "object_loss: channel offset outside the 50 regression channels");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MFX_HIP_CHECK(mfx::zero_async(vals, sizeof(float) * MFX_OBJ_VALUES, st));
+    if (N == 0) return MFX_OK;
+    hipLaunchKernelGGL(object_loss_kernel, dim3(N), dim3(64), 0, st, reg_nhwc, B, H, W, ld, ch_off, rows, N, *cfg, vals, G);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_object_loss_backward(const float* G, const float* gout_terms, const float* rows, int N, int B, int H, int W,
+                                        float* dreg_nhwc, int ld, int ch_off, void* stream) {
+    if (!G || !gout_terms || !rows || !dreg_nhwc) return mfx_fail(MFX_ERR_ARG, "object_loss_backward: null pointer");
+    if (B < 1 || H < 1 || W < 1 || N < 0 || ch_off < 0 || ch_off + 50 > ld) return mfx_fail(MFX_ERR_ARG, "object_loss_backward: bad sizes");
+    if (N == 0) return MFX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(object_loss_bwd_kernel, dim3(N), dim3(64), 0, st, G, gout_terms, rows, B, H, W, dreg_nhwc, ld, ch_off);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}

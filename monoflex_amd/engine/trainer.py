@@ -66,6 +66,7 @@ def prepare_targets(model, targets, device, fields=None):
     calibs = [t.get_field("calib") for t in targets]
     d["calib"] = calibs
     d["calib_f32"] = torch.tensor([[c.f_u, c.f_v, c.c_u, c.c_v, c.b_x, c.b_y] for c in calibs], dtype=torch.float32).to(dev)
+    d["object_rows"] = m.heads.loss_evaluator.pack_objects(d)
     pt.loss = (fields["hm"].to(dev), d)
     return pt
 

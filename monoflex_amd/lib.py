@@ -66,6 +66,17 @@ class KittiEvalDesc(ctypes.Structure):
         [(n, c_int) for n in ("B", "n_gt", "n_dt", "num_classes", "num_k", "compute_aos")] + [("n_pairs", ctypes.c_int64)]
 
 
+OBJ_ROW, OBJ_TERMS, OBJ_VALUES = 72, 10, 24                    # MFX_OBJ_ROW / MFX_OBJ_TERMS / MFX_OBJ_VALUES
+
+
+class ObjectLossCfg(ctypes.Structure):                          # mfx_object_loss_cfg
+    _fields_ = [("w", c_float * OBJ_TERMS), ("dim_mean", c_float * 9), ("dim_std", c_float * 9), ("dim_weight", c_float * 3),
+                ("depth_ref", c_float * 2), ("depth_range", c_float * 2)] + \
+        [(n, c_float) for n in ("unc_lo", "unc_hi", "down_ratio", "eps")] + \
+        [(n, c_int) for n in ("depth_mode", "has_depth_range", "dim_exp", "dim_use_std", "iou_type", "corner_depth_mode",
+                              "separate_trunc", "trunc_log", "modify_invalid")] + [("ch", c_int * 9)]
+
+
 # every symbol include/monoflex_hip.h declares: name -> (restype, argtypes)
 _P, _I, _F, _S = c_void_p, c_int, c_float, c_size_t
 SYMBOLS = {
@@ -108,6 +119,8 @@ SYMBOLS = {
     "mfx_dcn_backward_v2_workspace_bytes": (_S, [_I] * 6),
     "mfx_dcn_backward_v2": (_I, [_P] * 8 + [_I] * 6 + [_P, _S, _P]),
     "mfx_focal_loss": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "mfx_object_loss": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, ctypes.POINTER(ObjectLossCfg), _P, _P, _P]),
+    "mfx_object_loss_backward": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "mfx_kitti_encode_targets": (_I, [ctypes.POINTER(KittiDesc), _P]),
     "mfx_kitti_preprocess_u8": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P]),
     "mfx_kitti_eval_overlaps": (_I, [ctypes.POINTER(KittiEvalDesc), _P]),

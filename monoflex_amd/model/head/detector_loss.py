@@ -73,6 +73,8 @@ class Loss_Computation:
         self.down_ratio = cfg.MODEL.BACKBONE.DOWN_RATIO
         self.EPS = 1e-3
         self.log_as_float = True          # reference returns python floats in log_loss_dict; False keeps 0-d tensors
+        self.fused_object_loss = True     # CUDA maps: the regression terms run as ONE kernel (csrc/object_loss_math.h); False = tensor ops
+        self._obj_cfg = None
         self._consts = {}
 
     def _const(self, name, values, device, dtype=torch.float32):
@@ -98,7 +100,66 @@ class Loss_Computation:
         d["calib_f32"] = cal.to(d["reg_mask"].device)
         if all(x.has_field("ori_img") for x in targets):
             d["ori_imgs"] = torch.stack([torch.as_tensor(x.get_field("ori_img")) for x in targets])
+        d["object_rows"] = self.pack_objects(d)
         return st("hm"), d
+
+    def pack_objects(self, d):
+        """The stacked target fields as ONE fp32 table, a row per (image, object slot) (csrc/object_loss_math.h R_*): what the
+        per-object loss kernel reads.  Pure function of the targets -- built once per batch with them, outside the step."""
+        from ... import lib as L
+        rm = d["reg_mask"]
+        B, M = rm.shape[0], rm.shape[1]
+        N, dev = B * M, rm.device
+        if d["keypoints"].shape[-2] != 10 or d["orientations"].shape[-1] != 8:
+            return None                                    # the kernel is built for 10 keypoints / 4 orientation bins
+        f = lambda t, k: t.reshape(N, k).to(device=dev, dtype=torch.float32)
+        bidx = torch.arange(B, device=dev).view(B, 1).expand(B, M).reshape(N)
+        cal = d["calib_f32"].to(dev)
+        # the reference indexes the calibration list by the RANK of the image among those that own an object (anno_encoder.py:198-199)
+        present = rm.reshape(B, -1).bool().any(dim=1)
+        rank = (torch.cumsum(present.long(), 0) - 1).clamp(min=0)
+        cols = [f(rm, 1), f(d["cls_ids"], 1), f(d["target_centers"], 2), f(d["bboxes"], 4), f(d["keypoints"], 30),
+                f(d["keypoints_depth_mask"], 3), f(d["dimensions"], 3), f(d["locations"], 3)[:, 2:3], f(d["rotys"], 1),
+                f(d["orientations"], 8), f(d["offset_3D"], 2), f(d["trunc_mask"], 1), bidx.float().view(N, 1), cal[bidx],
+                d["pad_size"].to(device=dev, dtype=torch.float32).reshape(B, 2)[bidx], cal[:, 0][rank][bidx].view(N, 1)]
+        rows = torch.cat(cols, dim=1)
+        return torch.nn.functional.pad(rows, (0, L.OBJ_ROW - rows.shape[1])).contiguous()
+
+    def object_loss_cfg(self):
+        """mfx_object_loss_cfg of this evaluator (include/monoflex_hip.h); None when a setting is outside what the kernel covers."""
+        from ... import lib as L
+        if getattr(self, "_obj_cfg", None) is not None:
+            return self._obj_cfg
+        W, k = self.loss_weights, self.key2channel
+        if self.orien_bin_size != 4 or self.depth_mode not in ('exp', 'linear', 'inv_sigmoid') or self.depth_range is None \
+                or len(self.dim_mean) != 3:
+            return None
+        c = L.ObjectLossCfg()
+        names = ('bbox_loss', 'depth_loss', 'offset_loss', 'trunc_offset_loss', 'orien_loss', 'dims_loss', 'corner_loss', 'keypoint_loss',
+                 'keypoint_depth_loss', 'weighted_avg_depth_loss')
+        for i, n in enumerate(names):
+            c.w[i] = float(W.get(n, 0.0))
+        for i, v in enumerate(self.dim_mean.flatten().tolist()):
+            c.dim_mean[i] = v
+        for i, v in enumerate(self.dim_std.flatten().tolist()):
+            c.dim_std[i] = v
+        for i, v in enumerate(self.dim_weight.flatten().tolist()):
+            c.dim_weight[i] = v
+        c.depth_ref[0], c.depth_ref[1] = float(self.depth_ref[0]), float(self.depth_ref[1])
+        c.depth_range[0], c.depth_range[1] = float(self.depth_range[0]), float(self.depth_range[1])
+        lo, hi = self.uncertainty_range if self.uncertainty_range is not None else (-float('inf'), float('inf'))
+        c.unc_lo, c.unc_hi, c.down_ratio, c.eps = float(lo), float(hi), float(self.down_ratio), float(self.EPS)
+        c.depth_mode = ('exp', 'linear', 'inv_sigmoid').index(self.depth_mode)
+        c.has_depth_range, c.dim_exp, c.dim_use_std = 1, int(self.dim_modes[0] == 'exp'), int(bool(self.dim_modes[2]))
+        c.iou_type = ('giou', 'iou', 'linear_iou').index(self.iou_type)
+        c.corner_depth_mode = ('direct', 'keypoint_mean', 'soft_combine', 'hard_combine').index(self.corner_loss_depth)
+        c.separate_trunc, c.trunc_log = int(self.separate_trunc_offset), int(self.trunc_offset_loss_type != 'L1')
+        c.modify_invalid = int(bool(self.modify_invalid_keypoint_depths))
+        for i, key in enumerate(('2d_dim', '3d_offset', 'corner_offset', 'corner_uncertainty', '3d_dim', 'ori_cls', 'ori_offset', 'depth',
+                                 'depth_uncertainty')):
+            c.ch[i] = k(key).start
+        self._obj_cfg = c
+        return c
 
     # ---- Anno_Encoder pieces, batched over all B*MAX_OBJECTS rows --------------------------------------
     def _decode_depth(self, off):                                                 # anno_encoder.py:124-140
@@ -278,23 +339,59 @@ class Loss_Computation:
             reg_cnt = reg_cnt + wi.sum()
         return cls_losses / nb + reg_losses / torch.clamp(reg_cnt, min=1)
 
-    def __call__(self, predictions, targets):
-        dev = predictions['reg'].device
-        prepared = targets if isinstance(targets, tuple) else getattr(targets, "loss", None)
-        heat, tv = prepared if prepared is not None else self.prepare_targets(targets, dev)
-        T, P, sel, _ = self.prepare_predictions(tv, predictions)
-        W = self.loss_weights
-        valid, v = sel['valid'], sel['valid'].float()
-        v2 = sel['reg_2D'].float()
-        one = torch.ones((), device=dev)
-
+    def _heat_term(self, predictions, heat, dev):
         if predictions.get('cls_logits_nhwc') is not None and predictions['cls_logits_nhwc'].is_cuda:
             # fused heat-map term: the predictor hands over its fp32 NHWC logits; sigmoid + clamp + focal + gradient in one pass
             from ... import autograd as AG
             hm_loss, num_pos = AG.FocalLossFn.apply(predictions['cls_logits_nhwc'], heat.to(dev), float(self.focal_alpha), float(self.focal_beta))
         else:
             hm_loss, num_pos = self._focal(predictions['cls'], heat.to(dev))
-        hm_loss = W['hm_loss'] * hm_loss / torch.clamp(num_pos, 1)
+        return self.loss_weights['hm_loss'] * hm_loss / torch.clamp(num_pos, 1)
+
+    def _fused(self, predictions, heat, tv, dev):
+        """Device form of __call__: heat-map term + ONE launch for the nine regression terms and their gradient rows."""
+        from ... import autograd as AG
+        from ... import lib as L
+        cfg, rows = self.object_loss_cfg(), tv.get("object_rows")
+        if rows is None:
+            rows = self.pack_objects(tv)
+        if cfg is None or rows is None:
+            raise NotImplementedError("fused object loss: 4 orientation bins, 10 keypoints, a depth range (set fused_object_loss=False "
+                                      "for the tensor-op form)")
+        reg = predictions['reg'].permute(0, 2, 3, 1)                              # the predictor's NHWC map: a view
+        terms, logged = AG.ObjectLossFn.apply(reg.float(), rows.to(dev), cfg, 0)
+        t = terms.unbind(0)
+        loss_dict = {'hm_loss': self._heat_term(predictions, heat, dev), 'bbox_loss': t[0], 'dims_loss': t[5], 'orien_loss': t[4],
+                     'offset_loss': t[2]}
+        if self.separate_trunc_offset:
+            loss_dict['trunc_offset_loss'] = t[3]
+        loss_dict.update({'corner_loss': t[6], 'depth_loss': t[1], 'keypoint_loss': t[7], 'keypoint_depth_loss': t[8],
+                          'weighted_avg_depth_loss': t[9]})
+        with torch.no_grad():
+            lg = logged.unbind(0)
+            logs = {'2D_IoU': lg[0], '3D_IoU': lg[0] * 0, 'depth_loss': lg[1], 'keypoint_depth_loss': lg[2]}
+            for key, val in loss_dict.items():
+                if key not in logs:
+                    logs[key] = val.detach()
+            logs.update(dict(zip(('depth_MAE', 'center_MAE', '02_MAE', '13_MAE', 'lower_MAE', 'hard_MAE', 'soft_MAE', 'mean_MAE'), lg[3:11])))
+            if self.log_as_float:
+                vals = torch.stack([x.float() for x in logs.values()]).tolist()     # the step's single host sync
+                logs = dict(zip(logs.keys(), vals))
+        return loss_dict, logs
+
+    def __call__(self, predictions, targets):
+        dev = predictions['reg'].device
+        prepared = targets if isinstance(targets, tuple) else getattr(targets, "loss", None)
+        heat, tv = prepared if prepared is not None else self.prepare_targets(targets, dev)
+        W = self.loss_weights
+        if predictions['reg'].is_cuda and self.fused_object_loss:
+            return self._fused(predictions, heat, tv, dev)
+        T, P, sel, _ = self.prepare_predictions(tv, predictions)
+        valid, v = sel['valid'], sel['valid'].float()
+        v2 = sel['reg_2D'].float()
+        one = torch.ones((), device=dev)
+
+        hm_loss = self._heat_term(predictions, heat, dev)
 
         # 2D box (GIoU); unselected rows get a unit box on both sides
         m2 = sel['reg_2D'][:, None]

@@ -553,3 +553,42 @@ def test_fused_focal_loss_kernel_vs_reference_golden(name):
     ld2["hm_loss"].backward()
     full = (cls_d.grad.double() * p.to(DEV) * (1 - p.to(DEV))).cpu().flatten()
     assert float((dz - full).abs().max()) <= 2e-5 * max(1e-3, float(full.abs().max()))
+
+
+@pytest.mark.parametrize("name", ["b2", "b3_empty_middle_mixed_calib", "b1_many"])
+def test_fused_object_loss_kernel_vs_reference_golden(name):
+    """mfx_object_loss (one wavefront per object, forward-mode gradient rows) against the fixture recorded from the reference's
+    Loss_Computation: all eleven loss values, the logged means, and the gradient of the summed loss at the object centres."""
+    from test_loss_golden import check_case, evaluator
+    assert evaluator().fused_object_loss
+    check_case(name, DEV)
+
+
+def test_fused_object_loss_inside_a_wider_map_and_weighted_terms():
+    """The 50 channels at an offset inside a 64-channel pixel (ld 64, ch_off 8), and backward with a different incoming gradient
+    per term: against autograd of the tensor-op form on the same device."""
+    from test_loss_golden import case_inputs, evaluator, TERM_NAMES
+    from monoflex_amd import autograd as AG
+    from monoflex_amd.structures.params_3d import make_train_target
+    tg, cls, reg = case_inputs("b3_empty_middle_mixed_calib")
+    ev = evaluator()
+    targets = [make_train_target(t).to(DEV) for t in tg]
+    heat, tv = ev.prepare_targets(targets, DEV)
+    B, C, H, W = reg.shape
+    wide = torch.randn(B, H, W, 64, device=DEV)
+    wide[..., 8:58] = reg.to(DEV).permute(0, 2, 3, 1)
+    wide.requires_grad_()
+    terms, logged = AG.ObjectLossFn.apply(wide, tv["object_rows"], ev.object_loss_cfg(), 8)
+    gout = torch.linspace(0.5, 1.5, len(TERM_NAMES), device=DEV)
+    (terms * gout).sum().backward()
+    assert float(wide.grad[..., :8].abs().max()) == 0 and float(wide.grad[..., 58:].abs().max()) == 0
+    ev.fused_object_loss = False
+    reg_d = reg.to(DEV).requires_grad_()
+    loss_dict, logs = ev({"cls": cls.to(DEV), "reg": reg_d}, (heat, tv))
+    sum(loss_dict[k] * gout[i] for i, k in enumerate(TERM_NAMES)).backward()
+    for i, k in enumerate(TERM_NAMES):
+        assert abs(float(terms[i]) - float(loss_dict[k])) <= 2e-5 * max(1.0, abs(float(loss_dict[k]))), k
+    want = reg_d.grad.permute(0, 2, 3, 1)
+    assert float((wide.grad[..., 8:58] - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    for k, v in zip(('depth_MAE', 'center_MAE', '02_MAE', '13_MAE', 'lower_MAE', 'hard_MAE', 'soft_MAE', 'mean_MAE'), logged[3:11].tolist()):
+        assert abs(v - logs[k]) <= 1e-4 * max(1.0, abs(logs[k])), k

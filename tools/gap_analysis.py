@@ -36,3 +36,10 @@ print("| kernel | calls/step | busy us/step | gap-before us/step | avg gap us |"
 print("|---|---|---|---|---|")
 for k, _ in sorted(cnt.items(), key=lambda kv: -(tot[kv[0]] + gaps[kv[0]])):
     print("| %s | %.1f | %.1f | %.1f | %.2f |" % (k, cnt[k] / n, tot[k] / n / 1e3, gaps[k] / n / 1e3, gaps[k] / max(cnt[k], 1) / 1e3))
+if len(sys.argv) > 4:                                            # dump the dispatch sequence of the last step: start offset, duration, gap, name
+    a, b = idx[-2], idx[-1]
+    t0 = rows[a][1]; prev_end = None
+    with open(sys.argv[4], "w") as f:
+        for name, s, e in rows[a:b]:
+            f.write("%9.1f %8.1f %6.1f  %s\n" % ((s - t0) / 1e3, (e - s) / 1e3, 0.0 if prev_end is None else max(0, s - prev_end) / 1e3, short(name)[:110]))
+            prev_end = max(prev_end or e, e)
