@@ -249,6 +249,19 @@ int mfx_bn_act_fwd(const void* x, const float* scale, const float* shift, const 
  * sg[c] = sum g (= dbeta), sgx[c] = sum g*xhat (= dgamma), dx, and dres = g (optional); g = da * act'(a) */
 int mfx_bn_act_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
                    float* sg, float* sgx, void* dx, void* dres, long M, int C, int act, int dtype, void* stream);
+/* Two-launch train-mode BatchNorm (+act, +residual) and its backward for the single-process case: the statistics / gradient sums
+ * are accumulated in a persistent per-layer `scratch` (mfx_bn_scratch_bytes() bytes, ZERO before the first call; every call leaves
+ * it zero again), the finalize step (mean/rstd, running statistics with momentum and the unbiased variance, num_batches_tracked += 1;
+ * torch.nn.BatchNorm2d train-mode semantics, model/backbone/dla_dcn.py BatchNorm calls) happens in the prologue of the apply
+ * kernel.  mean/rstd (C floats each) are outputs for the backward.  Replaces stats + finalize + act_fwd (and reduce + apply +
+ * two gradient copies) with two launches each and no zero-fill launches. */
+size_t mfx_bn_scratch_bytes(void);
+int mfx_bn_train_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, long long* num_batches_tracked, float momentum, float eps, long M, int C, int act,
+                     int dtype, float* scratch, float* mean, float* rstd, void* stream);
+int mfx_bn_train_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
+                     void* dx, void* dres, float* dgamma, float* dbeta, long M, int C, int act, int dtype, float* scratch,
+                     void* stream);
 /* the two halves of mfx_bn_act_bwd, for synchronised BN (reference tools/plain_train_net.py:131-132, SyncBatchNorm):
  * reduce -> all-reduce(sg, sgx) across ranks -> apply with M_total = rows summed over ranks */
 int mfx_bn_bwd_reduce(const void* x, const void* a, const void* da, const float* mean, const float* rstd,

@@ -229,6 +229,20 @@ def _sync_group(sync):
     return None
 
 
+_BN_SEPARATE = [False]          # True: the five-launch form (stats, finalize, apply; reduce, apply) also in the single-process case
+_BN_SCRATCH = {}
+
+
+def _bn_scratch(gamma):
+    """Persistent zero scratch of one BN layer (keyed by its weight's storage): the kernels leave it zero after every call."""
+    key = (gamma.data_ptr(), gamma.device)
+    s = _BN_SCRATCH.get(key)
+    if s is None:
+        s = torch.zeros(L.load().mfx_bn_scratch_bytes() // 4, dtype=torch.float32, device=gamma.device)
+        _BN_SCRATCH[key] = s
+    return s
+
+
 @_device_guarded
 class BNActFn(Function):
     """Train-mode BatchNorm (batch statistics, biased variance) + activation (+ residual before the activation).
@@ -237,22 +251,42 @@ class BNActFn(Function):
     [sum g, sum g*xhat] backward, 2C(+1) floats each over RCCL."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, res, act, momentum, eps, sync):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, res, act, momentum, eps, sync, nbt=None):
         x = _c(x)
         C = x.shape[-1]
         M = x.numel() // C
-        st = torch.empty(2 * C + 1, dtype=torch.float32, device=x.device)
         lib_ = L.load()
-        L.check(lib_.mfx_bn_stats(_ptr(x), _ptr(st), st.data_ptr() + 4 * C, M, C, _dt(x.dtype), _stream()), "mfx_bn_stats")
         group = _sync_group(sync)
+        g32 = gamma.detach() if gamma.dtype == torch.float32 else gamma.detach().float()
+        b32 = beta.detach() if beta.dtype == torch.float32 else beta.detach().float()
+        if group is None and C <= 512 and M > 0 and not _BN_SEPARATE[0]:
+            # single process: statistics + apply in two launches on the layer's persistent (self-clearing) scratch
+            scratch = _bn_scratch(gamma)
+            mr = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+            y = torch.empty_like(x)
+            res_c = _c(res) if res is not None else None
+            rm = running_mean if running_mean is not None and running_mean.dtype == torch.float32 else None
+            if nbt is not None and (nbt.dtype != torch.int64 or rm is None):
+                nbt.add_(1)
+                nbt = None
+            L.check(lib_.mfx_bn_train_fwd(_ptr(x), _ptr(res_c), _ptr(y), _ptr(_c(g32)), _ptr(_c(b32)), _ptr(rm),
+                                          _ptr(running_var) if rm is not None else None, _ptr(nbt), ctypes.c_float(momentum), ctypes.c_float(eps),
+                                          M, C, act, _dt(x.dtype), _ptr(scratch), _ptr(mr), mr.data_ptr() + 4 * C, _stream()), "mfx_bn_train_fwd")
+            ctx.save_for_backward(x, y, mr[:C], mr[C:], _c(g32))
+            ctx.cfg = (act, res is not None, None, M)
+            ctx.scratch = scratch
+            return y
+        if nbt is not None:
+            nbt.add_(1)
+        ctx.scratch = None
+        st = torch.empty(2 * C + 1, dtype=torch.float32, device=x.device)
+        L.check(lib_.mfx_bn_stats(_ptr(x), _ptr(st), st.data_ptr() + 4 * C, M, C, _dt(x.dtype), _stream()), "mfx_bn_stats")
         Mt = M
         if group is not None:
             import torch.distributed as dist
             st[2 * C] = float(M)
             dist.all_reduce(st, group=group)
             Mt = M * dist.get_world_size(group)                # equal per-rank batches (weak scaling), no host sync
-        g32 = gamma.detach() if gamma.dtype == torch.float32 else gamma.detach().float()
-        b32 = beta.detach() if beta.dtype == torch.float32 else beta.detach().float()
         out = torch.empty(4 * C, dtype=torch.float32, device=x.device)          # mean | rstd | scale | shift
         mean, rstd, scale, shift = out[:C], out[C:2 * C], out[2 * C:3 * C], out[3 * C:]
         L.check(lib_.mfx_bn_finalize(_ptr(st), st.data_ptr() + 4 * C, _ptr(_c(g32)), _ptr(_c(b32)), _ptr(running_mean), _ptr(running_var),
@@ -274,6 +308,14 @@ class BNActFn(Function):
         da = _c(da)
         C = x.shape[-1]
         M = x.numel() // C
+        if ctx.scratch is not None:
+            dx = torch.empty_like(x)
+            dres = torch.empty_like(x) if has_res else None
+            dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+            dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+            L.check(L.load().mfx_bn_train_bwd(_ptr(x), _ptr(y), _ptr(da), _ptr(mean), _ptr(rstd), _ptr(g32), _ptr(dx), _ptr(dres), _ptr(dgamma),
+                                              _ptr(dbeta), M, C, act, _dt(x.dtype), _ptr(ctx.scratch), _stream()), "mfx_bn_train_bwd")
+            return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
         sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
         sg, sgx = sums[:C], sums[C:]
         dx = torch.empty_like(x)
@@ -289,7 +331,7 @@ class BNActFn(Function):
             local = sums
         L.check(lib_.mfx_bn_bwd_apply(_ptr(x), _ptr(y), _ptr(da), _ptr(mean), _ptr(rstd), _ptr(g32), _ptr(sg), sums.data_ptr() + 4 * C,
                                       _ptr(dx), _ptr(dres), M, Mt, C, act, _dt(x.dtype), _stream()), "mfx_bn_bwd_apply")
-        return dx, local[C:].clone(), local[:C].clone(), None, None, dres, None, None, None, None
+        return dx, local[C:].clone(), local[:C].clone(), None, None, dres, None, None, None, None, None
 
 
 @_device_guarded
@@ -477,8 +519,7 @@ def bn_act(x, bn, act, res=None, sync=None):
     """Train-mode BN module `bn` (+act, +res) on an NHWC tensor; updates bn.running_* like nn.BatchNorm2d.
     sync=None follows the module's `sync_bn` attribute (set by engine.trainer.convert_sync_batchnorm)."""
     mom = bn.momentum if bn.momentum is not None else 0.1
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    nbt = bn.num_batches_tracked if (bn.track_running_stats and bn.num_batches_tracked is not None) else None
     if sync is None:                    # torch's own converter (the reference script's literal call) leaves SyncBatchNorm holders
         sync = bool(getattr(bn, 'sync_bn', False)) or isinstance(bn, torch.nn.SyncBatchNorm)
-    return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, act, mom, bn.eps, sync)
+    return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, act, mom, bn.eps, sync, nbt)

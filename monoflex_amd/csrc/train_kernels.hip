@@ -313,7 +313,8 @@ __device__ __forceinline__ void block_reduce_columns(const float (&v)[NV][E], fl
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, long M, int C, int rows_per_block,
-                                                       float* __restrict__ sum, float* __restrict__ sumsq) {
+                                                       float* __restrict__ sum, float* __restrict__ sumsq, int ncopy) {
+    if (ncopy > 1) { const int k = blockIdx.x % ncopy; sum += (size_t)k * 2 * C; sumsq += (size_t)k * 2 * C; }      // spread the atomics over ncopy [sum|sumsq] pairs
     constexpr int E = ElemTraits<T>::ELEMS;
     extern __shared__ float sred[];                          // [256 / CPR][2 * C]
     const int CPR = C / E, tid = threadIdx.x;
@@ -450,7 +451,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ da,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             long M, int C, int rows_per_block, int act,
-                                                            float* __restrict__ sg, float* __restrict__ sgx) {
+                                                            float* __restrict__ sg, float* __restrict__ sgx, int ncopy) {
+    if (ncopy > 1) { const int k = blockIdx.x % ncopy; sg += (size_t)k * 2 * C; sgx += (size_t)k * 2 * C; }
     constexpr int E = ElemTraits<T>::ELEMS;
     extern __shared__ float sred[];                          // [256 / CPR][2 * C]
     const int CPR = C / E, tid = threadIdx.x;
@@ -521,6 +523,174 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         *reinterpret_cast<u32x4*>(dx + i * E) = ElemTraits<T>::pack(ov);
         if (dres) *reinterpret_cast<u32x4*>(dres + i * E) = ElemTraits<T>::pack(gq);
     }
+}
+
+// ---- two-launch forms (no zero-fill, finalize or copy launches) ----------------------------------
+// The column reductions above add into one of `ncopy` [2C] pairs of a persistent, ZERO scratch (ncopy * 2C = 1024 floats:
+// 64 cache lines take the atomics instead of 4).  The streaming kernel that consumes the sums first folds the copies (every
+// workgroup, 4 loads per thread), and the LAST workgroup to have done so zeroes the scratch again for the next call -- the
+// 66 BN layers x (zero-fill + finalize + 2 gradient copies + counter add) launches of a step disappear.
+constexpr int BN_SCRATCH_COLS = 1024;                            // floats per direction: ncopy * 2C
+
+__device__ __forceinline__ void bn_fold_copies(const float* __restrict__ sums, int C, int ncopy, float* colsum, float* part, int tid) {
+    const int cols = 2 * C;
+    if (cols <= 256) {
+        const int groups = 256 / cols, j = tid % cols, g0 = tid / cols;
+        float a = 0.f;
+        for (int k = g0; k < ncopy; k += groups) a += sums[(size_t)k * cols + j];
+        part[tid] = a;
+        __syncthreads();
+        if (tid < cols) {
+            float t = 0.f;
+            for (int g = 0; g < groups; ++g) t += part[g * cols + tid];
+            colsum[tid] = t;
+        }
+    } else {
+        for (int j = tid; j < cols; j += 256) {
+            float t = 0.f;
+            for (int k = 0; k < ncopy; ++k) t += sums[(size_t)k * cols + j];
+            colsum[j] = t;
+        }
+    }
+    __syncthreads();
+}
+
+// Every workgroup takes a ticket once it has read the sums (right after its fold) and looks at it only after streaming.  One
+// counter for ~2000 workgroups drains at ~8 ns per atomic (16 us, longer than the small layers' streaming), so the tickets are
+// two-level: 64 first-level counters on separate cache lines (workgroup index mod 64), the last arrival of each takes a
+// second-level ticket, and the holder of the last of those clears the sums.  Counters reset themselves.
+constexpr int BN_TICKET_GROUPS = 64, BN_TICKET_STRIDE = 32;      // counters: [64][32 words] first level, then one second-level word
+__device__ __forceinline__ unsigned bn_take_ticket(unsigned* cnt) { return atomicAdd(cnt + (blockIdx.x % BN_TICKET_GROUPS) * BN_TICKET_STRIDE, 1u); }
+__device__ __forceinline__ void bn_release_scratch(float* sums, unsigned* cnt, unsigned ticket, int tid, int* s_last) {
+    if (tid == 0) {
+        int last = 0;
+        const unsigned grp = blockIdx.x % BN_TICKET_GROUPS;
+        const unsigned members = (gridDim.x - grp + BN_TICKET_GROUPS - 1) / BN_TICKET_GROUPS;
+        if (ticket == members - 1) {
+            cnt[grp * BN_TICKET_STRIDE] = 0u;
+            const unsigned groups = gridDim.x < (unsigned)BN_TICKET_GROUPS ? gridDim.x : (unsigned)BN_TICKET_GROUPS;
+            if (atomicAdd(cnt + BN_TICKET_GROUPS * BN_TICKET_STRIDE, 1u) == groups - 1) { cnt[BN_TICKET_GROUPS * BN_TICKET_STRIDE] = 0u; last = 1; }
+        }
+        *s_last = last;
+    }
+    __syncthreads();
+    if (*s_last)
+        for (int i = tid; i < BN_SCRATCH_COLS; i += 256) sums[i] = 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_fused_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+        const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var, long long* nbt,
+        float momentum, float eps, float inv_count, float unbias, float* sums, unsigned* counter, int ncopy,
+        float* __restrict__ mean_out, float* __restrict__ rstd_out, long total_chunks, int C, int act) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    __shared__ float colsum[BN_SCRATCH_COLS], tab[BN_SCRATCH_COLS], part[256];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    bn_fold_copies(sums, C, ncopy, colsum, part, tid);
+    for (int c = tid; c < C; c += 256) {
+        const float m = colsum[c] * inv_count;
+        const float v = fmaxf(colsum[C + c] * inv_count - m * m, 0.f);
+        const float r = rsqrtf(v + eps), sc = gamma[c] * r;
+        tab[c] = sc; tab[C + c] = beta[c] - m * sc;
+        if (blockIdx.x == 0) {
+            mean_out[c] = m; rstd_out[c] = r;
+            if (running_mean) {
+                running_mean[c] = running_mean[c] * (1.f - momentum) + m * momentum;
+                running_var[c] = running_var[c] * (1.f - momentum) + v * unbias * momentum;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0 && nbt) *nbt += 1;
+    __syncthreads();
+    const unsigned ticket = tid == 0 ? bn_take_ticket(counter) : 0u;
+    const int CPR = C / E;
+    const long stride = (long)gridDim.x * blockDim.x;
+    auto finish = [&](long i, const u32x4& cx, const u32x4& cr) {
+        const int c0 = (int)(i % CPR) * E;
+        float v[E], sc[E], sh[E];
+        ElemTraits<T>::unpack(cx, v);
+        load_vec<E>(tab + c0, sc); load_vec<E>(tab + C + c0, sh);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = v[e] * sc[e] + sh[e];
+        if (res) {
+            float r[E];
+            ElemTraits<T>::unpack(cr, r);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] += r[e];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = apply_act(v[e], act, 0);
+        *reinterpret_cast<u32x4*>(y + i * E) = ElemTraits<T>::pack(v);
+    };
+    long i = blockIdx.x * (long)blockDim.x + tid;
+    for (; i + stride < total_chunks; i += 2 * stride) {         // two chunks (up to four 16-byte loads) in flight per thread
+        const long j = i + stride;
+        const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + i * E), x1 = *reinterpret_cast<const u32x4*>(x + j * E);
+        u32x4 r0 = x0, r1 = x1;
+        if (res) { r0 = *reinterpret_cast<const u32x4*>(res + i * E); r1 = *reinterpret_cast<const u32x4*>(res + j * E); }
+        finish(i, x0, r0); finish(j, x1, r1);
+    }
+    for (; i < total_chunks; i += stride) {
+        const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + i * E);
+        u32x4 r0 = x0;
+        if (res) r0 = *reinterpret_cast<const u32x4*>(res + i * E);
+        finish(i, x0, r0);
+    }
+    bn_release_scratch(sums, counter, ticket, tid, &s_last);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ da,
+        const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma, float* sums, unsigned* counter,
+        int ncopy, float invM, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta,
+        long total_chunks, int C, int act) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    __shared__ float colsum[BN_SCRATCH_COLS], coef[3 * (BN_SCRATCH_COLS / 2)], part[256];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    bn_fold_copies(sums, C, ncopy, colsum, part, tid);
+    for (int c = tid; c < C; c += 256) {
+        const float sg = colsum[c], sgx = colsum[C + c];
+        const float ca = gamma[c] * rstd[c], cb = -ca * rstd[c] * sgx * invM;
+        coef[c] = ca; coef[C + c] = cb; coef[2 * C + c] = -cb * mean[c] - ca * sg * invM;
+        if (blockIdx.x == 0) { dgamma[c] = sgx; dbeta[c] = sg; }
+    }
+    __syncthreads();
+    const unsigned ticket = tid == 0 ? bn_take_ticket(counter) : 0u;
+    const int CPR = C / E;
+    const long stride = (long)gridDim.x * blockDim.x;
+    auto finish = [&](long i, const u32x4& cx, const u32x4& cdv, const u32x4& cav) {
+        const int c0 = (int)(i % CPR) * E;
+        float xv[E], av[E], dv[E], gq[E], ov[E], ca[E], cb[E], cd[E];
+        ElemTraits<T>::unpack(cx, xv);
+        ElemTraits<T>::unpack(cdv, dv);
+        if (act != ACT_NONE) ElemTraits<T>::unpack(cav, av);
+        load_vec<E>(coef + c0, ca); load_vec<E>(coef + C + c0, cb); load_vec<E>(coef + 2 * C + c0, cd);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            gq[e] = act != ACT_NONE ? dv[e] * act_grad(av[e], act) : dv[e];
+            ov[e] = ca[e] * gq[e] + cb[e] * xv[e] + cd[e];
+        }
+        *reinterpret_cast<u32x4*>(dx + i * E) = ElemTraits<T>::pack(ov);
+        if (dres) *reinterpret_cast<u32x4*>(dres + i * E) = ElemTraits<T>::pack(gq);
+    };
+    long i = blockIdx.x * (long)blockDim.x + tid;
+    for (; i + stride < total_chunks; i += 2 * stride) {         // two chunks = six 16-byte loads in flight per thread
+        const long j = i + stride;
+        const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + i * E), x1 = *reinterpret_cast<const u32x4*>(x + j * E);
+        const u32x4 d0 = *reinterpret_cast<const u32x4*>(da + i * E), d1 = *reinterpret_cast<const u32x4*>(da + j * E);
+        u32x4 a0 = x0, a1 = x1;
+        if (act != ACT_NONE) { a0 = *reinterpret_cast<const u32x4*>(a + i * E); a1 = *reinterpret_cast<const u32x4*>(a + j * E); }
+        finish(i, x0, d0, a0); finish(j, x1, d1, a1);
+    }
+    for (; i < total_chunks; i += stride) {
+        const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + i * E), d0 = *reinterpret_cast<const u32x4*>(da + i * E);
+        u32x4 a0 = x0;
+        if (act != ACT_NONE) a0 = *reinterpret_cast<const u32x4*>(a + i * E);
+        finish(i, x0, d0, a0);
+    }
+    bn_release_scratch(sums, counter, ticket, tid, &s_last);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -805,6 +975,7 @@ extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int 
     return MFX_OK;
 }
 
+int g_opt_bn_apply_blocks = 1024;   // option "bn_apply_blocks": workgroup cap of the two-launch forms' streaming kernels
 int g_opt_bn_blocks = 768;     // option "bn_blocks": target workgroup count of the column reductions (BN statistics / backward sums / bias sums)
 
 // rows per workgroup of the column reductions: every workgroup ends with one global atomic per column, all workgroups on the
@@ -837,8 +1008,8 @@ extern "C" int mfx_bn_stats(const void* x, float* sum, float* sumsq, long M, int
     if (M == 0) return MFX_OK;
     const int rows = bn_rows_per_block(M, C, dtype);
     const size_t smem = (size_t)(256 / (C / (dtype == MFX_BF16 ? 8 : 4))) * 2 * C * sizeof(float);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, sum, sumsq),
-                      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, sum, sumsq));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, sum, sumsq, 1),
+                      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, sum, sumsq, 1));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -883,8 +1054,8 @@ extern "C" int mfx_bn_bwd_reduce(const void* x, const void* a, const void* da, c
     const int rows = bn_rows_per_block(M, C, dtype);
     const size_t smem = (size_t)(256 / (C / (dtype == MFX_BF16 ? 8 : 4))) * 2 * C * sizeof(float);
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sg, sgx),
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, M, C, rows, act, sg, sgx));
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sg, sgx, 1),
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, M, C, rows, act, sg, sgx, 1));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -902,6 +1073,65 @@ extern "C" int mfx_bn_bwd_apply(const void* x, const void* a, const void* da, co
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, BN_APPLY_GRID(chunks), dim3(256), (size_t)3 * C * sizeof(float), st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, gamma, sg, sgx, invM, (float*)dx, (float*)dres, chunks, C, act),
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, BN_APPLY_GRID(chunks), dim3(256), (size_t)3 * C * sizeof(float), st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, gamma, sg, sgx, invM, (bf16_t*)dx, (bf16_t*)dres, chunks, C, act));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+// scratch of the two-launch forms: [0, 1024) forward sums, [1024, 2048) backward sums, then the two ticket blocks; ZERO on entry,
+// zero again on exit.  One per BN layer, persistent.
+#define BN_FUSED_GRID(total) dim3((unsigned)std::min<long>(cdivt((total), 256), std::max(64, g_opt_bn_apply_blocks)))
+static int bn_ncopy(int C) { return std::max(1, BN_SCRATCH_COLS / (2 * C)); }
+
+constexpr int BN_TICKET_WORDS = BN_TICKET_GROUPS * BN_TICKET_STRIDE + BN_TICKET_STRIDE;
+extern "C" size_t mfx_bn_scratch_bytes(void) { return (size_t)(2 * BN_SCRATCH_COLS + 2 * BN_TICKET_WORDS) * sizeof(float); }
+
+extern "C" int mfx_bn_train_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, long long* num_batches_tracked, float momentum, float eps, long M, int C, int act,
+                                int dtype, float* scratch, float* mean, float* rstd, void* stream) {
+    if (!x || !y || !gamma || !beta || !scratch || !mean || !rstd) return mfx_fail(MFX_ERR_ARG, "bn_train_fwd: null pointer");
+    if ((running_mean == nullptr) != (running_var == nullptr)) return mfx_fail(MFX_ERR_ARG, "bn_train_fwd: running_mean/var must come together");
+    int rc = bn_check(C, dtype); if (rc) return rc;
+    if (2 * C > BN_SCRATCH_COLS) return mfx_fail(MFX_ERR_ARG, "bn_train_fwd: C > 512");
+    if (M <= 0) return mfx_fail(MFX_ERR_ARG, "bn_train_fwd: empty batch");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int E = dtype == MFX_BF16 ? 8 : 4, ncopy = bn_ncopy(C);
+    const int rows = bn_rows_per_block(M, C, dtype);
+    const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, scratch, scratch + C, ncopy),
+                      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, scratch, scratch + C, ncopy));
+    MFX_HIP_CHECK(hipGetLastError());
+    const long chunks = M * (C / E);
+    const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+    unsigned* counter = reinterpret_cast<unsigned*>(scratch + 2 * BN_SCRATCH_COLS);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(bn_act_fwd_fused_kernel<float>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const float*)x, (const float*)res, (float*)y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, (float)(1.0 / (double)M), unbias, scratch, counter, ncopy, mean, rstd, chunks, C, act),
+        hipLaunchKernelGGL(bn_act_fwd_fused_kernel<bf16_t>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, (float)(1.0 / (double)M), unbias, scratch, counter, ncopy, mean, rstd, chunks, C, act));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_bn_train_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
+                                void* dx, void* dres, float* dgamma, float* dbeta, long M, int C, int act, int dtype, float* scratch,
+                                void* stream) {
+    if (!x || !da || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !scratch || (act != MFX_ACT_NONE && !a))
+        return mfx_fail(MFX_ERR_ARG, "bn_train_bwd: null pointer");
+    int rc = bn_check(C, dtype); if (rc) return rc;
+    if (2 * C > BN_SCRATCH_COLS) return mfx_fail(MFX_ERR_ARG, "bn_train_bwd: C > 512");
+    if (M <= 0) return mfx_fail(MFX_ERR_ARG, "bn_train_bwd: empty batch");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int E = dtype == MFX_BF16 ? 8 : 4, ncopy = bn_ncopy(C);
+    const int rows = bn_rows_per_block(M, C, dtype);
+    const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
+    float* sums = scratch + BN_SCRATCH_COLS;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sums, sums + C, ncopy),
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, M, C, rows, act, sums, sums + C, ncopy));
+    MFX_HIP_CHECK(hipGetLastError());
+    const long chunks = M * (C / E);
+    unsigned* counter = reinterpret_cast<unsigned*>(scratch + 2 * BN_SCRATCH_COLS) + BN_TICKET_WORDS;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<float>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, gamma, sums, counter, ncopy, 1.f / (float)M, (float*)dx, (float*)dres, dgamma, dbeta, chunks, C, act),
+        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<bf16_t>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, gamma, sums, counter, ncopy, 1.f / (float)M, (bf16_t*)dx, (bf16_t*)dres, dgamma, dbeta, chunks, C, act));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

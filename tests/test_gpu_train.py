@@ -112,6 +112,47 @@ def test_bn_act_grads(act, res):
         assert _rel(rd.grad.permute(0, 3, 1, 2), rr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("C,shape,dt", [(16, (2, 40, 64), "fp32"), (64, (3, 12, 20), "bf16"), (512, (2, 6, 10), "fp32"), (128, (8, 48, 160), "bf16")])
+def test_bn_two_launch_form_reuses_its_scratch(C, shape, dt):
+    """mfx_bn_train_fwd / mfx_bn_train_bwd keep their sums in a persistent scratch that every call must leave zero: repeated
+    forwards, a forward without a backward, and two backwards through one forward all agree with the separate-kernel form
+    (stats / finalize / apply with freshly zeroed buffers), and num_batches_tracked counts in the kernel."""
+    from monoflex_amd import autograd as AG
+    from monoflex_amd import lib as L
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(C)
+    B, H, W = shape
+    bn_a, bn_b = torch.nn.BatchNorm2d(C).to(DEV), torch.nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.rand(C, generator=g) + 0.5); bn_a.bias.copy_(torch.randn(C, generator=g))
+    bn_b.load_state_dict(bn_a.state_dict())
+    tol = 2e-2 if dt == "bf16" else 1e-4
+    for it in range(3):
+        x = (torch.randn(B, H, W, C, generator=g) * (1 + it) + 0.3 * it).to(DEV).to(dtype)
+        r = torch.randn(B, H, W, C, generator=g).to(DEV).to(dtype)
+        outs = []
+        for bn, separate in ((bn_a, False), (bn_b, True)):
+            AG._BN_SEPARATE[0] = separate
+            try:
+                xd = x.clone().requires_grad_()
+                if it == 1:
+                    with torch.no_grad():
+                        AG.bn_act(xd, bn, L.ACT_RELU)                      # a forward that never sees a backward
+                y = AG.bn_act(xd, bn, L.ACT_RELU)
+                g1 = torch.autograd.grad(y, xd, r, retain_graph=True)[0]
+                bn.zero_grad()
+                (y.float() * r.float()).sum().backward()                   # second backward through the same forward
+                outs.append((y, g1, xd.grad, bn.weight.grad.clone(), bn.bias.grad.clone()))
+            finally:
+                AG._BN_SEPARATE[0] = False
+        for a, b in zip(*outs):
+            assert _rel(a.float(), b.float()) < tol
+        assert _rel(outs[0][1].float(), outs[0][2].float()) < (1e-2 if dt == "bf16" else 1e-4)             # the two backwards of the fused form agree with each other
+    assert _rel(bn_a.running_mean, bn_b.running_mean) < 1e-5 and _rel(bn_a.running_var, bn_b.running_var) < 1e-5
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 4
+    assert float(AG._bn_scratch(bn_a.weight).abs().max()) == 0.0
+
+
 def test_maxpool_and_upsample_grads():
     from monoflex_amd import autograd as AG
     g = torch.Generator().manual_seed(5)

@@ -1,3 +1,2 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_train.py -x -q -k "loss" 2>&1 | tail -15
-timeout 600 python bench.py --mode train --no-cpu-baseline --steps 10 2>&1 | tail -1 | cut -c1-330
+timeout 1500 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_step.py -q > gpurun_out/train_tests.log 2>&1; grep -E "passed|failed|FAILED|Error" gpurun_out/train_tests.log | tail -8
