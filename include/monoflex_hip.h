@@ -225,6 +225,12 @@ int mfx_conv_wgrad_nhwc_dil(const void* x, const void* dy, float* dw, int B, int
 int mfx_conv_wgrad_oihw(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
                         int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
                         int Cout_real, int Cin_real, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* Stem weight gradient (7x7 / stride 1 / pad 3, 3 -> 16 channels, bf16; model/backbone/dla_dcn.py:268-272 base_layer conv): xp is
+ * the zero-padded NHWC4 image the forward stem reads ((B, H+6, W+8, 4), mfx_pack_image_nhwc4), dy (B,H,W,16) bf16; dw fp32
+ * [16][7][32] with dw[o][th][dx*4 + c] = d/dw[o][c][th][dx] (dx = 7 and c = 3 are padding).  workspace: >= 14336 bytes per
+ * workgroup used (768 by default). */
+int mfx_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, int B, int H, int W, int Hp, int Wp, void* workspace,
+                        size_t workspace_bytes, void* stream);
 /* (workspace: optional fp32 scratch; with it the bf16 kernel writes per-slab partial tiles and sums them in a second pass
  *  instead of accumulating with atomics, which lets it use 4x more workgroups) */
 /* fp32 OIHW parameter -> packed operand [rows_pad][K_pad] of `dtype` (+ optional fragment-major copy, see mfx_conv_desc.w_frag).

@@ -185,6 +185,9 @@ class CatConv1x1Fn(Function):
         return (dw, *dxs)
 
 
+_STEM_WGRAD_GENERIC = [False]    # True: the generic dilated-tap weight-gradient kernel also for the 16-channel bf16 stem (test switch)
+
+
 @_device_guarded
 class StemConvFn(Function):
     """7x7 / stride 1 / pad 3 convolution of the NCHW fp32 image batch (dla_dcn.py:268-272); no data gradient."""
@@ -212,8 +215,13 @@ class StemConvFn(Function):
             # (the layout the forward stem uses); dW[o][th*4 + j][u*4 + c] is the gradient of w[o][c][th][2j + u]
             B, Hp, Wp, _ = xp.shape
             dws = torch.empty((dy.shape[-1], 28, 8), dtype=torch.float32, device=xp.device)
-            L.check(L.load().mfx_conv_wgrad_nhwc_dil(_ptr(xp), _ptr(dy), _ptr(dws), B, Hp, Wp, 4, 8, 7, 4, 1, 0, 0, 2, H, W, dy.shape[-1],
-                                                     dy.shape[-1], _dt(xp.dtype), _stream()), "mfx_conv_wgrad_nhwc_dil")
+            if dy.shape[-1] == 16 and not _STEM_WGRAD_GENERIC[0]:
+                ws = ops._splitk_workspace(xp.device)             # Toeplitz-row kernel: image and dy read once
+                L.check(L.load().mfx_stem_wgrad_bf16(_ptr(xp), _ptr(dy), _ptr(dws), B, H, W, Hp, Wp, _ptr(ws), ws.numel() * 4, _stream()),
+                        "mfx_stem_wgrad_bf16")
+            else:
+                L.check(L.load().mfx_conv_wgrad_nhwc_dil(_ptr(xp), _ptr(dy), _ptr(dws), B, Hp, Wp, 4, 8, 7, 4, 1, 0, 0, 2, H, W, dy.shape[-1],
+                                                         dy.shape[-1], _dt(xp.dtype), _stream()), "mfx_conv_wgrad_nhwc_dil")
             dw = dws[:Cout].view(Cout, 7, 4, 2, 4).reshape(Cout, 7, 8, 4)[:, :, :7, :3].permute(0, 3, 1, 2).contiguous()
         else:
             dwf = _wgrad(xp, dy, 7, 7, 1, 0, H, W, Ck=4, x_pixstride=4)      # padded image: pad 0 in padded coordinates

@@ -18,6 +18,7 @@
 #include "../../include/monoflex_hip.h"
 #include "common.h"
 #include "err.h"
+#include "fill.h"
 #include "wgrad.h"
 #include <algorithm>
 
@@ -243,18 +244,20 @@ constexpr int WP_XSUB = WP_PPIX * 32 + 32, WP_DSUB = WP_TH * WP_TW * 32 + 32;   
 
 struct WpGeom { int B, H, W, Cin, Cout, ldy, tiles_x, tiles_y, ntiles, tiles_per_slab, K; float* ws; long ws_slab; };
 
-// OS = 16-channel sub-tiles of dy handled by the workgroup (4: 64 output channels, 2: 32); NW = waves (6 or 12), each
-// owning JW = 36 / NW of the 36 (tap, 16-channel) operand sub-tiles
-template <int OS, int NW>
+// OS = 16-channel sub-tiles of dy handled by the workgroup (4: 64 output channels, 2: 32, 1: 16); XS = 16-channel sub-tiles of
+// the input slice (4: a 64-channel slice; 2 / 1: the whole input of the 32- and 16-channel full-resolution layers); NW = waves,
+// each owning JW = 9 * XS / NW of the (tap, 16-channel) operand sub-tiles
+template <int OS, int NW, int XS = 4>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad_patch_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, WpGeom g) {
-    constexpr int WP_NT = 64 * NW, JW = 36 / NW;
-    constexpr int XCH = WP_PPIX * 8, DCH = WP_TH * WP_TW * 2 * OS;           // 16-byte chunks per tile: x patch, dy
+    constexpr int WP_NT = 64 * NW, JW = 9 * XS / NW;
+    static_assert(9 * XS % NW == 0 && (JW == 6 || JW <= 3), "operand sub-tiles per wave");
+    constexpr int XCH = WP_PPIX * 2 * XS, DCH = WP_TH * WP_TW * 2 * OS;      // 16-byte chunks per tile: x patch, dy
     constexpr int XN = (XCH + WP_NT - 1) / WP_NT, DN = (DCH + WP_NT - 1) / WP_NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int STAGE = 4 * WP_XSUB + OS * WP_DSUB;                        // x patch [4 sub][204 px][32 B] | dy [OS sub][128 px][32 B]
+    constexpr int STAGE = XS * WP_XSUB + OS * WP_DSUB;                       // x patch [XS sub][204 px][32 B] | dy [OS sub][128 px][32 B]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               // k sub-tiles JW*wave .. JW*wave+JW-1 of 36
-    const int o0 = blockIdx.x * (16 * OS), cs = blockIdx.y;                  // first output channel, 64-channel input slice
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               // k sub-tiles JW*wave .. JW*wave+JW-1 of 9*XS
+    const int o0 = blockIdx.x * (16 * OS), cs = blockIdx.y;                  // first output channel, input slice of 16*XS channels
     const int t_begin = blockIdx.z * g.tiles_per_slab, t_end = min(t_begin + g.tiles_per_slab, g.ntiles);
 
     struct Regs { u32x4 xr[XN]; u32x4 dr[DN]; };
@@ -262,12 +265,12 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_patch_kernel(const bf16_t*
         const int tx = t % g.tiles_x; int q = t / g.tiles_x;
         const int ty = q % g.tiles_y, b = q / g.tiles_y;
         const int x0 = tx * WP_TW, y0 = ty * WP_TH;
-        const bf16_t* xb = x + (size_t)b * g.H * g.W * g.Cin + cs * 64;
+        const bf16_t* xb = x + (size_t)b * g.H * g.W * g.Cin + cs * (16 * XS);
         const bf16_t* db = dy + (size_t)b * g.H * g.W * g.ldy + o0;
 #pragma unroll
         for (int u = 0; u < XN; ++u) {
             const int id = tid + u * WP_NT;
-            const int p = id >> 3, c8 = id & 7;
+            const int p = id / (2 * XS), c8 = id - p * (2 * XS);
             const int pr = p / WP_PW, pc = p - pr * WP_PW;
             const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
             u32x4 z = {0u, 0u, 0u, 0u};
@@ -288,12 +291,13 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_patch_kernel(const bf16_t*
     };
     auto lstore = [&](int buf, const Regs& r) {
         char* xs = lds + buf * STAGE;
-        char* ds = xs + 4 * WP_XSUB;
+        char* ds = xs + XS * WP_XSUB;
 #pragma unroll
         for (int u = 0; u < XN; ++u) {
             const int id = tid + u * WP_NT;
+            const int p = id / (2 * XS), c8 = id - p * (2 * XS);
             if (XCH % WP_NT == 0 || id < XCH)
-                *reinterpret_cast<u32x4*>(xs + ((id & 7) >> 1) * WP_XSUB + (id >> 3) * 32 + (id & 1) * 16) = r.xr[u];
+                *reinterpret_cast<u32x4*>(xs + (c8 >> 1) * WP_XSUB + p * 32 + (c8 & 1) * 16) = r.xr[u];
         }
 #pragma unroll
         for (int u = 0; u < DN; ++u) {
@@ -313,11 +317,11 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_patch_kernel(const bf16_t*
     // lane part of every transposed read: pixel 4*gq + (l16 >> 2) of the 32-pixel segment, 8-byte quarter (l16 & 3)
     const int l16 = lane & 15, gq = lane >> 4;
     const uint32_t lane_off = (uint32_t)((4 * gq + (l16 >> 2)) * 32 + (l16 & 3) * 8);
-    const uint32_t xs_a = (uint32_t)(uintptr_t)lds, ds_a = xs_a + 4 * WP_XSUB;
+    const uint32_t xs_a = (uint32_t)(uintptr_t)lds, ds_a = xs_a + XS * WP_XSUB;
     uint32_t xoff[JW];                                                       // this wave's (tap, channel sub-tile) operands
 #pragma unroll
     for (int j = 0; j < JW; ++j) {
-        const int ks = wave * JW + j, tap = ks >> 2, sub = ks & 3, th = tap / 3, tw = tap - th * 3;
+        const int ks = wave * JW + j, tap = ks / XS, sub = ks % XS, th = tap / 3, tw = tap - th * 3;
         xoff[j] = xs_a + (uint32_t)(sub * WP_XSUB + (th * WP_PW + tw) * 32) + lane_off;
     }
     auto compute = [&](int buf) {
@@ -336,15 +340,21 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_patch_kernel(const bf16_t*
                         "ds_read_b64_tr_b16 %6, %8 offset:12384\n\tds_read_b64_tr_b16 %7, %8 offset:12896\n\t"
                         "s_waitcnt lgkmcnt(0)"
                         : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3) : "v"(da) : "memory");
-                } else {
+                } else if constexpr (OS == 2) {
                     asm volatile(
                         "ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
                         "ds_read_b64_tr_b16 %2, %4 offset:4128\n\tds_read_b64_tr_b16 %3, %4 offset:4640\n\t"
                         "s_waitcnt lgkmcnt(0)"
                         : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1) : "v"(da) : "memory");
+                } else {
+                    l1 = 0; h1 = 0;
+                    asm volatile(
+                        "ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(l0), "=&v"(h0) : "v"(da) : "memory");
                 }
                 df[0] = u32x4{(uint32_t)l0, (uint32_t)(l0 >> 32), (uint32_t)h0, (uint32_t)(h0 >> 32)};
-                df[1] = u32x4{(uint32_t)l1, (uint32_t)(l1 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32)};
+                if constexpr (OS >= 2) df[1] = u32x4{(uint32_t)l1, (uint32_t)(l1 >> 32), (uint32_t)h1, (uint32_t)(h1 >> 32)};
                 if constexpr (OS == 4) {
                     df[2] = u32x4{(uint32_t)l2, (uint32_t)(l2 >> 32), (uint32_t)h2, (uint32_t)(h2 >> 32)};
                     df[3] = u32x4{(uint32_t)l3, (uint32_t)(l3 >> 32), (uint32_t)h3, (uint32_t)(h3 >> 32)};
@@ -412,8 +422,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_patch_kernel(const bf16_t*
     float* wsb = g.ws + (size_t)blockIdx.z * g.ws_slab;
 #pragma unroll
     for (int j = 0; j < JW; ++j) {
-        const int ks = wave * JW + j, tap = ks >> 2, sub = ks & 3;
-        const int k = tap * g.Cin + cs * 64 + sub * 16 + (lane & 15);
+        const int ks = wave * JW + j, tap = ks / XS, sub = ks % XS;
+        const int k = tap * g.Cin + cs * (16 * XS) + sub * 16 + (lane & 15);
 #pragma unroll
         for (int i = 0; i < OS; ++i)
 #pragma unroll
@@ -435,14 +445,16 @@ int g_opt_wgrad_patch_waves = 12;   // option "wgrad_patch_waves": 6 (64 x 96 bl
 int try_conv_wgrad_patch(const void* x, const void* dy, WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st) {
     if (!g_opt_wgrad_patch || !workspace || g.direct) return 0;
     if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.pad_h != 1 || g.pad_w != 1 || g.dil_w != 1 || g.Ho != g.H || g.Wo != g.W) return 0;
-    if (g.Ck % 64 != 0 || g.x_pixstride != g.Ck || g.ldy % 8 != 0 || g.Cout % 8 != 0 || g.M < 2048) return 0;
+    if ((g.Ck % 64 != 0 && g.Ck != 32 && g.Ck != 16) || g.x_pixstride != g.Ck || g.ldy % 8 != 0 || g.Cout % 8 != 0 || g.M < 2048) return 0;
+    if (g.Ck < 64 && g.Cout > 32) return 0;
     WpGeom w;
     w.B = g.B; w.H = g.H; w.W = g.W; w.Cin = g.Ck; w.Cout = g.Cout; w.ldy = g.ldy; w.K = g.K;
     w.tiles_x = (g.W + WP_TW - 1) / WP_TW; w.tiles_y = (g.H + WP_TH - 1) / WP_TH; w.ntiles = w.tiles_x * w.tiles_y * g.B;
-    const int os = g.Cout > 32 ? 4 : 2;
-    const int otiles = (g.Cout + 16 * os - 1) / (16 * os), slices = g.Ck / 64;
+    const int xs = g.Ck >= 64 ? 4 : g.Ck / 16;
+    const int os = g.Cout > 32 ? 4 : (g.Cout > 16 || xs == 4 ? 2 : 1);
+    const int otiles = (g.Cout + 16 * os - 1) / (16 * os), slices = g.Ck / (16 * xs);
     const long ws_slab = (long)g.Cout * g.K;
-    int nslab = std::max(1, g_opt_wgrad_patch_blocks / (otiles * slices));
+    int nslab = std::max(1, (xs < 4 ? 8 : 1) * g_opt_wgrad_patch_blocks / (otiles * slices));    // small-channel form: ~7 of its workgroups fit a CU
     nslab = (int)std::min<long>(nslab, (long)(workspace_bytes / sizeof(float)) / ws_slab);
     nslab = std::min(nslab, std::max(1, w.ntiles / 4));       // at least four tiles per slab: the 147 KB epilogue must amortise
     if (nslab < 1) return 0;
@@ -452,6 +464,23 @@ int try_conv_wgrad_patch(const void* x, const void* dy, WgradGeom& g, void* work
     g.ws = w.ws; g.ws_ld = g.K; g.ws_slab = ws_slab;
     const dim3 grid(otiles, slices, nslab);
     const int nw = g_opt_wgrad_patch_waves == 12 ? 12 : 6;
+    if (xs < 4) {
+        // the 16- and 32-channel full-resolution layers (level0 / level1 of the DLA base): one slice holds the whole input;
+        // memory-bound (10 KB staged per 128 pixels for 36-72 MFMAs), so many slabs and small workgroups
+#define WP_LAUNCH_SMALL(OS_, NW_, XS_)                                                                                              \
+        do {                                                                                                                        \
+            constexpr int smem = 2 * (XS_ * WP_XSUB + OS_ * WP_DSUB);                                                               \
+            hipLaunchKernelGGL((conv_wgrad_patch_kernel<OS_, NW_, XS_>), grid, dim3(64 * NW_), smem, st, (const bf16_t*)x, (const bf16_t*)dy, w); \
+        } while (0)
+        if (xs == 1 && os == 1) WP_LAUNCH_SMALL(1, 3, 1);
+        else if (xs == 1) WP_LAUNCH_SMALL(2, 3, 1);
+        else if (os == 1) WP_LAUNCH_SMALL(1, 6, 2);
+        else WP_LAUNCH_SMALL(2, 6, 2);
+#undef WP_LAUNCH_SMALL
+        MFX_HIP_CHECK(hipGetLastError());
+        *nslab_out = nslab;
+        return 1;
+    }
     if (os == 4) {
         constexpr int smem = 2 * (4 * WP_XSUB + 4 * WP_DSUB);
         if (nw == 12) {
@@ -472,4 +501,166 @@ int try_conv_wgrad_patch(const void* x, const void* dy, WgradGeom& g, void* work
     MFX_HIP_CHECK(hipGetLastError());
     *nslab_out = nslab;
     return 1;
+}
+
+// ======================================================================================================================
+// Stem (7x7 / stride 1 / pad 3, 3 -> 16 channels at full resolution; dla_dcn.py:268-272): weight gradient in the forward
+// stem's operand layout -- the zero-padded NHWC4 image, super-taps of two 4-channel pixels: dW[o][th][dx*4 + c] with
+// dx = 0..7 (dx = 7 and c = 3 are padding columns the caller drops).
+// For a fixed kernel row th the implicit-im2col operand is Toeplitz: column (dx, c) of output pixel x is element
+// 4*(x + dx) + c of the FLAT image row, i.e. the 32 columns of pixel x are the 64 bytes starting at byte 8*x.  A transposed
+// read takes four 8-byte pieces per pixel row at ANY 8-byte aligned address, so the operand fragments come straight from the
+// flat rows in LDS (320 bytes per row for 32 output pixels) -- no im2col, and the 126 MB of dy + 31 MB of image are read
+// from memory once (the generic kernel re-read the image 28 times through a K = 224, Cout = 16 tile: 774 us at B = 8).
+// ======================================================================================================================
+namespace mfx {
+
+constexpr int SW_TH = 8, SW_TW = 32, SW_ROWS = SW_TH + 6, SW_ROWB = (SW_TW + 8) * 8;     // 14 image rows x 320 bytes
+constexpr int SW_XBYTES = SW_ROWS * SW_ROWB, SW_DBYTES = SW_TH * SW_TW * 32, SW_STAGE = SW_XBYTES + SW_DBYTES;
+constexpr int SW_K = 224;
+
+struct SwGeom { int B, H, W, Hp, Wp, tiles_x, tiles_y, ntiles, tiles_per_block; float* ws; };
+
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restrict__ xp, const bf16_t* __restrict__ dy, SwGeom g) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * SW_STAGE];
+    static_assert(2 * SW_STAGE >= 14 * 64 * 16, "the cross-wave reduction reuses the staging buffers");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t_begin = blockIdx.x * g.tiles_per_block, t_end = min(t_begin + g.tiles_per_block, g.ntiles);
+    constexpr int XCH = SW_ROWS * (SW_ROWB / 16), DCH = SW_TH * SW_TW * 2;      // 280 image chunks, 512 dy chunks of 16 bytes
+    struct Regs { u32x4 xr[2]; u32x4 dr[2]; };
+    auto gload = [&](Regs& r, int t) {
+        const int tx = t % g.tiles_x; int q = t / g.tiles_x;
+        const int ty = q % g.tiles_y, b = q / g.tiles_y;
+        const int x0 = tx * SW_TW, y0 = ty * SW_TH;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int id = tid + u * 256;
+            const int pr = id / (SW_ROWB / 16), c = id - pr * (SW_ROWB / 16);
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if (id < XCH && y0 + pr < g.Hp && x0 + 2 * c + 1 < g.Wp)
+                z = *reinterpret_cast<const u32x4*>(xp + (((size_t)b * g.Hp + y0 + pr) * g.Wp + x0 + 2 * c) * 4);
+            r.xr[u] = z;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int id = tid + u * 256;
+            const int px = id >> 1, c8 = id & 1;
+            const int oy = y0 + px / SW_TW, ox = x0 + (px % SW_TW);
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if (oy < g.H && ox < g.W) z = *reinterpret_cast<const u32x4*>(dy + (((size_t)b * g.H + oy) * g.W + ox) * 16 + c8 * 8);
+            r.dr[u] = z;
+        }
+    };
+    auto lstore = [&](int buf, const Regs& r) {
+        char* xs = lds + buf * SW_STAGE;
+        char* ds = xs + SW_XBYTES;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int id = tid + u * 256;
+            if (id < XCH) *reinterpret_cast<u32x4*>(xs + id * 16) = r.xr[u];
+            *reinterpret_cast<u32x4*>(ds + id * 16) = r.dr[u];
+        }
+    };
+    f32x4 acc[7][2];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int l16 = lane & 15, gq = lane >> 4;
+    const uint32_t base = (uint32_t)(uintptr_t)lds;
+    const uint32_t d_off = (uint32_t)((4 * gq + (l16 >> 2)) * 32 + (l16 & 3) * 8);       // dy: 32-byte pixel rows
+    const uint32_t x_off = (uint32_t)((4 * gq + (l16 >> 2)) * 8 + (l16 & 3) * 8);        // image: the Toeplitz rows start 8 bytes apart
+    auto tr2 = [](uint32_t a, uint32_t second) {
+        uint64_t l, h;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l), "=&v"(h) : "v"(a), "v"(a + second) : "memory");
+        return u32x4{(uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32)};
+    };
+    auto compute = [&](int buf) {
+        const uint32_t xs = base + (uint32_t)(buf * SW_STAGE), ds = xs + SW_XBYTES;
+#pragma unroll
+        for (int rr = 0; rr < SW_TH / 4; ++rr) {
+            const int r = wave + 4 * rr;                                                  // this wave's output rows of the tile
+            const u32x4 df = tr2(ds + (uint32_t)(r * SW_TW * 32) + d_off, 16 * 32);
+#pragma unroll
+            for (int th = 0; th < 7; ++th) {
+                const uint32_t xa = xs + (uint32_t)((r + th) * SW_ROWB) + x_off;
+                const u32x4 x0 = tr2(xa, 16 * 8), x1 = tr2(xa + 32, 16 * 8);
+                mma_chunk<bf16_t>(df, x0, acc[th][0]);
+                mma_chunk<bf16_t>(df, x1, acc[th][1]);
+            }
+        }
+    };
+    Regs R;
+    if (t_begin < t_end) {
+        gload(R, t_begin);
+        lstore(0, R);
+        __syncthreads();
+        for (int t = t_begin; t < t_end; ++t) {
+            const bool more = t + 1 < t_end;
+            const int cur = (t - t_begin) & 1;
+            if (more) gload(R, t + 1);
+            compute(cur);
+            if (more) lstore(cur ^ 1, R);
+            __syncthreads();
+        }
+    }
+    // the four waves' partial blocks -> one [16][224] slab per workgroup (summed through LDS, one wave after the other)
+    float* red = reinterpret_cast<float*>(lds);                                           // [14][64 lanes][4]
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    f32x4* p = reinterpret_cast<f32x4*>(red + ((i * 2 + c) * 64 + lane) * 4);
+                    f32x4 v = acc[i][c];
+                    if (w) { const f32x4 q = *p; v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3]; }
+                    *p = v;
+                }
+        }
+        __syncthreads();
+    }
+    float* slab = g.ws + (size_t)blockIdx.x * (16 * SW_K);
+    for (int e = tid; e < 14 * 64 * 4; e += 256) {
+        const int reg = e & 3, ln = (e >> 2) & 63, blk = e >> 8;                          // blk = th * 2 + column tile
+        const int o = (ln >> 4) * 4 + reg, col = (blk >> 1) * 32 + (blk & 1) * 16 + (ln & 15);
+        slab[o * SW_K + col] = red[e];
+    }
+}
+
+__global__ void slab_sum_kernel(const float* __restrict__ ws, int nslab, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 4 <= nslab; z += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += ws[(size_t)(z + u) * n + i];
+    }
+    for (; z < nslab; ++z) a[0] += ws[(size_t)z * n + i];
+    out[i] = (a[0] + a[1]) + (a[2] + a[3]);
+}
+
+}  // namespace mfx
+
+int g_opt_stem_wgrad_blocks = 768;      // option "stem_wgrad_blocks"
+
+extern "C" int mfx_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, int B, int H, int W, int Hp, int Wp, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    if (!xp || !dy || !dw || !workspace) return mfx_fail(MFX_ERR_ARG, "stem_wgrad: null pointer");
+    if (Hp < H + 6 || Wp < W + 8 || (Wp & 1)) return mfx_fail(MFX_ERR_ARG, "stem_wgrad: the padded image must be (H+6) x (W+8), even width");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    SwGeom g;
+    g.B = B; g.H = H; g.W = W; g.Hp = Hp; g.Wp = Wp;
+    g.tiles_x = (W + SW_TW - 1) / SW_TW; g.tiles_y = (H + SW_TH - 1) / SW_TH; g.ntiles = g.tiles_x * g.tiles_y * B;
+    if (g.ntiles == 0) { MFX_HIP_CHECK(mfx::zero_async(dw, sizeof(float) * 16 * SW_K, st)); return MFX_OK; }
+    int nb = std::min(g.ntiles, std::max(1, g_opt_stem_wgrad_blocks));
+    nb = (int)std::min<size_t>((size_t)nb, workspace_bytes / (sizeof(float) * 16 * SW_K));
+    if (nb < 1) return mfx_fail(MFX_ERR_WORKSPACE, "stem_wgrad: workspace too small");
+    g.tiles_per_block = (g.ntiles + nb - 1) / nb;
+    nb = (g.ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
+    g.ws = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(256), 0, st, (const bf16_t*)xp, (const bf16_t*)dy, g);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((16 * SW_K + 255) / 256), dim3(256), 0, st, (const float*)g.ws, nb, 16 * SW_K, dw);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
 }

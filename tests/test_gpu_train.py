@@ -80,6 +80,32 @@ def test_stem_conv_wgrad():
     assert _rel(yd.permute(0, 3, 1, 2), yr) < 1e-5 and _rel(wd.grad, wr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 32, 64), (3, 37, 70), (1, 8, 32), (2, 96, 320)])
+def test_stem_conv_wgrad_bf16_toeplitz_kernel(B, H, W):
+    """mfx_stem_wgrad_bf16 (flat image rows in LDS, Toeplitz operand through transposed reads) against the generic dilated-tap
+    kernel on the same bf16 operands and against torch autograd of F.conv2d; ragged tiles included."""
+    from monoflex_amd import autograd as AG
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, 3, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(16, 3, 7, 7, generator=g) * 0.1)
+    wr = w.clone().requires_grad_()
+    yr = F.conv2d(x, wr, padding=3)
+    r = torch.randn(yr.shape, generator=g).bfloat16().float()
+    (yr * r).sum().backward()
+    got = {}
+    for generic in (False, True):
+        AG._STEM_WGRAD_GENERIC[0] = generic
+        try:
+            wd = w.to(DEV).requires_grad_()
+            yd = AG.StemConvFn.apply(x.to(DEV), wd, torch.bfloat16)
+            (yd.float() * _nhwc(r).to(DEV)).sum().backward()
+            got[generic] = wd.grad.detach().cpu()
+        finally:
+            AG._STEM_WGRAD_GENERIC[0] = False
+    assert _rel(got[False], got[True]) < 2e-3, _rel(got[False], got[True])
+    assert _rel(got[False], wr.grad) < 1.5e-2, _rel(got[False], wr.grad)
+
+
 @pytest.mark.parametrize("act,res", [("relu", False), ("relu", True), ("leaky", False), ("none", False)])
 def test_bn_act_grads(act, res):
     from monoflex_amd import autograd as AG
@@ -527,7 +553,8 @@ def test_dcn_tile_owned_backward_vs_oracle(cin, cout, H, W, off_std, dtype):
 
 @pytest.mark.parametrize("cin,cout,k,stride,H,W", [(64, 256, 3, 1, 48, 96), (64, 64, 3, 1, 40, 72), (128, 128, 3, 2, 64, 80),
                                                    (256, 256, 3, 1, 24, 80), (512, 512, 3, 1, 12, 40), (64, 192, 3, 1, 33, 47),
-                                                   (128, 27, 3, 1, 48, 96), (64, 27, 3, 1, 37, 75), (64, 64, 3, 1, 96, 40)])
+                                                   (128, 27, 3, 1, 48, 96), (64, 27, 3, 1, 37, 75), (64, 64, 3, 1, 96, 40),
+                                                   (16, 16, 3, 1, 64, 96), (32, 32, 3, 1, 48, 80), (16, 32, 3, 1, 37, 75), (32, 16, 3, 1, 41, 70)])
 def test_conv_wgrad_transposed_read_kernel_vs_torch(cin, cout, k, stride, H, W):
     """Second-generation weight-gradient kernel (wgrad_tr.hip: natural-layout LDS tiles + ds_read_b64_tr_b16, 64x64 wave
     blocks, BK = 192) against torch autograd of F.conv2d on bf16-representable operands, and against the first-generation

@@ -1,2 +1,3 @@
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_step.py -q > gpurun_out/train_tests.log 2>&1; grep -E "passed|failed|FAILED|Error" gpurun_out/train_tests.log | tail -8
+timeout 900 python -m pytest tests/test_gpu_train.py -x -q -k "stem or transposed_read" > gpurun_out/t1.log 2>&1; grep -E "passed|failed|FAILED|Error|assert" gpurun_out/t1.log | tail -8
+timeout 600 python bench.py --mode train --no-cpu-baseline --steps 10 2>&1 | tail -1 | cut -c100-330
