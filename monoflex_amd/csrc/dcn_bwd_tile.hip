@@ -24,6 +24,7 @@
 #include "common.h"
 #include "err.h"
 #include "fill.h"
+#include <algorithm>
 #include <type_traits>
 
 // train_kernels.hip: weight gradient with a dense [M][K] A operand (direct = 1), written as (Cout, Cin, kh, kw)
@@ -32,6 +33,7 @@ int mfx_internal_conv_wgrad(const void* x, const void* dy, float* dw, int B, int
                             int dtype, int oihw, int Cin_out, int Cout_out, void* stream, int dil_w,
                             void* workspace, size_t workspace_bytes, int direct);
 
+int g_opt_dcn_bt_split = 1;    // option "dcn_bt_split": 1 = grad_offset/grad_mask/columns in dcn_bwd_sample_kernel, 0 = inside the tile kernel
 int g_opt_dcn_bt_dbg = 0;      // option "dcn_bt_dbg": experiment switches of dcn_bwd_tile_kernel (0 in production)
 
 namespace mfx {
@@ -316,6 +318,108 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const T* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The per-sample half of the backward pass as its own kernel: grad_offset / grad_mask (gradient of the raw offset/mask conv
+// output) and the modulated columns for the weight-gradient GEMM.  Inside dcn_bwd_tile_kernel this phase ran at the tile
+// kernel's occupancy (three workgroups per CU: 52 KB of corner lists each) and took 400 of its 610 us on 64 -> 64 @ 96x320,
+// B = 8 -- five dependent 16-byte gathers per sample with three waves per SIMD to hide them.  Here there is no LDS, the raw
+// offset/mask values of the NEXT sample are prefetched while the current one is blended, every sample's channel slices are
+// looped inside the lane group (no atomics on the offset gradients, so no zero-fill either), and the 27 gradient channels of
+// a pixel are written whether or not the sample lies inside the image.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    u32x4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const u32x4*>(p); }
+    __device__ __forceinline__ void zero() { v = u32x4{0u, 0u, 0u, 0u}; }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const { ElemTraits<bf16_t>::unpack(v, f); }
+};
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+    __device__ __forceinline__ void zero() { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const { f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3]; }
+};
+
+template <typename T, int LPS>
+__global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const T* __restrict__ x, const float* __restrict__ om,
+                                                            const T* __restrict__ gcol, BtGeom g, int xsplit,
+                                                            float* __restrict__ graw, T* __restrict__ col) {
+    constexpr int CS = 8 * LPS, SPW = 64 / LPS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sl = lane / LPS, cl = lane % LPS;
+    const int row = blockIdx.x;                                                // (image, output row)
+    const int b = row / g.H, my = row - b * g.H;
+    const int xw = (g.W + xsplit - 1) / xsplit, x_begin = blockIdx.y * xw, x_end = min(x_begin + xw, g.W);
+    const int nsamp = (x_end - x_begin) * 9;
+    const int HW = g.H * g.W;
+    const T* xb = x + (size_t)b * HW * g.C;
+    const size_t mrow = (size_t)b * HW + (size_t)my * g.W;
+    const int nsl = g.C / CS;
+
+    struct Pre { float oh, ow, mk; };
+    auto prefetch = [&](int j) {
+        Pre p = {0.f, 0.f, 0.f};
+        if (j < nsamp) {
+            const int px = j / 9, tap = j - px * 9;
+            const float* r = om + (mrow + x_begin + px) * 32;
+            p.oh = r[2 * tap]; p.ow = r[2 * tap + 1]; p.mk = r[18 + tap];
+        }
+        return p;
+    };
+    int j = wv * SPW + sl;
+    Pre cur = prefetch(j);
+    for (int base = wv * SPW; base < nsamp; base += 4 * SPW, j += 4 * SPW) {
+        const Pre nxt = prefetch(j + 4 * SPW);
+        const bool ok = j < nsamp;
+        const int px = j / 9, tap = j - px * 9, mx = x_begin + px;
+        const int th = (tap * 11) >> 5, tw = tap - th * 3;
+        const float h = (float)(my - 1 + th) + cur.oh, w = (float)(mx - 1 + tw) + cur.ow;
+        const bool inside = ok && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
+        const float hf = floorf(h), wf = floorf(w);
+        const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw, mask = cur.mk;
+        const int h0 = (int)fminf(fmaxf(hf, -4.f), 32000.f), w0 = (int)fminf(fmaxf(wf, -4.f), 32000.f);
+        const size_t m = mrow + mx;
+        float gh = 0.f, gw = 0.f, gm = 0.f;
+        for (int s = 0; s < nsl; ++s) {
+            const int c0 = s * CS + cl * 8;
+            Raw8<T> rg, rv[4];
+            if (inside) {
+                rg.load(gcol + m * g.Kp + tap * g.C + c0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int hc = h0 + (c >> 1), wc = w0 + (c & 1);
+                    if (hc >= 0 && hc < g.H && wc >= 0 && wc < g.W) rv[c].load(xb + ((size_t)hc * g.W + wc) * g.C + c0);
+                    else rv[c].zero();
+                }
+            }
+            float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (inside) {
+                float gc[8], v0[8], v1[8], v2[8], v3[8];
+                rg.unpack(gc); rv[0].unpack(v0); rv[1].unpack(v1); rv[2].unpack(v2); rv[3].unpack(v3);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    // top / bottom row blends share the horizontal differences (dmcn_get_coordinate_weight, dcn_v2_im2col_cuda.cu:82-122)
+                    const float d10 = v1[k] - v0[k], d32 = v3[k] - v2[k];
+                    const float top = v0[k] + lw * d10, bot = v2[k] + lw * d32;
+                    const float dh = bot - top, val = top + lh * dh, dw = d10 + lh * (d32 - d10);
+                    cv[k] = mask * val;
+                    gm += gc[k] * val; gh += gc[k] * dh; gw += gc[k] * dw;
+                }
+            }
+            if (ok) bt_store8<T>(col + m * g.Kp + tap * g.C + c0, cv);
+        }
+        gh = bt_group_sum<LPS>(gh); gw = bt_group_sum<LPS>(gw); gm = bt_group_sum<LPS>(gm);
+        if (cl == 0 && ok) {
+            float* o = graw + m * 32;
+            o[2 * tap] = gh * mask; o[2 * tap + 1] = gw * mask; o[18 + tap] = gm * mask * (1.f - mask);   // through the sigmoid of the mask logit
+            if (tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
+        }
+        cur = nxt;
+    }
+}
+
 // far corners (rare: offsets beyond the 8-pixel ring, or an over-full tile list): entry = (sample m, corner pixel, tap,
 // weight, first channel of the slice); 8 lanes per entry x 8 channels per lane per pass, fp32 atomics on the side buffer
 template <typename T>
@@ -410,7 +514,8 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
         const long total = (long)K * Cout;
         hipLaunchKernelGGL(bt_pack_weight_t<T>, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, weight, wT, Cout, C);
     }
-    MFX_HIP_CHECK(mfx::zero_async(d_raw, (size_t)M * 32 * 4, st));
+    const bool split = g_opt_dcn_bt_split != 0;                // per-sample half in its own kernel (writes every d_raw channel itself)
+    if (!split) MFX_HIP_CHECK(mfx::zero_async(d_raw, (size_t)M * 32 * 4, st));
     MFX_HIP_CHECK(mfx::zero_async(dx_far, (size_t)M * C * 4, st));
     MFX_HIP_CHECK(mfx::zero_async(cnt, 8, st));
     // d(columns)[m][k] = sum_o dy[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM on the matrix cores
@@ -423,7 +528,13 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     if (rc) return rc;
     BtGeom g;
     g.B = B; g.H = H; g.W = W; g.C = C; g.tiles_x = (W + BT_TW - 1) / BT_TW; g.tiles_y = (H + BT_TH - 1) / BT_TH; g.Kp = K;
-    g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg;
+    g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg | (split ? 8 : 0);
+    if (split) {
+        const int rows = B * H, xsplit = std::max(1, std::min(W / 16, (2048 + rows - 1) / rows));
+        const dim3 sgrid((unsigned)rows, (unsigned)xsplit);
+        if (g.CS == 64) hipLaunchKernelGGL((dcn_bwd_sample_kernel<T, 8>), sgrid, dim3(256), 0, st, x, offmask, (const T*)gcol, g, xsplit, d_raw, col);
+        else hipLaunchKernelGGL((dcn_bwd_sample_kernel<T, 16>), sgrid, dim3(256), 0, st, x, offmask, (const T*)gcol, g, xsplit, d_raw, col);
+    }
     const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * B), (unsigned)g.nslices);
     const size_t smem = (size_t)BT_NPIX * BT_LCAP * 8 + (size_t)BT_NPIX * 4 + (size_t)BT_FCAP * 8;
     if (g.CS == 64) {
