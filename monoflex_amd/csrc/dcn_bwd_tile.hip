@@ -4,22 +4,22 @@
 //
 // The first generation (dcn_bwd.hip) scattered every (pixel, tap) sample's four corners into grad_input with global fp32
 // atomics -- 36 atomic bursts per input element, 2.5 ms for one 64->64 @ 96x320 layer at B=8, 100x its HBM floor -- and
-// re-sampled the columns a second time on the vector ALUs for grad_weight.  Here the INPUT gradient is owned by tiles:
+// re-sampled the columns a second time on the vector ALUs for grad_weight.  Here (launch order):
 //
-//   * one workgroup owns an 8 x 16 tile of grad_input pixels (x a slice of <= 128 channels) and accumulates it in LDS
-//     (ds_add_f32, lanes = consecutive channels: conflict-free), then writes it ONCE with plain coalesced stores in the
-//     activation dtype -- no global atomics, no fp32 grad_input buffer, no zero-fill, no narrowing pass;
-//   * contributions come from the tile's own samples (phase S) and from the samples of the surrounding D = 8 pixel ring
-//     whose corners fall into the tile (phase A): the ring's sampling geometry is evaluated lane-parallel (one lane per
-//     (pixel, tap)), hits are compacted into an LDS work list, and only hits re-read their d(columns) row;
-//   * a corner further than D pixels from its sample's tile ("far": offsets beyond ~8 px) is added to an fp32 side buffer
-//     with global atomics and merged afterwards (dcn_bwd_far_merge_kernel, skipped when no far corner occurred), so every
-//     offset stays exact: a corner (sample m, pixel p) is handled by the owner of tile(p) iff m lies in tile(p) grown by D,
-//     and by the side buffer otherwise -- exactly once;
-//   * phase S also produces grad_offset / grad_mask (wave reduction over channels; the sigmoid derivative of the mask logit
-//     is folded in, so the result is the gradient of the raw 27-channel offset/mask conv output) and writes the modulated
-//     columns col[m][tap*C + c] in the activation dtype, which turns grad_weight into a plain MFMA GEMM
-//     (conv_wgrad_mfma_kernel, "direct" operand mode) instead of a second VALU re-sampling pass.
+//   1. d(columns) = dy x W^T as a 1x1 implicit GEMM on the matrix cores (gcol, activation dtype);
+//   2. dcn_bwd_sample_kernel: one lane group per (pixel, tap) sample blends the four corners once and produces grad_offset /
+//      grad_mask (the sigmoid derivative of the mask logit folded in: the gradient of the raw 27-channel offset/mask conv
+//      output) and the modulated columns col[m][tap*C + c], which turn grad_weight into a plain MFMA GEMM (step 5);
+//   3. dcn_bwd_tile_kernel: the INPUT gradient is owned by tiles.  One workgroup owns an 8 x 16 tile of grad_input pixels
+//      (x a slice of <= 128 channels).  Phase 1 walks the samples of the tile grown by D = 8 pixels and BINS every
+//      (sample, corner) pair that lands in the tile into that pixel's LDS list (one integer LDS atomic per pair); phase 3
+//      lets each pixel's lane group walk its list, gather the d(columns) rows, accumulate in registers and store the pixel
+//      ONCE in the activation dtype -- no global atomics, no fp32 grad_input buffer, no zero-fill, no narrowing pass;
+//   4. dcn_bwd_far_kernel: a corner further than D pixels from its sample's tile ("far": offsets beyond ~8 px), or one that
+//      found its pixel's list full, was appended to a global list instead; those are added into the finished grad_input with
+//      atomics, so every offset stays exact: a corner (sample m, pixel p) is handled by the owner of tile(p) iff m lies in
+//      tile(p) grown by D, and by the far list otherwise -- exactly once;
+//   5. grad_weight = dy^T x col (conv_wgrad_mfma_kernel, "direct" operand mode), grad_bias = column sums of dy.
 #include "../../include/monoflex_hip.h"
 #include "common.h"
 #include "err.h"
@@ -33,14 +33,12 @@ int mfx_internal_conv_wgrad(const void* x, const void* dy, float* dw, int B, int
                             int dtype, int oihw, int Cin_out, int Cout_out, void* stream, int dil_w,
                             void* workspace, size_t workspace_bytes, int direct);
 
-int g_opt_dcn_bt_split = 1;    // option "dcn_bt_split": 1 = grad_offset/grad_mask/columns in dcn_bwd_sample_kernel, 0 = inside the tile kernel
 int g_opt_dcn_bt_dbg = 0;      // option "dcn_bt_dbg": experiment switches of dcn_bwd_tile_kernel (0 in production)
 
 namespace mfx {
 
 constexpr int BT_TH = 8, BT_TW = 16, BT_D = 8, BT_NPIX = BT_TH * BT_TW;
-constexpr int BT_LCAP = 47, BT_FCAP = 512;   // BT_FCAP: far corners staged per workgroup before one global reservation
-            // list entries per target pixel (mean 36 = 9 taps x 4 corners); overflow takes the exact far path
+constexpr int BT_FCAP = 512;   // far corners staged per workgroup before one global reservation
 constexpr int BT_CH = BT_TH + 2 * BT_D, BT_CW = BT_TW + 2 * BT_D;        // candidate window (24 x 32 pixels)
 
 struct BtGeom { int B, H, W, C, tiles_x, tiles_y, Kp, CS, nslices, dbg; };
@@ -108,29 +106,52 @@ template <> __device__ __forceinline__ void bt_store4<bf16_t>(bf16_t* p, const f
 // adds of this layer).  So the tile is not accumulated by atomics at all: phase 1 BINS every (sample, corner) pair that
 // lands in the tile into a per-pixel list (one integer LDS atomic per pair, 64x fewer than per channel), and phase 3 lets
 // each target pixel's lane group walk its list and accumulate in registers.
+// List entries.  fp32 maps keep (sample, fp32 weight) pairs: 8 bytes, 47 per pixel in the 48 KB that leave three workgroups
+// per CU.  bf16 maps pack the sample as window coordinates (5 + 5 bits) + tap (4) and the weight's exponent and top ten
+// mantissa bits (18 bits, the weight is non-negative; 2^-11 relative, below the bf16 operands it multiplies) into 4 bytes:
+// 94 per pixel, so a list practically never overflows (mean 36 entries, sigma ~6) and the far path is left to far offsets.
+template <typename T> struct BtEntry;
+template <> struct BtEntry<float> {
+    typedef uint2 type;
+    static constexpr int LCAP = 47;
+    static __device__ __forceinline__ uint2 make(int wy, int wx, int tap, float w) { return uint2{((uint32_t)wy << 16) | ((uint32_t)wx << 4) | (uint32_t)tap, __float_as_uint(w)}; }
+    static __device__ __forceinline__ void read(const uint2& e, int& wy, int& wx, int& tap, float& w) {
+        wy = (int)(e.x >> 16); wx = (int)((e.x >> 4) & 0xfff); tap = (int)(e.x & 15); w = __uint_as_float(e.y);
+    }
+};
+template <> struct BtEntry<bf16_t> {
+    typedef uint32_t type;
+    static constexpr int LCAP = 94;
+    static __device__ __forceinline__ uint32_t make(int wy, int wx, int tap, float w) {
+        return ((uint32_t)wy << 27) | ((uint32_t)wx << 22) | ((uint32_t)tap << 18) | (((__float_as_uint(w) + 0x1000u) >> 13) & 0x3ffffu);
+    }
+    static __device__ __forceinline__ void read(uint32_t e, int& wy, int& wx, int& tap, float& w) {
+        wy = (int)(e >> 27); wx = (int)((e >> 22) & 31); tap = (int)((e >> 18) & 15); w = __uint_as_float((e & 0x3ffffu) << 13);
+    }
+};
+
 template <typename T, int LPS>
-__global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const T* __restrict__ x, const float* __restrict__ om,
-                                                          const T* __restrict__ gcol, BtGeom g, T* __restrict__ dx,
-                                                          float* __restrict__ dx_far, int* __restrict__ far_count,
-                                                          u32x4* __restrict__ far_list, int far_cap,
-                                                          float* __restrict__ graw, T* __restrict__ col) {
-    constexpr int CS = 8 * LPS, SPW = 64 / LPS;
+__global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const float* __restrict__ om, const T* __restrict__ gcol, BtGeom g,
+                                                          T* __restrict__ dx, int* __restrict__ far_count,
+                                                          u32x4* __restrict__ far_list, int far_cap) {
+    using EN = BtEntry<T>;
+    typedef typename EN::type entry_t;
+    constexpr int CS = 8 * LPS, SPW = 64 / LPS, LCAP = EN::LCAP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint2* lists = reinterpret_cast<uint2*>(smem);                             // [BT_NPIX][BT_LCAP] (sample id, weight bits)
-    int* counts = reinterpret_cast<int*>(smem + BT_NPIX * BT_LCAP * 8);        // [BT_NPIX]
-    uint2* fstage = reinterpret_cast<uint2*>(smem + BT_NPIX * BT_LCAP * 8 + BT_NPIX * 4);   // [BT_FCAP] (sample id | corner << 28, weight)
+    entry_t* lists = reinterpret_cast<entry_t*>(smem);                         // [BT_NPIX][LCAP]
+    int* counts = reinterpret_cast<int*>(smem + BT_NPIX * LCAP * sizeof(entry_t));     // [BT_NPIX]
+    uint2* fstage = reinterpret_cast<uint2*>(smem + BT_NPIX * LCAP * sizeof(entry_t) + BT_NPIX * 4);   // [BT_FCAP] (sample | corner << 28, weight)
     __shared__ int fcount, fbase;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sl = lane / LPS, cl = lane % LPS;                               // sample / pixel slot in the wave, 8-channel group
+    const int sl = lane / LPS, cl = lane % LPS;                               // pixel slot in the wave, 8-channel group
     int tile = blockIdx.x;
     const int tx = tile % g.tiles_x; tile /= g.tiles_x;
     const int ty = tile % g.tiles_y; const int b = tile / g.tiles_y;
     const int ty0 = ty * BT_TH, tx0 = tx * BT_TW;
     const int cs0 = blockIdx.y * CS, c0 = cs0 + cl * 8;                        // slice start, this lane's first channel
     const int HW = g.H * g.W;
-    const T* xb = x + (size_t)b * HW * g.C;
     const long mb = (long)b * HW;                                              // first sample index of image b
 
     for (int i = tid; i < BT_NPIX; i += 256) counts[i] = 0;
@@ -139,15 +160,15 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const T* __restrict__
 
     // a corner that cannot go through the tile lists (far from its sample's tile, or a full list) is staged in LDS and, after
     // phase 1, appended to a global list with ONE counter reservation per workgroup (a per-corner atomic on the single global
-    // counter serialised at ~12 ns each: +1 ms at 10 % far corners); dcn_bwd_far_kernel scatters that list into the fp32 side
-    // buffer with 8 lanes per entry.  If a stage or the global list is full, the lane walks the slice's channels itself.
+    // counter serialised at ~12 ns each: +1 ms at 10 % far corners); dcn_bwd_far_kernel adds that list into dx afterwards.
+    // A full stage reserves list slots one by one; the list holds every (sample, corner) pair of the map, so it cannot fill.
+    auto far_entry = [&](int slot, size_t m, int tap, int hc, int wc, uint32_t wbits) {
+        if (slot < far_cap) far_list[slot] = u32x4{(uint32_t)m, ((uint32_t)hc << 16) | ((uint32_t)wc << 4) | (uint32_t)tap, wbits, (uint32_t)cs0};
+    };
     auto to_far = [&](size_t m, int my, int mx, int tap, int q, int hc, int wc, float w) {
         const int fs = atomicAdd(&fcount, 1);
-        if (fs < BT_FCAP) { fstage[fs] = uint2{((uint32_t)q << 28) | ((uint32_t)my << 16) | ((uint32_t)mx << 4) | (uint32_t)tap, __float_as_uint(w)}; return; }
-        const T* gp = gcol + m * g.Kp + tap * g.C + cs0;
-        float* f = dx_far + ((size_t)b * HW + (size_t)hc * g.W + wc) * g.C + cs0;
-        for (int c = 0; c < CS; ++c) unsafeAtomicAdd(f + c, w * ElemTraits<T>::load(gp + c));
-        if (fs == BT_FCAP) atomicAdd(far_count + 1, 1);                       // "side buffer touched" flag for the merge pass
+        if (fs < BT_FCAP) fstage[fs] = uint2{((uint32_t)q << 28) | ((uint32_t)my << 16) | ((uint32_t)mx << 4) | (uint32_t)tap, __float_as_uint(w)};
+        else far_entry(atomicAdd(far_count, 1), m, tap, hc, wc, __float_as_uint(w));
     };
 
     // ---------------- phase 1: bin the (sample, corner) pairs of the candidate window by target pixel ----------------
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const T* __restrict__
                 if (ly >= 0 && ly < BT_TH && lx >= 0 && lx < BT_TW) {
                     const int p = ly * BT_TW + lx;
                     const int slot = atomicAdd(&counts[p], 1);
-                    if (slot < BT_LCAP) lists[p * BT_LCAP + slot] = uint2{((uint32_t)my << 16) | ((uint32_t)mx << 4) | (uint32_t)tap, __float_as_uint(wq)};
+                    if (slot < LCAP) lists[p * LCAP + slot] = EN::make(wy, wx, tap, wq);
                     else to_far(m, my, mx, tap, q, hc, wc, wq);               // list full: exact fallback
                 } else if (own) {
                     const int cty0 = (hc / BT_TH) * BT_TH, ctx0 = (wc / BT_TW) * BT_TW;
@@ -208,77 +229,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const T* __restrict__
                 const int q = (int)(en.x >> 28), emy = (int)((en.x >> 16) & 0xfff), emx = (int)((en.x >> 4) & 0xfff), etap = (int)(en.x & 15);
                 const size_t m = (size_t)(mb + (long)emy * g.W + emx);
                 const SampGeo sg = samp_geo(g, om + m * 32, emy, emx, etap);
-                const int hc = sg.h0 + (q >> 1), wc = sg.w0 + (q & 1);
-                const int slot = fbase + i;
-                if (slot < far_cap) far_list[slot] = u32x4{(uint32_t)m, ((uint32_t)hc << 16) | ((uint32_t)wc << 4) | (uint32_t)etap, en.y, (uint32_t)cs0};
-                else {
-                    const T* gp = gcol + m * g.Kp + etap * g.C + cs0;
-                    float* f = dx_far + ((size_t)b * HW + (size_t)hc * g.W + wc) * g.C + cs0;
-                    const float w = __uint_as_float(en.y);
-                    for (int c = 0; c < CS; ++c) unsafeAtomicAdd(f + c, w * ElemTraits<T>::load(gp + c));
-                }
+                far_entry(fbase + i, m, etap, sg.h0 + (q >> 1), sg.w0 + (q & 1), en.y);
             }
-        }
-    }
-
-    // ---------------- phase 2: the tile's own samples: grad_offset / grad_mask and the modulated columns ----------------
-    // two batches of SPW samples per iteration: all ten 16-byte loads of a lane are issued before the first is consumed
-    // (one batch at a time left this phase latency-bound: 380 us of the 650 us of the kernel on 64 -> 64 @ 96x320, B=8)
-    constexpr int NS = BT_NPIX * 9;
-    struct Samp { int tap, my, mx; bool ok; size_t m; SampGeo sg; float gc[8], v[4][8]; };
-    auto s_load = [&](Samp& q, int s) {
-        const int lp = s / 9;
-        q.tap = s - lp * 9; q.my = ty0 + lp / BT_TW; q.mx = tx0 + (lp % BT_TW);
-        q.ok = s < NS && q.my < g.H && q.mx < g.W;
-        q.m = (size_t)(mb + (long)q.my * g.W + q.mx);
-        q.sg = SampGeo{0, 0, 0.f, 0.f, 0.f, 0};
-        if (q.ok) q.sg = samp_geo(g, om + q.m * 32, q.my, q.mx, q.tap);
-        if (q.ok && q.sg.inside) {
-            bt_load8<T>(gcol + q.m * g.Kp + q.tap * g.C + c0, q.gc);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int hc = q.sg.h0 + (c >> 1), wc = q.sg.w0 + (c & 1);
-                if (hc >= 0 && hc < g.H && wc >= 0 && wc < g.W) bt_load8<T>(xb + ((size_t)hc * g.W + wc) * g.C + c0, q.v[c]);
-                else {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) q.v[c][k] = 0.f;
-                }
-            }
-        }
-    };
-    auto s_finish = [&](const Samp& q) {
-        float gh = 0.f, gw = 0.f, gm = 0.f;
-        if (q.ok) {
-            float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (q.sg.inside) {
-                const float lh = q.sg.lh, lw = q.sg.lw, hh = 1.f - lh, hw = 1.f - lw, mask = q.sg.mask;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float val = hh * hw * q.v[0][k] + hh * lw * q.v[1][k] + lh * hw * q.v[2][k] + lh * lw * q.v[3][k];
-                    cv[k] = mask * val;
-                    gm += q.gc[k] * val;
-                    // dmcn_get_coordinate_weight (dcn_v2_im2col_cuda.cu:82-122)
-                    gh += (-hw * q.v[0][k] - lw * q.v[1][k] + hw * q.v[2][k] + lw * q.v[3][k]) * q.gc[k] * mask;
-                    gw += (-hh * q.v[0][k] + hh * q.v[1][k] - lh * q.v[2][k] + lh * q.v[3][k]) * q.gc[k] * mask;
-                }
-            }
-            bt_store8<T>(col + q.m * g.Kp + q.tap * g.C + c0, cv);
-        }
-        gh = bt_group_sum<LPS>(gh); gw = bt_group_sum<LPS>(gw); gm = bt_group_sum<LPS>(gm);
-        if (cl == 0 && q.ok && q.sg.inside) {
-            float* o = graw + q.m * 32;
-            const float gmr = gm * q.sg.mask * (1.f - q.sg.mask);              // through the sigmoid of the mask logit
-            if (g.nslices == 1) { o[2 * q.tap] = gh; o[2 * q.tap + 1] = gw; o[18 + q.tap] = gmr; }
-            else { unsafeAtomicAdd(o + 2 * q.tap, gh); unsafeAtomicAdd(o + 2 * q.tap + 1, gw); unsafeAtomicAdd(o + 18 + q.tap, gmr); }
-        }
-    };
-    if (!(g.dbg & 8)) {
-        for (int base = wv * SPW; base < NS; base += 8 * SPW) {
-            Samp q0, q1;
-            s_load(q0, base + sl);
-            s_load(q1, base + 4 * SPW + sl);
-            s_finish(q0);
-            s_finish(q1);
         }
     }
 
@@ -286,35 +238,85 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const T* __restrict__
     for (int p = wv * SPW + sl; p < ((g.dbg & 1) ? 0 : BT_NPIX); p += 4 * SPW) {
         const int y = ty0 + p / BT_TW, xx = tx0 + (p % BT_TW);
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int n = min(counts[p], BT_LCAP);
-        const uint2* lp = lists + p * BT_LCAP;
+        const int n = min(counts[p], LCAP);
+        const entry_t* lp = lists + p * LCAP;
+        auto row = [&](const entry_t& en, float& w) {
+            int wy, wx, tap;
+            EN::read(en, wy, wx, tap, w);
+            const size_t m = (size_t)(mb + (long)(ty0 - BT_D + wy) * g.W + (tx0 - BT_D + wx));
+            return gcol + m * g.Kp + tap * g.C + c0;
+        };
         int e = 0;
         for (; e + 4 <= n; e += 4) {                                          // four rows in flight per lane group
-            uint2 en[4]; float gq[4][8];
+            entry_t en[4]; float gq[4][8], w[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) en[u] = lp[e + u];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const size_t m = (size_t)(mb + (long)(en[u].x >> 16) * g.W + ((en[u].x >> 4) & 0xfff));
-                bt_load8<T>(gcol + m * g.Kp + (en[u].x & 15) * g.C + c0, gq[u]);
-            }
+            for (int u = 0; u < 4; ++u) bt_load8<T>(row(en[u], w[u]), gq[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float w = __uint_as_float(en[u].y);
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) a[k] += w * gq[u][k];
-            }
+                for (int k = 0; k < 8; ++k) a[k] += w[u] * gq[u][k];
         }
         for (; e < n; ++e) {
-            const uint2 en = lp[e];
-            const size_t m = (size_t)(mb + (long)(en.x >> 16) * g.W + ((en.x >> 4) & 0xfff));
-            float gq[8];
-            bt_load8<T>(gcol + m * g.Kp + (en.x & 15) * g.C + c0, gq);
-            const float w = __uint_as_float(en.y);
+            float gq[8], w;
+            bt_load8<T>(row(lp[e], w), gq);
 #pragma unroll
             for (int k = 0; k < 8; ++k) a[k] += w * gq[k];
         }
         if (y < g.H && xx < g.W) bt_store8<T>(dx + ((size_t)b * HW + (size_t)y * g.W + xx) * g.C + c0, a);
+    }
+}
+
+// far corners (rare: offsets beyond the 8-pixel ring, or an over-full tile list): entry = (sample m, corner pixel, tap,
+// weight, first channel of the slice); 8 lanes per entry x 8 channels per lane per pass, added into the finished dx with
+// atomics (fp32 atomics, or packed bf16 atomics: each add rounds to bf16, which the few far contributions of a pixel can afford)
+__device__ __forceinline__ void bt_atomic_add8(float* p, const float (&v)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) unsafeAtomicAdd(p + k, v[k]);
+}
+__device__ __forceinline__ void bt_atomic_add8(bf16_t* p, const float (&v)[8]) {
+    typedef short s2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const bf16x2 t = __builtin_convertvector((f32x2){v[k], v[k + 1]}, bf16x2);
+        __builtin_amdgcn_global_atomic_fadd_v2bf16((s2_t __attribute__((address_space(1)))*)(p + k), __builtin_bit_cast(s2_t, t));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_bwd_far_kernel(const T* __restrict__ gcol, const u32x4* __restrict__ far_list,
+                                                         const int* __restrict__ far_count, int far_cap, BtGeom g,
+                                                         T* __restrict__ dx) {
+    const int n = min(*far_count, far_cap);
+    const int HW = g.H * g.W, cl = threadIdx.x & 7;
+    for (long e = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 3; e < n; e += ((long)gridDim.x * blockDim.x) >> 3) {
+        const u32x4 en = far_list[e];
+        const size_t m = en.x;
+        const int hc = (int)(en.y >> 16), wc = (int)((en.y >> 4) & 0xfff), tap = (int)(en.y & 15), cs0 = (int)en.w;
+        const float w = __uint_as_float(en.z);
+        const size_t bimg = m / HW;
+        const T* gp = gcol + m * g.Kp + tap * g.C + cs0;
+        T* f = dx + (bimg * HW + (size_t)hc * g.W + wc) * g.C + cs0;
+        for (int c = cl * 8; c < g.CS; c += 64) {
+            float gq[8];
+            bt_load8<T>(gp + c, gq);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gq[k] *= w;
+            bt_atomic_add8(f + c, gq);
+        }
+    }
+}
+
+// weight (Cout,C,9) fp32 -> wT[K][Cout] (k = tap*C + c), compute dtype: the B operand of d(columns) = dy x W
+template <typename T>
+__global__ void bt_pack_weight_t(const float* __restrict__ w, T* __restrict__ wT, int Cout, int C) {
+    const long total = (long)9 * C * Cout;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % Cout);
+        const int k = (int)(i / Cout);
+        const int tap = k / C, c = k - tap * C;
+        ElemTraits<T>::store(wT + i, w[((size_t)o * C + c) * 9 + tap]);
     }
 }
 
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const T* __restrict
         const float h = (float)(my - 1 + th) + cur.oh, w = (float)(mx - 1 + tw) + cur.ow;
         const bool inside = ok && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
         const float hf = floorf(h), wf = floorf(w);
-        const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw, mask = cur.mk;
+        const float lh = h - hf, lw = w - wf, mask = cur.mk;
         const int h0 = (int)fminf(fmaxf(hf, -4.f), 32000.f), w0 = (int)fminf(fmaxf(wf, -4.f), 32000.f);
         const size_t m = mrow + mx;
         float gh = 0.f, gw = 0.f, gm = 0.f;
@@ -420,74 +422,17 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const T* __restrict
     }
 }
 
-// far corners (rare: offsets beyond the 8-pixel ring, or an over-full tile list): entry = (sample m, corner pixel, tap,
-// weight, first channel of the slice); 8 lanes per entry x 8 channels per lane per pass, fp32 atomics on the side buffer
-template <typename T>
-__global__ __launch_bounds__(256) void dcn_bwd_far_kernel(const T* __restrict__ gcol, const u32x4* __restrict__ far_list,
-                                                         const int* __restrict__ far_count, int far_cap, BtGeom g,
-                                                         float* __restrict__ dx_far) {
-    const int n = min(*far_count, far_cap);
-    const int HW = g.H * g.W, cl = threadIdx.x & 7;
-    for (long e = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 3; e < n; e += ((long)gridDim.x * blockDim.x) >> 3) {
-        const u32x4 en = far_list[e];
-        const size_t m = en.x;
-        const int hc = (int)(en.y >> 16), wc = (int)((en.y >> 4) & 0xfff), tap = (int)(en.y & 15), cs0 = (int)en.w;
-        const float w = __uint_as_float(en.z);
-        const size_t bimg = m / HW;
-        const T* gp = gcol + m * g.Kp + tap * g.C + cs0;
-        float* f = dx_far + (bimg * HW + (size_t)hc * g.W + wc) * g.C + cs0;
-        for (int c = cl * 8; c < g.CS; c += 64) {
-            float gq[8];
-            bt_load8<T>(gp + c, gq);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) unsafeAtomicAdd(f + c + k, w * gq[k]);
-        }
-    }
-}
-
-// dx += dx_far where far corners occurred; nothing to do otherwise
-template <typename T>
-__global__ void dcn_bwd_far_merge_kernel(T* __restrict__ dx, const float* __restrict__ dx_far, const int* __restrict__ far_count, long n4) {
-    if (far_count[0] == 0 && far_count[1] == 0) return;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const f32x4 f = *reinterpret_cast<const f32x4*>(dx_far + i * 4);
-        if (f[0] == 0.f && f[1] == 0.f && f[2] == 0.f && f[3] == 0.f) continue;
-        f32x4 v;
-        if constexpr (std::is_same<T, float>::value) {
-            v = *reinterpret_cast<const f32x4*>(dx + i * 4);
-        } else {
-            const uint2 t = *reinterpret_cast<const uint2*>(dx + i * 4);
-            v = f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
-        }
-        v[0] += f[0]; v[1] += f[1]; v[2] += f[2]; v[3] += f[3];
-        bt_store4<T>(dx + i * 4, v);
-    }
-}
-
-// weight (Cout,C,9) fp32 -> wT[K][Cout] (k = tap*C + c), compute dtype: the B operand of d(columns) = dy x W
-template <typename T>
-__global__ void bt_pack_weight_t(const float* __restrict__ w, T* __restrict__ wT, int Cout, int C) {
-    const long total = (long)9 * C * Cout;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int o = (int)(i % Cout);
-        const int k = (int)(i / Cout);
-        const int tap = k / C, c = k - tap * C;
-        ElemTraits<T>::store(wT + i, w[((size_t)o * C + c) * 9 + tap]);
-    }
-}
-
 static inline size_t bt_al(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct BtLayout { size_t wT, gcol, col, far, cnt, flist, wg, total; long far_cap; };
+struct BtLayout { size_t wT, gcol, col, cnt, flist, wg, total; long far_cap; };
 static BtLayout bt_layout(int B, int C, int H, int W, int Cout, int es) {
     BtLayout L; size_t o = 0;
     const size_t M = (size_t)B * H * W, K = (size_t)9 * C;
     L.wT = o;   o += bt_al(K * Cout * es);
     L.gcol = o; o += bt_al(M * K * es);
     L.col = o;  o += bt_al(M * K * es);
-    L.far = o;  o += bt_al(M * C * 4);
     L.cnt = o;  o += 256;
-    L.far_cap = (long)M * 9;                                  // one far corner per sample on average before the serial fallback
+    L.far_cap = (long)M * 36 * (C >= 128 ? C / 128 : 1);      // every (sample, corner) pair of every channel slice: the list cannot fill
     L.flist = o; o += bt_al((size_t)L.far_cap * 16);
     L.wg = o;   o += bt_al((size_t)24 * 1024 * 1024);         // partial tiles of the MFMA weight-gradient slabs
     L.total = o;
@@ -505,8 +450,9 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char* ws = reinterpret_cast<char*>(workspace);
     T* wT = (T*)(ws + L.wT); T* gcol = (T*)(ws + L.gcol); T* col = (T*)(ws + L.col);
-    float* dx_far = (float*)(ws + L.far); int* cnt = (int*)(ws + L.cnt);
+    int* cnt = (int*)(ws + L.cnt);
     u32x4* flist = (u32x4*)(ws + L.flist);
+    if (L.far_cap >= (1L << 31)) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_backward_v2: map too large for the far-corner list");
     const int far_cap = (int)L.far_cap;
     const long M = (long)B * H * W;
     const int K = 9 * C;
@@ -514,9 +460,6 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
         const long total = (long)K * Cout;
         hipLaunchKernelGGL(bt_pack_weight_t<T>, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, weight, wT, Cout, C);
     }
-    const bool split = g_opt_dcn_bt_split != 0;                // per-sample half in its own kernel (writes every d_raw channel itself)
-    if (!split) MFX_HIP_CHECK(mfx::zero_async(d_raw, (size_t)M * 32 * 4, st));
-    MFX_HIP_CHECK(mfx::zero_async(dx_far, (size_t)M * C * 4, st));
     MFX_HIP_CHECK(mfx::zero_async(cnt, 8, st));
     // d(columns)[m][k] = sum_o dy[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM on the matrix cores
     mfx_conv_desc cd = {};
@@ -528,26 +471,18 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     if (rc) return rc;
     BtGeom g;
     g.B = B; g.H = H; g.W = W; g.C = C; g.tiles_x = (W + BT_TW - 1) / BT_TW; g.tiles_y = (H + BT_TH - 1) / BT_TH; g.Kp = K;
-    g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg | (split ? 8 : 0);
-    if (split) {
+    g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg;
+    {   // grad_offset / grad_mask and the modulated columns: one lane group per (pixel, tap), every d_raw channel written
         const int rows = B * H, xsplit = std::max(1, std::min(W / 16, (2048 + rows - 1) / rows));
         const dim3 sgrid((unsigned)rows, (unsigned)xsplit);
         if (g.CS == 64) hipLaunchKernelGGL((dcn_bwd_sample_kernel<T, 8>), sgrid, dim3(256), 0, st, x, offmask, (const T*)gcol, g, xsplit, d_raw, col);
         else hipLaunchKernelGGL((dcn_bwd_sample_kernel<T, 16>), sgrid, dim3(256), 0, st, x, offmask, (const T*)gcol, g, xsplit, d_raw, col);
     }
     const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * B), (unsigned)g.nslices);
-    const size_t smem = (size_t)BT_NPIX * BT_LCAP * 8 + (size_t)BT_NPIX * 4 + (size_t)BT_FCAP * 8;
-    if (g.CS == 64) {
-        hipLaunchKernelGGL((dcn_bwd_tile_kernel<T, 8>), grid, dim3(256), smem, st, x, offmask, (const T*)gcol, g, dx, dx_far, cnt, flist, far_cap, d_raw, col);
-    } else {
-        auto k = dcn_bwd_tile_kernel<T, 16>;
-        hipLaunchKernelGGL(k, grid, dim3(256), smem, st, x, offmask, (const T*)gcol, g, dx, dx_far, cnt, flist, far_cap, d_raw, col);
-    }
-    hipLaunchKernelGGL(dcn_bwd_far_kernel<T>, dim3(1024), dim3(256), 0, st, (const T*)gcol, (const u32x4*)flist, (const int*)cnt, far_cap, g, dx_far);
-    {
-        const long n4 = M * C / 4;
-        hipLaunchKernelGGL(dcn_bwd_far_merge_kernel<T>, dim3((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0, st, dx, (const float*)dx_far, (const int*)cnt, n4);
-    }
+    const size_t smem = (size_t)BT_NPIX * BtEntry<T>::LCAP * sizeof(typename BtEntry<T>::type) + (size_t)BT_NPIX * 4 + (size_t)BT_FCAP * 8;
+    if (g.CS == 64) hipLaunchKernelGGL((dcn_bwd_tile_kernel<T, 8>), grid, dim3(256), smem, st, offmask, (const T*)gcol, g, dx, cnt, flist, far_cap);
+    else hipLaunchKernelGGL((dcn_bwd_tile_kernel<T, 16>), grid, dim3(256), smem, st, offmask, (const T*)gcol, g, dx, cnt, flist, far_cap);
+    hipLaunchKernelGGL(dcn_bwd_far_kernel<T>, dim3(1024), dim3(256), 0, st, (const T*)gcol, (const u32x4*)flist, (const int*)cnt, far_cap, g, dx);
     MFX_HIP_CHECK(hipGetLastError());
     // grad_weight[o][c][tap] = sum_m dy[m][o] * col[m][tap*C + c]: MFMA GEMM over the pixels, written as (Cout, C, 3, 3)
     rc = mfx_internal_conv_wgrad(col, dy, dweight, 1, 1, (int)M, K, C, 3, 3, 1, 0, 0, 1, (int)M, Cout, Cout, dt, 1, C, Cout, stream, 1,

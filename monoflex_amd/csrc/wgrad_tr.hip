@@ -527,7 +527,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restric
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t_begin = blockIdx.x * g.tiles_per_block, t_end = min(t_begin + g.tiles_per_block, g.ntiles);
-    constexpr int XCH = SW_ROWS * (SW_ROWB / 16), DCH = SW_TH * SW_TW * 2;      // 280 image chunks, 512 dy chunks of 16 bytes
+    constexpr int XCH = SW_ROWS * (SW_ROWB / 16);                            // 280 image chunks (and 512 dy chunks) of 16 bytes
+    static_assert(SW_TH * SW_TW * 2 == 512, "two dy chunks per thread");
     struct Regs { u32x4 xr[2]; u32x4 dr[2]; };
     auto gload = [&](Regs& r, int t) {
         const int tx = t % g.tiles_x; int q = t / g.tiles_x;
