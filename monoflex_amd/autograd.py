@@ -66,21 +66,114 @@ def _pad_channels(n, dtype):
     return p
 
 
+class _PackRegistry:
+    """Persistent packed copies of the conv parameters (forward operand, data-gradient operand) with the parameter version they
+    were packed from.  A parameter changes once per optimisation step, so `pack_all_weights()` at the top of a step re-packs
+    every registered operand in ONE launch (mfx_pack_conv_weights_batched); `_pack_weight` then only hands out the buffers.
+    Without that call (or for an operand seen for the first time) the operand is packed on demand, one launch, as before."""
+
+    def __init__(self):
+        self.entries = {}              # key -> dict(ref, weight version, buffers, descriptor fields)
+        self.tables = {}               # (device, dtype) -> (keys, descs tensor, prefix tensor, total)
+        self.dirty = set()
+
+    def lookup(self, weight, dtype, mode, rows, ck, stride, pad_h, pad_w, register=True):
+        import weakref
+        key = (id(weight), dtype, mode, rows, ck, stride, pad_h, pad_w)
+        e = self.entries.get(key) if register else None
+        if e is not None and (e["ref"]() is not weight or e["ptr"] != weight.data_ptr()):
+            e = None                                           # the id was recycled, or the parameter moved (.to(), load)
+        if e is None:
+            Cout, Cin, kh, kw = weight.shape
+            E = 4 if dtype == torch.float32 else 8
+            if (ck & (ck - 1) and kh * kw > 1) or ck < E or ck % E:
+                raise ValueError("conv operand: channels per tap must be a power of two >= %d (any multiple of %d for 1x1), got %d" % (E, E, ck))
+            K_pad = (kh * kw * ck + 8 * E - 1) // (8 * E) * (8 * E)
+            cp = ops.cout_pad(rows)
+            packed = torch.empty((cp, K_pad), dtype=dtype, device=weight.device)
+            frag = torch.empty_like(packed) if (kh == 3 and kw == 3 and stride == 1 and pad_h == 1 and pad_w == 1) else None
+            e = dict(ref=weakref.ref(weight), ptr=weight.data_ptr(), version=-1, packed=packed, frag=frag, cp=cp, K_pad=K_pad,
+                     shape=(Cout, Cin, kh, kw), mode=mode, ck=ck, fp32=weight.dtype == torch.float32)
+            if register:
+                self.entries[key] = e
+                self.dirty.add((weight.device, dtype))
+        return e
+
+    def pack_one(self, e, weight, dtype):
+        Cout, Cin, kh, kw = e["shape"]
+        w32 = weight.detach()
+        w32 = _c(w32 if w32.dtype == torch.float32 else w32.float())
+        L.check(L.load().mfx_pack_conv_weight(_ptr(w32), Cout, Cin, kh, kw, e["mode"], _ptr(e["packed"]), _ptr(e["frag"]), e["cp"], e["K_pad"],
+                                              e["ck"], _dt(dtype), _stream()), "mfx_pack_conv_weight")
+        e["version"] = weight._version
+
+    def _rebuild(self, dev, dtype):
+        import numpy as np
+        keys, descs, prefix, total = [], [], [0], 0
+        for key, e in list(self.entries.items()):
+            w = e["ref"]()
+            if w is None or w.data_ptr() != e["ptr"]:
+                del self.entries[key]
+                continue
+            if key[1] != dtype or w.device != dev or not e["fp32"] or not w.is_contiguous():
+                continue
+            d = L.PackDesc()
+            d.w, d.packed, d.frag = w.data_ptr(), e["packed"].data_ptr(), (e["frag"].data_ptr() if e["frag"] is not None else None)
+            d.Cout, d.Cin, d.kh, d.kw = e["shape"]
+            d.mode, d.rows_pad, d.K_pad, d.ck = e["mode"], e["cp"], e["K_pad"], e["ck"]
+            keys.append(key); descs.append(bytes(d))
+            total += e["cp"] * e["K_pad"]
+            prefix.append(total)
+        if not keys:
+            self.tables.pop((dev, dtype), None)
+            return
+        dt = torch.from_numpy(np.frombuffer(b"".join(descs), dtype=np.uint8).copy()).to(dev)
+        pt = torch.tensor(prefix, dtype=torch.int64).to(dev)
+        self.tables[(dev, dtype)] = (keys, dt, pt, total)
+
+    def pack_all(self):
+        capturing = torch.cuda.is_current_stream_capturing()
+        for tk in list(self.dirty):
+            if not capturing:                                  # the tables are uploaded from the host: not inside a capture
+                self._rebuild(*tk)
+                self.dirty.discard(tk)
+        for (dev, dtype), (keys, dt, pt, total) in list(self.tables.items()):
+            live = [self.entries.get(k) for k in keys]
+            if any(e is None or e["ref"]() is None or e["ref"]().data_ptr() != e["ptr"] for e in live):
+                if capturing:
+                    continue
+                self._rebuild(dev, dtype)
+                if (dev, dtype) not in self.tables:
+                    continue
+                keys, dt, pt, total = self.tables[(dev, dtype)]
+                live = [self.entries[k] for k in keys]
+            with torch.cuda.device(dev):
+                L.check(L.load().mfx_pack_conv_weights_batched(_ptr(dt), _ptr(pt), len(keys), total, _dt(dtype), _stream()),
+                        "mfx_pack_conv_weights_batched")
+            for e in live:
+                e["version"] = e["ref"]()._version
+
+
+_PACKS = _PackRegistry()
+
+
+def pack_all_weights():
+    """Re-pack every conv operand the training path has used so far, one launch per (device, dtype); call at the top of a step."""
+    _PACKS.pack_all()
+
+
 def _pack_weight(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, shift=None):
-    """One-launch packing of an fp32 OIHW parameter into the conv operand (mode 0 forward, 1 data gradient)."""
+    """The conv operand of an fp32 OIHW parameter (mode 0 forward, 1 data gradient), packed on the device from the CURRENT
+    parameter values: handed out from the step's batched packing when the parameter has not changed since, else packed now."""
     Cout, Cin, kh, kw = weight.shape
-    E = 4 if dtype == torch.float32 else 8
-    if (ck & (ck - 1) and kh * kw > 1) or ck < E or ck % E:
-        raise ValueError("conv operand: channels per tap must be a power of two >= %d (any multiple of %d for 1x1), got %d" % (E, E, ck))
-    K_pad = (kh * kw * ck + 8 * E - 1) // (8 * E) * (8 * E)
-    cp = ops.cout_pad(rows)
-    w32 = weight.detach()
-    w32 = _c(w32 if w32.dtype == torch.float32 else w32.float())
-    packed = torch.empty((cp, K_pad), dtype=dtype, device=weight.device)
-    frag = torch.empty_like(packed) if (kh == 3 and kw == 3 and stride == 1 and pad_h == 1 and pad_w == 1) else None
-    L.check(L.load().mfx_pack_conv_weight(_ptr(w32), Cout, Cin, kh, kw, mode, _ptr(packed), _ptr(frag), cp, K_pad, ck, _dt(dtype), _stream()),
-            "mfx_pack_conv_weight")
-    return ops.PackedConv(packed, None, shift, kh, kw, stride, pad_h, pad_w, 1, ck, rows, cp, K_pad, L.ACT_NONE, frag)
+    if isinstance(weight, torch.nn.Parameter):
+        e = _PACKS.lookup(weight, dtype, mode, rows, ck, stride, pad_h, pad_w)
+        if e["version"] != weight._version:
+            _PACKS.pack_one(e, weight, dtype)
+    else:                                                      # a temporary (stacked head weights, a view): nothing to remember
+        e = _PACKS.lookup(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, register=False)
+        _PACKS.pack_one(e, weight, dtype)
+    return ops.PackedConv(e["packed"], None, shift, kh, kw, stride, pad_h, pad_w, 1, ck, rows, e["cp"], e["K_pad"], L.ACT_NONE, e["frag"])
 
 
 @_device_guarded
@@ -402,7 +495,12 @@ class DCNFn(Function):
         else:
             om = raw.clone()
             om[..., 18:27] = torch.sigmoid(raw[..., 18:27])
-        p = ops.pack_conv(weight, x.dtype, None, bias, stride=stride, pad=pad, act=L.ACT_NONE)
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        shift = None
+        if bias is not None:
+            cp = ops.cout_pad(Cout)
+            shift = _c(bias.detach().float()) if cp == Cout else torch.nn.functional.pad(bias.detach().float(), (0, cp - Cout))
+        p = _pack_weight(weight, x.dtype, 0, Cout, Cin, stride, pad, pad, shift)
         p.dil_w = dil
         y = ops.dcn(x, om, p)
         ctx.save_for_backward(x, om, weight)

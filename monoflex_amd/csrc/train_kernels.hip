@@ -14,6 +14,7 @@ namespace mfx {
 static inline int cdivt(long a, long b) { return (int)((a + b - 1) / b); }
 // elementwise BN passes: at most ~8 workgroups per CU, each streaming many chunks (amortises the per-workgroup table)
 #define BN_APPLY_GRID(total) dim3((unsigned)(cdivt((total), 256) < 2048 ? cdivt((total), 256) : 2048))
+#define WR_GRID(total) dim3((unsigned)(cdivt((total), 64) < 8192 ? cdivt((total), 64) : 8192))
 #define TR_GRID(total) dim3((unsigned)(cdivt((total), 256) < 16384 ? cdivt((total), 256) : 16384))
 
 template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
@@ -223,23 +224,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const bf16_t* __re
 
 // sums the per-slab partial tiles of conv_wgrad_mfma_kernel and writes the gradient in its final layout
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int slabs, long ws_slab, int ws_ld, WgradGeom g, float* __restrict__ dw) {
-    // one thread per output element; the slab loop is unrolled by 8 with independent accumulators (one load in flight per
-    // thread left this pass latency-bound: 28 us for a 150 KB gradient summed over 130 slabs)
+    // a workgroup owns 64 consecutive output elements; its four waves each sum a quarter of the slabs (four independent
+    // accumulators per thread), then the quarters meet in LDS.  (One thread per element walking all slabs left the pass
+    // latency-bound and the chip under-filled: 144 workgroups for a 64x576 gradient, 10 us per layer, 84 layers per step.)
+    __shared__ float part[4][64];
     const long total = (long)g.Cout * g.K;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int o = (int)(i / g.K), k = (int)(i - (long)o * g.K);
-        const float* p = ws + (size_t)o * ws_ld + k;
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int z = 0;
-        for (; z + 8 <= slabs; z += 8) {
+    const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (long i0 = (long)blockIdx.x * 64; i0 < total; i0 += (long)gridDim.x * 64) {
+        const long i = i0 + col;
+        float s = 0.f;
+        int o = 0, k = 0;
+        if (i < total) {
+            o = (int)(i / g.K); k = (int)(i - (long)o * g.K);
+            const float* p = ws + (size_t)o * ws_ld + k;
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            int z = q;
+            for (; z + 12 < slabs; z += 16) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += p[(size_t)(z + u) * ws_slab];
+                for (int u = 0; u < 4; ++u) a[u] += p[(size_t)(z + 4 * u) * ws_slab];
+            }
+            for (; z < slabs; z += 4) a[0] += p[(size_t)z * ws_slab];
+            s = (a[0] + a[1]) + (a[2] + a[3]);
         }
-        for (; z < slabs; ++z) a[0] += p[(size_t)z * ws_slab];
-        const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-        if (!g.oihw) { dw[(size_t)o * g.K + k] = s; continue; }
-        const int tap = k / g.Ck, c = k - tap * g.Ck;
-        if (o < g.Cout_out && c < g.Cin_out) dw[((size_t)o * g.Cin_out + c) * (g.kh * g.kw) + tap] = s;
+        part[q][col] = s;
+        __syncthreads();
+        if (q == 0 && i < total) {
+            s = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+            if (!g.oihw) dw[(size_t)o * g.K + k] = s;
+            else {
+                const int tap = k / g.Ck, c = k - tap * g.Ck;
+                if (o < g.Cout_out && c < g.Cin_out) dw[((size_t)o * g.Cin_out + c) * (g.kh * g.kw) + tap] = s;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -267,6 +284,35 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
         if (frag) {
             const size_t f = (((size_t)(n >> 4) * (K_pad / (4 * E)) + k / (4 * E)) * 4 + (k % (4 * E)) / E) * (16 * E) + (n & 15) * E + k % E;
             ElemTraits<T>::store(frag + f, v);
+        }
+    }
+}
+
+// All conv operands of a training step in ONE launch: element i of the concatenated outputs belongs to descriptor d with
+// prefix[d] <= i < prefix[d+1] (binary search, ~150 descriptors); same element rule as pack_conv_weight_kernel.
+// (One launch per operand was 148 launches of ~5 us per step.)
+template <typename T>
+__global__ void pack_conv_weight_batched_kernel(const mfx_pack_desc* __restrict__ descs, const long long* __restrict__ prefix, int n, long total) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((long)prefix[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const mfx_pack_desc d = descs[lo];
+        const long j = i - (long)prefix[lo];
+        const int nrow = (int)(j / d.K_pad), k = (int)(j - (long)nrow * d.K_pad);
+        const int taps = d.kh * d.kw, tap = k / d.ck, cc = k - tap * d.ck;
+        float v = 0.f;
+        if (tap < taps) {
+            if (d.mode == 0) { if (nrow < d.Cout && cc < d.Cin) v = d.w[((size_t)nrow * d.Cin + cc) * taps + tap]; }
+            else if (nrow < d.Cin && cc < d.Cout) v = d.w[((size_t)cc * d.Cin + nrow) * taps + (taps - 1 - tap)];
+        }
+        ElemTraits<T>::store(reinterpret_cast<T*>(d.packed) + j, v);
+        if (d.frag) {
+            const size_t f = (((size_t)(nrow >> 4) * (d.K_pad / (4 * E)) + k / (4 * E)) * 4 + (k % (4 * E)) / E) * (16 * E) + (nrow & 15) * E + k % E;
+            ElemTraits<T>::store(reinterpret_cast<T*>(d.frag) + f, v);
         }
     }
 }
@@ -762,52 +808,75 @@ __global__ void upsample_bwd_dx_kernel(const T* __restrict__ dy, const float* __
 }
 
 // depthwise-deconv weight gradient: dw[tap][c] = sum over input pixels of x[b,ih,iw,c] * dy[b, ih*f - f/2 + kh, iw*f - f/2 + kw, c].
-// thread -> (tap, 16-byte channel chunk); a block walks `rows_per_block` input rows (b, ih) with 16-byte loads, four columns
-// in flight (the first version walked pixels with 2-byte loads and three integer divisions per pixel: 155 us per call)
+// A workgroup of 1024 threads walks `rows_per_block` input rows (b, ih); thread -> (item = (tap, 16-byte channel chunk),
+// column group): the S = 1024 / items groups take interleaved columns, four 16-byte load pairs in flight each, and meet in
+// LDS before ONE atomic per (tap, channel) and workgroup.  (With one thread per item and 256-thread workgroups the f = 2
+// layers ran 128 threads per workgroup, 768 waves on the whole chip, each walking a full row: 85-110 us per call.)
 template <typename T>
-__global__ __launch_bounds__(256) void upsample_bwd_dw_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
-                                                              int B, int H, int W, int C, int f, int rows_per_block) {
+__global__ __launch_bounds__(1024) void upsample_bwd_dw_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
+                                                               int B, int H, int W, int C, int f, int rows_per_block) {
     constexpr int E = ElemTraits<T>::ELEMS;
-    const int k = 2 * f, p_ = f / 2, Ho = H * f, Wo = W * f, taps = k * k, CG = C / E;
+    extern __shared__ float red[];                                    // [S][items * E] when S > 1
+    const int k = 2 * f, p_ = f / 2, Ho = H * f, Wo = W * f, taps = k * k, CG = C / E, items = taps * CG;
+    const int S = items >= 1024 ? 1 : 1024 / items;                   // items is a power of two
     const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, B * H);
-    for (int item = threadIdx.x; item < taps * CG; item += 256) {
-        const int cg = item % CG, tap = item / CG, kh = tap / k, kw = tap - kh * k;
+    for (int it0 = 0; it0 < items; it0 += 1024) {
+        const int item = it0 + (S > 1 ? (int)threadIdx.x % items : (int)threadIdx.x), grp = S > 1 ? (int)threadIdx.x / items : 0;
         float acc[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] = 0.f;
-        // columns iw with 0 <= iw*f - p_ + kw < Wo
-        const int iw_lo = max(0, (p_ - kw + f - 1) / f), iw_hi = min(W - 1, (Wo - 1 + p_ - kw) / f);
-        for (int row = r0; row < r1; ++row) {
-            const int b = row / H, ih = row - b * H, oh = ih * f - p_ + kh;
-            if (oh < 0 || oh >= Ho) continue;
-            const T* xr = x + (size_t)row * W * C + cg * E;
-            const T* dr = dy + ((size_t)(b * Ho + oh) * Wo + (kw - p_)) * C + cg * E;      // + iw*f*C per column
-            int iw = iw_lo;
-            for (; iw + 3 <= iw_hi; iw += 4) {
-                u32x4 xv[4], dv[4];
+        if (item < items && grp < S) {
+            const int cg = item % CG, tap = item / CG, kh = tap / k, kw = tap - kh * k;
+            // columns iw with 0 <= iw*f - p_ + kw < Wo
+            const int iw_lo = max(0, (p_ - kw + f - 1) / f), iw_hi = min(W - 1, (Wo - 1 + p_ - kw) / f);
+            for (int row = r0; row < r1; ++row) {
+                const int b = row / H, ih = row - b * H, oh = ih * f - p_ + kh;
+                if (oh < 0 || oh >= Ho) continue;
+                const T* xr = x + (size_t)row * W * C + cg * E;
+                const T* dr = dy + ((size_t)(b * Ho + oh) * Wo + (kw - p_)) * C + cg * E;      // + iw*f*C per column
+                int iw = iw_lo + grp;
+                for (; iw + 3 * S <= iw_hi; iw += 4 * S) {
+                    u32x4 xv[4], dv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    xv[u] = *reinterpret_cast<const u32x4*>(xr + (size_t)(iw + u) * C);
-                    dv[u] = *reinterpret_cast<const u32x4*>(dr + (size_t)(iw + u) * f * C);
+                    for (int u = 0; u < 4; ++u) {
+                        xv[u] = *reinterpret_cast<const u32x4*>(xr + (size_t)(iw + u * S) * C);
+                        dv[u] = *reinterpret_cast<const u32x4*>(dr + (size_t)(iw + u * S) * f * C);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float a[E], d[E];
+                        ElemTraits<T>::unpack(xv[u], a); ElemTraits<T>::unpack(dv[u], d);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) acc[e] += a[e] * d[e];
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (; iw <= iw_hi; iw += S) {
                     float a[E], d[E];
-                    ElemTraits<T>::unpack(xv[u], a); ElemTraits<T>::unpack(dv[u], d);
+                    ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(xr + (size_t)iw * C), a);
+                    ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(dr + (size_t)iw * f * C), d);
 #pragma unroll
                     for (int e = 0; e < E; ++e) acc[e] += a[e] * d[e];
                 }
             }
-            for (; iw <= iw_hi; ++iw) {
-                float a[E], d[E];
-                ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(xr + (size_t)iw * C), a);
-                ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(dr + (size_t)iw * f * C), d);
-#pragma unroll
-                for (int e = 0; e < E; ++e) acc[e] += a[e] * d[e];
-            }
         }
+        if (S > 1) {
+            if (grp < S) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) unsafeAtomicAdd(dw + (size_t)tap * C + cg * E + e, acc[e]);
+                for (int e = 0; e < E; ++e) red[(size_t)grp * items * E + (size_t)e * items + item] = acc[e];
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < items * E; i += 1024) {
+                float t = 0.f;
+                for (int q = 0; q < S; ++q) t += red[(size_t)q * items * E + i];
+                const int e = i / items, im = i - e * items, cg = im % CG, tap = im / CG;
+                unsafeAtomicAdd(dw + (size_t)tap * C + cg * E + e, t);
+            }
+            __syncthreads();
+        } else if (item < items) {
+            const int cg = item % CG, tap = item / CG;
+#pragma unroll
+            for (int e = 0; e < E; ++e) unsafeAtomicAdd(dw + (size_t)tap * C + cg * E + e, acc[e]);
+        }
     }
 }
 
@@ -862,7 +931,7 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
         if (rc_tr != 1) rc_tr = try_conv_wgrad_tr(x, dy, g, workspace, workspace_bytes, &nslab_tr, st);
         if (rc_tr == 1) {
             const long total = (long)Cout * g.K;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, TR_GRID(total), dim3(256), 0, st, g.ws, nslab_tr, g.ws_slab, g.ws_ld, g, dw);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, WR_GRID(total), dim3(256), 0, st, g.ws, nslab_tr, g.ws_slab, g.ws_ld, g, dw);
             MFX_HIP_CHECK(hipGetLastError());
             return MFX_OK;
         }
@@ -891,7 +960,7 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
         else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
         if (ws_ok) {
             const long total = (long)Cout * g.K;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, TR_GRID(total), dim3(256), 0, st, g.ws, nslab, ws_slab, ws_ld, g, dw);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, WR_GRID(total), dim3(256), 0, st, g.ws, nslab, ws_slab, ws_ld, g, dw);
         }
         MFX_HIP_CHECK(hipGetLastError());
         return MFX_OK;
@@ -945,6 +1014,17 @@ extern "C" int mfx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_kernel<float>, TR_GRID(total), dim3(256), 0, st, w_oihw, Cout, Cin, kh, kw, mode, (float*)packed, (float*)frag, rows_pad, K_pad, ck),
                       hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, w_oihw, Cout, Cin, kh, kw, mode, (bf16_t*)packed, (bf16_t*)frag, rows_pad, K_pad, ck));
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" int mfx_pack_conv_weights_batched(const mfx_pack_desc* descs_dev, const long long* prefix_dev, int n, long long total, int dtype,
+                                             void* stream) {
+    if (n <= 0 || total <= 0) return MFX_OK;
+    if (!descs_dev || !prefix_dev) return mfx_fail(MFX_ERR_ARG, "pack_conv_weights_batched: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_batched_kernel<float>, TR_GRID(total), dim3(256), 0, st, descs_dev, prefix_dev, n, (long)total),
+                      hipLaunchKernelGGL(pack_conv_weight_batched_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, descs_dev, prefix_dev, n, (long)total));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1167,11 +1247,14 @@ extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* 
     if (total == 0) return MFX_OK;
     const int nrows = B * H;
     const int ppb = nrows >= 1024 ? 2 : 1;                   // input rows per block: >= ~512 blocks
+    const int dw_items = 4 * f * f * (C / E);
+    if (dw_items & (dw_items - 1)) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: taps x channel chunks must be a power of two");
+    const size_t dw_smem = dw_items >= 1024 ? 0 : (size_t)1024 * E * sizeof(float);          // [S][items * E], S * items = 1024
     DISPATCH_T(dtype,
         { hipLaunchKernelGGL(upsample_bwd_dx_kernel<float>, TR_GRID(total), dim3(256), 0, st, (const float*)dy, w, (float*)dx, B, H, W, C, f);
-          hipLaunchKernelGGL(upsample_bwd_dw_kernel<float>, dim3(cdivt(nrows, ppb)), dim3(256), 0, st, (const float*)x, (const float*)dy, dw, B, H, W, C, f, ppb); },
+          hipLaunchKernelGGL(upsample_bwd_dw_kernel<float>, dim3(cdivt(nrows, ppb)), dim3(1024), dw_smem, st, (const float*)x, (const float*)dy, dw, B, H, W, C, f, ppb); },
         { hipLaunchKernelGGL(upsample_bwd_dx_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, (const bf16_t*)dy, w, (bf16_t*)dx, B, H, W, C, f);
-          hipLaunchKernelGGL(upsample_bwd_dw_kernel<bf16_t>, dim3(cdivt(nrows, ppb)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, C, f, ppb); });
+          hipLaunchKernelGGL(upsample_bwd_dw_kernel<bf16_t>, dim3(cdivt(nrows, ppb)), dim3(1024), dw_smem, st, (const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, C, f, ppb); });
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

@@ -628,22 +628,26 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restric
     }
 }
 
-__global__ void slab_sum_kernel(const float* __restrict__ ws, int nslab, int n, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ ws, int nslab, int n, float* __restrict__ out) {
+    __shared__ float part[4][64];                                     // 64 outputs per workgroup, a quarter of the slabs per wave
+    const int col = threadIdx.x & 63, q = threadIdx.x >> 6, i = blockIdx.x * 64 + col;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    int z = 0;
-    for (; z + 4 <= nslab; z += 4) {
+    if (i < n) {
+        int z = q;
+        for (; z + 12 < nslab; z += 16) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] += ws[(size_t)(z + u) * n + i];
+            for (int u = 0; u < 4; ++u) a[u] += ws[(size_t)(z + 4 * u) * n + i];
+        }
+        for (; z < nslab; z += 4) a[0] += ws[(size_t)z * n + i];
     }
-    for (; z < nslab; ++z) a[0] += ws[(size_t)z * n + i];
-    out[i] = (a[0] + a[1]) + (a[2] + a[3]);
+    part[q][col] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (q == 0 && i < n) out[i] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 
 }  // namespace mfx
 
-int g_opt_stem_wgrad_blocks = 768;      // option "stem_wgrad_blocks"
+int g_opt_stem_wgrad_blocks = 512;      // option "stem_wgrad_blocks"
 
 extern "C" int mfx_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, int B, int H, int W, int Hp, int Wp, void* workspace,
                                    size_t workspace_bytes, void* stream) {
@@ -661,7 +665,7 @@ extern "C" int mfx_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, in
     nb = (g.ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
     g.ws = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(256), 0, st, (const bf16_t*)xp, (const bf16_t*)dy, g);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((16 * SW_K + 255) / 256), dim3(256), 0, st, (const float*)g.ws, nb, 16 * SW_K, dw);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((16 * SW_K + 63) / 64), dim3(256), 0, st, (const float*)g.ws, nb, 16 * SW_K, dw);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

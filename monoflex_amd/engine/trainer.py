@@ -131,6 +131,9 @@ class GraphedTrainStep:
             optimizer.step()
 
     def _fwd_bwd(self):
+        if self.images.is_cuda:
+            from .. import autograd as AG
+            AG.pack_all_weights()
         loss_dict, _ = self.model(self.images, self.targets)
         losses = sum(loss_dict.values())
         self.optimizer.zero_grad(set_to_none=True)
@@ -192,6 +195,9 @@ def _target_tensors(pt):
 
 def train_step(model, optimizer, images, targets, grad_norm_clip=-1.0, scheduler=None):
     """trainer.py:109-126: forward -> summed loss -> zero_grad -> backward (+DDP all-reduce) -> clip -> step."""
+    if images.is_cuda:
+        from .. import autograd as AG
+        AG.pack_all_weights()                                   # every conv operand of the step from the current parameters, one launch
     loss_dict, log_loss_dict = model(images, targets)
     losses = sum(loss_dict.values())
     optimizer.zero_grad(set_to_none=True)

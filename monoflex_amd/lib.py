@@ -66,6 +66,11 @@ class KittiEvalDesc(ctypes.Structure):
         [(n, c_int) for n in ("B", "n_gt", "n_dt", "num_classes", "num_k", "compute_aos")] + [("n_pairs", ctypes.c_int64)]
 
 
+class PackDesc(ctypes.Structure):                               # mfx_pack_desc
+    _fields_ = [("w", c_void_p), ("packed", c_void_p), ("frag", c_void_p)] + \
+        [(n, c_int) for n in ("Cout", "Cin", "kh", "kw", "mode", "rows_pad", "K_pad", "ck")]
+
+
 OBJ_ROW, OBJ_TERMS, OBJ_VALUES = 72, 10, 24                    # MFX_OBJ_ROW / MFX_OBJ_TERMS / MFX_OBJ_VALUES
 
 
@@ -109,6 +114,7 @@ SYMBOLS = {
     "mfx_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_act_bwd": (_I, [_P] * 10 + [ctypes.c_long, _I, _I, _I, _P]),
     "mfx_stem_wgrad_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "mfx_pack_conv_weights_batched": (_I, [_P, _P, _I, ctypes.c_longlong, _I, _P]),
     "mfx_bn_scratch_bytes": (_S, []),
     "mfx_bn_train_fwd": (_I, [_P] * 8 + [_F, _F, ctypes.c_long, _I, _I, _I, _P, _P, _P, _P]),
     "mfx_bn_train_bwd": (_I, [_P] * 10 + [ctypes.c_long, _I, _I, _I, _P, _P]),
