@@ -239,16 +239,18 @@ int mfx_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, int B, int H,
 int mfx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int kh, int kw, int mode, void* packed, void* frag,
                          int rows_pad, int K_pad, int ck, int dtype, void* stream);
 /* The same packing for MANY operands in one launch (every conv operand of a training step: the weights change once per step,
- * so they are re-packed once per step).  descs / prefix live in device memory: prefix[i] = first element (of rows_pad * K_pad
- * per operand) of descriptor i in the concatenated index space, prefix[n] = total.  All operands of one call share `dtype`. */
+ * so they are re-packed once per step).  descs / prefix live in device memory.  Every operand is cut into chunks of
+ * mfx_pack_chunk_elems() elements (of its rows_pad * K_pad); prefix[i] = first chunk of descriptor i in the concatenated chunk
+ * index space, prefix[n] = total_chunks.  All operands of one call share `dtype`. */
+int mfx_pack_chunk_elems(void);
 typedef struct mfx_pack_desc {
     const float* w;               /* (Cout, Cin, kh, kw) fp32 parameter */
     void* packed;                 /* [rows_pad][K_pad] */
     void* frag;                   /* fragment-major copy, or NULL */
     int Cout, Cin, kh, kw, mode, rows_pad, K_pad, ck;
 } mfx_pack_desc;
-int mfx_pack_conv_weights_batched(const mfx_pack_desc* descs_dev, const long long* prefix_dev, int n, long long total, int dtype,
-                                  void* stream);
+int mfx_pack_conv_weights_batched(const mfx_pack_desc* descs_dev, const long long* prefix_dev, int n, long long total_chunks,
+                                  int dtype, void* stream);
 /* out[c] = sum_m x[m*ld + c]  (bias gradients) */
 int mfx_colsum(const void* x, float* out, long M, int C, int ld, int dtype, void* stream);
 /* train-mode BatchNorm over [M][C]: per-channel sum and sum of squares (fp32, overwritten) */

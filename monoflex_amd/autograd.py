@@ -110,6 +110,7 @@ class _PackRegistry:
     def _rebuild(self, dev, dtype):
         import numpy as np
         keys, descs, prefix, total = [], [], [0], 0
+        chunk = L.load().mfx_pack_chunk_elems()
         for key, e in list(self.entries.items()):
             w = e["ref"]()
             if w is None or w.data_ptr() != e["ptr"]:
@@ -122,7 +123,7 @@ class _PackRegistry:
             d.Cout, d.Cin, d.kh, d.kw = e["shape"]
             d.mode, d.rows_pad, d.K_pad, d.ck = e["mode"], e["cp"], e["K_pad"], e["ck"]
             keys.append(key); descs.append(bytes(d))
-            total += e["cp"] * e["K_pad"]
+            total += (e["cp"] * e["K_pad"] + chunk - 1) // chunk
             prefix.append(total)
         if not keys:
             self.tables.pop((dev, dtype), None)

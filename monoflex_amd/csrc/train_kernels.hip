@@ -288,31 +288,40 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
     }
 }
 
-// All conv operands of a training step in ONE launch: element i of the concatenated outputs belongs to descriptor d with
-// prefix[d] <= i < prefix[d+1] (binary search, ~150 descriptors); same element rule as pack_conv_weight_kernel.
-// (One launch per operand was 148 launches of ~5 us per step.)
+// All conv operands of a training step in ONE launch.  The operands are cut into chunks of PACK_CHUNK elements; workgroup b
+// packs chunk b, which belongs to descriptor d with prefix[d] <= b < prefix[d+1] (prefix counts CHUNKS; wave-uniform binary
+// search over ~150 descriptors, descriptor fetched once per workgroup); same element rule as pack_conv_weight_kernel.
+// (One launch per operand was 148 launches of ~5 us per step; a per-element search made the single launch 330 us.)
+constexpr int PACK_CHUNK = 2048;
 template <typename T>
-__global__ void pack_conv_weight_batched_kernel(const mfx_pack_desc* __restrict__ descs, const long long* __restrict__ prefix, int n, long total) {
+__global__ __launch_bounds__(256) void pack_conv_weight_batched_kernel(const mfx_pack_desc* __restrict__ descs, const long long* __restrict__ prefix, int n) {
     constexpr int E = ElemTraits<T>::ELEMS;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = n - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if ((long)prefix[mid] <= i) lo = mid; else hi = mid - 1;
-        }
-        const mfx_pack_desc d = descs[lo];
-        const long j = i - (long)prefix[lo];
+    const long chunk = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((long)prefix[mid] <= chunk) lo = mid; else hi = mid - 1;
+    }
+    const mfx_pack_desc d = descs[lo];
+    const long total = (long)d.rows_pad * d.K_pad, j0 = (chunk - (long)prefix[lo]) * PACK_CHUNK;
+    const int taps = d.kh * d.kw;
+    T* packed = reinterpret_cast<T*>(d.packed);
+    T* frag = reinterpret_cast<T*>(d.frag);
+#pragma unroll
+    for (int u = 0; u < PACK_CHUNK / 256; ++u) {
+        const long j = j0 + u * 256 + threadIdx.x;
+        if (j >= total) break;
         const int nrow = (int)(j / d.K_pad), k = (int)(j - (long)nrow * d.K_pad);
-        const int taps = d.kh * d.kw, tap = k / d.ck, cc = k - tap * d.ck;
+        const int tap = k / d.ck, cc = k - tap * d.ck;
         float v = 0.f;
         if (tap < taps) {
             if (d.mode == 0) { if (nrow < d.Cout && cc < d.Cin) v = d.w[((size_t)nrow * d.Cin + cc) * taps + tap]; }
             else if (nrow < d.Cin && cc < d.Cout) v = d.w[((size_t)cc * d.Cin + nrow) * taps + (taps - 1 - tap)];
         }
-        ElemTraits<T>::store(reinterpret_cast<T*>(d.packed) + j, v);
-        if (d.frag) {
+        ElemTraits<T>::store(packed + j, v);
+        if (frag) {
             const size_t f = (((size_t)(nrow >> 4) * (d.K_pad / (4 * E)) + k / (4 * E)) * 4 + (k % (4 * E)) / E) * (16 * E) + (nrow & 15) * E + k % E;
-            ElemTraits<T>::store(reinterpret_cast<T*>(d.frag) + f, v);
+            ElemTraits<T>::store(frag + f, v);
         }
     }
 }
@@ -1018,13 +1027,16 @@ extern "C" int mfx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int 
     return MFX_OK;
 }
 
-extern "C" int mfx_pack_conv_weights_batched(const mfx_pack_desc* descs_dev, const long long* prefix_dev, int n, long long total, int dtype,
-                                             void* stream) {
-    if (n <= 0 || total <= 0) return MFX_OK;
+extern "C" int mfx_pack_chunk_elems(void) { return PACK_CHUNK; }
+
+extern "C" int mfx_pack_conv_weights_batched(const mfx_pack_desc* descs_dev, const long long* prefix_dev, int n, long long total_chunks,
+                                             int dtype, void* stream) {
+    if (n <= 0 || total_chunks <= 0) return MFX_OK;
     if (!descs_dev || !prefix_dev) return mfx_fail(MFX_ERR_ARG, "pack_conv_weights_batched: null pointer");
+    if (total_chunks >= (1LL << 31)) return mfx_fail(MFX_ERR_ARG, "pack_conv_weights_batched: too many chunks");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_batched_kernel<float>, TR_GRID(total), dim3(256), 0, st, descs_dev, prefix_dev, n, (long)total),
-                      hipLaunchKernelGGL(pack_conv_weight_batched_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, descs_dev, prefix_dev, n, (long)total));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_batched_kernel<float>, dim3((unsigned)total_chunks), dim3(256), 0, st, descs_dev, prefix_dev, n),
+                      hipLaunchKernelGGL(pack_conv_weight_batched_kernel<bf16_t>, dim3((unsigned)total_chunks), dim3(256), 0, st, descs_dev, prefix_dev, n));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
