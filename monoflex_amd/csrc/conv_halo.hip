@@ -373,16 +373,21 @@ int try_conv_halo(const mfx_conv_desc* d, hipStream_t st) {
     const int px_tiles = d->B * cdivh(d->H, kHaloRows) * cdivh(d->W, 16);
     // variant table from tools/conv_probe.py on MI355X (profiles/r01_*): two or four waves share a patch,
     // 32 output channels per wave; narrow outputs on small maps split N further to get more waves in flight
+    // variant table from tools/conv_bench.py on MI355X, B = 8 (graph replay, us; profiles/r02_conv_variants.md):
+    //   N = 32 (level1, the DCN offset/mask convs): 32ch@192x640 v2 44 / v10 76; 64ch@96x320 v9 22 / v10 27; 128ch@48x160 v8 11;
+    //     256ch@24x80 v10 12; 512ch@12x40 v10 20 -- the fewer pixel tiles, the more the waves split K
+    //   N = 64: 64ch@96x320 v6 32 / v12 36; 64ch@48x160 v12 10.5 / v6 14; 128ch@96x320 v12 58 / v6 66;
+    //     256ch@96x320 (the heads' data gradient) v13 103 / v12 137
+    //   N % 128: 64->256@96x320 (the heads' trunks in training) v5 81 / v7 99; 256->128@48x160 v11 47 / v7 61;
+    //     128->128@48x160 v7 26; level4/5 (120-240 pixel tiles) v11
     int v;
+    const int Ck = d->Ck;
     if (N == 16) v = 1;
-    // N = 32 is the DCN offset/mask conv: one or two waves per pixel tile cannot hide anything, so the waves split K
-    // (tools/layer_bench.py, B=8: 512ch@12x40 83 -> 34 us, 256ch@24x80 50 -> 23, 128ch@48x160 43 -> 24, 64ch@96x320 49 -> 37)
-    else if (N == 32) v = (px_tiles >= 300 && px_tiles < 1500) ? 8 : 10;
-    else if (N == 64) v = px_tiles >= 1500 ? 12 : 6;        // 64ch@96x320: 2-way K split 35 us vs 38.6
+    else if (N == 32) v = px_tiles >= 8000 ? 2 : (px_tiles >= 1500 ? 9 : (px_tiles >= 300 ? 8 : 10));
+    else if (N == 64) v = Ck >= 256 ? 13 : (Ck >= 128 ? 12 : (px_tiles >= 1500 ? 6 : 12));
     else if (N % 128 == 0) {
-        // few pixel tiles (level4 24x80: 240, level5 12x40: 192 workgroups): 8 waves with a 2-way K split keep the CUs busy
-        // (256ch@24x80: 27 us vs 43 generic / 38 unsplit; 512ch@12x40: 50 vs 54 generic)
-        v = px_tiles * (N / 128) < 300 ? 11 : 7;
+        if (N % 256 == 0 && Ck <= 64 && px_tiles >= 1500) v = 5;
+        else v = (Ck >= 256 || px_tiles * (N / 128) < 300) ? 11 : 7;
     } else v = 6;
     if (g_opt_halo >= 2) {
         const int f = g_opt_halo - 1, bn = variant_bn(f);
