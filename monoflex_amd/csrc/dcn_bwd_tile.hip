@@ -370,55 +370,78 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const T* __restrict
         }
         return p;
     };
-    int j = wv * SPW + sl;
-    Pre cur = prefetch(j);
-    for (int base = wv * SPW; base < nsamp; base += 4 * SPW, j += 4 * SPW) {
-        const Pre nxt = prefetch(j + 4 * SPW);
-        const bool ok = j < nsamp;
-        const int px = j / 9, tap = j - px * 9, mx = x_begin + px;
-        const int th = (tap * 11) >> 5, tw = tap - th * 3;
-        const float h = (float)(my - 1 + th) + cur.oh, w = (float)(mx - 1 + tw) + cur.ow;
-        const bool inside = ok && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
+    struct Geo { bool ok, inside; int tap, h0, w0; size_t m; float lh, lw, mask; };
+    auto geo = [&](int j, const Pre& p) {
+        Geo q;
+        q.ok = j < nsamp;
+        const int px = j / 9, mx = x_begin + px;
+        q.tap = j - px * 9;
+        const int th = (q.tap * 11) >> 5, tw = q.tap - th * 3;
+        const float h = (float)(my - 1 + th) + p.oh, w = (float)(mx - 1 + tw) + p.ow;
+        q.inside = q.ok && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
         const float hf = floorf(h), wf = floorf(w);
-        const float lh = h - hf, lw = w - wf, mask = cur.mk;
-        const int h0 = (int)fminf(fmaxf(hf, -4.f), 32000.f), w0 = (int)fminf(fmaxf(wf, -4.f), 32000.f);
-        const size_t m = mrow + mx;
+        q.lh = h - hf; q.lw = w - wf; q.mask = p.mk;
+        q.h0 = (int)fminf(fmaxf(hf, -4.f), 32000.f); q.w0 = (int)fminf(fmaxf(wf, -4.f), 32000.f);
+        q.m = mrow + mx;
+        return q;
+    };
+    struct Raw5 { Raw8<T> g, v[4]; };
+    auto issue = [&](const Geo& q, int s) {
+        Raw5 r;
+        const int c0 = s * CS + cl * 8;
+        if (q.inside) {
+            r.g.load(gcol + q.m * g.Kp + q.tap * g.C + c0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int hc = q.h0 + (c >> 1), wc = q.w0 + (c & 1);
+                if (hc >= 0 && hc < g.H && wc >= 0 && wc < g.W) r.v[c].load(xb + ((size_t)hc * g.W + wc) * g.C + c0);
+                else r.v[c].zero();
+            }
+        }
+        return r;
+    };
+    auto finish = [&](const Geo& q, const Raw5& r, int s, float& gh, float& gw, float& gm) {
+        float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (q.inside) {
+            float gc[8], v0[8], v1[8], v2[8], v3[8];
+            r.g.unpack(gc); r.v[0].unpack(v0); r.v[1].unpack(v1); r.v[2].unpack(v2); r.v[3].unpack(v3);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // top / bottom row blends share the horizontal differences (dmcn_get_coordinate_weight, dcn_v2_im2col_cuda.cu:82-122)
+                const float d10 = v1[k] - v0[k], d32 = v3[k] - v2[k];
+                const float top = v0[k] + q.lw * d10, bot = v2[k] + q.lw * d32;
+                const float dh = bot - top, val = top + q.lh * dh, dw = d10 + q.lh * (d32 - d10);
+                cv[k] = q.mask * val;
+                gm += gc[k] * val; gh += gc[k] * dh; gw += gc[k] * dw;
+            }
+        }
+        if (q.ok) bt_store8<T>(col + q.m * g.Kp + q.tap * g.C + s * CS + cl * 8, cv);
+    };
+    // software pipeline: the raw offset/mask values of sample i+2 and the five gathers of sample i+1 (first channel slice) are
+    // in flight while sample i is blended
+    int j = wv * SPW + sl;
+    const int step = 4 * SPW;
+    Pre pre1 = prefetch(j + step);
+    Geo q0 = geo(j, prefetch(j));
+    Raw5 r0 = issue(q0, 0);
+    for (int base = wv * SPW; base < nsamp; base += step, j += step) {
+        const Pre pre2 = prefetch(j + 2 * step);
+        const Geo q1 = geo(j + step, pre1);
+        const Raw5 r1 = issue(q1, 0);
         float gh = 0.f, gw = 0.f, gm = 0.f;
-        for (int s = 0; s < nsl; ++s) {
-            const int c0 = s * CS + cl * 8;
-            Raw8<T> rg, rv[4];
-            if (inside) {
-                rg.load(gcol + m * g.Kp + tap * g.C + c0);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int hc = h0 + (c >> 1), wc = w0 + (c & 1);
-                    if (hc >= 0 && hc < g.H && wc >= 0 && wc < g.W) rv[c].load(xb + ((size_t)hc * g.W + wc) * g.C + c0);
-                    else rv[c].zero();
-                }
-            }
-            float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (inside) {
-                float gc[8], v0[8], v1[8], v2[8], v3[8];
-                rg.unpack(gc); rv[0].unpack(v0); rv[1].unpack(v1); rv[2].unpack(v2); rv[3].unpack(v3);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    // top / bottom row blends share the horizontal differences (dmcn_get_coordinate_weight, dcn_v2_im2col_cuda.cu:82-122)
-                    const float d10 = v1[k] - v0[k], d32 = v3[k] - v2[k];
-                    const float top = v0[k] + lw * d10, bot = v2[k] + lw * d32;
-                    const float dh = bot - top, val = top + lh * dh, dw = d10 + lh * (d32 - d10);
-                    cv[k] = mask * val;
-                    gm += gc[k] * val; gh += gc[k] * dh; gw += gc[k] * dw;
-                }
-            }
-            if (ok) bt_store8<T>(col + m * g.Kp + tap * g.C + c0, cv);
+        finish(q0, r0, 0, gh, gw, gm);
+        for (int s = 1; s < nsl; ++s) {
+            const Raw5 rs = issue(q0, s);
+            finish(q0, rs, s, gh, gw, gm);
         }
         gh = bt_group_sum<LPS>(gh); gw = bt_group_sum<LPS>(gw); gm = bt_group_sum<LPS>(gm);
-        if (cl == 0 && ok) {
-            float* o = graw + m * 32;
-            o[2 * tap] = gh * mask; o[2 * tap + 1] = gw * mask; o[18 + tap] = gm * mask * (1.f - mask);   // through the sigmoid of the mask logit
-            if (tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
+        if (cl == 0 && q0.ok) {
+            float* o = graw + q0.m * 32;
+            o[2 * q0.tap] = gh * q0.mask; o[2 * q0.tap + 1] = gw * q0.mask;
+            o[18 + q0.tap] = gm * q0.mask * (1.f - q0.mask);                   // through the sigmoid of the mask logit
+            if (q0.tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
         }
-        cur = nxt;
+        q0 = q1; r0 = r1; pre1 = pre2;
     }
 }
 
