@@ -43,8 +43,9 @@ def invalidate_packs(module):
 
 def _eval_only(m):
     if m.training:
-        raise NotImplementedError("%s: the HIP path implements eval-mode BatchNorm (running statistics); "
-                                  "call .eval() -- the training kernels are a later round" % type(m).__name__)
+        raise NotImplementedError("%s: this entry point is the fused eval-mode path (BatchNorm folded into the conv epilogue from the "
+                                  "running statistics); call .eval(), or use the module's training forward (forward_nhwc_train / "
+                                  "model(images, targets) in train mode)" % type(m).__name__)
 
 
 def _train_conv_bn(x, conv, bn, act, res=None):
