@@ -79,7 +79,7 @@ __global__ __launch_bounds__(WO * 192) void conv_wgrad_tr_kernel(const bf16_t* _
 
     struct Regs { u32x4 a[A_N]; u32x4 d[D_N]; };
     // (b, oh, ow) of this thread's A rows, advanced by 32 pixels per load: integer divisions per chunk made the first version
-    // VALU-bound (12.5 VALU instructions per MFMA, PMC in profiles/r02_wgrad_tr_pmc.md)
+    // VALU-bound (12.5 VALU instructions per MFMA, PMC pass of round 2: SQ_INSTS_VALU / SQ_INSTS_MFMA)
     int pb[A_N], poh[A_N], pow_[A_N];
 #pragma unroll
     for (int j = 0; j < A_N; ++j) {

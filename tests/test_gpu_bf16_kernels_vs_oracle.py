@@ -5,7 +5,7 @@ deformable conv, torch fp32 convolution for the rest) on bf16-representable inpu
 Error model of a bf16 layer whose inputs are exact in bf16: fp32 accumulation (error ~1e-6 relative), then ONE rounding of
 the output to bf16 (2^-9 = 1.95e-3 relative).  The DCN LDS-patch kernel additionally blends the four corners in packed fp16
 (2^-11 per operation, weights carry the mask) before its fp16 MFMA.  Bounds below are ~2x the values observed on MI355X
-(printed by the tests; recorded in profiles/r02_bf16_parity.md)."""
+(printed by the tests; recorded in profiles/r02_bf16_kernel_parity.json)."""
 import json
 import os
 

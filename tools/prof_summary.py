@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Turn a rocprofv3 results .db (--kernel-trace --stats) into the per-kernel summary kept under profiles/.
-usage: python tools/prof_summary.py gpurun_out/prof_r1/r1_results.db [steps] > profiles/r01_kernel_stats.md"""
+usage: python tools/prof_summary.py gpurun_out/prof_r1/r1_results.db [steps] > profiles/rNN_<what>_kernel_stats.md"""
 import re
 import sqlite3
 import sys
