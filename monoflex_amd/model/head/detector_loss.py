@@ -356,8 +356,7 @@ class Loss_Computation:
         if rows is None:
             rows = self.pack_objects(tv)
         if cfg is None or rows is None:
-            raise NotImplementedError("fused object loss: 4 orientation bins, 10 keypoints, a depth range (set fused_object_loss=False "
-                                      "for the tensor-op form)")
+            raise NotImplementedError("fused object loss: 4 orientation bins, 10 keypoints, a depth range")
         reg = predictions['reg'].permute(0, 2, 3, 1)                              # the predictor's NHWC map: a view
         terms, logged = AG.ObjectLossFn.apply(reg.float(), rows.to(dev), cfg, 0)
         t = terms.unbind(0)
@@ -384,8 +383,9 @@ class Loss_Computation:
         prepared = targets if isinstance(targets, tuple) else getattr(targets, "loss", None)
         heat, tv = prepared if prepared is not None else self.prepare_targets(targets, dev)
         W = self.loss_weights
-        if predictions['reg'].is_cuda and self.fused_object_loss:
-            return self._fused(predictions, heat, tv, dev)
+        if predictions['reg'].is_cuda and self.fused_object_loss and self.object_loss_cfg() is not None \
+                and (tv.get("object_rows") is not None or tv["keypoints"].shape[-2] == 10):
+            return self._fused(predictions, heat, tv, dev)          # else: the tensor-op form below (same device, ~900 launches)
         T, P, sel, _ = self.prepare_predictions(tv, predictions)
         valid, v = sel['valid'], sel['valid'].float()
         v2 = sel['reg_2D'].float()
