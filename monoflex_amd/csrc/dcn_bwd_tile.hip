@@ -33,12 +33,17 @@ int mfx_internal_conv_wgrad(const void* x, const void* dy, float* dw, int B, int
                             int dtype, int oihw, int Cin_out, int Cout_out, void* stream, int dil_w,
                             void* workspace, size_t workspace_bytes, int direct);
 
+int g_opt_dcn_bt_cs = 0;       // option "dcn_bt_cs": channel slice of the tile kernel for C >= 128 (0 = by workgroup count, 64, 128)
+int g_opt_dcn_bt_cs_wgs = 1000; // option "dcn_bt_cs_wgs": below this many 128-channel workgroups the tile kernel takes 64-channel slices
 int g_opt_dcn_bt_dbg = 0;      // option "dcn_bt_dbg": experiment switches of dcn_bwd_tile_kernel (0 in production)
 
 namespace mfx {
 
 constexpr int BT_TH = 8, BT_TW = 16, BT_D = 8, BT_NPIX = BT_TH * BT_TW;
 constexpr int BT_FCAP = 512;   // far corners staged per workgroup before one global reservation
+#ifndef BT_LCAP_BF16
+#define BT_LCAP_BF16 62       // 4-byte list entries per target pixel (mean 36, sigma ~6): 32 KB of lists = four workgroups per CU
+#endif
 constexpr int BT_CH = BT_TH + 2 * BT_D, BT_CW = BT_TW + 2 * BT_D;        // candidate window (24 x 32 pixels)
 
 struct BtGeom { int B, H, W, C, tiles_x, tiles_y, Kp, CS, nslices, dbg; };
@@ -121,7 +126,7 @@ template <> struct BtEntry<float> {
 };
 template <> struct BtEntry<bf16_t> {
     typedef uint32_t type;
-    static constexpr int LCAP = 94;
+    static constexpr int LCAP = BT_LCAP_BF16;
     static __device__ __forceinline__ uint32_t make(int wy, int wx, int tap, float w) {
         return ((uint32_t)wy << 27) | ((uint32_t)wx << 22) | ((uint32_t)tap << 18) | (((__float_as_uint(w) + 0x1000u) >> 13) & 0x3ffffu);
     }
@@ -455,7 +460,7 @@ static BtLayout bt_layout(int B, int C, int H, int W, int Cout, int es) {
     L.gcol = o; o += bt_al(M * K * es);
     L.col = o;  o += bt_al(M * K * es);
     L.cnt = o;  o += 256;
-    L.far_cap = (long)M * 36 * (C >= 128 ? C / 128 : 1);      // every (sample, corner) pair of every channel slice: the list cannot fill
+    L.far_cap = (long)M * 36 * (C / 64);                      // every (sample, corner) pair of every (64-channel) slice: the list cannot fill
     L.flist = o; o += bt_al((size_t)L.far_cap * 16);
     L.wg = o;   o += bt_al((size_t)24 * 1024 * 1024);         // partial tiles of the MFMA weight-gradient slabs
     L.total = o;
@@ -495,11 +500,19 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     BtGeom g;
     g.B = B; g.H = H; g.W = W; g.C = C; g.tiles_x = (W + BT_TW - 1) / BT_TW; g.tiles_y = (H + BT_TH - 1) / BT_TH; g.Kp = K;
     g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg;
+    BtGeom gs = g;                                             // the sample kernel loops its slices inside a lane group: widest slice
+    // tile kernel: one workgroup per (tile, slice).  On the small maps 128-channel slices leave the chip under-filled
+    // (256ch@24x80: 240 workgroups), so those take 64-channel slices (the binning is repeated per slice, the gathers are not)
+    {
+        const long wgs128 = (long)g.tiles_x * g.tiles_y * B * g.nslices;
+        const int force = g_opt_dcn_bt_cs;
+        if (C >= 128 && (force == 64 || (force == 0 && wgs128 < g_opt_dcn_bt_cs_wgs))) { g.CS = 64; g.nslices = C / 64; }
+    }
     {   // grad_offset / grad_mask and the modulated columns: one lane group per (pixel, tap), every d_raw channel written
         const int rows = B * H, xsplit = std::max(1, std::min(W / 16, (2048 + rows - 1) / rows));
         const dim3 sgrid((unsigned)rows, (unsigned)xsplit);
-        if (g.CS == 64) hipLaunchKernelGGL((dcn_bwd_sample_kernel<T, 8>), sgrid, dim3(256), 0, st, x, offmask, (const T*)gcol, g, xsplit, d_raw, col);
-        else hipLaunchKernelGGL((dcn_bwd_sample_kernel<T, 16>), sgrid, dim3(256), 0, st, x, offmask, (const T*)gcol, g, xsplit, d_raw, col);
+        if (gs.CS == 64) hipLaunchKernelGGL((dcn_bwd_sample_kernel<T, 8>), sgrid, dim3(256), 0, st, x, offmask, (const T*)gcol, gs, xsplit, d_raw, col);
+        else hipLaunchKernelGGL((dcn_bwd_sample_kernel<T, 16>), sgrid, dim3(256), 0, st, x, offmask, (const T*)gcol, gs, xsplit, d_raw, col);
     }
     const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * B), (unsigned)g.nslices);
     const size_t smem = (size_t)BT_NPIX * BtEntry<T>::LCAP * sizeof(typename BtEntry<T>::type) + (size_t)BT_NPIX * 4 + (size_t)BT_FCAP * 8;
