@@ -29,9 +29,18 @@ struct HeadGeom {
 };
 struct HeadTabs { int ch_off[16]; int c_out[16]; };
 
-template <typename T> struct HeadSmem {
-    static constexpr int PS = kHeadC * (int)sizeof(T) + 16;
-    static constexpr int patch_bytes = (kHeadRows + 2) * 18 * PS;
+// Halo patch in LDS: FOUR PLANES, one per MFMA k-group (lane >> 4).  A lane of k-group q only ever reads the 16-byte channel
+// chunks q, q+4, (q+8, q+12) of a pixel, so plane q holds exactly those, pixels PS = (chunks + 1) * 16 bytes apart (48 / 80:
+// an odd number of 16-byte slots, so 16 consecutive pixels cover all 64 banks once) and the planes a multiple of 256 bytes
+// apart.  ds_read_b128 serves the lanes in groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...: eight lanes of one k-group and
+// eight of the next -- with every k-group's chunks inside ONE 144-byte pixel record (the first layout) the two halves of a
+// group collided on 7 of 8 slots (PMC: bank conflicts on 48 % of the LDS cycles of this kernel); with planes they read the
+// same slots as 16 consecutive pixels of one plane would.  PL = false keeps the single-record layout (option "heads_planes" = 0).
+template <typename T, bool PL> struct HeadSmem {
+    static constexpr int CPL = kHeadC * (int)sizeof(T) / 16 / 4;        // 16-byte chunks of a pixel per plane: 2 (bf16) / 4 (f32)
+    static constexpr int PS = PL ? (CPL + 1) * 16 : kHeadC * (int)sizeof(T) + 16;    // pixel stride (inside a plane / of the single record)
+    static constexpr int PLANE = PL ? ((kHeadRows + 2) * 18 * PS + 255) / 256 * 256 : 0;
+    static constexpr int patch_bytes = PL ? 4 * PLANE : (kHeadRows + 2) * 18 * PS;
     static constexpr int red_ld = 20;                                   // fp32 words per pixel row of a partial-sum slice (16 + pad)
     static constexpr int red_bytes = kHeadRows * 16 * red_ld * 4;       // one wave's slice: [128 px][20]
     static constexpr int bytes = patch_bytes + kHeadWaves * red_bytes;
@@ -55,19 +64,19 @@ template <> struct TrunkPack<float> {       // k-block = 16 trunk channels = D f
 
 // w1p: fragment-major 3x3 weights  [branch][wn 4][step][j 4][lane 64][16 B]
 // w2p: fragment-major 1x1 weights  [branch][wn 4][kblk][of 2][lane 64][16 B]  (K order matching TrunkPack)
-template <typename T>
+template <typename T, bool PL>
 __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T* __restrict__ x, const u32x4* __restrict__ w1p,
                                                                          const float* __restrict__ scale1, const float* __restrict__ shift1,
                                                                          const u32x4* __restrict__ w2p, const float* __restrict__ bias2,
                                                                          float* __restrict__ out, HeadGeom g, HeadTabs tabs) {
     constexpr int NT = kHeadWaves * 64, FM = kHeadRows, FN = kHeadFN;
     constexpr int ELEMS = ElemTraits<T>::ELEMS;
-    constexpr int PS = HeadSmem<T>::PS;
+    constexpr int PS = HeadSmem<T, PL>::PS, PLANE = HeadSmem<T, PL>::PLANE;
     constexpr int KBLK = TrunkPack<T>::KBLK;
-    constexpr int RLD = HeadSmem<T>::red_ld;
+    constexpr int RLD = HeadSmem<T, PL>::red_ld;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
-    float* red = reinterpret_cast<float*>(smem + HeadSmem<T>::patch_bytes);      // [4 waves][128 px][20]
+    float* red = reinterpret_cast<float*>(smem + HeadSmem<T, PL>::patch_bytes);      // [4 waves][128 px][20]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xl = lane & 15, kq = lane >> 4;
@@ -99,7 +108,8 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 const int idx = base + u * NT + tid;
-                if (idx < nchunks) *reinterpret_cast<u32x4*>(patch + (idx / CPP) * PS + (idx % CPP) * 16) = pr[u];
+                if (idx < nchunks) *reinterpret_cast<u32x4*>(patch + (PL ? ((idx % CPP) & 3) * PLANE + (idx / CPP) * PS + ((idx % CPP) >> 2) * 16
+                                                                       : (idx / CPP) * PS + (idx % CPP) * 16)) = pr[u];
             }
         }
     }
@@ -123,7 +133,8 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
             const int e = s * (4 * ELEMS) + kq * ELEMS;      // this lane's K chunk -> (tap, channel)
             const int tap = e >> 6, cl = e & 63;
             const int th = (tap * 21846) >> 16, tw = tap - th * 3;
-            const char* ap = patch + (th * 18 + xl + tw) * PS + cl * (int)sizeof(T);
+            const char* ap = patch + (PL ? kq * PLANE + (th * 18 + xl + tw) * PS + (cl * (int)sizeof(T) / 64) * 16   // chunk kq + 4*(cl*sizeof/64)
+                                         : (th * 18 + xl + tw) * PS + cl * (int)sizeof(T));
             // pixel fragments two rows ahead of the MFMAs that consume them: left to itself the scheduler (at 250+ VGPRs) sinks
             // each ds_read pair right in front of its 8 MFMAs and every pair then exposes a full LDS round trip
             u32x4 pf[2][2];
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
     }
 }
 
-template <typename T> static int launch_heads(const mfx_heads_desc* d, hipStream_t st) {
+template <typename T, bool PL> static int launch_heads(const mfx_heads_desc* d, hipStream_t st) {
     HeadGeom g;
     g.B = d->B; g.H = d->H; g.W = d->W; g.tiles_x = (d->W + 15) / 16; g.tiles_y = (d->H + kHeadRows - 1) / kHeadRows;
     g.nbranch = d->nbranch; g.ld_out = d->ld_out; g.planar = d->planar; g.planar_c = d->planar_c;
@@ -239,8 +250,8 @@ template <typename T> static int launch_heads(const mfx_heads_desc* d, hipStream
     HeadTabs t;
     for (int i = 0; i < 16; ++i) { t.ch_off[i] = d->ch_off[i]; t.c_out[i] = d->c_out[i]; }
     const int tiles = g.tiles_x * g.tiles_y * d->B;
-    auto k = heads_fused_kernel<T>;
-    constexpr int smem = HeadSmem<T>::bytes;
+    auto k = heads_fused_kernel<T, PL>;
+    constexpr int smem = HeadSmem<T, PL>::bytes;
     static bool attr_set = false;
     if (!attr_set && smem > 64 * 1024) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
     hipLaunchKernelGGL(k, dim3(tiles), dim3(kHeadWaves * 64), smem, st, reinterpret_cast<const T*>(d->x),
@@ -253,6 +264,9 @@ template <typename T> static int launch_heads(const mfx_heads_desc* d, hipStream
 }  // namespace mfx
 using namespace mfx;
 
+int g_opt_heads_planes = 0;    // option "heads_planes": 1 = four k-group planes (no LDS bank conflicts: 48 % -> 11 % of the LDS cycles, LDS-active
+                               // cycles -42 %), 0 = one 144-byte record per pixel.  Same kernel time (555 vs 555 us, A/B in one run): not LDS-bound
+
 extern "C" int mfx_heads_fused(const mfx_heads_desc* d, void* stream) {
     if (!d || !d->x || !d->w1 || !d->scale1 || !d->shift1 || !d->w2 || !d->bias2 || !d->out)
         return mfx_fail(MFX_ERR_ARG, "heads_fused: null pointer");
@@ -263,7 +277,7 @@ extern "C" int mfx_heads_fused(const mfx_heads_desc* d, void* stream) {
             return mfx_fail(MFX_ERR_ARG, "heads_fused: branch output channels out of range");
     if (d->B * d->H * d->W == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (d->dtype == MFX_F32) return launch_heads<float>(d, st);
-    if (d->dtype == MFX_BF16) return launch_heads<bf16_t>(d, st);
+    if (d->dtype == MFX_F32) return g_opt_heads_planes ? launch_heads<float, true>(d, st) : launch_heads<float, false>(d, st);
+    if (d->dtype == MFX_BF16) return g_opt_heads_planes ? launch_heads<bf16_t, true>(d, st) : launch_heads<bf16_t, false>(d, st);
     return mfx_fail(MFX_ERR_ARG, "heads_fused: bad dtype");
 }
