@@ -279,8 +279,11 @@ int mfx_bn_train_fwd(const void* x, const void* res, void* y, const float* gamma
                      float* running_var, long long* num_batches_tracked, float momentum, float eps, long M, int C, int act,
                      int dtype, float* scratch, float* mean, float* rstd, void* stream);
 int mfx_bn_train_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
-                     void* dx, void* dres, float* dgamma, float* dbeta, long M, int C, int act, int dtype, float* scratch,
-                     void* stream);
+                     const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, long M, int C, int act, int dtype,
+                     float* scratch, void* stream);
+/* (`a` = the forward output, read only for the activation's derivative.  When no residual entered the activation it may be
+ * NULL: the sign of x*scale + shift is then recomputed from x, gamma, beta, mean, rstd with the forward's expression, which
+ * drops one of the three input streams of both backward launches.) */
 /* the two halves of mfx_bn_act_bwd, for synchronised BN (reference tools/plain_train_net.py:131-132, SyncBatchNorm):
  * reduce -> all-reduce(sg, sgx) across ranks -> apply with M_total = rows summed over ranks */
 int mfx_bn_bwd_reduce(const void* x, const void* a, const void* da, const float* mean, const float* rstd,

@@ -332,6 +332,7 @@ def _sync_group(sync):
 
 
 _BN_SEPARATE = [False]          # True: the five-launch form (stats, finalize, apply; reduce, apply) also in the single-process case
+_BN_READ_OUTPUT = [False]       # True: the backward always reads the forward output for the activation derivative (test switch)
 _BN_SCRATCH = {}
 
 
@@ -377,6 +378,7 @@ class BNActFn(Function):
             ctx.save_for_backward(x, y, mr[:C], mr[C:], _c(g32))
             ctx.cfg = (act, res is not None, None, M)
             ctx.scratch = scratch
+            ctx.beta32 = _c(b32)
             return y
         if nbt is not None:
             nbt.add_(1)
@@ -415,8 +417,11 @@ class BNActFn(Function):
             dres = torch.empty_like(x) if has_res else None
             dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
             dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-            L.check(L.load().mfx_bn_train_bwd(_ptr(x), _ptr(y), _ptr(da), _ptr(mean), _ptr(rstd), _ptr(g32), _ptr(dx), _ptr(dres), _ptr(dgamma),
-                                              _ptr(dbeta), M, C, act, _dt(x.dtype), _ptr(ctx.scratch), _stream()), "mfx_bn_train_bwd")
+            # without a residual the activation's derivative is recomputed from x (the forward output is not read)
+            a_in = y if (has_res or act == L.ACT_NONE or _BN_READ_OUTPUT[0]) else None
+            L.check(L.load().mfx_bn_train_bwd(_ptr(x), _ptr(a_in), _ptr(da), _ptr(mean), _ptr(rstd), _ptr(g32), _ptr(ctx.beta32), _ptr(dx),
+                                              _ptr(dres), _ptr(dgamma), _ptr(dbeta), M, C, act, _dt(x.dtype), _ptr(ctx.scratch), _stream()),
+                    "mfx_bn_train_bwd")
             return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
         sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
         sg, sgx = sums[:C], sums[C:]

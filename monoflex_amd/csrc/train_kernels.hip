@@ -506,22 +506,31 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ da,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             long M, int C, int rows_per_block, int act,
-                                                            float* __restrict__ sg, float* __restrict__ sgx, int ncopy) {
+                                                            float* __restrict__ sg, float* __restrict__ sgx, int ncopy,
+                                                            const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
     if (ncopy > 1) { const int k = blockIdx.x % ncopy; sg += (size_t)k * 2 * C; sgx += (size_t)k * 2 * C; }
     constexpr int E = ElemTraits<T>::ELEMS;
     extern __shared__ float sred[];                          // [256 / CPR][2 * C]
     const int CPR = C / E, tid = threadIdx.x;
     const int cc = tid % CPR, rstep = 256 / CPR, roff = tid / CPR;
-    float acc[2][E], mu[E], rs[E];
+    // a == nullptr with an activation: no residual entered the activation, so its sign is the sign of x*scale + shift, recomputed
+    // with the forward's own expression instead of reading the stored output (one of the three streams of this pass)
+    const bool recompute = act != ACT_NONE && a == nullptr;
+    float acc[2][E], mu[E], rs[E], sc[E], sh[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; mu[e] = mean[cc * E + e]; rs[e] = rstd[cc * E + e]; }
+    for (int e = 0; e < E; ++e) {
+        acc[0][e] = 0.f; acc[1][e] = 0.f; mu[e] = mean[cc * E + e]; rs[e] = rstd[cc * E + e];
+        sc[e] = recompute ? gamma[cc * E + e] * rs[e] : 0.f;
+        sh[e] = recompute ? beta[cc * E + e] - mu[e] * sc[e] : 0.f;
+    }
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(r0 + (long)rows_per_block, M);
     auto fold = [&](const u32x4& cx, const u32x4& cd, const u32x4& ca) {
         float xv[E], av[E], dv[E];
         ElemTraits<T>::unpack(cx, xv); ElemTraits<T>::unpack(cd, dv);
-        if (act != ACT_NONE) ElemTraits<T>::unpack(ca, av);
+        if (act != ACT_NONE && !recompute) ElemTraits<T>::unpack(ca, av);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
+            if (recompute) av[e] = xv[e] * sc[e] + sh[e];
             const float gq = act != ACT_NONE ? dv[e] * act_grad(av[e], act) : dv[e];
             acc[0][e] += gq; acc[1][e] += gq * (xv[e] - mu[e]) * rs[e];
         }
@@ -533,14 +542,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + o0), x1 = *reinterpret_cast<const u32x4*>(x + o1);
             const u32x4 d0 = *reinterpret_cast<const u32x4*>(da + o0), d1 = *reinterpret_cast<const u32x4*>(da + o1);
             u32x4 a0 = x0, a1 = x1;
-            if (act != ACT_NONE) { a0 = *reinterpret_cast<const u32x4*>(a + o0); a1 = *reinterpret_cast<const u32x4*>(a + o1); }
+            if (act != ACT_NONE && !recompute) { a0 = *reinterpret_cast<const u32x4*>(a + o0); a1 = *reinterpret_cast<const u32x4*>(a + o1); }
             fold(x0, d0, a0); fold(x1, d1, a1);
         }
         for (; r < r1; r += rstep) {
             const size_t o = (size_t)r * C + cc * E;
             const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + o), d0 = *reinterpret_cast<const u32x4*>(da + o);
             u32x4 a0 = x0;
-            if (act != ACT_NONE) a0 = *reinterpret_cast<const u32x4*>(a + o);
+            if (act != ACT_NONE && !recompute) a0 = *reinterpret_cast<const u32x4*>(a + o);
             fold(x0, d0, a0);
         }
     }
@@ -699,16 +708,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ da,
         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma, float* sums, unsigned* counter,
         int ncopy, float invM, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dgamma, float* __restrict__ dbeta,
-        long total_chunks, int C, int act) {
+        long total_chunks, int C, int act, const float* __restrict__ beta) {
     constexpr int E = ElemTraits<T>::ELEMS;
-    __shared__ float colsum[BN_SCRATCH_COLS], coef[3 * (BN_SCRATCH_COLS / 2)], part[256];
+    __shared__ float colsum[BN_SCRATCH_COLS], coef[5 * (BN_SCRATCH_COLS / 2)], part[256];      // [A | B | D | scale | shift]
     __shared__ int s_last;
     const int tid = threadIdx.x;
+    const bool recompute = act != ACT_NONE && a == nullptr;          // see bn_bwd_reduce_kernel
     bn_fold_copies(sums, C, ncopy, colsum, part, tid);
     for (int c = tid; c < C; c += 256) {
         const float sg = colsum[c], sgx = colsum[C + c];
         const float ca = gamma[c] * rstd[c], cb = -ca * rstd[c] * sgx * invM;
         coef[c] = ca; coef[C + c] = cb; coef[2 * C + c] = -cb * mean[c] - ca * sg * invM;
+        if (recompute) { coef[3 * C + c] = ca; coef[4 * C + c] = beta[c] - mean[c] * ca; }
         if (blockIdx.x == 0) { dgamma[c] = sgx; dbeta[c] = sg; }
     }
     __syncthreads();
@@ -720,7 +731,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __rest
         float xv[E], av[E], dv[E], gq[E], ov[E], ca[E], cb[E], cd[E];
         ElemTraits<T>::unpack(cx, xv);
         ElemTraits<T>::unpack(cdv, dv);
-        if (act != ACT_NONE) ElemTraits<T>::unpack(cav, av);
+        if (recompute) {
+            float sc[E], sh[E];
+            load_vec<E>(coef + 3 * C + c0, sc); load_vec<E>(coef + 4 * C + c0, sh);
+#pragma unroll
+            for (int e = 0; e < E; ++e) av[e] = xv[e] * sc[e] + sh[e];
+        } else if (act != ACT_NONE) ElemTraits<T>::unpack(cav, av);
         load_vec<E>(coef + c0, ca); load_vec<E>(coef + C + c0, cb); load_vec<E>(coef + 2 * C + c0, cd);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -736,13 +752,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __rest
         const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + i * E), x1 = *reinterpret_cast<const u32x4*>(x + j * E);
         const u32x4 d0 = *reinterpret_cast<const u32x4*>(da + i * E), d1 = *reinterpret_cast<const u32x4*>(da + j * E);
         u32x4 a0 = x0, a1 = x1;
-        if (act != ACT_NONE) { a0 = *reinterpret_cast<const u32x4*>(a + i * E); a1 = *reinterpret_cast<const u32x4*>(a + j * E); }
+        if (act != ACT_NONE && !recompute) { a0 = *reinterpret_cast<const u32x4*>(a + i * E); a1 = *reinterpret_cast<const u32x4*>(a + j * E); }
         finish(i, x0, d0, a0); finish(j, x1, d1, a1);
     }
     for (; i < total_chunks; i += stride) {
         const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + i * E), d0 = *reinterpret_cast<const u32x4*>(da + i * E);
         u32x4 a0 = x0;
-        if (act != ACT_NONE) a0 = *reinterpret_cast<const u32x4*>(a + i * E);
+        if (act != ACT_NONE && !recompute) a0 = *reinterpret_cast<const u32x4*>(a + i * E);
         finish(i, x0, d0, a0);
     }
     bn_release_scratch(sums, counter, ticket, tid, &s_last);
@@ -1203,10 +1219,11 @@ extern "C" int mfx_bn_train_fwd(const void* x, const void* res, void* y, const f
 }
 
 extern "C" int mfx_bn_train_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
-                                void* dx, void* dres, float* dgamma, float* dbeta, long M, int C, int act, int dtype, float* scratch,
-                                void* stream) {
-    if (!x || !da || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !scratch || (act != MFX_ACT_NONE && !a))
+                                const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, long M, int C, int act, int dtype,
+                                float* scratch, void* stream) {
+    if (!x || !da || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !scratch || (act != MFX_ACT_NONE && !a && !beta))
         return mfx_fail(MFX_ERR_ARG, "bn_train_bwd: null pointer");
+    if (act != MFX_ACT_NONE && !a && dres) return mfx_fail(MFX_ERR_ARG, "bn_train_bwd: a residual entered the activation: pass the forward output `a`");
     int rc = bn_check(C, dtype); if (rc) return rc;
     if (2 * C > BN_SCRATCH_COLS) return mfx_fail(MFX_ERR_ARG, "bn_train_bwd: C > 512");
     if (M <= 0) return mfx_fail(MFX_ERR_ARG, "bn_train_bwd: empty batch");
@@ -1216,14 +1233,14 @@ extern "C" int mfx_bn_train_bwd(const void* x, const void* a, const void* da, co
     const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
     float* sums = scratch + BN_SCRATCH_COLS;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sums, sums + C, ncopy),
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, M, C, rows, act, sums, sums + C, ncopy));
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sums, sums + C, ncopy, gamma, beta),
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, M, C, rows, act, sums, sums + C, ncopy, gamma, beta));
     MFX_HIP_CHECK(hipGetLastError());
     const long chunks = M * (C / E);
     unsigned* counter = reinterpret_cast<unsigned*>(scratch + 2 * BN_SCRATCH_COLS) + BN_TICKET_WORDS;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<float>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, gamma, sums, counter, ncopy, 1.f / (float)M, (float*)dx, (float*)dres, dgamma, dbeta, chunks, C, act),
-        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<bf16_t>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, gamma, sums, counter, ncopy, 1.f / (float)M, (bf16_t*)dx, (bf16_t*)dres, dgamma, dbeta, chunks, C, act));
+        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<float>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, gamma, sums, counter, ncopy, 1.f / (float)M, (float*)dx, (float*)dres, dgamma, dbeta, chunks, C, act, beta),
+        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<bf16_t>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, gamma, sums, counter, ncopy, 1.f / (float)M, (bf16_t*)dx, (bf16_t*)dres, dgamma, dbeta, chunks, C, act, beta));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

@@ -118,7 +118,7 @@ SYMBOLS = {
     "mfx_pack_conv_weights_batched": (_I, [_P, _P, _I, ctypes.c_longlong, _I, _P]),
     "mfx_bn_scratch_bytes": (_S, []),
     "mfx_bn_train_fwd": (_I, [_P] * 8 + [_F, _F, ctypes.c_long, _I, _I, _I, _P, _P, _P, _P]),
-    "mfx_bn_train_bwd": (_I, [_P] * 10 + [ctypes.c_long, _I, _I, _I, _P, _P]),
+    "mfx_bn_train_bwd": (_I, [_P] * 11 + [ctypes.c_long, _I, _I, _I, _P, _P]),
     "mfx_bn_bwd_reduce": (_I, [_P] * 7 + [ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_bwd_apply": (_I, [_P] * 10 + [ctypes.c_long, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_maxpool2x2_bwd_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -179,6 +179,40 @@ def test_bn_two_launch_form_reuses_its_scratch(C, shape, dt):
     assert float(AG._bn_scratch(bn_a.weight).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("act", ["relu", "leaky"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_bn_backward_recomputes_the_activation_sign_from_its_input(act, dt):
+    """Without a residual the BN backward does not read the forward output: the sign of x*scale + shift is recomputed with the
+    forward's expression.  Same gradients as the form that reads the stored output (bitwise for the data gradient's ReLU mask)."""
+    from monoflex_amd import autograd as AG
+    from monoflex_amd import lib as L
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(11)
+    C = 128
+    x = (torch.randn(4, 24, 40, C, generator=g) * 1.5 + 0.2).to(DEV).to(dtype)
+    r = torch.randn(4, 24, 40, C, generator=g).to(DEV).to(dtype)
+    bn = torch.nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g) * 0.5)
+    code = {"relu": L.ACT_RELU, "leaky": L.ACT_LEAKY}[act]
+    out = []
+    for read_output in (False, True):
+        AG._BN_READ_OUTPUT[0] = read_output
+        try:
+            xd = x.clone().requires_grad_()
+            bn.zero_grad()
+            y = AG.bn_act(xd, bn, code)
+            y.backward(r)
+            out.append((xd.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), y.detach().clone()))
+        finally:
+            AG._BN_READ_OUTPUT[0] = False
+    (dx0, dg0, db0, y0), (dx1, dg1, db1, y1) = out
+    tol = 1e-2 if dt == "bf16" else 2e-5                               # two runs differ by the summation order of the statistics' atomics
+    assert _rel(y0.float(), y1.float()) < tol
+    assert _rel(dg0, dg1) < 1e-4 and _rel(db0, db1) < 1e-4
+    assert _rel(dx0.float(), dx1.float()) < tol
+
+
 def test_maxpool_and_upsample_grads():
     from monoflex_amd import autograd as AG
     g = torch.Generator().manual_seed(5)

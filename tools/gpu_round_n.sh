@@ -1,5 +1,2 @@
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-for o in 1 0 1 0; do
-cd /tmp && rm -rf /tmp/p_h && timeout 120 rocprofv3 --kernel-trace --stats -d /tmp/p_h -o r -- python $R/bench.py --no-cpu-baseline --steps 20 --opts heads_planes=$o > /tmp/b.log 2>&1
-cd $R; DB=$(find /tmp/p_h -name "*.db" | head -1); echo "planes=$o $(tail -1 /tmp/b.log | cut -c160-215)"; python tools/prof_summary.py $DB | grep -E "heads_fused" | cut -c1-110
-done
+timeout 600 python -m pytest tests/test_gpu_train.py -x -q -k "bn" 2>&1 | grep -E "Error|assert|FAILED|passed|failed" | head -12
+timeout 1200 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_step.py -x -q -k "network or graphed or train_steps or oracle or ddp" > gpurun_out/t3.log 2>&1; grep -E "passed|failed|FAILED" gpurun_out/t3.log | tail -3
