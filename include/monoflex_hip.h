@@ -336,7 +336,8 @@ int mfx_focal_loss(const float* logits_nhwc, const float* heat_nchw, int B, int 
  *         depth / center / 02 / 13 / lower / hard / soft / mean MAE)
  *   G     fp32 [N][MFX_OBJ_TERMS][64] (overwritten): d(term)/d(channel) at the object's pixel
  * mfx_object_loss_backward ADDS sum_t gout[t] * G[n][t][c] into dreg (same geometry as reg; the caller zero-fills it): objects
- * sharing a centre pixel accumulate, as the gather's backward does. */
+ * sharing a centre pixel accumulate, as the gather's backward does.
+ * B = 0 selects the GATHERED form: reg / dreg are [N][ld] tables, row n belonging to object row n (mfx_head_sparse_fwd's output). */
 #define MFX_OBJ_ROW 72
 #define MFX_OBJ_TERMS 10
 #define MFX_OBJ_VALUES 24
@@ -357,6 +358,38 @@ int mfx_object_loss(const float* reg_nhwc, int B, int H, int W, int ld, int ch_o
                     const mfx_object_loss_cfg* cfg, float* vals, float* G, void* stream);
 int mfx_object_loss_backward(const float* G, const float* gout_terms, const float* rows, int N, int B, int H, int W,
                              float* dreg_nhwc, int ld, int ch_off, void* stream);
+
+/* Regression branches of the training step evaluated at the object centres only (csrc/head_sparse.hip; reference
+ * model/head/detector_predictor.py:125-169 + the gather of model/layers/utils.py:120-145).  Per branch i: y[i] = the dense trunk
+ * conv output (B,H,W,256) in `dtype`, mean/rstd = its batch statistics, gamma/beta = the ABN parameters, w2 (k,256) / b2 (k) = the
+ * stacked 1x1 heads.  rows = the object table of mfx_object_loss (valid flag, image, centre).
+ *   forward : out[n][out_off[i] + j] for every row (zeros for empty slots), out fp32 [N][ld_out]
+ *   backward: dout [N][ld_out] -> dx[i] (dense, overwritten, `dtype`), sums[i] = [sum g | sum g*xhat] (= dbeta | dgamma),
+ *             dw2[i] (k,256), db2[i] (k) fp32.  sums / dw2 / db2 of all branches must lie inside ONE buffer `arena` (zero-filled
+ *             by the call); g = scratch fp32 [nbranch][N][256]. */
+#define MFX_HEAD_MAX_BRANCH 8
+typedef struct mfx_head_sparse_desc {
+    int nbranch, N, B, H, W, C, dtype, ld_out;
+    const float* rows;
+    const void* y[MFX_HEAD_MAX_BRANCH];
+    const float* mean[MFX_HEAD_MAX_BRANCH]; const float* rstd[MFX_HEAD_MAX_BRANCH];
+    const float* gamma[MFX_HEAD_MAX_BRANCH]; const float* beta[MFX_HEAD_MAX_BRANCH];
+    const float* w2[MFX_HEAD_MAX_BRANCH]; const float* b2[MFX_HEAD_MAX_BRANCH];
+    int k[MFX_HEAD_MAX_BRANCH], out_off[MFX_HEAD_MAX_BRANCH];
+    float* out;
+    const float* dout;
+    float* g;
+    float* sums[MFX_HEAD_MAX_BRANCH]; float* dw2[MFX_HEAD_MAX_BRANCH]; float* db2[MFX_HEAD_MAX_BRANCH];
+    void* dx[MFX_HEAD_MAX_BRANCH];
+    void* arena; size_t arena_bytes;
+} mfx_head_sparse_desc;
+int mfx_head_sparse_fwd(const mfx_head_sparse_desc* d, void* stream);
+int mfx_head_sparse_bwd(const mfx_head_sparse_desc* d, void* stream);
+/* Batch statistics of a train-mode BN without applying it: mean / rstd (C floats each), running statistics and
+ * num_batches_tracked updated as mfx_bn_train_fwd does; `scratch` as there (zero before, zero after). */
+int mfx_bn_train_stats(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       long long* num_batches_tracked, float momentum, float eps, long M, int C, int dtype, float* scratch,
+                       float* mean, float* rstd, void* stream);
 
 /* ---- (4) input pipeline: KITTI sample -> network input + training targets, on the device ------------------------------
  * Replaces the per-sample numpy/PIL work of the reference's dataset (data/datasets/kitti.py:231-525 __getitem__,

@@ -597,7 +597,12 @@ class ObjectLossFn(Function):
         if reg.dtype != torch.float32 or rows.dtype != torch.float32:
             raise TypeError("object loss: fp32 regression map and fp32 target rows")
         rows = _c(rows)
-        B, H, W, ld = reg.shape
+        if reg.dim() == 2:                                     # gathered table (N, ld): the kernels' B = 0 form
+            if reg.shape[0] != rows.shape[0]:
+                raise ValueError("object loss: a gathered table needs one row per object row")
+            B, H, W, ld = 0, 1, reg.shape[0], reg.shape[1]
+        else:
+            B, H, W, ld = reg.shape
         N = rows.shape[0]
         vals = torch.empty(L.OBJ_VALUES, dtype=torch.float32, device=reg.device)
         G = torch.empty(N, L.OBJ_TERMS, 64, dtype=torch.float32, device=reg.device)
@@ -614,11 +619,94 @@ class ObjectLossFn(Function):
     def backward(ctx, g_terms, g_logged):
         G, rows = ctx.saved_tensors
         B, H, W, ld, ch_off = ctx.geom
-        dreg = torch.zeros(B, H, W, ld, dtype=torch.float32, device=G.device)
+        dreg = torch.zeros((W, ld) if B == 0 else (B, H, W, ld), dtype=torch.float32, device=G.device)
         g = _c(g_terms.float())
         L.check(L.load().mfx_object_loss_backward(_ptr(G), _ptr(g), _ptr(rows), rows.shape[0], B, H, W, _ptr(dreg), ld, ch_off, _stream()),
                 "mfx_object_loss_backward")
         return dreg, None, None, None
+
+
+@_device_guarded
+class SparseRegHeadsFn(Function):
+    """Regression branches of the training step at the object centres only (csrc/head_sparse.hip): per branch the dense trunk
+    conv output y (B,H,W,256), its ABN holder and the stacked 1x1 heads (w2 (k,256[,1,1]), b2 (k)) -> out fp32 [N][ld_out], row n
+    = object row n of `rows`, branch i at columns [offs[i], offs[i]+k_i).  The ABN's batch statistics are taken over the dense
+    map (running statistics and num_batches_tracked move as in bn_act); backward is one dense pass per branch."""
+
+    @staticmethod
+    def forward(ctx, rows, abns, offs, ld_out, *ts):
+        nb = len(abns)
+        ys, gammas, betas, w2s, b2s = (ts[i * nb:(i + 1) * nb] for i in range(5))
+        ys = [_c(y) for y in ys]
+        y0 = ys[0]
+        B, H, W, C = y0.shape
+        lib_ = L.load()
+        d = L.HeadSparseDesc()
+        d.nbranch, d.N, d.B, d.H, d.W, d.C, d.dtype, d.ld_out = nb, rows.shape[0], B, H, W, C, _dt(y0.dtype), ld_out
+        rows = _c(rows)
+        d.rows = rows.data_ptr()
+        keep = []
+        stats = torch.empty(nb, 2, C, dtype=torch.float32, device=y0.device)              # mean | rstd per branch
+        for i, abn in enumerate(abns):
+            g32, b32 = _c(gammas[i].detach().float()), _c(betas[i].detach().float())
+            w2 = _c(w2s[i].detach().float().reshape(w2s[i].shape[0], C))
+            b2 = _c(b2s[i].detach().float()) if b2s[i] is not None else None
+            mom = abn.momentum if abn.momentum is not None else 0.1
+            nbt = abn.num_batches_tracked if (abn.track_running_stats and abn.num_batches_tracked is not None
+                                              and abn.num_batches_tracked.dtype == torch.int64) else None
+            L.check(lib_.mfx_bn_train_stats(_ptr(ys[i]), _ptr(g32), _ptr(b32), _ptr(abn.running_mean), _ptr(abn.running_var), _ptr(nbt),
+                                            ctypes.c_float(mom), ctypes.c_float(abn.eps), B * H * W, C, _dt(y0.dtype), _ptr(_bn_scratch(gammas[i])),
+                                            _ptr(stats[i, 0]), _ptr(stats[i, 1]), _stream()), "mfx_bn_train_stats")
+            d.y[i], d.mean[i], d.rstd[i] = ys[i].data_ptr(), stats[i, 0].data_ptr(), stats[i, 1].data_ptr()
+            d.gamma[i], d.beta[i], d.w2[i], d.b2[i] = g32.data_ptr(), b32.data_ptr(), w2.data_ptr(), (b2.data_ptr() if b2 is not None else None)
+            d.k[i], d.out_off[i] = w2.shape[0], offs[i]
+            keep += [g32, b32, w2, b2]
+        out = torch.zeros(rows.shape[0], ld_out, dtype=torch.float32, device=y0.device)
+        d.out = out.data_ptr()
+        L.check(lib_.mfx_head_sparse_fwd(ctypes.byref(d), _stream()), "mfx_head_sparse_fwd")
+        ctx.save_for_backward(rows, stats, *ys, *[t for t in keep if t is not None])
+        ctx.meta = (nb, offs, ld_out, [w.shape for w in w2s], [b is not None for b in b2s], [w.shape[0] for w in w2s])
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        nb, offs, ld_out, wshapes, has_b, ks = ctx.meta
+        saved = list(ctx.saved_tensors)
+        rows, stats = saved[0], saved[1]
+        ys = saved[2:2 + nb]
+        rest = saved[2 + nb:]
+        B, H, W, C = ys[0].shape
+        dev = ys[0].device
+        d = L.HeadSparseDesc()
+        d.nbranch, d.N, d.B, d.H, d.W, d.C, d.dtype, d.ld_out = nb, rows.shape[0], B, H, W, C, _dt(ys[0].dtype), ld_out
+        d.rows = rows.data_ptr()
+        dout = _c(dout.float())
+        d.dout = dout.data_ptr()
+        sizes = [2 * C + k * C + k for k in ks]
+        arena = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        g = torch.empty(nb, rows.shape[0], C, dtype=torch.float32, device=dev)
+        d.g, d.arena, d.arena_bytes = g.data_ptr(), arena.data_ptr(), arena.numel() * 4
+        dxs, sums, dw2s, db2s, o, r = [], [], [], [], 0, 0
+        for i in range(nb):
+            g32, b32, w2 = rest[r], rest[r + 1], rest[r + 2]
+            r += 3
+            b2 = None
+            if has_b[i]:
+                b2 = rest[r]; r += 1
+            k = ks[i]
+            sm, dw, db = arena[o:o + 2 * C], arena[o + 2 * C:o + 2 * C + k * C], arena[o + 2 * C + k * C:o + sizes[i]]
+            o += sizes[i]
+            dx = torch.empty_like(ys[i])
+            d.y[i], d.mean[i], d.rstd[i] = ys[i].data_ptr(), stats[i, 0].data_ptr(), stats[i, 1].data_ptr()
+            d.gamma[i], d.beta[i], d.w2[i], d.b2[i] = g32.data_ptr(), b32.data_ptr(), w2.data_ptr(), (b2.data_ptr() if b2 is not None else None)
+            d.k[i], d.out_off[i] = k, offs[i]
+            d.sums[i], d.dw2[i], d.db2[i], d.dx[i] = sm.data_ptr(), dw.data_ptr(), db.data_ptr(), dx.data_ptr()
+            dxs.append(dx); sums.append(sm); dw2s.append(dw.view(wshapes[i])); db2s.append(db if has_b[i] else None)
+        L.check(L.load().mfx_head_sparse_bwd(ctypes.byref(d), _stream()), "mfx_head_sparse_bwd")
+        dgammas = [sm[C:] for sm in sums]
+        dbetas = [sm[:C] for sm in sums]
+        return (None, None, None, None, *dxs, *dgammas, *dbetas, *dw2s, *db2s)
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, out_dtype=None):

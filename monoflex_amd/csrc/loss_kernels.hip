@@ -82,7 +82,9 @@ struct PixelReader {                                        // channel ch of the
     __device__ Dual operator()(int ch) const { return Dual{p[ch], ch == seed ? 1.f : 0.f}; }
 };
 
-__device__ __forceinline__ const float* object_pixel(const float* base, const float* t, int B, int H, int W, int ld, int ch_off) {
+// dense map: the row's (image, centre) pixel.  B == 0: `base` is already the gathered table, one row of `ld` floats per object row n
+__device__ __forceinline__ const float* object_pixel(const float* base, const float* t, int n, int B, int H, int W, int ld, int ch_off) {
+    if (B == 0) return base + (size_t)n * ld + ch_off;
     const int b = min(max((int)t[R_B], 0), B - 1), cx = min(max((int)t[R_CX], 0), W - 1), cy = min(max((int)t[R_CY], 0), H - 1);
     return base + ((size_t)(b * H + cy) * W + cx) * ld + ch_off;
 }
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(64) void object_loss_kernel(const float* __restrict
         for (int off = 32; off > 0; off >>= 1) cn[i] += __shfl_xor(cn[i], off);
     const float* t = rows + (size_t)n * ROW;
     Dual out[NVAL];
-    const PixelReader X{object_pixel(reg, t, B, H, W, ld, ch_off), lane};
+    const PixelReader X{object_pixel(reg, t, n, B, H, W, ld, ch_off), lane};
     object_terms(X, t, c, cn, out);
 #pragma unroll
     for (int k = 0; k < NTERM; ++k) G[((size_t)n * NTERM + k) * 64 + lane] = out[k].d;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64) void object_loss_bwd_kernel(const float* __rest
     float g = 0.f;
 #pragma unroll
     for (int k = 0; k < NTERM; ++k) g += gout[k] * G[((size_t)n * NTERM + k) * 64 + lane];
-    float* p = const_cast<float*>(object_pixel(dreg, t, B, H, W, ld, ch_off));
+    float* p = const_cast<float*>(object_pixel(dreg, t, n, B, H, W, ld, ch_off));
     unsafeAtomicAdd(p + lane, g);
 }
 
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(64) void object_loss_bwd_kernel(const float* __rest
 extern "C" int mfx_object_loss(const float* reg_nhwc, int B, int H, int W, int ld, int ch_off, const float* rows, int N,
                                const mfx_object_loss_cfg* cfg, float* vals, float* G, void* stream) {
     if (!reg_nhwc || !rows || !cfg || !vals || !G) return mfx_fail(MFX_ERR_ARG, "object_loss: null pointer");
-    if (B < 1 || H < 1 || W < 1 || N < 0 || ch_off < 0 || ch_off + 50 > ld) return mfx_fail(MFX_ERR_ARG, "object_loss: bad sizes");
+    if (B < 0 || (B > 0 && (H < 1 || W < 1)) || N < 0 || ch_off < 0 || ch_off + 50 > ld) return mfx_fail(MFX_ERR_ARG, "object_loss: bad sizes");
     for (int i = 0; i < 9; ++i)
         if (cfg->ch[i] < 0 || cfg->ch[i] >= 50) return mfx_fail(MFX_ERR_ARG, "object_loss: channel offset outside the 50 regression channels");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -146,7 +148,7 @@ extern "C" int mfx_object_loss(const float* reg_nhwc, int B, int H, int W, int l
 extern "C" int mfx_object_loss_backward(const float* G, const float* gout_terms, const float* rows, int N, int B, int H, int W,
                                         float* dreg_nhwc, int ld, int ch_off, void* stream) {
     if (!G || !gout_terms || !rows || !dreg_nhwc) return mfx_fail(MFX_ERR_ARG, "object_loss_backward: null pointer");
-    if (B < 1 || H < 1 || W < 1 || N < 0 || ch_off < 0 || ch_off + 50 > ld) return mfx_fail(MFX_ERR_ARG, "object_loss_backward: bad sizes");
+    if (B < 0 || (B > 0 && (H < 1 || W < 1)) || N < 0 || ch_off < 0 || ch_off + 50 > ld) return mfx_fail(MFX_ERR_ARG, "object_loss_backward: bad sizes");
     if (N == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(object_loss_bwd_kernel, dim3(N), dim3(64), 0, st, G, gout_terms, rows, B, H, W, dreg_nhwc, ld, ch_off);

@@ -1218,6 +1218,47 @@ extern "C" int mfx_bn_train_fwd(const void* x, const void* res, void* y, const f
     return MFX_OK;
 }
 
+// statistics only (the sparse regression heads apply the BN themselves, at the object pixels): fold the copies, finalize, clear
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(float* sums, int ncopy, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* running_mean, float* running_var, long long* nbt, float momentum, float eps,
+                                                                float inv_count, float unbias, float* __restrict__ mean_out, float* __restrict__ rstd_out, int C) {
+    __shared__ float colsum[BN_SCRATCH_COLS], part[256];
+    const int tid = threadIdx.x;
+    bn_fold_copies(sums, C, ncopy, colsum, part, tid);
+    for (int c = tid; c < C; c += 256) {
+        const float m = colsum[c] * inv_count;
+        const float v = fmaxf(colsum[C + c] * inv_count - m * m, 0.f);
+        mean_out[c] = m; rstd_out[c] = rsqrtf(v + eps);
+        if (running_mean) {
+            running_mean[c] = running_mean[c] * (1.f - momentum) + m * momentum;
+            running_var[c] = running_var[c] * (1.f - momentum) + v * unbias * momentum;
+        }
+    }
+    if (tid == 0 && nbt) *nbt += 1;
+    __syncthreads();
+    for (int i = tid; i < BN_SCRATCH_COLS; i += 256) sums[i] = 0.f;
+}
+
+extern "C" int mfx_bn_train_stats(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  long long* num_batches_tracked, float momentum, float eps, long M, int C, int dtype, float* scratch,
+                                  float* mean, float* rstd, void* stream) {
+    if (!x || !gamma || !beta || !scratch || !mean || !rstd) return mfx_fail(MFX_ERR_ARG, "bn_train_stats: null pointer");
+    if ((running_mean == nullptr) != (running_var == nullptr)) return mfx_fail(MFX_ERR_ARG, "bn_train_stats: running_mean/var must come together");
+    int rc = bn_check(C, dtype); if (rc) return rc;
+    if (2 * C > BN_SCRATCH_COLS || M <= 0) return mfx_fail(MFX_ERR_ARG, "bn_train_stats: C > 512 or empty batch");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int E = dtype == MFX_BF16 ? 8 : 4, ncopy = bn_ncopy(C);
+    const int rows = bn_rows_per_block(M, C, dtype);
+    const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, scratch, scratch + C, ncopy),
+                      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, scratch, scratch + C, ncopy));
+    const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, ncopy, gamma, beta, running_mean, running_var, num_batches_tracked,
+                       momentum, eps, (float)(1.0 / (double)M), unbias, mean, rstd, C);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
 extern "C" int mfx_bn_train_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
                                 const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, long M, int C, int act, int dtype,
                                 float* scratch, void* stream) {

@@ -71,6 +71,16 @@ class PackDesc(ctypes.Structure):                               # mfx_pack_desc
         [(n, c_int) for n in ("Cout", "Cin", "kh", "kw", "mode", "rows_pad", "K_pad", "ck")]
 
 
+HEAD_MAX_BRANCH = 8
+
+
+class HeadSparseDesc(ctypes.Structure):                         # mfx_head_sparse_desc
+    _fields_ = [(n, c_int) for n in ("nbranch", "N", "B", "H", "W", "C", "dtype", "ld_out")] + [("rows", c_void_p)] + \
+        [(n, c_void_p * HEAD_MAX_BRANCH) for n in ("y", "mean", "rstd", "gamma", "beta", "w2", "b2")] + \
+        [("k", c_int * HEAD_MAX_BRANCH), ("out_off", c_int * HEAD_MAX_BRANCH), ("out", c_void_p), ("dout", c_void_p), ("g", c_void_p)] + \
+        [(n, c_void_p * HEAD_MAX_BRANCH) for n in ("sums", "dw2", "db2", "dx")] + [("arena", c_void_p), ("arena_bytes", c_size_t)]
+
+
 OBJ_ROW, OBJ_TERMS, OBJ_VALUES = 72, 10, 24                    # MFX_OBJ_ROW / MFX_OBJ_TERMS / MFX_OBJ_VALUES
 
 
@@ -116,6 +126,9 @@ SYMBOLS = {
     "mfx_stem_wgrad_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
     "mfx_pack_chunk_elems": (_I, []),
     "mfx_pack_conv_weights_batched": (_I, [_P, _P, _I, ctypes.c_longlong, _I, _P]),
+    "mfx_head_sparse_fwd": (_I, [ctypes.POINTER(HeadSparseDesc), _P]),
+    "mfx_head_sparse_bwd": (_I, [ctypes.POINTER(HeadSparseDesc), _P]),
+    "mfx_bn_train_stats": (_I, [_P] * 6 + [_F, _F, ctypes.c_long, _I, _I, _P, _P, _P, _P]),
     "mfx_bn_scratch_bytes": (_S, []),
     "mfx_bn_train_fwd": (_I, [_P] * 8 + [_F, _F, ctypes.c_long, _I, _I, _I, _P, _P, _P, _P]),
     "mfx_bn_train_bwd": (_I, [_P] * 11 + [ctypes.c_long, _I, _I, _I, _P, _P]),

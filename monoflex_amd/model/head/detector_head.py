@@ -25,7 +25,18 @@ class Detect_Head(nn.Module):
         """Head maps of an evaluation batch -> decoded (N,14) rows per image plus the decode by-products."""
         return self.post_processor(maps, targets, test=test, features=features)
 
+    sparse_regression = True       # training on the device: regression branches evaluated at the object centres only
+
     def forward(self, features, targets=None, test=False):
+        if self.training and self.sparse_regression and features.is_cuda and self.loss_evaluator.fused_object_loss \
+                and self.loss_evaluator.object_loss_cfg() is not None:
+            prepared = targets if isinstance(targets, tuple) else getattr(targets, "loss", None)
+            if prepared is None:
+                prepared = self.loss_evaluator.prepare_targets(targets, features.device)
+            rows = prepared[1].get("object_rows")
+            if rows is not None:
+                maps = self.predictor(features, targets, object_rows=rows.to(features.device))
+                return self.loss_evaluator(maps, prepared)
         maps = self.predictor(features, targets)
         return self.losses(maps, targets) if self.training else self.detections(maps, targets, test, features)
 

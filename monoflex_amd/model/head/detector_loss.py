@@ -357,8 +357,11 @@ class Loss_Computation:
             rows = self.pack_objects(tv)
         if cfg is None or rows is None:
             raise NotImplementedError("fused object loss: 4 orientation bins, 10 keypoints, a depth range")
-        reg = predictions['reg'].permute(0, 2, 3, 1)                              # the predictor's NHWC map: a view
-        terms, logged = AG.ObjectLossFn.apply(reg.float(), rows.to(dev), cfg, 0)
+        if predictions.get('reg') is None:
+            terms, logged = AG.ObjectLossFn.apply(predictions['reg_rows'].float(), rows.to(dev), cfg, 0)      # (N,50): row n = object row n
+        else:
+            reg = predictions['reg'].permute(0, 2, 3, 1)                          # the predictor's NHWC map: a view
+            terms, logged = AG.ObjectLossFn.apply(reg.float(), rows.to(dev), cfg, 0)
         t = terms.unbind(0)
         loss_dict = {'hm_loss': self._heat_term(predictions, heat, dev), 'bbox_loss': t[0], 'dims_loss': t[5], 'orien_loss': t[4],
                      'offset_loss': t[2]}
@@ -379,10 +382,12 @@ class Loss_Computation:
         return loss_dict, logs
 
     def __call__(self, predictions, targets):
-        dev = predictions['reg'].device
+        dev = (predictions['reg'] if predictions.get('reg') is not None else predictions['reg_rows']).device
         prepared = targets if isinstance(targets, tuple) else getattr(targets, "loss", None)
         heat, tv = prepared if prepared is not None else self.prepare_targets(targets, dev)
         W = self.loss_weights
+        if predictions.get('reg') is None:                         # the predictor handed over the gathered regression table
+            return self._fused(predictions, heat, tv, dev)
         if predictions['reg'].is_cuda and self.fused_object_loss and self.object_loss_cfg() is not None \
                 and (tv.get("object_rows") is not None or tv["keypoints"].shape[-2] == 10):
             return self._fused(predictions, heat, tv, dev)          # else: the tensor-op form below (same device, ~900 launches)

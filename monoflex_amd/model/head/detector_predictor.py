@@ -195,18 +195,30 @@ class _predictor(nn.Module):
                 ops.edge_scatter_add(hm, choff, cout, o, edge_indices, edge_lens, planar=planar if choff == 0 else None)
         return hm
 
-    def forward_train(self, features, edge_indices=None, edge_lens=None):
+    def forward_train(self, features, edge_indices=None, edge_lens=None, object_rows=None):
         """Training form (detector_predictor.py:125-169), unfused and differentiable: per branch
         conv3x3 -> ABN(batch statistics, leaky 0.01) -> one 1x1 conv over the branch's stacked heads; edge fusion
-        gathers the two trunks at the border points.  Returns (class logits (B,H,W,ncls), regression (B,H,W,50))."""
+        gathers the two trunks at the border points.  Returns (class logits (B,H,W,ncls), regression (B,H,W,50)).
+
+        With `object_rows` (the loss's packed object table, fp32 [N,72]) the regression branches whose activation nothing else
+        reads are evaluated at the object centres only (csrc/head_sparse.hip) and the second result is the GATHERED table
+        (N,50) -- the rows select_point_of_interest would pick (layers/utils.py:120-145); the class head (dense focal loss) and
+        the 3d_offset head (edge fusion reads its trunk) keep the dense path."""
         B, H, W, _ = features.shape
         trunks = [self.class_head] + list(self.reg_features)
         lasts = [[self.class_head[2]]] + [list(h) for h in self.reg_heads]
-        feats, outs = [], []
-        for t, heads in zip(trunks, lasts):
-            f = AG.bn_act(AG.conv2d(features, t[0].weight, None, 1, 1), t[1], L.ACT_LEAKY)
+        oi = self.offset_index[0]
+        sparse = object_rows is not None
+        feats, outs, sp = [], [], []
+        for bi, (t, heads) in enumerate(zip(trunks, lasts)):
             w = heads[0].weight if len(heads) == 1 else torch.cat([h.weight for h in heads], 0)
             b = heads[0].bias if len(heads) == 1 else torch.cat([h.bias for h in heads], 0)
+            y = AG.conv2d(features, t[0].weight, None, 1, 1)
+            if sparse and bi != 0 and bi - 1 != oi:
+                sp.append((bi - 1, y, t[1], w, b))
+                feats.append(None); outs.append(None)
+                continue
+            f = AG.bn_act(y, t[1], L.ACT_LEAKY)
             feats.append(f)
             outs.append(AG.conv2d(f, w, b, 1, 0, out_dtype=torch.float32))
         cls, regs = outs[0], outs[1:]
@@ -237,12 +249,28 @@ class _predictor(nn.Module):
                     add = torch.nn.functional.pad(add, (lo, base.shape[-1] - lo - co))
                 new.append(base + add)
             cls, regs[oi] = new[0], new[1]
-        return cls, torch.cat(regs, dim=3)
+        if not sparse:
+            return cls, torch.cat(regs, dim=3)
+        # gathered regression table in the reference's channel order
+        starts = [sum(sum(c) for c in self.regression_channel_cfg[:i]) for i in range(len(self.regression_channel_cfg))]
+        rows = object_rows
+        tab = AG.SparseRegHeadsFn.apply(rows, tuple(a for _, _, a, _, _ in sp), tuple(starts[i] for i, _, _, _, _ in sp), 50,
+                                        *[y for _, y, _, _, _ in sp], *[a.weight for _, _, a, _, _ in sp], *[a.bias for _, _, a, _, _ in sp],
+                                        *[w for _, _, _, w, _ in sp], *[b for _, _, _, _, b in sp])
+        bidx, cx, cy = rows[:, 57].long().clamp(0, B - 1), rows[:, 2].long().clamp(0, W - 1), rows[:, 3].long().clamp(0, H - 1)
+        lo, n_off = starts[oi], sum(self.regression_channel_cfg[oi])
+        off_rows = regs[oi][bidx, cy, cx][:, :n_off]                                   # the dense 3d_offset head at the centres
+        return cls, torch.cat((tab[:, :lo], off_rows, tab[:, lo + n_off:]), dim=1)
 
-    def forward(self, features, targets):
-        """Reference surface: features (B,64,H,W) (any strides) + targets -> {'cls','reg'} NCHW views."""
+    def forward(self, features, targets, object_rows=None):
+        """Reference surface: features (B,64,H,W) (any strides) + targets -> {'cls','reg'} NCHW views.  Training with
+        `object_rows` (see forward_train): {'cls', 'reg_rows' (N,50), 'cls_logits_nhwc'} -- what the loss reads, no dense 'reg'."""
         x = features.permute(0, 2, 3, 1).contiguous()
         ei, el = getattr(targets, "edge", None) or stack_edge_fields(targets, x.device)
+        if self.training and object_rows is not None:
+            logits, reg_rows = self.forward_train(x, ei, el, object_rows)
+            cls = torch.sigmoid(logits.detach()).clamp(min=1e-4, max=1 - 1e-4)
+            return {'cls': cls.permute(0, 3, 1, 2), 'reg': None, 'reg_rows': reg_rows, 'cls_logits_nhwc': logits}
         if self.training:
             logits, reg = self.forward_train(x, ei, el)
             # 'cls' keeps the reference's contract (sigmoid_hm of the logits, NCHW); the loss uses the raw NHWC logits and does

@@ -213,6 +213,70 @@ def test_bn_backward_recomputes_the_activation_sign_from_its_input(act, dt):
     assert _rel(dx0.float(), dx1.float()) < tol
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_sparse_regression_heads_function_vs_torch(dt):
+    """SparseRegHeadsFn (csrc/head_sparse.hip) against torch: train-mode BN over the dense trunk map + leaky(0.01) + 1x1 heads,
+    gathered at the object centres (duplicate centres, empty slots), output rows and every gradient (trunk map, ABN weight /
+    bias, 1x1 weights / biases) for a random upstream gradient."""
+    from monoflex_amd import autograd as AG
+    from monoflex_amd.model.head.detector_predictor import InPlaceABN
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(23)
+    B, H, W, C, N = 2, 12, 20, 256, 16
+    ks, offs = (4, 20, 3), (0, 6, 26)
+    rows = torch.zeros(N, 72)
+    rows[:, 0] = (torch.rand(N, generator=g) > 0.25).float()
+    rows[:, 57] = torch.randint(0, B, (N,), generator=g).float()
+    rows[:, 2] = torch.randint(0, W, (N,), generator=g).float()
+    rows[:, 3] = torch.randint(0, H, (N,), generator=g).float()
+    rows[3] = rows[5]; rows[3, 0] = rows[5, 0] = 1.0                      # two objects on one pixel
+    dout = torch.randn(N, 50, generator=g)
+    ys = [(torch.randn(B, H, W, C, generator=g) * 1.3 + 0.2).to(dtype) for _ in ks]
+    abns_r, w2s, b2s = [], [], []
+    for k in ks:
+        m = torch.nn.BatchNorm2d(C)
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(C, generator=g) + 0.5); m.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        abns_r.append(m)
+        w2s.append(torch.randn(k, C, 1, 1, generator=g) * 0.1)
+        b2s.append(torch.randn(k, generator=g) * 0.1)
+    # torch reference (fp32 on the rounded inputs)
+    ref_in = [y.float().clone().requires_grad_() for y in ys]
+    ref_w = [w.clone().requires_grad_() for w in w2s]
+    ref_b = [b.clone().requires_grad_() for b in b2s]
+    bi, cy, cx, valid = rows[:, 57].long(), rows[:, 3].long(), rows[:, 2].long(), rows[:, 0]
+    tot = 0
+    outs_ref = []
+    for i, k in enumerate(ks):
+        a = F.leaky_relu(abns_r[i](ref_in[i].permute(0, 3, 1, 2)), 0.01)
+        o = F.conv2d(a, ref_w[i], ref_b[i]).permute(0, 2, 3, 1)[bi, cy, cx] * valid[:, None]
+        outs_ref.append(o)
+        tot = tot + (o * dout[:, offs[i]:offs[i] + k]).sum()
+    tot.backward()
+    # device
+    abns_d = []
+    for m in abns_r:
+        h = InPlaceABN(C)
+        h.load_state_dict({k: v for k, v in torch.nn.BatchNorm2d(C).state_dict().items()})
+        with torch.no_grad():
+            h.weight.copy_(m.weight); h.bias.copy_(m.bias)
+        abns_d.append(h.to(DEV))
+    yd = [y.to(DEV).requires_grad_() for y in ys]
+    wd = [w.to(DEV).requires_grad_() for w in w2s]
+    bd = [b.to(DEV).requires_grad_() for b in b2s]
+    out = AG.SparseRegHeadsFn.apply(rows.to(DEV), tuple(abns_d), offs, 50, *yd, *[h.weight for h in abns_d], *[h.bias for h in abns_d], *wd, *bd)
+    (out * dout.to(DEV)).sum().backward()
+    tol = 3e-2 if dt == "bf16" else 2e-4
+    for i, k in enumerate(ks):
+        assert _rel(out[:, offs[i]:offs[i] + k].cpu(), outs_ref[i].detach()) < tol, i
+        assert _rel(yd[i].grad.float().cpu(), ref_in[i].grad) < tol, (i, _rel(yd[i].grad.float().cpu(), ref_in[i].grad))
+        assert _rel(abns_d[i].weight.grad.cpu(), abns_r[i].weight.grad) < tol and _rel(abns_d[i].bias.grad.cpu(), abns_r[i].bias.grad) < tol, i
+        assert _rel(wd[i].grad.cpu(), ref_w[i].grad) < tol and _rel(bd[i].grad.cpu(), ref_b[i].grad) < tol, i
+        assert _rel(abns_d[i].running_var.cpu(), abns_r[i].running_var) < 1e-3 and int(abns_d[i].num_batches_tracked) == 1
+    unused = [c for c in range(50) if not any(o <= c < o + k for o, k in zip(offs, ks))]
+    assert float(out[:, unused].abs().max()) == 0.0 and float(out[rows[:, 0] == 0].abs().max()) == 0.0
+
+
 def test_maxpool_and_upsample_grads():
     from monoflex_amd import autograd as AG
     g = torch.Generator().manual_seed(5)

@@ -123,6 +123,48 @@ def test_graphed_train_step_equals_the_eager_step(split, nccl_world1):
     assert np.isfinite(float(step()))
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_regression_heads_at_object_centres_equal_the_dense_heads(dtype):
+    """csrc/head_sparse.hip: seven regression branches evaluated (and differentiated) at the object centres only, against the
+    dense conv1x1 + BN + gather path of the SAME head on the SAME backbone features: the 11 losses, the gradient handed to the
+    backbone, the gradients of every head parameter, and the ABN running statistics.  (Same features on purpose: the loss of a
+    randomly initialised network has kinks -- ReLU'd keypoint heights over an epsilon, clamped depths -- so two runs of the
+    whole network, whose BN statistics differ by their atomics' summation order, can land on different sides of one and differ
+    by 10 % in a single uncertainty branch's gradient whichever head path is used.)"""
+    import copy
+    m = _model(dtype)
+    imgs, tg = _batch(m, B=2)
+    with torch.no_grad():
+        feat = m.backbone(imgs)
+    state = copy.deepcopy(m.heads.state_dict())
+    out = {}
+    for sparse in (True, False):
+        m.heads.load_state_dict(state)
+        m.heads.sparse_regression = sparse
+        m.zero_grad(set_to_none=True)
+        f = feat.clone().requires_grad_()
+        ld, _ = m.heads(f, tg)
+        sum(ld.values()).backward()
+        out[sparse] = (ld, f.grad.float().clone(), {n: p.grad.clone() for n, p in m.heads.named_parameters() if p.grad is not None},
+                       {k: v.clone() for k, v in m.heads.state_dict().items() if "running_" in k or "num_batches" in k})
+    (la, fa, ga, sa), (lb, fb, gb, sb) = out[True], out[False]
+    tol = 3e-2 if dtype == "bf16" else 2e-3
+    for k in la:
+        assert abs(float(la[k]) - float(lb[k])) <= (1e-2 if dtype == "bf16" else 1e-4) * max(1.0, abs(float(lb[k]))), (k, float(la[k]), float(lb[k]))
+    rel = lambda u, v: float((u.double() - v.double()).norm() / v.double().norm().clamp(min=1e-30))
+    assert rel(fa, fb) < tol, rel(fa, fb)
+    assert sorted(ga) == sorted(gb) and len(ga) >= 9 * 5
+    scale = max(float(v.double().norm()) for v in gb.values())
+    for n in ga:                                    # (a conv bias in front of a BN has a zero gradient: absolute floor)
+        err = float((ga[n].double() - gb[n].double()).norm())
+        assert err < tol * float(gb[n].double().norm()) + 1e-6 * scale, (n, err, float(gb[n].double().norm()))
+    for k in sa:
+        if "num_batches" in k:
+            assert int(sa[k]) == int(sb[k]), k
+        else:
+            assert (sa[k] - sb[k]).abs().max() <= 1e-4 * max(1.0, float(sb[k].abs().max())), k
+
+
 def test_torch_sync_batchnorm_converter_is_accepted():
     """The reference script's literal call (plain_train_net.py:131-132): torch.nn.SyncBatchNorm.convert_sync_batchnorm
     replaces the BN holders; the HIP path reads their parameters/buffers and treats them as synchronised; the nine head
