@@ -108,6 +108,12 @@ typedef struct {
     int32_t dtype, out_dtype;
     void* workspace;          /* optional scratch for split-K (small-M / long-K layers): fp32, >= ksplit*M*Cout_pad*4 bytes  */
     int64_t workspace_bytes;  /* 0 / NULL: never split                                           */
+    /* optional: train-mode BN statistics of the OUTPUT accumulated by the conv's own epilogue.  stats = the BN layer's scratch
+     * ([stats_ncopy][2*Cout] fp32 sums | sums of squares of the values as stored, see mfx_bn_train_fwd; stats_ncopy = mfx_bn_ncopy(Cout));
+     * *stats_done is set to 1 when the kernel that ran supports it (the LDS-halo 3x3 kernels), else to 0 and nothing is added. */
+    float* stats;
+    int stats_ncopy;
+    int* stats_done;
 } mfx_conv_desc;
 int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream);
 
@@ -275,9 +281,11 @@ int mfx_bn_act_bwd(const void* x, const void* a, const void* da, const float* me
  * kernel.  mean/rstd (C floats each) are outputs for the backward.  Replaces stats + finalize + act_fwd (and reduce + apply +
  * two gradient copies) with two launches each and no zero-fill launches. */
 size_t mfx_bn_scratch_bytes(void);
+int mfx_bn_ncopy(int C);      /* copies of the [2C] sums inside the scratch (the conv epilogue adds into copy workgroup % ncopy) */
+/* stats_done != 0: the producing conv already added the statistics of x to the scratch (mfx_conv_desc.stats): no statistics launch */
 int mfx_bn_train_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, long long* num_batches_tracked, float momentum, float eps, long M, int C, int act,
-                     int dtype, float* scratch, float* mean, float* rstd, void* stream);
+                     int dtype, float* scratch, float* mean, float* rstd, int stats_done, void* stream);
 int mfx_bn_train_bwd(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, void* dx, void* dres, float* dgamma, float* dbeta, long M, int C, int act, int dtype,
                      float* scratch, void* stream);
@@ -389,7 +397,7 @@ int mfx_head_sparse_bwd(const mfx_head_sparse_desc* d, void* stream);
  * num_batches_tracked updated as mfx_bn_train_fwd does; `scratch` as there (zero before, zero after). */
 int mfx_bn_train_stats(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                        long long* num_batches_tracked, float momentum, float eps, long M, int C, int dtype, float* scratch,
-                       float* mean, float* rstd, void* stream);
+                       float* mean, float* rstd, int stats_done, void* stream);
 
 /* ---- (4) input pipeline: KITTI sample -> network input + training targets, on the device ------------------------------
  * Replaces the per-sample numpy/PIL work of the reference's dataset (data/datasets/kitti.py:231-525 __getitem__,

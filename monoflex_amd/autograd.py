@@ -183,9 +183,11 @@ class Conv2dFn(Function):
     multiple of the 16-byte chunk (extra channels are exactly zero); callers slice."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, out_dtype=None, act=L.ACT_NONE):
+    def forward(ctx, x, weight, bias, stride, pad, out_dtype=None, act=L.ACT_NONE, stats=None):
         """`act` = ACT_DCN_OFFMASK fuses the sigmoid of the DCN mask channels into the epilogue; the CONSUMER (DCNFn with
-        post_sigmoid=True) then hands back the gradient of the pre-activation, which is what backward() below expects."""
+        post_sigmoid=True) then hands back the gradient of the pre-activation, which is what backward() below expects.
+        `stats` = the scratch of the train-mode BN that follows: the conv's epilogue adds the output's statistics to it where
+        the kernel supports that (ops.conv2d.last_stats_done)."""
         x = _c(x)
         Cout, Cin, kh, kw = weight.shape
         cpad = _pad_channels(Cout, out_dtype or x.dtype)
@@ -195,7 +197,10 @@ class Conv2dFn(Function):
             shift = bias.detach().float() if cp == Cout else torch.nn.functional.pad(bias.detach().float(), (0, cp - Cout))
         p = _pack_weight(weight, x.dtype, 0, cpad, Cin, stride, pad, pad, shift)
         p.act = act
-        y = ops.conv2d(x, p, out_dtype=out_dtype)             # bf16 mode: fp32 out for DCN offsets and the head maps
+        if stats is not None and (cpad != Cout or ops.cout_pad(cpad) != Cout or act != L.ACT_NONE):
+            stats = None                                       # padded output channels / an activation: leave the statistics to the BN
+        ops.conv2d.last_stats_done = False
+        y = ops.conv2d(x, p, out_dtype=out_dtype, stats=stats)     # bf16 mode: fp32 out for DCN offsets and the head maps
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, bias is not None, Cout)
         return y
@@ -235,7 +240,7 @@ class Conv2dFn(Function):
             dw = dwf if weight.dtype == torch.float32 else dwf.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy)[:Cout]
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 @_device_guarded
@@ -333,6 +338,7 @@ def _sync_group(sync):
 
 _BN_SEPARATE = [False]          # True: the five-launch form (stats, finalize, apply; reduce, apply) also in the single-process case
 _BN_READ_OUTPUT = [False]       # True: the backward always reads the forward output for the activation derivative (test switch)
+_CONV_STATS_OFF = [__import__('os').environ.get('MFX_CONV_STATS', '1') == '0']       # True: convs never accumulate the following BN's statistics (test switch; env MFX_CONV_STATS=0)
 _BN_SCRATCH = {}
 
 
@@ -354,7 +360,7 @@ class BNActFn(Function):
     [sum g, sum g*xhat] backward, 2C(+1) floats each over RCCL."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, res, act, momentum, eps, sync, nbt=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, res, act, momentum, eps, sync, nbt=None, stats_done=False):
         x = _c(x)
         C = x.shape[-1]
         M = x.numel() // C
@@ -374,12 +380,15 @@ class BNActFn(Function):
                 nbt = None
             L.check(lib_.mfx_bn_train_fwd(_ptr(x), _ptr(res_c), _ptr(y), _ptr(_c(g32)), _ptr(_c(b32)), _ptr(rm),
                                           _ptr(running_var) if rm is not None else None, _ptr(nbt), ctypes.c_float(momentum), ctypes.c_float(eps),
-                                          M, C, act, _dt(x.dtype), _ptr(scratch), _ptr(mr), mr.data_ptr() + 4 * C, _stream()), "mfx_bn_train_fwd")
+                                          M, C, act, _dt(x.dtype), _ptr(scratch), _ptr(mr), mr.data_ptr() + 4 * C, int(bool(stats_done)), _stream()),
+                    "mfx_bn_train_fwd")
             ctx.save_for_backward(x, y, mr[:C], mr[C:], _c(g32))
             ctx.cfg = (act, res is not None, None, M)
             ctx.scratch = scratch
             ctx.beta32 = _c(b32)
             return y
+        if stats_done:
+            raise RuntimeError("bn_act: the conv's epilogue filled the statistics scratch, but this BN takes the separate-kernel path")
         if nbt is not None:
             nbt.add_(1)
         ctx.scratch = None
@@ -422,7 +431,7 @@ class BNActFn(Function):
             L.check(L.load().mfx_bn_train_bwd(_ptr(x), _ptr(a_in), _ptr(da), _ptr(mean), _ptr(rstd), _ptr(g32), _ptr(ctx.beta32), _ptr(dx),
                                               _ptr(dres), _ptr(dgamma), _ptr(dbeta), M, C, act, _dt(x.dtype), _ptr(ctx.scratch), _stream()),
                     "mfx_bn_train_bwd")
-            return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None
+            return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
         sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
         sg, sgx = sums[:C], sums[C:]
         dx = torch.empty_like(x)
@@ -438,7 +447,7 @@ class BNActFn(Function):
             local = sums
         L.check(lib_.mfx_bn_bwd_apply(_ptr(x), _ptr(y), _ptr(da), _ptr(mean), _ptr(rstd), _ptr(g32), _ptr(sg), sums.data_ptr() + 4 * C,
                                       _ptr(dx), _ptr(dres), M, Mt, C, act, _dt(x.dtype), _stream()), "mfx_bn_bwd_apply")
-        return dx, local[C:].clone(), local[:C].clone(), None, None, dres, None, None, None, None, None
+        return dx, local[C:].clone(), local[:C].clone(), None, None, dres, None, None, None, None, None, None
 
 
 @_device_guarded
@@ -634,7 +643,7 @@ class SparseRegHeadsFn(Function):
     map (running statistics and num_batches_tracked move as in bn_act); backward is one dense pass per branch."""
 
     @staticmethod
-    def forward(ctx, rows, abns, offs, ld_out, *ts):
+    def forward(ctx, rows, abns, offs, ld_out, stats_done, *ts):
         nb = len(abns)
         ys, gammas, betas, w2s, b2s = (ts[i * nb:(i + 1) * nb] for i in range(5))
         ys = [_c(y) for y in ys]
@@ -656,7 +665,7 @@ class SparseRegHeadsFn(Function):
                                               and abn.num_batches_tracked.dtype == torch.int64) else None
             L.check(lib_.mfx_bn_train_stats(_ptr(ys[i]), _ptr(g32), _ptr(b32), _ptr(abn.running_mean), _ptr(abn.running_var), _ptr(nbt),
                                             ctypes.c_float(mom), ctypes.c_float(abn.eps), B * H * W, C, _dt(y0.dtype), _ptr(_bn_scratch(gammas[i])),
-                                            _ptr(stats[i, 0]), _ptr(stats[i, 1]), _stream()), "mfx_bn_train_stats")
+                                            _ptr(stats[i, 0]), _ptr(stats[i, 1]), int(bool(stats_done[i])), _stream()), "mfx_bn_train_stats")
             d.y[i], d.mean[i], d.rstd[i] = ys[i].data_ptr(), stats[i, 0].data_ptr(), stats[i, 1].data_ptr()
             d.gamma[i], d.beta[i], d.w2[i], d.b2[i] = g32.data_ptr(), b32.data_ptr(), w2.data_ptr(), (b2.data_ptr() if b2 is not None else None)
             d.k[i], d.out_off[i] = w2.shape[0], offs[i]
@@ -706,7 +715,7 @@ class SparseRegHeadsFn(Function):
         L.check(L.load().mfx_head_sparse_bwd(ctypes.byref(d), _stream()), "mfx_head_sparse_bwd")
         dgammas = [sm[C:] for sm in sums]
         dbetas = [sm[:C] for sm in sums]
-        return (None, None, None, None, *dxs, *dgammas, *dbetas, *dw2s, *db2s)
+        return (None, None, None, None, None, *dxs, *dgammas, *dbetas, *dw2s, *db2s)
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, out_dtype=None):
@@ -715,11 +724,30 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, out_dtype=None):
     return y if y.shape[-1] == weight.shape[0] else y[..., :weight.shape[0]]
 
 
-def bn_act(x, bn, act, res=None, sync=None):
+def bn_fuses_statistics(bn, sync=None):
+    """True when train-mode `bn` takes the two-launch path whose statistics a producing conv may accumulate itself."""
+    if _BN_SEPARATE[0] or _CONV_STATS_OFF[0] or bn.weight.numel() > 512:
+        return False
+    if sync is None:
+        sync = bool(getattr(bn, 'sync_bn', False)) or isinstance(bn, torch.nn.SyncBatchNorm)
+    return _sync_group(sync) is None
+
+
+def conv2d_bn_stats(x, weight, bias, stride, pad, bn):
+    """conv2d whose epilogue also accumulates the batch statistics of its output for the train-mode BN `bn` that follows.
+    Returns (y, stats_done): pass stats_done on to bn_act / SparseRegHeadsFn."""
+    if not bn_fuses_statistics(bn) or x.shape[0] * x.shape[1] * x.shape[2] == 0:
+        return conv2d(x, weight, bias, stride, pad), False
+    y = Conv2dFn.apply(x, weight, bias, stride, pad, None, L.ACT_NONE, _bn_scratch(bn.weight))
+    done = ops.conv2d.last_stats_done
+    return (y if y.shape[-1] == weight.shape[0] else y[..., :weight.shape[0]]), done
+
+
+def bn_act(x, bn, act, res=None, sync=None, stats_done=False):
     """Train-mode BN module `bn` (+act, +res) on an NHWC tensor; updates bn.running_* like nn.BatchNorm2d.
     sync=None follows the module's `sync_bn` attribute (set by engine.trainer.convert_sync_batchnorm)."""
     mom = bn.momentum if bn.momentum is not None else 0.1
     nbt = bn.num_batches_tracked if (bn.track_running_stats and bn.num_batches_tracked is not None) else None
     if sync is None:                    # torch's own converter (the reference script's literal call) leaves SyncBatchNorm holders
         sync = bool(getattr(bn, 'sync_bn', False)) or isinstance(bn, torch.nn.SyncBatchNorm)
-    return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, act, mom, bn.eps, sync, nbt)
+    return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, act, mom, bn.eps, sync, nbt, stats_done)

@@ -29,6 +29,7 @@ template <> struct ElemTraits<float> {
     static constexpr int DT = 0;
     __device__ static __forceinline__ float load(const float* p) { return *p; }
     __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float round(float v) { return v; }            // the value as it will be stored
     // unpack a 16-byte chunk to floats / pack floats to a chunk
     __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
         f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y);
@@ -44,6 +45,7 @@ template <> struct ElemTraits<bf16_t> {
     static constexpr int DT = 1;
     __device__ static __forceinline__ float load(const bf16_t* p) { return bf2f(p->v); }
     __device__ static __forceinline__ void store(bf16_t* p, float v) { p->v = __builtin_bit_cast(uint16_t, (__bf16)v); }
+    __device__ static __forceinline__ float round(float v) { return __uint_as_float((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v) << 16); }
     __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
         f[0] = __uint_as_float(c.x << 16); f[1] = __uint_as_float(c.x & 0xffff0000u);
         f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);

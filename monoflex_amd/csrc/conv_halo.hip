@@ -44,6 +44,14 @@ template <typename T, int WN, int FN, int WK = 1> struct HaloSmem {
 // WK > 1: WK waves share each output slice and split the K steps among themselves (step s belongs to wave s % WK); their
 // partial accumulators meet in LDS after the K loop and each wave finishes FM / WK output rows.  For narrow outputs
 // (the 27-channel DCN offset/mask conv: N = 32) a workgroup would otherwise be ONE wave walking the whole K alone.
+// two output values as they will be stored (identity for fp32, one packed convert for bf16)
+template <typename TO> __device__ __forceinline__ f32x2 halo_round2(float a, float b);
+template <> __device__ __forceinline__ f32x2 halo_round2<float>(float a, float b) { return f32x2{a, b}; }
+template <> __device__ __forceinline__ f32x2 halo_round2<bf16_t>(float a, float b) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2));
+    return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+
 template <typename T, typename TO, int WN, int FN, int WK = 1>
 __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                                       const u32x4* __restrict__ wfm, HaloGeom g, EpiArgs ep) {
@@ -248,14 +256,38 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
         sc[j] = ep.scale ? ep.scale[n0 + j * 16 + xl] : 1.f;
         sh[j] = ep.shift ? ep.shift[n0 + j * 16 + xl] : 0.f;
     }
+    // train-mode BN statistics of the output (ep.stats; the conv has no residual / activation then): every lane sums its column
+    // n = j*16 + xl over its pixels, of the values AS STORED (rounded to the output type), then the four pixel groups of the
+    // wave meet by shuffles and lanes 0..15 add into the layer's scratch -- the separate statistics pass over the map disappears
+    // (two values per step in 2-wide vectors: packed convert + v_pk_add_f32 / v_pk_fma_f32 -- 128 values per lane on the widest
+    // variant, and the epilogue's VALU work is not hidden behind MFMAs)
+    f32x2 st_s[FN], st_q[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) { st_s[j] = f32x2{0.f, 0.f}; st_q[j] = f32x2{0.f, 0.f}; }
+    const bool st_on = ep.stats != nullptr;
 #pragma unroll
     for (int ii = 0; ii < RW; ++ii) {
         const int i = WK > 1 ? wk * RW + ii : ii;             // output row of accumulator slot ii
         // D layout: col n = lane&15, row (pixel x) = (lane>>4)*4 + r
+        const bool row_in = y0 + i < g.H;
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j) {
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[((lane >> 4) * 4 + r) * LDS_ + j * 16 + xl] = acc[ii][j][r] * sc[j] + sh[j];
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[ii][j][r] * sc[j] + sh[j];
+                stage[((lane >> 4) * 4 + r) * LDS_ + j * 16 + xl] = v[r];
+            }
+            if (st_on && row_in) {
+                const int px = x0 + (lane >> 4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    f32x2 vr = halo_round2<TO>(v[r], v[r + 1]);
+                    if (px + r + 1 >= g.W) { if (px + r >= g.W) vr[0] = 0.f; vr[1] = 0.f; }      // ragged right edge only
+                    st_s[j] += vr; st_q[j] += vr * vr;
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();                      // same wave: DS ops complete in order
         const int oy = y0 + i;
 #pragma unroll
@@ -295,6 +327,17 @@ apply_act_chunk<OE>(v, ep.act, gn);
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (ep.stats) {
+        float* sp = ep.stats + (size_t)(blockIdx.x % ep.stats_ncopy) * 2 * ep.Cout;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            float a = st_s[j][0] + st_s[j][1], q = st_q[j][0] + st_q[j][1];
+            a += __shfl_xor(a, 16); q += __shfl_xor(q, 16);
+            a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
+            const int n = n0 + j * 16 + xl;
+            if (lane < 16 && n < ep.Cout) { unsafeAtomicAdd(sp + n, a); unsafeAtomicAdd(sp + ep.Cout + n, q); }
+        }
+    }
 }
 
 static inline int cdivh(int a, int b) { return (a + b - 1) / b; }
@@ -318,6 +361,7 @@ static int launch_halo(const mfx_conv_desc* d, hipStream_t st) {
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
+    ep.stats = d->stats; ep.stats_ncopy = d->stats_ncopy > 0 ? d->stats_ncopy : 1;
     const int smem = SM::total(g.CG);
     auto k = conv3x3_wave_kernel<T, TO, WN, FN, WK>;
     static int attr_smem = 0;

@@ -443,9 +443,15 @@ extern "C" int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream) {
     if (d->M <= 0) return MFX_OK;
     if (d->dtype == MFX_BF16 && d->out_dtype == MFX_F32 && d->res) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: residual needs out_dtype == dtype");
     if (d->dtype == MFX_F32 && d->out_dtype != MFX_F32) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: f32 input needs f32 output");
+    if (d->stats && (!d->stats_done || d->res || d->act != MFX_ACT_NONE || d->rowmap))
+        return mfx_fail(MFX_ERR_ARG, "conv2d: output statistics need stats_done and a plain (no residual / activation / row map) epilogue");
+    if (d->stats_done) *d->stats_done = 0;
     {
         const int h = try_conv_halo(d, reinterpret_cast<hipStream_t>(stream));   // 3x3/s1: LDS-staged halo kernel
-        if (h != 0) return h < 0 ? h : MFX_OK;
+        if (h != 0) {
+            if (h > 0 && d->stats && d->stats_done) *d->stats_done = 1;
+            return h < 0 ? h : MFX_OK;
+        }
     }
     ConvGeom g;
     g.H = d->H; g.W = d->W; g.Ho = d->Ho; g.Wo = d->Wo; g.x_pixstride = d->x_pixstride; g.lgC = ilog2(d->Ck);

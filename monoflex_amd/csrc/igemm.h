@@ -34,6 +34,9 @@ struct EpiArgs {
     // sums to ws[split][M][ws_ld]; splitk_finalize_kernel adds them and applies the real epilogue
     int ksplit = 1, ws_ld = 0;
     float* ws = nullptr;
+    // train-mode BN statistics of the output, accumulated by the epilogue (conv_halo.hip): [stats_ncopy][2*Cout] sums | sums of squares
+    float* stats = nullptr;
+    int stats_ncopy = 1;
 };
 
 // Weight (B operand) loader: rows n0.. of a [N_pad][K_pad] K-contiguous matrix.

@@ -1191,11 +1191,13 @@ extern "C" int mfx_bn_bwd_apply(const void* x, const void* a, const void* da, co
 static int bn_ncopy(int C) { return std::max(1, BN_SCRATCH_COLS / (2 * C)); }
 
 constexpr int BN_TICKET_WORDS = BN_TICKET_GROUPS * BN_TICKET_STRIDE + BN_TICKET_STRIDE;
+extern "C" int mfx_bn_ncopy(int C) { return C > 0 && 2 * C <= BN_SCRATCH_COLS ? bn_ncopy(C) : 0; }
+
 extern "C" size_t mfx_bn_scratch_bytes(void) { return (size_t)(2 * BN_SCRATCH_COLS + 2 * BN_TICKET_WORDS) * sizeof(float); }
 
 extern "C" int mfx_bn_train_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, long long* num_batches_tracked, float momentum, float eps, long M, int C, int act,
-                                int dtype, float* scratch, float* mean, float* rstd, void* stream) {
+                                int dtype, float* scratch, float* mean, float* rstd, int stats_done, void* stream) {
     if (!x || !y || !gamma || !beta || !scratch || !mean || !rstd) return mfx_fail(MFX_ERR_ARG, "bn_train_fwd: null pointer");
     if ((running_mean == nullptr) != (running_var == nullptr)) return mfx_fail(MFX_ERR_ARG, "bn_train_fwd: running_mean/var must come together");
     int rc = bn_check(C, dtype); if (rc) return rc;
@@ -1205,8 +1207,9 @@ extern "C" int mfx_bn_train_fwd(const void* x, const void* res, void* y, const f
     const int E = dtype == MFX_BF16 ? 8 : 4, ncopy = bn_ncopy(C);
     const int rows = bn_rows_per_block(M, C, dtype);
     const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, scratch, scratch + C, ncopy),
-                      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, scratch, scratch + C, ncopy));
+    if (!stats_done)
+        DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, scratch, scratch + C, ncopy),
+                          hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, scratch, scratch + C, ncopy));
     MFX_HIP_CHECK(hipGetLastError());
     const long chunks = M * (C / E);
     const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
@@ -1241,7 +1244,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(float* sums, int
 
 extern "C" int mfx_bn_train_stats(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                   long long* num_batches_tracked, float momentum, float eps, long M, int C, int dtype, float* scratch,
-                                  float* mean, float* rstd, void* stream) {
+                                  float* mean, float* rstd, int stats_done, void* stream) {
     if (!x || !gamma || !beta || !scratch || !mean || !rstd) return mfx_fail(MFX_ERR_ARG, "bn_train_stats: null pointer");
     if ((running_mean == nullptr) != (running_var == nullptr)) return mfx_fail(MFX_ERR_ARG, "bn_train_stats: running_mean/var must come together");
     int rc = bn_check(C, dtype); if (rc) return rc;
@@ -1250,8 +1253,9 @@ extern "C" int mfx_bn_train_stats(const void* x, const float* gamma, const float
     const int E = dtype == MFX_BF16 ? 8 : 4, ncopy = bn_ncopy(C);
     const int rows = bn_rows_per_block(M, C, dtype);
     const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, scratch, scratch + C, ncopy),
-                      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, scratch, scratch + C, ncopy));
+    if (!stats_done)
+        DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, scratch, scratch + C, ncopy),
+                          hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, scratch, scratch + C, ncopy));
     const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, ncopy, gamma, beta, running_mean, running_var, num_batches_tracked,
                        momentum, eps, (float)(1.0 / (double)M), unbias, mean, rstd, C);

@@ -23,7 +23,8 @@ class ConvDesc(ctypes.Structure):
                 ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad_h", c_int), ("pad_w", c_int), ("dil_w", c_int),
                 ("Ho", c_int), ("Wo", c_int), ("M", c_int), ("Cout", c_int), ("Cout_pad", c_int), ("K_pad", c_int),
                 ("ldy", c_int), ("ldres", c_int), ("act", c_int), ("dtype", c_int), ("out_dtype", c_int),
-                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64)]
+                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64),
+                ("stats", c_void_p), ("stats_ncopy", c_int), ("stats_done", ctypes.POINTER(c_int))]
 
 
 class CatDesc(ctypes.Structure):
@@ -128,9 +129,10 @@ SYMBOLS = {
     "mfx_pack_conv_weights_batched": (_I, [_P, _P, _I, ctypes.c_longlong, _I, _P]),
     "mfx_head_sparse_fwd": (_I, [ctypes.POINTER(HeadSparseDesc), _P]),
     "mfx_head_sparse_bwd": (_I, [ctypes.POINTER(HeadSparseDesc), _P]),
-    "mfx_bn_train_stats": (_I, [_P] * 6 + [_F, _F, ctypes.c_long, _I, _I, _P, _P, _P, _P]),
+    "mfx_bn_train_stats": (_I, [_P] * 6 + [_F, _F, ctypes.c_long, _I, _I, _P, _P, _P, _I, _P]),
     "mfx_bn_scratch_bytes": (_S, []),
-    "mfx_bn_train_fwd": (_I, [_P] * 8 + [_F, _F, ctypes.c_long, _I, _I, _I, _P, _P, _P, _P]),
+    "mfx_bn_ncopy": (_I, [_I]),
+    "mfx_bn_train_fwd": (_I, [_P] * 8 + [_F, _F, ctypes.c_long, _I, _I, _I, _P, _P, _P, _I, _P]),
     "mfx_bn_train_bwd": (_I, [_P] * 11 + [ctypes.c_long, _I, _I, _I, _P, _P]),
     "mfx_bn_bwd_reduce": (_I, [_P] * 7 + [ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_bwd_apply": (_I, [_P] * 10 + [ctypes.c_long, ctypes.c_long, _I, _I, _I, _P]),

@@ -50,7 +50,8 @@ def _eval_only(m):
 
 def _train_conv_bn(x, conv, bn, act, res=None):
     """Training form of conv -> BN(batch statistics) -> act (+res before the act)."""
-    return AG.bn_act(AG.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0]), bn, act, res)
+    y, done = AG.conv2d_bn_stats(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bn)
+    return AG.bn_act(y, bn, act, res, stats_done=done)
 
 
 def _conv_bn(owner, key, conv, bn, dtype, act):

@@ -213,12 +213,12 @@ class _predictor(nn.Module):
         for bi, (t, heads) in enumerate(zip(trunks, lasts)):
             w = heads[0].weight if len(heads) == 1 else torch.cat([h.weight for h in heads], 0)
             b = heads[0].bias if len(heads) == 1 else torch.cat([h.bias for h in heads], 0)
-            y = AG.conv2d(features, t[0].weight, None, 1, 1)
+            y, done = AG.conv2d_bn_stats(features, t[0].weight, None, 1, 1, t[1])
             if sparse and bi != 0 and bi - 1 != oi:
-                sp.append((bi - 1, y, t[1], w, b))
+                sp.append((bi - 1, y, t[1], w, b, done))
                 feats.append(None); outs.append(None)
                 continue
-            f = AG.bn_act(y, t[1], L.ACT_LEAKY)
+            f = AG.bn_act(y, t[1], L.ACT_LEAKY, stats_done=done)
             feats.append(f)
             outs.append(AG.conv2d(f, w, b, 1, 0, out_dtype=torch.float32))
         cls, regs = outs[0], outs[1:]
@@ -254,9 +254,9 @@ class _predictor(nn.Module):
         # gathered regression table in the reference's channel order
         starts = [sum(sum(c) for c in self.regression_channel_cfg[:i]) for i in range(len(self.regression_channel_cfg))]
         rows = object_rows
-        tab = AG.SparseRegHeadsFn.apply(rows, tuple(a for _, _, a, _, _ in sp), tuple(starts[i] for i, _, _, _, _ in sp), 50,
-                                        *[y for _, y, _, _, _ in sp], *[a.weight for _, _, a, _, _ in sp], *[a.bias for _, _, a, _, _ in sp],
-                                        *[w for _, _, _, w, _ in sp], *[b for _, _, _, _, b in sp])
+        tab = AG.SparseRegHeadsFn.apply(rows, tuple(e[2] for e in sp), tuple(starts[e[0]] for e in sp), 50, tuple(e[5] for e in sp),
+                                        *[e[1] for e in sp], *[e[2].weight for e in sp], *[e[2].bias for e in sp],
+                                        *[e[3] for e in sp], *[e[4] for e in sp])
         bidx, cx, cy = rows[:, 57].long().clamp(0, B - 1), rows[:, 2].long().clamp(0, W - 1), rows[:, 3].long().clamp(0, H - 1)
         lo, n_off = starts[oi], sum(self.regression_channel_cfg[oi])
         off_rows = regs[oi][bidx, cy, cx][:, :n_off]                                   # the dense 3d_offset head at the centres

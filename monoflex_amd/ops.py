@@ -196,7 +196,7 @@ def pack_stem(weight, dtype, scale, shift, act=L.ACT_RELU):
 # --------------------------------------------------------------------------------------------
 @on_tensor_device
 def conv2d(x, p: PackedConv, res=None, out_dtype=None, rowmap=None, x_channels=None, x_ch_off=0,
-           out_hw=None, in_hw=None):
+           out_hw=None, in_hw=None, stats=None):
     """y = act(conv(x)*scale + shift (+res)).  x: (B,H,W,Cx) NHWC.  With `rowmap` (int32 [M], pixel
     indices into the (B,Ho,Wo) grid, -1 = zero row) the output is the dense (M, Cout) row list."""
     _need_cuda(x, res, rowmap)
@@ -227,8 +227,19 @@ def conv2d(x, p: PackedConv, res=None, out_dtype=None, rowmap=None, x_channels=N
     if rowmap is None and M * p.Cout_pad <= SPLITK_MAX_ELEMS and p.K_pad * x.element_size() >= 2048:
         ws = _splitk_workspace(x.device)                      # small-M / long-K layers: lets the library split K
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if stats is not None:
+        # train-mode BN statistics of y accumulated by the conv's epilogue into the BN layer's scratch (where the kernel that
+        # runs supports it: conv2d.last_stats_done tells the caller whether a statistics pass is still needed)
+        done = ctypes.c_int(0)
+        d.stats, d.stats_ncopy, d.stats_done = stats.data_ptr(), L.load().mfx_bn_ncopy(p.Cout), ctypes.pointer(done)
+        L.check(L.load().mfx_conv2d_nhwc(ctypes.byref(d), _stream()), "mfx_conv2d_nhwc")
+        conv2d.last_stats_done = bool(done.value)
+        return y
     L.check(L.load().mfx_conv2d_nhwc(ctypes.byref(d), _stream()), "mfx_conv2d_nhwc")
     return y
+
+
+conv2d.last_stats_done = False
 
 
 @dataclass

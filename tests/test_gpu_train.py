@@ -264,7 +264,7 @@ def test_sparse_regression_heads_function_vs_torch(dt):
     yd = [y.to(DEV).requires_grad_() for y in ys]
     wd = [w.to(DEV).requires_grad_() for w in w2s]
     bd = [b.to(DEV).requires_grad_() for b in b2s]
-    out = AG.SparseRegHeadsFn.apply(rows.to(DEV), tuple(abns_d), offs, 50, *yd, *[h.weight for h in abns_d], *[h.bias for h in abns_d], *wd, *bd)
+    out = AG.SparseRegHeadsFn.apply(rows.to(DEV), tuple(abns_d), offs, 50, (False,) * len(ks), *yd, *[h.weight for h in abns_d], *[h.bias for h in abns_d], *wd, *bd)
     (out * dout.to(DEV)).sum().backward()
     tol = 3e-2 if dt == "bf16" else 2e-4
     for i, k in enumerate(ks):
@@ -275,6 +275,44 @@ def test_sparse_regression_heads_function_vs_torch(dt):
         assert _rel(abns_d[i].running_var.cpu(), abns_r[i].running_var) < 1e-3 and int(abns_d[i].num_batches_tracked) == 1
     unused = [c for c in range(50) if not any(o <= c < o + k for o, k in zip(offs, ks))]
     assert float(out[:, unused].abs().max()) == 0.0 and float(out[rows[:, 0] == 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("cin,cout,H,W,k,stride", [(64, 64, 24, 40, 3, 1), (64, 256, 40, 72, 3, 1), (256, 64, 13, 37, 3, 1), (128, 128, 9, 20, 3, 1),
+                                                   (16, 16, 32, 64, 3, 1), (32, 32, 31, 45, 3, 1), (512, 512, 6, 10, 3, 1), (64, 128, 24, 40, 3, 2),
+                                                   (64, 128, 24, 40, 1, 1)])
+def test_conv_epilogue_accumulates_the_bn_statistics(cin, cout, H, W, k, stride, dt):
+    """The LDS-halo 3x3 kernels add the sums / sums of squares of their (rounded) output to the following BN's scratch
+    (mfx_conv_desc.stats), so the BN skips its statistics pass: same mean / rstd / output / gradients as the separate pass, for every
+    halo variant the table picks (plain, wide, K-split, ragged tiles); convs other kernels run (stride 2, 1x1) report
+    stats_done = 0 and the BN does its own pass."""
+    from monoflex_amd import autograd as AG, ops
+    from monoflex_amd import lib as L
+    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(cin + cout + H)
+    B = 3
+    x = torch.randn(B, H, W, cin, generator=g).to(DEV).to(dtype)
+    w = (torch.randn(cout, cin, k, k, generator=g) / (k * cin ** 0.5)).to(DEV)
+    bn_a, bn_b = torch.nn.BatchNorm2d(cout).to(DEV), torch.nn.BatchNorm2d(cout).to(DEV)
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.rand(cout, generator=g) + 0.5); bn_a.bias.copy_(torch.randn(cout, generator=g) * 0.2)
+    bn_b.load_state_dict(bn_a.state_dict())
+    out = []
+    for bn, off in ((bn_a, False), (bn_b, True)):
+        AG._CONV_STATS_OFF[0] = off
+        try:
+            xd, wd = x.clone().requires_grad_(), w.clone().requires_grad_()
+            y, done = AG.conv2d_bn_stats(xd, wd, None, stride, k // 2, bn)
+            assert done == ((not off) and k == 3 and stride == 1), done
+            z = AG.bn_act(y, bn, L.ACT_RELU, stats_done=done)
+            z.float().square().sum().backward()
+            out.append((z.detach().float(), xd.grad.float(), wd.grad, bn.weight.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()))
+        finally:
+            AG._CONV_STATS_OFF[0] = False
+    tol = 2e-2 if dt == "bf16" else 1e-4
+    for a_, b_ in zip(*out):
+        assert _rel(a_, b_) < tol, _rel(a_, b_)
+    assert float(AG._bn_scratch(bn_a.weight).abs().max()) == 0.0
 
 
 def test_maxpool_and_upsample_grads():

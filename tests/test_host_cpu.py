@@ -24,13 +24,25 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert cdll.mfx_abi_version() == 1
 
 
-def test_ctypes_struct_layout_matches_header_sizes():
-    # sizes of the descriptor structs as laid out by the C compiler for this ABI (LP64)
+def test_ctypes_struct_layout_matches_header_sizes(tmp_path):
+    """Every descriptor struct of include/monoflex_hip.h as the C compiler lays it out (gcc on the header itself) against its
+    ctypes mirror in monoflex_amd/lib.py."""
+    import subprocess
     from monoflex_amd import lib as L
-    assert ctypes.sizeof(L.ConvDesc) == 8 * 8 + 22 * 4 + 16
-    assert ctypes.sizeof(L.DcnDesc) == 7 * 8 + 17 * 4 + 4 + 8 + 16   # 4 bytes of padding before the trailing pointers
-    assert ctypes.sizeof(L.CatDesc) == 9 * 8 + 18 * 4 + 2 * 4 + 5 * 8 + 8 * 4
-    assert ctypes.sizeof(L.HeadsDesc) == 8 * 8 + 8 * 4 + 32 * 4
+    pairs = [("mfx_conv_desc", L.ConvDesc), ("mfx_dcn_desc", L.DcnDesc), ("mfx_cat_desc", L.CatDesc), ("mfx_heads_desc", L.HeadsDesc),
+             ("mfx_pack_desc", L.PackDesc), ("mfx_object_loss_cfg", L.ObjectLossCfg), ("mfx_head_sparse_desc", L.HeadSparseDesc),
+             ("mfx_kitti_desc", L.KittiDesc), ("mfx_kitti_eval_desc", L.KittiEvalDesc)]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) {\n%s\nreturn 0; }\n'
+                   % (os.path.join(ROOT, "include", "monoflex_hip.h"),
+                      "\n".join('printf("%%zu\\n", sizeof(%s));' % n for n, _ in pairs)))
+    exe = str(tmp_path / "sizes")
+    r = subprocess.run(["gcc", "-std=c99", "-o", exe, str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True).stdout.split()]
+    for (name, mirror), size in zip(pairs, sizes):
+        assert ctypes.sizeof(mirror) == size, (name, ctypes.sizeof(mirror), size)
+    assert ctypes.sizeof(L.ConvDesc) == 8 * 8 + 22 * 4 + 16 + 8 + 8 + 8      # ... + statistics pointer, copies (+pad), done pointer
 
 
 def test_reference_yaml_drives_the_config():
