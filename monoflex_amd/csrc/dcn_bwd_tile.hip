@@ -41,6 +41,9 @@ namespace mfx {
 
 constexpr int BT_TH = 8, BT_TW = 16, BT_D = 8, BT_NPIX = BT_TH * BT_TW;
 constexpr int BT_FCAP = 512;   // far corners staged per workgroup before one global reservation
+#ifndef BT_ROWS_IN_FLIGHT
+#define BT_ROWS_IN_FLIGHT 8
+#endif
 #ifndef BT_LCAP_BF16
 #define BT_LCAP_BF16 62       // 4-byte list entries per target pixel (mean 36, sigma ~6): 32 KB of lists = four workgroups per CU
 #endif
@@ -111,6 +114,20 @@ template <> __device__ __forceinline__ void bt_store4<bf16_t>(bf16_t* p, const f
 // adds of this layer).  So the tile is not accumulated by atomics at all: phase 1 BINS every (sample, corner) pair that
 // lands in the tile into a per-pixel list (one integer LDS atomic per pair, 64x fewer than per channel), and phase 3 lets
 // each target pixel's lane group walk its list and accumulate in registers.
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    u32x4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const u32x4*>(p); }
+    __device__ __forceinline__ void zero() { v = u32x4{0u, 0u, 0u, 0u}; }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const { ElemTraits<bf16_t>::unpack(v, f); }
+};
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+    __device__ __forceinline__ void zero() { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const { f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3]; }
+};
+
 // List entries.  fp32 maps keep (sample, fp32 weight) pairs: 8 bytes, 47 per pixel in the 48 KB that leave three workgroups
 // per CU.  bf16 maps pack the sample as window coordinates (5 + 5 bits) + tap (4) and the weight's exponent and top ten
 // mantissa bits (18 bits, the weight is non-negative; 2^-11 relative, below the bf16 operands it multiplies) into 4 bytes:
@@ -252,16 +269,20 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const float* __restri
             return gcol + m * g.Kp + tap * g.C + c0;
         };
         int e = 0;
-        for (; e + 4 <= n; e += 4) {                                          // four rows in flight per lane group
-            entry_t en[4]; float gq[4][8], w[4];
+        constexpr int NF = BT_ROWS_IN_FLIGHT;                                 // d(columns) rows in flight per lane group
+        for (; e + NF <= n; e += NF) {
+            entry_t en[NF]; Raw8<T> gr[NF]; float w[NF];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) en[u] = lp[e + u];
+            for (int u = 0; u < NF; ++u) en[u] = lp[e + u];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bt_load8<T>(row(en[u], w[u]), gq[u]);
+            for (int u = 0; u < NF; ++u) gr[u].load(row(en[u], w[u]));
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NF; ++u) {
+                float gq[8];
+                gr[u].unpack(gq);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) a[k] += w[u] * gq[u][k];
+                for (int k = 0; k < 8; ++k) a[k] += w[u] * gq[k];
+            }
         }
         for (; e < n; ++e) {
             float gq[8], w;
@@ -334,20 +355,6 @@ __global__ void bt_pack_weight_t(const float* __restrict__ w, T* __restrict__ wT
 // looped inside the lane group (no atomics on the offset gradients, so no zero-fill either), and the 27 gradient channels of
 // a pixel are written whether or not the sample lies inside the image.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <typename T> struct Raw8;
-template <> struct Raw8<bf16_t> {
-    u32x4 v;
-    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const u32x4*>(p); }
-    __device__ __forceinline__ void zero() { v = u32x4{0u, 0u, 0u, 0u}; }
-    __device__ __forceinline__ void unpack(float (&f)[8]) const { ElemTraits<bf16_t>::unpack(v, f); }
-};
-template <> struct Raw8<float> {
-    f32x4 a, b;
-    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
-    __device__ __forceinline__ void zero() { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
-    __device__ __forceinline__ void unpack(float (&f)[8]) const { f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3]; }
-};
-
 template <typename T, int LPS>
 __global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const T* __restrict__ x, const float* __restrict__ om,
                                                             const T* __restrict__ gcol, BtGeom g, int xsplit,
