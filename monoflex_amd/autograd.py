@@ -339,6 +339,7 @@ def _sync_group(sync):
 _BN_SEPARATE = [False]          # True: the five-launch form (stats, finalize, apply; reduce, apply) also in the single-process case
 _BN_READ_OUTPUT = [False]       # True: the backward always reads the forward output for the activation derivative (test switch)
 _CONV_STATS_OFF = [__import__('os').environ.get('MFX_CONV_STATS', '1') == '0']       # True: convs never accumulate the following BN's statistics (test switch; env MFX_CONV_STATS=0)
+_CONV_STATS_MAX_COUT = [128]
 _BN_SCRATCH = {}
 
 
@@ -736,7 +737,9 @@ def bn_fuses_statistics(bn, sync=None):
 def conv2d_bn_stats(x, weight, bias, stride, pad, bn):
     """conv2d whose epilogue also accumulates the batch statistics of its output for the train-mode BN `bn` that follows.
     Returns (y, stats_done): pass stats_done on to bn_act / SparseRegHeadsFn."""
-    if not bn_fuses_statistics(bn) or x.shape[0] * x.shape[1] * x.shape[2] == 0:
+    # wide outputs pay more for the epilogue's atomics (one per column and wave, each covering only the wave's 128 pixels) than
+    # the separate pass costs: 64->256 @ 96x320 went 80 -> 150 us against a 33 us statistics pass; up to 128 channels it is +1..2 us
+    if not bn_fuses_statistics(bn) or weight.shape[0] > _CONV_STATS_MAX_COUT[0] or x.shape[0] * x.shape[1] * x.shape[2] == 0:
         return conv2d(x, weight, bias, stride, pad), False
     y = Conv2dFn.apply(x, weight, bias, stride, pad, None, L.ACT_NONE, _bn_scratch(bn.weight))
     done = ops.conv2d.last_stats_done
