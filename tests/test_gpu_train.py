@@ -317,6 +317,36 @@ def test_conv_epilogue_accumulates_the_bn_statistics(cin, cout, H, W, k, stride,
     assert float(AG._bn_scratch(bn_a.weight).abs().max()) == 0.0
 
 
+def test_packed_conv_operands_follow_the_parameter():
+    """The training path keeps packed copies of every conv parameter (forward and data-gradient operands) keyed by the
+    parameter and its version: an in-place update (what an optimizer does) is seen by the next conv, with or without the
+    step's batched re-pack, and a parameter that moved (.to / load) gets fresh buffers."""
+    from monoflex_amd import autograd as AG
+    g = torch.Generator().manual_seed(2)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    x = torch.randn(2, 16, 24, 64, generator=g).to(DEV)
+
+    def ref():
+        return F.conv2d(x.permute(0, 3, 1, 2), conv.weight, padding=1).permute(0, 2, 3, 1)
+    for step in range(3):
+        xd = x.clone().requires_grad_()
+        y = AG.conv2d(xd, conv.weight, None, 1, 1)
+        assert _rel(y, ref().detach()) < 1e-5, step
+        y.square().sum().backward()
+        gx = torch.autograd.grad(F.conv2d(xd.permute(0, 3, 1, 2), conv.weight.detach(), padding=1).square().sum(), xd)[0]
+        assert _rel(xd.grad, gx) < 1e-4, step                     # data-gradient operand (mode 1) is current too
+        with torch.no_grad():
+            conv.weight.mul_(0.5).add_(0.01 * (step + 1))          # optimizer-style in-place update: version bump
+        if step == 1:
+            AG.pack_all_weights()                                  # the step's batched re-pack sees the new values as well
+    w2 = torch.nn.Parameter(conv.weight.detach().clone() * 3)      # a different parameter object with the same shape
+    assert _rel(AG.conv2d(x, w2, None, 1, 1), F.conv2d(x.permute(0, 3, 1, 2), w2, padding=1).permute(0, 2, 3, 1).detach()) < 1e-5
+    tmp = conv.weight.detach() * 2                                 # a temporary (not a Parameter): packed on demand, nothing cached
+    n_before = len(AG._PACKS.entries)
+    assert _rel(AG.conv2d(x, tmp, None, 1, 1), F.conv2d(x.permute(0, 3, 1, 2), tmp, padding=1).permute(0, 2, 3, 1)) < 1e-5
+    assert len(AG._PACKS.entries) == n_before
+
+
 def test_maxpool_and_upsample_grads():
     from monoflex_amd import autograd as AG
     g = torch.Generator().manual_seed(5)
