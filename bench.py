@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of captured hipGraphs")
+    ap.add_argument("--streams", type=int, default=1, help="inference: run the batch as this many sub-batches on forked streams inside one step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-images", type=int, default=6)
     ap.add_argument("--sync-bn", action="store_true", help="train mode, N > 1: synchronised BatchNorm statistics")
@@ -177,6 +178,28 @@ def run_infer(args, rank, world, device):
     def step():
         return model.detect_device(images, *tg)
 
+    if args.streams > 1:
+        # the batch as `streams` sub-batches on forked streams inside ONE step / one graph: independent sub-batches overlap their
+        # under-filled launches (level 4/5 convs and DCNs run 120-240 workgroups on 256 CUs at B = 8) and their tails
+        ns = args.streams
+        if B % ns:
+            raise SystemExit("--streams must divide --batch")
+        per = B // ns
+        parts = [(images[i * per:(i + 1) * per].contiguous(), model.device_targets(targets[i * per:(i + 1) * per], device)) for i in range(ns)]
+        side_streams = [torch.cuda.Stream() for _ in range(ns - 1)]
+
+        def step():                                               # noqa: F811
+            cur = torch.cuda.current_stream()
+            outs = [None] * ns
+            for i, st in enumerate(side_streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    outs[i + 1] = model.detect_device(parts[i + 1][0], *parts[i + 1][1])
+            outs[0] = model.detect_device(parts[0][0], *parts[0][1])
+            for st in side_streams:
+                cur.wait_stream(st)
+            return tuple(torch.cat([o[k] for o in outs]) for k in range(3)) + ([o[3] for o in outs],)
+
     with torch.no_grad():
         for _ in range(max(args.warmup, 2)):
             out = step()
@@ -212,6 +235,9 @@ def run_infer(args, rank, world, device):
             dist.barrier()
         elapsed = time.perf_counter() - t0
         det, topk, valid, hm = out
+        if isinstance(hm, list):
+            hm = torch.cat(hm)
+            out = (det, topk, valid, hm)
         rate, elapsed, n_img = parallel.aggregate_throughput(elapsed, B * args.steps, device=device)
 
         # ---- roofline of the dominant kernel (fused heads: 46 % of the forward FLOPs), HIP events on the launch stream
