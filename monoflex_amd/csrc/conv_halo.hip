@@ -52,7 +52,7 @@ template <> __device__ __forceinline__ f32x2 halo_round2<bf16_t>(float a, float 
     return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
 }
 
-template <typename T, typename TO, int WN, int FN, int WK = 1>
+template <typename T, typename TO, int WN, int FN, int WK = 1, bool ST = false>
 __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                                       const u32x4* __restrict__ wfm, HaloGeom g, EpiArgs ep) {
     constexpr int NT = WN * WK * 64, FM = kHaloRows;
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
     f32x2 st_s[FN], st_q[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) { st_s[j] = f32x2{0.f, 0.f}; st_q[j] = f32x2{0.f, 0.f}; }
-    const bool st_on = ep.stats != nullptr;
+    constexpr bool st_on = ST;           // a SEPARATE instantiation: with the statistics code merely branched around, the widest variant
+                                         // (<4,4>: 250+ VGPRs) lost a third of its speed even with ep.stats == nullptr (80 -> 130 us)
 #pragma unroll
     for (int ii = 0; ii < RW; ++ii) {
         const int i = WK > 1 ? wk * RW + ii : ii;             // output row of accumulator slot ii
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
                 v[r] = acc[ii][j][r] * sc[j] + sh[j];
                 stage[((lane >> 4) * 4 + r) * LDS_ + j * 16 + xl] = v[r];
             }
-            if (st_on && row_in) {
+            if (ST && row_in) {
                 const int px = x0 + (lane >> 4) * 4;
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
@@ -327,7 +328,7 @@ apply_act_chunk<OE>(v, ep.act, gn);
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (ep.stats) {
+    if constexpr (ST) {
         float* sp = ep.stats + (size_t)(blockIdx.x % ep.stats_ncopy) * 2 * ep.Cout;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -346,8 +347,23 @@ static inline int ilog2h(int v) { int l = 0; while ((1 << l) < v) ++l; return l;
 int g_opt_halo = 1;          // 0 = generic kernel only, 1 = automatic, >= 2 = force variant (value - 1)
 int g_opt_halo_cg = 0;       // max channels per patch pass (0 = default)
 
+template <typename T, typename TO, int WN, int FN, int WK = 1, bool ST = false>
+static int launch_halo_st(const mfx_conv_desc* d, hipStream_t st);
+
+static bool g_halo_stats_ran = false;    // set by the launch that ran a statistics-accumulating instantiation (read by try_conv_halo)
+
+// statistics-accumulating instantiations exist for output tiles up to 128 channels wide (wider ones are atomic-bound there,
+// autograd.py keeps the separate pass for them)
 template <typename T, typename TO, int WN, int FN, int WK = 1>
 static int launch_halo(const mfx_conv_desc* d, hipStream_t st) {
+    if constexpr (WN * FN * 16 <= 128 && std::is_same<T, TO>::value) {
+        if (d->stats) { g_halo_stats_ran = true; return launch_halo_st<T, TO, WN, FN, WK, true>(d, st); }
+    }
+    return launch_halo_st<T, TO, WN, FN, WK, false>(d, st);
+}
+
+template <typename T, typename TO, int WN, int FN, int WK, bool ST>
+static int launch_halo_st(const mfx_conv_desc* d, hipStream_t st) {
     using SM = HaloSmem<T, WN, FN, WK>;
     constexpr int ELEMS = ElemTraits<T>::ELEMS;
     constexpr int BN = WN * FN * 16;
@@ -361,9 +377,9 @@ static int launch_halo(const mfx_conv_desc* d, hipStream_t st) {
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
-    ep.stats = d->stats; ep.stats_ncopy = d->stats_ncopy > 0 ? d->stats_ncopy : 1;
+    ep.stats = ST ? d->stats : nullptr; ep.stats_ncopy = d->stats_ncopy > 0 ? d->stats_ncopy : 1;
     const int smem = SM::total(g.CG);
-    auto k = conv3x3_wave_kernel<T, TO, WN, FN, WK>;
+    auto k = conv3x3_wave_kernel<T, TO, WN, FN, WK, ST>;
     static int attr_smem = 0;
     if (smem > 64 * 1024 && smem > attr_smem) {
         MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -407,7 +423,16 @@ template <typename T, typename TO> static int halo_variant(int v, const mfx_conv
 static int variant_bn(int v) { const int bn[15] = {0, 16, 32, 64, 128, 256, 64, 128, 32, 32, 16, 128, 64, 64, 128}; return (v >= 1 && v <= 14) ? bn[v] : 0; }
 
 // returns 1 if the halo kernel handled the convolution, 0 if the caller should use the generic kernel, <0 on error
-int try_conv_halo(const mfx_conv_desc* d, hipStream_t st) {
+static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st);
+
+int try_conv_halo(const mfx_conv_desc* d, hipStream_t st, int* stats_ran) {
+    g_halo_stats_ran = false;
+    const int rc = try_conv_halo_impl(d, st);
+    if (stats_ran) *stats_ran = (rc == 1 && g_halo_stats_ran) ? 1 : 0;
+    return rc;
+}
+
+static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st) {
     if (g_opt_halo == 0) return 0;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_h != 1 || d->pad_w != 1 || d->dil_w != 1) return 0;
     if (d->rowmap || d->x_pixstride != d->Ck || d->Ho != d->H || d->Wo != d->W || d->M != d->B * d->H * d->W) return 0;

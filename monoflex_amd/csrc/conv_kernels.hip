@@ -274,7 +274,7 @@ static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; 
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-int try_conv_halo(const mfx_conv_desc* d, hipStream_t st);   // conv_halo.hip
+int try_conv_halo(const mfx_conv_desc* d, hipStream_t st, int* stats_ran);   // conv_halo.hip
 extern int g_opt_halo, g_opt_halo_cg, g_opt_dcn_wave, g_opt_dcn_patch, g_opt_dcn_patch_fn8, g_opt_dcn_wgrad_m;
 }
 extern int g_opt_heads_planes, g_opt_dcn_bt_cs, g_opt_dcn_bt_cs_wgs, g_opt_dcn_bt_dbg, g_opt_wgrad_tr, g_opt_wgrad_tr_blocks, g_opt_bn_blocks, g_opt_bn_apply_blocks, g_opt_wgrad_patch, g_opt_wgrad_patch_blocks, g_opt_wgrad_patch_waves;
@@ -447,9 +447,10 @@ extern "C" int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream) {
         return mfx_fail(MFX_ERR_ARG, "conv2d: output statistics need stats_done and a plain (no residual / activation / row map) epilogue");
     if (d->stats_done) *d->stats_done = 0;
     {
-        const int h = try_conv_halo(d, reinterpret_cast<hipStream_t>(stream));   // 3x3/s1: LDS-staged halo kernel
+        int ran = 0;
+        const int h = try_conv_halo(d, reinterpret_cast<hipStream_t>(stream), &ran);   // 3x3/s1: LDS-staged halo kernel
         if (h != 0) {
-            if (h > 0 && d->stats && d->stats_done) *d->stats_done = 1;
+            if (h > 0 && ran && d->stats_done) *d->stats_done = 1;
             return h < 0 ? h : MFX_OK;
         }
     }
