@@ -1,4 +1,4 @@
-# final artefacts of the round: bench lines (the exact default command first), training profile + timeline
+# bench lines (the exact default command first) and the training-step profile + replay timeline of the current HEAD -> gpurun_out/r02_*
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd $R
 timeout 900 python bench.py > gpurun_out/r02_final_bench_infer.json 2> gpurun_out/bench_infer.err; tail -c 600 gpurun_out/r02_final_bench_infer.json; echo
 timeout 600 python bench.py --dtype fp32 --no-cpu-baseline > gpurun_out/r02_final_bench_infer_fp32.json 2>/dev/null; cut -c1-260 gpurun_out/r02_final_bench_infer_fp32.json
