@@ -157,7 +157,7 @@ def test_regression_heads_at_object_centres_equal_the_dense_heads(dtype):
     scale = max(float(v.double().norm()) for v in gb.values())
     for n in ga:                                    # (a conv bias in front of a BN has a zero gradient: absolute floor)
         err = float((ga[n].double() - gb[n].double()).norm())
-        assert err < tol * float(gb[n].double().norm()) + 1e-6 * scale, (n, err, float(gb[n].double().norm()))
+        assert err < tol * float(gb[n].double().norm()) + (1e-5 if dtype == "bf16" else 1e-6) * scale, (n, err, float(gb[n].double().norm()))
     for k in sa:
         if "num_batches" in k:
             assert int(sa[k]) == int(sb[k]), k
