@@ -61,9 +61,16 @@ def dominant_kernel_roofline(dtype, B, device, H=96, W=320, C=64, Cout=64, reps=
     else:
         achieved = flops / ms / 1e9
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype], 4)}
+    traffic = traffic_source = None
+    try:                                                       # PMC pass of the same group (tools/pmc_dcnbwd.sh), committed with its raw CSV
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02_dcnbwd_traffic.json")))
+        if t.get("dtype") == dtype and t.get("batch") == B and (H, W, C, Cout) == (96, 320, 64, 64):
+            traffic, traffic_source = int(t["traffic_bytes"]), t["source"]
+    except (OSError, ValueError, KeyError):
+        pass
     roof.update({"kernel": "DCNv2 backward group (d(columns) GEMM, dcn_bwd_sample, dcn_bwd_tile, dcn_bwd_far, weight-gradient GEMM), %d->%d @ %dx%d, B=%d"
                            % (C, Cout, H, W, B),
-                 "traffic": None, "traffic_source": None, "avg_launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops,
+                 "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops,
                  "algorithmic_bytes_per_launch": alg_bytes, "hbm_floor_ms": round(hbm_floor_ms, 4), "mfma_floor_ms": round(mfma_floor_ms, 4),
                  "materialised_bytes_per_launch": int(2 * 2 * M * 9 * C * es),
                  "note": "the group writes and re-reads d(columns) and the columns (2 x M x 9C each): its own traffic is ~6x the algorithmic bytes"})
