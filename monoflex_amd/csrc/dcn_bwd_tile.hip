@@ -33,6 +33,9 @@ int mfx_internal_conv_wgrad(const void* x, const void* dy, float* dw, int B, int
                             int dtype, int oihw, int Cin_out, int Cout_out, void* stream, int dil_w,
                             void* workspace, size_t workspace_bytes, int direct);
 
+int mfx_internal_wgrad_slab_sum(const float* ws, int nslab, int Cout, int Ck, int kh, int kw, float* dw_oihw, void* stream);
+
+int g_opt_dcn_bt_fuse_wgrad = 1;   // option "dcn_bt_fuse_wgrad": 64 -> 64 bf16 layers accumulate grad_weight inside the sample kernel (no columns in memory)
 int g_opt_dcn_bt_cs = 0;       // option "dcn_bt_cs": channel slice of the tile kernel for C >= 128 (0 = by workgroup count, 64, 128)
 int g_opt_dcn_bt_cs_wgs = 1000; // option "dcn_bt_cs_wgs": below this many 128-channel workgroups the tile kernel takes 64-channel slices
 int g_opt_dcn_bt_dbg = 0;      // option "dcn_bt_dbg": experiment switches of dcn_bwd_tile_kernel (0 in production)
@@ -457,6 +460,160 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const T* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 64 -> 64 channel bf16 layers (the five 96x320 layers: 283 MB of columns each): the sample kernel with the weight gradient
+// folded in.  A workgroup walks chunks of 32 consecutive pixels of a row for ONE group of three taps (grid.y = 0..2): its four
+// waves blend the chunk's 96 samples as dcn_bwd_sample_kernel does, but the modulated columns go into an LDS tile
+// [tap][16-channel sub][pixel][32 B] next to the chunk's dy rows, and after a barrier the tile is multiplied on the matrix cores:
+// grad_weight[o][tap, c] += sum_px dy[px][o] * col[px][tap, c], both operands fetched with transposed LDS reads (the pixel is the
+// MFMA k index; wgrad_tr.hip explains the lane pattern), twelve 16x16 accumulator blocks per wave kept across all chunks.
+// The columns never reach memory: per launch 283 MB written + 283 MB re-read + the separate GEMM (103 us) are replaced by
+// 3 x 31 MB of dy reads and 75 MB of partial gradient blocks.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int SF_PX = 32, SF_TAPS = 3, SF_BT = SF_TAPS * 4;                   // chunk pixels, taps per workgroup, (tap, sub) tiles
+constexpr int SF_TILE = SF_PX * 32;                                          // bytes of one 16-channel tile of the chunk
+constexpr int SF_STAGE = (SF_BT + 4) * SF_TILE;                              // columns + dy of one chunk: 16 KB
+
+__global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
+                                                                  const bf16_t* __restrict__ gcol, const bf16_t* __restrict__ dy, BtGeom g,
+                                                                  int chunks_per_block, int nchunks, float* __restrict__ graw,
+                                                                  float* __restrict__ ws) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * SF_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sl = lane >> 3, cl = lane & 7;                                  // sample slot in the wave, 8-channel group
+    const int tg = blockIdx.y;                                                // taps 3*tg .. 3*tg+2
+    const int HW = g.H * g.W, cpr = g.W / SF_PX;                              // chunks per row (W is a multiple of 32)
+    const int c_begin = blockIdx.x * chunks_per_block, c_end = min(c_begin + chunks_per_block, nchunks);
+    const int c0 = cl * 8;
+
+    f32x4 acc[4][SF_TAPS];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < SF_TAPS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l16 = lane & 15, gq = lane >> 4;
+    const uint32_t lane_off = (uint32_t)((4 * gq + (l16 >> 2)) * 32 + (l16 & 3) * 8);
+    const uint32_t lds_a = (uint32_t)(uintptr_t)lds;
+    auto tr2 = [](uint32_t a) {
+        uint64_t l, h;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l), "=&v"(h) : "v"(a) : "memory");
+        return u32x4{(uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32)};
+    };
+
+    // raw offset / mask values of this lane's three samples of a chunk (prefetched one chunk ahead: they complete behind the
+    // previous chunk's barrier and MFMAs, so a chunk exposes ONE memory round trip -- its fifteen 16-byte gathers, all in flight)
+    struct Pre3 { float oh[3], ow[3], mk[3]; };
+    auto prefetch = [&](int ch) {
+        Pre3 p;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) { p.oh[it] = 0.f; p.ow[it] = 0.f; p.mk[it] = 0.f; }
+        if (ch < c_end) {
+            const int row = ch / cpr, x_begin = (ch - row * cpr) * SF_PX;
+            const size_t mrow = (size_t)row * g.W + x_begin;                  // row = b*H + my: pixel index of the chunk's first pixel
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int s = it * 32 + wv * 8 + sl, px = s / 3, tap = tg * SF_TAPS + (s - px * 3);
+                const float* r = om + (mrow + px) * 32;
+                p.oh[it] = r[2 * tap]; p.ow[it] = r[2 * tap + 1]; p.mk[it] = r[18 + tap];
+            }
+        }
+        return p;
+    };
+    Pre3 cur = prefetch(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        char* stage = lds + ((ch - c_begin) & 1) * SF_STAGE;
+        const int row = ch / cpr, x_begin = (ch - row * cpr) * SF_PX;         // (image, output row) and first pixel of the chunk
+        const int b = row / g.H, my = row - b * g.H;
+        const bf16_t* xb = x + (size_t)b * HW * g.C;
+        const size_t mrow = (size_t)b * HW + (size_t)my * g.W + x_begin;
+        // issue: dy rows of the chunk, then the five gathers of each of the three samples
+        const u32x4 dyv = *reinterpret_cast<const u32x4*>(dy + (mrow + (tid >> 3)) * g.C + (tid & 7) * 8);          // (Cout = C = 64)
+        struct Geo3 { bool inside; int tap, px, h0, w0; float lh, lw, mask; };
+        Geo3 q[3];
+        Raw8<bf16_t> rg[3], rv[3][4];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int s = it * 32 + wv * 8 + sl;
+            q[it].px = s / 3; q[it].tap = tg * SF_TAPS + (s - q[it].px * 3);
+            const int mx = x_begin + q[it].px;
+            const int th = (q[it].tap * 11) >> 5, tw = q[it].tap - th * 3;
+            const float h = (float)(my - 1 + th) + cur.oh[it], w = (float)(mx - 1 + tw) + cur.ow[it];
+            q[it].mask = cur.mk[it];
+            q[it].inside = h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
+            const float hf = floorf(h), wf = floorf(w);
+            q[it].lh = h - hf; q[it].lw = w - wf;
+            q[it].h0 = (int)fminf(fmaxf(hf, -4.f), 32000.f); q[it].w0 = (int)fminf(fmaxf(wf, -4.f), 32000.f);
+            if (q[it].inside) {
+                rg[it].load(gcol + (mrow + q[it].px) * g.Kp + q[it].tap * g.C + c0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int hc = q[it].h0 + (c >> 1), wc = q[it].w0 + (c & 1);
+                    if (hc >= 0 && hc < g.H && wc >= 0 && wc < g.W) rv[it][c].load(xb + ((size_t)hc * g.W + wc) * g.C + c0);
+                    else rv[it][c].zero();
+                }
+            }
+        }
+        const Pre3 nxt = prefetch(ch + 1);
+        // [o sub][pixel][32 B]
+        *reinterpret_cast<u32x4*>(stage + (SF_BT + ((tid & 7) >> 1)) * SF_TILE + (tid >> 3) * 32 + (tid & 1) * 16) = dyv;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int tap = q[it].tap, px = q[it].px, tl = tap - tg * SF_TAPS;
+            const size_t m = mrow + px;
+            const float lh = q[it].lh, lw = q[it].lw, mask = q[it].mask;
+            float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float gh = 0.f, gw = 0.f, gm = 0.f;
+            if (q[it].inside) {
+                float gc[8], v0[8], v1[8], v2[8], v3[8];
+                rg[it].unpack(gc); rv[it][0].unpack(v0); rv[it][1].unpack(v1); rv[it][2].unpack(v2); rv[it][3].unpack(v3);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float d10 = v1[k] - v0[k], d32 = v3[k] - v2[k];
+                    const float top = v0[k] + lw * d10, bot = v2[k] + lw * d32;
+                    const float dh = bot - top, val = top + lh * dh, dw = d10 + lh * (d32 - d10);
+                    cv[k] = mask * val;
+                    gm += gc[k] * val; gh += gc[k] * dh; gw += gc[k] * dw;
+                }
+            }
+            *reinterpret_cast<u32x4*>(stage + (tl * 4 + (cl >> 1)) * SF_TILE + px * 32 + (cl & 1) * 16) = ElemTraits<bf16_t>::pack(cv);
+            gh = bt_group_sum<8>(gh); gw = bt_group_sum<8>(gw); gm = bt_group_sum<8>(gm);
+            if (cl == 0) {
+                float* o = graw + m * 32;
+                o[2 * tap] = gh * mask; o[2 * tap + 1] = gw * mask; o[18 + tap] = gm * mask * (1.f - mask);
+                if (tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
+            }
+        }
+        cur = nxt;
+        __syncthreads();                                                      // tile complete (the other stage is free: two chunks ago)
+        {
+            const uint32_t sb = lds_a + (uint32_t)(((ch - c_begin) & 1) * SF_STAGE);
+            u32x4 df[4], cf[SF_TAPS];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) df[i] = tr2(sb + (uint32_t)((SF_BT + i) * SF_TILE) + lane_off);
+#pragma unroll
+            for (int j = 0; j < SF_TAPS; ++j) cf[j] = tr2(sb + (uint32_t)((wv * SF_TAPS + j) * SF_TILE) + lane_off);      // wave wv: tiles 3wv..3wv+2 of 12
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < SF_TAPS; ++j) mma_chunk<bf16_t>(df[i], cf[j], acc[i][j]);
+        }
+        // (two stages: the next chunk writes the other one; the barrier after ITS writes orders this chunk's reads before the
+        // writes of the chunk after next)
+    }
+    // partial block -> ws[blockIdx.x][o][k], k = tap*64 + sub*16 + (lane & 15); tile t = wv*3 + j = tl*4 + sub
+    float* slab = ws + (size_t)blockIdx.x * (64 * 576);
+#pragma unroll
+    for (int j = 0; j < SF_TAPS; ++j) {
+        const int t = wv * SF_TAPS + j, tl = t >> 2, sub = t & 3;
+        const int k = (tg * SF_TAPS + tl) * 64 + sub * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(size_t)(i * 16 + (lane >> 4) * 4 + r) * 576 + k] = acc[i][j][r];
+    }
+}
+
 static inline size_t bt_al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct BtLayout { size_t wT, gcol, col, cnt, flist, wg, total; long far_cap; };
@@ -469,7 +626,7 @@ static BtLayout bt_layout(int B, int C, int H, int W, int Cout, int es) {
     L.cnt = o;  o += 256;
     L.far_cap = (long)M * 36 * (C / 64);                      // every (sample, corner) pair of every (64-channel) slice: the list cannot fill
     L.flist = o; o += bt_al((size_t)L.far_cap * 16);
-    L.wg = o;   o += bt_al((size_t)24 * 1024 * 1024);         // partial tiles of the MFMA weight-gradient slabs
+    L.wg = o;   o += bt_al((size_t)80 * 1024 * 1024);         // partial blocks of the weight gradient (512 x 64 x 576 fp32 for the fused 64 -> 64 form)
     L.total = o;
     return L;
 }
@@ -515,7 +672,24 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
         const int force = g_opt_dcn_bt_cs;
         if (C >= 128 && (force == 64 || (force == 0 && wgs128 < g_opt_dcn_bt_cs_wgs))) { g.CS = 64; g.nslices = C / 64; }
     }
-    {   // grad_offset / grad_mask and the modulated columns: one lane group per (pixel, tap), every d_raw channel written
+    bool fused_wgrad = false;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        const long nchunks = M / SF_PX;
+        const size_t slab_bytes = (size_t)64 * 576 * sizeof(float);
+        if (g_opt_dcn_bt_fuse_wgrad && C == 64 && Cout == 64 && W % SF_PX == 0 && nchunks >= 1024 && L.total - L.wg >= 128 * slab_bytes) {
+            int nblk = (int)std::min<long>(512, (long)((L.total - L.wg) / slab_bytes));
+            const int cpb = (int)((nchunks + nblk - 1) / nblk);
+            nblk = (int)((nchunks + cpb - 1) / cpb);
+            float* slabs = reinterpret_cast<float*>(ws + L.wg);
+            hipLaunchKernelGGL(dcn_bwd_sample_wgrad_kernel, dim3((unsigned)nblk, 3), dim3(256), 0, st, x, offmask, (const bf16_t*)gcol, dy, gs, cpb, (int)nchunks,
+                               d_raw, slabs);
+            MFX_HIP_CHECK(hipGetLastError());
+            rc = mfx_internal_wgrad_slab_sum(slabs, nblk, Cout, C, 3, 3, dweight, stream);
+            if (rc) return rc;
+            fused_wgrad = true;
+        }
+    }
+    if (!fused_wgrad) {   // grad_offset / grad_mask and the modulated columns: one lane group per (pixel, tap), every d_raw channel written
         const int rows = B * H, xsplit = std::max(1, std::min(W / 16, (2048 + rows - 1) / rows));
         const dim3 sgrid((unsigned)rows, (unsigned)xsplit);
         if (gs.CS == 64) hipLaunchKernelGGL((dcn_bwd_sample_kernel<T, 8>), sgrid, dim3(256), 0, st, x, offmask, (const T*)gcol, gs, xsplit, d_raw, col);
@@ -528,7 +702,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     hipLaunchKernelGGL(dcn_bwd_far_kernel<T>, dim3(1024), dim3(256), 0, st, (const T*)gcol, (const u32x4*)flist, (const int*)cnt, far_cap, g, dx);
     MFX_HIP_CHECK(hipGetLastError());
     // grad_weight[o][c][tap] = sum_m dy[m][o] * col[m][tap*C + c]: MFMA GEMM over the pixels, written as (Cout, C, 3, 3)
-    rc = mfx_internal_conv_wgrad(col, dy, dweight, 1, 1, (int)M, K, C, 3, 3, 1, 0, 0, 1, (int)M, Cout, Cout, dt, 1, C, Cout, stream, 1,
+    if (!fused_wgrad) rc = mfx_internal_conv_wgrad(col, dy, dweight, 1, 1, (int)M, K, C, 3, 3, 1, 0, 0, 1, (int)M, Cout, Cout, dt, 1, C, Cout, stream, 1,
                                  ws + L.wg, L.total - L.wg, 1);
     if (rc) return rc;
     return mfx_colsum(dy, dbias, M, Cout, Cout, dt, stream);                    // grad_bias[o] = sum_m dy[m][o]

@@ -998,6 +998,16 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
     return MFX_OK;
 }
 
+// library-internal (dcn_bwd_tile.hip): sum `nslab` partial gradient blocks ws[slab][Cout][K] (k = tap*Ck + c) into dW (Cout, Ck, kh, kw)
+int mfx_internal_wgrad_slab_sum(const float* ws, int nslab, int Cout, int Ck, int kh, int kw, float* dw_oihw, void* stream) {
+    WgradGeom g = {};
+    g.Cout = Cout; g.Ck = Ck; g.kh = kh; g.kw = kw; g.K = kh * kw * Ck; g.oihw = 1; g.Cin_out = Ck; g.Cout_out = Cout;
+    const long total = (long)Cout * g.K;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, WR_GRID(total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ws, nslab, total, g.K, g, dw_oihw);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
 // library-internal (dcn_bwd_tile.hip): the DCN weight gradient is a weight gradient over the dense columns matrix
 int mfx_internal_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
                             int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
