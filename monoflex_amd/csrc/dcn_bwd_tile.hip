@@ -35,6 +35,7 @@ int mfx_internal_conv_wgrad(const void* x, const void* dy, float* dw, int B, int
 
 int mfx_internal_wgrad_slab_sum(const float* ws, int nslab, int Cout, int Ck, int kh, int kw, float* dw_oihw, void* stream);
 
+int g_opt_dcn_bt_fuse_blocks = 170; // option "dcn_bt_fuse_blocks": workgroups per tap group of the fused kernel
 int g_opt_dcn_bt_fuse_wgrad = 1;   // option "dcn_bt_fuse_wgrad": 64 -> 64 bf16 layers accumulate grad_weight inside the sample kernel (no columns in memory)
 int g_opt_dcn_bt_cs = 0;       // option "dcn_bt_cs": channel slice of the tile kernel for C >= 128 (0 = by workgroup count, 64, 128)
 int g_opt_dcn_bt_cs_wgs = 1000; // option "dcn_bt_cs_wgs": below this many 128-channel workgroups the tile kernel takes 64-channel slices
@@ -501,90 +502,97 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const bf16_t*
         return u32x4{(uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32)};
     };
 
-    // raw offset / mask values of this lane's three samples of a chunk (prefetched one chunk ahead: they complete behind the
-    // previous chunk's barrier and MFMAs, so a chunk exposes ONE memory round trip -- its fifteen 16-byte gathers, all in flight)
-    struct Pre3 { float oh[3], ow[3], mk[3]; };
-    auto prefetch = [&](int ch) {
-        Pre3 p;
-#pragma unroll
-        for (int it = 0; it < 3; ++it) { p.oh[it] = 0.f; p.ow[it] = 0.f; p.mk[it] = 0.f; }
-        if (ch < c_end) {
-            const int row = ch / cpr, x_begin = (ch - row * cpr) * SF_PX;
-            const size_t mrow = (size_t)row * g.W + x_begin;                  // row = b*H + my: pixel index of the chunk's first pixel
-#pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int s = it * 32 + wv * 8 + sl, px = s / 3, tap = tg * SF_TAPS + (s - px * 3);
-                const float* r = om + (mrow + px) * 32;
-                p.oh[it] = r[2 * tap]; p.ow[it] = r[2 * tap + 1]; p.mk[it] = r[18 + tap];
-            }
-        }
+    // The lane's samples form one stream over (chunk, it = 0..2), software-pipelined as in dcn_bwd_sample_kernel: while sample i
+    // is blended, the five gathers of sample i+1 are in flight and the raw offsets of sample i+2 are being fetched -- also across
+    // the chunk's barrier and MFMAs.  (Issuing all three samples of a chunk at once cost 194 VGPRs next to the 48 accumulators.)
+    struct Loc { bool ok; int my, px, tap; size_t m; const bf16_t* xb; int mx; };
+    auto locate = [&](int ch, int it) {
+        Loc q;
+        q.ok = ch < c_end;
+        const int chc = q.ok ? ch : c_begin;
+        const int row = chc / cpr, x_begin = (chc - row * cpr) * SF_PX;
+        const int b = row / g.H;
+        q.my = row - b * g.H;
+        const int s = it * 32 + wv * 8 + sl;
+        q.px = s / 3; q.tap = tg * SF_TAPS + (s - q.px * 3);
+        q.mx = x_begin + q.px;
+        q.m = (size_t)b * HW + (size_t)q.my * g.W + q.mx;
+        q.xb = x + (size_t)b * HW * g.C;
+        return q;
+    };
+    struct Pre { float oh, ow, mk; };
+    auto prefetch = [&](const Loc& q) {
+        Pre p = {0.f, 0.f, 0.f};
+        if (q.ok) { const float* r = om + q.m * 32; p.oh = r[2 * q.tap]; p.ow = r[2 * q.tap + 1]; p.mk = r[18 + q.tap]; }
         return p;
     };
-    Pre3 cur = prefetch(c_begin);
+    struct Geo { bool inside; int h0, w0; float lh, lw, mask; };
+    auto geo = [&](const Loc& q, const Pre& p) {
+        Geo e;
+        const int th = (q.tap * 11) >> 5, tw = q.tap - th * 3;
+        const float h = (float)(q.my - 1 + th) + p.oh, w = (float)(q.mx - 1 + tw) + p.ow;
+        e.mask = p.mk;
+        e.inside = q.ok && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
+        const float hf = floorf(h), wf = floorf(w);
+        e.lh = h - hf; e.lw = w - wf;
+        e.h0 = (int)fminf(fmaxf(hf, -4.f), 32000.f); e.w0 = (int)fminf(fmaxf(wf, -4.f), 32000.f);
+        return e;
+    };
+    struct Raw5 { Raw8<bf16_t> g, v[4]; };
+    auto issue = [&](const Loc& q, const Geo& e) {
+        Raw5 r;
+        if (e.inside) {
+            r.g.load(gcol + q.m * g.Kp + q.tap * g.C + c0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int hc = e.h0 + (c >> 1), wc = e.w0 + (c & 1);
+                if (hc >= 0 && hc < g.H && wc >= 0 && wc < g.W) r.v[c].load(q.xb + ((size_t)hc * g.W + wc) * g.C + c0);
+                else r.v[c].zero();
+            }
+        }
+        return r;
+    };
+    Loc l0 = locate(c_begin, 0), l1 = locate(c_begin, 1);
+    Geo e0 = geo(l0, prefetch(l0));
+    Raw5 r0 = issue(l0, e0);
+    Pre p1 = prefetch(l1);
     for (int ch = c_begin; ch < c_end; ++ch) {
         char* stage = lds + ((ch - c_begin) & 1) * SF_STAGE;
-        const int row = ch / cpr, x_begin = (ch - row * cpr) * SF_PX;         // (image, output row) and first pixel of the chunk
-        const int b = row / g.H, my = row - b * g.H;
-        const bf16_t* xb = x + (size_t)b * HW * g.C;
-        const size_t mrow = (size_t)b * HW + (size_t)my * g.W + x_begin;
-        // issue: dy rows of the chunk, then the five gathers of each of the three samples
-        const u32x4 dyv = *reinterpret_cast<const u32x4*>(dy + (mrow + (tid >> 3)) * g.C + (tid & 7) * 8);          // (Cout = C = 64)
-        struct Geo3 { bool inside; int tap, px, h0, w0; float lh, lw, mask; };
-        Geo3 q[3];
-        Raw8<bf16_t> rg[3], rv[3][4];
+        const u32x4 dyv = *reinterpret_cast<const u32x4*>(dy + (l0.m - l0.px + (tid >> 3)) * g.C + (tid & 7) * 8);      // dy rows of the chunk (Cout = C = 64)
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
-            const int s = it * 32 + wv * 8 + sl;
-            q[it].px = s / 3; q[it].tap = tg * SF_TAPS + (s - q[it].px * 3);
-            const int mx = x_begin + q[it].px;
-            const int th = (q[it].tap * 11) >> 5, tw = q[it].tap - th * 3;
-            const float h = (float)(my - 1 + th) + cur.oh[it], w = (float)(mx - 1 + tw) + cur.ow[it];
-            q[it].mask = cur.mk[it];
-            q[it].inside = h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
-            const float hf = floorf(h), wf = floorf(w);
-            q[it].lh = h - hf; q[it].lw = w - wf;
-            q[it].h0 = (int)fminf(fmaxf(hf, -4.f), 32000.f); q[it].w0 = (int)fminf(fmaxf(wf, -4.f), 32000.f);
-            if (q[it].inside) {
-                rg[it].load(gcol + (mrow + q[it].px) * g.Kp + q[it].tap * g.C + c0);
+            const Loc l2 = it == 0 ? locate(ch, 2) : locate(ch + 1, it - 1);          // the sample after next
+            const Pre p2 = prefetch(l2);
+            const Geo e1 = geo(l1, p1);
+            const Raw5 r1 = issue(l1, e1);
+            {   // blend sample l0 (always inside this chunk)
+                const int tl = l0.tap - tg * SF_TAPS;
+                float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float gh = 0.f, gw = 0.f, gm = 0.f;
+                if (e0.inside) {
+                    float gc[8], v0[8], v1[8], v2[8], v3[8];
+                    r0.g.unpack(gc); r0.v[0].unpack(v0); r0.v[1].unpack(v1); r0.v[2].unpack(v2); r0.v[3].unpack(v3);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int hc = q[it].h0 + (c >> 1), wc = q[it].w0 + (c & 1);
-                    if (hc >= 0 && hc < g.H && wc >= 0 && wc < g.W) rv[it][c].load(xb + ((size_t)hc * g.W + wc) * g.C + c0);
-                    else rv[it][c].zero();
+                    for (int k = 0; k < 8; ++k) {
+                        const float d10 = v1[k] - v0[k], d32 = v3[k] - v2[k];
+                        const float top = v0[k] + e0.lw * d10, bot = v2[k] + e0.lw * d32;
+                        const float dh = bot - top, val = top + e0.lh * dh, dw = d10 + e0.lh * (d32 - d10);
+                        cv[k] = e0.mask * val;
+                        gm += gc[k] * val; gh += gc[k] * dh; gw += gc[k] * dw;
+                    }
+                }
+                *reinterpret_cast<u32x4*>(stage + (tl * 4 + (cl >> 1)) * SF_TILE + l0.px * 32 + (cl & 1) * 16) = ElemTraits<bf16_t>::pack(cv);
+                gh = bt_group_sum<8>(gh); gw = bt_group_sum<8>(gw); gm = bt_group_sum<8>(gm);
+                if (cl == 0) {
+                    float* o = graw + l0.m * 32;
+                    o[2 * l0.tap] = gh * e0.mask; o[2 * l0.tap + 1] = gw * e0.mask; o[18 + l0.tap] = gm * e0.mask * (1.f - e0.mask);
+                    if (l0.tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
                 }
             }
+            l0 = l1; e0 = e1; r0 = r1; l1 = l2; p1 = p2;
         }
-        const Pre3 nxt = prefetch(ch + 1);
         // [o sub][pixel][32 B]
         *reinterpret_cast<u32x4*>(stage + (SF_BT + ((tid & 7) >> 1)) * SF_TILE + (tid >> 3) * 32 + (tid & 1) * 16) = dyv;
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int tap = q[it].tap, px = q[it].px, tl = tap - tg * SF_TAPS;
-            const size_t m = mrow + px;
-            const float lh = q[it].lh, lw = q[it].lw, mask = q[it].mask;
-            float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            float gh = 0.f, gw = 0.f, gm = 0.f;
-            if (q[it].inside) {
-                float gc[8], v0[8], v1[8], v2[8], v3[8];
-                rg[it].unpack(gc); rv[it][0].unpack(v0); rv[it][1].unpack(v1); rv[it][2].unpack(v2); rv[it][3].unpack(v3);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float d10 = v1[k] - v0[k], d32 = v3[k] - v2[k];
-                    const float top = v0[k] + lw * d10, bot = v2[k] + lw * d32;
-                    const float dh = bot - top, val = top + lh * dh, dw = d10 + lh * (d32 - d10);
-                    cv[k] = mask * val;
-                    gm += gc[k] * val; gh += gc[k] * dh; gw += gc[k] * dw;
-                }
-            }
-            *reinterpret_cast<u32x4*>(stage + (tl * 4 + (cl >> 1)) * SF_TILE + px * 32 + (cl & 1) * 16) = ElemTraits<bf16_t>::pack(cv);
-            gh = bt_group_sum<8>(gh); gw = bt_group_sum<8>(gw); gm = bt_group_sum<8>(gm);
-            if (cl == 0) {
-                float* o = graw + m * 32;
-                o[2 * tap] = gh * mask; o[2 * tap + 1] = gw * mask; o[18 + tap] = gm * mask * (1.f - mask);
-                if (tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
-            }
-        }
-        cur = nxt;
         __syncthreads();                                                      // tile complete (the other stage is free: two chunks ago)
         {
             const uint32_t sb = lds_a + (uint32_t)(((ch - c_begin) & 1) * SF_STAGE);
@@ -677,7 +685,8 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
         const long nchunks = M / SF_PX;
         const size_t slab_bytes = (size_t)64 * 576 * sizeof(float);
         if (g_opt_dcn_bt_fuse_wgrad && C == 64 && Cout == 64 && W % SF_PX == 0 && nchunks >= 1024 && L.total - L.wg >= 128 * slab_bytes) {
-            int nblk = (int)std::min<long>(512, (long)((L.total - L.wg) / slab_bytes));
+            // two workgroups fit a CU (210 registers per lane): 170 x 3 tap groups = one resident round of the chip, no tail, 170 slabs to sum
+            int nblk = (int)std::min<long>(g_opt_dcn_bt_fuse_blocks, (long)((L.total - L.wg) / slab_bytes));
             const int cpb = (int)((nchunks + nblk - 1) / nblk);
             nblk = (int)((nchunks + cpb - 1) / cpb);
             float* slabs = reinterpret_cast<float*>(ws + L.wg);
