@@ -92,12 +92,21 @@ class _PackRegistry:
             cp = ops.cout_pad(rows)
             packed = torch.empty((cp, K_pad), dtype=dtype, device=weight.device)
             frag = torch.empty_like(packed) if (kh == 3 and kw == 3 and stride == 1 and pad_h == 1 and pad_w == 1) else None
-            e = dict(ref=weakref.ref(weight), ptr=weight.data_ptr(), version=-1, packed=packed, frag=frag, cp=cp, K_pad=K_pad,
+            e = dict(ref=None, ptr=weight.data_ptr(), version=-1, packed=packed, frag=frag, cp=cp, K_pad=K_pad,
                      shape=(Cout, Cin, kh, kw), mode=mode, ck=ck, fp32=weight.dtype == torch.float32)
             if register:
+                tk = (weight.device, dtype)
+                # the entry (and its packed buffers) goes away with the parameter
+                e["ref"] = weakref.ref(weight, lambda _r, k=key, t=tk, reg=self: reg._drop(k, t))
                 self.entries[key] = e
-                self.dirty.add((weight.device, dtype))
+                self.dirty.add(tk)
+            else:
+                e["ref"] = weakref.ref(weight)
         return e
+
+    def _drop(self, key, table_key):
+        if self.entries.pop(key, None) is not None:
+            self.dirty.add(table_key)
 
     def pack_one(self, e, weight, dtype):
         Cout, Cin, kh, kw = e["shape"]

@@ -345,6 +345,10 @@ def test_packed_conv_operands_follow_the_parameter():
     n_before = len(AG._PACKS.entries)
     assert _rel(AG.conv2d(x, tmp, None, 1, 1), F.conv2d(x.permute(0, 3, 1, 2), tmp, padding=1).permute(0, 2, 3, 1)) < 1e-5
     assert len(AG._PACKS.entries) == n_before
+    import gc
+    del conv, w2, y, xd                                            # the packed buffers go with their parameters
+    gc.collect()
+    assert len(AG._PACKS.entries) <= n_before - 3                  # conv.weight: forward + data-gradient operands; w2: forward
 
 
 def test_maxpool_and_upsample_grads():
