@@ -5,11 +5,15 @@ torch.autograd only records the graph and routes gradients; every forward and ba
 libmonoflex_hip.so.  Activations are NHWC (B,H,W,C) CUDA tensors; parameters keep the reference's shapes
 (conv OIHW, BN vectors, deconv (C,1,k,k)), so optimizers and checkpoints see the usual tensors.
 
-Gradient recipes:
-  conv      dx = conv(dy [zero-inserted when stride 2], W flipped + in/out swapped)   (forward MFMA kernels)
-            dW = mfx_conv_wgrad_nhwc, db = mfx_colsum
-  BN+act    mfx_bn_stats / mfx_bn_act_fwd / mfx_bn_act_bwd (train-mode statistics, running stats updated in place)
-  DCNv2     mfx_dcn_nhwc / mfx_dcn_backward_nhwc (offsets, modulation mask, input, weight, bias)
+Gradient recipes (DESIGN.md section 4.6 has the kernels):
+  conv      dx = conv(dy [zero-inserted when stride 2], W flipped + in/out swapped)   (the forward MFMA kernels)
+            dW = mfx_conv_wgrad_oihw (LDS-patch / transposed-read / slab kernels), stem: mfx_stem_wgrad_bf16; db = mfx_colsum
+            operands packed once per step for every parameter: pack_all_weights() -> mfx_pack_conv_weights_batched
+  BN+act    mfx_bn_train_fwd / mfx_bn_train_bwd (two launches each; statistics optionally from the producing conv's epilogue:
+            conv2d_bn_stats); with SyncBN: mfx_bn_stats -> all-reduce -> mfx_bn_finalize -> mfx_bn_act_fwd and the split backward
+  DCNv2     mfx_dcn_nhwc / mfx_dcn_backward_v2 (tile-owned grad_input; offsets, mask, weight, bias gradients)
+  heads     dense: conv + BN + conv1x1; regression branches in training: SparseRegHeadsFn (object centres only)
+  loss      FocalLossFn (heat map), ObjectLossFn (the nine per-object terms, forward-mode gradient rows)
 """
 import ctypes
 
