@@ -223,6 +223,14 @@ class Conv2dFn(Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         stride, pad, has_bias, Cout = ctx.cfg
+        dx, dw, db = _conv_backward(x, weight, dy, stride, pad, has_bias, Cout, ctx.needs_input_grad[:3])
+        return dx, dw, db, None, None, None, None, None
+
+
+def _conv_backward(x, weight, dy, stride, pad, has_bias, Cout, needs, res=None):
+    """Gradients of y = conv2d(x, weight) (+ bias) given dy: (dx, dW, db).  `res` (same shape / dtype as dx) is added to dx in the
+    data-gradient conv's epilogue -- the other gradient path of x, so autograd has nothing left to add."""
+    if True:
         dy = _c(dy)
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
@@ -233,7 +241,7 @@ class Conv2dFn(Function):
         _, Ho, Wo, Cp = dy.shape
         kh, kw = weight.shape[2], weight.shape[3]
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if needs[0]:
             # the kernel rotated by 180 degrees with in/out swapped, as the operand of a stride-1 'full' correlation
             cin_pad = _pad_channels(Cin, x.dtype)
             pt = _pack_weight(weight, x.dtype, 1, cin_pad, Cp, 1, kh - 1 - pad, kw - 1 - pad)
@@ -242,18 +250,20 @@ class Conv2dFn(Function):
                 g = torch.empty((B, H, W, Cp), dtype=dy.dtype, device=dy.device)
                 L.check(L.load().mfx_zero_insert2_nhwc(_ptr(dy), _ptr(g), B, Ho, Wo, Cp, H, W, _dt(dy.dtype), _stream()),
                         "mfx_zero_insert2_nhwc")
-            dx = ops.conv2d(g, pt)
+            dx = ops.conv2d(g, pt, res=res if (res is not None and cin_pad == Cin) else None)
             if cin_pad != Cin:
                 dx = dx[..., :Cin]
-        if ctx.needs_input_grad[1]:
+                if res is not None:
+                    dx = dx + res
+        if needs[1]:
             dwf = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
             ws = ops._splitk_workspace(x.device)                 # per-slab partial tiles (bf16 path), shared per stream
             L.check(L.load().mfx_conv_wgrad_oihw(_ptr(x), _ptr(dy), _ptr(dwf), B, H, W, Cin, Cin, kh, kw, stride, pad, pad, Ho, Wo, Cp, Cp,
                                                  Cout, Cin, _dt(x.dtype), _ptr(ws), ws.numel() * 4, _stream()), "mfx_conv_wgrad_oihw")
             dw = dwf if weight.dtype == torch.float32 else dwf.to(weight.dtype)
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and needs[2]:
             db = _colsum(dy)[:Cout]
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db
 
 
 @_device_guarded
@@ -580,6 +590,67 @@ class DCNFn(Function):
 
 
 _DCN_BWD_V1 = [False]          # tests: force the first-generation (global-atomics) backward for comparison
+
+
+@_device_guarded
+class DCNModuleFn(Function):
+    """The DCN module of the training path as ONE node (reference dcn_v2.py:118-128: conv_offset_mask -> sigmoid -> dcn_v2_conv):
+    x feeds both the offset/mask conv and the deformable sampling, so as two nodes autograd adds their two input gradients in a
+    separate pass per layer; here the offset conv's data-gradient conv takes the DCN's input gradient as its epilogue residual.
+    3x3 / stride 1 / pad 1 / dilation 1, channels a power of two >= 64 (the tile-owned backward)."""
+
+    @staticmethod
+    def forward(ctx, x, w_off, b_off, weight, bias):
+        x = _c(x)
+        n_off, Cin = w_off.shape[0], w_off.shape[1]
+        cpad = _pad_channels(n_off, torch.float32)
+        cp = ops.cout_pad(cpad)
+        sh = b_off.detach().float() if cp == n_off else torch.nn.functional.pad(b_off.detach().float(), (0, cp - n_off))
+        po = _pack_weight(w_off, x.dtype, 0, cpad, Cin, 1, 1, 1, sh)
+        po.act = L.ACT_DCN_OFFMASK
+        om = ops.conv2d(x, po, out_dtype=torch.float32)                       # offsets | sigmoid(mask logits), (B,H,W,32) fp32
+        Cout = weight.shape[0]
+        cpm = ops.cout_pad(Cout)
+        shift = None
+        if bias is not None:
+            shift = _c(bias.detach().float()) if cpm == Cout else torch.nn.functional.pad(bias.detach().float(), (0, cpm - Cout))
+        y = ops.dcn(x, om, _pack_weight(weight, x.dtype, 0, Cout, weight.shape[1], 1, 1, 1, shift))
+        ctx.save_for_backward(x, om, w_off, weight)
+        ctx.n_off = n_off
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, om, w_off, weight = ctx.saved_tensors
+        dy = _c(dy)
+        B, H, W, C = x.shape
+        Cout = weight.shape[0]
+        lib_ = L.load()
+        dt = _dt(x.dtype)
+        ws = ops._workspace(lib_.mfx_dcn_backward_v2_workspace_bytes(B, C, H, W, Cout, dt), x.device)
+        dx = torch.empty_like(x)
+        draw = torch.empty_like(om)
+        dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+        wc = _c(weight.detach() if weight.dtype == torch.float32 else weight.detach().float())
+        L.check(lib_.mfx_dcn_backward_v2(_ptr(x), _ptr(om), _ptr(wc), _ptr(dy if dy.dtype == x.dtype else dy.to(x.dtype)), _ptr(dx), _ptr(draw),
+                                         _ptr(dw), _ptr(db), B, C, H, W, Cout, dt, _ptr(ws), ws.numel(), _stream()), "mfx_dcn_backward_v2")
+        dx, dw_off, db_off = _conv_backward(x, w_off, draw, 1, 1, True, ctx.n_off, (True, True, True), res=dx)
+        return dx, dw_off, db_off, dw if weight.dtype == torch.float32 else dw.to(weight.dtype), db
+
+
+def dcn_module(x, w_off, b_off, weight, bias, stride, pad, dil):
+    """conv_offset_mask + DCNv2 of one module, differentiable; one fused node where the tile-owned backward applies."""
+    Cout, C, kh, kw = weight.shape
+    pow2 = lambda v: v >= 64 and (v & (v - 1)) == 0
+    if (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1) and pow2(C) and pow2(Cout) and b_off is not None and not _DCN_BWD_V1[0] and not _DCN_TWO_NODES[0]:
+        return DCNModuleFn.apply(x, w_off, b_off, weight, bias)
+    om = Conv2dFn.apply(x, w_off, b_off, stride, pad, torch.float32, L.ACT_DCN_OFFMASK)
+    return DCNFn.apply(x, om, weight, bias, stride, pad, dil, True)
+
+
+_DCN_TWO_NODES = [False]       # tests: offset conv and DCN as two autograd nodes (their input gradients added by autograd)
 
 
 @_device_guarded

@@ -118,8 +118,7 @@ class DCN(DCNv2):
         c = self.conv_offset_mask
         # (B,H,W,32), 27 used; the sigmoid of the 9 mask channels runs in the conv epilogue, and DCNFn returns the gradient
         # of the pre-activation (both generations of the backward fold the sigmoid derivative in)
-        om = AG.Conv2dFn.apply(x, c.weight, c.bias, self.stride[0], self.padding[0], torch.float32, L.ACT_DCN_OFFMASK)
-        return AG.DCNFn.apply(x, om, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0], True)
+        return AG.dcn_module(x, c.weight, c.bias, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
 
     def forward(self, input):
         if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad and self.training):
