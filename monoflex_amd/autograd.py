@@ -640,6 +640,47 @@ class DCNModuleFn(Function):
         return dx, dw_off, db_off, dw if weight.dtype == torch.float32 else dw.to(weight.dtype), db
 
 
+@_device_guarded
+class FanOutConvFn(Function):
+    """Several bias-free stride-1 convolutions of ONE input (the nine head trunks on the backbone feature map) as one node: the
+    data-gradient convs are chained through their epilogue residual, so the input gradient comes out summed instead of as one map
+    per consumer for autograd to add."""
+
+    @staticmethod
+    def forward(ctx, x, pad, *weights):
+        x = _c(x)
+        ys = []
+        for w in weights:
+            Cout, Cin = w.shape[0], w.shape[1]
+            cpad = _pad_channels(Cout, x.dtype)
+            if cpad != Cout:
+                raise ValueError("FanOutConvFn: output channels must fill whole 16-byte chunks")
+            ys.append(ops.conv2d(x, _pack_weight(w, x.dtype, 0, cpad, Cin, 1, pad, pad)))
+        ctx.save_for_backward(x, *weights)
+        ctx.pad = pad
+        return tuple(ys)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        x, weights = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dx, dws = None, []
+        for i, (w, dy) in enumerate(zip(weights, dys)):
+            if dy is None:
+                dws.append(None)
+                continue
+            need_x = ctx.needs_input_grad[0]
+            d, dw, _ = _conv_backward(x, w, dy, 1, ctx.pad, False, w.shape[0], (need_x, ctx.needs_input_grad[2 + i], False), res=dx)
+            dx = d if need_x else None
+            dws.append(dw)
+        return (dx, None, *dws)
+
+
+def fanout_conv(x, weights, pad):
+    """[conv2d(x, w, stride 1, pad) for w in weights] with ONE summed input gradient (FanOutConvFn)."""
+    return list(FanOutConvFn.apply(x, pad, *weights))
+
+
 def dcn_module(x, w_off, b_off, weight, bias, stride, pad, dil):
     """conv_offset_mask + DCNv2 of one module, differentiable; one fused node where the tile-owned backward applies."""
     Cout, C, kh, kw = weight.shape

@@ -210,10 +210,11 @@ class _predictor(nn.Module):
         oi = self.offset_index[0]
         sparse = object_rows is not None
         feats, outs, sp = [], [], []
+        ys = AG.fanout_conv(features, [t[0].weight for t in trunks], 1)         # nine trunk convs, one summed gradient for `features`
         for bi, (t, heads) in enumerate(zip(trunks, lasts)):
             w = heads[0].weight if len(heads) == 1 else torch.cat([h.weight for h in heads], 0)
             b = heads[0].bias if len(heads) == 1 else torch.cat([h.bias for h in heads], 0)
-            y, done = AG.conv2d_bn_stats(features, t[0].weight, None, 1, 1, t[1])
+            y, done = ys[bi], False
             if sparse and bi != 0 and bi - 1 != oi:
                 sp.append((bi - 1, y, t[1], w, b, done))
                 feats.append(None); outs.append(None)
