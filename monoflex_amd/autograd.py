@@ -230,40 +230,39 @@ class Conv2dFn(Function):
 def _conv_backward(x, weight, dy, stride, pad, has_bias, Cout, needs, res=None):
     """Gradients of y = conv2d(x, weight) (+ bias) given dy: (dx, dW, db).  `res` (same shape / dtype as dx) is added to dx in the
     data-gradient conv's epilogue -- the other gradient path of x, so autograd has nothing left to add."""
-    if True:
-        dy = _c(dy)
-        if dy.dtype != x.dtype:
-            dy = dy.to(x.dtype)
-        emin = 4 if x.dtype == torch.float32 else 8
-        if dy.shape[-1] < emin:                                # fp32-out head conv in bf16 mode: 4 channels < one bf16 chunk
-            dy = torch.nn.functional.pad(dy, (0, emin - dy.shape[-1]))
-        B, H, W, Cin = x.shape
-        _, Ho, Wo, Cp = dy.shape
-        kh, kw = weight.shape[2], weight.shape[3]
-        dx = dw = db = None
-        if needs[0]:
-            # the kernel rotated by 180 degrees with in/out swapped, as the operand of a stride-1 'full' correlation
-            cin_pad = _pad_channels(Cin, x.dtype)
-            pt = _pack_weight(weight, x.dtype, 1, cin_pad, Cp, 1, kh - 1 - pad, kw - 1 - pad)
-            g = dy
-            if stride == 2:
-                g = torch.empty((B, H, W, Cp), dtype=dy.dtype, device=dy.device)
-                L.check(L.load().mfx_zero_insert2_nhwc(_ptr(dy), _ptr(g), B, Ho, Wo, Cp, H, W, _dt(dy.dtype), _stream()),
-                        "mfx_zero_insert2_nhwc")
-            dx = ops.conv2d(g, pt, res=res if (res is not None and cin_pad == Cin) else None)
-            if cin_pad != Cin:
-                dx = dx[..., :Cin]
-                if res is not None:
-                    dx = dx + res
-        if needs[1]:
-            dwf = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-            ws = ops._splitk_workspace(x.device)                 # per-slab partial tiles (bf16 path), shared per stream
-            L.check(L.load().mfx_conv_wgrad_oihw(_ptr(x), _ptr(dy), _ptr(dwf), B, H, W, Cin, Cin, kh, kw, stride, pad, pad, Ho, Wo, Cp, Cp,
-                                                 Cout, Cin, _dt(x.dtype), _ptr(ws), ws.numel() * 4, _stream()), "mfx_conv_wgrad_oihw")
-            dw = dwf if weight.dtype == torch.float32 else dwf.to(weight.dtype)
-        if has_bias and needs[2]:
-            db = _colsum(dy)[:Cout]
-        return dx, dw, db
+    dy = _c(dy)
+    if dy.dtype != x.dtype:
+        dy = dy.to(x.dtype)
+    emin = 4 if x.dtype == torch.float32 else 8
+    if dy.shape[-1] < emin:                                # fp32-out head conv in bf16 mode: 4 channels < one bf16 chunk
+        dy = torch.nn.functional.pad(dy, (0, emin - dy.shape[-1]))
+    B, H, W, Cin = x.shape
+    _, Ho, Wo, Cp = dy.shape
+    kh, kw = weight.shape[2], weight.shape[3]
+    dx = dw = db = None
+    if needs[0]:
+        # the kernel rotated by 180 degrees with in/out swapped, as the operand of a stride-1 'full' correlation
+        cin_pad = _pad_channels(Cin, x.dtype)
+        pt = _pack_weight(weight, x.dtype, 1, cin_pad, Cp, 1, kh - 1 - pad, kw - 1 - pad)
+        g = dy
+        if stride == 2:
+            g = torch.empty((B, H, W, Cp), dtype=dy.dtype, device=dy.device)
+            L.check(L.load().mfx_zero_insert2_nhwc(_ptr(dy), _ptr(g), B, Ho, Wo, Cp, H, W, _dt(dy.dtype), _stream()),
+                    "mfx_zero_insert2_nhwc")
+        dx = ops.conv2d(g, pt, res=res if (res is not None and cin_pad == Cin) else None)
+        if cin_pad != Cin:
+            dx = dx[..., :Cin]
+            if res is not None:
+                dx = dx + res
+    if needs[1]:
+        dwf = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+        ws = ops._splitk_workspace(x.device)                 # per-slab partial tiles (bf16 path), shared per stream
+        L.check(L.load().mfx_conv_wgrad_oihw(_ptr(x), _ptr(dy), _ptr(dwf), B, H, W, Cin, Cin, kh, kw, stride, pad, pad, Ho, Wo, Cp, Cp,
+                                             Cout, Cin, _dt(x.dtype), _ptr(ws), ws.numel() * 4, _stream()), "mfx_conv_wgrad_oihw")
+        dw = dwf if weight.dtype == torch.float32 else dwf.to(weight.dtype)
+    if has_bias and needs[2]:
+        db = _colsum(dy)[:Cout]
+    return dx, dw, db
 
 
 @_device_guarded
