@@ -19,12 +19,16 @@
 #include "err.h"
 #include "igemm.h"
 
+int g_opt_heads_persist = 1;   // option "heads_persist": 1 = one workgroup per resident slot (n > 1: n workgroups), each a contiguous range of (tile, branch)
+                               // units; 0 = one workgroup per tile.  B=8 bf16: 516 -> 503 us (tools/probes/heads_probe.py), bit-identical output
+int g_opt_heads_dbg = 0;       // option "heads_dbg": timing probes of the bf16 kernel (see DBG below); results are wrong
+
 namespace mfx {
 
 constexpr int kHeadC = 64, kHeadTrunk = 256, kHeadRows = 8, kHeadWaves = 4, kHeadFN = 4;
 
 struct HeadGeom {
-    int B, H, W, tiles_x, tiles_y, nbranch, ld_out, planar_c, steps;
+    int B, H, W, tiles_x, tiles_y, nbranch, ld_out, planar_c, steps, persist;
     float* planar;
 };
 struct HeadTabs { int ch_off[16]; int c_out[16]; };
@@ -64,7 +68,9 @@ template <> struct TrunkPack<float> {       // k-block = 16 trunk channels = D f
 
 // w1p: fragment-major 3x3 weights  [branch][wn 4][step][j 4][lane 64][16 B]
 // w2p: fragment-major 1x1 weights  [branch][wn 4][kblk][of 2][lane 64][16 B]  (K order matching TrunkPack)
-template <typename T, bool PL>
+// DBG (timing probes only, results are wrong; option "heads_dbg"): bit 0 = the K loop keeps the first step's weight fragments
+// (no L2 -> register weight stream), bit 1 = it keeps the first pixel fragments (no LDS reads).
+template <typename T, bool PL, int DBG = 0>
 __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T* __restrict__ x, const u32x4* __restrict__ w1p,
                                                                          const float* __restrict__ scale1, const float* __restrict__ shift1,
                                                                          const u32x4* __restrict__ w2p, const float* __restrict__ bias2,
@@ -81,42 +87,62 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xl = lane & 15, kq = lane >> 4;
 
-    int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx = tile % g.tiles_x; tile /= g.tiles_x;
-    const int ty = tile % g.tiles_y; const int b = tile / g.tiles_y;
-    const int x0 = tx * 16, y0 = ty * kHeadRows;
-
-    // ---- halo patch (zero outside the image)
-    {
-        constexpr int CPP = kHeadC * (int)sizeof(T) / 16;
-        constexpr int nchunks = (kHeadRows + 2) * 18 * CPP;
-        const T* xg = x + (size_t)b * g.H * g.W * kHeadC;
-        constexpr int PU = 4;
-        for (int base = 0; base < nchunks; base += NT * PU) {
-            u32x4 pr[PU];
-#pragma unroll
-            for (int u = 0; u < PU; ++u) {
-                const int idx = base + u * NT + tid;
-                const int pix = idx / CPP, ch = idx - pix * CPP;
-                const int py = pix / 18, px = pix - py * 18;
-                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-                u32x4 z = {0u, 0u, 0u, 0u};
-                if (idx < nchunks && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-                    z = *reinterpret_cast<const u32x4*>(xg + ((size_t)iy * g.W + ix) * kHeadC + ch * ELEMS);
-                pr[u] = z;
-            }
-#pragma unroll
-            for (int u = 0; u < PU; ++u) {
-                const int idx = base + u * NT + tid;
-                if (idx < nchunks) *reinterpret_cast<u32x4*>(patch + (PL ? ((idx % CPP) & 3) * PLANE + (idx / CPP) * PS + ((idx % CPP) >> 2) * 16
-                                                                       : (idx / CPP) * PS + (idx % CPP) * 16)) = pr[u];
-            }
-        }
-    }
-    __syncthreads();
-
+    // Work = (tile, branch) units, tile-major.  Workgroup i of n takes the contiguous range [i*U/n, (i+1)*U/n): with one workgroup per
+    // tile (n = tiles) that is the tile's nine branches; the persistent launch (g.persist: n = resident workgroups, 2 per CU)
+    // hands every workgroup U/n +- 1 units, so the chip drains together instead of running a 3/4-full last round of whole tiles
+    // (1920 tiles on 512 slots).  The patch is reloaded whenever the tile changes.
+    const int wg = g.persist ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const long long units = (long long)g.tiles_x * g.tiles_y * g.B * g.nbranch;
+    const int u0 = (int)(units * wg / gridDim.x), u1 = (int)(units * (wg + 1) / gridDim.x);
+    if (u0 >= u1) return;
     const int steps = g.steps;                               // 9 * 64 / (4 * ELEMS): 18 (bf16) / 36 (f32)
-    for (int br = 0; br < g.nbranch; ++br) {
+
+    auto wsrc_of = [&](int br) { return w1p + ((size_t)(br * kHeadWaves + wn) * steps) * (FN * 64) + lane; };
+    auto wfetch = [&](const u32x4* wsrc, int s, u32x4 (&wf)[FN]) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) wf[j] = wsrc[(size_t)(s * FN + j) * 64];
+    };
+
+    int cur_tile = -1, b = 0, x0 = 0, y0 = 0;
+    for (int u = u0; u < u1; ++u) {
+        const int tile_u = u / g.nbranch, br = u - tile_u * g.nbranch;
+        if (tile_u != cur_tile) {
+            // ---- halo patch (zero outside the image).  Every wave is past the previous unit's reduction barriers, i.e. done reading
+            if (cur_tile >= 0) __syncthreads();
+            cur_tile = tile_u;
+            int ptid = tid;                                  // opaque here: hoisted out of the unit loop, the per-thread chunk offsets of
+            asm volatile("" : "+v"(ptid));                   // the patch copy (11 chunks x address pairs) stay live through the K loop and spill
+            int tile = tile_u;
+            const int tx = tile % g.tiles_x; tile /= g.tiles_x;
+            const int ty = tile % g.tiles_y; b = tile / g.tiles_y;
+            x0 = tx * 16; y0 = ty * kHeadRows;
+            constexpr int CPP = kHeadC * (int)sizeof(T) / 16;
+            constexpr int nchunks = (kHeadRows + 2) * 18 * CPP;
+            const T* xg = x + (size_t)b * g.H * g.W * kHeadC;
+            constexpr int PU = 4;
+            for (int base = 0; base < nchunks; base += NT * PU) {
+                u32x4 pr[PU];
+#pragma unroll
+                for (int q = 0; q < PU; ++q) {
+                    const int idx = base + q * NT + ptid;
+                    const int pix = idx / CPP, ch = idx - pix * CPP;
+                    const int py = pix / 18, px = pix - py * 18;
+                    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                    u32x4 z = {0u, 0u, 0u, 0u};
+                    if (idx < nchunks && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                        z = *reinterpret_cast<const u32x4*>(xg + ((size_t)iy * g.W + ix) * kHeadC + ch * ELEMS);
+                    pr[q] = z;
+                }
+#pragma unroll
+                for (int q = 0; q < PU; ++q) {
+                    const int idx = base + q * NT + ptid;
+                    if (idx < nchunks) *reinterpret_cast<u32x4*>(patch + (PL ? ((idx % CPP) & 3) * PLANE + (idx / CPP) * PS + ((idx % CPP) >> 2) * 16
+                                                                           : (idx / CPP) * PS + (idx % CPP) * 16)) = pr[q];
+                }
+            }
+            __syncthreads();
+        }
+
         f32x4 acc[FM][FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -124,11 +150,7 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // ---- GEMM1 (transposed): D[j][i] rows = trunk channel 64wn+16j+.., cols = pixel (row i, x = lane&15)
-        const u32x4* wsrc = w1p + ((size_t)(br * kHeadWaves + wn) * steps) * (FN * 64) + lane;
-        auto wfetch = [&](int s, u32x4 (&wf)[FN]) {
-#pragma unroll
-            for (int j = 0; j < FN; ++j) wf[j] = wsrc[(size_t)(s * FN + j) * 64];
-        };
+        const u32x4* wsrc = wsrc_of(br);
         auto compute = [&](int s, const u32x4 (&wf)[FN]) {
             const int e = s * (4 * ELEMS) + kq * ELEMS;      // this lane's K chunk -> (tap, channel)
             const int tap = e >> 6, cl = e & 63;
@@ -142,8 +164,8 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
             pf[0][1] = *reinterpret_cast<const u32x4*>(ap + 18 * PS);
 #pragma unroll
             for (int i = 0; i < FM; i += 2) {
-                const int cur = (i >> 1) & 1;
-                if (i + 2 < FM) {
+                const int cur = (DBG & 2) ? 0 : (i >> 1) & 1;
+                if (i + 2 < FM && !(DBG & 2)) {
                     pf[cur ^ 1][0] = *reinterpret_cast<const u32x4*>(ap + (i + 2) * 18 * PS);
                     pf[cur ^ 1][1] = *reinterpret_cast<const u32x4*>(ap + (i + 3) * 18 * PS);
                 }
@@ -156,35 +178,44 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
             }
         };
         u32x4 wb[3][FN];
-        wfetch(0, wb[0]);
-        wfetch(1, wb[1]);
-        for (int s = 0; s < steps; s += 3) {                 // steps is a multiple of 3 (18 / 36)
-            wfetch(s + 2, wb[2]);
-            compute(s, wb[0]);
-            if (s + 3 < steps) wfetch(s + 3, wb[0]);
-            compute(s + 1, wb[1]);
-            if (s + 4 < steps) wfetch(s + 4, wb[1]);
-            compute(s + 2, wb[2]);
-        }
-
-        // ---- BN + leaky in registers; GEMM2 straight from the accumulators
-        float sc[FN][4], sh[FN][4];
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(scale1 + br * kHeadTrunk + wn * 64 + j * 16 + kq * 4);
-            const f32x4 h4 = *reinterpret_cast<const f32x4*>(shift1 + br * kHeadTrunk + wn * 64 + j * 16 + kq * 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { sc[j][r] = s4[r]; sh[j][r] = h4[r]; }
-        }
         const int cn = tabs.c_out[br];
         const bool two = cn > 16;                            // second 16-row output fragment needed?
+        f32x4 s4[FN], h4[FN];                                // BN scale / shift of this wave's trunk channels
         u32x4 w2f[KBLK][2];
-        const u32x4* w2src = w2p + ((size_t)(br * kHeadWaves + wn) * KBLK) * (2 * 64) + lane;
+        auto load_scale = [&]() {
+            const int ko = kq * 4;
 #pragma unroll
-        for (int kb = 0; kb < KBLK; ++kb) {
-            w2f[kb][0] = w2src[(size_t)(kb * 2 + 0) * 64];
-            w2f[kb][1] = w2src[(size_t)(kb * 2 + 1) * 64];
+            for (int j = 0; j < FN; ++j) s4[j] = *reinterpret_cast<const f32x4*>(scale1 + br * kHeadTrunk + wn * 64 + j * 16 + ko);
+        };
+        auto load_shift = [&]() {
+            const int ko = kq * 4;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) h4[j] = *reinterpret_cast<const f32x4*>(shift1 + br * kHeadTrunk + wn * 64 + j * 16 + ko);
+        };
+        auto load_w2 = [&](int of) {
+            const u32x4* src = w2p + ((size_t)(br * kHeadWaves + wn) * KBLK) * (2 * 64) + lane;
+#pragma unroll
+            for (int kb = 0; kb < KBLK; ++kb) w2f[kb][of] = src[(size_t)(kb * 2 + of) * 64];
+        };
+        wfetch(wsrc, 0, wb[0]);
+        wfetch(wsrc, 1, wb[1]);
+        if (DBG & 1) wfetch(wsrc, 2, wb[2]);
+        for (int s = 0; s < steps; s += 3) {                 // steps is a multiple of 3 (18 / 36)
+            if (!(DBG & 1)) wfetch(wsrc, s + 2, wb[2]);
+            compute(s, wb[0]);
+            if (!(DBG & 1) && s + 3 < steps) wfetch(wsrc, s + 3, wb[0]);
+            compute(s + 1, wb[1]);
+            if (!(DBG & 1) && s + 4 < steps) wfetch(wsrc, s + 4, wb[1]);
+            compute(s + 2, wb[2]);
         }
+        // (fetching these between the last steps' MFMA blocks -- their ring slots are free by then -- was built and measured: the
+        // extra live registers spill, the scratch traffic shares vmcnt with the loads, 516 -> 542 us.  Not kept.)
+        load_scale();
+        load_shift();
+        load_w2(0);
+        load_w2(1);
+
+        // ---- BN + leaky in registers; GEMM2 straight from the accumulators
         const int co = tabs.ch_off[br];
         float* mine = red + wn * (kHeadRows * 16 * RLD);
         // partial 1x1 outputs of this wave: po[i][of] = D2[o = 16*of + 4*kq + r][pixel (row i, x = xl)]
@@ -196,7 +227,7 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
             for (int j = 0; j < FN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = acc[i][j][r] * sc[j][r] + sh[j][r];
+                    const float v = acc[i][j][r] * s4[j][r] + h4[j][r];
                     t[j][r] = v > 0.f ? v : 0.01f * v;
                 }
             po[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; po[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -242,19 +273,32 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
     }
 }
 
-template <typename T, bool PL> static int launch_heads(const mfx_heads_desc* d, hipStream_t st) {
+template <typename T, bool PL, int DBG = 0> static int launch_heads(const mfx_heads_desc* d, hipStream_t st) {
     HeadGeom g;
     g.B = d->B; g.H = d->H; g.W = d->W; g.tiles_x = (d->W + 15) / 16; g.tiles_y = (d->H + kHeadRows - 1) / kHeadRows;
     g.nbranch = d->nbranch; g.ld_out = d->ld_out; g.planar = d->planar; g.planar_c = d->planar_c;
     g.steps = 9 * kHeadC / (4 * ElemTraits<T>::ELEMS);
+    g.persist = 0;
     HeadTabs t;
     for (int i = 0; i < 16; ++i) { t.ch_off[i] = d->ch_off[i]; t.c_out[i] = d->c_out[i]; }
     const int tiles = g.tiles_x * g.tiles_y * d->B;
-    auto k = heads_fused_kernel<T, PL>;
+    int grid = tiles;
+    if (g_opt_heads_persist) {                               // two workgroups fit a CU (LDS, 2 waves per SIMD): one unit range per slot
+        static int slots = 0;
+        if (!slots) {
+            int dev = 0, cus = 0;
+            MFX_HIP_CHECK(hipGetDevice(&dev));
+            MFX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            slots = cus * (2 * HeadSmem<T, PL>::bytes <= 160 * 1024 ? 2 : 1);       // fp32: one 90 KB workgroup per CU
+        }
+        const int want = g_opt_heads_persist > 1 ? g_opt_heads_persist : slots;      // (> 1: that many workgroups -- tests)
+        if (tiles > want) { grid = want; g.persist = 1; }
+    }
+    auto k = heads_fused_kernel<T, PL, DBG>;
     constexpr int smem = HeadSmem<T, PL>::bytes;
     static bool attr_set = false;
     if (!attr_set && smem > 64 * 1024) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(kHeadWaves * 64), smem, st, reinterpret_cast<const T*>(d->x),
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kHeadWaves * 64), smem, st, reinterpret_cast<const T*>(d->x),
                        reinterpret_cast<const u32x4*>(d->w1), d->scale1, d->shift1, reinterpret_cast<const u32x4*>(d->w2), d->bias2,
                        d->out, g, t);
     MFX_HIP_CHECK(hipGetLastError());
@@ -278,6 +322,9 @@ extern "C" int mfx_heads_fused(const mfx_heads_desc* d, void* stream) {
     if (d->B * d->H * d->W == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == MFX_F32) return g_opt_heads_planes ? launch_heads<float, true>(d, st) : launch_heads<float, false>(d, st);
+    if (d->dtype == MFX_BF16 && g_opt_heads_dbg == 1) return launch_heads<bf16_t, false, 1>(d, st);
+    if (d->dtype == MFX_BF16 && g_opt_heads_dbg == 2) return launch_heads<bf16_t, false, 2>(d, st);
+    if (d->dtype == MFX_BF16 && g_opt_heads_dbg == 3) return launch_heads<bf16_t, false, 3>(d, st);
     if (d->dtype == MFX_BF16) return g_opt_heads_planes ? launch_heads<bf16_t, true>(d, st) : launch_heads<bf16_t, false>(d, st);
     return mfx_fail(MFX_ERR_ARG, "heads_fused: bad dtype");
 }

@@ -266,6 +266,42 @@ def test_heads_fused_vs_torch(dtype):
     assert float((got_reg - maps["reg"]).abs().max()) < tol * max(1.0, float(maps["reg"].abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_heads_fused_schedules_agree(dtype):
+    """The persistent launch (contiguous ranges of (tile, branch) units per workgroup, patch reloaded when the tile changes inside a
+    range) computes every output with the same operations in the same order as the one-workgroup-per-tile launch: bit-identical maps."""
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.model.head.detector_predictor import _predictor
+    import os
+    ops, L = _ops()
+    lib_ = L.load()
+    cfg = get_cfg(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "runs", "monoflex.yaml"))
+    m = _predictor(cfg, 64).eval().to(DEV)
+    pk = m._pack(dtype)
+    written = torch.zeros(pk.ld_out, dtype=torch.bool)                              # the row's gaps between branches are never written
+    for o, c in zip(pk.ch_off, pk.c_out):
+        written[o:o + c] = True
+    written = written.to(DEV)
+    x = torch.randn(3, 21, 37, 64, generator=_g(4)).relu().to(DEV, dtype)           # ragged: 3 x 3 tiles per image, 243 units
+
+    def run(**opts):
+        for k, v in opts.items():
+            L.check(lib_.mfx_set_option(k.encode(), v), "opt")
+        try:
+            hm, planar = ops.heads_fused(x, pk, planar_classes=3)
+            torch.cuda.synchronize()
+            return hm[..., written].clone(), planar.clone()
+        finally:
+            lib_.mfx_set_option(b"heads_persist", 1)      # the defaults
+            lib_.mfx_set_option(b"heads_planes", 0)
+
+    want = run(heads_persist=0)
+    assert bool(torch.isfinite(want[0]).all())
+    for opts in ({"heads_persist": 7}, {"heads_persist": 26}, {"heads_persist": 1}, {"heads_persist": 11, "heads_planes": 1}):
+        got = run(**opts)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), opts
+
+
 def test_decode_vs_reference_goldens(golden_dir):
     """Device decode against fixtures captured from the reference's own PostProcessor."""
     import os
