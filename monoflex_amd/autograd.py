@@ -171,9 +171,61 @@ class _PackRegistry:
 _PACKS = _PackRegistry()
 
 
+class _PadRegistry:
+    """Persistent zero-padded fp32 copies of bias parameters whose conv pads its output channels (the 27 -> 32 channel DCN offset
+    conv, the 3-channel class head): `F.pad` was a fill plus a copy launch per layer and step.  The tail is zeroed once; the head
+    is refreshed from the parameter -- all entries in one `_foreach_copy_` at the top of a step (`pack_all_weights`), or on demand
+    when the parameter's version moved."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, vec, n):
+        import weakref
+        key = (id(vec), n)
+        e = self.entries.get(key)
+        if e is not None and (e["ref"]() is not vec or e["ptr"] != vec.data_ptr()):
+            e = None
+        if e is None:
+            e = dict(ref=weakref.ref(vec, lambda _r, k=key, reg=self: reg.entries.pop(k, None)), ptr=vec.data_ptr(), version=-1,
+                     buf=torch.zeros(n, dtype=torch.float32, device=vec.device), m=vec.numel())
+            self.entries[key] = e
+        if e["version"] != vec._version:
+            e["buf"][:e["m"]].copy_(vec.detach())
+            e["version"] = vec._version
+        return e["buf"]
+
+    def refresh_all(self):
+        live = []
+        for key, e in list(self.entries.items()):
+            v = e["ref"]()
+            if v is None or v.data_ptr() != e["ptr"]:
+                del self.entries[key]
+            else:
+                live.append((e, v))
+        if live:                                               # unconditional, like the batched packing: a captured step replays it
+            torch._foreach_copy_([e["buf"][:e["m"]] for e, _ in live], [v.detach() for _, v in live])
+            for e, v in live:
+                e["version"] = v._version
+
+
+_PADS = _PadRegistry()
+
+
+def _padded_bias(bias, n):
+    """fp32 [n] shift vector of a conv whose output channels are padded to n: the bias followed by zeros."""
+    if bias.numel() == n:
+        return _c(bias.detach().float())
+    if isinstance(bias, torch.nn.Parameter) and bias.dtype == torch.float32 and bias.is_contiguous():
+        return _PADS.get(bias, n)
+    return torch.nn.functional.pad(bias.detach().float(), (0, n - bias.numel()))
+
+
 def pack_all_weights():
-    """Re-pack every conv operand the training path has used so far, one launch per (device, dtype); call at the top of a step."""
+    """Re-pack every conv operand the training path has used so far, one launch per (device, dtype), and refresh the padded bias
+    vectors; call at the top of a step."""
     _PACKS.pack_all()
+    _PADS.refresh_all()
 
 
 def _pack_weight(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, shift=None):
@@ -207,7 +259,7 @@ class Conv2dFn(Function):
         shift = None
         if bias is not None:
             cp = ops.cout_pad(cpad)
-            shift = bias.detach().float() if cp == Cout else torch.nn.functional.pad(bias.detach().float(), (0, cp - Cout))
+            shift = _padded_bias(bias, cp)
         p = _pack_weight(weight, x.dtype, 0, cpad, Cin, stride, pad, pad, shift)
         p.act = act
         if stats is not None and (cpad != Cout or ops.cout_pad(cpad) != Cout or act != L.ACT_NONE):
@@ -266,6 +318,64 @@ def _conv_backward(x, weight, dy, stride, pad, has_bias, Cout, needs, res=None):
 
 
 @_device_guarded
+class HeadConvGatherFn(Function):
+    """A head's 1x1 conv of its trunk activation f AND the gather of f's rows at the edge-sequence pixels, as ONE node
+    (reference detector_predictor.py:125-147: the class / 3d_offset trunks feed both their head conv and the edge fusion).
+    As two nodes the gather's gradient is a dense zero map of f's size (126 MB at B=8) with ~6.7k rows scattered into it, which
+    autograd then adds to the conv's data gradient in another full pass; here the rows are added into the data gradient in place.
+    Returns (y with padded channels, rows [len(rowmap), C])."""
+
+    @staticmethod
+    def forward(ctx, f, weight, bias, rowmap):
+        f = _c(f)
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        cpad = _pad_channels(Cout, torch.float32)
+        shift = _padded_bias(bias, ops.cout_pad(cpad)) if bias is not None else None
+        y = ops.conv2d(f, _pack_weight(weight, f.dtype, 0, cpad, Cin, 1, 0, 0, shift), out_dtype=torch.float32)
+        e = f.view(-1, Cin).index_select(0, rowmap)
+        ctx.save_for_backward(f, weight, rowmap)
+        ctx.cfg = (bias is not None, Cout)
+        return y, e
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, de):
+        f, weight, rowmap = ctx.saved_tensors
+        has_bias, Cout = ctx.cfg
+        needs = (True,) + tuple(ctx.needs_input_grad[1:3])       # the rows' gradient lands in dx
+        dx, dw, db = _conv_backward(f, weight, dy, 1, 0, has_bias, Cout, needs)
+        if not dx.is_contiguous():
+            dx = dx.contiguous()
+        dx.view(-1, dx.shape[-1]).index_add_(0, rowmap, _c(de).to(dx.dtype))       # replicate-padded ends / padding rows repeat: atomics
+        return dx, dw, db, None
+
+
+@_device_guarded
+class EdgeScatterAddFn(Function):
+    """out = base with o[b, l, :] added to channels [lo, lo + co) of the border pixel edge_xy[b, l], l < edge_len[b] (reference
+    detector_predictor.py:139-147; the first edge_len points of an image are unique).  `rows` = flat pixel row of every (b, l),
+    `valid` = (l < edge_len[b]) as fp32 [B, L, 1]: both depend on the targets only."""
+
+    @staticmethod
+    def forward(ctx, base, o, edge_xy, edge_len, lo, rows, valid):
+        out = base.clone() if base.is_contiguous() else base.contiguous()
+        o = _c(o.float())
+        ops.edge_scatter_add(out, lo, o.shape[-1], o, edge_xy, edge_len)
+        ctx.save_for_backward(rows, valid)
+        ctx.cfg = (lo, tuple(o.shape))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        rows, valid = ctx.saved_tensors
+        lo, (B, Lmax, co) = ctx.cfg
+        g = _c(g)
+        do = g.view(-1, g.shape[-1]).index_select(0, rows)[:, lo:lo + co].reshape(B, Lmax, co) * valid
+        return g, do, None, None, None, None, None
+
+
+@_device_guarded
 class CatConv1x1Fn(Function):
     """Root (dla_dcn.py:203-220): y = conv1x1(cat(xs, channel axis), weight) without materialising the concat.
     Backward per source i: dx_i = dy @ W[:, seg_i], dW[:, seg_i] = dy^T x_i."""
@@ -309,6 +419,9 @@ class CatConv1x1Fn(Function):
 _STEM_WGRAD_GENERIC = [False]    # True: the generic dilated-tap weight-gradient kernel also for the 16-channel bf16 stem (test switch)
 
 
+_STEM_FWD_GENERIC = [False]      # True: the stem's forward goes through the generic implicit-GEMM kernel (test switch)
+
+
 @_device_guarded
 class StemConvFn(Function):
     """7x7 / stride 1 / pad 3 convolution of the NCHW fp32 image batch (dla_dcn.py:268-272); no data gradient."""
@@ -319,7 +432,10 @@ class StemConvFn(Function):
         xp = ops.pack_image(images, dtype)
         one = torch.ones(weight.shape[0], device=images.device)
         p = ops.pack_stem(weight, dtype, one, torch.zeros_like(one), act=L.ACT_NONE)
-        y = ops.conv2d(xp, p, out_hw=(H, W))
+        if dtype == torch.bfloat16 and weight.shape[0] == 16 and not _STEM_FWD_GENERIC[0]:
+            y = ops.stem_conv(images, p)          # the inference stem kernel, raw output (60 vs 170 us at B=8); xp is only kept for the backward
+        else:
+            y = ops.conv2d(xp, p, out_hw=(H, W))
         ctx.save_for_backward(xp, weight)
         ctx.hw = (H, W)
         return y
@@ -537,7 +653,7 @@ class DCNFn(Function):
         shift = None
         if bias is not None:
             cp = ops.cout_pad(Cout)
-            shift = _c(bias.detach().float()) if cp == Cout else torch.nn.functional.pad(bias.detach().float(), (0, cp - Cout))
+            shift = _padded_bias(bias, cp)
         p = _pack_weight(weight, x.dtype, 0, Cout, Cin, stride, pad, pad, shift)
         p.dil_w = dil
         y = ops.dcn(x, om, p)
@@ -604,7 +720,7 @@ class DCNModuleFn(Function):
         n_off, Cin = w_off.shape[0], w_off.shape[1]
         cpad = _pad_channels(n_off, torch.float32)
         cp = ops.cout_pad(cpad)
-        sh = b_off.detach().float() if cp == n_off else torch.nn.functional.pad(b_off.detach().float(), (0, cp - n_off))
+        sh = _padded_bias(b_off, cp)
         po = _pack_weight(w_off, x.dtype, 0, cpad, Cin, 1, 1, 1, sh)
         po.act = L.ACT_DCN_OFFMASK
         om = ops.conv2d(x, po, out_dtype=torch.float32)                       # offsets | sigmoid(mask logits), (B,H,W,32) fp32
@@ -612,7 +728,7 @@ class DCNModuleFn(Function):
         cpm = ops.cout_pad(Cout)
         shift = None
         if bias is not None:
-            shift = _c(bias.detach().float()) if cpm == Cout else torch.nn.functional.pad(bias.detach().float(), (0, cpm - Cout))
+            shift = _padded_bias(bias, cpm)
         y = ops.dcn(x, om, _pack_weight(weight, x.dtype, 0, Cout, weight.shape[1], 1, 1, 1, shift))
         ctx.save_for_backward(x, om, w_off, weight)
         ctx.n_off = n_off

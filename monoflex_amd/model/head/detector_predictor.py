@@ -46,6 +46,8 @@ class InPlaceABN(nn.Module):
 
 
 class _predictor(nn.Module):
+    fused_edge_nodes = True         # training: head conv + edge-row gather as one autograd node, border scatter as one kernel (False: torch indexing)
+
     def __init__(self, cfg, in_channels):
         super().__init__()
         classes = len(cfg.DATASETS.DETECT_CLASSES)
@@ -211,6 +213,16 @@ class _predictor(nn.Module):
         sparse = object_rows is not None
         feats, outs, sp = [], [], []
         ys = AG.fanout_conv(features, [t[0].weight for t in trunks], 1)         # nine trunk convs, one summed gradient for `features`
+        fuse_nodes = self.enable_edge_fusion and self.fused_edge_nodes
+        edge_rows = {}
+        if self.enable_edge_fusion:
+            if edge_indices is None:
+                raise ValueError("edge fusion is enabled: targets must carry edge_indices / edge_len")
+            if fuse_nodes:                                   # functions of the targets only, shared by both fusions
+                Lm = edge_indices.shape[1]
+                rm = make_edge_rowmap(edge_indices, H, W).long()                          # rows of positions -1 .. L (replicate padding, k = 3)
+                rowmap, rows_center = rm, rm.view(B, Lm + 2)[:, 1:-1].reshape(-1)
+                valid_l = (torch.arange(Lm, device=features.device).view(1, Lm) < edge_lens.view(B, 1)).float().unsqueeze(-1)
         for bi, (t, heads) in enumerate(zip(trunks, lasts)):
             w = heads[0].weight if len(heads) == 1 else torch.cat([h.weight for h in heads], 0)
             b = heads[0].bias if len(heads) == 1 else torch.cat([h.bias for h in heads], 0)
@@ -221,25 +233,36 @@ class _predictor(nn.Module):
                 continue
             f = AG.bn_act(y, t[1], L.ACT_LEAKY, stats_done=done)
             feats.append(f)
-            outs.append(AG.conv2d(f, w, b, 1, 0, out_dtype=torch.float32))
+            if fuse_nodes and (bi == 0 or bi - 1 == oi):
+                # head conv + gather of the trunk's rows at the edge pixels in one node (one data gradient for f)
+                yo, er = AG.HeadConvGatherFn.apply(f, w, b, rowmap)
+                outs.append(yo if yo.shape[-1] == w.shape[0] else yo[..., :w.shape[0]])
+                edge_rows[bi] = er
+            else:
+                outs.append(AG.conv2d(f, w, b, 1, 0, out_dtype=torch.float32))
         cls, regs = outs[0], outs[1:]
         if self.enable_edge_fusion:
-            if edge_indices is None:
-                raise ValueError("edge fusion is enabled: targets must carry edge_indices / edge_len")
             oi, oj = self.offset_index
             Lmax = edge_indices.shape[1]
-            pos = torch.arange(-1, Lmax + 1, device=features.device).clamp(0, Lmax - 1)      # replicate padding, k=3
-            xy = edge_indices[:, pos].long()
-            bidx = torch.arange(B, device=features.device).view(B, 1).expand(B, Lmax + 2)
+            if not fuse_nodes:
+                pos = torch.arange(-1, Lmax + 1, device=features.device).clamp(0, Lmax - 1)      # replicate padding, k=3
+                xy = edge_indices[:, pos].long()
+                bidx = torch.arange(B, device=features.device).view(B, 1).expand(B, Lmax + 2)
             new = []
-            for f, seq, base in ((feats[0], self.trunc_heatmap_conv, cls), (feats[1 + oi], self.trunc_offset_conv, regs[oi])):
-                e = f[bidx, xy[..., 1], xy[..., 0]].view(B, 1, Lmax + 2, self.head_conv)      # grid_sample at integer points
+            for bi_f, f, seq, base in ((0, feats[0], self.trunc_heatmap_conv, cls), (1 + oi, feats[1 + oi], self.trunc_offset_conv, regs[oi])):
+                if fuse_nodes:
+                    e = edge_rows[bi_f].view(B, 1, Lmax + 2, self.head_conv)
+                else:
+                    e = f[bidx, xy[..., 1], xy[..., 0]].view(B, 1, Lmax + 2, self.head_conv)  # grid_sample at integer points
                 c1, bn, c3 = seq[0], seq[1], seq[3]
                 h1 = AG.bn_act(AG.conv2d(e, c1.weight.unsqueeze(2), c1.bias, 1, 0), bn,
                                L.ACT_RELU if self.edge_fusion_relu else L.ACT_NONE)
                 o = AG.conv2d(h1, c3.weight.unsqueeze(2), c3.bias, 1, 0, out_dtype=torch.float32).view(B, Lmax, -1)
                 lo = 0 if base is cls else sum(self.regression_channel_cfg[oi][:oj])
                 co = o.shape[-1]
+                if fuse_nodes:
+                    new.append(AG.EdgeScatterAddFn.apply(base, o, edge_indices, edge_lens, lo, rows_center, valid_l))
+                    continue
                 # static-shape scatter (no nonzero()/host sync, graph-capturable): positions >= edge_len contribute zeros;
                 # the valid border pixels are unique, so accumulate == the reference's '+='
                 valid = (torch.arange(Lmax, device=features.device).view(1, Lmax) < edge_lens.view(B, 1).long()).to(o.dtype)
@@ -260,7 +283,8 @@ class _predictor(nn.Module):
                                         *[e[3] for e in sp], *[e[4] for e in sp])
         bidx, cx, cy = rows[:, 57].long().clamp(0, B - 1), rows[:, 2].long().clamp(0, W - 1), rows[:, 3].long().clamp(0, H - 1)
         lo, n_off = starts[oi], sum(self.regression_channel_cfg[oi])
-        off_rows = regs[oi][bidx, cy, cx][:, :n_off]                                   # the dense 3d_offset head at the centres
+        # the dense 3d_offset head at the centres (index_select: its gradient is one index_add_, no sort as behind advanced indexing)
+        off_rows = regs[oi].reshape(-1, regs[oi].shape[-1]).index_select(0, (bidx * H + cy) * W + cx)[:, :n_off]
         return cls, torch.cat((tab[:, :lo], off_rows, tab[:, lo + n_off:]), dim=1)
 
     def forward(self, features, targets, object_rows=None):

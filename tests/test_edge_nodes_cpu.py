@@ -1,0 +1,111 @@
+"""Host logic of the training path's edge-fusion nodes (autograd.HeadConvGatherFn / EdgeScatterAddFn), on CPU: the device operators
+they call (conv, data/weight gradient, border scatter) are replaced by plain torch stand-ins, so what is checked here is the index
+arithmetic and the gradient routing of the nodes against the reference formulation (detector_predictor.py:125-147: gather of the
+trunk at the edge points, '+=' of the edge outputs at the border pixels) differentiated by torch autograd."""
+import types
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from monoflex_amd import autograd as AG, ops
+from monoflex_amd.model.head.detector_predictor import make_edge_rowmap
+
+
+def _edges(B, H, W, L, gen):
+    """Unique border points per image (first edge_len entries), zero padding after, like the reference's edge_indices."""
+    ei = torch.zeros(B, L, 2, dtype=torch.int32)
+    el = torch.zeros(B, dtype=torch.int32)
+    border = [(x, 0) for x in range(W)] + [(W - 1, y) for y in range(1, H)] + [(x, H - 1) for x in range(W - 1)] + [(0, y) for y in range(1, H - 1)]
+    for b in range(B):
+        n = int(torch.randint(3, min(L, len(border)) + 1, (1,), generator=gen))
+        start = int(torch.randint(0, len(border), (1,), generator=gen))
+        pts = [border[(start + i) % len(border)] for i in range(n)]
+        ei[b, :n] = torch.tensor(pts, dtype=torch.int32)
+        el[b] = n
+    return ei, el
+
+
+@pytest.fixture
+def cpu_ops(monkeypatch):
+    def scatter(out, ch_off, C, v, edge_xy, edge_len, planar=None):
+        for b in range(out.shape[0]):
+            for j in range(int(edge_len[b])):
+                x, y = int(edge_xy[b, j, 0]), int(edge_xy[b, j, 1])
+                out[b, y, x, ch_off:ch_off + C] += v[b, j, :C]
+    monkeypatch.setattr(ops, "edge_scatter_add", scatter)
+
+    def pack_weight(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, shift=None):
+        return types.SimpleNamespace(weight=weight.detach(), shift=shift, rows=rows)
+
+    def conv2d(x, p, out_dtype=None, **kw):                      # 1x1 NHWC conv with padded output channels
+        w = p.weight.reshape(p.weight.shape[0], -1).float()
+        y = x.float() @ w.t()
+        if p.rows > y.shape[-1]:
+            y = F.pad(y, (0, p.rows - y.shape[-1]))
+        if p.shift is not None:
+            y = y + p.shift[:y.shape[-1]]
+        return y.to(out_dtype or x.dtype)
+
+    def conv_backward(x, weight, dy, stride, pad, has_bias, Cout, needs, res=None):
+        w = weight.reshape(weight.shape[0], -1).float()
+        g = dy[..., :Cout].float()
+        dx = (g @ w).to(x.dtype)
+        dw = (g.reshape(-1, Cout).t() @ x.reshape(-1, x.shape[-1]).float()).view_as(weight)
+        return dx, dw, (g.reshape(-1, Cout).sum(0) if has_bias else None)
+
+    monkeypatch.setattr(AG, "_pack_weight", pack_weight)
+    monkeypatch.setattr(ops, "conv2d", conv2d)
+    monkeypatch.setattr(AG, "_conv_backward", conv_backward)
+    monkeypatch.setattr(ops, "cout_pad", lambda n: n)
+
+
+@pytest.mark.parametrize("lo,co,cb", [(0, 3, 3), (4, 2, 7)])
+def test_edge_scatter_add_node_matches_reference_formulation(cpu_ops, lo, co, cb):
+    gen = torch.Generator().manual_seed(5)
+    B, H, W, L = 3, 6, 9, 20
+    ei, el = _edges(B, H, W, L, gen)
+    base = torch.randn(B, H, W, cb, generator=gen).requires_grad_()
+    o = torch.randn(B, L, co, generator=gen).requires_grad_()
+    r = torch.randn(B, H, W, cb, generator=gen)
+    # reference formulation (static shapes, as the predictor's torch path)
+    valid = (torch.arange(L).view(1, L) < el.view(B, 1).long()).float()
+    bl = torch.arange(B).view(B, 1).expand(B, L)
+    add = torch.zeros(B, H, W, co).index_put((bl, ei[..., 1].long(), ei[..., 0].long()), o * valid.unsqueeze(-1), accumulate=True)
+    want = base + F.pad(add, (lo, cb - lo - co))
+    gb, go = torch.autograd.grad((want * r).sum(), (base, o))
+    # the node
+    rm = make_edge_rowmap(ei, H, W).long()
+    rows = rm.view(B, L + 2)[:, 1:-1].reshape(-1)
+    got = AG.EdgeScatterAddFn.apply(base, o, ei, el, lo, rows, valid.unsqueeze(-1))
+    hb, ho = torch.autograd.grad((got * r).sum(), (base, o))
+    assert torch.allclose(got, want, atol=1e-6) and torch.allclose(hb, gb) and torch.allclose(ho, go, atol=1e-6)
+    # a non-contiguous base (the sliced padded conv output) takes the same path
+    wide = torch.randn(B, H, W, cb + 1, generator=gen)
+    got2 = AG.EdgeScatterAddFn.apply(wide[..., :cb], o, ei, el, lo, rows, valid.unsqueeze(-1))
+    assert torch.allclose(got2 - wide[..., :cb], want.detach() - base.detach(), atol=1e-6)
+
+
+def test_head_conv_gather_node_matches_two_nodes(cpu_ops):
+    gen = torch.Generator().manual_seed(6)
+    B, H, W, L, C, Cout = 2, 5, 8, 14, 16, 3
+    ei, el = _edges(B, H, W, L, gen)
+    f = torch.randn(B, H, W, C, generator=gen).requires_grad_()
+    w = torch.randn(Cout, C, 1, 1, generator=gen).requires_grad_()
+    b = torch.randn(Cout, generator=gen).requires_grad_()
+    ry = torch.randn(B, H, W, Cout, generator=gen)
+    re = torch.randn(B, L + 2, C, generator=gen)
+    # two nodes: 1x1 conv, and the gather at positions -1 .. L with replicate padding (k = 3 Conv1d)
+    pos = torch.arange(-1, L + 1).clamp(0, L - 1)
+    xy = ei[:, pos].long()
+    bidx = torch.arange(B).view(B, 1).expand(B, L + 2)
+    y_ref = f @ w.view(Cout, C).t() + b
+    e_ref = f[bidx, xy[..., 1], xy[..., 0]]
+    want = torch.autograd.grad((y_ref * ry).sum() + (e_ref * re).sum(), (f, w, b))
+    rm = make_edge_rowmap(ei, H, W).long()
+    y, e = AG.HeadConvGatherFn.apply(f, w, b, rm)
+    assert y.shape[-1] >= Cout and torch.allclose(y[..., :Cout], y_ref, atol=1e-5)
+    assert torch.equal(e.view(B, L + 2, C), e_ref)
+    got = torch.autograd.grad((y[..., :Cout] * ry).sum() + (e.view(B, L + 2, C) * re).sum(), (f, w, b))
+    for g, h in zip(got, want):
+        assert torch.allclose(g, h, atol=1e-4), float((g - h).abs().max())
