@@ -109,3 +109,30 @@ def test_head_conv_gather_node_matches_two_nodes(cpu_ops):
     got = torch.autograd.grad((y[..., :Cout] * ry).sum() + (e.view(B, L + 2, C) * re).sum(), (f, w, b))
     for g, h in zip(got, want):
         assert torch.allclose(g, h, atol=1e-4), float((g - h).abs().max())
+
+
+def test_padded_bias_registry_follows_the_parameter():
+    """autograd._padded_bias: persistent zero-padded copy of a bias parameter -- same buffer every step, refreshed when the
+    parameter's version moves (on demand) or by pack_all_weights() (one _foreach_copy_), dropped with the parameter."""
+    import gc
+    reg = AG._PADS
+    n0 = len(reg.entries)
+    b = torch.nn.Parameter(torch.arange(1., 28.))                      # the 27-channel offset/mask conv bias
+    p1 = AG._padded_bias(b, 32)
+    assert p1.shape == (32,) and torch.equal(p1[:27], b.detach()) and float(p1[27:].abs().sum()) == 0
+    assert AG._padded_bias(b, 32) is p1                                # handed out again, nothing copied
+    with torch.no_grad():
+        b.mul_(2.0)                                                    # an optimizer step: version moves
+    assert torch.equal(AG._padded_bias(b, 32)[:27], b.detach()) and AG._padded_bias(b, 32) is p1
+    with torch.no_grad():
+        b.add_(1.0)
+    reg.refresh_all()                                                  # what pack_all_weights() runs at the top of a step
+    assert torch.equal(p1[:27], b.detach()) and float(p1[27:].abs().sum()) == 0
+    # exact size: the parameter itself; a temporary (stacked head biases): padded on the spot
+    c = torch.nn.Parameter(torch.ones(16))
+    assert AG._padded_bias(c, 16).data_ptr() == c.data_ptr()
+    t = torch.cat([torch.ones(3), torch.zeros(2)])
+    assert torch.equal(AG._padded_bias(t, 8), torch.nn.functional.pad(t, (0, 3))) and len(reg.entries) == n0 + 1
+    del b, p1
+    gc.collect()
+    assert len(reg.entries) == n0
