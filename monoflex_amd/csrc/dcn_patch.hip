@@ -32,11 +32,15 @@ namespace mfx {
 struct DcnPGeom { int B, H, W, C, tiles_x, tiles_y, tiles_n, fsteps, cpt; };   // cpt = C/32: k-steps per tap
 
 // patch = output tile grown by R+1 pixels on every side (1 for the 3x3 taps, R for the offsets), CS channels per slice
-template <int FM, int R, int CS> struct DcnPSmem {
+// PD = padded layout: pixels CS*2 + 16 bytes apart and no XOR swizzle, so the four corners of a sample are ONE base address plus
+// compile-time offsets (0, PB, PW*PB, PW*PB + PB: the ds_read offset field) and the owner lane hands out that base instead of
+// coordinates every consumer lane turns into four swizzled addresses (20 VALU per fragment and tap: PMC counted 18 VALU
+// instructions per MFMA in the swizzled form, most of them this address arithmetic).  Not yet measured: option dcn_patch = 8.
+template <int FM, int R, int CS, bool PD = false> struct DcnPSmem {
     static constexpr int PW = 16 + 2 * (R + 1);
     static constexpr int rows = 4 * FM + 2 * (R + 1);
     static constexpr int pix = rows * PW;
-    static constexpr int PB = CS * 2;                        // bytes per patch pixel (fp16)
+    static constexpr int PB = CS * 2 + (PD ? 16 : 0);        // bytes per patch pixel (fp16)
     static constexpr int NC = CS / 8;                        // 16-byte columns per pixel
     static constexpr int bytes = pix * PB;
 };
@@ -50,10 +54,10 @@ __device__ __forceinline__ uint32_t bf2_to_h2(uint32_t d) {
 }
 __device__ __forceinline__ u32x4 bf8_to_h8(const u32x4& v) { return u32x4{bf2_to_h2(v.x), bf2_to_h2(v.y), bf2_to_h2(v.z), bf2_to_h2(v.w)}; }
 
-template <int FN, int FM, int R = 3, int CS = 64>
+template <int FN, int FM, int R = 3, int CS = 64, bool PD = false>
 __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
                                                           const u32x4* __restrict__ wfm, DcnPGeom g, EpiArgs ep) {
-    using SM = DcnPSmem<FM, R, CS>;
+    using SM = DcnPSmem<FM, R, CS, PD>;
     constexpr int kPW = SM::PW, PB = SM::PB, NC = SM::NC, KS = CS / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -111,22 +115,34 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
         const uint32_t wa = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(hh * hw_ * m_, hh * lw * m_));
         const uint32_t wb_ = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lh * hw_ * m_, lh * lw * m_));
         const int hw = (h0 + 32) | ((w0 + 32) << 16);
+        int own_base = 0;
+        if constexpr (PD) {                                   // patch byte offset of the top-left corner; bit 31 = sample leaves the patch
+            const int ry = h0 - py0, rx = w0 - px0;
+            const bool in_patch = ry >= 0 && ry + 1 < SM::rows && rx >= 0 && rx + 1 < kPW;
+            own_base = in_patch ? (ry * kPW + rx) * PB : (int)0x80000000;
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int src = (i * 16 + xl) << 2;
             cwa[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)wa);
             cwb[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)wb_);
             chw[i] = __builtin_amdgcn_ds_bpermute(src, hw);
+            if constexpr (PD) {
+                cb[i][0] = __builtin_amdgcn_ds_bpermute(src, own_base);
+                inp[i] = cb[i][0] >= 0;
+            }
         }
+        if constexpr (!PD) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int ry = (chw[i] & 0xffff) - 32 - py0, rx = (chw[i] >> 16) - 32 - px0;
-            inp[i] = ry >= 0 && ry + 1 < SM::rows && rx >= 0 && rx + 1 < kPW;
-            const int p = ry * kPW + rx;
+            for (int i = 0; i < FM; ++i) {
+                const int ry = (chw[i] & 0xffff) - 32 - py0, rx = (chw[i] >> 16) - 32 - px0;
+                inp[i] = ry >= 0 && ry + 1 < SM::rows && rx >= 0 && rx + 1 < kPW;
+                const int p = ry * kPW + rx;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int pq = p + (q >> 1) * kPW + (q & 1);
-                cb[i][q] = pq * PB + ((pq & (NC - 1)) << 4);
+                for (int q = 0; q < 4; ++q) {
+                    const int pq = p + (q >> 1) * kPW + (q & 1);
+                    cb[i][q] = pq * PB + ((pq & (NC - 1)) << 4);
+                }
             }
         }
     };
@@ -134,7 +150,9 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
     auto corners = [&](int i, int col, int c0, u32x4 (&v)[4]) {
         if (inp[i]) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(smem + (cb[i][q] ^ (col << 4)));
+            for (int q = 0; q < 4; ++q)
+                v[q] = PD ? *reinterpret_cast<const u32x4*>(smem + cb[i][0] + (col << 4) + ((q >> 1) * kPW + (q & 1)) * PB)
+                          : *reinterpret_cast<const u32x4*>(smem + (cb[i][q] ^ (col << 4)));
         } else {                                              // rare: sample left the patch -> exact global gather
             const int h0 = (chw[i] & 0xffff) - 32, w0 = (chw[i] >> 16) - 32;
 #pragma unroll
@@ -174,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
             u32x4 v = u32x4{0u, 0u, 0u, 0u};
             if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
                 v = bf8_to_h8(*reinterpret_cast<const u32x4*>(xb + ((size_t)gy * g.W + gx) * g.C + c0 + col * 8));
-            *reinterpret_cast<u32x4*>(smem + ((p * PB + ((p & (NC - 1)) << 4)) ^ (col << 4))) = v;
+            *reinterpret_cast<u32x4*>(smem + (PD ? p * PB + (col << 4) : ((p * PB + ((p & (NC - 1)) << 4)) ^ (col << 4)))) = v;
         }
         // weights of the slice's first two steps while the patch lands
         constexpr int RD = FN >= 8 ? 2 : 3;                   // weight ring depth (registers: RD*FN*4)
@@ -245,9 +263,9 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
 }
 
 int g_opt_dcn_patch_fn8 = 1;
-int g_opt_dcn_patch = 1;     // 0 = off, 1 = automatic, 2 = force (FM 4), 3 = force FM 2, 4 = force FM 1
+int g_opt_dcn_patch = 1;     // 0 = off, 1 = automatic, 2 = force (FM 4), 3 = force FM 2, 4 = force FM 1, 5-7 = wide margin FM 4/2/1, 8 = padded layout
 
-template <int FN, int FM, int R = 3, int CS = 64>
+template <int FN, int FM, int R = 3, int CS = 64, bool PD = false>
 static int launch_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
     DcnPGeom g;
     g.B = d->B; g.H = d->H; g.W = d->W; g.C = d->C;
@@ -257,13 +275,13 @@ static int launch_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
     ep.scale = d->scale; ep.shift = d->shift; ep.res = nullptr; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = 0;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
     const int tiles = d->B * g.tiles_y * g.tiles_x * g.tiles_n;
-    constexpr int smem = DcnPSmem<FM, R, CS>::bytes;
+    constexpr int smem = DcnPSmem<FM, R, CS, PD>::bytes;
     static bool attr_done = false;
     if (!attr_done) {
-        MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_patch_kernel<FN, FM, R, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_patch_kernel<FN, FM, R, CS, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    hipLaunchKernelGGL((dcn_patch_kernel<FN, FM, R, CS>), dim3(tiles), dim3(256), smem, st, reinterpret_cast<const bf16_t*>(d->x), d->offmask,
+    hipLaunchKernelGGL((dcn_patch_kernel<FN, FM, R, CS, PD>), dim3(tiles), dim3(256), smem, st, reinterpret_cast<const bf16_t*>(d->x), d->offmask,
                        reinterpret_cast<const u32x4*>(d->w_frag_f16), g, ep);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -278,6 +296,10 @@ int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
     if (g_opt_dcn_patch >= 5 && g_opt_dcn_patch <= 7) {       // wide-margin variants: +-7 pixel offsets in range, 32-channel slices
         const int rc = g_opt_dcn_patch == 5 ? launch_dcn_patch<4, 4, 7, 32>(d, st)
                      : g_opt_dcn_patch == 6 ? launch_dcn_patch<4, 2, 7, 32>(d, st) : launch_dcn_patch<4, 1, 7, 32>(d, st);
+        return rc == MFX_OK ? 1 : rc;
+    }
+    if (g_opt_dcn_patch == 8) {                               // padded patch, owner-computed corner base (see DcnPSmem): candidate, unmeasured
+        const int rc = launch_dcn_patch<4, 4, 7, 32, true>(d, st);
         return rc == MFX_OK ? 1 : rc;
     }
     int fm = g_opt_dcn_patch == 2 ? 4 : g_opt_dcn_patch == 3 ? 2 : g_opt_dcn_patch == 4 ? 1 : 0;
