@@ -35,7 +35,8 @@ struct DcnPGeom { int B, H, W, C, tiles_x, tiles_y, tiles_n, fsteps, cpt; };   /
 // PD = padded layout: pixels CS*2 + 16 bytes apart and no XOR swizzle, so the four corners of a sample are ONE base address plus
 // compile-time offsets (0, PB, PW*PB, PW*PB + PB: the ds_read offset field) and the owner lane hands out that base instead of
 // coordinates every consumer lane turns into four swizzled addresses (20 VALU per fragment and tap: PMC counted 18 VALU
-// instructions per MFMA in the swizzled form, most of them this address arithmetic).  Not yet measured: option dcn_patch = 8.
+// instructions per MFMA in the swizzled form, a good part of them this address arithmetic).  64->64 @ 8x96x320: 80.8 -> 75.0 us, same
+// bits (tools/probes/dcn_patch_probe.py); the automatic choice for those layers, option dcn_patch = 8 forces it, 5 = the swizzled form.
 template <int FM, int R, int CS, bool PD = false> struct DcnPSmem {
     static constexpr int PW = 16 + 2 * (R + 1);
     static constexpr int rows = 4 * FM + 2 * (R + 1);
@@ -298,7 +299,7 @@ int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
                      : g_opt_dcn_patch == 6 ? launch_dcn_patch<4, 2, 7, 32>(d, st) : launch_dcn_patch<4, 1, 7, 32>(d, st);
         return rc == MFX_OK ? 1 : rc;
     }
-    if (g_opt_dcn_patch == 8) {                               // padded patch, owner-computed corner base (see DcnPSmem): candidate, unmeasured
+    if (g_opt_dcn_patch == 8) {                               // padded patch, owner-computed corner base (see DcnPSmem)
         const int rc = launch_dcn_patch<4, 4, 7, 32, true>(d, st);
         return rc == MFX_OK ? 1 : rc;
     }
@@ -311,7 +312,8 @@ int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
         // in the network 86-88 us vs 102-117) and is what those layers use; the multi-slice layers (C >= 128, smaller maps,
         // larger offsets) stay on the first-generation kernel, which measured faster there.
         if (d->C == 64 && d->Cout_pad == 64 && px >= 65536) {
-            const int rc0 = launch_dcn_patch<4, 4, 7, 32>(d, st);
+            // padded layout (one corner base + immediate offsets): bit-identical, 80.8 -> 75.0 us (tools/probes/dcn_patch_probe.py)
+            const int rc0 = launch_dcn_patch<4, 4, 7, 32, true>(d, st);
             return rc0 == MFX_OK ? 1 : rc0;
         }
         return 0;
