@@ -44,7 +44,9 @@ const char* mfx_last_error(void);
  * Tuning/debug overrides: "conv_tile" | "dcn_tile" | "cat_tile" (tile id, 0 = automatic), "kc" (4 | 8 | 0),
  * "halo" (0 = generic kernel only, 1 = automatic, 2.. = force LDS-halo variant), "halo_cg", "dcn_wave", "dcn_patch" (same
  * convention), "ksplit" / "dcn_ksplit" (split-K factor), "topk_strips" (row strips of the top-K stage, 1 = single workgroup),
- * "wgrad_*" / "dcn_wgrad_m" (training GEMM partitioning). Unknown names return MFX_ERR_ARG. */
+ * "wgrad_*" / "dcn_wgrad_m" (training GEMM partitioning), "heads_persist" (1 = one workgroup per resident slot over (tile, branch)
+ * unit ranges, n > 1 = n workgroups, 0 = one workgroup per tile), "heads_planes", "heads_dbg" (timing probes: wrong results).
+ * Unknown names return MFX_ERR_ARG. */
 int mfx_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------
