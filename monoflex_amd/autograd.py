@@ -824,8 +824,9 @@ class FocalLossFn(Function):
         L.check(L.load().mfx_focal_loss(_ptr(z), _ptr(t), B, H, W, C, ctypes.c_float(alpha), ctypes.c_float(beta), _ptr(sums), _ptr(dz),
                                         _stream()), "mfx_focal_loss")
         ctx.save_for_backward(dz)
-        ctx.mark_non_differentiable(sums[1:])
-        return sums[0], sums[1]
+        loss_sum, num_pos = sums[0], sums[1]
+        ctx.mark_non_differentiable(num_pos)                  # (the very tensor that is returned, not another view of it)
+        return loss_sum, num_pos
 
     @staticmethod
     @once_differentiable

@@ -23,24 +23,40 @@ def _hipcc():
     return "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
 
 
-def _stamp():
+def _headers_digest():
     h = hashlib.sha1()
     for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
         for fn in sorted(os.listdir(root)):
-            if fn.endswith((".hip", ".h")):
+            if fn.endswith(".h"):
                 with open(os.path.join(root, fn), "rb") as f:
                     h.update(fn.encode() + f.read())
-    h.update((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
+    return h.hexdigest()
+
+
+def _source_stamp(src, headers):
+    h = hashlib.sha1()
+    with open(os.path.join(CSRC, src), "rb") as f:
+        h.update(f.read())
+    h.update((headers + " ".join(FLAGS + EXTRA_FLAGS.get(src, []))).encode())
     return h.hexdigest()
 
 
 def build_lib(force=False, verbose=False):
+    """Compile what changed (a translation unit is rebuilt when its source, any header or its flags changed) and relink."""
     os.makedirs(OBJ, exist_ok=True)
-    stamp_file = os.path.join(OBJ, "stamp")
-    stamp = _stamp()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
-        return LIB
     hipcc = _hipcc()
+    headers = _headers_digest()
+    stamps = {src: _source_stamp(src, headers) for src in SOURCES}
+
+    def stale(src):
+        obj, st = os.path.join(OBJ, src.replace(".hip", ".o")), os.path.join(OBJ, src.replace(".hip", ".stamp"))
+        return force or not os.path.exists(obj) or not os.path.exists(st) or open(st).read() != stamps[src]
+
+    todo = [src for src in SOURCES if stale(src)]
+    link_stamp_file = os.path.join(OBJ, "stamp")
+    link_stamp = hashlib.sha1("".join(stamps[s] for s in SOURCES).encode()).hexdigest()
+    if not todo and os.path.exists(LIB) and os.path.exists(link_stamp_file) and open(link_stamp_file).read() == link_stamp:
+        return LIB
 
     def compile_one(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
@@ -50,14 +66,17 @@ def build_lib(force=False, verbose=False):
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
         if verbose and r.stderr:
             sys.stderr.write(r.stderr)
+        with open(os.path.join(OBJ, src.replace(".hip", ".stamp")), "w") as f:
+            f.write(stamps[src])
         return obj
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        list(ex.map(compile_one, todo))
+    objs = [os.path.join(OBJ, src.replace(".hip", ".o")) for src in SOURCES]
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
-    with open(stamp_file, "w") as f:
-        f.write(stamp)
+    with open(link_stamp_file, "w") as f:
+        f.write(link_stamp)
     return LIB
 
 

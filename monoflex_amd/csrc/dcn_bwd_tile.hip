@@ -37,6 +37,8 @@ int mfx_internal_wgrad_slab_sum(const float* ws, int nslab, int Cout, int Ck, in
 
 int g_opt_dcn_bt_fuse_blocks = 170; // option "dcn_bt_fuse_blocks": workgroups per tap group of the fused kernel
 int g_opt_dcn_bt_fuse_wgrad = 1;   // option "dcn_bt_fuse_wgrad": 64 -> 64 bf16 layers accumulate grad_weight inside the sample kernel (no columns in memory)
+int g_opt_dcn_bt_fuse_min_chunks = 1024; // option "dcn_bt_fuse_min_chunks": fewer 32-pixel chunks than this keep the unfused kernels (tests lower it)
+long g_cnt_dcn_bt_fused = 0;   // counter "dcn_bt_fused": launches of dcn_bwd_sample_wgrad_kernel since process start
 int g_opt_dcn_bt_cs = 0;       // option "dcn_bt_cs": channel slice of the tile kernel for C >= 128 (0 = by workgroup count, 64, 128)
 int g_opt_dcn_bt_cs_wgs = 1000; // option "dcn_bt_cs_wgs": below this many 128-channel workgroups the tile kernel takes 64-channel slices
 int g_opt_dcn_bt_dbg = 0;      // option "dcn_bt_dbg": experiment switches of dcn_bwd_tile_kernel (0 in production)
@@ -684,7 +686,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     if constexpr (std::is_same<T, bf16_t>::value) {
         const long nchunks = M / SF_PX;
         const size_t slab_bytes = (size_t)64 * 576 * sizeof(float);
-        if (g_opt_dcn_bt_fuse_wgrad && C == 64 && Cout == 64 && W % SF_PX == 0 && nchunks >= 1024 && L.total - L.wg >= 128 * slab_bytes) {
+        if (g_opt_dcn_bt_fuse_wgrad && C == 64 && Cout == 64 && W % SF_PX == 0 && nchunks >= g_opt_dcn_bt_fuse_min_chunks && L.total - L.wg >= 128 * slab_bytes) {
             // two workgroups fit a CU (210 registers per lane): 170 x 3 tap groups = one resident round of the chip, no tail, 170 slabs to sum
             int nblk = (int)std::min<long>(g_opt_dcn_bt_fuse_blocks, (long)((L.total - L.wg) / slab_bytes));
             const int cpb = (int)((nchunks + nblk - 1) / nblk);
@@ -693,6 +695,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
             hipLaunchKernelGGL(dcn_bwd_sample_wgrad_kernel, dim3((unsigned)nblk, 3), dim3(256), 0, st, x, offmask, (const bf16_t*)gcol, dy, gs, cpb, (int)nchunks,
                                d_raw, slabs);
             MFX_HIP_CHECK(hipGetLastError());
+            ++g_cnt_dcn_bt_fused;
             rc = mfx_internal_wgrad_slab_sum(slabs, nblk, Cout, C, 3, 3, dweight, stream);
             if (rc) return rc;
             fused_wgrad = true;

@@ -210,6 +210,16 @@ def train_step(model, optimizer, images, targets, grad_norm_clip=-1.0, scheduler
     return losses.detach(), loss_dict, log_loss_dict
 
 
+def advance_schedule(iteration, warmup_iters, scheduler, warmup_scheduler):
+    """engine/trainer.py:123-126: after the optimizer step of `iteration`, the warm-up schedule (while iteration < warmup_iters)
+    or the main schedule is SET to `iteration` -- `step(iteration)`, not `step()`: the main LambdaLR is not advanced during the
+    warm-up, so with a plain step() its decay STEPS would fire WARMUP_STEPS iterations late, and a resumed run would restart at 0."""
+    from ..solver import step_scheduler
+    sched = warmup_scheduler if (warmup_scheduler is not None and iteration < warmup_iters) else scheduler
+    if sched is not None:
+        step_scheduler(sched, iteration)
+
+
 def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, scheduler, warmup_scheduler, checkpointer, device,
              arguments):
     """The reference's training loop (engine/trainer.py:62-230) over this build's loaders: forward -> summed loss -> backward
@@ -232,7 +242,7 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
         if data.get("fields") is not None:
             targets = prepare_targets(net, targets, device, fields=data["fields"])
         losses, loss_dict, log_loss_dict = train_step(model, optimizer, images, targets, grad_norm_clip=clip)
-        (warmup_scheduler if iteration < warmup_iters else scheduler).step()
+        advance_schedule(iteration, warmup_iters, scheduler, warmup_scheduler)
         iteration += 1
         arguments["iteration"] = iteration
         if iteration % 10 == 0 or iteration == max_iter:

@@ -59,7 +59,7 @@ def optimizer_state_to_reference(model, optimizer):
     groups, state = [], {}
     for j, n in enumerate(names):
         i, gi = loc[n]
-        g = {k: copy.deepcopy(v) for k, v in sd["param_groups"][gi].items() if k != "params"}
+        g = {k: _scalar(v) for k, v in sd["param_groups"][gi].items() if k != "params"}     # (device-scalar lr -> float: the reference's files hold floats)
         g["params"] = [j]
         groups.append(g)
         if i in sd["state"]:
@@ -67,12 +67,45 @@ def optimizer_state_to_reference(model, optimizer):
     return {"state": state, "param_groups": groups}
 
 
+NUMERIC_HYPER = ("lr", "betas", "eps", "weight_decay", "amsgrad", "initial_lr", "momentum", "dampening", "nesterov", "maximize")
+
+
+def _scalar(v):
+    return float(v) if torch.is_tensor(v) else copy.deepcopy(v)
+
+
+def _keep_build_flags(mine_group, saved_group):
+    """The saved group's numeric hyper-parameters over THIS build's group: `capturable`, `fused`, `foreach`, `differentiable`
+    describe how the optimizer was constructed here (a reference checkpoint carries capturable=False / fused=None, which would
+    switch a capturable fused optimizer off and break GraphedTrainStep), so they are never taken from the file."""
+    g = dict(mine_group)
+    for k in NUMERIC_HYPER:
+        if k in saved_group:
+            g[k] = _scalar(saved_group[k])
+    return g
+
+
+def load_optimizer_state(optimizer, sd):
+    """optimizer.load_state_dict(sd) that keeps device-scalar learning rates (solver.build_optimizer(capturable=True)) as the same
+    tensor objects a captured graph reads, filled with the loaded values."""
+    lr_tensors = [(g["lr"], g.get("initial_lr")) for g in optimizer.param_groups]
+    optimizer.load_state_dict(sd)
+    for g, (lr, init) in zip(optimizer.param_groups, lr_tensors):
+        if torch.is_tensor(lr):
+            lr.fill_(float(g["lr"]))
+            g["lr"] = lr
+            if torch.is_tensor(init) and "initial_lr" in g:
+                init.fill_(float(g["initial_lr"]))
+                g["initial_lr"] = init
+
+
 def optimizer_state_from_reference(model, optimizer, sd):
     """A per-parameter-group state (the reference's layout) mapped by name onto `optimizer`'s own groups; entries of
     parameters this model does not have (backbone.base.fc.*) are dropped.  Returns None when the layout is not recognised."""
     mine = optimizer.state_dict()
     if len(sd["param_groups"]) == len(mine["param_groups"]):
-        return sd
+        groups = [_keep_build_flags(m, g) for m, g in zip(mine["param_groups"], sd["param_groups"])]
+        return {"state": sd["state"], "param_groups": groups}
     ref_names = _reference_names(model, len(sd["param_groups"]))
     if ref_names is None or any(len(g["params"]) != 1 for g in sd["param_groups"]):
         return None
@@ -86,9 +119,7 @@ def optimizer_state_from_reference(model, optimizer, sd):
         src = sd["param_groups"][j]
         if gi not in seen:                                   # hyper-parameters of a merged group: those of its first member
             seen.add(gi)
-            for k, v in src.items():
-                if k != "params":
-                    groups[gi][k] = copy.deepcopy(v)
+            groups[gi] = _keep_build_flags(groups[gi], src)
         pid = src["params"][0]
         if pid in sd["state"]:
             state[i] = sd["state"][pid]
@@ -183,7 +214,7 @@ class Checkpointer:
                 if sd is None:
                     self.logger.warning("optimizer state has an unknown parameter-group layout: not loaded (weights were)")
                 else:
-                    self.optimizer.load_state_dict(sd)
+                    load_optimizer_state(self.optimizer, sd)
             if "scheduler" in ckpt and self.scheduler:
                 sd = ckpt.pop("scheduler")
                 if self.optimizer is not None:

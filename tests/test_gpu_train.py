@@ -723,6 +723,62 @@ def test_dcn_tile_owned_backward_vs_oracle(cin, cout, H, W, off_std, dtype):
             assert _rel(a, b_) < 3e-4, (n, _rel(a, b_))
 
 
+@pytest.mark.parametrize("H,W,off_std,min_chunks", [(96, 320, 1.5, None), (96, 320, 5.0, None), (32, 64, 2.5, 1), (9, 32, 6.0, 1)])
+def test_dcn_fused_sample_wgrad_kernel_vs_oracle(H, W, off_std, min_chunks):
+    """`dcn_bwd_sample_wgrad_kernel` (dcn_bwd_tile.hip: grad_offset / grad_mask + grad_weight on the matrix cores from an LDS
+    column tile, bf16, C = Cout = 64, W % 32 == 0) against the C restatement of the reference backward
+    (dcn_v2_cuda.cu:206-335, dcn_v2_im2col_cuda.cu:197-327): all five gradients, at the shape the benchmarked training step
+    dispatches it on (B=2, 64->64 @ 96x320: 1920 chunks >= the default threshold) and on small maps forced onto it through the
+    option `dcn_bt_fuse_min_chunks`.  The launch counter proves the fused kernel ran; the unfused kernels (option
+    `dcn_bt_fuse_wgrad` = 0) on the same inputs are the A/B side: same bf16 operands, so they agree far below the bf16 bar."""
+    from oracle import monoflex_ref as R
+    from monoflex_amd import lib as L
+    from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCN
+    g = torch.Generator().manual_seed(77)
+    rnd = lambda t: t.bfloat16().float()                         # noqa: E731
+    ref = R.DCN(64, 64)
+    dev = DCN(64, 64, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
+    with torch.no_grad():
+        ref.weight.copy_(rnd(torch.randn(ref.weight.shape, generator=g) * 0.05))
+        ref.bias.copy_(torch.randn(64, generator=g) * 0.1)
+        ref.conv_offset_mask.weight.copy_(rnd(torch.randn(ref.conv_offset_mask.weight.shape, generator=g) * (0.3 / 576 ** 0.5)))
+        b = torch.randn(27, generator=g) * off_std
+        b[18:] = torch.randn(9, generator=g)
+        ref.conv_offset_mask.bias.copy_(b)
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.to(DEV).train()
+    x = rnd(torch.randn(2, 64, H, W, generator=g))
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    r = rnd(torch.randn(yr.shape, generator=g))
+    (yr * r).sum().backward()
+    lib_ = L.load()
+    names = ["input"] + [n for n, _ in dev.named_parameters()]
+    want = [xr.grad] + [dict(ref.named_parameters())[n].grad for n in names[1:]]
+    got = {}
+    try:
+        if min_chunks is not None:
+            L.check(lib_.mfx_set_option(b"dcn_bt_fuse_min_chunks", min_chunks), "opt")
+        for fuse in (1, 0):
+            L.check(lib_.mfx_set_option(b"dcn_bt_fuse_wgrad", fuse), "opt")
+            before = lib_.mfx_get_counter(b"dcn_bt_fused")
+            dev.zero_grad(set_to_none=True)
+            xd = _nhwc(x).to(DEV).bfloat16().requires_grad_()
+            yd = dev.forward_nhwc_train(xd)
+            (yd.float() * _nhwc(r).to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            assert lib_.mfx_get_counter(b"dcn_bt_fused") - before == fuse, "the fused kernel %s" % ("did not run" if fuse else "ran")
+            got[fuse] = [xd.grad.float().permute(0, 3, 1, 2).cpu()] + [p.grad.float().cpu() for _, p in dev.named_parameters()]
+    finally:
+        L.check(lib_.mfx_set_option(b"dcn_bt_fuse_wgrad", 1), "opt")
+        L.check(lib_.mfx_set_option(b"dcn_bt_fuse_min_chunks", 1024), "opt")
+    assert _rel(yd.permute(0, 3, 1, 2), yr) < 2e-2
+    for n, a, w_ in zip(names, got[1], want):
+        assert _rel(a, w_) < (3e-2 if n == "input" else 4e-2), (n, _rel(a, w_))      # bars of test_dcn_train_grads_bf16_vs_oracle
+    for n, a, b_ in zip(names, got[1], got[0]):
+        assert _rel(a, b_) < 1e-2, ("fused vs unfused", n, _rel(a, b_))
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,H,W", [(64, 256, 3, 1, 48, 96), (64, 64, 3, 1, 40, 72), (128, 128, 3, 2, 64, 80),
                                                    (256, 256, 3, 1, 24, 80), (512, 512, 3, 1, 12, 40), (64, 192, 3, 1, 33, 47),
                                                    (128, 27, 3, 1, 48, 96), (64, 27, 3, 1, 37, 75), (64, 64, 3, 1, 96, 40),
