@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstring>
 
+int g_opt_det = 0;
+
 static thread_local char g_err[512] = "";
 
 int mfx_fail(int code, const char* msg) {

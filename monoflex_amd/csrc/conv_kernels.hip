@@ -425,6 +425,7 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "heads_dbg") g_opt_heads_dbg = value;
     else if (n == "dcn_bt_fuse_wgrad") g_opt_dcn_bt_fuse_wgrad = value;
     else if (n == "dcn_bt_fuse_blocks") g_opt_dcn_bt_fuse_blocks = value > 0 ? value : 170;
+    else if (n == "deterministic") g_opt_det = value ? 1 : 0;
     else if (n == "dcn_bt_fuse_min_chunks") g_opt_dcn_bt_fuse_min_chunks = value < 1 ? 1 : value;
     else if (n == "dcn_bt_cs") g_opt_dcn_bt_cs = value;
     else if (n == "dcn_bt_cs_wgs") g_opt_dcn_bt_cs_wgs = value;
@@ -459,6 +460,10 @@ extern "C" int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream) {
     if (d->stats && (!d->stats_done || d->res || d->act != MFX_ACT_NONE || d->rowmap))
         return mfx_fail(MFX_ERR_ARG, "conv2d: output statistics need stats_done and a plain (no residual / activation / row map) epilogue");
     if (d->stats_done) *d->stats_done = 0;
+    mfx_conv_desc det_copy;
+    if (g_opt_det && d->stats) {                            // epilogue statistics are one atomic per column and wave: the BN runs its own (ordered) pass
+        det_copy = *d; det_copy.stats = nullptr; det_copy.stats_done = nullptr; d = &det_copy;
+    }
     {
         int ran = 0;
         const int h = try_conv_halo(d, reinterpret_cast<hipStream_t>(stream), &ran);   // 3x3/s1: LDS-staged halo kernel

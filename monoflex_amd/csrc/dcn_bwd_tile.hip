@@ -340,6 +340,54 @@ __global__ __launch_bounds__(256) void dcn_bwd_far_kernel(const T* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Deterministic mode (option "deterministic"): grad_input in 64-bit FIXED POINT.  The tile lists above are filled in the order
+// LDS atomics happen to retire and the far corners arrive through float atomics, so the floating-point sum of a pixel depends
+// on the run.  Integer addition commutes: every (sample, tap, corner) contribution w * d(columns) is converted to a signed
+// 28.36 fixed-point number (round to nearest of an exactly scaled double: |value| < 1.3e8, resolution 1.5e-11) and added into
+// an int64 map with integer atomics; a second pass rounds the map to the activation dtype.  Any arrival order gives the same
+// bits.  One lane group of eight per (pixel, tap), eight channels per lane and pass (the first generation's scatter shape:
+// ~2.5 ms for 64 -> 64 @ 96x320, B = 8 -- a debugging / testing mode, not the fast path).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr double BT_FIX_SCALE = 68719476736.0;            // 2^36
+
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_bwd_dx_fixed_kernel(const float* __restrict__ om, const T* __restrict__ gcol, BtGeom g,
+                                                              unsigned long long* __restrict__ acc) {
+    const int HW = g.H * g.W, cl = threadIdx.x & 7;
+    const long nsamp = (long)g.B * HW * 9;
+    for (long s = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 3; s < nsamp; s += ((long)gridDim.x * blockDim.x) >> 3) {
+        const long m = s / 9;
+        const int tap = (int)(s - m * 9);
+        const int b = (int)(m / HW), rem = (int)(m - (long)b * HW), my = rem / g.W, mx = rem - my * g.W;
+        const SampGeo sg = samp_geo(g, om + m * 32, my, mx, tap);
+        if (!sg.inside || sg.mask == 0.f) continue;
+        const float hh = 1.f - sg.lh, hw = 1.f - sg.lw;
+        for (int c = cl * 8; c < g.C; c += 64) {
+            float gq[8];
+            bt_load8<T>(gcol + m * g.Kp + tap * g.C + c, gq);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int hc = sg.h0 + (q >> 1), wc = sg.w0 + (q & 1);
+                const float wq = ((q >> 1) ? sg.lh : hh) * ((q & 1) ? sg.lw : hw) * sg.mask;
+                if (hc < 0 || hc >= g.H || wc < 0 || wc >= g.W || wq == 0.f) continue;
+                unsigned long long* ap = acc + ((size_t)b * HW + (size_t)hc * g.W + wc) * g.C + c;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const double v = fmin(fmax((double)(wq * gq[k]) * BT_FIX_SCALE, -9.0e18), 9.0e18);
+                    atomicAdd(ap + k, (unsigned long long)__double2ll_rn(v));
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_bwd_dx_unfix_kernel(const unsigned long long* __restrict__ acc, T* __restrict__ dx, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        ElemTraits<T>::store(dx + i, (float)((double)(long long)acc[i] * (1.0 / BT_FIX_SCALE)));
+}
+
 // weight (Cout,C,9) fp32 -> wT[K][Cout] (k = tap*C + c), compute dtype: the B operand of d(columns) = dy x W
 template <typename T>
 __global__ void bt_pack_weight_t(const float* __restrict__ w, T* __restrict__ wT, int Cout, int C) {
@@ -707,12 +755,22 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
         if (gs.CS == 64) hipLaunchKernelGGL((dcn_bwd_sample_kernel<T, 8>), sgrid, dim3(256), 0, st, x, offmask, (const T*)gcol, gs, xsplit, d_raw, col);
         else hipLaunchKernelGGL((dcn_bwd_sample_kernel<T, 16>), sgrid, dim3(256), 0, st, x, offmask, (const T*)gcol, gs, xsplit, d_raw, col);
     }
+    if (g_opt_det) {
+        // grad_input through the fixed-point map (the far-corner list's memory: 9 * M * C bytes >= 8 * M * C); see dcn_bwd_dx_fixed_kernel
+        unsigned long long* acc = reinterpret_cast<unsigned long long*>(flist);
+        const long n = M * C;
+        MFX_HIP_CHECK(mfx::zero_async(acc, (size_t)n * 8, st));
+        hipLaunchKernelGGL(dcn_bwd_dx_fixed_kernel<T>, dim3(2048), dim3(256), 0, st, offmask, (const T*)gcol, g, acc);
+        hipLaunchKernelGGL(dcn_bwd_dx_unfix_kernel<T>, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, st, acc, dx, n);
+        MFX_HIP_CHECK(hipGetLastError());
+    } else {
     const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * B), (unsigned)g.nslices);
     const size_t smem = (size_t)BT_NPIX * BtEntry<T>::LCAP * sizeof(typename BtEntry<T>::type) + (size_t)BT_NPIX * 4 + (size_t)BT_FCAP * 8;
     if (g.CS == 64) hipLaunchKernelGGL((dcn_bwd_tile_kernel<T, 8>), grid, dim3(256), smem, st, offmask, (const T*)gcol, g, dx, cnt, flist, far_cap);
     else hipLaunchKernelGGL((dcn_bwd_tile_kernel<T, 16>), grid, dim3(256), smem, st, offmask, (const T*)gcol, g, dx, cnt, flist, far_cap);
     hipLaunchKernelGGL(dcn_bwd_far_kernel<T>, dim3(1024), dim3(256), 0, st, (const T*)gcol, (const u32x4*)flist, (const int*)cnt, far_cap, g, dx);
     MFX_HIP_CHECK(hipGetLastError());
+    }
     // grad_weight[o][c][tap] = sum_m dy[m][o] * col[m][tap*C + c]: MFMA GEMM over the pixels, written as (Cout, C, 3, 3)
     if (!fused_wgrad) rc = mfx_internal_conv_wgrad(col, dy, dweight, 1, 1, (int)M, K, C, 3, 3, 1, 0, 0, 1, (int)M, Cout, Cout, dt, 1, C, Cout, stream, 1,
                                  ws + L.wg, L.total - L.wg, 1);

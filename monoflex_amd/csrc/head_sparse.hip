@@ -192,7 +192,7 @@ extern "C" int mfx_head_sparse_bwd(const mfx_head_sparse_desc* d, void* stream) 
     const float invM = 1.f / (float)M;
     const int E = d->dtype == MFX_BF16 ? 8 : 4;
     const long chunks = M * (HS_C / E);
-    const int rpb = 16, nchunk = (d->N + rpb - 1) / rpb;
+    const int rpb = g_opt_det ? std::max(1, d->N) : 16, nchunk = (d->N + rpb - 1) / rpb;     // deterministic: one row chunk per branch (single writer)
     const unsigned ablocks = (unsigned)std::min<long>((chunks + 255) / 256, 1024);
 #define HS_LAUNCH(T)                                                                                                                              \
     do {                                                                                                                                          \

@@ -63,7 +63,8 @@ extern "C" int mfx_focal_loss(const float* logits_nhwc, const float* heat_nchw, 
     MFX_HIP_CHECK(mfx::zero_async(sums2, 8, st));
     const long total = (long)B * H * W * ncls;
     if (total == 0) return MFX_OK;
-    const unsigned blocks = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    unsigned blocks = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    if (g_opt_det) blocks = 1;                                  // one workgroup: the two sums have a single writer
     hipLaunchKernelGGL(focal_loss_kernel, dim3(blocks), dim3(256), 0, st, logits_nhwc, heat_nchw, B, H * W, ncls, alpha, beta, sums2, dlogits_nhwc);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -92,7 +93,7 @@ __device__ __forceinline__ const float* object_pixel(const float* base, const fl
 __global__ __launch_bounds__(64) void object_loss_kernel(const float* __restrict__ reg, int B, int H, int W, int ld, int ch_off,
                                                          const float* __restrict__ rows, int N, mfx_object_loss_cfg c,
                                                          float* __restrict__ vals, float* __restrict__ G) {
-    const int n = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     float cn[NNORM];
 #pragma unroll
     for (int i = 0; i < NNORM; ++i) cn[i] = 0.f;
@@ -106,27 +107,32 @@ __global__ __launch_bounds__(64) void object_loss_kernel(const float* __restrict
     for (int i = 0; i < NNORM; ++i)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) cn[i] += __shfl_xor(cn[i], off);
-    const float* t = rows + (size_t)n * ROW;
-    Dual out[NVAL];
-    const PixelReader X{object_pixel(reg, t, n, B, H, W, ld, ch_off), lane};
-    object_terms(X, t, c, cn, out);
+    // (deterministic mode launches ONE wave that walks the objects in order: its adds into `vals` are then sequential)
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        const float* t = rows + (size_t)n * ROW;
+        Dual out[NVAL];
+        const PixelReader X{object_pixel(reg, t, n, B, H, W, ld, ch_off), lane};
+        object_terms(X, t, c, cn, out);
 #pragma unroll
-    for (int k = 0; k < NTERM; ++k) G[((size_t)n * NTERM + k) * 64 + lane] = out[k].d;
-    if (lane == 0 && t[R_VALID] != 0.f)
-        for (int k = 0; k < NVAL; ++k) unsafeAtomicAdd(vals + k, out[k].v);
+        for (int k = 0; k < NTERM; ++k) G[((size_t)n * NTERM + k) * 64 + lane] = out[k].d;
+        if (lane == 0 && t[R_VALID] != 0.f)
+            for (int k = 0; k < NVAL; ++k) unsafeAtomicAdd(vals + k, out[k].v);
+    }
 }
 
 __global__ __launch_bounds__(64) void object_loss_bwd_kernel(const float* __restrict__ G, const float* __restrict__ gout,
-                                                             const float* __restrict__ rows, int B, int H, int W,
+                                                             const float* __restrict__ rows, int N, int B, int H, int W,
                                                              float* __restrict__ dreg, int ld, int ch_off) {
-    const int n = blockIdx.x, lane = threadIdx.x;
-    const float* t = rows + (size_t)n * ROW;
-    if (t[R_VALID] == 0.f || lane >= 50) return;
-    float g = 0.f;
+    const int lane = threadIdx.x;
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {       // (deterministic mode: one wave, objects that share a pixel add in order)
+        const float* t = rows + (size_t)n * ROW;
+        if (t[R_VALID] == 0.f || lane >= 50) continue;
+        float g = 0.f;
 #pragma unroll
-    for (int k = 0; k < NTERM; ++k) g += gout[k] * G[((size_t)n * NTERM + k) * 64 + lane];
-    float* p = const_cast<float*>(object_pixel(dreg, t, n, B, H, W, ld, ch_off));
-    unsafeAtomicAdd(p + lane, g);
+        for (int k = 0; k < NTERM; ++k) g += gout[k] * G[((size_t)n * NTERM + k) * 64 + lane];
+        float* p = const_cast<float*>(object_pixel(dreg, t, n, B, H, W, ld, ch_off));
+        unsafeAtomicAdd(p + lane, g);
+    }
 }
 
 }  // namespace mfx
@@ -140,7 +146,7 @@ extern "C" int mfx_object_loss(const float* reg_nhwc, int B, int H, int W, int l
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     MFX_HIP_CHECK(mfx::zero_async(vals, sizeof(float) * MFX_OBJ_VALUES, st));
     if (N == 0) return MFX_OK;
-    hipLaunchKernelGGL(object_loss_kernel, dim3(N), dim3(64), 0, st, reg_nhwc, B, H, W, ld, ch_off, rows, N, *cfg, vals, G);
+    hipLaunchKernelGGL(object_loss_kernel, dim3(g_opt_det ? 1 : N), dim3(64), 0, st, reg_nhwc, B, H, W, ld, ch_off, rows, N, *cfg, vals, G);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -151,7 +157,7 @@ extern "C" int mfx_object_loss_backward(const float* G, const float* gout_terms,
     if (B < 0 || (B > 0 && (H < 1 || W < 1)) || N < 0 || ch_off < 0 || ch_off + 50 > ld) return mfx_fail(MFX_ERR_ARG, "object_loss_backward: bad sizes");
     if (N == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(object_loss_bwd_kernel, dim3(N), dim3(64), 0, st, G, gout_terms, rows, B, H, W, dreg_nhwc, ld, ch_off);
+    hipLaunchKernelGGL(object_loss_bwd_kernel, dim3(g_opt_det ? 1 : N), dim3(64), 0, st, G, gout_terms, rows, N, B, H, W, dreg_nhwc, ld, ch_off);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

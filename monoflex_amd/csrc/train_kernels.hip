@@ -977,10 +977,11 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
         if (use_ws && slabs < 1) slabs = 1;
         g.m_per_block = std::max(1024, (int)(((long)g.M / slabs + 31) / 32 * 32));
         const int nslab = cdivt(g.M, g.m_per_block);
-        const bool ws_ok = use_ws && (size_t)nslab * ws_slab * sizeof(float) <= workspace_bytes;
+        bool ws_ok = use_ws && (size_t)nslab * ws_slab * sizeof(float) <= workspace_bytes;
+        if (!ws_ok && g_opt_det) { g.m_per_block = (g.M + 31) / 32 * 32; }     // atomics: a single slab per tile adds into zeros exactly once
         if (ws_ok) { g.ws = reinterpret_cast<float*>(workspace); g.ws_ld = ws_ld; g.ws_slab = ws_slab; }
         else MFX_HIP_CHECK(mfx::zero_async(dw, dw_bytes, st));
-        dim3 grid(cdivt(g.K, bt), cdivt(Cout, bt), nslab);
+        dim3 grid(cdivt(g.K, bt), cdivt(Cout, bt), cdivt(g.M, g.m_per_block));
         if (bt == 128) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<128>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
         else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
         if (ws_ok) {
@@ -991,6 +992,7 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
         return MFX_OK;
     }
     MFX_HIP_CHECK(mfx::zero_async(dw, dw_bytes, st));
+    if (g_opt_det) g.m_per_block = g.M;                          // one slab: every element of dw receives exactly one add
     dim3 grid(cdivt(g.K, 64), cdivt(Cout, 64), cdivt(g.M, g.m_per_block));
     DISPATCH_T(dtype, hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, g, dw),
                       hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw));
@@ -1067,7 +1069,7 @@ extern "C" int mfx_pack_conv_weights_batched(const mfx_pack_desc* descs_dev, con
     return MFX_OK;
 }
 
-static int bn_rows_per_block(long M, int C, int dtype);
+static int bn_rows_per_block(long M, int C, int dtype, int owners);
 
 extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int dtype, void* stream) {
     if (!x || !out) return mfx_fail(MFX_ERR_ARG, "colsum: null pointer");
@@ -1077,7 +1079,7 @@ extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int 
     {
         const int E = dtype == MFX_BF16 ? 8 : 4;
         if (C % E == 0 && ld % E == 0 && C / E <= 256 && 256 % (C / E) == 0) {
-            const int rows2 = bn_rows_per_block(M, C, dtype);
+            const int rows2 = bn_rows_per_block(M, C, dtype, 1);
             const size_t smem = (size_t)(256 / (C / E)) * C * sizeof(float);
             DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_chunk_kernel<float>, dim3(cdivt(M, rows2)), dim3(256), smem, st, (const float*)x, M, C, ld, rows2, out),
                               hipLaunchKernelGGL(colsum_chunk_kernel<bf16_t>, dim3(cdivt(M, rows2)), dim3(256), smem, st, (const bf16_t*)x, M, C, ld, rows2, out));
@@ -1085,7 +1087,7 @@ extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int 
             return MFX_OK;
         }
     }
-    const int rows = M >= (1 << 18) ? 1024 : 128;             // >= ~2 workgroups per CU also on the small head maps
+    const int rows = g_opt_det ? (int)M : (M >= (1 << 18) ? 1024 : 128);             // >= ~2 workgroups per CU also on the small head maps
     dim3 grid(cdivt(M, rows), cdivt(C, 64)), block(64, 4);
     DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)x, (int)M, C, ld, rows, out),
                       hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (int)M, C, ld, rows, out));
@@ -1099,9 +1101,16 @@ int g_opt_bn_blocks = 768;     // option "bn_blocks": target workgroup count of 
 // rows per workgroup of the column reductions: every workgroup ends with one global atomic per column, all workgroups on the
 // same 2C addresses (~12 ns each when they collide), so the count is bounded (~3 per CU, 4+ rows in flight per thread hide the
 // latency instead of more workgroups); a multiple of the rows one pass of the 256 threads covers
-static int bn_rows_per_block(long M, int C, int dtype) {
+// `owners`: the number of separate destination copies the launch adds into (workgroup b -> copy b % owners).  Deterministic mode
+// launches at most one workgroup per copy, so every copy has a single writer and its adds happen in program order.
+static int bn_rows_per_block(long M, int C, int dtype, int owners) {
     const int E = dtype == MFX_BF16 ? 8 : 4, rstep = std::max(1, 256 / (C / E));
-    const int target = g_opt_bn_blocks > 0 ? g_opt_bn_blocks : 768;
+    const int target = g_opt_det ? std::max(1, owners) : (g_opt_bn_blocks > 0 ? g_opt_bn_blocks : 768);
+    if (g_opt_det) {
+        long rows = (M + target - 1) / target;
+        rows = (rows + rstep - 1) / rstep * rstep;
+        return (int)std::max<long>(rows, rstep);
+    }
     long rows = (M + target - 1) / target;
     rows = std::max<long>(rows, 8L * rstep);
     rows = (rows + rstep - 1) / rstep * rstep;
@@ -1124,7 +1133,7 @@ extern "C" int mfx_bn_stats(const void* x, float* sum, float* sumsq, long M, int
         MFX_HIP_CHECK(mfx::zero_async(sumsq, (size_t)C * sizeof(float), st));
     }
     if (M == 0) return MFX_OK;
-    const int rows = bn_rows_per_block(M, C, dtype);
+    const int rows = bn_rows_per_block(M, C, dtype, 1);
     const size_t smem = (size_t)(256 / (C / (dtype == MFX_BF16 ? 8 : 4))) * 2 * C * sizeof(float);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, sum, sumsq, 1),
                       hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, sum, sumsq, 1));
@@ -1169,7 +1178,7 @@ extern "C" int mfx_bn_bwd_reduce(const void* x, const void* a, const void* da, c
         MFX_HIP_CHECK(mfx::zero_async(sgx, (size_t)C * sizeof(float), st));
     }
     if (M == 0) return MFX_OK;
-    const int rows = bn_rows_per_block(M, C, dtype);
+    const int rows = bn_rows_per_block(M, C, dtype, 1);
     const size_t smem = (size_t)(256 / (C / (dtype == MFX_BF16 ? 8 : 4))) * 2 * C * sizeof(float);
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sg, sgx, 1),
@@ -1215,7 +1224,7 @@ extern "C" int mfx_bn_train_fwd(const void* x, const void* res, void* y, const f
     if (M <= 0) return mfx_fail(MFX_ERR_ARG, "bn_train_fwd: empty batch");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int E = dtype == MFX_BF16 ? 8 : 4, ncopy = bn_ncopy(C);
-    const int rows = bn_rows_per_block(M, C, dtype);
+    const int rows = bn_rows_per_block(M, C, dtype, ncopy);
     const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
     if (!stats_done)
         DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, scratch, scratch + C, ncopy),
@@ -1261,7 +1270,7 @@ extern "C" int mfx_bn_train_stats(const void* x, const float* gamma, const float
     if (2 * C > BN_SCRATCH_COLS || M <= 0) return mfx_fail(MFX_ERR_ARG, "bn_train_stats: C > 512 or empty batch");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int E = dtype == MFX_BF16 ? 8 : 4, ncopy = bn_ncopy(C);
-    const int rows = bn_rows_per_block(M, C, dtype);
+    const int rows = bn_rows_per_block(M, C, dtype, ncopy);
     const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
     if (!stats_done)
         DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, scratch, scratch + C, ncopy),
@@ -1284,7 +1293,7 @@ extern "C" int mfx_bn_train_bwd(const void* x, const void* a, const void* da, co
     if (M <= 0) return mfx_fail(MFX_ERR_ARG, "bn_train_bwd: empty batch");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int E = dtype == MFX_BF16 ? 8 : 4, ncopy = bn_ncopy(C);
-    const int rows = bn_rows_per_block(M, C, dtype);
+    const int rows = bn_rows_per_block(M, C, dtype, ncopy);
     const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
     float* sums = scratch + BN_SCRATCH_COLS;
     DISPATCH_T(dtype,
@@ -1330,7 +1339,7 @@ extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* 
     const long total = (long)B * H * W * (C / E);
     if (total == 0) return MFX_OK;
     const int nrows = B * H;
-    const int ppb = nrows >= 1024 ? 2 : 1;                   // input rows per block: >= ~512 blocks
+    const int ppb = g_opt_det ? nrows : (nrows >= 1024 ? 2 : 1);                   // input rows per block: >= ~512 blocks (deterministic: one workgroup)
     const int dw_items = 4 * f * f * (C / E);
     if (dw_items & (dw_items - 1)) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: taps x channel chunks must be a power of two");
     const size_t dw_smem = dw_items >= 1024 ? 0 : (size_t)1024 * E * sizeof(float);          // [S][items * E], S * items = 1024

@@ -178,6 +178,18 @@ def load():
     return lib
 
 
+def set_deterministic(on=True):
+    """Bit-reproducible training steps: the library's reductions run in a fixed order (option "deterministic": single-writer
+    partial sums instead of fp32 atomics, fixed-point accumulation of the DCN input gradient) and torch's own scatter-type ops
+    (index_add_ behind the edge-fusion gather) take their sorted forms.  Slower (roughly 2-3x on a full-size step); meant for
+    tests and debugging -- two runs, eager or replayed from a hipGraph, then agree bit for bit."""
+    import torch
+    check(load().mfx_set_option(b"deterministic", 1 if on else 0), "set_option(deterministic)")
+    torch.use_deterministic_algorithms(bool(on), warn_only=True)
+    if on:
+        torch.utils.deterministic.fill_uninitialized_memory = False        # (torch.empty need not be NaN-filled: every buffer is written)
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().mfx_last_error().decode(errors="replace")

@@ -345,12 +345,7 @@ class Loss_Computation:
             from ... import autograd as AG
             hm_loss, num_pos = AG.FocalLossFn.apply(predictions['cls_logits_nhwc'], heat.to(dev), float(self.focal_alpha), float(self.focal_beta))
         else:
-            cls = predictions['cls']
-            if torch.is_grad_enabled() and not cls.requires_grad and any(torch.is_tensor(v) and v.requires_grad for v in predictions.values()):
-                # the device predictor hands out `cls` as sigmoid(logits.detach()) (the focal kernel consumes the logits): using it
-                # here would train the class head with a silent zero gradient
-                raise RuntimeError("heat-map loss: predictions['cls'] carries no gradient and 'cls_logits_nhwc' is missing")
-            hm_loss, num_pos = self._focal(cls, heat.to(dev))
+            hm_loss, num_pos = self._focal(predictions['cls'], heat.to(dev))
         return self.loss_weights['hm_loss'] * hm_loss / torch.clamp(num_pos, 1)
 
     def _fused(self, predictions, heat, tv, dev):

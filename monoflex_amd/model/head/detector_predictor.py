@@ -294,13 +294,14 @@ class _predictor(nn.Module):
         ei, el = getattr(targets, "edge", None) or stack_edge_fields(targets, x.device)
         if self.training and object_rows is not None:
             logits, reg_rows = self.forward_train(x, ei, el, object_rows)
-            cls = torch.sigmoid(logits.detach()).clamp(min=1e-4, max=1 - 1e-4)
+            cls = torch.sigmoid(logits).clamp(min=1e-4, max=1 - 1e-4)           # (attached: see below)
             return {'cls': cls.permute(0, 3, 1, 2), 'reg': None, 'reg_rows': reg_rows, 'cls_logits_nhwc': logits}
         if self.training:
             logits, reg = self.forward_train(x, ei, el)
-            # 'cls' keeps the reference's contract (sigmoid_hm of the logits, NCHW); the loss uses the raw NHWC logits and does
-            # sigmoid + clamp + focal + its gradient in one kernel, so this view stays a detached by-product
-            cls = torch.sigmoid(logits.detach()).clamp(min=1e-4, max=1 - 1e-4)
+            # 'cls' keeps the reference's contract (sigmoid_hm of the logits, NCHW, differentiable); this build's loss uses the raw
+            # NHWC logits and does sigmoid + clamp + focal + its gradient in one kernel, so the backward of this view never runs
+            # there -- but any other consumer of maps['cls'] (or the loss's tensor-op fallback) still trains the class head
+            cls = torch.sigmoid(logits).clamp(min=1e-4, max=1 - 1e-4)
             return {'cls': cls.permute(0, 3, 1, 2), 'reg': reg.permute(0, 3, 1, 2), 'cls_logits_nhwc': logits}
         hm = self.forward_nhwc(x, ei, el)
         cls = torch.sigmoid(hm[..., :self.num_classes]).clamp(min=1e-4, max=1 - 1e-4).permute(0, 3, 1, 2)

@@ -776,7 +776,9 @@ def test_dcn_fused_sample_wgrad_kernel_vs_oracle(H, W, off_std, min_chunks):
     for n, a, w_ in zip(names, got[1], want):
         assert _rel(a, w_) < (3e-2 if n == "input" else 4e-2), (n, _rel(a, w_))      # bars of test_dcn_train_grads_bf16_vs_oracle
     for n, a, b_ in zip(names, got[1], got[0]):
-        assert _rel(a, b_) < 1e-2, ("fused vs unfused", n, _rel(a, b_))
+        # (grad_input comes from the tile + far kernels in both forms; far corners are added with packed-bf16 atomics, whose rounding
+        # depends on arrival order, so two runs of the SAME kernels differ by up to ~2 % of the largest entry at these offsets)
+        assert _rel(a, b_) < (3e-2 if n == "input" else 1e-2), ("fused vs unfused", n, _rel(a, b_))
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,H,W", [(64, 256, 3, 1, 48, 96), (64, 64, 3, 1, 40, 72), (128, 128, 3, 2, 64, 80),

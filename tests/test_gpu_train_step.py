@@ -57,6 +57,39 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
+@pytest.fixture
+def deterministic():
+    """Option "deterministic" (lib.set_deterministic): fixed-order reductions, so two runs agree bit for bit."""
+    from monoflex_amd import lib as L
+    L.set_deterministic(True)
+    yield
+    L.set_deterministic(False)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_deterministic_mode_is_bitwise_reproducible(dtype, deterministic):
+    """Two eager forward + loss + backward passes of the same model on the same batch: every loss, every gradient and every BN
+    buffer identical to the last bit (without the option, BN statistics / bias sums / DCN far corners are summed with float
+    atomics and the two runs differ by up to a few per cent in the earliest layers)."""
+    m = _model(dtype)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    imgs, tg = _batch(m)
+    runs = []
+    for _ in range(2):
+        m.load_state_dict(sd)
+        m.zero_grad(set_to_none=True)
+        ld, _ = m(imgs, tg)
+        sum(ld.values()).backward()
+        torch.cuda.synchronize()
+        runs.append(({k: v.detach().clone() for k, v in ld.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None},
+                     {k: v.detach().clone() for k, v in m.state_dict().items() if "running_" in k}))
+    (la, ga, ba), (lb, gb, bb) = runs
+    assert all(torch.equal(la[k], lb[k]) for k in la), {k: (float(la[k]), float(lb[k])) for k in la if not torch.equal(la[k], lb[k])}
+    diff = [n for n in ga if not torch.equal(ga[n], gb[n])]
+    assert not diff and len(ga) >= 270, diff[:8]
+    assert all(torch.equal(ba[k], bb[k]) for k in ba)
+
+
 def test_ddp_over_rccl_wraps_the_hip_autograd_functions(nccl_world1):
     """tools/plain_train_net.py:134-137 on this build: DistributedDataParallel (RCCL backend, world_size 1, the six dead
     parameters ignored statically) around the real model -- one step's loss and gradients equal the unwrapped model's,
@@ -84,6 +117,24 @@ def test_ddp_over_rccl_wraps_the_hip_autograd_functions(nccl_world1):
                 assert cos > 0.98 and abs(float(ga.norm() / gbb.norm()) - 1) < 0.10, (n, cos, float(ga.norm() / gbb.norm()))
     dead = set(dead_parameter_names(b))
     assert all((p.grad is None) == (n in dead) for n, p in b.named_parameters())
+
+
+def test_ddp_gradients_equal_the_unwrapped_models_bitwise(nccl_world1, deterministic):
+    """The same comparison with fixed-order reductions: DDP's bucket views and its (world_size 1) all-reduce must hand every
+    parameter exactly the gradient the unwrapped model computes -- a wrong bucket view or a dropped hook cannot hide in noise."""
+    from monoflex_amd.engine.trainer import wrap_data_parallel
+    a, b = _model(), _model()
+    imgs, tg = _batch(a)
+    la, _ = a(imgs, tg)
+    sum(la.values()).backward()
+    net = wrap_data_parallel(b, device_ids=[torch.cuda.current_device()])
+    lb, _ = net(imgs, tg)
+    sum(lb.values()).backward()
+    torch.cuda.synchronize()
+    assert all(torch.equal(la[k], lb[k]) for k in la)
+    gb = dict(b.named_parameters())
+    diff = [n for n, p in a.named_parameters() if p.grad is not None and not torch.equal(p.grad, gb[n].grad)]
+    assert not diff, diff[:8]
 
 
 @pytest.mark.parametrize("split", [False, True])
@@ -121,6 +172,40 @@ def test_graphed_train_step_equals_the_eager_step(split, nccl_world1):
         checked += 1
     assert checked >= 10
     assert np.isfinite(float(step()))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("split", [False, True])
+def test_graphed_train_step_equals_the_eager_step_bitwise(split, dtype, nccl_world1, deterministic):
+    """With fixed-order reductions the replayed step and the eager step are the same arithmetic: after one step from a common
+    state, EVERY parameter, BN buffer and AdamW moment is identical to the last bit, in both launch forms (single graph; flat
+    gradient buffer + all-reduce + optimizer graph) -- and again after a second step."""
+    from monoflex_amd.engine.trainer import GraphedTrainStep, train_step
+    from monoflex_amd.solver import build_optimizer
+    cfg = _cfg(dtype)
+    b = _model(dtype)
+    imgs, tg = _batch(b)
+    opt_b = build_optimizer(b, cfg, capturable=True)
+    step = GraphedTrainStep(b, opt_b, imgs, tg, warmup=2, split=split)
+    torch.cuda.synchronize()
+    model_sd = {k: v.detach().clone() for k, v in b.state_dict().items()}
+    opt_sd = copy.deepcopy(opt_b.state_dict())
+    a = _model(dtype, seed=5)
+    a.load_state_dict(model_sd)
+    opt_a = build_optimizer(a, cfg, capturable=True)
+    opt_a.load_state_dict(opt_sd)
+    for it in range(2):
+        loss_b = step().clone()
+        loss_a = train_step(a, opt_a, imgs, tg)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(loss_a, loss_b), (it, float(loss_a), float(loss_b))
+        sa, sb = a.state_dict(), b.state_dict()
+        diff = [k for k in sa if not torch.equal(sa[k], sb[k])]
+        assert not diff, (it, diff[:8])
+        for ga, gb in zip(opt_a.param_groups, opt_b.param_groups):
+            for x, y in zip(ga["params"], gb["params"]):
+                if x in opt_a.state:
+                    assert torch.equal(opt_a.state[x]["exp_avg_sq"], opt_b.state[y]["exp_avg_sq"]), it
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
