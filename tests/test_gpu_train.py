@@ -536,6 +536,78 @@ def test_training_forward_loss_vs_oracle():
     assert all(isinstance(v, float) for v in logs.values())
 
 
+FULL_SIZE_TENSORS = (
+    "backbone.base.base_layer.0.weight", "backbone.base.level0.0.weight", "backbone.base.level1.0.weight",
+    "backbone.base.level2.tree1.conv1.weight", "backbone.base.level2.root.conv.weight", "backbone.base.level3.tree1.tree1.conv2.weight",
+    "backbone.base.level3.tree2.root.conv.weight", "backbone.base.level4.tree2.tree1.conv1.weight", "backbone.base.level5.tree2.conv2.weight",
+    "backbone.base.level5.root.conv.weight", "backbone.dla_up.ida_0.proj_1.conv.weight", "backbone.dla_up.ida_0.node_1.conv.conv_offset_mask.weight",
+    "backbone.dla_up.ida_1.node_2.conv.weight", "backbone.dla_up.ida_1.up_1.weight", "backbone.dla_up.ida_2.proj_3.conv.weight",
+    "backbone.dla_up.ida_2.node_1.conv.weight", "backbone.dla_up.ida_2.node_3.conv.conv_offset_mask.weight", "backbone.dla_up.ida_2.node_3.conv.conv_offset_mask.bias",
+    "backbone.dla_up.ida_2.node_3.actf.0.weight", "backbone.ida_up.proj_2.conv.weight", "backbone.ida_up.node_1.conv.weight",
+    "backbone.ida_up.node_2.conv.weight", "backbone.ida_up.node_2.conv.conv_offset_mask.weight", "backbone.ida_up.up_2.weight",
+    "heads.predictor.class_head.0.weight", "heads.predictor.class_head.2.weight", "heads.predictor.reg_features.2.0.weight",
+    "heads.predictor.reg_heads.2.0.weight", "heads.predictor.reg_features.1.0.weight", "heads.predictor.trunc_offset_conv.0.weight",
+)
+
+
+def _full_size_rows(gdev, gref):
+    rows = []
+    for n in FULL_SIZE_TENSORS:
+        if gref[n].grad is None:
+            continue
+        a, b = gdev[n].grad.detach().double().cpu().flatten(), gref[n].grad.double().flatten()
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp(min=1e-30))
+        rows.append((n, cos, float((a - b).norm() / b.norm().clamp(min=1e-30))))
+    return rows
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_full_size_training_step_vs_oracle(dtype):
+    """`model(images, targets)` + backward at the benchmarked size (B = 2, 1280 x 384) against the oracle network in fp32 (CPU,
+    train-mode BN, C restatement of the reference DCN backward) with the same loss module on the same inputs.
+
+    fp32: the 11 losses and 29 gradient tensors spread over the stem, every DLA level, DCN main / offset-mask convs, the
+    depthwise up-samplers and the heads (measured on MI355X: losses 1e-4, every cosine >= 0.9988, relative l2 <= 5.1e-2 --
+    rounding amplified through ~100 batch-statistics BN layers; bounds ~2x).
+    bf16: ONLY the 11 losses are bounded end to end (measured worst 13.6 %).  A randomly initialised DLA-34 under batch-statistics BN
+    is chaotic: the bf16 feature map leaves the fp32 one by 86 % in l2 (13 % already at level5, doubling per level;
+    tools/probes/train_bf16_diag.py) and whole-network gradients are uncorrelated with the oracle's although every layer is
+    right -- which is what tests/test_gpu_train_fullsize.py pins, layer by layer on the same step, to bf16 rounding."""
+    from monoflex_amd import lib as L, synthetic as S
+    from monoflex_amd.structures.params_3d import make_train_target
+    out_w, out_h, B = 320, 96, 2
+    m, ref = _models(out_w, out_h)
+    m.set_compute_dtype(dtype)
+    tg = [S.synthetic_train_target(1000 + i) for i in range(B)]
+    targets = [make_train_target(t) for t in tg]
+    imgs = S.synthetic_images(B, seed=1000)
+    ei = torch.stack([torch.as_tensor(t["edge_indices"]) for t in tg])
+    el = torch.as_tensor([int(t["edge_len"]) for t in tg])
+    lib_ = L.load()
+    fused0 = lib_.mfx_get_counter(b"dcn_bt_fused")
+    loss_dict, _ = m(imgs.to(DEV), [t.to(DEV) for t in targets])
+    sum(loss_dict.values()).backward()
+    torch.cuda.synchronize()
+    assert lib_.mfx_get_counter(b"dcn_bt_fused") - fused0 == (5 if dtype == "bf16" else 0)
+    om = ref.forward_maps(imgs, ei, el)
+    want, _ = m.heads.loss_evaluator(om, targets)
+    assert set(loss_dict) == set(want) and len(want) == 11
+    worst_loss = max(abs(float(loss_dict[k]) - float(want[k])) / max(1.0, abs(float(want[k]))) for k in want)
+    print("full-size %s step vs oracle: worst relative loss deviation %.3e" % (dtype, worst_loss),
+          {k: (round(float(loss_dict[k]), 5), round(float(want[k]), 5)) for k in want})
+    assert worst_loss < (3e-4 if dtype == "fp32" else 0.28), worst_loss
+    if dtype == "bf16":
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+        return
+    sum(want.values()).backward()
+    rows = _full_size_rows(dict(m.named_parameters()), dict(ref.named_parameters()))
+    for r in rows:
+        print("   %-70s cos %.5f  rel %.3e" % r)
+    assert len(rows) >= 29
+    assert min(r[1] for r in rows) > 0.997, min(rows, key=lambda r: r[1])
+    assert max(r[2] for r in rows) < 0.1, max(rows, key=lambda r: r[2])
+
+
 def test_train_steps_update_parameters():
     """Four optimisation steps (engine.trainer.train_step, AdamW groups of solver.build_optimizer): finite losses,
     every live parameter moves, the six dead ones never get a gradient, BN running statistics move."""
