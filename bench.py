@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="inference: run the batch as this many sub-batches on forked streams inside one step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-images", type=int, default=6)
+    ap.add_argument("--split", action="store_true", help="train mode: the segmented data-parallel form (cut backward, flat gradient buffer, "
+                                                        "per-segment exchange, optimizer graph) also on one GPU, to price the segmentation")
     ap.add_argument("--sync-bn", action="store_true", help="train mode, N > 1: synchronised BatchNorm statistics")
     ap.add_argument("--legs", default="all", choices=["all", "none"], help="infer mode: add the `train` and `fp32_parity` legs to the line")
     ap.add_argument("--repeats", type=int, default=None, help="timed regions of exactly --steps steps; the median is reported")
@@ -365,8 +367,10 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False):
     graphed = not args.no_graph and not (args.sync_bn and world > 1)        # SyncBN collectives sit inside the network
     opt = build_optimizer(model, cfg, capturable=graphed)
     if graphed:
-        step = GraphedTrainStep(model, opt, imgs, targets)
-        mode = "hipGraph (fwd+loss+bwd+AdamW)" if world == 1 else "hipGraph fwd+bwd | RCCL all-reduce(flat fp32 grads) | hipGraph AdamW"
+        step = GraphedTrainStep(model, opt, imgs, targets, split=True if args.split else None)
+        mode = "hipGraph (fwd+loss+bwd+AdamW)" if not step.split else \
+            "%d hipGraphs (fwd+loss+bwd piece 0 | bwd pieces 1..%d), RCCL all-reduce of piece k's slice of the flat fp32 gradient buffer on a " \
+            "comm stream while piece k+1 runs | hipGraph AdamW" % (len(step.graphs), len(step.graphs) - 1)
     else:
         net = wrap_data_parallel(model, device_ids=[device.index]) if world > 1 else model
         mode = "eager" + (" + torch DDP (bucketed all-reduce overlapped with backward)" if world > 1 else "")

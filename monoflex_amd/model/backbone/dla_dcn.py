@@ -178,10 +178,10 @@ class DLA(nn.Module):
             inplanes = planes
         return nn.Sequential(*modules)
 
-    def forward(self, images, dtype):
-        """images: (B,3,H,W) fp32 NCHW -> list of 6 NHWC feature maps (strides 1..32)."""
+    def forward(self, images, dtype, cut=None):
+        """images: (B,3,H,W) fp32 NCHW -> list of 6 NHWC feature maps (strides 1..32).  `cut` (training): see DLASeg.forward_nhwc."""
         if self.training:
-            return self._forward_train(images, dtype)
+            return self._forward_train(images, dtype, cut)
         packs = self.__dict__.setdefault("_packs", {})
         if ("stem", dtype) not in packs:
             scale, shift = ops.fold_bn(self.base_layer[1])
@@ -203,11 +203,13 @@ class DLA(nn.Module):
         return y
 
 
-def _dla_forward_train(self, images, dtype):
+def _dla_forward_train(self, images, dtype, cut=None):
     x = AG.bn_act(AG.StemConvFn.apply(images, self.base_layer[0].weight, dtype), self.base_layer[1], L.ACT_RELU)
     y = []
     for i in range(6):
         lvl = getattr(self, "level{}".format(i))
+        if cut is not None and i == 4:
+            x = cut("level3", [x])[0]                           # level4 reads level3's map through a gradient cut
         if i < 2:
             for j in range(0, len(lvl), 3):
                 x = _train_conv_bn(x, lvl[j], lvl[j + 1], L.ACT_RELU)
@@ -324,15 +326,24 @@ class DLASeg(nn.Module):
                             [2 ** i for i in range(self.last_level - self.first_level)])
         self.compute_dtype = torch.float32
 
-    def forward_nhwc(self, images):
-        x = self.base(images, self.compute_dtype)
+    def forward_nhwc(self, images, cut=None):
+        """`cut(name, tensors) -> tensors` (training, optional): called at three points of the forward pass -- level3 -> level4
+        ("level3"), DLA base -> DLAUp ("base", the six level maps) and DLAUp -> IDAUp ("dla_up") -- so that a trainer can replace
+        the maps by detached leaves and run the backward pass in four pieces (heads + IDAUp, DLAUp, level5/4, level3..stem), each
+        followed by the all-reduce of its own gradients (engine/trainer.GraphedTrainStep; KeypointDetector.backward_thunks)."""
+        cut = cut if (cut is not None and self.training) else None
+        x = self.base(images, self.compute_dtype, cut) if cut is not None else self.base(images, self.compute_dtype)
+        if cut is not None:
+            x = cut("base", list(x))
         x = self.dla_up(list(x))
         # the reference clones x[0..2] because IDAUp mutates its list argument (dla_dcn.py:53-56); here the
         # list itself is fresh and tensors are never written in place, so no copy is needed
         y = [x[i] for i in range(self.last_level - self.first_level)]
+        if cut is not None:
+            y = cut("dla_up", y)
         self.ida_up(y, 0, len(y))
         return y[-1]
 
-    def forward(self, images):
+    def forward(self, images, cut=None):
         """(B,3,H,W) -> (B,64,H/4,W/4): logical NCHW view of the NHWC result (channels_last strides)."""
-        return self.forward_nhwc(images).permute(0, 3, 1, 2)
+        return self.forward_nhwc(images, cut).permute(0, 3, 1, 2)

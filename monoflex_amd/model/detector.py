@@ -57,6 +57,47 @@ class KeypointDetector(nn.Module):
         pr = self.heads.predictor
         return ei, el, pad, calib, size, make_edge_rowmap(ei, pr.output_height, pr.output_width)
 
+    # ---- backward pass in pieces (data-parallel overlap of the gradient exchange; engine/trainer.GraphedTrainStep) -----------------
+    BACKWARD_SEGMENTS = 4
+
+    def backward_segment_of(self, name):
+        """Which of the four backward pieces produces the gradient of parameter `name`: 0 = heads + IDAUp (first to finish),
+        1 = DLAUp, 2 = DLA level5 / level4, 3 = level3 .. stem (last)."""
+        if name.startswith("heads.") or name.startswith("backbone.ida_up."):
+            return 0
+        if name.startswith("backbone.dla_up."):
+            return 1
+        if name.startswith("backbone.base.level4.") or name.startswith("backbone.base.level5."):
+            return 2
+        return 3
+
+    def set_backward_cuts(self, cut):
+        """The next training forward passes call `cut(name, tensors)` at the segment boundaries (None: one autograd graph again)."""
+        self._cut = cut
+
+    @staticmethod
+    def backward_thunks(losses, cuts):
+        """The four pieces of `losses.backward()` over the cut forward pass, in execution order.  `cuts[name] = (maps the forward
+        produced, the detached leaves the next stage consumed)`; a piece back-propagates the leaves' gradients into the maps.
+        level3's map has two consumers (level4 through "level3", DLAUp through "base"): their gradients are added first."""
+        def run(tensors, grads):
+            pairs = [(t, g) for t, g in zip(tensors, grads) if g is not None and t.requires_grad]
+            torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+
+        def dla_up():
+            o, l = cuts["dla_up"]
+            run(o, [x.grad for x in l])
+
+        def level54():
+            o, l = cuts["base"]
+            run(o[4:6], [l[4].grad, l[5].grad])
+
+        def level3_to_stem():
+            o, l = cuts["base"]
+            g3, gx = l[3].grad, cuts["level3"][1][0].grad
+            run([o[2], o[3]], [l[2].grad, gx if g3 is None else (g3 if gx is None else g3 + gx)])
+        return [lambda: losses.backward(), dla_up, level54, level3_to_stem]
+
     def forward(self, images, targets=None):
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")
@@ -64,7 +105,7 @@ class KeypointDetector(nn.Module):
         if not images.tensors.is_cuda:
             raise RuntimeError("KeypointDetector (HIP build) needs CUDA/HIP tensors: there is no CPU fallback")
         if self.training:                                           # detector.py:30-33 -> (loss_dict, log_loss_dict)
-            return self.heads(self.backbone(images.tensors), targets)
+            return self.heads(self.backbone(images.tensors, getattr(self, "_cut", None)), targets)
         with torch.no_grad():
             features = self.backbone(images.tensors)
             return self.heads(features, targets, test=self.test)

@@ -48,9 +48,13 @@ def get_model_params(model, cfg, per_parameter_groups=False, tensor_lr_device=No
     return [{"params": w, "lr": mk(base_lr)}, {"params": b, "lr": mk(bias_lr)}]
 
 
-def build_optimizer(model, cfg, per_parameter_groups=False, capturable=False):
+def build_optimizer(model, cfg, per_parameter_groups=False, capturable=None):
+    """`capturable=None`: capturable (device-side step counters and learning rates) whenever the model lives on a GPU, so that the
+    training loop can replay the step from hipGraphs (engine/trainer.do_train); the arithmetic is AdamW's either way."""
     s = cfg.SOLVER
     dev = next((p.device for p in model.parameters() if p.is_cuda), None)
+    if capturable is None:
+        capturable = dev is not None and s.OPTIMIZER == "adamw"
     tensor_lr = capturable and dev is not None and s.OPTIMIZER == "adamw"
     params = get_model_params(model, cfg, per_parameter_groups, tensor_lr_device=dev if tensor_lr else None)
     on_gpu = dev is not None

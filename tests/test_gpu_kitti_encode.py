@@ -85,6 +85,51 @@ def test_frames_bit_exact():
         E.preprocess_images([np.zeros((400, 1300, 3), np.uint8)], [0], E.EncodeParams(), "cuda")
 
 
+def test_do_train_replays_the_graphed_step(tmp_path):
+    """engine.trainer.do_train (the reference's loop, engine/trainer.py:61-225) over DeviceLoader batches: the first batch captures
+    the step as hipGraphs, the following ones are copied into the captured buffers and replayed; the learning rate the captured
+    AdamW reads follows the warm-up + step schedule (device scalars), parameters move, the loss stays finite."""
+    from PIL import Image
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.data import DeviceLoader, KITTIDataset
+    from monoflex_amd.engine import trainer as TR
+    from monoflex_amd.model.detector import KeypointDetector
+    from monoflex_amd.solver import build_optimizer, build_scheduler
+    for d in ("image_2", "label_2", "calib", "ImageSets"):
+        (tmp_path / d).mkdir()
+    P = np.asarray(S.KITTI_P2).reshape(-1)
+    for i, (w, h) in enumerate([(1242, 375), (1224, 370), (1238, 374), (1242, 375)]):
+        Image.fromarray(np.random.RandomState(i).randint(0, 256, (h, w, 3)).astype(np.uint8)).save(tmp_path / "image_2" / ("%06d.png" % i))
+        (tmp_path / "label_2" / ("%06d.txt" % i)).write_text("".join(l + "\n" for l in S.synthetic_kitti_labels(60 + i, w, h, 5 + i)))
+        (tmp_path / "calib" / ("%06d.txt" % i)).write_text("P2: " + " ".join("%.12e" % v for v in P) + "\nP3: " + " ".join("%.12e" % v for v in P) + "\n")
+    (tmp_path / "ImageSets" / "train.txt").write_text("000000\n000001\n000002\n000003\n")
+    cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"))
+    cfg.MODEL.PRETRAIN = False
+    cfg.MODEL.COMPUTE_DTYPE = "bf16"
+    cfg.SOLVER.MAX_ITERATION, cfg.SOLVER.LR_WARMUP, cfg.SOLVER.WARMUP_STEPS, cfg.SOLVER.STEPS = 6, True, 3, [4]
+    cfg.SOLVER.SAVE_CHECKPOINT_INTERVAL, cfg.SOLVER.EVAL_INTERVAL = 1000, 0
+    ds = KITTIDataset(cfg, str(tmp_path), is_train=True, augment=False)
+    batches = list(DeviceLoader(ds, batch_size=2)) * 3                           # 6 iterations over two different batches
+    torch.manual_seed(0)
+    model = KeypointDetector(cfg).cuda().train()
+    model.heads.loss_evaluator.log_as_float = False
+    opt = build_optimizer(model, cfg)                                            # capturable on a GPU: device-scalar learning rates
+    sched, warm = build_scheduler(opt, total_iters_each_epoch=2, optim_cfg=cfg.SOLVER)
+    replays = []
+    real_call = TR.GraphedTrainStep.__call__
+    TR.GraphedTrainStep.__call__ = lambda self: replays.append(len(self.graphs)) or real_call(self)
+    w0 = model.backbone.base.level2.tree1.conv1.weight.detach().clone()
+    args = {"iteration": 0}
+    try:
+        loss = TR.do_train(cfg, False, model, batches, None, opt, sched, warm, None, "cuda", args)
+    finally:
+        TR.GraphedTrainStep.__call__ = real_call
+    assert args["iteration"] == 6 and len(replays) == 6 and np.isfinite(loss)
+    assert not torch.equal(w0, model.backbone.base.level2.tree1.conv1.weight)
+    base = cfg.SOLVER.BASE_LR
+    assert torch.is_tensor(opt.param_groups[0]["lr"]) and float(opt.param_groups[0]["lr"]) == pytest.approx(base * cfg.SOLVER.LR_DECAY, rel=1e-5)
+
+
 def test_dataset_loader_feeds_a_training_step(tmp_path):
     """Generated KITTI directory -> DeviceLoader -> model(images, targets): the encoded batch drives the HIP training
     forward/backward unchanged, and equals the oracle's encoding of the same files."""

@@ -164,7 +164,7 @@ def _flat_step_worker(rank, world, port, out):
     m = _ToyDetector()
     opt = torch.optim.SGD([p for n, p in m.named_parameters() if "project" not in n], lr=0.1)
     xs = torch.arange(12, dtype=torch.float32).view(2, 6) / 10
-    step = GraphedTrainStep(m, opt, xs[rank:rank + 1].clone(), None, comm_chunks=3, use_graphs=False)
+    step = GraphedTrainStep(m, opt, xs[rank:rank + 1].clone(), None, use_graphs=False)
     assert step.split and step.flat.numel() == 3 * 6 + 3                 # live.weight + live.bias only: dead ones left out
     w0 = m.live.weight.detach().clone()
     step()
@@ -196,6 +196,93 @@ def test_flat_gradient_exchange_of_the_graphed_step_over_two_ranks():
         assert torch.allclose(torch.tensor(g1), want, atol=1e-6) and all(dead_none)
     assert torch.allclose(torch.tensor(res[0][2]), torch.tensor(res[1][2]), atol=1e-7)                # ranks stay in lock step
     assert not torch.allclose(torch.tensor(res[0][2]), torch.tensor(res[0][3]))                     # and the weights moved
+
+
+class _ToyStaged(torch.nn.Module):
+    """Three stages with the cut protocol of KeypointDetector (set_backward_cuts / backward_segment_of / backward_thunks): the
+    head's gradients are ready first (segment 0), the stem's last (segment 2); `dead` never receives a gradient."""
+    BACKWARD_SEGMENTS = 3
+
+    def __init__(self):
+        super().__init__()
+        self.stem, self.mid, self.head = torch.nn.Linear(6, 5), torch.nn.Linear(5, 4), torch.nn.Linear(4, 2)
+        self._cut = None
+
+    def backward_segment_of(self, name):
+        return {"head": 0, "mid": 1, "stem": 2}[name.split(".")[0]]
+
+    def set_backward_cuts(self, cut):
+        self._cut = cut
+
+    @staticmethod
+    def backward_thunks(losses, cuts):
+        def piece(name):
+            def run():
+                o, l = cuts[name]
+                torch.autograd.backward(o, [x.grad for x in l])
+            return run
+        return [lambda: losses.backward(), piece("mid_out"), piece("stem_out")]
+
+    def forward(self, images, targets=None):
+        a = torch.tanh(self.stem(images))
+        if self._cut is not None:
+            a = self._cut("stem_out", [a])[0]
+        b = torch.tanh(self.mid(a))
+        if self._cut is not None:
+            b = self._cut("mid_out", [b])[0]
+        y = self.head(b)
+        return {"a_loss": y.pow(2).sum(), "b_loss": y.sum() * 0.5}, {}
+
+
+def _staged_step_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from monoflex_amd import parallel
+    from monoflex_amd.engine.trainer import GraphedTrainStep
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    m = _ToyStaged()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    xs = torch.arange(24, dtype=torch.float32).view(4, 6) / 10
+    step = GraphedTrainStep(m, opt, xs[2 * rank:2 * rank + 2].clone(), None, use_graphs=False)
+    calls = []
+    exchange = step._exchange
+
+    def spy(k):
+        # at the moment slice k is exchanged, the LATER pieces have not run: their parameters hold no gradient yet
+        calls.append((k, [all(p.grad is None for p in step.seg_params[q]) for q in range(k + 1, step.nseg)]))
+        exchange(k)
+    step._exchange = spy
+    step()
+    names = [n for n, p in m.named_parameters()]
+    order = [next(n for n, q in m.named_parameters() if q is p) for p in step.params]
+    out.put((rank, step.flat.tolist(), step.seg_bounds, calls, order, step.overlap, {n: p.detach().tolist() for n, p in m.named_parameters()}, names))
+    dist.destroy_process_group()
+
+
+def test_segmented_gradient_exchange_over_two_ranks():
+    """engine.trainer.GraphedTrainStep with a model that cuts its backward pass into pieces (the overlap form of the data-parallel
+    step), run eagerly over gloo, world_size 2: the flat buffer is laid out in piece order (head | mid | stem) with contiguous,
+    disjoint slices that cover it; slice k is exchanged right after piece k and BEFORE piece k+1 has produced anything; after the
+    step the buffer holds the mean over the ranks of the gradients an uncut single-process backward computes; ranks stay in lock step."""
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    ps = [ctx.Process(target=_staged_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted((q.get(timeout=120) for _ in ps), key=lambda t: t[0])
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    torch.manual_seed(0)
+    m = _ToyStaged()
+    xs = torch.arange(24, dtype=torch.float32).view(4, 6) / 10
+    (sum(m(xs[0:2])[0].values()) + sum(m(xs[2:4])[0].values())).backward()             # no cuts: one autograd graph
+    grads = {n: p.grad / 2 for n, p in m.named_parameters()}
+    for rank, flat, bounds, calls, order, overlap, params, names in res:
+        assert overlap and order == ["head.weight", "head.bias", "mid.weight", "mid.bias", "stem.weight", "stem.bias"]
+        assert bounds == [(0, 10), (10, 34), (34, 69)] and len(flat) == 69
+        assert [k for k, _ in calls] == [0, 1, 2] and all(all(later) for _, later in calls)
+        want = torch.cat([grads[n].flatten() for n in order])
+        assert torch.allclose(torch.tensor(flat), want, atol=1e-6)
+    assert all(torch.allclose(torch.tensor(res[0][6][n]), torch.tensor(res[1][6][n]), atol=1e-7) for n in res[0][7])
 
 
 def test_bench_respawns_itself_under_torchrun_for_n_ranks(monkeypatch):
