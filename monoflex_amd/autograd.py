@@ -242,6 +242,18 @@ def _pack_weight(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, shift=None
     return ops.PackedConv(e["packed"], None, shift, kh, kw, stride, pad_h, pad_w, 1, ck, rows, e["cp"], e["K_pad"], L.ACT_NONE, e["frag"])
 
 
+def _with_f16_fragments(p, x):
+    """The DCN LDS-patch kernel (dcn_patch.hip; 64 -> 64 layers on large maps, bf16) multiplies with an IEEE fp16 copy of the
+    fragment-major weights.  bf16 -> fp16 is exact and element-wise, and both fragment layouts hold 8 elements per 16 bytes, so the
+    copy is one small cast of the bf16 fragments the step's batched packing already produced (36.9 k elements per layer): the
+    training forward then runs the third-generation kernel on the five full-resolution layers (102 -> 75 us each) instead of the
+    first-generation gather."""
+    if p.w_frag is not None and p.w.dtype == torch.bfloat16 and p.Ck == 64 and p.Cout_pad == 64 \
+            and x.shape[0] * x.shape[1] * x.shape[2] >= 65536:
+        p.w_frag_f16 = p.w_frag.to(torch.float16)
+    return p
+
+
 @_device_guarded
 class Conv2dFn(Function):
     """y = conv2d(x, weight) (+ bias), k in {1,3}, stride in {1,2}, pad = k//2.  Output channels are padded up to a
@@ -630,8 +642,10 @@ class UpsampleAddFn(Function):
         B, H, W, C = x.shape
         dx = torch.empty_like(x)
         dw = torch.empty((4 * f * f, C), dtype=torch.float32, device=x.device)
-        L.check(L.load().mfx_upsample_bwd_nhwc(_ptr(x), _ptr(wt), _ptr(dy), _ptr(dx), _ptr(dw), B, H, W, C, f, _dt(x.dtype), _stream()),
-                "mfx_upsample_bwd_nhwc")
+        nws = L.load().mfx_upsample_bwd_workspace_bytes(B, H, C, f)
+        ws = torch.empty(nws // 4, dtype=torch.float32, device=x.device)
+        L.check(L.load().mfx_upsample_bwd_nhwc(_ptr(x), _ptr(wt), _ptr(dy), _ptr(dx), _ptr(dw), B, H, W, C, f, _dt(x.dtype), _ptr(ws), nws,
+                                               _stream()), "mfx_upsample_bwd_nhwc")
         return dx, dw.t().reshape(ctx.wshape).contiguous(), dy, None
 
 
@@ -656,6 +670,8 @@ class DCNFn(Function):
             shift = _padded_bias(bias, cp)
         p = _pack_weight(weight, x.dtype, 0, Cout, Cin, stride, pad, pad, shift)
         p.dil_w = dil
+        if stride == 1 and pad == 1 and dil == 1:
+            _with_f16_fragments(p, x)
         y = ops.dcn(x, om, p)
         ctx.save_for_backward(x, om, weight)
         ctx.cfg = (stride, pad, dil)
@@ -729,7 +745,7 @@ class DCNModuleFn(Function):
         shift = None
         if bias is not None:
             shift = _padded_bias(bias, cpm)
-        y = ops.dcn(x, om, _pack_weight(weight, x.dtype, 0, Cout, weight.shape[1], 1, 1, 1, shift))
+        y = ops.dcn(x, om, _with_f16_fragments(_pack_weight(weight, x.dtype, 0, Cout, weight.shape[1], 1, 1, 1, shift), x))
         ctx.save_for_backward(x, om, w_off, weight)
         ctx.n_off = n_off
         return y

@@ -839,7 +839,11 @@ __global__ void upsample_bwd_dx_kernel(const T* __restrict__ dy, const float* __
 // layers ran 128 threads per workgroup, 768 waves on the whole chip, each walking a full row: 85-110 us per call.)
 template <typename T>
 __global__ __launch_bounds__(1024) void upsample_bwd_dw_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
-                                                               int B, int H, int W, int C, int f, int rows_per_block) {
+                                                               int B, int H, int W, int C, int f, int rows_per_block, float* __restrict__ part) {
+    // `part` != nullptr: the workgroup's sums go to part[blockIdx.x][tap][c] with plain stores (every element written) and
+    // upsample_dw_sum_kernel adds the workgroups in order -- 384 workgroups x 1024 atomics on the same 64 cache lines serialised in L2
+    // (66 us for a 7 us streaming job) and needed a zero-fill; the partial form is also bit-reproducible.
+    if (part) dw = part + (size_t)blockIdx.x * (size_t)(4 * f * f) * C;
     constexpr int E = ElemTraits<T>::ELEMS;
     extern __shared__ float red[];                                    // [S][items * E] when S > 1
     const int k = 2 * f, p_ = f / 2, Ho = H * f, Wo = W * f, taps = k * k, CG = C / E, items = taps * CG;
@@ -894,15 +898,31 @@ __global__ __launch_bounds__(1024) void upsample_bwd_dw_kernel(const T* __restri
                 float t = 0.f;
                 for (int q = 0; q < S; ++q) t += red[(size_t)q * items * E + i];
                 const int e = i / items, im = i - e * items, cg = im % CG, tap = im / CG;
-                unsafeAtomicAdd(dw + (size_t)tap * C + cg * E + e, t);
+                if (part) dw[(size_t)tap * C + cg * E + e] = t;
+                else unsafeAtomicAdd(dw + (size_t)tap * C + cg * E + e, t);
             }
             __syncthreads();
         } else if (item < items) {
             const int cg = item % CG, tap = item / CG;
 #pragma unroll
-            for (int e = 0; e < E; ++e) unsafeAtomicAdd(dw + (size_t)tap * C + cg * E + e, acc[e]);
+            for (int e = 0; e < E; ++e) {
+                if (part) dw[(size_t)tap * C + cg * E + e] = acc[e];
+                else unsafeAtomicAdd(dw + (size_t)tap * C + cg * E + e, acc[e]);
+            }
         }
     }
+}
+
+__global__ void upsample_dw_sum_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        a0 += part[(size_t)b * n + i]; a1 += part[(size_t)(b + 1) * n + i]; a2 += part[(size_t)(b + 2) * n + i]; a3 += part[(size_t)(b + 3) * n + i];
+    }
+    for (; b < nblk; ++b) a0 += part[(size_t)b * n + i];
+    dw[i] = (a0 + a1) + (a2 + a3);
 }
 
 // zero insertion for the data gradient of a stride-2 conv: up[b, 2*oh, 2*ow, :] = dy[b, oh, ow, :], zeros elsewhere
@@ -1329,25 +1349,43 @@ extern "C" int mfx_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, 
     return MFX_OK;
 }
 
+static int upsample_dw_rows_per_block(int nrows) { return (nrows + 255) / 256; }      // <= 256 workgroups: one resident round, 256 partial blocks to sum
+
+extern "C" size_t mfx_upsample_bwd_workspace_bytes(int B, int H, int C, int f) {
+    const int nrows = B * H, ppb = upsample_dw_rows_per_block(nrows);
+    return (size_t)((nrows + ppb - 1) / ppb) * 4 * f * f * C * sizeof(float);
+}
+
 extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* dy, void* dx, float* dw,
-                                     int B, int H, int W, int C, int f, int dtype, void* stream) {
+                                     int B, int H, int W, int C, int f, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !dy || !dx || !dw) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: null pointer");
     const int E = dtype == MFX_BF16 ? 8 : 4;
     if (C % E != 0 || f < 1) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: bad C or f");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    MFX_HIP_CHECK(mfx::zero_async(dw, (size_t)4 * f * f * C * sizeof(float), st));
     const long total = (long)B * H * W * (C / E);
-    if (total == 0) return MFX_OK;
     const int nrows = B * H;
-    const int ppb = g_opt_det ? nrows : (nrows >= 1024 ? 2 : 1);                   // input rows per block: >= ~512 blocks (deterministic: one workgroup)
+    float* part = nullptr;
+    int ppb;
+    if (workspace && workspace_bytes >= mfx_upsample_bwd_workspace_bytes(B, H, C, f) && total > 0) {
+        part = reinterpret_cast<float*>(workspace);            // partial sums per workgroup, summed in order: no atomics, no zero-fill
+        ppb = upsample_dw_rows_per_block(nrows);
+    } else {
+        MFX_HIP_CHECK(mfx::zero_async(dw, (size_t)4 * f * f * C * sizeof(float), st));
+        ppb = g_opt_det ? nrows : (nrows >= 1024 ? 2 : 1);     // input rows per block: >= ~512 blocks (deterministic: one workgroup)
+    }
+    if (total == 0) return MFX_OK;
     const int dw_items = 4 * f * f * (C / E);
     if (dw_items & (dw_items - 1)) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: taps x channel chunks must be a power of two");
     const size_t dw_smem = dw_items >= 1024 ? 0 : (size_t)1024 * E * sizeof(float);          // [S][items * E], S * items = 1024
     DISPATCH_T(dtype,
         { hipLaunchKernelGGL(upsample_bwd_dx_kernel<float>, TR_GRID(total), dim3(256), 0, st, (const float*)dy, w, (float*)dx, B, H, W, C, f);
-          hipLaunchKernelGGL(upsample_bwd_dw_kernel<float>, dim3(cdivt(nrows, ppb)), dim3(1024), dw_smem, st, (const float*)x, (const float*)dy, dw, B, H, W, C, f, ppb); },
+          hipLaunchKernelGGL(upsample_bwd_dw_kernel<float>, dim3(cdivt(nrows, ppb)), dim3(1024), dw_smem, st, (const float*)x, (const float*)dy, dw, B, H, W, C, f, ppb, part); },
         { hipLaunchKernelGGL(upsample_bwd_dx_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, (const bf16_t*)dy, w, (bf16_t*)dx, B, H, W, C, f);
-          hipLaunchKernelGGL(upsample_bwd_dw_kernel<bf16_t>, dim3(cdivt(nrows, ppb)), dim3(1024), dw_smem, st, (const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, C, f, ppb); });
+          hipLaunchKernelGGL(upsample_bwd_dw_kernel<bf16_t>, dim3(cdivt(nrows, ppb)), dim3(1024), dw_smem, st, (const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, C, f, ppb, part); });
+    if (part) {
+        const int n = 4 * f * f * C;
+        hipLaunchKernelGGL(upsample_dw_sum_kernel, dim3(cdivt(n, 256)), dim3(256), 0, st, part, cdivt(nrows, ppb), n, dw);
+    }
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

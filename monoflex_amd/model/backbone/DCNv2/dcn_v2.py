@@ -69,6 +69,9 @@ class DCNv2(nn.Module):
                            self.dilation, self.deformable_groups)
 
 
+OFFSET_CONV_FP32 = [False]
+
+
 class DCN(DCNv2):
     """DCNv2 + its own 27-channel offset/mask conv (zero-initialised), reference dcn_v2.py:97-128."""
 
@@ -109,7 +112,10 @@ class DCN(DCNv2):
     def forward_nhwc(self, x, bn=None, act=L.ACT_NONE):
         """x (B,H,W,C) NHWC; offset/mask conv (fp32 out, sigmoid on the 9 mask channels fused) then the
         fused gather+MFMA kernel with bias (+BN, +act) folded into its epilogue."""
-        offmask = ops.conv2d(x, self.packed_offset(x.dtype), out_dtype=torch.float32)
+        if OFFSET_CONV_FP32[0] and x.dtype != torch.float32:    # ablation switch (tools/bf16_ablation.py): offsets from fp32 operands
+            offmask = ops.conv2d(x.float(), self.packed_offset(torch.float32), out_dtype=torch.float32)
+        else:
+            offmask = ops.conv2d(x, self.packed_offset(x.dtype), out_dtype=torch.float32)
         return ops.dcn(x, offmask, self.packed_main(x.dtype, bn, act))
 
     def forward_nhwc_train(self, x):

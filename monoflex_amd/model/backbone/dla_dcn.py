@@ -273,6 +273,8 @@ class IDAUp(nn.Module):
 
     def forward(self, layers, startp, endp):                   # dla_dcn.py:419-425, in-place list semantics kept
         packs = self.__dict__.setdefault("_packs", {})
+        if not self.training and PARALLEL_PROJ[0] and endp - startp > 2 and layers[startp].is_cuda:
+            return self._forward_parallel_proj(layers, startp, endp, packs)
         for i in range(startp + 1, endp):
             k = i - startp
             up = getattr(self, "up_" + str(k))
@@ -285,6 +287,37 @@ class IDAUp(nn.Module):
                 continue
             t = ops.upsample_add(t, packs[k], up.stride[0], skip=layers[i - 1])      # up(proj(x_i)) + x_{i-1}
             layers[i] = getattr(self, "node_" + str(k))(t)
+
+
+def _idaup_forward_parallel_proj(self, layers, startp, endp, packs):
+    """Inference: proj_k(layers[startp + k]) reads only its own level's map, so the proj DCN modules of one IDAUp are independent
+    of each other and of the node chain before them.  They are issued on forked streams (inside a hipGraph capture these become
+    parallel branches): the small-map DCN launches (120-480 workgroups on 256 CUs) overlap instead of running one after another."""
+    cur = torch.cuda.current_stream()
+    n = endp - startp - 1
+    side = self.__dict__.setdefault("_side_streams", [])
+    while len(side) < n - 1:
+        side.append(torch.cuda.Stream())
+    proj = [None] * n
+    for k in range(2, n + 1):                                  # proj_2 .. proj_n on side streams
+        st = side[k - 2]
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            proj[k - 1] = getattr(self, "proj_" + str(k))(layers[startp + k])
+    proj[0] = self.proj_1(layers[startp + 1])
+    for k in range(1, n + 1):
+        i = startp + k
+        up = getattr(self, "up_" + str(k))
+        if k not in packs:
+            packs[k] = ops.pack_upsample(up.weight)
+        if k >= 2:
+            cur.wait_stream(side[k - 2])
+        t = ops.upsample_add(proj[k - 1], packs[k], up.stride[0], skip=layers[i - 1])
+        layers[i] = getattr(self, "node_" + str(k))(t)
+
+
+IDAUp._forward_parallel_proj = _idaup_forward_parallel_proj
+PARALLEL_PROJ = [__import__("os").environ.get("MFX_PARALLEL_PROJ", "0") == "1"]     # measured neutral at B = 8 (3.18-3.21 vs 3.20 ms/step): off
 
 
 class DLAUp(nn.Module):

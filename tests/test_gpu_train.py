@@ -553,7 +553,7 @@ FULL_SIZE_TENSORS = (
 def _full_size_rows(gdev, gref):
     rows = []
     for n in FULL_SIZE_TENSORS:
-        if gref[n].grad is None:
+        if gref[n].grad is None or float(gref[n].grad.abs().max()) == 0.0:      # (no truncated object in the batch: that branch has no gradient)
             continue
         a, b = gdev[n].grad.detach().double().cpu().flatten(), gref[n].grad.double().flatten()
         cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp(min=1e-30))
