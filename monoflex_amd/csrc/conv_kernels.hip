@@ -275,7 +275,7 @@ static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 int try_conv_halo(const mfx_conv_desc* d, hipStream_t st, int* stats_ran);   // conv_halo.hip
-extern int g_opt_halo, g_opt_halo_cg, g_opt_dcn_wave, g_opt_dcn_patch, g_opt_dcn_patch_fn8, g_opt_dcn_patch_dbg, g_opt_dcn_wgrad_m;
+extern int g_opt_halo, g_opt_halo_cg, g_opt_dcn_wave, g_opt_dcn_patch, g_opt_dcn_patch_fn8, g_opt_dcn_wgrad_m;
 }
 extern long g_cnt_dcn_bt_fused;
 extern int g_opt_dcn_bt_fuse_min_chunks, g_opt_dcn_bt_fuse_blocks, g_opt_dcn_bt_fuse_wgrad, g_opt_heads_planes, g_opt_heads_persist, g_opt_heads_dbg, g_opt_dcn_bt_cs, g_opt_dcn_bt_cs_wgs, g_opt_dcn_bt_dbg, g_opt_wgrad_tr, g_opt_wgrad_tr_blocks, g_opt_bn_blocks, g_opt_bn_apply_blocks, g_opt_wgrad_patch, g_opt_wgrad_patch_blocks, g_opt_wgrad_patch_waves;
@@ -415,7 +415,6 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "halo_cg") g_opt_halo_cg = value;
     else if (n == "dcn_wave") g_opt_dcn_wave = value;
     else if (n == "dcn_patch") g_opt_dcn_patch = value;
-    else if (n == "dcn_patch_dbg") g_opt_dcn_patch_dbg = value;
     else if (n == "dcn_patch_fn8") g_opt_dcn_patch_fn8 = value;
     else if (n == "topk_strips") g_opt_topk_strips = value;
     else if (n == "dcn_bt_dbg") g_opt_dcn_bt_dbg = value;

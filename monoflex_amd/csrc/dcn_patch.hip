@@ -29,7 +29,7 @@
 
 namespace mfx {
 
-struct DcnPGeom { int B, H, W, C, tiles_x, tiles_y, tiles_n, fsteps, cpt, dbg; };   // cpt = C/32: k-steps per tap
+struct DcnPGeom { int B, H, W, C, tiles_x, tiles_y, tiles_n, fsteps, cpt; };   // cpt = C/32: k-steps per tap
 
 // patch = output tile grown by R+1 pixels on every side (1 for the 3x3 taps, R for the offsets), CS channels per slice
 // PD = padded layout: pixels CS*2 + 16 bytes apart and no XOR swizzle, so the four corners of a sample are ONE base address plus
@@ -54,22 +54,6 @@ __device__ __forceinline__ uint32_t bf2_to_h2(uint32_t d) {
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)));
 }
 __device__ __forceinline__ u32x4 bf8_to_h8(const u32x4& v) { return u32x4{bf2_to_h2(v.x), bf2_to_h2(v.y), bf2_to_h2(v.z), bf2_to_h2(v.w)}; }
-
-// The rare path (a sample whose corners leave the LDS patch): exact gather from global memory.  Out of line on purpose: inlined at
-// its 36 call sites (9 taps x FM fragments, fully unrolled) it made the kernel 64 KB of straight-line code -- the size of the
-// instruction cache two CUs share -- and every wave streamed its instructions from L2 (a 27 us floor with all the work probed away).
-struct DcnFar4 { u32x4 q[4]; };
-__device__ __attribute__((noinline)) DcnFar4 dcn_far_corners(const bf16_t* __restrict__ xb, int H, int W, int C, int hw, int coff) {
-    DcnFar4 r;
-    const int h0 = (hw & 0xffff) - 32, w0 = (hw >> 16) - 32;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int hc = h0 + (q >> 1), wc = w0 + (q & 1);
-        const bool ok = hc >= 0 && hc < H && wc >= 0 && wc < W;
-        r.q[q] = ok ? bf8_to_h8(*reinterpret_cast<const u32x4*>(xb + ((size_t)hc * W + wc) * C + coff)) : u32x4{0u, 0u, 0u, 0u};
-    }
-    return r;
-}
 
 template <int FN, int FM, int R = 3, int CS = 64, bool PD = false>
 __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
@@ -96,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
     const bool own_ok = yo < g.H && xo < g.W;
     float omv[27];
     {
-        const float* r = om + ((g.dbg & 128) ? (size_t)0 : ((size_t)(b * g.H + min(yo, g.H - 1)) * g.W + min(xo, g.W - 1)) * 32);
+        const float* r = om + ((size_t)(b * g.H + min(yo, g.H - 1)) * g.W + min(xo, g.W - 1)) * 32;
 #pragma unroll
         for (int q = 0; q < 24; q += 4) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(r + q);
@@ -113,7 +97,6 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
 
     const u32x4* wfl = wfm + (size_t)(n0 >> 4) * g.fsteps * 64 + lane;
     auto wfetch = [&](int s, u32x4 (&wf)[FN]) {
-        if (g.dbg & 32) s = 0;                                // timing probe: the same fragment every step (L1-resident)
 #pragma unroll
         for (int j = 0; j < FN; ++j) wf[j] = wfl[((size_t)j * g.fsteps + s) * 64];
     };
@@ -166,23 +149,23 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
     };
     // corners of fragment i, 16-byte channel column col of the current 64-channel slice (fp16x8 each)
     auto corners = [&](int i, int col, int c0, u32x4 (&v)[4]) {
-        if (g.dbg & 1) {                                      // timing probe: no corner reads
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = u32x4{(uint32_t)cb[i][0], 0u, 0u, 0u};
-        } else if (inp[i]) {
+        if (inp[i]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 v[q] = PD ? *reinterpret_cast<const u32x4*>(smem + cb[i][0] + (col << 4) + ((q >> 1) * kPW + (q & 1)) * PB)
                           : *reinterpret_cast<const u32x4*>(smem + (cb[i][q] ^ (col << 4)));
-        } else {                                              // rare: sample left the patch -> exact global gather (out of line)
-            const DcnFar4 f = dcn_far_corners(xb, g.H, g.W, g.C, chw[i], c0 + col * 8);
+        } else {                                              // rare: sample left the patch -> exact global gather
+            const int h0 = (chw[i] & 0xffff) - 32, w0 = (chw[i] >> 16) - 32;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = f.q[q];
+            for (int q = 0; q < 4; ++q) {
+                const int hc = h0 + (q >> 1), wc = w0 + (q & 1);
+                const bool ok = hc >= 0 && hc < g.H && wc >= 0 && wc < g.W;
+                v[q] = ok ? bf8_to_h8(*reinterpret_cast<const u32x4*>(xb + ((size_t)hc * g.W + wc) * g.C + c0 + col * 8)) : u32x4{0u, 0u, 0u, 0u};
+            }
         }
     };
     // bilinear blend in packed fp16 (weights carry the modulation mask): 1 v_pk_mul + 3 v_pk_fma per channel pair
     auto blend = [&](int i, const u32x4 (&v)[4]) -> u32x4 {
-        if (g.dbg & 2) return v[0];                           // timing probe: no blend
         const h2_t wa = __builtin_bit_cast(h2_t, cwa[i]), wb_ = __builtin_bit_cast(h2_t, cwb[i]);
         const h2_t w0 = {wa[0], wa[0]}, w1 = {wa[1], wa[1]}, w2 = {wb_[0], wb_[0]}, w3 = {wb_[1], wb_[1]};
         u32x4 o;
@@ -203,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
         const int c0 = sl * CS;
         if (sl) __syncthreads();                              // previous slice fully consumed
         // ---- patch load: pix x 8 columns of 16 bytes (bf16 -> fp16), zero outside the image
-        for (int idx = tid; idx < ((g.dbg & 16) ? 0 : SM::pix * NC); idx += 256) {
+        for (int idx = tid; idx < SM::pix * NC; idx += 256) {
             const int p = idx / NC, col = idx % NC;
             const int ry = p / kPW, rx = p - ry * kPW;
             const int gy = py0 + ry, gx = px0 + rx;
@@ -225,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             const int tap = u / KS, ks = u % KS;
-            if (ks == 0 && (!(g.dbg & 8) || tap == 0)) geom(tap);
+            if (ks == 0) geom(tap);
             if (u + RD - 1 < NS) wfetch(sidx((u + RD - 1) / KS, (u + RD - 1) % KS), wb[(u + RD - 1) % RD]);
             const int col = ks * 4 + kq;
             u32x4 v[2][4];
@@ -235,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
                 if (i + 1 < FM) corners(i + 1, col, c0, v[(i + 1) & 1]);
                 const u32x4 af = blend(i, v[i & 1]);
 #pragma unroll
-                for (int j = 0; j < ((g.dbg & 4) ? 1 : FN); ++j)
+                for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, af), __builtin_bit_cast(h8_t, wb[u % RD][j]),
                                                                        acc[i][j], 0, 0, 0);
             }
@@ -255,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
         sh[j] = ep.shift ? ep.shift[n0 + j * 16 + xl] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < ((g.dbg & 64) ? 1 : FM); ++i) {      // (timing probe 64: one output row per wave)
+    for (int i = 0; i < FM; ++i) {
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -280,7 +263,6 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
     }
 }
 
-int g_opt_dcn_patch_dbg = 0;  // option "dcn_patch_dbg": timing probes of dcn_patch_kernel (wrong results): 1 no corner reads, 2 no blend, 4 one MFMA per fragment, 8 geometry of tap 0 only, 16 no patch load
 int g_opt_dcn_patch_fn8 = 1;
 int g_opt_dcn_patch = 1;     // 0 = off, 1 = automatic, 2 = force (FM 4), 3 = force FM 2, 4 = force FM 1, 5-7 = wide margin FM 4/2/1, 8 = padded layout
 
@@ -289,7 +271,7 @@ static int launch_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
     DcnPGeom g;
     g.B = d->B; g.H = d->H; g.W = d->W; g.C = d->C;
     g.tiles_x = (d->W + 15) / 16; g.tiles_y = (d->H + 4 * FM - 1) / (4 * FM); g.tiles_n = d->Cout_pad / (FN * 16);
-    g.fsteps = d->K_pad / 32; g.cpt = d->C / 32; g.dbg = g_opt_dcn_patch_dbg;
+    g.fsteps = d->K_pad / 32; g.cpt = d->C / 32;
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = nullptr; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = 0;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;

@@ -218,3 +218,4 @@ BOUND = {
              ("stem", "fwd"): 2e-6, ("stem", "grad"): 2e-5, ("heads", "fwd"): 3e-6, ("heads", "grad"): 5e-3},
     # (fp32 gradient rows are differences of nearly cancelling sums -- BN backward, DCN offset gradients -- accumulated with float
     # atomics: between two runs they move from 6e-4 to 2.5e-3 (conv + BN) and 2.5e-3 to 7.7e-3 (DCN); the bounds cover that spread)
+}
