@@ -38,7 +38,7 @@ TRAIN_GFLOP_PER_IMG = 3 * FWD_GFLOP_PER_IMG          # dgrad + wgrad 
 HEADS_GFLOP_PER_IMG = 2 * 41.185    # Appendix A: 9 x (3x3 64->256 + 1x1) per image
 PEAK_BF16_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_F32_TFLOPS = 157.3
-HEADS_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_heads_traffic.json")
+HEADS_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_heads_traffic.json")      # PMC passes of the persistent-launch kernel now in HEAD (tools/pmc_heads.sh r03)
 
 
 def parse():
