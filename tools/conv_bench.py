@@ -12,6 +12,9 @@ from monoflex_amd import lib, ops
 L = lib.load()
 B, H, W, Cin, Cout = map(int, sys.argv[1:6])
 variants = [int(v) for v in sys.argv[6].split(",")]
+for kv in (sys.argv[7].split(",") if len(sys.argv) > 7 else []):      # extra library options k=v,...
+    k, v = kv.split("=")
+    lib.check(L.mfx_set_option(k.encode(), int(v)), "opt")
 x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
 w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
 p = ops.pack_conv(w, torch.bfloat16, None, None, stride=1, pad=1)
