@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--sync-bn", action="store_true", help="train mode, N > 1: synchronised BatchNorm statistics")
     ap.add_argument("--legs", default="all", choices=["all", "none"], help="infer mode: add the `train` and `fp32_parity` legs to the line")
     ap.add_argument("--repeats", type=int, default=None, help="timed regions of exactly --steps steps; the median is reported")
+    ap.add_argument("--leg-timeout", type=int, default=420, help="seconds after which unfinished legs are reported as errors and the line is printed")
     ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--train-warmup", type=int, default=3)
     ap.add_argument("--opts", default="", help="library tuning options k=v,... (mfx_set_option), for experiments")
@@ -446,14 +447,32 @@ def main():
         res = run_infer(args, rank, world, device)
         if args.legs == "all" and args.dtype == "bf16" and not args.no_graph:
             import gc
-            gc.collect()
-            torch.cuda.empty_cache()
-            train = run_train(args, rank, world, device, steps=args.train_steps, warmup=args.train_warmup, leg=True)
-            gc.collect()
-            torch.cuda.empty_cache()
-            fp32 = run_infer(args, rank, world, device, dtype="fp32", leg=True)
+            import threading
+            legs = {}
+
+            def bail():
+                # a leg that hangs (first multi-rank RCCL run of the segmented exchange, a wedged capture) must not take the headline with
+                # it: after --leg-timeout seconds rank 0 prints the line with what is finished and every rank leaves
+                if rank == 0:
+                    out = dict(res, **legs)
+                    out.setdefault("train", {"error": "leg did not finish within %d s" % args.leg_timeout})
+                    out.setdefault("fp32_parity", {"error": "leg did not finish within %d s" % args.leg_timeout})
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            dog = threading.Timer(args.leg_timeout, bail)
+            dog.daemon = True
+            dog.start()
+            for name, fn in (("train", lambda: run_train(args, rank, world, device, steps=args.train_steps, warmup=args.train_warmup, leg=True)),
+                             ("fp32_parity", lambda: run_infer(args, rank, world, device, dtype="fp32", leg=True))):
+                gc.collect()
+                torch.cuda.empty_cache()
+                try:
+                    legs[name] = fn()
+                except Exception as e:                                         # noqa: BLE001  (a failed leg is reported, not fatal)
+                    legs[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            dog.cancel()
             if rank == 0:
-                res["train"], res["fp32_parity"] = train, fp32
+                res.update(legs)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
