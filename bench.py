@@ -14,7 +14,9 @@
 The default run (`python bench.py --gpus N`, what the driver records) carries the whole BASELINE.json metric in ONE line: the
 top level is the forward+decode number (bf16, configs[1]); `"train"` is a short graphed run of the training step (fwd + loss +
 bwd + AdamW, data parallel for N > 1: the metric's "fwd+bwd img/s") with its own roofline object; `"fp32_parity"` is the mode
-that meets the north-star tolerance (<= 1e-3 on logits, identical top-K against the reference's goldens) timed the same way.
+that meets the north-star tolerance (<= 1e-3 on logits, identical top-K against the reference's goldens) timed the same way;
+`"fp16"` is the same measurement with IEEE-half activations (same kernels instantiated for fp16, same MFMA rate; its deviation from
+the reference is 4-8x smaller than bf16's -- the headline stays bf16 because BASELINE.json configs[1] names bf16).
 `--legs none` prints the top level only.  Every timed region is exactly `--steps` steps between barrier + synchronize; it is
 repeated `--repeats` times and the MEDIAN repeat is reported (all repeats are listed in `config.timing`).
 
@@ -48,7 +50,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--mode", default="infer", choices=["infer", "train"])
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"], help="fp16: inference only")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of captured hipGraphs")
     ap.add_argument("--streams", type=int, default=2, help="inference: run the batch as this many sub-batches on forked streams inside the one "
                                                            "captured step (independent sub-batches overlap their under-filled launches and tails; "
@@ -273,7 +275,9 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
         if leg:
             if rank != 0:
                 return None
-            return {"metric": "images/sec at 1280x384, DLA-34+DCNv2 forward+decode (the mode inside the north-star tolerance)",
+            return {"metric": "images/sec at 1280x384, DLA-34+DCNv2 forward+decode (%s)"
+                              % ("the mode inside the north-star tolerance" if dtype == "fp32" else
+                                 "IEEE-half activations: the bf16 mode's kernels and speed, 4-8x closer to the reference"),
                     "value": round(n_img / elapsed, 2), "unit": "images/s", "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                     "steps": args.steps, "dtype": dtype, "batch_per_gpu": B, "launch": mode,
                     "vs_reference": deviation_vs_reference(out, dtype)}
@@ -287,7 +291,7 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
 
     if rank != 0:
         return None
-    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_F32_TFLOPS if dtype == "fp32" else PEAK_BF16_TFLOPS          # (dense fp16 MFMA = the bf16 rate)
     achieved = HEADS_GFLOP_PER_IMG * B / heads_ms                # GFLOP / ms = TFLOP/s
     traffic, traffic_source = heads_traffic(dtype, B)
     res = {
@@ -457,13 +461,15 @@ def main():
                     out = dict(res, **legs)
                     out.setdefault("train", {"error": "leg did not finish within %d s" % args.leg_timeout})
                     out.setdefault("fp32_parity", {"error": "leg did not finish within %d s" % args.leg_timeout})
+                    out.setdefault("fp16", {"error": "leg did not finish within %d s" % args.leg_timeout})
                     print(json.dumps(out), flush=True)
                 os._exit(0)
             dog = threading.Timer(args.leg_timeout, bail)
             dog.daemon = True
             dog.start()
             for name, fn in (("train", lambda: run_train(args, rank, world, device, steps=args.train_steps, warmup=args.train_warmup, leg=True)),
-                             ("fp32_parity", lambda: run_infer(args, rank, world, device, dtype="fp32", leg=True))):
+                             ("fp32_parity", lambda: run_infer(args, rank, world, device, dtype="fp32", leg=True)),
+                             ("fp16", lambda: run_infer(args, rank, world, device, dtype="fp16", leg=True))):
                 gc.collect()
                 torch.cuda.empty_cache()
                 try:

@@ -30,7 +30,7 @@ extern "C" {
 #define MFX_ABI_VERSION 1
 
 /* element types of activations / packed weights */
-enum { MFX_F32 = 0, MFX_BF16 = 1 };
+enum { MFX_F32 = 0, MFX_BF16 = 1, MFX_F16 = 2 /* IEEE half: inference operators only (conv2d, cat-conv, dcn, heads, max-pool, up-sample, stem, layout) */ };
 /* epilogue activations */
 enum { MFX_ACT_NONE = 0, MFX_ACT_RELU = 1, MFX_ACT_LEAKY = 2 /* slope 0.01 */, MFX_ACT_DCN_OFFMASK = 3 /* sigmoid on ch 18..26 */ };
 /* error codes */

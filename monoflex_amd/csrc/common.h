@@ -63,6 +63,37 @@ template <> struct ElemTraits<bf16_t> {
     }
 };
 
+// IEEE fp16 activations (inference perf mode "fp16"): the same MFMA rate as bf16 with three more mantissa bits -- the forward pass stays
+// 8x closer to the fp32 reference (profiles/r03_bf16_ablation.md) -- at fp16's range (65504), which post-BN activations of this network
+// never approach.  Training keeps bf16 (no loss scaling needed there).
+struct half_t { uint16_t v; };
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <> struct ElemTraits<half_t> {
+    static constexpr int ELEMS = 8;
+    static constexpr int DT = 2;
+    __device__ static __forceinline__ float load(const half_t* p) { return (float)__builtin_bit_cast(_Float16, p->v); }
+    __device__ static __forceinline__ void store(half_t* p, float v) { p->v = __builtin_bit_cast(uint16_t, (_Float16)v); }
+    __device__ static __forceinline__ float round(float v) { return (float)(_Float16)v; }
+    __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t d = c[i];                          // (copied out first: bit_cast of a vector-element lvalue is miscompiled by this clang)
+            const f16x2 h = __builtin_bit_cast(f16x2, d);
+            f[2 * i] = (float)h[0]; f[2 * i + 1] = (float)h[1];
+        }
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        u32x4 c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f16x2 h = __builtin_convertvector((f32x2){f[2 * i], f[2 * i + 1]}, f16x2);      // round-to-nearest-even
+            c[i] = __builtin_bit_cast(uint32_t, h);
+        }
+        return c;
+    }
+};
+
 // ---- MFMA step over one 16-byte K-chunk per lane -------------------------------------------
 // A fragment: lane l holds row (l&15), k-group (l>>4): 8 bf16 or 4 f32 consecutive in K.
 // D layout (both dtypes): col = lane&15, row = (lane>>4)*4 + reg.
@@ -70,6 +101,9 @@ template <typename T> __device__ __forceinline__ void mma_chunk(const u32x4& a, 
 template <> __device__ __forceinline__ void mma_chunk<bf16_t>(const u32x4& a, const u32x4& b, f32x4& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                   acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma_chunk<half_t>(const u32x4& a, const u32x4& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 // f32: the lane's 4 consecutive k feed 4 MFMAs (element j of every lane forms one K=4 step);
 // the k order inside the 16-wide block is permuted identically for A and B, so the sum is the same.

@@ -52,6 +52,11 @@ template <> __device__ __forceinline__ f32x2 halo_round2<bf16_t>(float a, float 
     return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
 }
 
+template <> __device__ __forceinline__ f32x2 halo_round2<half_t>(float a, float b) {
+    const f16x2 h = __builtin_convertvector((f32x2){a, b}, f16x2);
+    return f32x2{(float)h[0], (float)h[1]};
+}
+
 template <typename T, typename TO, int WN, int FN, int WK = 1, bool ST = false>
 __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                                       const u32x4* __restrict__ wfm, HaloGeom g, EpiArgs ep) {
@@ -436,7 +441,7 @@ static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st) {
     if (g_opt_halo == 0) return 0;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_h != 1 || d->pad_w != 1 || d->dil_w != 1) return 0;
     if (d->rowmap || d->x_pixstride != d->Ck || d->Ho != d->H || d->Wo != d->W || d->M != d->B * d->H * d->W) return 0;
-    const int elems = d->dtype == MFX_BF16 ? 8 : 4;
+    const int elems = d->dtype == MFX_F32 ? 4 : 8;
     if (d->Ck < 2 * elems || d->K_pad < 9 * d->Ck) return 0;
     const int N = d->Cout_pad;
     const int px_tiles = d->B * cdivh(d->H, kHaloRows) * cdivh(d->W, 16);
@@ -464,6 +469,7 @@ static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st) {
     }
     int rc;
     if (d->dtype == MFX_F32) rc = halo_variant<float, float>(v, d, st);
+    else if (d->dtype == MFX_F16) rc = d->out_dtype == MFX_F16 ? halo_variant<half_t, half_t>(v, d, st) : halo_variant<half_t, float>(v, d, st);
     else if (d->out_dtype == MFX_BF16) rc = halo_variant<bf16_t, bf16_t>(v, d, st);
     else rc = halo_variant<bf16_t, float>(v, d, st);
     return rc == MFX_OK ? 1 : rc;

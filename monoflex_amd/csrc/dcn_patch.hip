@@ -54,9 +54,13 @@ __device__ __forceinline__ uint32_t bf2_to_h2(uint32_t d) {
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)));
 }
 __device__ __forceinline__ u32x4 bf8_to_h8(const u32x4& v) { return u32x4{bf2_to_h2(v.x), bf2_to_h2(v.y), bf2_to_h2(v.z), bf2_to_h2(v.w)}; }
+// 16-byte chunk of the input map as fp16: bf16 maps are converted (exact), fp16 maps are copied
+template <typename TX> __device__ __forceinline__ u32x4 to_h8(const u32x4& v);
+template <> __device__ __forceinline__ u32x4 to_h8<bf16_t>(const u32x4& v) { return bf8_to_h8(v); }
+template <> __device__ __forceinline__ u32x4 to_h8<half_t>(const u32x4& v) { return v; }
 
-template <int FN, int FM, int R = 3, int CS = 64, bool PD = false>
-__global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
+template <int FN, int FM, int R = 3, int CS = 64, bool PD = false, typename TX = bf16_t>
+__global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const TX* __restrict__ x, const float* __restrict__ om,
                                                           const u32x4* __restrict__ wfm, DcnPGeom g, EpiArgs ep) {
     using SM = DcnPSmem<FM, R, CS, PD>;
     constexpr int kPW = SM::PW, PB = SM::PB, NC = SM::NC, KS = CS / 32;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
     const int ty = tile % g.tiles_y, b = tile / g.tiles_y;
     const int ty0 = ty * (4 * FM), tx0 = tx * 16, n0 = tn * (FN * 16);
     const int py0 = ty0 - (R + 1), px0 = tx0 - (R + 1);        // image coordinates of patch pixel (0,0)
-    const bf16_t* xb = x + (size_t)b * g.H * g.W * g.C;
+    const TX* xb = x + (size_t)b * g.H * g.W * g.C;
 
     // ---- sampling geometry is computed ONCE per pixel: lane l owns pixel (tile row wv*FM + (l>>4) % FM, column l&15) and
     // hands the result to the four k-group lanes of that pixel through ds_bpermute
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
             for (int q = 0; q < 4; ++q) {
                 const int hc = h0 + (q >> 1), wc = w0 + (q & 1);
                 const bool ok = hc >= 0 && hc < g.H && wc >= 0 && wc < g.W;
-                v[q] = ok ? bf8_to_h8(*reinterpret_cast<const u32x4*>(xb + ((size_t)hc * g.W + wc) * g.C + c0 + col * 8)) : u32x4{0u, 0u, 0u, 0u};
+                v[q] = ok ? to_h8<TX>(*reinterpret_cast<const u32x4*>(xb + ((size_t)hc * g.W + wc) * g.C + c0 + col * 8)) : u32x4{0u, 0u, 0u, 0u};
             }
         }
     };
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
             const int gy = py0 + ry, gx = px0 + rx;
             u32x4 v = u32x4{0u, 0u, 0u, 0u};
             if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
-                v = bf8_to_h8(*reinterpret_cast<const u32x4*>(xb + ((size_t)gy * g.W + gx) * g.C + c0 + col * 8));
+                v = to_h8<TX>(*reinterpret_cast<const u32x4*>(xb + ((size_t)gy * g.W + gx) * g.C + c0 + col * 8));
             *reinterpret_cast<u32x4*>(smem + (PD ? p * PB + (col << 4) : ((p * PB + ((p & (NC - 1)) << 4)) ^ (col << 4)))) = v;
         }
         // weights of the slice's first two steps while the patch lands
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
     constexpr int LDS_ = FN * 16 + 4;
     constexpr int GPR = FN * 16 / 8;
     float* stage = reinterpret_cast<float*>(smem) + wv * (16 * LDS_);
-    bf16_t* y = reinterpret_cast<bf16_t*>(ep.y);
+    TX* y = reinterpret_cast<TX*>(ep.y);
     float sc[FN], sh[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
                     v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
                 }
                 apply_act_chunk<8>(v, ep.act, gn);
-                *reinterpret_cast<u32x4*>(y + ((size_t)(b * g.H + yg) * g.W + gx) * ep.ldy + gn) = ElemTraits<bf16_t>::pack(v);
+                *reinterpret_cast<u32x4*>(y + ((size_t)(b * g.H + yg) * g.W + gx) * ep.ldy + gn) = ElemTraits<TX>::pack(v);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -266,8 +270,20 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const bf16_t* __restr
 int g_opt_dcn_patch_fn8 = 1;
 int g_opt_dcn_patch = 1;     // 0 = off, 1 = automatic, 2 = force (FM 4), 3 = force FM 2, 4 = force FM 1, 5-7 = wide margin FM 4/2/1, 8 = padded layout
 
+template <int FN, int FM, int R = 3, int CS = 64, bool PD = false, typename TX = bf16_t>
+static int launch_dcn_patch_t(const mfx_dcn_desc* d, hipStream_t st);
+
 template <int FN, int FM, int R = 3, int CS = 64, bool PD = false>
 static int launch_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
+    if constexpr (FN == 4 && FM == 4 && R == 7 && CS == 32 && PD) {      // the production variant exists for fp16 maps too
+        if (d->dtype == MFX_F16) return launch_dcn_patch_t<FN, FM, R, CS, PD, half_t>(d, st);
+    }
+    if (d->dtype != MFX_BF16) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn patch: this variant is built for bf16 maps only");
+    return launch_dcn_patch_t<FN, FM, R, CS, PD, bf16_t>(d, st);
+}
+
+template <int FN, int FM, int R, int CS, bool PD, typename TX>
+static int launch_dcn_patch_t(const mfx_dcn_desc* d, hipStream_t st) {
     DcnPGeom g;
     g.B = d->B; g.H = d->H; g.W = d->W; g.C = d->C;
     g.tiles_x = (d->W + 15) / 16; g.tiles_y = (d->H + 4 * FM - 1) / (4 * FM); g.tiles_n = d->Cout_pad / (FN * 16);
@@ -279,10 +295,10 @@ static int launch_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
     constexpr int smem = DcnPSmem<FM, R, CS, PD>::bytes;
     static bool attr_done = false;
     if (!attr_done) {
-        MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_patch_kernel<FN, FM, R, CS, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_patch_kernel<FN, FM, R, CS, PD, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    hipLaunchKernelGGL((dcn_patch_kernel<FN, FM, R, CS, PD>), dim3(tiles), dim3(256), smem, st, reinterpret_cast<const bf16_t*>(d->x), d->offmask,
+    hipLaunchKernelGGL((dcn_patch_kernel<FN, FM, R, CS, PD, TX>), dim3(tiles), dim3(256), smem, st, reinterpret_cast<const TX*>(d->x), d->offmask,
                        reinterpret_cast<const u32x4*>(d->w_frag_f16), g, ep);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -290,7 +306,8 @@ static int launch_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
 
 // returns 1 if handled, 0 to fall through to the older kernels, < 0 on error
 int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
-    if (g_opt_dcn_patch == 0 || !d->w_frag_f16 || d->dtype != MFX_BF16) return 0;
+    if (g_opt_dcn_patch == 0 || !d->w_frag_f16 || (d->dtype != MFX_BF16 && d->dtype != MFX_F16)) return 0;
+    if (d->dtype == MFX_F16 && g_opt_dcn_patch != 1 && g_opt_dcn_patch != 8) return 0;      // fp16 maps: the production variant only
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dil != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
     if (d->C % 64 != 0 || d->K_pad != 9 * d->C || d->Cout_pad % 64 != 0) return 0;
     const long px = (long)d->B * d->H * d->W;

@@ -233,7 +233,7 @@ template <typename T> static int dcn_wave_variant(int v, const mfx_dcn_desc* d, 
 // returns 1 if handled, 0 to fall back to the first-generation kernel, < 0 on error
 int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st) {
     if (g_opt_dcn_wave == 0 || !d->w_frag) return 0;
-    const int elems = d->dtype == MFX_BF16 ? 8 : 4;
+    const int elems = d->dtype == MFX_F32 ? 4 : 8;
     if (d->C < 4 * elems || d->K_pad != d->kh * d->kw * d->C) return 0;
     const int N = d->Cout_pad;
     if (N % 64 != 0) return 0;
@@ -245,7 +245,8 @@ int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st) {
     if (g_opt_dcn_wave < 2 && (N % 128 != 0 || (d->B * d->Ho * d->Wo / 64) * (N / 128) < 512)) return 0;
     int v = N % 256 == 0 ? 5 : N % 128 == 0 ? 3 : 6;
     if (g_opt_dcn_wave >= 2 && g_opt_dcn_wave - 1 <= 7 && N % bn[g_opt_dcn_wave - 1] == 0) v = g_opt_dcn_wave - 1;
-    const int rc = d->dtype == MFX_F32 ? dcn_wave_variant<float>(v, d, st) : dcn_wave_variant<bf16_t>(v, d, st);
+    const int rc = d->dtype == MFX_F32 ? dcn_wave_variant<float>(v, d, st)
+                 : (d->dtype == MFX_F16 ? dcn_wave_variant<half_t>(v, d, st) : dcn_wave_variant<bf16_t>(v, d, st));
     return rc == MFX_OK ? 1 : rc;
 }
 

@@ -59,6 +59,13 @@ template <> struct TrunkPack<bf16_t> {      // k-block = 32 trunk channels = D f
         return ElemTraits<bf16_t>::pack(v);
     }
 };
+template <> struct TrunkPack<half_t> {
+    static constexpr int KBLK = 2;
+    __device__ static __forceinline__ u32x4 make(const float (&t)[kHeadFN][4], int kb) {
+        float v[8] = {t[2 * kb][0], t[2 * kb][1], t[2 * kb][2], t[2 * kb][3], t[2 * kb + 1][0], t[2 * kb + 1][1], t[2 * kb + 1][2], t[2 * kb + 1][3]};
+        return ElemTraits<half_t>::pack(v);
+    }
+};
 template <> struct TrunkPack<float> {       // k-block = 16 trunk channels = D fragment kb: 4 values per lane
     static constexpr int KBLK = 4;
     __device__ static __forceinline__ u32x4 make(const float (&t)[kHeadFN][4], int kb) {
@@ -326,5 +333,6 @@ extern "C" int mfx_heads_fused(const mfx_heads_desc* d, void* stream) {
     if (d->dtype == MFX_BF16 && g_opt_heads_dbg == 2) return launch_heads<bf16_t, false, 2>(d, st);
     if (d->dtype == MFX_BF16 && g_opt_heads_dbg == 3) return launch_heads<bf16_t, false, 3>(d, st);
     if (d->dtype == MFX_BF16) return g_opt_heads_planes ? launch_heads<bf16_t, true>(d, st) : launch_heads<bf16_t, false>(d, st);
+    if (d->dtype == MFX_F16) return launch_heads<half_t, false>(d, st);
     return mfx_fail(MFX_ERR_ARG, "heads_fused: bad dtype");
 }

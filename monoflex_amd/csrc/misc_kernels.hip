@@ -161,12 +161,13 @@ using namespace mfx;
 
 extern "C" int mfx_maxpool2x2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
     if (!x || !y) return mfx_fail(MFX_ERR_ARG, "maxpool: null pointer");
-    const int E = dtype == MFX_BF16 ? 8 : 4;
+    const int E = dtype == MFX_F32 ? 4 : 8;
     if (C % E != 0 || (H & 1) || (W & 1)) return mfx_fail(MFX_ERR_ARG, "maxpool: C must be a multiple of 16 bytes, H/W even");
     const long total = (long)B * (H / 2) * (W / 2) * (C / E);
     if (total == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MFX_F32) hipLaunchKernelGGL(maxpool2x2_kernel<float>, MFX_GRID(total, 256), dim3(256), 0, st, (const float*)x, (float*)y, B, H, W, C);
+    else if (dtype == MFX_F16) hipLaunchKernelGGL(maxpool2x2_kernel<half_t>, MFX_GRID(total, 256), dim3(256), 0, st, (const half_t*)x, (half_t*)y, B, H, W, C);
     else hipLaunchKernelGGL(maxpool2x2_kernel<bf16_t>, MFX_GRID(total, 256), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -175,12 +176,13 @@ extern "C" int mfx_maxpool2x2_nhwc(const void* x, void* y, int B, int H, int W, 
 extern "C" int mfx_upsample_add_nhwc(const void* x, const float* w, const void* skip, void* y,
                                      int B, int H, int W, int C, int f, int dtype, void* stream) {
     if (!x || !w || !y) return mfx_fail(MFX_ERR_ARG, "upsample: null pointer");
-    const int E = dtype == MFX_BF16 ? 8 : 4;
+    const int E = dtype == MFX_F32 ? 4 : 8;
     if (C % E != 0 || f < 1) return mfx_fail(MFX_ERR_ARG, "upsample: bad C or f");
     const long total = (long)B * H * f * W * f * (C / E);
     if (total == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MFX_F32) hipLaunchKernelGGL(upsample_add_kernel<float>, MFX_GRID(total, 256), dim3(256), 0, st, (const float*)x, w, (const float*)skip, (float*)y, B, H, W, C, f);
+    else if (dtype == MFX_F16) hipLaunchKernelGGL(upsample_add_kernel<half_t>, MFX_GRID(total, 256), dim3(256), 0, st, (const half_t*)x, w, (const half_t*)skip, (half_t*)y, B, H, W, C, f);
     else hipLaunchKernelGGL(upsample_add_kernel<bf16_t>, MFX_GRID(total, 256), dim3(256), 0, st, (const bf16_t*)x, w, (const bf16_t*)skip, (bf16_t*)y, B, H, W, C, f);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -192,6 +194,7 @@ extern "C" int mfx_nchw_to_nhwc(const float* x, void* y, int B, int C, int H, in
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv_i((long)H * W, 32), cdiv_i(ldy, 32), B), block(32, 8);
     if (dtype == MFX_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, block, 0, st, x, (float*)y, C, H * W, ldy);
+    else if (dtype == MFX_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, grid, block, 0, st, x, (half_t*)y, C, H * W, ldy);
     else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, block, 0, st, x, (bf16_t*)y, C, H * W, ldy);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -203,6 +206,7 @@ extern "C" int mfx_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, in
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(cdiv_i((long)H * W, 32), cdiv_i(C, 32), B), block(32, 8);
     if (dtype == MFX_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, st, (const float*)x, y, C, H * W, ldx);
+    else if (dtype == MFX_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, grid, block, 0, st, (const half_t*)x, y, C, H * W, ldx);
     else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, y, C, H * W, ldx);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -215,6 +219,7 @@ extern "C" int mfx_pack_image_nhwc4(const float* x, void* y, int B, int H, int W
     if (total == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MFX_F32) hipLaunchKernelGGL(pack_image_kernel<float>, MFX_GRID(total, 256), dim3(256), 0, st, x, (float*)y, B, H, W, pad_h, pad_w_left, pad_w_right);
+    else if (dtype == MFX_F16) hipLaunchKernelGGL(pack_image_kernel<half_t>, MFX_GRID(total, 256), dim3(256), 0, st, x, (half_t*)y, B, H, W, pad_h, pad_w_left, pad_w_right);
     else hipLaunchKernelGGL(pack_image_kernel<bf16_t>, MFX_GRID(total, 256), dim3(256), 0, st, x, (bf16_t*)y, B, H, W, pad_h, pad_w_left, pad_w_right);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;

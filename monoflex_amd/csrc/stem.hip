@@ -20,9 +20,10 @@ namespace mfx {
 
 constexpr int kStemRows = 8, kStemCols = 64, kStemPW = 72, kStemPH = kStemRows + 6;
 
-__global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restrict__ img, const bf16_t* __restrict__ w, int K_pad,
+template <typename T>                       // bf16_t or half_t (16-bit activations: 4 x T per patch pixel)
+__global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restrict__ img, const T* __restrict__ w, int K_pad,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          bf16_t* __restrict__ y, int B, int H, int W, int act) {
+                                                          T* __restrict__ y, int B, int H, int W, int act) {
     __shared__ __attribute__((aligned(16))) uint2 patch[kStemPH * kStemPW];          // 4 x bf16 per pixel
     __shared__ float stage_all[4][16 * 20];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
             v0 = ib[o]; v1 = ib[o + (size_t)H * W]; v2 = ib[o + 2 * (size_t)H * W];
         }
         const float q[8] = {v0, v1, v2, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const u32x4 pk = ElemTraits<bf16_t>::pack(q);
+        const u32x4 pk = ElemTraits<T>::pack(q);
         patch[i] = uint2{pk.x, pk.y};
     }
     __syncthreads();
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
                 const uint2* p = &patch[(ly + s) * kStemPW + lx + 2 * kq];
                 const uint2 a = p[0], c = p[1];
                 const u32x4 af = u32x4{a.x, a.y, c.x, c.y};
-                mma_chunk<bf16_t>(af, wf[s], acc);
+                mma_chunk<T>(af, wf[s], acc);
             }
             // D: col (lane&15) = channel, row (lane>>4)*4 + q = pixel within the fragment
 #pragma unroll
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
                         const f32x4 t = *reinterpret_cast<const f32x4*>(stage + px * 20 + half * 8 + e);
                         v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
                     }
-                    *reinterpret_cast<u32x4*>(y + (((size_t)b * H + gy) * W + gx) * 16 + half * 8) = ElemTraits<bf16_t>::pack(v);
+                    *reinterpret_cast<u32x4*>(y + (((size_t)b * H + gy) * W + gx) * 16 + half * 8) = ElemTraits<T>::pack(v);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -98,12 +99,16 @@ using namespace mfx;
 extern "C" int mfx_stem_conv7x7_nchw(const float* images, const void* w, const float* scale, const float* shift, void* y,
                                      int B, int H, int W, int Cout, int K_pad, int act, int dtype, void* stream) {
     if (!images || !w || !y) return mfx_fail(MFX_ERR_ARG, "stem_conv7x7: null pointer");
-    if (dtype != MFX_BF16 || Cout != 16 || K_pad < 224 || K_pad % 8 != 0)
-        return mfx_fail(MFX_ERR_UNSUPPORTED, "stem_conv7x7: bf16, 16 output channels, super-tap weights [16][K_pad >= 224] only");
+    if ((dtype != MFX_BF16 && dtype != MFX_F16) || Cout != 16 || K_pad < 224 || K_pad % 8 != 0)
+        return mfx_fail(MFX_ERR_UNSUPPORTED, "stem_conv7x7: bf16 / fp16, 16 output channels, super-tap weights [16][K_pad >= 224] only");
     if (B <= 0 || H <= 0 || W <= 0) return MFX_OK;
     const int tiles = B * ((H + kStemRows - 1) / kStemRows) * ((W + kStemCols - 1) / kStemCols);
-    hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), images,
-                       reinterpret_cast<const bf16_t*>(w), K_pad, scale, shift, reinterpret_cast<bf16_t*>(y), B, H, W, act);
+    if (dtype == MFX_F16)
+        hipLaunchKernelGGL(stem_conv7x7_kernel<half_t>, dim3(tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), images,
+                           reinterpret_cast<const half_t*>(w), K_pad, scale, shift, reinterpret_cast<half_t*>(y), B, H, W, act);
+    else
+        hipLaunchKernelGGL(stem_conv7x7_kernel<bf16_t>, dim3(tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), images,
+                           reinterpret_cast<const bf16_t*>(w), K_pad, scale, shift, reinterpret_cast<bf16_t*>(y), B, H, W, act);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libmonoflex_hip.so")
 
-MFX_F32, MFX_BF16 = 0, 1
+MFX_F32, MFX_BF16, MFX_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_DCN_OFFMASK = 0, 1, 2, 3
 MAX_SEG = 9
 

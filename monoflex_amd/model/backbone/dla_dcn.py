@@ -187,7 +187,7 @@ class DLA(nn.Module):
             scale, shift = ops.fold_bn(self.base_layer[1])
             packs[("stem", dtype)] = ops.pack_stem(self.base_layer[0].weight, dtype, scale, shift)
         B, _, H, W = images.shape
-        if dtype == torch.bfloat16 and packs[("stem", dtype)].Cout == 16:
+        if dtype in (torch.bfloat16, torch.float16) and packs[("stem", dtype)].Cout == 16:
             x = ops.stem_conv(images, packs[("stem", dtype)])                 # reads the NCHW planes directly
         else:
             x = ops.conv2d(ops.pack_image(images, dtype), packs[("stem", dtype)], out_hw=(H, W))

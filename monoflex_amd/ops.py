@@ -53,7 +53,9 @@ def _dt(dtype):
         return L.MFX_F32
     if dtype == torch.bfloat16:
         return L.MFX_BF16
-    raise TypeError("MonoFlex HIP kernels take float32 or bfloat16, got %s" % dtype)
+    if dtype == torch.float16:                                   # inference operators only (MFX_F16)
+        return L.MFX_F16
+    raise TypeError("MonoFlex HIP kernels take float32, bfloat16 or (inference) float16, got %s" % dtype)
 
 
 def _elems(dtype):
@@ -176,7 +178,7 @@ def pack_stem(weight, dtype, scale, shift, act=L.ACT_RELU):
     Cout = weight.shape[0]
     w = weight.detach().float()
     w4 = torch.cat((w, w.new_zeros(Cout, 1, 7, 7)), dim=1)              # (Cout,4,7,7)
-    if dtype == torch.bfloat16:
+    if dtype in (torch.bfloat16, torch.float16):
         w8 = torch.cat((w4, w4.new_zeros(Cout, 4, 7, 1)), dim=3)        # kw 7 -> 8
         # [n][th][j][u][c] with kw = 2j+u
         wp = w8.permute(0, 2, 3, 1).reshape(Cout, 7, 4, 2, 4).reshape(Cout, 7 * 4 * 8)
@@ -288,7 +290,9 @@ def cat_conv1x1(srcs, p: PackedCat):
 
 def add_f16_fragments(p: PackedConv, weight):
     """Attach the fp16 fragment-major weights the DCN LDS-patch kernel multiplies with (bf16 mode, 3x3/s1/p1)."""
-    if p.w_frag is not None and p.w.dtype == torch.bfloat16:
+    if p.w_frag is not None and p.w.dtype == torch.float16:
+        p.w_frag_f16 = p.w_frag                                  # fp16 mode: the fragments already are IEEE fp16
+    elif p.w_frag is not None and p.w.dtype == torch.bfloat16:
         Cout, Cin, kh, kw = weight.shape
         w2 = _pad_rows_cols(weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, kh * kw * Cin), p.Cout_pad, p.K_pad)
         p.w_frag_f16 = fragment_major(w2.to(device=p.w.device, dtype=torch.float16).contiguous(), torch.float16)
@@ -384,10 +388,10 @@ def stem_conv(images, p: PackedConv):
     _need_cuda(images)
     images = images.float().contiguous()
     B, C, H, W = images.shape
-    assert C == 3 and p.w.dtype == torch.bfloat16 and p.Cout == 16
-    y = torch.empty((B, H, W, 16), dtype=torch.bfloat16, device=images.device)
+    assert C == 3 and p.w.dtype in (torch.bfloat16, torch.float16) and p.Cout == 16
+    y = torch.empty((B, H, W, 16), dtype=p.w.dtype, device=images.device)
     L.check(L.load().mfx_stem_conv7x7_nchw(_ptr(images), _ptr(p.w), _ptr(p.scale), _ptr(p.shift), _ptr(y), B, H, W, 16, p.K_pad, p.act,
-                                           L.MFX_BF16, _stream()), "mfx_stem_conv7x7_nchw")
+                                           _dt(p.w.dtype), _stream()), "mfx_stem_conv7x7_nchw")
     return y
 
 
