@@ -249,8 +249,10 @@ class GraphedTrainStep:
                 sl.mul_(1.0 / self.world)
             return
         self.comm.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.comm):
-            self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+        avg = dist.get_backend(self.group) == "nccl"              # RCCL averages in the collective; other backends (gloo on device
+        with torch.cuda.stream(self.comm):                         # tensors: tests) sum, and the buffer is scaled once at the end
+            self._works.append(dist.all_reduce(sl, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._scale_after = not avg
 
     def _finish_exchange(self):
         if self.dist_on and self.comm is not None:
@@ -258,6 +260,8 @@ class GraphedTrainStep:
                 w.wait()                                                  # the compute stream waits for the collective; the host does not
             self._works = []
             torch.cuda.current_stream().wait_stream(self.comm)
+            if getattr(self, "_scale_after", False) and self.world > 1:
+                self.flat.mul_(1.0 / self.world)
 
     def _eager(self):
         if not self.split:

@@ -228,6 +228,51 @@ def test_graphed_train_step_equals_the_eager_step_bitwise(split, dtype, nccl_wor
         assert worst < tol, worst
 
 
+def _two_rank_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from monoflex_amd import lib as L
+    from monoflex_amd.engine.trainer import GraphedTrainStep
+    from monoflex_amd.solver import build_optimizer
+    L.set_deterministic(True)
+    m = _model("bf16")
+    imgs, tg = _batch(m, B=2, seed0=20 + 10 * rank)                 # every rank its own shard
+    opt = build_optimizer(m, _cfg("bf16"), capturable=True)
+    step = GraphedTrainStep(m, opt, imgs, tg, warmup=2)
+    assert step.split and step.overlap and len(step.graphs) == 4 and step.graph_b is not None
+    g_local = None
+    losses = []
+    for it in range(2):
+        losses.append(float(step()))
+    torch.cuda.synchronize()
+    digest = torch.stack([p.detach().double().sum() for p in m.parameters()]).cpu()
+    flat = step.flat.detach().double().cpu()
+    out.put((rank, losses, digest.tolist(), float(flat.abs().sum()), [list(b) for b in step.seg_bounds]))
+    dist.destroy_process_group()
+
+
+def test_segmented_graphed_step_on_two_ranks_sharing_the_gpu():
+    """The data-parallel fast path end to end with world_size 2: two processes on this one GPU (gloo moves the slices; RCCL refuses two
+    ranks on one device), each capturing its four backward graphs + the optimizer graph and exchanging slice k on the comm stream after
+    graph k.  Different shards per rank, so local gradients differ; after two replayed steps the ranks must hold bit-identical
+    parameters (same averaged buffer, same AdamW), finite different losses, and the same slice layout."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted((q.get(timeout=600) for _ in ps), key=lambda t: t[0])
+    [p.join(timeout=120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (_, l0, d0, f0, b0), (_, l1, d1, f1, b1) = res
+    assert all(np.isfinite(l0 + l1)) and l0 != l1                   # different shards
+    assert d0 == d1, [i for i, (a, b) in enumerate(zip(d0, d1)) if a != b][:8]     # parameters in lock step, to the bit
+    assert f0 == f1 and f0 > 0 and b0 == b1 and len(b0) == 4 and b0[0][0] == 0 and all(b0[k][1] == b0[k + 1][0] for k in range(3))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_regression_heads_at_object_centres_equal_the_dense_heads(dtype):
     """csrc/head_sparse.hip: seven regression branches evaluated (and differentiated) at the object centres only, against the
