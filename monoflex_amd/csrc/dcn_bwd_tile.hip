@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_dx_unfix_kernel(const unsigned lo
 
 // weight (Cout,C,9) fp32 -> wT[K][Cout] (k = tap*C + c), compute dtype: the B operand of d(columns) = dy x W
 template <typename T>
-__global__ void bt_pack_weight_t(const float* __restrict__ w, T* __restrict__ wT, int Cout, int C) {
+__global__ void bt_pack_weight_t(const float* __restrict__ w, T* __restrict__ wT, int Cout, int C, int* __restrict__ far_count) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) far_count[threadIdx.x] = 0;       // the far-corner counter of this call (was a separate 8-byte fill launch)
     const long total = (long)9 * C * Cout;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int o = (int)(i % Cout);
@@ -708,9 +709,8 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     const int K = 9 * C;
     {
         const long total = (long)K * Cout;
-        hipLaunchKernelGGL(bt_pack_weight_t<T>, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, weight, wT, Cout, C);
+        hipLaunchKernelGGL(bt_pack_weight_t<T>, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, weight, wT, Cout, C, cnt);
     }
-    MFX_HIP_CHECK(mfx::zero_async(cnt, 8, st));
     // d(columns)[m][k] = sum_o dy[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM on the matrix cores
     mfx_conv_desc cd = {};
     cd.x = dy; cd.w = wT; cd.y = gcol;
