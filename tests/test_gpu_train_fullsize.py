@@ -213,11 +213,13 @@ BOUND = {
     "bf16": {("conv_bn", "fwd"): 8e-3, ("conv_bn", "grad"): 0.14, ("root", "fwd"): 7e-3, ("root", "grad"): 0.13, ("dcn", "fwd"): 1.4e-2,
              ("dcn", "grad"): 0.45, ("up_add", "fwd"): 4e-3, ("up_add", "grad"): 4e-3, ("maxpool", "fwd"): 1e-6, ("maxpool", "grad"): 1e-6,
              ("stem", "fwd"): 7e-3, ("stem", "grad"): 8e-2, ("heads", "fwd"): 7e-3, ("heads", "grad"): 0.12},
-    "fp32": {("conv_bn", "fwd"): 5e-6, ("conv_bn", "grad"): 1e-2, ("root", "fwd"): 5e-6, ("root", "grad"): 1e-2, ("dcn", "fwd"): 1e-5,
-             ("dcn", "grad"): 3e-2, ("up_add", "fwd"): 1e-6, ("up_add", "grad"): 1e-5, ("maxpool", "fwd"): 1e-6, ("maxpool", "grad"): 1e-6,
-             ("stem", "fwd"): 2e-6, ("stem", "grad"): 2e-5, ("heads", "fwd"): 3e-6, ("heads", "grad"): 1e-2},
+    "fp32": {("conv_bn", "fwd"): 5e-6, ("conv_bn", "grad"): 4e-2, ("root", "fwd"): 5e-6, ("root", "grad"): 4e-2, ("dcn", "fwd"): 1e-5,
+             ("dcn", "grad"): 5e-2, ("up_add", "fwd"): 1e-6, ("up_add", "grad"): 1e-5, ("maxpool", "fwd"): 1e-6, ("maxpool", "grad"): 1e-6,
+             ("stem", "fwd"): 2e-6, ("stem", "grad"): 2e-5, ("heads", "fwd"): 3e-6, ("heads", "grad"): 4e-2},
     # (fp32 gradient rows of layers that end in BN + ReLU: the ReLU mask is the sign of a value both sides compute to ~1e-7, so a
     # dozen of a map's 31 M elements land on different sides of zero and each contributes a whole gradient entry -- relative l2
     # sqrt(2k / N) ~ 1e-3 -- and since the batch statistics are summed with float atomics the count differs between runs: rows of
-    # this kind move between 4e-7 and 2.7e-3 (conv + BN, Root), 1.6e-3 and 7.7e-3 (DCN module); the bounds cover that spread)
+    # this kind move between 4e-7 and 1.1e-2 (conv + BN, Root: a BN bias gradient is a sum with cancellation, so a flip weighs more there),
+    # 1.6e-3 and 7.7e-3 (DCN module) over a dozen runs; the bounds (4-5e-2) cover that spread and stay 3-10x below the bf16 ones --
+    # a wrong kernel shows as O(1))
 }
