@@ -3,8 +3,10 @@ oracle/gen_lr_golden.py from /root/reference/solver: build_optimizer + build_sch
 drives them): rising cosine warm-up from BASE_LR / DIV_FACTOR, hand-over to the step decay at the right iteration, bias groups at
 BIAS_LR_FACTOR x, with float and with device-scalar (capturable) learning rates."""
 import json
+import math
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -86,3 +88,57 @@ def test_reference_checkpoint_keeps_this_builds_optimizer_flags():
         assert g["lr"] is lr and float(lr) == pytest.approx(want, rel=1e-6)
         assert g["foreach"] is False and g["capturable"] is False and g["fused"] is None
     assert len(opt.state) == 2 and all("exp_avg" in s for s in opt.state.values())
+
+
+class _ToyDetector(torch.nn.Module):
+    """The training surface of KeypointDetector: model(images, targets) -> (loss_dict, log_loss_dict)."""
+
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(6, 3)
+
+    def forward(self, images, targets=None):
+        y = self.lin(images)
+        return {"a_loss": y.pow(2).mean(), "b_loss": y.abs().mean() * 0.5}, {}
+
+
+class _Target:
+    def to(self, device):
+        return self
+
+
+def test_do_train_loop_on_cpu(tmp_path):
+    """engine.trainer.do_train, eager path (CPU tensors never take the graphed step): the reference's loop order -- forward, summed
+    loss, backward, optimizer step, THEN the schedule set to the finished iteration (warm-up below WARMUP_STEPS, the step decay after
+    it) -- iteration bookkeeping from a resume point, periodic and final checkpoints from rank 0, and a falling loss."""
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.engine import trainer as TR
+    from monoflex_amd.solver import build_optimizer, build_scheduler
+    cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"))
+    cfg.SOLVER.MAX_ITERATION, cfg.SOLVER.LR_WARMUP, cfg.SOLVER.WARMUP_STEPS, cfg.SOLVER.STEPS = 12, True, 4, [8]
+    cfg.SOLVER.SAVE_CHECKPOINT_INTERVAL, cfg.SOLVER.EVAL_INTERVAL, cfg.SOLVER.BASE_LR = 5, 0, 0.05
+    torch.manual_seed(0)
+    m = _ToyDetector()
+    opt = build_optimizer(m, cfg)
+    assert not opt.param_groups[0].get("capturable", False) and isinstance(opt.param_groups[0]["lr"], float)      # CPU: plain AdamW
+    sched, warm = build_scheduler(opt, total_iters_each_epoch=4, optim_cfg=cfg.SOLVER)
+    g = torch.Generator().manual_seed(1)
+    batches = [{"images": torch.randn(4, 6, generator=g), "targets": [_Target()]} for _ in range(20)]
+    saved, lrs = [], []
+
+    class Ck:
+        def save(self, name, **kw):
+            saved.append((name, kw["iteration"]))
+    real_step = opt.step
+    opt.step = lambda *a, **k: (lrs.append(opt.param_groups[0]["lr"]), real_step(*a, **k))[1]
+    args = {"iteration": 2}                                      # resumed after two iterations
+    first = float(sum(m(batches[0]["images"])[0].values()))
+    loss = TR.do_train(cfg, False, m, batches, None, opt, sched, warm, Ck(), "cpu", args)
+    assert args["iteration"] == 12 and len(lrs) == 10 and np.isfinite(loss)
+    assert saved == [("model_checkpoint", 5), ("model_checkpoint", 10), ("model_final", 12)]
+    eta = cfg.SOLVER.BASE_LR / cfg.SOLVER.DIV_FACTOR
+    cosw = lambda t: eta + (cfg.SOLVER.BASE_LR - eta) * (1 - math.cos(math.pi * t / 4)) / 2       # noqa: E731
+    # lr used at iteration it (after the schedule was set to it - 1): warm-up values for it - 1 < 4, then BASE_LR, then the decay
+    want = [cosw(2), cosw(3)] + [cfg.SOLVER.BASE_LR] * 4 + [cfg.SOLVER.BASE_LR * cfg.SOLVER.LR_DECAY] * 3
+    assert lrs[1:] == pytest.approx(want, rel=1e-9), (lrs, want)
+    assert float(sum(m(batches[0]["images"])[0].values())) < first
