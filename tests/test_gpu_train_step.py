@@ -228,6 +228,44 @@ def test_graphed_train_step_equals_the_eager_step_bitwise(split, dtype, nccl_wor
         assert worst < tol, worst
 
 
+def test_c3_c4_per_gpu_shape_segmented_graphed_step(nccl_world1):
+    """BASELINE configs[2] / [3] per-GPU shape -- B = 8 images of 1280x384, bf16 activations, forward + 11 losses + backward + AdamW --
+    in the data-parallel launch form (four backward graphs, per-slice RCCL all-reduce on the comm stream, optimizer graph) on the
+    world_size-1 RCCL group: three replayed steps, finite losses, every live parameter moves, the six dead ones never do, the learning
+    rate written between replays is what the captured AdamW uses."""
+    from monoflex_amd import synthetic as S
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.engine.trainer import GraphedTrainStep, dead_parameter_names, prepare_targets
+    from monoflex_amd.model.detector import KeypointDetector
+    from monoflex_amd.solver import build_optimizer
+    from monoflex_amd.structures.params_3d import make_train_target
+    cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"))
+    cfg.MODEL.PRETRAIN = False
+    cfg.MODEL.COMPUTE_DTYPE = "bf16"
+    m = KeypointDetector(cfg)
+    m.load_state_dict(S.synthetic_state_dict(m.state_dict(), seed=0))
+    m = m.to(DEV).train()
+    m.heads.loss_evaluator.log_as_float = False
+    imgs = S.synthetic_images(8, seed=1000).to(DEV)
+    tg = prepare_targets(m, [make_train_target(S.synthetic_train_target(1000 + i)).to(DEV) for i in range(8)], DEV)
+    opt = build_optimizer(m, cfg, capturable=True)
+    step = GraphedTrainStep(m, opt, imgs, tg, warmup=2, split=True)
+    assert step.overlap and len(step.graphs) == 4 and step.flat.numel() > 20_000_000
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    losses = [float(step()) for _ in range(2)]
+    for g in opt.param_groups:
+        g["lr"].fill_(0.0)                                       # a scheduler writing the device scalar: the next replay must not move anything
+    frozen = {n: p.detach().clone() for n, p in m.named_parameters()}
+    losses.append(float(step()))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)), losses
+    dead = set(dead_parameter_names(m))
+    moved = [n for n, p in m.named_parameters() if not torch.equal(p, before[n])]
+    assert set(moved) == {n for n, _ in m.named_parameters()} - dead, sorted(set(n for n, _ in m.named_parameters()) - dead - set(moved))[:8]
+    # weight decay is multiplied by the learning rate in AdamW: with lr = 0 the third replay is the identity on the parameters
+    assert all(torch.equal(p, frozen[n]) for n, p in m.named_parameters())
+
+
 def _two_rank_worker(rank, world, port, out):
     import torch.distributed as dist
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
