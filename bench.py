@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- images/sec of the MonoFlex hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train] [--batch B] [--dtype bf16|fp32]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train] [--batch B] [--dtype bf16|fp16|fp32]
 
 --mode infer (default; BASELINE configs[1] / C5 with --batch 32): one "step" = DLA-34 + DCNv2 + all heads forward +
     NMS / top-K / 3D decode over one batch of synthetic 1280x384 images already resident in HBM, replayed from one hipGraph.
@@ -16,7 +16,9 @@ top level is the forward+decode number (bf16, configs[1]); `"train"` is a short 
 bwd + AdamW, data parallel for N > 1: the metric's "fwd+bwd img/s") with its own roofline object; `"fp32_parity"` is the mode
 that meets the north-star tolerance (<= 1e-3 on logits, identical top-K against the reference's goldens) timed the same way;
 `"fp16"` is the same measurement with IEEE-half activations (same kernels instantiated for fp16, same MFMA rate; its deviation from
-the reference is 4-8x smaller than bf16's -- the headline stays bf16 because BASELINE.json configs[1] names bf16).
+the reference is 4-8x smaller than bf16's -- the headline stays bf16 because BASELINE.json configs[1] names bf16);
+`"train_fp16"` is the training step with fp16 activations under the dynamic loss scaler (BASELINE configs[3]'s "fp16 MFMA path";
+`config.loss_scale` / `optimizer_steps_applied` say what the scaler did).
 `--legs none` prints the top level only.  Every timed region is exactly `--steps` steps between barrier + synchronize; it is
 repeated `--repeats` times and the MEDIAN repeat is reported (all repeats are listed in `config.timing`).
 
@@ -50,7 +52,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--mode", default="infer", choices=["infer", "train"])
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"], help="fp16: inference only")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"], help="activation dtype (parameters, gradients and accumulators are fp32); fp16 training runs under the dynamic loss scaler")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of captured hipGraphs")
     ap.add_argument("--streams", type=int, default=2, help="inference: run the batch as this many sub-batches on forked streams inside the one "
                                                            "captured step (independent sub-batches overlap their under-filled launches and tails; "
@@ -353,17 +355,18 @@ def cpu_train_baseline(n_steps=1):
             "sample": "%d x (B=1 forward + 11 losses + backward), oracle/monoflex_ref.py, %.1f s" % (n_steps, dt)}
 
 
-def run_train(args, rank, world, device, steps=None, warmup=None, leg=False):
+def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dtype=None):
     import torch
     from monoflex_amd import lib, parallel, synthetic as S
-    from monoflex_amd.engine.trainer import (GraphedTrainStep, convert_sync_batchnorm, prepare_targets, train_step,
+    from monoflex_amd.engine.trainer import (GraphedTrainStep, LossScaler, convert_sync_batchnorm, prepare_targets, train_step,
                                              wrap_data_parallel)
     from monoflex_amd.solver import build_optimizer
     from monoflex_amd.structures.params_3d import make_train_target
     lib.load()
+    dtype = dtype or args.dtype
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
-    model, _, cfg = build_model(args.dtype, device, train=True)
+    model, _, cfg = build_model(dtype, device, train=True)
     model.heads.loss_evaluator.log_as_float = False                  # no host sync inside the step
     if args.sync_bn and world > 1:
         convert_sync_batchnorm(model)
@@ -374,8 +377,11 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False):
     targets = prepare_targets(model, targets, device)
     graphed = not args.no_graph and not (args.sync_bn and world > 1)        # SyncBN collectives sit inside the network
     opt = build_optimizer(model, cfg, capturable=graphed)
+    scaler = LossScaler.for_model(model, device)                       # fp16 activations: dynamic loss scaling (None otherwise)
+    if scaler is not None:
+        scaler.attach(opt)
     if graphed:
-        step = GraphedTrainStep(model, opt, imgs, targets, split=True if args.split else None)
+        step = GraphedTrainStep(model, opt, imgs, targets, split=True if args.split else None, scaler=scaler)
         mode = "hipGraph (fwd+loss+bwd+AdamW)" if not step.split else \
             "%d hipGraphs (fwd+loss+bwd piece 0 | bwd pieces 1..%d), RCCL all-reduce of piece k's slice of the flat fp32 gradient buffer on a " \
             "comm stream while piece k+1 runs | hipGraph AdamW" % (len(step.graphs), len(step.graphs) - 1)
@@ -384,7 +390,7 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False):
         mode = "eager" + (" + torch DDP (bucketed all-reduce overlapped with backward)" if world > 1 else "")
 
         def step():
-            return train_step(net, opt, imgs, targets)[0]
+            return train_step(net, opt, imgs, targets, scaler=scaler)[0]
     for _ in range(warmup):
         loss = step()
     last = [loss]
@@ -394,26 +400,31 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False):
     elapsed, n_img, all_s = timed_repeats(run, steps, 1 if leg else args.repeats, B * steps, device)
     loss_v = float(last[0])
     overlap = bool(getattr(step, "overlap", False))
+    loss_scale_info = {}
+    if scaler is not None:                                             # fp16: the dynamic loss scale after the run and the steps AdamW applied
+        applied = min(int(st["step"]) for st in opt.state.values()) if opt.state else 0
+        total = warmup + steps * len(all_s) + (3 if graphed else 0)    # (+ the eager warm-up steps GraphedTrainStep runs before capturing)
+        loss_scale_info = {"loss_scale": float(scaler.scale), "optimizer_steps_applied": applied, "optimizer_steps_run": total}
 
     # ---- roofline of the dominant training kernel family, timed live on one representative layer
     from tools.train_layer_bench import dominant_kernel_roofline
-    roof = dominant_kernel_roofline(args.dtype, B, device)
+    roof = dominant_kernel_roofline(dtype, B, device)
     if rank != 0:
         return None
     res = {
         "metric": "images/sec at 1280x384, DLA-34+DCNv2 forward+loss+backward+AdamW (training step)",
         "value": round(n_img / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": dtype, "data": "synthetic",
         "config": {"workload": "MonoFlex training step (fwd + 11 losses + bwd + AdamW), batch %d per GPU, 1280x384, %s activations, "
-                               "fp32 parameters/gradients (BASELINE.json configs[2]/[3] per-GPU shape)" % (B, args.dtype),
+                               "fp32 parameters/gradients (BASELINE.json configs[2]/[3] per-GPU shape)" % (B, dtype),
                    "batch_per_gpu": B, "global_batch": B * world, "launch": mode,
                    "parallelism": "dp%d" % world if world > 1 else "single GPU", "sync_bn": bool(args.sync_bn and world > 1),
                    "overlap": overlap,
                    "timing": {"repeats": len(all_s), "reported": "median repeat", "steps_per_repeat": steps,
                               "ms_per_step_each": [round(1e3 * t / steps, 4) for t in all_s]},
                    "model_tflops_per_s": round(TRAIN_GFLOP_PER_IMG * n_img / elapsed / 1e3, 2), "loss_last_step": loss_v,
-                   "h2d_excluded": True},
+                   "h2d_excluded": True, **loss_scale_info},
         "roofline": roof,
     }
     if leg:
@@ -462,6 +473,7 @@ def main():
                     out.setdefault("train", {"error": "leg did not finish within %d s" % args.leg_timeout})
                     out.setdefault("fp32_parity", {"error": "leg did not finish within %d s" % args.leg_timeout})
                     out.setdefault("fp16", {"error": "leg did not finish within %d s" % args.leg_timeout})
+                    out.setdefault("train_fp16", {"error": "leg did not finish within %d s" % args.leg_timeout})
                     print(json.dumps(out), flush=True)
                 os._exit(0)
             dog = threading.Timer(args.leg_timeout, bail)
@@ -469,7 +481,9 @@ def main():
             dog.start()
             for name, fn in (("train", lambda: run_train(args, rank, world, device, steps=args.train_steps, warmup=args.train_warmup, leg=True)),
                              ("fp32_parity", lambda: run_infer(args, rank, world, device, dtype="fp32", leg=True)),
-                             ("fp16", lambda: run_infer(args, rank, world, device, dtype="fp16", leg=True))):
+                             ("fp16", lambda: run_infer(args, rank, world, device, dtype="fp16", leg=True)),
+                             ("train_fp16", lambda: run_train(args, rank, world, device, steps=args.train_steps, warmup=args.train_warmup, leg=True,
+                                                              dtype="fp16"))):
                 gc.collect()
                 torch.cuda.empty_cache()
                 try:

@@ -30,7 +30,8 @@ extern "C" {
 #define MFX_ABI_VERSION 1
 
 /* element types of activations / packed weights */
-enum { MFX_F32 = 0, MFX_BF16 = 1, MFX_F16 = 2 /* IEEE half: inference operators only (conv2d, cat-conv, dcn, heads, max-pool, up-sample, stem, layout) */ };
+enum { MFX_F32 = 0, MFX_BF16 = 1, MFX_F16 = 2 /* IEEE half: every operator that takes bf16 takes it (the fused heads and the LDS-patch DCN forward are inference
+                                            * kernels in both); fp16 TRAINING needs loss scaling on the host side (engine/trainer.py) */ };
 /* epilogue activations */
 enum { MFX_ACT_NONE = 0, MFX_ACT_RELU = 1, MFX_ACT_LEAKY = 2 /* slope 0.01 */, MFX_ACT_DCN_OFFMASK = 3 /* sigmoid on ch 18..26 */ };
 /* error codes */
@@ -243,6 +244,9 @@ int mfx_conv_wgrad_oihw(const void* x, const void* dy, float* dw, int B, int H, 
  * workgroup used (768 by default). */
 int mfx_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, int B, int H, int W, int Hp, int Wp, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* the same for either 16-bit activation type: dtype = MFX_BF16 or MFX_F16 */
+int mfx_stem_wgrad_16(const void* xp, const void* dy, float* dw, int B, int H, int W, int Hp, int Wp, int dtype, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* (workspace: optional fp32 scratch; with it the bf16 kernel writes per-slab partial tiles and sums them in a second pass
  *  instead of accumulating with atomics, which lets it use 4x more workgroups) */
 /* fp32 OIHW parameter -> packed operand [rows_pad][K_pad] of `dtype` (+ optional fragment-major copy, see mfx_conv_desc.w_frag).
@@ -327,7 +331,7 @@ int mfx_dcn_backward_nhwc_bf16(const void* x, const float* offmask, const float*
                                int B, int C, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
                                void* workspace, size_t workspace_bytes, void* stream);
 /* Second-generation DCNv2 backward (dcn_bwd_tile.hip): 3x3 / stride 1 / pad 1 / dilation 1, C and Cout powers of two >= 64,
- * x / dy / dx in `dtype` (MFX_F32 or MFX_BF16).  grad_input is accumulated per tile in LDS and written once in the
+ * x / dy / dx in `dtype` (MFX_F32, MFX_BF16 or MFX_F16).  grad_input is accumulated per tile in LDS and written once in the
  * activation dtype (no global atomics for offsets within 8 pixels of the sampling pixel's tile); `d_raw` is the fp32
  * gradient of the RAW 27(32)-channel offset/mask conv output (B,H,W,32): offsets 0..17, mask LOGITS 18..26 (the sigmoid
  * derivative is applied here), channels 27..31 zero.  `offmask` holds the offsets and the POST-sigmoid mask, as the forward

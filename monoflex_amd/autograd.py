@@ -248,9 +248,11 @@ def _with_f16_fragments(p, x):
     copy is one small cast of the bf16 fragments the step's batched packing already produced (36.9 k elements per layer): the
     training forward then runs the third-generation kernel on the five full-resolution layers (102 -> 75 us each) instead of the
     first-generation gather."""
-    if p.w_frag is not None and p.w.dtype == torch.bfloat16 and p.Ck == 64 and p.Cout_pad == 64 \
-            and x.shape[0] * x.shape[1] * x.shape[2] >= 65536:
-        p.w_frag_f16 = p.w_frag.to(torch.float16)
+    if p.w_frag is not None and p.Ck == 64 and p.Cout_pad == 64 and x.shape[0] * x.shape[1] * x.shape[2] >= 65536:
+        if p.w.dtype == torch.bfloat16:
+            p.w_frag_f16 = p.w_frag.to(torch.float16)
+        elif p.w.dtype == torch.float16:
+            p.w_frag_f16 = p.w_frag                            # fp16 mode: the fragments already are IEEE fp16
     return p
 
 
@@ -444,7 +446,7 @@ class StemConvFn(Function):
         xp = ops.pack_image(images, dtype)
         one = torch.ones(weight.shape[0], device=images.device)
         p = ops.pack_stem(weight, dtype, one, torch.zeros_like(one), act=L.ACT_NONE)
-        if dtype == torch.bfloat16 and weight.shape[0] == 16 and not _STEM_FWD_GENERIC[0]:
+        if dtype in (torch.bfloat16, torch.float16) and weight.shape[0] == 16 and not _STEM_FWD_GENERIC[0]:
             y = ops.stem_conv(images, p)          # the inference stem kernel, raw output (60 vs 170 us at B=8); xp is only kept for the backward
         else:
             y = ops.conv2d(xp, p, out_hw=(H, W))
@@ -459,15 +461,15 @@ class StemConvFn(Function):
         H, W = ctx.hw
         Cout = weight.shape[0]
         dy = _c(dy)
-        if xp.dtype == torch.bfloat16:
-            # bf16: the matrix-core kernel needs 16-byte K chunks -> 8-element super-taps (two 4-channel pixels), kw = 4, dilation 2
+        if xp.dtype in (torch.bfloat16, torch.float16):
+            # 16-bit activations: the matrix-core kernel needs 16-byte K chunks -> 8-element super-taps (two 4-channel pixels), kw = 4, dilation 2
             # (the layout the forward stem uses); dW[o][th*4 + j][u*4 + c] is the gradient of w[o][c][th][2j + u]
             B, Hp, Wp, _ = xp.shape
             dws = torch.empty((dy.shape[-1], 28, 8), dtype=torch.float32, device=xp.device)
             if dy.shape[-1] == 16 and not _STEM_WGRAD_GENERIC[0]:
                 ws = ops._splitk_workspace(xp.device)             # Toeplitz-row kernel: image and dy read once
-                L.check(L.load().mfx_stem_wgrad_bf16(_ptr(xp), _ptr(dy), _ptr(dws), B, H, W, Hp, Wp, _ptr(ws), ws.numel() * 4, _stream()),
-                        "mfx_stem_wgrad_bf16")
+                L.check(L.load().mfx_stem_wgrad_16(_ptr(xp), _ptr(dy), _ptr(dws), B, H, W, Hp, Wp, _dt(xp.dtype), _ptr(ws), ws.numel() * 4, _stream()),
+                        "mfx_stem_wgrad_16")
             else:
                 L.check(L.load().mfx_conv_wgrad_nhwc_dil(_ptr(xp), _ptr(dy), _ptr(dws), B, Hp, Wp, 4, 8, 7, 4, 1, 0, 0, 2, H, W, dy.shape[-1],
                                                          dy.shape[-1], _dt(xp.dtype), _stream()), "mfx_conv_wgrad_nhwc_dil")

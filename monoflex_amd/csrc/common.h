@@ -46,6 +46,7 @@ template <> struct ElemTraits<bf16_t> {
     __device__ static __forceinline__ float load(const bf16_t* p) { return bf2f(p->v); }
     __device__ static __forceinline__ void store(bf16_t* p, float v) { p->v = __builtin_bit_cast(uint16_t, (__bf16)v); }
     __device__ static __forceinline__ float round(float v) { return __uint_as_float((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v) << 16); }
+    __device__ static __forceinline__ uint32_t pack2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2)); }
     __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
         f[0] = __uint_as_float(c.x << 16); f[1] = __uint_as_float(c.x & 0xffff0000u);
         f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
@@ -65,7 +66,7 @@ template <> struct ElemTraits<bf16_t> {
 
 // IEEE fp16 activations (inference perf mode "fp16"): the same MFMA rate as bf16 with three more mantissa bits -- the forward pass stays
 // 8x closer to the fp32 reference (profiles/r03_bf16_ablation.md) -- at fp16's range (65504), which post-BN activations of this network
-// never approach.  Training keeps bf16 (no loss scaling needed there).
+// never approach.  Training in fp16 runs under dynamic loss scaling (engine/trainer.py); bf16 stays the default there.
 struct half_t { uint16_t v; };
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -75,6 +76,7 @@ template <> struct ElemTraits<half_t> {
     __device__ static __forceinline__ float load(const half_t* p) { return (float)__builtin_bit_cast(_Float16, p->v); }
     __device__ static __forceinline__ void store(half_t* p, float v) { p->v = __builtin_bit_cast(uint16_t, (_Float16)v); }
     __device__ static __forceinline__ float round(float v) { return (float)(_Float16)v; }
+    __device__ static __forceinline__ uint32_t pack2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, f16x2)); }
     __device__ static __forceinline__ void unpack(const u32x4& c, float* f) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -449,8 +449,8 @@ extern "C" int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "conv2d: null pointer");
     const int elems = d->dtype == MFX_F32 ? 4 : 8;
     if (d->dtype != MFX_F32 && d->dtype != MFX_BF16 && d->dtype != MFX_F16) return mfx_fail(MFX_ERR_ARG, "conv2d: bad dtype");
-    if (d->dtype == MFX_F16 && (d->stats || (d->out_dtype != MFX_F16 && d->out_dtype != MFX_F32)))
-        return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: fp16 is an inference dtype (fp16 or fp32 output, no statistics epilogue)");
+    if (d->dtype == MFX_F16 && d->out_dtype != MFX_F16 && d->out_dtype != MFX_F32)
+        return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: fp16 input needs fp16 or fp32 output");
     if (!is_pow2(d->Ck) || d->Ck < elems) return mfx_fail(MFX_ERR_ARG, "conv2d: Ck must be a power of two >= one 16-byte chunk");
     if (d->K_pad % (4 * elems) != 0 || d->K_pad < d->kh * d->kw * d->Ck) return mfx_fail(MFX_ERR_ARG, "conv2d: bad K_pad");
     const int oe = d->out_dtype == MFX_F32 ? 4 : 8;

@@ -85,31 +85,26 @@ template <int LPS> __device__ __forceinline__ float bt_group_sum(float v) {
     return v;
 }
 
-template <typename T> __device__ __forceinline__ void bt_load8(const T* p, float (&v)[8]);
+// the primary templates serve both 16-bit activation types (bf16_t, half_t: eight elements per 16-byte chunk); float is specialised
+template <typename T> __device__ __forceinline__ void bt_load8(const T* p, float (&v)[8]) {
+    ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(p), v);
+}
 template <> __device__ __forceinline__ void bt_load8<float>(const float* p, float (&v)[8]) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
     v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
-template <> __device__ __forceinline__ void bt_load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
-    ElemTraits<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(p), v);
+template <typename T> __device__ __forceinline__ void bt_store8(T* p, const float (&v)[8]) {
+    *reinterpret_cast<u32x4*>(p) = ElemTraits<T>::pack(v);
 }
-template <typename T> __device__ __forceinline__ void bt_store8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void bt_store8<float>(float* p, const float (&v)[8]) {
     *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
-template <> __device__ __forceinline__ void bt_store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
-    *reinterpret_cast<u32x4*>(p) = ElemTraits<bf16_t>::pack(v);
-}
 
-template <typename T> __device__ __forceinline__ void bt_store4(T* p, const f32x4& v);
-template <> __device__ __forceinline__ void bt_store4<float>(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
-template <> __device__ __forceinline__ void bt_store4<bf16_t>(bf16_t* p, const f32x4& v) {
-    uint2 o;
-    o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2));
-    o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2));
-    *reinterpret_cast<uint2*>(p) = o;
+template <typename T> __device__ __forceinline__ void bt_store4(T* p, const f32x4& v) {
+    *reinterpret_cast<uint2*>(p) = uint2{ElemTraits<T>::pack2(v[0], v[1]), ElemTraits<T>::pack2(v[2], v[3])};
 }
+template <> __device__ __forceinline__ void bt_store4<float>(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // LPS = lanes per pixel / sample: every lane owns 8 consecutive channels (one 16-byte chunk in bf16), so a channel slice is
 // CS = 8 * LPS channels and a wavefront works on 64 / LPS samples (or target pixels) at once.
@@ -120,12 +115,11 @@ template <> __device__ __forceinline__ void bt_store4<bf16_t>(bf16_t* p, const f
 // adds of this layer).  So the tile is not accumulated by atomics at all: phase 1 BINS every (sample, corner) pair that
 // lands in the tile into a per-pixel list (one integer LDS atomic per pair, 64x fewer than per channel), and phase 3 lets
 // each target pixel's lane group walk its list and accumulate in registers.
-template <typename T> struct Raw8;
-template <> struct Raw8<bf16_t> {
+template <typename T> struct Raw8 {          // 16-bit activations
     u32x4 v;
-    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const u32x4*>(p); }
+    __device__ __forceinline__ void load(const T* p) { v = *reinterpret_cast<const u32x4*>(p); }
     __device__ __forceinline__ void zero() { v = u32x4{0u, 0u, 0u, 0u}; }
-    __device__ __forceinline__ void unpack(float (&f)[8]) const { ElemTraits<bf16_t>::unpack(v, f); }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const { ElemTraits<T>::unpack(v, f); }
 };
 template <> struct Raw8<float> {
     f32x4 a, b;
@@ -136,18 +130,9 @@ template <> struct Raw8<float> {
 
 // List entries.  fp32 maps keep (sample, fp32 weight) pairs: 8 bytes, 47 per pixel in the 48 KB that leave three workgroups
 // per CU.  bf16 maps pack the sample as window coordinates (5 + 5 bits) + tap (4) and the weight's exponent and top ten
-// mantissa bits (18 bits, the weight is non-negative; 2^-11 relative, below the bf16 operands it multiplies) into 4 bytes:
+// mantissa bits (18 bits, the weight is non-negative; 2^-11 relative: below the bf16 operands it multiplies, at the rounding of fp16 ones) into 4 bytes:
 // 94 per pixel, so a list practically never overflows (mean 36 entries, sigma ~6) and the far path is left to far offsets.
-template <typename T> struct BtEntry;
-template <> struct BtEntry<float> {
-    typedef uint2 type;
-    static constexpr int LCAP = 47;
-    static __device__ __forceinline__ uint2 make(int wy, int wx, int tap, float w) { return uint2{((uint32_t)wy << 16) | ((uint32_t)wx << 4) | (uint32_t)tap, __float_as_uint(w)}; }
-    static __device__ __forceinline__ void read(const uint2& e, int& wy, int& wx, int& tap, float& w) {
-        wy = (int)(e.x >> 16); wx = (int)((e.x >> 4) & 0xfff); tap = (int)(e.x & 15); w = __uint_as_float(e.y);
-    }
-};
-template <> struct BtEntry<bf16_t> {
+template <typename T> struct BtEntry {        // 16-bit activations
     typedef uint32_t type;
     static constexpr int LCAP = BT_LCAP_BF16;
     static __device__ __forceinline__ uint32_t make(int wy, int wx, int tap, float w) {
@@ -155,6 +140,14 @@ template <> struct BtEntry<bf16_t> {
     }
     static __device__ __forceinline__ void read(uint32_t e, int& wy, int& wx, int& tap, float& w) {
         wy = (int)(e >> 27); wx = (int)((e >> 22) & 31); tap = (int)((e >> 18) & 15); w = __uint_as_float((e & 0x3ffffu) << 13);
+    }
+};
+template <> struct BtEntry<float> {
+    typedef uint2 type;
+    static constexpr int LCAP = 47;
+    static __device__ __forceinline__ uint2 make(int wy, int wx, int tap, float w) { return uint2{((uint32_t)wy << 16) | ((uint32_t)wx << 4) | (uint32_t)tap, __float_as_uint(w)}; }
+    static __device__ __forceinline__ void read(const uint2& e, int& wy, int& wx, int& tap, float& w) {
+        wy = (int)(e.x >> 16); wx = (int)((e.x >> 4) & 0xfff); tap = (int)(e.x & 15); w = __uint_as_float(e.y);
     }
 };
 
@@ -313,6 +306,13 @@ __device__ __forceinline__ void bt_atomic_add8(bf16_t* p, const float (&v)[8]) {
     for (int k = 0; k < 8; k += 2) {
         const bf16x2 t = __builtin_convertvector((f32x2){v[k], v[k + 1]}, bf16x2);
         __builtin_amdgcn_global_atomic_fadd_v2bf16((s2_t __attribute__((address_space(1)))*)(p + k), __builtin_bit_cast(s2_t, t));
+    }
+}
+__device__ __forceinline__ void bt_atomic_add8(half_t* p, const float (&v)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const f16x2 t = __builtin_convertvector((f32x2){v[k], v[k + 1]}, f16x2);
+        __builtin_amdgcn_global_atomic_fadd_v2f16((f16x2 __attribute__((address_space(1)))*)(p + k), t);
     }
 }
 
@@ -526,8 +526,9 @@ constexpr int SF_PX = 32, SF_TAPS = 3, SF_BT = SF_TAPS * 4;                   //
 constexpr int SF_TILE = SF_PX * 32;                                          // bytes of one 16-channel tile of the chunk
 constexpr int SF_STAGE = (SF_BT + 4) * SF_TILE;                              // columns + dy of one chunk: 16 KB
 
-__global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const bf16_t* __restrict__ x, const float* __restrict__ om,
-                                                                  const bf16_t* __restrict__ gcol, const bf16_t* __restrict__ dy, BtGeom g,
+template <typename T>                                                       // T = bf16_t or half_t
+__global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ om,
+                                                                  const T* __restrict__ gcol, const T* __restrict__ dy, BtGeom g,
                                                                   int chunks_per_block, int nchunks, float* __restrict__ graw,
                                                                   float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) char lds[2 * SF_STAGE];
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const bf16_t*
     // The lane's samples form one stream over (chunk, it = 0..2), software-pipelined as in dcn_bwd_sample_kernel: while sample i
     // is blended, the five gathers of sample i+1 are in flight and the raw offsets of sample i+2 are being fetched -- also across
     // the chunk's barrier and MFMAs.  (Issuing all three samples of a chunk at once cost 194 VGPRs next to the 48 accumulators.)
-    struct Loc { bool ok; int my, px, tap; size_t m; const bf16_t* xb; int mx; };
+    struct Loc { bool ok; int my, px, tap; size_t m; const T* xb; int mx; };
     auto locate = [&](int ch, int it) {
         Loc q;
         q.ok = ch < c_end;
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const bf16_t*
         e.h0 = (int)fminf(fmaxf(hf, -4.f), 32000.f); e.w0 = (int)fminf(fmaxf(wf, -4.f), 32000.f);
         return e;
     };
-    struct Raw5 { Raw8<bf16_t> g, v[4]; };
+    struct Raw5 { Raw8<T> g, v[4]; };
     auto issue = [&](const Loc& q, const Geo& e) {
         Raw5 r;
         if (e.inside) {
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const bf16_t*
                         gm += gc[k] * val; gh += gc[k] * dh; gw += gc[k] * dw;
                     }
                 }
-                *reinterpret_cast<u32x4*>(stage + (tl * 4 + (cl >> 1)) * SF_TILE + l0.px * 32 + (cl & 1) * 16) = ElemTraits<bf16_t>::pack(cv);
+                *reinterpret_cast<u32x4*>(stage + (tl * 4 + (cl >> 1)) * SF_TILE + l0.px * 32 + (cl & 1) * 16) = ElemTraits<T>::pack(cv);
                 gh = bt_group_sum<8>(gh); gw = bt_group_sum<8>(gw); gm = bt_group_sum<8>(gm);
                 if (cl == 0) {
                     float* o = graw + l0.m * 32;
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const bf16_t*
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < SF_TAPS; ++j) mma_chunk<bf16_t>(df[i], cf[j], acc[i][j]);
+                for (int j = 0; j < SF_TAPS; ++j) mma_chunk<T>(df[i], cf[j], acc[i][j]);
         }
         // (two stages: the next chunk writes the other one; the barrier after ITS writes orders this chunk's reads before the
         // writes of the chunk after next)
@@ -695,7 +696,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
                                 float* dweight, float* dbias, int B, int C, int H, int W, int Cout, void* workspace,
                                 size_t workspace_bytes, void* stream) {
     constexpr int es = (int)sizeof(T);
-    constexpr int dt = std::is_same<T, float>::value ? MFX_F32 : MFX_BF16;
+    constexpr int dt = ElemTraits<T>::DT;                    // MFX_F32 / MFX_BF16 / MFX_F16
     const BtLayout L = bt_layout(B, C, H, W, Cout, es);
     if (!workspace || workspace_bytes < L.total) return mfx_fail(MFX_ERR_WORKSPACE, "dcn_backward_v2: workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -731,7 +732,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
         if (C >= 128 && (force == 64 || (force == 0 && wgs128 < g_opt_dcn_bt_cs_wgs))) { g.CS = 64; g.nslices = C / 64; }
     }
     bool fused_wgrad = false;
-    if constexpr (std::is_same<T, bf16_t>::value) {
+    if constexpr (!std::is_same<T, float>::value) {
         const long nchunks = M / SF_PX;
         const size_t slab_bytes = (size_t)64 * 576 * sizeof(float);
         if (g_opt_dcn_bt_fuse_wgrad && C == 64 && Cout == 64 && W % SF_PX == 0 && nchunks >= g_opt_dcn_bt_fuse_min_chunks && L.total - L.wg >= 128 * slab_bytes) {
@@ -740,7 +741,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
             const int cpb = (int)((nchunks + nblk - 1) / nblk);
             nblk = (int)((nchunks + cpb - 1) / cpb);
             float* slabs = reinterpret_cast<float*>(ws + L.wg);
-            hipLaunchKernelGGL(dcn_bwd_sample_wgrad_kernel, dim3((unsigned)nblk, 3), dim3(256), 0, st, x, offmask, (const bf16_t*)gcol, dy, gs, cpb, (int)nchunks,
+            hipLaunchKernelGGL(dcn_bwd_sample_wgrad_kernel<T>, dim3((unsigned)nblk, 3), dim3(256), 0, st, x, offmask, (const T*)gcol, dy, gs, cpb, (int)nchunks,
                                d_raw, slabs);
             MFX_HIP_CHECK(hipGetLastError());
             ++g_cnt_dcn_bt_fused;
@@ -782,7 +783,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
 using namespace mfx;
 
 extern "C" size_t mfx_dcn_backward_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int dtype) {
-    return bt_layout(B, C, H, W, Cout, dtype == MFX_BF16 ? 2 : 4).total;
+    return bt_layout(B, C, H, W, Cout, dtype == MFX_F32 ? 4 : 2).total;
 }
 
 extern "C" int mfx_dcn_backward_v2(const void* x, const float* offmask, const float* weight_oihw, const void* dy, void* dx,
@@ -796,5 +797,7 @@ extern "C" int mfx_dcn_backward_v2(const void* x, const float* offmask, const fl
         return dcn_backward_v2_impl<float>((const float*)x, offmask, weight_oihw, (const float*)dy, (float*)dx, d_raw, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream);
     if (dtype == MFX_BF16)
         return dcn_backward_v2_impl<bf16_t>((const bf16_t*)x, offmask, weight_oihw, (const bf16_t*)dy, (bf16_t*)dx, d_raw, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream);
+    if (dtype == MFX_F16)
+        return dcn_backward_v2_impl<half_t>((const half_t*)x, offmask, weight_oihw, (const half_t*)dy, (half_t*)dx, d_raw, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream);
     return mfx_fail(MFX_ERR_ARG, "dcn_backward_v2: bad dtype");
 }

@@ -176,6 +176,7 @@ extern "C" int mfx_head_sparse_fwd(const mfx_head_sparse_desc* d, void* stream) 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == MFX_F32) hipLaunchKernelGGL(head_sparse_fwd_kernel<float>, dim3(d->N, d->nbranch), dim3(256), 0, st, g, d->rows, d->out);
     else if (d->dtype == MFX_BF16) hipLaunchKernelGGL(head_sparse_fwd_kernel<bf16_t>, dim3(d->N, d->nbranch), dim3(256), 0, st, g, d->rows, d->out);
+    else if (d->dtype == MFX_F16) hipLaunchKernelGGL(head_sparse_fwd_kernel<half_t>, dim3(d->N, d->nbranch), dim3(256), 0, st, g, d->rows, d->out);
     else return mfx_fail(MFX_ERR_ARG, "head_sparse_fwd: bad dtype");
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
@@ -185,12 +186,12 @@ extern "C" int mfx_head_sparse_bwd(const mfx_head_sparse_desc* d, void* stream) 
     HsGeom g;
     int rc = hs_geom(d, g, true); if (rc) return rc;
     if (!d->dout || !d->g || !d->arena || d->arena_bytes == 0) return mfx_fail(MFX_ERR_ARG, "head_sparse_bwd: null pointer");
-    if (d->dtype != MFX_F32 && d->dtype != MFX_BF16) return mfx_fail(MFX_ERR_ARG, "head_sparse_bwd: bad dtype");
+    if (d->dtype != MFX_F32 && d->dtype != MFX_BF16 && d->dtype != MFX_F16) return mfx_fail(MFX_ERR_ARG, "head_sparse_bwd: bad dtype");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     MFX_HIP_CHECK(mfx::zero_async(d->arena, d->arena_bytes, st));        // sums, dW2, db2 of every branch: carved from one arena by the caller
     const long M = (long)d->B * d->H * d->W;
     const float invM = 1.f / (float)M;
-    const int E = d->dtype == MFX_BF16 ? 8 : 4;
+    const int E = d->dtype == MFX_F32 ? 4 : 8;
     const long chunks = M * (HS_C / E);
     const int rpb = g_opt_det ? std::max(1, d->N) : 16, nchunk = (d->N + rpb - 1) / rpb;     // deterministic: one row chunk per branch (single writer)
     const unsigned ablocks = (unsigned)std::min<long>((chunks + 255) / 256, 1024);
@@ -200,7 +201,7 @@ extern "C" int mfx_head_sparse_bwd(const mfx_head_sparse_desc* d, void* stream) 
         hipLaunchKernelGGL(head_sparse_apply_kernel<T>, dim3(ablocks, d->nbranch), dim3(256), 0, st, g, chunks, invM);                            \
         if (d->N > 0) hipLaunchKernelGGL(head_sparse_fix_kernel<T>, dim3(d->N, d->nbranch), dim3(256), 0, st, g, d->rows, (const float*)d->g, invM); \
     } while (0)
-    if (d->dtype == MFX_F32) HS_LAUNCH(float); else HS_LAUNCH(bf16_t);
+    if (d->dtype == MFX_F32) HS_LAUNCH(float); else if (d->dtype == MFX_BF16) HS_LAUNCH(bf16_t); else HS_LAUNCH(half_t);
 #undef HS_LAUNCH
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;

@@ -26,6 +26,11 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
     v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void load4<half_t>(const half_t* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    const f16x2 a = __builtin_bit_cast(f16x2, t.x), b = __builtin_bit_cast(f16x2, t.y);
+    v[0] = (float)a[0]; v[1] = (float)a[1]; v[2] = (float)b[0]; v[3] = (float)b[1];
+}
 
 // ------------------------------------------------------------------------------------------------
 // conv weight gradient: dW[o][tap][c] = sum_m dy[m][o] * x[pixel(m,tap)][c]       (fp32 [Cout][taps][Ck])
@@ -108,8 +113,8 @@ constexpr int kWgRow = 80;                                   // LDS row: 32 pixe
 // the head-trunk weight gradients alone re-read ~20 GB of operand tiles from L2 per step; 128-wide tiles halve that.
 // Global loads run TWO steps ahead of their LDS store (two register sets): one step of MFMAs is far shorter than an L2 round
 // trip and the large tiles leave only a few waves per SIMD to hide it.
-template <int BT>
-__global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, WgradGeom g,
+template <typename T, int BT>                                 // T = bf16_t or half_t: the staging moves 16-bit words, only the MFMA knows the format
+__global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const T* __restrict__ x, const T* __restrict__ dy, WgradGeom g,
                                                               float* __restrict__ dw) {
     constexpr int NCH = BT / 8, FR = BT / 32;                 // 16-byte chunks per tile row; 16-row fragments per wave and operand
     __shared__ __attribute__((aligned(16))) char lds[2][2][BT * kWgRow];      // [buffer][0 = dy^T, 1 = A^T][BT rows]
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const bf16_t* __re
 #pragma unroll
         for (int i = 0; i < FR; ++i)
 #pragma unroll
-            for (int j = 0; j < FR; ++j) mma_chunk<bf16_t>(af[i], bf[j], acc[i][j]);
+            for (int j = 0; j < FR; ++j) mma_chunk<T>(af[i], bf[j], acc[i][j]);
     };
 
     // steps s = 0 .. ns-1; registers R[s & 1] hold the data of step s once loaded (two steps ahead of its LDS store)
@@ -961,7 +966,9 @@ int g_opt_wgrad_ws = 1;        // option "wgrad_ws": 0 = always accumulate the t
 int g_opt_wgrad_ws_blocks = 1200;  // option "wgrad_ws_blocks": target workgroup count when partial tiles go to the workspace (step: 1200 -> 58.0 ms, 2400 -> 58.3, 4800 -> 58.6; atomics: 59.6)
 int g_opt_wgrad_mfma = 1;     // option "wgrad_mfma": 0 = VALU kernel for bf16 too, 1 = 64x64 MFMA tiles, 3 = 128x128 where they fit
 
-#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == MFX_F32) { CALL_F32; } else if ((dtype) == MFX_BF16) { CALL_BF16; } else return mfx_fail(MFX_ERR_ARG, "bad dtype"); } while (0)
+// CALL_16 is written once for both 16-bit activation types: T16 = bf16_t or half_t
+#define DISPATCH_T(dtype, CALL_F32, CALL_16) do { if ((dtype) == MFX_F32) { CALL_F32; } else if ((dtype) == MFX_BF16) { using T16 = bf16_t; CALL_16; } \
+    else if ((dtype) == MFX_F16) { using T16 = half_t; CALL_16; } else return mfx_fail(MFX_ERR_ARG, "bad dtype"); } while (0)
 
 static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int H, int W, int x_pixstride, int Ck,
                            int kh, int kw, int stride, int pad_h, int pad_w, int Ho, int Wo, int Cout, int ldy,
@@ -977,10 +984,11 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
     const size_t dw_bytes = (oihw ? (size_t)Cout_out * Cin_out * kh * kw : (size_t)Cout * g.K) * sizeof(float);
     if (g.M == 0) { MFX_HIP_CHECK(mfx::zero_async(dw, dw_bytes, st)); return MFX_OK; }
     // (x chunks only need 4-byte alignment: the stem reads 8-element super-taps at a pixel stride of 4 elements)
-    if (dtype == MFX_BF16 && g_opt_wgrad_mfma) {
+    const bool is16 = dtype == MFX_BF16 || dtype == MFX_F16;
+    if (is16 && g_opt_wgrad_mfma) {
         int nslab_tr = 0;
-        int rc_tr = try_conv_wgrad_patch(x, dy, g, workspace, workspace_bytes, &nslab_tr, st);
-        if (rc_tr != 1) rc_tr = try_conv_wgrad_tr(x, dy, g, workspace, workspace_bytes, &nslab_tr, st);
+        int rc_tr = try_conv_wgrad_patch(x, dy, g, dtype, workspace, workspace_bytes, &nslab_tr, st);
+        if (rc_tr != 1) rc_tr = try_conv_wgrad_tr(x, dy, g, dtype, workspace, workspace_bytes, &nslab_tr, st);
         if (rc_tr == 1) {
             const long total = (long)Cout * g.K;
             hipLaunchKernelGGL(wgrad_reduce_kernel, WR_GRID(total), dim3(256), 0, st, g.ws, nslab_tr, g.ws_slab, g.ws_ld, g, dw);
@@ -990,7 +998,7 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
         g.ws = nullptr; g.ws_ld = 0; g.ws_slab = 0; g.m_per_block = 2048;
     }
     // (the workspace paths end in wgrad_reduce_kernel, which writes every element of dw; only the atomic paths need zeros)
-    if (dtype == MFX_BF16 && Ck % 8 == 0 && x_pixstride % 2 == 0 && ldy % 8 == 0 && g_opt_wgrad_mfma) {
+    if (is16 && Ck % 8 == 0 && x_pixstride % 2 == 0 && ldy % 8 == 0 && g_opt_wgrad_mfma) {
         const int bt = (Cout >= 128 && g.K >= 128 && g_opt_wgrad_mfma == 3) ? 128 : 64;     // 128-wide tiles measured slower (83 vs 78 ms)
         const int tiles = cdivt(g.K, bt) * cdivt(Cout, bt);
         // pixel slabs.  With a workspace every slab writes its partial tile with plain stores and wgrad_reduce_kernel sums them,
@@ -1009,8 +1017,13 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
         if (ws_ok) { g.ws = reinterpret_cast<float*>(workspace); g.ws_ld = ws_ld; g.ws_slab = ws_slab; }
         else MFX_HIP_CHECK(mfx::zero_async(dw, dw_bytes, st));
         dim3 grid(cdivt(g.K, bt), cdivt(Cout, bt), cdivt(g.M, g.m_per_block));
-        if (bt == 128) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<128>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
-        else hipLaunchKernelGGL(conv_wgrad_mfma_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
+        if (dtype == MFX_BF16) {
+            if (bt == 128) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<bf16_t, 128>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
+            else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<bf16_t, 64>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw);
+        } else {
+            if (bt == 128) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<half_t, 128>), grid, dim3(256), 0, st, (const half_t*)x, (const half_t*)dy, g, dw);
+            else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<half_t, 64>), grid, dim3(256), 0, st, (const half_t*)x, (const half_t*)dy, g, dw);
+        }
         if (ws_ok) {
             const long total = (long)Cout * g.K;
             hipLaunchKernelGGL(wgrad_reduce_kernel, WR_GRID(total), dim3(256), 0, st, g.ws, nslab, ws_slab, ws_ld, g, dw);
@@ -1022,7 +1035,7 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
     if (g_opt_det) g.m_per_block = g.M;                          // one slab: every element of dw receives exactly one add
     dim3 grid(cdivt(g.K, 64), cdivt(Cout, 64), cdivt(g.M, g.m_per_block));
     DISPATCH_T(dtype, hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, g, dw),
-                      hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, g, dw));
+                      hipLaunchKernelGGL(conv_wgrad_kernel<T16>, grid, dim3(256), 0, st, (const T16*)x, (const T16*)dy, g, dw));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1070,14 +1083,14 @@ extern "C" int mfx_conv_wgrad_oihw(const void* x, const void* dy, float* dw, int
 extern "C" int mfx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int kh, int kw, int mode, void* packed, void* frag,
                                     int rows_pad, int K_pad, int ck, int dtype, void* stream) {
     if (!w_oihw || !packed) return mfx_fail(MFX_ERR_ARG, "pack_conv_weight: null pointer");
-    const int E = dtype == MFX_BF16 ? 8 : 4;
+    const int E = dtype == MFX_F32 ? 4 : 8;
     if (mode < 0 || mode > 1 || ck < 1 || K_pad < kh * kw * ck || K_pad % (4 * E) != 0 || rows_pad % 16 != 0 ||
         rows_pad < (mode == 0 ? Cout : Cin) || ck < (mode == 0 ? Cin : Cout))
         return mfx_fail(MFX_ERR_ARG, "pack_conv_weight: bad geometry");
     const long total = (long)rows_pad * K_pad;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_kernel<float>, TR_GRID(total), dim3(256), 0, st, w_oihw, Cout, Cin, kh, kw, mode, (float*)packed, (float*)frag, rows_pad, K_pad, ck),
-                      hipLaunchKernelGGL(pack_conv_weight_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, w_oihw, Cout, Cin, kh, kw, mode, (bf16_t*)packed, (bf16_t*)frag, rows_pad, K_pad, ck));
+                      hipLaunchKernelGGL(pack_conv_weight_kernel<T16>, TR_GRID(total), dim3(256), 0, st, w_oihw, Cout, Cin, kh, kw, mode, (T16*)packed, (T16*)frag, rows_pad, K_pad, ck));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1091,7 +1104,7 @@ extern "C" int mfx_pack_conv_weights_batched(const mfx_pack_desc* descs_dev, con
     if (total_chunks >= (1LL << 31)) return mfx_fail(MFX_ERR_ARG, "pack_conv_weights_batched: too many chunks");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_T(dtype, hipLaunchKernelGGL(pack_conv_weight_batched_kernel<float>, dim3((unsigned)total_chunks), dim3(256), 0, st, descs_dev, prefix_dev, n),
-                      hipLaunchKernelGGL(pack_conv_weight_batched_kernel<bf16_t>, dim3((unsigned)total_chunks), dim3(256), 0, st, descs_dev, prefix_dev, n));
+                      hipLaunchKernelGGL(pack_conv_weight_batched_kernel<T16>, dim3((unsigned)total_chunks), dim3(256), 0, st, descs_dev, prefix_dev, n));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1104,12 +1117,12 @@ extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int 
     MFX_HIP_CHECK(mfx::zero_async(out, (size_t)C * sizeof(float), st));
     if (M == 0) return MFX_OK;
     {
-        const int E = dtype == MFX_BF16 ? 8 : 4;
+        const int E = dtype == MFX_F32 ? 4 : 8;
         if (C % E == 0 && ld % E == 0 && C / E <= 256 && 256 % (C / E) == 0) {
             const int rows2 = bn_rows_per_block(M, C, dtype, 1);
             const size_t smem = (size_t)(256 / (C / E)) * C * sizeof(float);
             DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_chunk_kernel<float>, dim3(cdivt(M, rows2)), dim3(256), smem, st, (const float*)x, M, C, ld, rows2, out),
-                              hipLaunchKernelGGL(colsum_chunk_kernel<bf16_t>, dim3(cdivt(M, rows2)), dim3(256), smem, st, (const bf16_t*)x, M, C, ld, rows2, out));
+                              hipLaunchKernelGGL(colsum_chunk_kernel<T16>, dim3(cdivt(M, rows2)), dim3(256), smem, st, (const T16*)x, M, C, ld, rows2, out));
             MFX_HIP_CHECK(hipGetLastError());
             return MFX_OK;
         }
@@ -1117,7 +1130,7 @@ extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int 
     const int rows = g_opt_det ? (int)M : (M >= (1 << 18) ? 1024 : 128);             // >= ~2 workgroups per CU also on the small head maps
     dim3 grid(cdivt(M, rows), cdivt(C, 64)), block(64, 4);
     DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)x, (int)M, C, ld, rows, out),
-                      hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (int)M, C, ld, rows, out));
+                      hipLaunchKernelGGL(colsum_kernel<T16>, grid, block, 0, st, (const T16*)x, (int)M, C, ld, rows, out));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1131,7 +1144,7 @@ int g_opt_bn_blocks = 768;     // option "bn_blocks": target workgroup count of 
 // `owners`: the number of separate destination copies the launch adds into (workgroup b -> copy b % owners).  Deterministic mode
 // launches at most one workgroup per copy, so every copy has a single writer and its adds happen in program order.
 static int bn_rows_per_block(long M, int C, int dtype, int owners) {
-    const int E = dtype == MFX_BF16 ? 8 : 4, rstep = std::max(1, 256 / (C / E));
+    const int E = dtype == MFX_F32 ? 4 : 8, rstep = std::max(1, 256 / (C / E));
     const int target = g_opt_det ? std::max(1, owners) : (g_opt_bn_blocks > 0 ? g_opt_bn_blocks : 768);
     if (g_opt_det) {
         long rows = (M + target - 1) / target;
@@ -1145,7 +1158,7 @@ static int bn_rows_per_block(long M, int C, int dtype, int owners) {
 }
 
 static int bn_check(int C, int dtype) {
-    const int E = dtype == MFX_BF16 ? 8 : 4;
+    const int E = dtype == MFX_F32 ? 4 : 8;
     if (C % E != 0 || C / E > 256 || (256 % (C / E)) != 0) return mfx_fail(MFX_ERR_ARG, "bn: C must be a power-of-two multiple of one 16-byte chunk (<= 256 chunks)");
     return MFX_OK;
 }
@@ -1161,9 +1174,9 @@ extern "C" int mfx_bn_stats(const void* x, float* sum, float* sumsq, long M, int
     }
     if (M == 0) return MFX_OK;
     const int rows = bn_rows_per_block(M, C, dtype, 1);
-    const size_t smem = (size_t)(256 / (C / (dtype == MFX_BF16 ? 8 : 4))) * 2 * C * sizeof(float);
+    const size_t smem = (size_t)(256 / (C / (dtype == MFX_F32 ? 4 : 8))) * 2 * C * sizeof(float);
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, sum, sumsq, 1),
-                      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, sum, sumsq, 1));
+                      hipLaunchKernelGGL(bn_stats_kernel<T16>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const T16*)x, M, C, rows, sum, sumsq, 1));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1187,9 +1200,9 @@ extern "C" int mfx_bn_act_fwd(const void* x, const float* scale, const float* sh
     int rc = bn_check(C, dtype); if (rc) return rc;
     if (M == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const long chunks = M * (C / (dtype == MFX_BF16 ? 8 : 4));
+    const long chunks = M * (C / (dtype == MFX_F32 ? 4 : 8));
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<float>, TR_GRID(chunks), dim3(256), 0, st, (const float*)x, scale, shift, (const float*)res, (float*)y, chunks, C, act),
-                      hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, TR_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (const bf16_t*)res, (bf16_t*)y, chunks, C, act));
+                      hipLaunchKernelGGL(bn_act_fwd_kernel<T16>, TR_GRID(chunks), dim3(256), 0, st, (const T16*)x, scale, shift, (const T16*)res, (T16*)y, chunks, C, act));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1206,10 +1219,10 @@ extern "C" int mfx_bn_bwd_reduce(const void* x, const void* a, const void* da, c
     }
     if (M == 0) return MFX_OK;
     const int rows = bn_rows_per_block(M, C, dtype, 1);
-    const size_t smem = (size_t)(256 / (C / (dtype == MFX_BF16 ? 8 : 4))) * 2 * C * sizeof(float);
+    const size_t smem = (size_t)(256 / (C / (dtype == MFX_F32 ? 4 : 8))) * 2 * C * sizeof(float);
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sg, sgx, 1),
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, M, C, rows, act, sg, sgx, 1));
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<T16>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const T16*)x, (const T16*)a, (const T16*)da, mean, rstd, M, C, rows, act, sg, sgx, 1));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1222,11 +1235,11 @@ extern "C" int mfx_bn_bwd_apply(const void* x, const void* a, const void* da, co
     if (M == 0) return MFX_OK;
     if (M_total < M) return mfx_fail(MFX_ERR_ARG, "bn_bwd_apply: M_total < M");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const long chunks = M * (C / (dtype == MFX_BF16 ? 8 : 4));
+    const long chunks = M * (C / (dtype == MFX_F32 ? 4 : 8));
     const float invM = 1.f / (float)M_total;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, BN_APPLY_GRID(chunks), dim3(256), (size_t)3 * C * sizeof(float), st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, gamma, sg, sgx, invM, (float*)dx, (float*)dres, chunks, C, act),
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, BN_APPLY_GRID(chunks), dim3(256), (size_t)3 * C * sizeof(float), st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, gamma, sg, sgx, invM, (bf16_t*)dx, (bf16_t*)dres, chunks, C, act));
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<T16>, BN_APPLY_GRID(chunks), dim3(256), (size_t)3 * C * sizeof(float), st, (const T16*)x, (const T16*)a, (const T16*)da, mean, rstd, gamma, sg, sgx, invM, (T16*)dx, (T16*)dres, chunks, C, act));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1250,19 +1263,19 @@ extern "C" int mfx_bn_train_fwd(const void* x, const void* res, void* y, const f
     if (2 * C > BN_SCRATCH_COLS) return mfx_fail(MFX_ERR_ARG, "bn_train_fwd: C > 512");
     if (M <= 0) return mfx_fail(MFX_ERR_ARG, "bn_train_fwd: empty batch");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int E = dtype == MFX_BF16 ? 8 : 4, ncopy = bn_ncopy(C);
+    const int E = dtype == MFX_F32 ? 4 : 8, ncopy = bn_ncopy(C);
     const int rows = bn_rows_per_block(M, C, dtype, ncopy);
     const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
     if (!stats_done)
         DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, scratch, scratch + C, ncopy),
-                          hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, scratch, scratch + C, ncopy));
+                          hipLaunchKernelGGL(bn_stats_kernel<T16>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const T16*)x, M, C, rows, scratch, scratch + C, ncopy));
     MFX_HIP_CHECK(hipGetLastError());
     const long chunks = M * (C / E);
     const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
     unsigned* counter = reinterpret_cast<unsigned*>(scratch + 2 * BN_SCRATCH_COLS);
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_act_fwd_fused_kernel<float>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const float*)x, (const float*)res, (float*)y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, (float)(1.0 / (double)M), unbias, scratch, counter, ncopy, mean, rstd, chunks, C, act),
-        hipLaunchKernelGGL(bn_act_fwd_fused_kernel<bf16_t>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, (float)(1.0 / (double)M), unbias, scratch, counter, ncopy, mean, rstd, chunks, C, act));
+        hipLaunchKernelGGL(bn_act_fwd_fused_kernel<T16>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const T16*)x, (const T16*)res, (T16*)y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, (float)(1.0 / (double)M), unbias, scratch, counter, ncopy, mean, rstd, chunks, C, act));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1296,12 +1309,12 @@ extern "C" int mfx_bn_train_stats(const void* x, const float* gamma, const float
     int rc = bn_check(C, dtype); if (rc) return rc;
     if (2 * C > BN_SCRATCH_COLS || M <= 0) return mfx_fail(MFX_ERR_ARG, "bn_train_stats: C > 512 or empty batch");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int E = dtype == MFX_BF16 ? 8 : 4, ncopy = bn_ncopy(C);
+    const int E = dtype == MFX_F32 ? 4 : 8, ncopy = bn_ncopy(C);
     const int rows = bn_rows_per_block(M, C, dtype, ncopy);
     const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
     if (!stats_done)
         DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, scratch, scratch + C, ncopy),
-                          hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, M, C, rows, scratch, scratch + C, ncopy));
+                          hipLaunchKernelGGL(bn_stats_kernel<T16>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const T16*)x, M, C, rows, scratch, scratch + C, ncopy));
     const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(256), 0, st, scratch, ncopy, gamma, beta, running_mean, running_var, num_batches_tracked,
                        momentum, eps, (float)(1.0 / (double)M), unbias, mean, rstd, C);
@@ -1319,19 +1332,19 @@ extern "C" int mfx_bn_train_bwd(const void* x, const void* a, const void* da, co
     if (2 * C > BN_SCRATCH_COLS) return mfx_fail(MFX_ERR_ARG, "bn_train_bwd: C > 512");
     if (M <= 0) return mfx_fail(MFX_ERR_ARG, "bn_train_bwd: empty batch");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int E = dtype == MFX_BF16 ? 8 : 4, ncopy = bn_ncopy(C);
+    const int E = dtype == MFX_F32 ? 4 : 8, ncopy = bn_ncopy(C);
     const int rows = bn_rows_per_block(M, C, dtype, ncopy);
     const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
     float* sums = scratch + BN_SCRATCH_COLS;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sums, sums + C, ncopy, gamma, beta),
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, M, C, rows, act, sums, sums + C, ncopy, gamma, beta));
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<T16>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const T16*)x, (const T16*)a, (const T16*)da, mean, rstd, M, C, rows, act, sums, sums + C, ncopy, gamma, beta));
     MFX_HIP_CHECK(hipGetLastError());
     const long chunks = M * (C / E);
     unsigned* counter = reinterpret_cast<unsigned*>(scratch + 2 * BN_SCRATCH_COLS) + BN_TICKET_WORDS;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<float>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, gamma, sums, counter, ncopy, 1.f / (float)M, (float*)dx, (float*)dres, dgamma, dbeta, chunks, C, act, beta),
-        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<bf16_t>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)a, (const bf16_t*)da, mean, rstd, gamma, sums, counter, ncopy, 1.f / (float)M, (bf16_t*)dx, (bf16_t*)dres, dgamma, dbeta, chunks, C, act, beta));
+        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<T16>, BN_FUSED_GRID(chunks), dim3(256), 0, st, (const T16*)x, (const T16*)a, (const T16*)da, mean, rstd, gamma, sums, counter, ncopy, 1.f / (float)M, (T16*)dx, (T16*)dres, dgamma, dbeta, chunks, C, act, beta));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1345,13 +1358,13 @@ extern "C" int mfx_bn_act_bwd(const void* x, const void* a, const void* da, cons
 
 extern "C" int mfx_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
     if (!x || !dy || !dx) return mfx_fail(MFX_ERR_ARG, "maxpool_bwd: null pointer");
-    const int E = dtype == MFX_BF16 ? 8 : 4;
+    const int E = dtype == MFX_F32 ? 4 : 8;
     if (C % E != 0 || (H & 1) || (W & 1)) return mfx_fail(MFX_ERR_ARG, "maxpool_bwd: C must be a multiple of 16 bytes, H/W even");
     const long total = (long)B * (H / 2) * (W / 2) * (C / E);
     if (total == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<float>, TR_GRID(total), dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, B, H, W, C),
-                      hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C));
+                      hipLaunchKernelGGL(maxpool_bwd_kernel<T16>, TR_GRID(total), dim3(256), 0, st, (const T16*)x, (const T16*)dy, (T16*)dx, B, H, W, C));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
@@ -1366,7 +1379,7 @@ extern "C" size_t mfx_upsample_bwd_workspace_bytes(int B, int H, int C, int f) {
 extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* dy, void* dx, float* dw,
                                      int B, int H, int W, int C, int f, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !dy || !dx || !dw) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: null pointer");
-    const int E = dtype == MFX_BF16 ? 8 : 4;
+    const int E = dtype == MFX_F32 ? 4 : 8;
     if (C % E != 0 || f < 1) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: bad C or f");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long total = (long)B * H * W * (C / E);
@@ -1387,8 +1400,8 @@ extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* 
     DISPATCH_T(dtype,
         { hipLaunchKernelGGL(upsample_bwd_dx_kernel<float>, TR_GRID(total), dim3(256), 0, st, (const float*)dy, w, (float*)dx, B, H, W, C, f);
           hipLaunchKernelGGL(upsample_bwd_dw_kernel<float>, dim3(cdivt(nrows, ppb)), dim3(1024), dw_smem, st, (const float*)x, (const float*)dy, dw, B, H, W, C, f, ppb, part); },
-        { hipLaunchKernelGGL(upsample_bwd_dx_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, (const bf16_t*)dy, w, (bf16_t*)dx, B, H, W, C, f);
-          hipLaunchKernelGGL(upsample_bwd_dw_kernel<bf16_t>, dim3(cdivt(nrows, ppb)), dim3(1024), dw_smem, st, (const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, C, f, ppb, part); });
+        { hipLaunchKernelGGL(upsample_bwd_dx_kernel<T16>, TR_GRID(total), dim3(256), 0, st, (const T16*)dy, w, (T16*)dx, B, H, W, C, f);
+          hipLaunchKernelGGL(upsample_bwd_dw_kernel<T16>, dim3(cdivt(nrows, ppb)), dim3(1024), dw_smem, st, (const T16*)x, (const T16*)dy, dw, B, H, W, C, f, ppb, part); });
     if (part) {
         const int n = 4 * f * f * C;
         hipLaunchKernelGGL(upsample_dw_sum_kernel, dim3(cdivt(n, 16)), dim3(256), 0, st, part, cdivt(nrows, ppb), n, dw);
@@ -1399,13 +1412,13 @@ extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* 
 
 extern "C" int mfx_zero_insert2_nhwc(const void* dy, void* up, int B, int Ho, int Wo, int C, int H, int W, int dtype, void* stream) {
     if (!dy || !up) return mfx_fail(MFX_ERR_ARG, "zero_insert2: null pointer");
-    const int E = dtype == MFX_BF16 ? 8 : 4;
+    const int E = dtype == MFX_F32 ? 4 : 8;
     if (C % E != 0) return mfx_fail(MFX_ERR_ARG, "zero_insert2: C must be a multiple of 16 bytes");
     const long total = (long)B * H * W * (C / E);
     if (total == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     DISPATCH_T(dtype, hipLaunchKernelGGL(zero_insert2_kernel<float>, TR_GRID(total), dim3(256), 0, st, (const float*)dy, (float*)up, B, Ho, Wo, C, H, W),
-                      hipLaunchKernelGGL(zero_insert2_kernel<bf16_t>, TR_GRID(total), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)up, B, Ho, Wo, C, H, W));
+                      hipLaunchKernelGGL(zero_insert2_kernel<T16>, TR_GRID(total), dim3(256), 0, st, (const T16*)dy, (T16*)up, B, Ho, Wo, C, H, W));
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }

@@ -12,7 +12,7 @@ struct WgradGeom { int B, H, W, Ho, Wo, x_pixstride, Ck, kh, kw, stride, pad_h, 
 
 }  // namespace mfx
 
-// wgrad_tr.hip: returns 1 if it launched (partial tiles in g.ws, *nslab slabs: run wgrad_reduce_kernel), 0 to fall through
-int try_conv_wgrad_tr(const void* x, const void* dy, mfx::WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab, hipStream_t st);
+// wgrad_tr.hip (dtype = MFX_BF16 or MFX_F16): returns 1 if it launched (partial tiles in g.ws, *nslab slabs: run wgrad_reduce_kernel), 0 to fall through
+int try_conv_wgrad_tr(const void* x, const void* dy, mfx::WgradGeom& g, int dtype, void* workspace, size_t workspace_bytes, int* nslab, hipStream_t st);
 // wgrad_tr.hip, 3x3 / s1 / p1 form with the input patch in LDS: same contract
-int try_conv_wgrad_patch(const void* x, const void* dy, mfx::WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab, hipStream_t st);
+int try_conv_wgrad_patch(const void* x, const void* dy, mfx::WgradGeom& g, int dtype, void* workspace, size_t workspace_bytes, int* nslab, hipStream_t st);

@@ -52,8 +52,8 @@ __device__ __forceinline__ void tr_read4(uint32_t alo, uint32_t ahi, u32x4 (&f)[
     f[3] = u32x4{(uint32_t)l3, (uint32_t)(l3 >> 32), (uint32_t)h3, (uint32_t)(h3 >> 32)};
 }
 
-template <int WO>
-__global__ __launch_bounds__(WO * 192) void conv_wgrad_tr_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, WgradGeom g) {
+template <typename T, int WO>                                 // T = bf16_t or half_t (the staging and the transposed reads move 16-bit words)
+__global__ __launch_bounds__(WO * 192) void conv_wgrad_tr_kernel(const T* __restrict__ x, const T* __restrict__ dy, WgradGeom g) {
     constexpr int NT = WO * 192, BO = WO * 64, BK = TR_BK;
     constexpr int OB = BO / 16, KB = BK / 16;                 // 16-channel sub-tiles per operand
     constexpr int SUB = TR_STEP * 32 + 32;                    // bytes per sub-tile: 32 rows x 32 B, + 32 so that the sub-tiles of one
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(WO * 192) void conv_wgrad_tr_kernel(const bf16_t* _
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mma_chunk<bf16_t>(af[i], bf[j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) mma_chunk<T>(af[i], bf[j], acc[i][j]);
     };
 
     // steps s = 0 .. ns-1; register set R[s & 1] holds the data of step s.  Global loads run TWO steps ahead of their LDS
@@ -196,7 +196,12 @@ int g_opt_wgrad_tr = 1;          // option "wgrad_tr": 0 = first-generation kern
 int g_opt_wgrad_tr_blocks = 512;   // option "wgrad_tr_blocks": target workgroup count (tiles x pixel slabs)
 
 // returns 1 if handled (partial tiles are in g.ws: the caller runs wgrad_reduce_kernel), 0 to fall through
-int try_conv_wgrad_tr(const void* x, const void* dy, WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st) {
+template <typename T> static int conv_wgrad_tr_t(const void* x, const void* dy, WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st);
+int try_conv_wgrad_tr(const void* x, const void* dy, WgradGeom& g, int dtype, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st) {
+    if (dtype == MFX_F16) return conv_wgrad_tr_t<half_t>(x, dy, g, workspace, workspace_bytes, nslab_out, st);
+    return conv_wgrad_tr_t<bf16_t>(x, dy, g, workspace, workspace_bytes, nslab_out, st);
+}
+template <typename T> static int conv_wgrad_tr_t(const void* x, const void* dy, WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st) {
     if (!g_opt_wgrad_tr || !workspace) return 0;
     // Cout = 64: the 64 x 192 workgroup tile (49 FLOP per L1 byte) measured slower than the first-generation kernel
     // (188 vs 137 us on 64->64 @ 96x320, B=8), so those layers fall through unless option wgrad_tr = 2 forces it
@@ -215,10 +220,10 @@ int try_conv_wgrad_tr(const void* x, const void* dy, WgradGeom& g, void* workspa
     const dim3 grid(g.K / TR_BK, g.Cout / bo, nslab);
     if (wo == 2) {
         constexpr int smem = 2 * ((128 / 16) + (TR_BK / 16)) * (TR_STEP * 32 + 32);
-        hipLaunchKernelGGL(conv_wgrad_tr_kernel<2>, grid, dim3(384), smem, st, (const bf16_t*)x, (const bf16_t*)dy, g);
+        hipLaunchKernelGGL((conv_wgrad_tr_kernel<T, 2>), grid, dim3(384), smem, st, (const T*)x, (const T*)dy, g);
     } else {
         constexpr int smem = 2 * ((64 / 16) + (TR_BK / 16)) * (TR_STEP * 32 + 32);
-        hipLaunchKernelGGL(conv_wgrad_tr_kernel<1>, grid, dim3(192), smem, st, (const bf16_t*)x, (const bf16_t*)dy, g);
+        hipLaunchKernelGGL((conv_wgrad_tr_kernel<T, 1>), grid, dim3(192), smem, st, (const T*)x, (const T*)dy, g);
     }
     *nslab_out = nslab;
     return 1;
@@ -247,8 +252,8 @@ struct WpGeom { int B, H, W, Cin, Cout, ldy, tiles_x, tiles_y, ntiles, tiles_per
 // OS = 16-channel sub-tiles of dy handled by the workgroup (4: 64 output channels, 2: 32, 1: 16); XS = 16-channel sub-tiles of
 // the input slice (4: a 64-channel slice; 2 / 1: the whole input of the 32- and 16-channel full-resolution layers); NW = waves,
 // each owning JW = 9 * XS / NW of the (tap, 16-channel) operand sub-tiles
-template <int OS, int NW, int XS = 4>
-__global__ __launch_bounds__(64 * NW) void conv_wgrad_patch_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, WpGeom g) {
+template <typename T, int OS, int NW, int XS = 4>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_patch_kernel(const T* __restrict__ x, const T* __restrict__ dy, WpGeom g) {
     constexpr int WP_NT = 64 * NW, JW = 9 * XS / NW;
     static_assert(9 * XS % NW == 0 && (JW == 6 || JW <= 3), "operand sub-tiles per wave");
     constexpr int XCH = WP_PPIX * 2 * XS, DCH = WP_TH * WP_TW * 2 * OS;      // 16-byte chunks per tile: x patch, dy
@@ -265,8 +270,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_patch_kernel(const bf16_t*
         const int tx = t % g.tiles_x; int q = t / g.tiles_x;
         const int ty = q % g.tiles_y, b = q / g.tiles_y;
         const int x0 = tx * WP_TW, y0 = ty * WP_TH;
-        const bf16_t* xb = x + (size_t)b * g.H * g.W * g.Cin + cs * (16 * XS);
-        const bf16_t* db = dy + (size_t)b * g.H * g.W * g.ldy + o0;
+        const T* xb = x + (size_t)b * g.H * g.W * g.Cin + cs * (16 * XS);
+        const T* db = dy + (size_t)b * g.H * g.W * g.ldy + o0;
 #pragma unroll
         for (int u = 0; u < XN; ++u) {
             const int id = tid + u * WP_NT;
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_patch_kernel(const bf16_t*
 #pragma unroll
             for (int i = 0; i < OS; ++i)
 #pragma unroll
-                for (int j = 0; j < JW; ++j) mma_chunk<bf16_t>(df[i], xf[j], acc[i][j]);
+                for (int j = 0; j < JW; ++j) mma_chunk<T>(df[i], xf[j], acc[i][j]);
         }
     };
 
@@ -442,7 +447,12 @@ int g_opt_wgrad_patch_blocks = 256; // option "wgrad_patch_blocks": target workg
 int g_opt_wgrad_patch_waves = 12;   // option "wgrad_patch_waves": 6 (64 x 96 block per wave) or 12 (64 x 48)
 
 // 3x3 / s1 / p1, Cin % 64 == 0: returns 1 if launched (partials in g.ws, *nslab slabs), 0 to fall through
-int try_conv_wgrad_patch(const void* x, const void* dy, WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st) {
+template <typename T> static int conv_wgrad_patch_t(const void* x, const void* dy, WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st);
+int try_conv_wgrad_patch(const void* x, const void* dy, WgradGeom& g, int dtype, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st) {
+    if (dtype == MFX_F16) return conv_wgrad_patch_t<half_t>(x, dy, g, workspace, workspace_bytes, nslab_out, st);
+    return conv_wgrad_patch_t<bf16_t>(x, dy, g, workspace, workspace_bytes, nslab_out, st);
+}
+template <typename T> static int conv_wgrad_patch_t(const void* x, const void* dy, WgradGeom& g, void* workspace, size_t workspace_bytes, int* nslab_out, hipStream_t st) {
     if (!g_opt_wgrad_patch || !workspace || g.direct) return 0;
     if (g.kh != 3 || g.kw != 3 || g.stride != 1 || g.pad_h != 1 || g.pad_w != 1 || g.dil_w != 1 || g.Ho != g.H || g.Wo != g.W) return 0;
     if ((g.Ck % 64 != 0 && g.Ck != 32 && g.Ck != 16) || g.x_pixstride != g.Ck || g.ldy % 8 != 0 || g.Cout % 8 != 0 || g.M < 2048) return 0;
@@ -470,7 +480,7 @@ int try_conv_wgrad_patch(const void* x, const void* dy, WgradGeom& g, void* work
 #define WP_LAUNCH_SMALL(OS_, NW_, XS_)                                                                                              \
         do {                                                                                                                        \
             constexpr int smem = 2 * (XS_ * WP_XSUB + OS_ * WP_DSUB);                                                               \
-            hipLaunchKernelGGL((conv_wgrad_patch_kernel<OS_, NW_, XS_>), grid, dim3(64 * NW_), smem, st, (const bf16_t*)x, (const bf16_t*)dy, w); \
+            hipLaunchKernelGGL((conv_wgrad_patch_kernel<T, OS_, NW_, XS_>), grid, dim3(64 * NW_), smem, st, (const T*)x, (const T*)dy, w); \
         } while (0)
         if (xs == 1 && os == 1) WP_LAUNCH_SMALL(1, 3, 1);
         else if (xs == 1) WP_LAUNCH_SMALL(2, 3, 1);
@@ -484,19 +494,19 @@ int try_conv_wgrad_patch(const void* x, const void* dy, WgradGeom& g, void* work
     if (os == 4) {
         constexpr int smem = 2 * (4 * WP_XSUB + 4 * WP_DSUB);
         if (nw == 12) {
-            auto k = conv_wgrad_patch_kernel<4, 12>;
+            auto k = conv_wgrad_patch_kernel<T, 4, 12>;
             static bool a12 = false; if (!a12) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); a12 = true; }
-            hipLaunchKernelGGL(k, grid, dim3(768), smem, st, (const bf16_t*)x, (const bf16_t*)dy, w);
+            hipLaunchKernelGGL(k, grid, dim3(768), smem, st, (const T*)x, (const T*)dy, w);
         } else {
-            auto k = conv_wgrad_patch_kernel<4, 6>;
+            auto k = conv_wgrad_patch_kernel<T, 4, 6>;
             static bool a6 = false; if (!a6) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); a6 = true; }
-            hipLaunchKernelGGL(k, grid, dim3(384), smem, st, (const bf16_t*)x, (const bf16_t*)dy, w);
+            hipLaunchKernelGGL(k, grid, dim3(384), smem, st, (const T*)x, (const T*)dy, w);
         }
     } else {
         constexpr int smem = 2 * (4 * WP_XSUB + 2 * WP_DSUB);
-        auto k = conv_wgrad_patch_kernel<2, 6>;
+        auto k = conv_wgrad_patch_kernel<T, 2, 6>;
         static bool a2 = false; if (!a2) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); a2 = true; }
-        hipLaunchKernelGGL(k, grid, dim3(384), smem, st, (const bf16_t*)x, (const bf16_t*)dy, w);
+        hipLaunchKernelGGL(k, grid, dim3(384), smem, st, (const T*)x, (const T*)dy, w);
     }
     MFX_HIP_CHECK(hipGetLastError());
     *nslab_out = nslab;
@@ -521,7 +531,8 @@ constexpr int SW_K = 224;
 
 struct SwGeom { int B, H, W, Hp, Wp, tiles_x, tiles_y, ntiles, tiles_per_block; float* ws; };
 
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restrict__ xp, const bf16_t* __restrict__ dy, SwGeom g) {
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ xp, const T* __restrict__ dy, SwGeom g) {
     __shared__ __attribute__((aligned(16))) char lds[2 * SW_STAGE];
     static_assert(2 * SW_STAGE >= 14 * 64 * 16, "the cross-wave reduction reuses the staging buffers");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -585,8 +596,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const bf16_t* __restric
             for (int th = 0; th < 7; ++th) {
                 const uint32_t xa = xs + (uint32_t)((r + th) * SW_ROWB) + x_off;
                 const u32x4 x0 = tr2(xa, 16 * 8), x1 = tr2(xa + 32, 16 * 8);
-                mma_chunk<bf16_t>(df, x0, acc[th][0]);
-                mma_chunk<bf16_t>(df, x1, acc[th][1]);
+                mma_chunk<T>(df, x0, acc[th][0]);
+                mma_chunk<T>(df, x1, acc[th][1]);
             }
         }
     };
@@ -651,6 +662,12 @@ int g_opt_stem_wgrad_blocks = 512;      // option "stem_wgrad_blocks"
 
 extern "C" int mfx_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, int B, int H, int W, int Hp, int Wp, void* workspace,
                                    size_t workspace_bytes, void* stream) {
+    return mfx_stem_wgrad_16(xp, dy, dw, B, H, W, Hp, Wp, MFX_BF16, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mfx_stem_wgrad_16(const void* xp, const void* dy, float* dw, int B, int H, int W, int Hp, int Wp, int dtype, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (dtype != MFX_BF16 && dtype != MFX_F16) return mfx_fail(MFX_ERR_ARG, "stem_wgrad: 16-bit activations (bf16 / fp16) only");
     if (!xp || !dy || !dw || !workspace) return mfx_fail(MFX_ERR_ARG, "stem_wgrad: null pointer");
     if (Hp < H + 6 || Wp < W + 8 || (Wp & 1)) return mfx_fail(MFX_ERR_ARG, "stem_wgrad: the padded image must be (H+6) x (W+8), even width");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -664,7 +681,8 @@ extern "C" int mfx_stem_wgrad_bf16(const void* xp, const void* dy, float* dw, in
     g.tiles_per_block = (g.ntiles + nb - 1) / nb;
     nb = (g.ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
     g.ws = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(256), 0, st, (const bf16_t*)xp, (const bf16_t*)dy, g);
+    if (dtype == MFX_BF16) hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)xp, (const bf16_t*)dy, g);
+    else hipLaunchKernelGGL(stem_wgrad_kernel<half_t>, dim3(nb), dim3(256), 0, st, (const half_t*)xp, (const half_t*)dy, g);
     hipLaunchKernelGGL(slab_sum_kernel, dim3((16 * SW_K + 63) / 64), dim3(256), 0, st, (const float*)g.ws, nb, 16 * SW_K, dw);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;

@@ -71,6 +71,61 @@ def prepare_targets(model, targets, device, fields=None):
     return pt
 
 
+class LossScaler:
+    """Dynamic loss scaling for fp16 training (COMPUTE_DTYPE = "fp16"), entirely on the device, so a captured step carries it:
+
+        losses * scale -> backward -> [gradient exchange] -> gradients / scale + non-finite check (one foreach launch)
+        -> [clip] -> fused AdamW, which reads `found_inf` and leaves parameters, moments and step counters untouched when it is set
+        -> scale *= backoff if found_inf else (scale *= growth every `growth_interval` clean steps)
+
+    fp16 keeps three more mantissa bits than bf16 but only five exponent bits: activation gradients below 6e-5 lose precision and
+    below 6e-8 vanish, above 65504 they overflow, so the loss is scaled into range and the scale follows the run (the arithmetic of
+    torch.amp.GradScaler, without its host synchronisation).  Data parallel: the check runs on the all-reduced gradients, where an
+    inf/nan of any rank has reached every rank, so all ranks take the same decision.  bf16 / fp32 training needs none of this.
+
+    Range of this network (tools/probes/fp16_range_probe.py, random init, B = 8 at 1280 x 384, scale 1): the gradients of the 16-bit
+    maps grow from ~1e-7 (median of the dense head-trunk gradients: at fp16's smallest subnormal) to ~1e2 (full-resolution DLA levels)
+    on their way down the network, 30 of fp16's 40 binades; scales 2^5 .. 2^9 keep both ends.  The default start (2^8) needs no
+    back-off there; a start that is too high costs one skipped step per halving."""
+
+    def __init__(self, device, init_scale=2.0 ** 8, growth_factor=2.0, backoff_factor=0.5, growth_interval=1000):
+        self.scale = torch.full((), float(init_scale), dtype=torch.float32, device=device)
+        self.growth_tracker = torch.zeros((), dtype=torch.int32, device=device)
+        self.found_inf = torch.zeros((), dtype=torch.float32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+
+    @staticmethod
+    def for_model(model, device=None):
+        """A scaler when the model computes in fp16, else None."""
+        net = model.module if hasattr(model, "module") else model
+        if getattr(net, "compute_dtype", None) != torch.float16:
+            return None
+        dev = device if device is not None else next(p.device for p in net.parameters())
+        return LossScaler(dev)
+
+    def attach(self, optimizer):
+        """The fused AdamW step skips itself while `found_inf` is set (torch.optim's AMP hook)."""
+        optimizer.found_inf = self.found_inf
+        return self
+
+    def scale_loss(self, losses):
+        return losses * self.scale
+
+    def unscale_(self, grads):
+        self.found_inf.zero_()
+        torch._amp_foreach_non_finite_check_and_unscale_(list(grads), self.found_inf, self.scale.reciprocal())
+
+    def update(self):
+        torch._amp_update_scale_(self.scale, self.growth_tracker, self.found_inf, self.growth_factor, self.backoff_factor, self.growth_interval)
+
+    def state_dict(self):
+        return {"scale": float(self.scale), "growth_tracker": int(self.growth_tracker)}
+
+    def load_state_dict(self, sd):
+        self.scale.fill_(float(sd["scale"]))
+        self.growth_tracker.fill_(int(sd.get("growth_tracker", 0)))
+
+
 class GraphedTrainStep:
     """One optimisation step replayed from hipGraphs, single GPU or data-parallel, with the gradient exchange OVERLAPPED with
     the backward pass (reference: DDP's bucket hooks inside `losses.backward()`, tools/plain_train_net.py:134-137,
@@ -97,10 +152,13 @@ class GraphedTrainStep:
     the eager path (bench.py --sync-bn); the graphed step normalises with rank-local batch statistics (per-GPU batch 8)."""
 
     def __init__(self, model, optimizer, images, targets, group=None, comm_chunks=None, warmup=3, split=None, use_graphs=None,
-                 grad_norm_clip=-1.0):
+                 grad_norm_clip=-1.0, scaler="auto"):
         import torch.distributed as dist
         self.model, self.optimizer, self.images, self.targets = model, optimizer, images, targets
         self.net = model.module if hasattr(model, "module") else model
+        self.scaler = LossScaler.for_model(self.net, images.device) if scaler == "auto" else scaler      # fp16 activations: dynamic loss scaling
+        if self.scaler is not None:
+            self.scaler.attach(optimizer)
         self.dist_on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.dist_on else 1
         self.group = group
@@ -160,8 +218,7 @@ class GraphedTrainStep:
         if not self.split:
             with torch.cuda.graph(g0, capture_error_mode="thread_local"):     # (an RCCL watchdog thread may poll events meanwhile)
                 self.loss = self._fwd_bwd()
-                self._clip()
-                optimizer.step()
+                self._update()
             self.graphs = [g0]
             return
         thunks = None
@@ -176,8 +233,7 @@ class GraphedTrainStep:
         self._point_grads_at_views()
         self.graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_b, pool=g0.pool(), capture_error_mode="thread_local"):
-            self._clip()
-            optimizer.step()
+            self._update()
 
     # ---- pieces ---------------------------------------------------------------------------------------------------
     def _pack(self):
@@ -191,8 +247,20 @@ class GraphedTrainStep:
         loss_dict, _ = self.model(self.images, self.targets)
         losses = sum(loss_dict.values())
         self.optimizer.zero_grad(set_to_none=True)
-        losses.backward()
+        self._scaled(losses).backward()
         return losses.detach()
+
+    def _scaled(self, losses):
+        return losses if self.scaler is None else self.scaler.scale_loss(losses)
+
+    def _update(self):
+        """[unscale + non-finite check,] [clip,] optimizer step [, loss-scale update] on the step's final gradients."""
+        if self.scaler is not None:
+            self.scaler.unscale_([self.flat] if self.flat is not None else [p.grad for p in self.net.parameters() if p.grad is not None])
+        self._clip()
+        self.optimizer.step()
+        if self.scaler is not None:
+            self.scaler.update()
 
     def _forward_cut(self):
         """Forward pass with the model's gradient cuts -> (detached total loss, the K backward pieces in execution order)."""
@@ -201,7 +269,8 @@ class GraphedTrainStep:
         if self.nseg == 1:
             loss_dict, _ = self.model(self.images, self.targets)
             losses = sum(loss_dict.values())
-            return losses.detach(), [lambda: losses.backward()]
+            scaled = self._scaled(losses)
+            return losses.detach(), [lambda: scaled.backward()]
         cuts = {}
 
         def cut(name, tensors):
@@ -214,7 +283,7 @@ class GraphedTrainStep:
         finally:
             self.net.set_backward_cuts(None)
         losses = sum(loss_dict.values())
-        return losses.detach(), self.net.backward_thunks(losses, cuts)
+        return losses.detach(), self.net.backward_thunks(self._scaled(losses), cuts)
 
     def _flatten(self, k):
         params, views = self.seg_params[k], self.seg_views[k]
@@ -266,8 +335,7 @@ class GraphedTrainStep:
     def _eager(self):
         if not self.split:
             loss = self._fwd_bwd()
-            self._clip()
-            self.optimizer.step()
+            self._update()
             return loss
         loss, thunks = self._forward_cut()
         for k, t in enumerate(thunks):
@@ -276,8 +344,7 @@ class GraphedTrainStep:
             self._exchange(k)
         self._finish_exchange()
         self._point_grads_at_views()
-        self._clip()
-        self.optimizer.step()
+        self._update()
         return loss
 
     def load_batch(self, images, targets=None):
@@ -315,18 +382,23 @@ def _target_tensors(pt):
     return out
 
 
-def train_step(model, optimizer, images, targets, grad_norm_clip=-1.0, scheduler=None):
-    """trainer.py:109-126: forward -> summed loss -> zero_grad -> backward (+DDP all-reduce) -> clip -> step."""
+def train_step(model, optimizer, images, targets, grad_norm_clip=-1.0, scheduler=None, scaler=None):
+    """trainer.py:109-126: forward -> summed loss -> zero_grad -> backward (+DDP all-reduce) -> clip -> step.
+    `scaler`: a LossScaler (attached to `optimizer`) when the model computes in fp16."""
     if images.is_cuda:
         from .. import autograd as AG
         AG.pack_all_weights()                                   # every conv operand of the step from the current parameters, one launch
     loss_dict, log_loss_dict = model(images, targets)
     losses = sum(loss_dict.values())
     optimizer.zero_grad(set_to_none=True)
-    losses.backward()
+    (losses if scaler is None else scaler.scale_loss(losses)).backward()
+    if scaler is not None:
+        scaler.unscale_([p.grad for p in model.parameters() if p.grad is not None])
     if grad_norm_clip > 0:
         torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], grad_norm_clip)
     optimizer.step()
+    if scaler is not None:
+        scaler.update()
     if scheduler is not None:
         scheduler.step()
     return losses.detach(), loss_dict, log_loss_dict
@@ -364,6 +436,9 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
     # every later batch is copied into the captured buffers.  Anything else (DDP-wrapped model, SyncBN, CPU tensors, ragged
     # shapes) takes the eager step, the reference's literal loop.
     graphed, graphed_shapes = None, None
+    scaler = LossScaler.for_model(net, device) if torch.device(device).type == "cuda" else None     # fp16 activations: dynamic loss scaling
+    if scaler is not None:
+        scaler.attach(optimizer)
     want_graph = bool(cfg.SOLVER.get("GRAPHED_STEP", True)) and not hasattr(model, "module") \
         and all(g.get("capturable", False) and torch.is_tensor(g["lr"]) for g in optimizer.param_groups) \
         and not any(getattr(mod, "sync_bn", False) or isinstance(mod, torch.nn.SyncBatchNorm) for mod in net.modules())
@@ -379,16 +454,16 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
         if use_graph:
             shapes = (tuple(img_t.shape),) + tuple(tuple(t.shape) for t in _target_tensors(targets))
             if graphed is None:
-                graphed = GraphedTrainStep(model, optimizer, img_t.clone(), _clone_targets(targets), grad_norm_clip=clip)
+                graphed = GraphedTrainStep(model, optimizer, img_t.clone(), _clone_targets(targets), grad_norm_clip=clip, scaler=scaler)
                 graphed_shapes = shapes
                 logger.info("training step captured as hipGraphs (%d graph(s), overlap %s)", len(graphed.graphs) + (graphed.graph_b is not None), graphed.overlap)
             if shapes == graphed_shapes:
                 graphed.load_batch(img_t, targets)
                 losses = graphed()
             else:                                               # a batch of another shape (last partial batch): the eager step
-                losses, _, _ = train_step(model, optimizer, images, targets, grad_norm_clip=clip)
+                losses, _, _ = train_step(model, optimizer, images, targets, grad_norm_clip=clip, scaler=scaler)
         else:
-            losses, loss_dict, log_loss_dict = train_step(model, optimizer, images, targets, grad_norm_clip=clip)
+            losses, loss_dict, log_loss_dict = train_step(model, optimizer, images, targets, grad_norm_clip=clip, scaler=scaler)
         advance_schedule(iteration, warmup_iters, scheduler, warmup_scheduler)
         iteration += 1
         arguments["iteration"] = iteration

@@ -126,6 +126,7 @@ SYMBOLS = {
     "mfx_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_act_bwd": (_I, [_P] * 10 + [ctypes.c_long, _I, _I, _I, _P]),
     "mfx_stem_wgrad_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "mfx_stem_wgrad_16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
     "mfx_pack_chunk_elems": (_I, []),
     "mfx_pack_conv_weights_batched": (_I, [_P, _P, _I, ctypes.c_longlong, _I, _P]),
     "mfx_head_sparse_fwd": (_I, [ctypes.POINTER(HeadSparseDesc), _P]),

@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}      # activation dtypes of the training path
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -80,24 +81,25 @@ def test_stem_conv_wgrad():
     assert _rel(yd.permute(0, 3, 1, 2), yr) < 1e-5 and _rel(wd.grad, wr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,H,W", [(2, 32, 64), (3, 37, 70), (1, 8, 32), (2, 96, 320)])
-def test_stem_conv_wgrad_bf16_toeplitz_kernel(B, H, W):
+def test_stem_conv_wgrad_bf16_toeplitz_kernel(B, H, W, half):
     """mfx_stem_wgrad_bf16 (flat image rows in LDS, Toeplitz operand through transposed reads) against the generic dilated-tap
     kernel on the same bf16 operands and against torch autograd of F.conv2d; ragged tiles included."""
     from monoflex_amd import autograd as AG
     g = torch.Generator().manual_seed(7)
-    x = torch.randn(B, 3, H, W, generator=g).bfloat16().float()
+    x = torch.randn(B, 3, H, W, generator=g).to(DT[half]).float()
     w = (torch.randn(16, 3, 7, 7, generator=g) * 0.1)
     wr = w.clone().requires_grad_()
     yr = F.conv2d(x, wr, padding=3)
-    r = torch.randn(yr.shape, generator=g).bfloat16().float()
+    r = torch.randn(yr.shape, generator=g).to(DT[half]).float()
     (yr * r).sum().backward()
     got = {}
     for generic in (False, True):
         AG._STEM_WGRAD_GENERIC[0] = generic
         try:
             wd = w.to(DEV).requires_grad_()
-            yd = AG.StemConvFn.apply(x.to(DEV), wd, torch.bfloat16)
+            yd = AG.StemConvFn.apply(x.to(DEV), wd, DT[half])
             (yd.float() * _nhwc(r).to(DEV)).sum().backward()
             got[generic] = wd.grad.detach().cpu()
         finally:
@@ -138,21 +140,22 @@ def test_bn_act_grads(act, res):
         assert _rel(rd.grad.permute(0, 3, 1, 2), rr.grad) < 1e-5
 
 
-@pytest.mark.parametrize("C,shape,dt", [(16, (2, 40, 64), "fp32"), (64, (3, 12, 20), "bf16"), (512, (2, 6, 10), "fp32"), (128, (8, 48, 160), "bf16")])
+@pytest.mark.parametrize("C,shape,dt", [(16, (2, 40, 64), "fp32"), (64, (3, 12, 20), "bf16"), (512, (2, 6, 10), "fp32"), (128, (8, 48, 160), "bf16"),
+                                         (64, (3, 12, 20), "fp16"), (128, (8, 48, 160), "fp16")])
 def test_bn_two_launch_form_reuses_its_scratch(C, shape, dt):
     """mfx_bn_train_fwd / mfx_bn_train_bwd keep their sums in a persistent scratch that every call must leave zero: repeated
     forwards, a forward without a backward, and two backwards through one forward all agree with the separate-kernel form
     (stats / finalize / apply with freshly zeroed buffers), and num_batches_tracked counts in the kernel."""
     from monoflex_amd import autograd as AG
     from monoflex_amd import lib as L
-    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    dtype = DT[dt]
     g = torch.Generator().manual_seed(C)
     B, H, W = shape
     bn_a, bn_b = torch.nn.BatchNorm2d(C).to(DEV), torch.nn.BatchNorm2d(C).to(DEV)
     with torch.no_grad():
         bn_a.weight.copy_(torch.rand(C, generator=g) + 0.5); bn_a.bias.copy_(torch.randn(C, generator=g))
     bn_b.load_state_dict(bn_a.state_dict())
-    tol = 2e-2 if dt == "bf16" else 1e-4
+    tol = 2e-2 if dt != "fp32" else 1e-4
     for it in range(3):
         x = (torch.randn(B, H, W, C, generator=g) * (1 + it) + 0.3 * it).to(DEV).to(dtype)
         r = torch.randn(B, H, W, C, generator=g).to(DEV).to(dtype)
@@ -173,20 +176,20 @@ def test_bn_two_launch_form_reuses_its_scratch(C, shape, dt):
                 AG._BN_SEPARATE[0] = False
         for a, b in zip(*outs):
             assert _rel(a.float(), b.float()) < tol
-        assert _rel(outs[0][1].float(), outs[0][2].float()) < (1e-2 if dt == "bf16" else 1e-4)             # the two backwards of the fused form agree with each other
+        assert _rel(outs[0][1].float(), outs[0][2].float()) < (1e-2 if dt != "fp32" else 1e-4)             # the two backwards of the fused form agree with each other
     assert _rel(bn_a.running_mean, bn_b.running_mean) < 1e-5 and _rel(bn_a.running_var, bn_b.running_var) < 1e-5
     assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 4
     assert float(AG._bn_scratch(bn_a.weight).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("act", ["relu", "leaky"])
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 def test_bn_backward_recomputes_the_activation_sign_from_its_input(act, dt):
     """Without a residual the BN backward does not read the forward output: the sign of x*scale + shift is recomputed with the
     forward's expression.  Same gradients as the form that reads the stored output (bitwise for the data gradient's ReLU mask)."""
     from monoflex_amd import autograd as AG
     from monoflex_amd import lib as L
-    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    dtype = DT[dt]
     g = torch.Generator().manual_seed(11)
     C = 128
     x = (torch.randn(4, 24, 40, C, generator=g) * 1.5 + 0.2).to(DEV).to(dtype)
@@ -207,20 +210,20 @@ def test_bn_backward_recomputes_the_activation_sign_from_its_input(act, dt):
         finally:
             AG._BN_READ_OUTPUT[0] = False
     (dx0, dg0, db0, y0), (dx1, dg1, db1, y1) = out
-    tol = 1e-2 if dt == "bf16" else 2e-5                               # two runs differ by the summation order of the statistics' atomics
+    tol = 1e-2 if dt != "fp32" else 2e-5                               # two runs differ by the summation order of the statistics' atomics
     assert _rel(y0.float(), y1.float()) < tol
     assert _rel(dg0, dg1) < 1e-4 and _rel(db0, db1) < 1e-4
     assert _rel(dx0.float(), dx1.float()) < tol
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 def test_sparse_regression_heads_function_vs_torch(dt):
     """SparseRegHeadsFn (csrc/head_sparse.hip) against torch: train-mode BN over the dense trunk map + leaky(0.01) + 1x1 heads,
     gathered at the object centres (duplicate centres, empty slots), output rows and every gradient (trunk map, ABN weight /
     bias, 1x1 weights / biases) for a random upstream gradient."""
     from monoflex_amd import autograd as AG
     from monoflex_amd.model.head.detector_predictor import InPlaceABN
-    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    dtype = DT[dt]
     g = torch.Generator().manual_seed(23)
     B, H, W, C, N = 2, 12, 20, 256, 16
     ks, offs = (4, 20, 3), (0, 6, 26)
@@ -266,7 +269,7 @@ def test_sparse_regression_heads_function_vs_torch(dt):
     bd = [b.to(DEV).requires_grad_() for b in b2s]
     out = AG.SparseRegHeadsFn.apply(rows.to(DEV), tuple(abns_d), offs, 50, (False,) * len(ks), *yd, *[h.weight for h in abns_d], *[h.bias for h in abns_d], *wd, *bd)
     (out * dout.to(DEV)).sum().backward()
-    tol = 3e-2 if dt == "bf16" else 2e-4
+    tol = 3e-2 if dt != "fp32" else 2e-4
     for i, k in enumerate(ks):
         assert _rel(out[:, offs[i]:offs[i] + k].cpu(), outs_ref[i].detach()) < tol, i
         assert _rel(yd[i].grad.float().cpu(), ref_in[i].grad) < tol, (i, _rel(yd[i].grad.float().cpu(), ref_in[i].grad))
@@ -277,7 +280,7 @@ def test_sparse_regression_heads_function_vs_torch(dt):
     assert float(out[:, unused].abs().max()) == 0.0 and float(out[rows[:, 0] == 0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("cin,cout,H,W,k,stride", [(64, 64, 24, 40, 3, 1), (64, 256, 40, 72, 3, 1), (256, 64, 13, 37, 3, 1), (128, 128, 9, 20, 3, 1),
                                                    (16, 16, 32, 64, 3, 1), (32, 32, 31, 45, 3, 1), (512, 512, 6, 10, 3, 1), (64, 128, 24, 40, 3, 2),
                                                    (64, 128, 24, 40, 1, 1)])
@@ -288,7 +291,7 @@ def test_conv_epilogue_accumulates_the_bn_statistics(cin, cout, H, W, k, stride,
     stats_done = 0 and the BN does its own pass."""
     from monoflex_amd import autograd as AG, ops
     from monoflex_amd import lib as L
-    dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    dtype = DT[dt]
     g = torch.Generator().manual_seed(cin + cout + H)
     B = 3
     x = torch.randn(B, H, W, cin, generator=g).to(DEV).to(dtype)
@@ -311,7 +314,7 @@ def test_conv_epilogue_accumulates_the_bn_statistics(cin, cout, H, W, k, stride,
         finally:
             AG._CONV_STATS_OFF[0] = False
     AG._CONV_STATS_MAX_COUT[0] = 128
-    tol = 2e-2 if dt == "bf16" else 1e-4
+    tol = 2e-2 if dt != "fp32" else 1e-4
     for a_, b_ in zip(*out):
         assert _rel(a_, b_) < tol, _rel(a_, b_)
     assert float(AG._bn_scratch(bn_a.weight).abs().max()) == 0.0
@@ -644,26 +647,27 @@ def test_train_steps_update_parameters():
 
 
 # ---- bf16 training mode (activations bf16, fp32 master weights / statistics / gradients of parameters) ------------------
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
 @pytest.mark.parametrize("cin,cout,k,stride,bias,f32out", [(16, 32, 3, 1, False, False), (32, 64, 3, 2, False, False),
                                                            (64, 27, 3, 1, True, True), (256, 3, 1, 1, True, True),
                                                            (64, 256, 3, 1, False, False), (128, 128, 3, 2, False, False),
                                                            (256, 512, 1, 1, False, False)])
-def test_conv_grads_bf16(cin, cout, k, stride, bias, f32out):
+def test_conv_grads_bf16(cin, cout, k, stride, bias, f32out, half):
     from monoflex_amd import autograd as AG
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(2, cin, 20, 36, generator=g).bfloat16().float()
+    x = torch.randn(2, cin, 20, 36, generator=g).to(DT[half]).float()
     w = torch.randn(cout, cin, k, k, generator=g) * 0.1
     b = torch.randn(cout, generator=g) if bias else None
     xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
     br = b.clone().requires_grad_() if bias else None
     yr = F.conv2d(xr, wr, br, stride=stride, padding=k // 2)
-    r = torch.randn(yr.shape, generator=g).bfloat16().float()
+    r = torch.randn(yr.shape, generator=g).to(DT[half]).float()
     (yr * r).sum().backward()
-    xd = _nhwc(x).to(DEV).bfloat16().requires_grad_()
+    xd = _nhwc(x).to(DEV).to(DT[half]).requires_grad_()
     wd = w.to(DEV).requires_grad_()
     bd = b.to(DEV).requires_grad_() if bias else None
     yd = AG.conv2d(xd, wd, bd, stride, k // 2, out_dtype=torch.float32 if f32out else None)
-    assert yd.dtype == (torch.float32 if f32out else torch.bfloat16)
+    assert yd.dtype == (torch.float32 if f32out else DT[half])
     assert _rel(yd.permute(0, 3, 1, 2), yr) < 2e-2
     (yd.float() * _nhwc(r).to(DEV)).sum().backward()
     assert _rel(xd.grad.permute(0, 3, 1, 2), xr.grad) < 2e-2
@@ -672,15 +676,17 @@ def test_conv_grads_bf16(cin, cout, k, stride, bias, f32out):
         assert _rel(bd.grad, br.grad) < 2e-2
 
 
-def test_train_steps_bf16_mode():
-    """bf16 training mode end to end: three AdamW steps on one batch; finite, decreasing loss; losses close to fp32 mode's."""
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+def test_train_steps_bf16_mode(half):
+    """16-bit training modes end to end: four AdamW steps on one batch; finite, decreasing loss; losses close to fp32 mode's.
+    fp16 runs under the dynamic loss scaler (engine.trainer.LossScaler): the scale must have survived (no skipped step at 2^12)."""
     from monoflex_amd.config import get_cfg
-    from monoflex_amd.engine.trainer import train_step
+    from monoflex_amd.engine.trainer import LossScaler, train_step
     from monoflex_amd.solver import build_optimizer
     out_w, out_h = 96, 32
     m32, _ = _models(out_w, out_h)
     m16, _ = _models(out_w, out_h)
-    m16.set_compute_dtype("bf16")
+    m16.set_compute_dtype(half)
     cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"))
     imgs, _, targets = _train_batch(2, out_w, out_h)
     imgs, targets = imgs.to(DEV), [t.to(DEV) for t in targets]
@@ -692,28 +698,85 @@ def test_train_steps_bf16_mode():
     # (BN statistics are accumulated with atomics: run-to-run the bf16 roundings downstream differ, so the bound is loose)
     assert abs(float(l16["hm_loss"]) - float(l32["hm_loss"])) <= 0.15 * float(l32["hm_loss"])
     opt = build_optimizer(m16, cfg)
-    losses = [float(train_step(m16, opt, imgs, targets)[0]) for _ in range(4)]
+    scaler = LossScaler.for_model(m16)
+    assert (scaler is not None) == (half == "fp16")
+    if scaler is not None:
+        scaler.attach(opt)
+    before = [p.detach().clone() for p in m16.parameters()]
+    n = 4 if scaler is None else 8
+    losses = [float(train_step(m16, opt, imgs, targets, scaler=scaler)[0]) for _ in range(n)]
     assert all(np.isfinite(losses)) and min(losses[1:]) < losses[0], losses
+    assert sum(int(not torch.equal(a, b)) for a, b in zip(before, m16.parameters())) > 100       # steps were applied
+    if scaler is not None:
+        # this 384 x 128 toy configuration has the steepest gradient growth (643x at scale 1): the scaler halves 2^8 until the step fits,
+        # skipping those steps, and then stays; the applied steps are counted by the growth tracker and by AdamW's own step counters
+        sc, halvings = float(scaler.scale), int(round(np.log2(256.0 / float(scaler.scale))))
+        assert sc in (256.0, 128.0, 64.0, 32.0, 16.0), sc
+        assert 1 <= int(scaler.growth_tracker) <= n - halvings                 # (clean steps since the last overflow)
+        assert all(int(st["step"]) == n - halvings for st in opt.state.values())
 
 
-def test_stem_conv_wgrad_bf16():
+def test_loss_scaler_skips_an_overflowing_step_exactly():
+    """fp16 mode with a loss scale that must overflow (2^24): the step's gradients are non-finite, so the fused AdamW leaves the
+    parameters, both moments and its step counters BITWISE untouched, the scale is halved and the growth tracker reset; the next
+    step at a fitting scale is applied.  Same through the captured step (GraphedTrainStep)."""
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.engine.trainer import GraphedTrainStep, LossScaler, prepare_targets, train_step
+    from monoflex_amd.solver import build_optimizer
+    out_w, out_h = 96, 32
+    m, _ = _models(out_w, out_h)
+    m.set_compute_dtype("fp16")
+    m.heads.loss_evaluator.log_as_float = False
+    cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"))
+    imgs, _, targets = _train_batch(2, out_w, out_h)
+    imgs, targets = imgs.to(DEV), [t.to(DEV) for t in targets]
+    opt = build_optimizer(m, cfg)
+    scaler = LossScaler(torch.device(DEV), init_scale=2.0 ** 4).attach(opt)
+    train_step(m, opt, imgs, targets, scaler=scaler)                       # a clean step first: the optimizer state exists
+    assert float(scaler.found_inf) == 0.0 and int(scaler.growth_tracker) == 1
+    snap = [p.detach().clone() for p in m.parameters()]
+    state = [(st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"].clone()) for st in opt.state.values()]
+    scaler.scale.fill_(2.0 ** 24)
+    train_step(m, opt, imgs, targets, scaler=scaler)
+    assert float(scaler.found_inf) == 1.0 and float(scaler.scale) == 2.0 ** 23 and int(scaler.growth_tracker) == 0
+    assert all(torch.equal(a, b) for a, b in zip(snap, m.parameters()))
+    for (ea, es, stp), st in zip(state, opt.state.values()):
+        assert torch.equal(ea, st["exp_avg"]) and torch.equal(es, st["exp_avg_sq"]) and torch.equal(stp, st["step"])
+    # the captured step carries the scaler: one replay at 2^24 is skipped, the following one at 2^4 is applied
+    step = GraphedTrainStep(m, opt, imgs.clone(), prepare_targets(m, targets, torch.device(DEV)), scaler=scaler, warmup=2)
+    scaler.scale.fill_(2.0 ** 24)
+    snap = [p.detach().clone() for p in m.parameters()]
+    step()
+    torch.cuda.synchronize()
+    assert float(scaler.found_inf) == 1.0 and float(scaler.scale) == 2.0 ** 23
+    assert all(torch.equal(a, b) for a, b in zip(snap, m.parameters()))
+    scaler.scale.fill_(2.0 ** 4)
+    loss = step()
+    torch.cuda.synchronize()
+    assert float(scaler.found_inf) == 0.0 and torch.isfinite(loss)
+    assert sum(int(not torch.equal(a, b)) for a, b in zip(snap, m.parameters())) > 100
+
+
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+def test_stem_conv_wgrad_bf16(half):
     """bf16 stem weight gradient: matrix-core kernel over 8-element super-taps with dilation 2, mapped back to (16,3,7,7)."""
     from monoflex_amd import autograd as AG
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(2, 3, 32, 64, generator=g).bfloat16().float()
+    x = torch.randn(2, 3, 32, 64, generator=g).to(DT[half]).float()
     w = (torch.randn(16, 3, 7, 7, generator=g) * 0.1)
     wr = w.clone().requires_grad_()
     yr = F.conv2d(x, wr, padding=3)
-    r = torch.randn(yr.shape, generator=g).bfloat16().float()
+    r = torch.randn(yr.shape, generator=g).to(DT[half]).float()
     (yr * r).sum().backward()
     wd = w.to(DEV).requires_grad_()
-    yd = AG.StemConvFn.apply(x.to(DEV), wd, torch.bfloat16)
+    yd = AG.StemConvFn.apply(x.to(DEV), wd, DT[half])
     (yd.float() * _nhwc(r).to(DEV)).sum().backward()
     assert _rel(yd.permute(0, 3, 1, 2), yr) < 2e-2 and _rel(wd.grad, wr.grad) < 2e-2
 
 
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64)])
-def test_dcn_train_grads_bf16_vs_oracle(cin, cout):
+def test_dcn_train_grads_bf16_vs_oracle(cin, cout, half):
     """bf16 DCN backward (bf16 x / dy / d(columns), fp32 accumulation of every gradient) against the C oracle's fp32
     gradients on bf16-representable inputs; tolerance of a bf16 pipeline."""
     from oracle import monoflex_ref as R
@@ -722,18 +785,18 @@ def test_dcn_train_grads_bf16_vs_oracle(cin, cout):
     ref = R.DCN(cin, cout)
     dev = DCN(cin, cout, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
     with torch.no_grad():
-        ref.weight.copy_((torch.randn(ref.weight.shape, generator=g) * 0.05).bfloat16().float())
+        ref.weight.copy_((torch.randn(ref.weight.shape, generator=g) * 0.05).to(DT[half]).float())
         ref.bias.copy_(torch.randn(cout, generator=g) * 0.1)
-        ref.conv_offset_mask.weight.copy_((torch.randn(ref.conv_offset_mask.weight.shape, generator=g) * 0.02).bfloat16().float())
+        ref.conv_offset_mask.weight.copy_((torch.randn(ref.conv_offset_mask.weight.shape, generator=g) * 0.02).to(DT[half]).float())
         ref.conv_offset_mask.bias.copy_(torch.randn(27, generator=g) * 0.5)
     dev.load_state_dict(ref.state_dict())
     dev = dev.to(DEV).train()
-    x = torch.randn(2, cin, 12, 20, generator=g).bfloat16().float()
+    x = torch.randn(2, cin, 12, 20, generator=g).to(DT[half]).float()
     xr = x.clone().requires_grad_()
     yr = ref(xr)
-    r = torch.randn(yr.shape, generator=g).bfloat16().float()
+    r = torch.randn(yr.shape, generator=g).to(DT[half]).float()
     (yr * r).sum().backward()
-    xd = _nhwc(x).to(DEV).bfloat16().requires_grad_()
+    xd = _nhwc(x).to(DEV).to(DT[half]).requires_grad_()
     yd = dev.forward_nhwc_train(xd)
     (yd.float() * _nhwc(r).to(DEV)).sum().backward()
     assert _rel(yd.permute(0, 3, 1, 2), yr) < 2e-2
@@ -743,7 +806,7 @@ def test_dcn_train_grads_bf16_vs_oracle(cin, cout):
         assert _rel(p.grad, refp[n].grad) < 4e-2, n
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cin,cout,H,W,off_std", [(64, 64, 13, 37, 0.5), (64, 128, 24, 40, 3.0), (128, 64, 9, 50, 6.0), (256, 64, 12, 20, 12.0),
                                                   (512, 256, 12, 40, 2.0)])
 def test_dcn_tile_owned_backward_vs_oracle(cin, cout, H, W, off_std, dtype):
@@ -755,8 +818,8 @@ def test_dcn_tile_owned_backward_vs_oracle(cin, cout, H, W, off_std, dtype):
     from monoflex_amd import autograd as AG
     from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCN
     g = torch.Generator().manual_seed(18)
-    bf = dtype == torch.bfloat16
-    rnd = (lambda t: t.bfloat16().float()) if bf else (lambda t: t)
+    bf = dtype != torch.float32                                  # 16-bit activations (bf16 / fp16)
+    rnd = (lambda t: t.to(dtype).float()) if bf else (lambda t: t)
     ref = R.DCN(cin, cout)
     dev = DCN(cin, cout, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
     with torch.no_grad():
@@ -795,8 +858,9 @@ def test_dcn_tile_owned_backward_vs_oracle(cin, cout, H, W, off_std, dtype):
             assert _rel(a, b_) < 3e-4, (n, _rel(a, b_))
 
 
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
 @pytest.mark.parametrize("H,W,off_std,min_chunks", [(96, 320, 1.5, None), (96, 320, 5.0, None), (32, 64, 2.5, 1), (9, 32, 6.0, 1)])
-def test_dcn_fused_sample_wgrad_kernel_vs_oracle(H, W, off_std, min_chunks):
+def test_dcn_fused_sample_wgrad_kernel_vs_oracle(H, W, off_std, min_chunks, half):
     """`dcn_bwd_sample_wgrad_kernel` (dcn_bwd_tile.hip: grad_offset / grad_mask + grad_weight on the matrix cores from an LDS
     column tile, bf16, C = Cout = 64, W % 32 == 0) against the C restatement of the reference backward
     (dcn_v2_cuda.cu:206-335, dcn_v2_im2col_cuda.cu:197-327): all five gradients, at the shape the benchmarked training step
@@ -807,7 +871,7 @@ def test_dcn_fused_sample_wgrad_kernel_vs_oracle(H, W, off_std, min_chunks):
     from monoflex_amd import lib as L
     from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCN
     g = torch.Generator().manual_seed(77)
-    rnd = lambda t: t.bfloat16().float()                         # noqa: E731
+    rnd = lambda t: t.to(DT[half]).float()                         # noqa: E731
     ref = R.DCN(64, 64)
     dev = DCN(64, 64, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
     with torch.no_grad():
@@ -835,7 +899,7 @@ def test_dcn_fused_sample_wgrad_kernel_vs_oracle(H, W, off_std, min_chunks):
             L.check(lib_.mfx_set_option(b"dcn_bt_fuse_wgrad", fuse), "opt")
             before = lib_.mfx_get_counter(b"dcn_bt_fused")
             dev.zero_grad(set_to_none=True)
-            xd = _nhwc(x).to(DEV).bfloat16().requires_grad_()
+            xd = _nhwc(x).to(DEV).to(DT[half]).requires_grad_()
             yd = dev.forward_nhwc_train(xd)
             (yd.float() * _nhwc(r).to(DEV)).sum().backward()
             torch.cuda.synchronize()
@@ -857,22 +921,23 @@ def test_dcn_fused_sample_wgrad_kernel_vs_oracle(H, W, off_std, min_chunks):
         assert _rel(a, b_) < (6e-2 if n == "input" else 1e-2), ("fused vs unfused", n, _rel(a, b_))
 
 
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
 @pytest.mark.parametrize("cin,cout,k,stride,H,W", [(64, 256, 3, 1, 48, 96), (64, 64, 3, 1, 40, 72), (128, 128, 3, 2, 64, 80),
                                                    (256, 256, 3, 1, 24, 80), (512, 512, 3, 1, 12, 40), (64, 192, 3, 1, 33, 47),
                                                    (128, 27, 3, 1, 48, 96), (64, 27, 3, 1, 37, 75), (64, 64, 3, 1, 96, 40),
                                                    (16, 16, 3, 1, 64, 96), (32, 32, 3, 1, 48, 80), (16, 32, 3, 1, 37, 75), (32, 16, 3, 1, 41, 70)])
-def test_conv_wgrad_transposed_read_kernel_vs_torch(cin, cout, k, stride, H, W):
+def test_conv_wgrad_transposed_read_kernel_vs_torch(cin, cout, k, stride, H, W, half):
     """Second-generation weight-gradient kernel (wgrad_tr.hip: natural-layout LDS tiles + ds_read_b64_tr_b16, 64x64 wave
     blocks, BK = 192) against torch autograd of F.conv2d on bf16-representable operands, and against the first-generation
     kernel; ragged pixel slabs, stride 2, Cout not a multiple of 128."""
     from monoflex_amd import autograd as AG, lib as L
     g = torch.Generator().manual_seed(31)
     B = 3
-    x = torch.randn(B, cin, H, W, generator=g).bfloat16().float()
+    x = torch.randn(B, cin, H, W, generator=g).to(DT[half]).float()
     w = torch.randn(cout, cin, k, k, generator=g) * 0.05
     wr = w.clone().requires_grad_()
     yr = F.conv2d(x, wr, None, stride=stride, padding=k // 2)
-    r = torch.randn(yr.shape, generator=g).bfloat16().float()
+    r = torch.randn(yr.shape, generator=g).to(DT[half]).float()
     (yr * r).sum().backward()
     lib_ = L.load()
     got = {}
@@ -880,7 +945,7 @@ def test_conv_wgrad_transposed_read_kernel_vs_torch(cin, cout, k, stride, H, W):
         for tr in (1, 2, 0):                                     # 1: LDS-patch form where it applies, 2: plain transposed-read form, 0: first generation
             L.check(lib_.mfx_set_option(b"wgrad_tr", 1 if tr else 0), "opt")
             L.check(lib_.mfx_set_option(b"wgrad_patch", 1 if tr == 1 else 0), "opt")
-            xd = _nhwc(x).to(DEV).bfloat16()
+            xd = _nhwc(x).to(DEV).to(DT[half])
             wd = w.to(DEV).requires_grad_()
             yd = AG.conv2d(xd, wd, None, stride, k // 2)
             (yd.float() * _nhwc(r).to(DEV)).sum().backward()

@@ -66,7 +66,7 @@ def deterministic():
     L.set_deterministic(False)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_deterministic_mode_is_bitwise_reproducible(dtype, deterministic):
     """Two eager forward + loss + backward passes of the same model on the same batch: every loss, every gradient and every BN
     buffer identical to the last bit (without the option, BN statistics / bias sums / DCN far corners are summed with float
@@ -174,13 +174,14 @@ def test_graphed_train_step_equals_the_eager_step(split, nccl_world1):
     assert np.isfinite(float(step()))
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("split", [False, True])
 def test_graphed_train_step_equals_the_eager_step_bitwise(split, dtype, nccl_world1, deterministic):
     """With fixed-order reductions the replayed step and the eager step are the same arithmetic: after one step from a common
     state, EVERY parameter, BN buffer and AdamW moment is identical to the last bit, in both launch forms (single graph; flat
-    gradient buffer + all-reduce + optimizer graph) -- and again after a second step."""
-    from monoflex_amd.engine.trainer import GraphedTrainStep, train_step
+    gradient buffer + all-reduce + optimizer graph) -- and again after a second step.  fp16: both sides run under a loss scaler
+    started from the same scale (skipped steps included: the scale and the skip decision are part of the compared state)."""
+    from monoflex_amd.engine.trainer import GraphedTrainStep, LossScaler, train_step
     from monoflex_amd.solver import build_optimizer
     cfg = _cfg(dtype)
     b = _model(dtype)
@@ -194,14 +195,20 @@ def test_graphed_train_step_equals_the_eager_step_bitwise(split, dtype, nccl_wor
     a.load_state_dict(model_sd)
     opt_a = build_optimizer(a, cfg, capturable=True)
     opt_a.load_state_dict(opt_sd)
+    sc_a = LossScaler.for_model(a)
+    assert (sc_a is not None) == (dtype == "fp16") == (step.scaler is not None)
+    if sc_a is not None:
+        sc_a.attach(opt_a).load_state_dict(step.scaler.state_dict())
     # the twin runs the same pieces eagerly: split form = the cut backward (its pieces add the gradients of a map with several
     # consumers in another order than one autograd graph does, so cut and uncut agree to rounding, not to the bit -- checked below)
-    twin = GraphedTrainStep(a, opt_a, imgs, tg, split=True, use_graphs=False) if split else None
+    twin = GraphedTrainStep(a, opt_a, imgs, tg, split=True, use_graphs=False, scaler=sc_a) if split else None
     for it in range(2):
         loss_b = step().clone()
-        loss_a = twin() if split else train_step(a, opt_a, imgs, tg)[0]
+        loss_a = twin() if split else train_step(a, opt_a, imgs, tg, scaler=sc_a)[0]
         torch.cuda.synchronize()
         assert torch.equal(loss_a, loss_b), (it, float(loss_a), float(loss_b))
+        if sc_a is not None:
+            assert sc_a.state_dict() == step.scaler.state_dict() and torch.equal(sc_a.found_inf, step.scaler.found_inf)
         sa, sb = a.state_dict(), b.state_dict()
         diff = [k for k in sa if not torch.equal(sa[k], sb[k])]
         assert not diff, (it, diff[:8])
@@ -213,8 +220,9 @@ def test_graphed_train_step_equals_the_eager_step_bitwise(split, dtype, nccl_wor
         # cut vs uncut backward from the same state: the same gradients up to the order of a few additions
         c = _model(dtype, seed=5)
         c.load_state_dict(a.state_dict())
+        sf = float(sc_a.scale) if sc_a is not None else 1.0        # (fp16: both sides back-propagate the loss at the scaler's current scale)
         ld, _ = c(imgs, tg)
-        sum(ld.values()).backward()
+        (sum(ld.values()) * sf).backward()
         twin._forward_cut()                                     # (leaves a's gradients of one more cut pass in a.grad via the pieces)
         a.zero_grad(set_to_none=True)
         loss, thunks = twin._forward_cut()
@@ -222,7 +230,7 @@ def test_graphed_train_step_equals_the_eager_step_bitwise(split, dtype, nccl_wor
             t()
         torch.cuda.synchronize()
         ga, gc = dict(a.named_parameters()), dict(c.named_parameters())
-        tol = 2e-2 if dtype == "bf16" else 1e-4
+        tol = 2e-2 if dtype != "fp32" else 1e-4
         worst = max(float((ga[n].grad.double() - gc[n].grad.double()).norm() / gc[n].grad.double().norm().clamp(min=1e-30))
                     for n in gc if gc[n].grad is not None and float(gc[n].grad.norm()) > 1e-6)
         assert worst < tol, worst

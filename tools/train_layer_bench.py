@@ -17,13 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK = {"bf16": 2500.0, "fp32": 157.3}
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}          # dense MFMA TFLOP/s (fp16 = the bf16 rate)
 
 
 def dominant_kernel_roofline(dtype, B, device, H=96, W=320, C=64, Cout=64, reps=10):
     import torch
     from monoflex_amd import autograd as AG
-    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(dtype, torch.float32)
     g = torch.Generator(device="cpu").manual_seed(5)
     x = torch.randn(B, H, W, C, generator=g).relu().to(dt).to(device).requires_grad_()
     raw = torch.zeros(B, H, W, 32)
@@ -49,7 +49,7 @@ def dominant_kernel_roofline(dtype, B, device, H=96, W=320, C=64, Cout=64, reps=
     ms = e0.elapsed_time(e1) / reps
     M = B * H * W
     flops = 4.0 * M * 9 * C * Cout
-    es = 2 if dtype == "bf16" else 4
+    es = 4 if dtype == "fp32" else 2
     alg_bytes = M * (C * es + Cout * es + C * 4 + 32 * 4 * 2)
     # roofline of the group: the larger of its MFMA floor and its HBM floor (bytes that MUST move: x, dy, offsets in; dx, d(offsets),
     # dW out -- the d(columns) / columns intermediates the implementation materialises are not algorithmic)
