@@ -12,7 +12,7 @@ from .head.detector_head import bulid_head
 from .head.detector_predictor import make_edge_rowmap, stack_edge_fields
 
 _DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
-           "fp16": torch.float16, "float16": torch.float16}      # fp16: inference only (IEEE half activations, same MFMA rate as bf16)
+           "fp16": torch.float16, "float16": torch.float16}      # fp16: IEEE half activations, same MFMA rate as bf16 (training: under a loss scaler)
 
 
 class KeypointDetector(nn.Module):
@@ -25,7 +25,8 @@ class KeypointDetector(nn.Module):
 
     def set_compute_dtype(self, name):
         """'fp32' = parity mode (f32 MFMA, <=1e-3 on logits), 'bf16' = perf mode (bf16 MFMA, fp32 accumulate; inference and training),
-        'fp16' = inference perf mode with IEEE-half activations (same MFMA rate, three more mantissa bits: ~8x closer to the reference)."""
+        'fp16' = perf mode with IEEE-half activations (same MFMA rate, three more mantissa bits: ~8x closer to the reference in inference;
+        training in fp16 runs under engine.trainer.LossScaler, which do_train / GraphedTrainStep create by themselves)."""
         self.compute_dtype = _DTYPES[name] if isinstance(name, str) else name
         self.backbone.compute_dtype = self.compute_dtype
         return self

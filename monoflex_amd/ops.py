@@ -53,9 +53,9 @@ def _dt(dtype):
         return L.MFX_F32
     if dtype == torch.bfloat16:
         return L.MFX_BF16
-    if dtype == torch.float16:                                   # inference operators only (MFX_F16)
+    if dtype == torch.float16:
         return L.MFX_F16
-    raise TypeError("MonoFlex HIP kernels take float32, bfloat16 or (inference) float16, got %s" % dtype)
+    raise TypeError("MonoFlex HIP kernels take float32, bfloat16 or float16, got %s" % dtype)
 
 
 def _elems(dtype):

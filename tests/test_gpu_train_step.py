@@ -236,8 +236,10 @@ def test_graphed_train_step_equals_the_eager_step_bitwise(split, dtype, nccl_wor
         assert worst < tol, worst
 
 
-def test_c3_c4_per_gpu_shape_segmented_graphed_step(nccl_world1):
-    """BASELINE configs[2] / [3] per-GPU shape -- B = 8 images of 1280x384, bf16 activations, forward + 11 losses + backward + AdamW --
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_c3_c4_per_gpu_shape_segmented_graphed_step(dtype, nccl_world1):
+    """BASELINE configs[2] / [3] per-GPU shape -- B = 8 images of 1280x384, 16-bit activations (bf16; fp16 = configs[3]'s "fp16 MFMA
+    path", under the dynamic loss scaler, whose skipped steps leave AdamW's counters behind), forward + 11 losses + backward + AdamW --
     in the data-parallel launch form (four backward graphs, per-slice RCCL all-reduce on the comm stream, optimizer graph) on the
     world_size-1 RCCL group: three replayed steps, finite losses, every live parameter moves, the six dead ones never do, the learning
     rate written between replays is what the captured AdamW uses."""
@@ -249,7 +251,7 @@ def test_c3_c4_per_gpu_shape_segmented_graphed_step(nccl_world1):
     from monoflex_amd.structures.params_3d import make_train_target
     cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"))
     cfg.MODEL.PRETRAIN = False
-    cfg.MODEL.COMPUTE_DTYPE = "bf16"
+    cfg.MODEL.COMPUTE_DTYPE = dtype
     m = KeypointDetector(cfg)
     m.load_state_dict(S.synthetic_state_dict(m.state_dict(), seed=0))
     m = m.to(DEV).train()
@@ -259,8 +261,13 @@ def test_c3_c4_per_gpu_shape_segmented_graphed_step(nccl_world1):
     opt = build_optimizer(m, cfg, capturable=True)
     step = GraphedTrainStep(m, opt, imgs, tg, warmup=2, split=True)
     assert step.overlap and len(step.graphs) == 4 and step.flat.numel() > 20_000_000
+    assert (step.scaler is not None) == (dtype == "fp16")
     before = {n: p.detach().clone() for n, p in m.named_parameters()}
-    losses = [float(step()) for _ in range(2)]
+    counted = min(int(st["step"]) for st in opt.state.values())
+    losses = [float(step()) for _ in range(2 if dtype == "bf16" else 5)]
+    if step.scaler is not None:                                  # at least one of the five replays fitted the scale and was applied
+        applied = min(int(st["step"]) for st in opt.state.values()) - counted
+        assert 1 <= applied <= 5 and float(step.scaler.scale) in (2.0 ** k for k in range(3, 10)), (applied, float(step.scaler.scale))
     for g in opt.param_groups:
         g["lr"].fill_(0.0)                                       # a scheduler writing the device scalar: the next replay must not move anything
     frozen = {n: p.detach().clone() for n, p in m.named_parameters()}
