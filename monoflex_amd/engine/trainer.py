@@ -439,6 +439,8 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
     scaler = LossScaler.for_model(net, device) if torch.device(device).type == "cuda" else None     # fp16 activations: dynamic loss scaling
     if scaler is not None:
         scaler.attach(optimizer)
+        if arguments.get("loss_scaler"):                             # resumed run: continue from the checkpointed scale
+            scaler.load_state_dict(arguments["loss_scaler"])
     want_graph = bool(cfg.SOLVER.get("GRAPHED_STEP", True)) and not hasattr(model, "module") \
         and all(g.get("capturable", False) and torch.is_tensor(g["lr"]) for g in optimizer.param_groups) \
         and not any(getattr(mod, "sync_bn", False) or isinstance(mod, torch.nn.SyncBatchNorm) for mod in net.modules())
@@ -472,6 +474,8 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
             logger.info("iter: %d  loss: %.4f  lr: %.8f  %.3f s/iter", iteration, loss_v, optimizer.param_groups[0]["lr"],
                         (time.time() - t0) / (iteration - start_iter))
         if comm.get_rank() == 0 and checkpointer is not None:
+            if scaler is not None and (iteration % cfg.SOLVER.SAVE_CHECKPOINT_INTERVAL == 0 or iteration == max_iter):
+                arguments["loss_scaler"] = scaler.state_dict()             # (travels with the checkpoint's `arguments`)
             if iteration % cfg.SOLVER.SAVE_CHECKPOINT_INTERVAL == 0:
                 checkpointer.save("model_checkpoint", **arguments)
             if iteration == max_iter:

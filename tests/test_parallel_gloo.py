@@ -285,6 +285,58 @@ def test_segmented_gradient_exchange_over_two_ranks():
     assert all(torch.allclose(torch.tensor(res[0][6][n]), torch.tensor(res[1][6][n]), atol=1e-7) for n in res[0][7])
 
 
+def _scaled_step_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from monoflex_amd import parallel
+    from monoflex_amd.engine.trainer import GraphedTrainStep, LossScaler
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    m = _ToyStaged()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2, fused=True)
+    scaler = LossScaler(torch.device("cpu"), init_scale=8.0, growth_interval=2)
+    xs = torch.arange(24, dtype=torch.float32).view(4, 6) / 10
+    step = GraphedTrainStep(m, opt, xs[2 * rank:2 * rank + 2].clone(), None, use_graphs=False, scaler=scaler)
+    trace = []
+
+    def snap():
+        return {n: p.detach().clone() for n, p in m.named_parameters()}
+    for it in range(4):
+        if it == 1 and rank == 1:
+            step.images[0, 0] = float("inf")                     # ONE rank's shard overflows on the second step
+        if it == 2 and rank == 1:
+            step.images.copy_(xs[2:4])
+        before = snap()
+        loss = float(step())
+        after = snap()
+        trace.append((it, loss, float(scaler.scale), float(scaler.found_inf), int(scaler.growth_tracker),
+                      all(torch.equal(before[n], after[n]) for n in before), {n: v.tolist() for n, v in after.items()},
+                      sorted(int(st["step"]) for st in opt.state.values())))
+    out.put((rank, trace))
+    dist.destroy_process_group()
+
+
+def test_loss_scaler_takes_the_same_decision_on_every_rank():
+    """fp16's dynamic loss scaling in the data-parallel step (engine.trainer.LossScaler inside GraphedTrainStep, eager over gloo,
+    world_size 2): the gradients are checked AFTER the exchange, so an overflow in ONE rank's shard reaches both ranks -- both skip
+    that step (parameters, AdamW counters untouched; scale halved), both apply the next ones, the scale grows back after
+    `growth_interval` clean steps, and the ranks' parameters stay identical throughout."""
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    ps = [ctx.Process(target=_scaled_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted((q.get(timeout=120) for _ in ps), key=lambda t: t[0])
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (_, t0), (_, t1) = res
+    for a, b in zip(t0, t1):
+        assert a[2:6] == b[2:6] and a[7] == b[7], (a[:6], b[:6])       # scale, found_inf, tracker, skipped?, AdamW counters: same on both ranks
+        assert all(torch.equal(torch.tensor(a[6][n]), torch.tensor(b[6][n])) for n in a[6])         # replicas in lock step, bitwise
+    # step 0 applied at 8; step 1 skipped (found_inf, scale 8 -> 4, parameters and counters untouched); steps 2, 3 applied, and the
+    # second clean step in a row doubles the scale again
+    assert [(t[2], t[3], t[4], t[5]) for t in t0] == [(8.0, 0.0, 1, False), (4.0, 1.0, 0, True), (4.0, 0.0, 1, False), (8.0, 0.0, 0, False)]
+    assert [set(t[7]) for t in t0] == [{1}, {1}, {2}, {3}]
+
+
 def test_bench_respawns_itself_under_torchrun_for_n_ranks(monkeypatch):
     """`python bench.py --gpus N` outside a torchrun environment starts N ranks on 127.0.0.1 (reference engine/launch.py:23-89)."""
     import importlib

@@ -142,3 +142,46 @@ def test_do_train_loop_on_cpu(tmp_path):
     want = [cosw(2), cosw(3)] + [cfg.SOLVER.BASE_LR] * 4 + [cfg.SOLVER.BASE_LR * cfg.SOLVER.LR_DECAY] * 3
     assert lrs[1:] == pytest.approx(want, rel=1e-9), (lrs, want)
     assert float(sum(m(batches[0]["images"])[0].values())) < first
+
+
+def test_loss_scaler_arithmetic_on_cpu():
+    """engine.trainer.LossScaler (fp16 training): the scaled loss back-propagates scaled gradients, `unscale_` restores them and raises
+    `found_inf` on a non-finite entry, the fused AdamW then leaves parameters / moments / counters untouched, the scale halves on an
+    overflow and doubles after `growth_interval` clean steps; state_dict round trip."""
+    from monoflex_amd.engine.trainer import LossScaler
+    torch.manual_seed(0)
+    m = torch.nn.Linear(4, 3)
+    ref = torch.nn.Linear(4, 3)
+    ref.load_state_dict(m.state_dict())
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2, fused=True)
+    opt_ref = torch.optim.AdamW(ref.parameters(), lr=1e-2, fused=True)
+    sc = LossScaler(torch.device("cpu"), init_scale=16.0, growth_interval=2).attach(opt)
+    x = torch.randn(5, 4)
+
+    def step(poison=False):
+        loss = m(x).pow(2).sum()
+        opt.zero_grad()
+        sc.scale_loss(loss).backward()
+        if poison:
+            m.weight.grad[0, 0] = float("inf")
+        sc.unscale_([p.grad for p in m.parameters()])
+        opt.step()
+        sc.update()
+
+    def ref_step():
+        opt_ref.zero_grad()
+        ref(x).pow(2).sum().backward()
+        opt_ref.step()
+    step(); ref_step()
+    assert torch.allclose(m.weight, ref.weight, atol=1e-7) and sc.state_dict() == {"scale": 16.0, "growth_tracker": 1}
+    w, st = m.weight.detach().clone(), [(s["exp_avg"].clone(), int(s["step"])) for s in opt.state.values()]
+    step(poison=True)                                              # skipped: nothing moves, the scale halves
+    assert torch.equal(w, m.weight) and float(sc.found_inf) == 1.0 and sc.state_dict() == {"scale": 8.0, "growth_tracker": 0}
+    assert all(torch.equal(a, s["exp_avg"]) and n == int(s["step"]) for (a, n), s in zip(st, opt.state.values()))
+    step(); ref_step()
+    step(); ref_step()                                             # second clean step in a row: the scale doubles
+    assert torch.allclose(m.weight, ref.weight, atol=1e-6) and sc.state_dict() == {"scale": 16.0, "growth_tracker": 0}
+    sc2 = LossScaler(torch.device("cpu"))
+    sc2.load_state_dict({"scale": 4.0, "growth_tracker": 7})
+    assert sc2.state_dict() == {"scale": 4.0, "growth_tracker": 7}
+    assert LossScaler.for_model(m) is None                         # (only an fp16 model gets one)
