@@ -50,7 +50,7 @@ const char* mfx_last_error(void);
  * Unknown names return MFX_ERR_ARG. */
 int mfx_set_option(const char* name, int value);
 /* Dispatch counters since process start, so a test can assert WHICH kernel variant a call took: "dcn_bt_fused" = launches of the
- * fused sample + weight-gradient kernel of mfx_dcn_backward_v2 (selected for bf16, C = Cout = 64, W % 32 == 0 and at least
+ * fused sample + weight-gradient kernel of mfx_dcn_backward_v2 (selected for bf16 / fp16, C = Cout = 64, W % 32 == 0 and at least
  * option "dcn_bt_fuse_min_chunks" (default 1024) 32-pixel chunks).  Unknown names return MFX_ERR_ARG (negative). */
 long mfx_get_counter(const char* name);
 
@@ -107,7 +107,7 @@ typedef struct {
     int32_t kh, kw, stride, pad_h, pad_w, dil_w;
     int32_t Ho, Wo;
     int32_t M;                /* rows: B*Ho*Wo, or the rowmap length                            */
-    int32_t Cout;             /* valid output channels (multiple of 4 for f32 out, 8 for bf16)  */
+    int32_t Cout;             /* valid output channels (multiple of 4 for f32 out, 8 for bf16 / fp16)  */
     int32_t Cout_pad;         /* weight rows; multiple of 16, and of 64 when > 32                */
     int32_t K_pad;            /* multiple of 64 bytes of K                                      */
     int32_t ldy, ldres;
@@ -144,10 +144,10 @@ int mfx_cat_conv1x1_nhwc(const mfx_cat_desc* d, void* stream);
 typedef struct {
     const void* x; const float* offmask; const void* w; const float* scale; const float* shift; void* y;
     const void* w_frag;       /* optional fragment-major weights (see mfx_conv_desc.w_frag): enables the 2nd-generation kernel */
-    int32_t B, H, W, C;       /* C: power of two >= 64 (bf16) / 16 (f32) elements                */
+    int32_t B, H, W, C;       /* C: power of two >= 64 (16-bit) / 16 (f32) elements                  */
     int32_t kh, kw, stride, pad, dil;
     int32_t Ho, Wo, Cout, Cout_pad, K_pad, ldy, act, dtype;
-    const void* w_frag_f16;   /* optional (bf16 mode): the fragment-major weights as IEEE fp16: enables the LDS-patch kernel,
+    const void* w_frag_f16;   /* optional (16-bit modes): the fragment-major weights as IEEE fp16: enables the LDS-patch kernel,
                                  which samples and multiplies in fp16 (3x3, stride 1, pad 1, C % 64 == 0)            */
     void* workspace;          /* optional fp32 scratch for split-K on small maps (>= 9*M*Cout_pad*4 bytes to allow every split) */
     int64_t workspace_bytes;
