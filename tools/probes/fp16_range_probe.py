@@ -61,7 +61,3 @@ for r in sorted(rec, key=lambda r: -r[4])[:8]:
     print("  %-28s %-22s max %.3e finite %s  below-normal %.3f  median %.2e" % r)
 for n, g in bad[:10]:
     print("non-finite parameter gradient:", n)
-# forward range
-acts = {}
-def fhook(mod, inp, out, name=None):
-    pass
