@@ -297,21 +297,104 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
 // packs chunk b, which belongs to descriptor d with prefix[d] <= b < prefix[d+1] (prefix counts CHUNKS; wave-uniform binary
 // search over ~150 descriptors, descriptor fetched once per workgroup); same element rule as pack_conv_weight_kernel.
 // (One launch per operand was 148 launches of ~5 us per step; a per-element search made the single launch 330 us.)
+//
+// The chunk's source values go through LDS: an operand row is a PERMUTATION of parameter memory -- forward rows interleave
+// (channel, tap) -> (tap, channel), data-gradient rows gather one input channel's taps from every output channel, 9 floats out of
+// every Cin * 9 -- so element-wise gathers touched one cache line per lane (mode 1) or a ninth of each line per pass (mode 0), and
+// every line was fetched once per tap: 308 us per step for 84 MB of parameters.  Here the workgroup first copies the parameter
+// range its rows need into LDS with consecutive lanes on consecutive addresses (whole rows for mode 0; for mode 1 the run of
+// (rows x taps) floats of every output channel), then every lane forms 8 consecutive operand elements from LDS and stores them as
+// 16-byte pieces (packed copy and fragment-major copy alike).  Rows that do not fit the staging buffer take the element-wise path.
 constexpr int PACK_CHUNK = 2048;
+constexpr int PACK_STAGE = 10240;                              // floats of LDS staging (two rows of a 512-channel 3x3 operand + slack)
+template <typename T> __device__ __forceinline__ void pack_store8(T* p, const float (&v)[8]) { *reinterpret_cast<u32x4*>(p) = ElemTraits<T>::pack(v); }
+template <> __device__ __forceinline__ void pack_store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv_weight_batched_kernel(const mfx_pack_desc* __restrict__ descs, const long long* __restrict__ prefix, int n) {
     constexpr int E = ElemTraits<T>::ELEMS;
+    __shared__ float stage[PACK_STAGE];
+    __shared__ int below[4];
     const long chunk = blockIdx.x;
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if ((long)prefix[mid] <= chunk) lo = mid; else hi = mid - 1;
+    // descriptor of this chunk = (number of prefix entries <= chunk) - 1: every lane tests one entry and the four waves' ballots are
+    // counted -- ONE round trip to the table instead of the eight dependent ones of a binary search, which were most of a workgroup's
+    // life (20 k workgroups of ~10 us on 1024 resident slots)
+    int cnt = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int idx = base + (int)threadIdx.x;
+        cnt += __popcll(__ballot(idx < n && (long)prefix[idx] <= chunk));
     }
+    if ((threadIdx.x & 63) == 0) below[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    const int lo = below[0] + below[1] + below[2] + below[3] - 1;
     const mfx_pack_desc d = descs[lo];
     const long total = (long)d.rows_pad * d.K_pad, j0 = (chunk - (long)prefix[lo]) * PACK_CHUNK;
+    const long j1 = j0 + PACK_CHUNK < total ? j0 + PACK_CHUNK : total;
     const int taps = d.kh * d.kw;
     T* packed = reinterpret_cast<T*>(d.packed);
     T* frag = reinterpret_cast<T*>(d.frag);
+    // operand rows of this chunk and the parameter rows behind them (mode 0: output channels, mode 1: input channels)
+    const int r0 = (int)(j0 / d.K_pad), r1 = (int)((j1 - 1) / d.K_pad);
+    const int src_rows = d.mode == 0 ? d.Cout : d.Cin;
+    const int rv = (r1 < src_rows ? r1 : src_rows - 1) - r0 + 1;          // valid rows (<= 0: the chunk is all padding)
+    const int run = rv > 0 ? rv * taps : 0;                                // mode 1: floats per output channel
+    const long need = rv <= 0 ? 0 : (d.mode == 0 ? (long)rv * d.Cin * taps : (long)d.Cout * run);
+    const bool staged = need <= PACK_STAGE && (d.K_pad & 7) == 0;
+    if (staged && need > 0) {
+        // (eight loads in flight per lane before the first LDS write: one load per iteration left every workgroup waiting on ~16
+        // dependent round trips)
+        const float* src = d.w + (size_t)r0 * (d.mode == 0 ? d.Cin * taps : taps);
+        for (int base = threadIdx.x; base < (int)need; base += 256 * 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256;
+                t[u] = 0.f;
+                if (i < (int)need) {
+                    if (d.mode == 0) t[u] = src[i];
+                    else { const int o = i / run, rem = i - o * run; t[u] = src[(size_t)o * d.Cin * taps + rem]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256;
+                if (i < (int)need) stage[i] = t[u];
+            }
+        }
+    }
+    __syncthreads();
+    if (staged) {
+        const long j = j0 + (long)threadIdx.x * 8;                             // 8 consecutive elements: one row, one tap (ck % E == 0, K_pad % 8 == 0)
+        if (j >= j1) return;
+        const int nrow = (int)(j / d.K_pad), k = (int)(j - (long)nrow * d.K_pad);
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 8; h += E) {                                       // (fp32 operands: ck is a multiple of 4 only, so per 4-element half)
+            const int kk = k + h, tap = kk / d.ck, cc = kk - tap * d.ck;
+#pragma unroll
+            for (int e = 0; e < E && e < 8; ++e) {
+                float x = 0.f;
+                if (tap < taps && nrow - r0 < rv) {
+                    if (d.mode == 0) { if (cc + e < d.Cin) x = stage[((nrow - r0) * d.Cin + cc + e) * taps + tap]; }
+                    else if (cc + e < d.Cout) x = stage[(cc + e) * run + (nrow - r0) * taps + (taps - 1 - tap)];
+                }
+                v[h + e] = x;
+            }
+        }
+        pack_store8<T>(packed + j, v);
+        if (frag) {
+#pragma unroll
+            for (int h = 0; h < 8; h += E) {
+                const int kk = k + h;
+                const size_t f = (((size_t)(nrow >> 4) * (d.K_pad / (4 * E)) + kk / (4 * E)) * 4 + (kk % (4 * E)) / E) * (16 * E) + (nrow & 15) * E;
+                if (E == 8) pack_store8<T>(frag + f, v);
+                else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(frag) + f) = f32x4{v[h], v[h + 1], v[h + 2], v[h + 3]};
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < PACK_CHUNK / 256; ++u) {
         const long j = j0 + u * 256 + threadIdx.x;

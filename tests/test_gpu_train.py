@@ -361,6 +361,56 @@ def test_packed_conv_operands_follow_the_parameter():
     assert len(AG._PACKS.entries) <= n_before - 3                  # conv.weight: forward + data-gradient operands; w2: forward
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+def test_batched_operand_packing_equals_the_single_operand_kernel(dt):
+    """mfx_pack_conv_weights_batched (one launch for every conv operand of a step; chunks staged through LDS) against
+    mfx_pack_conv_weight (one element per lane) on the operand shapes of the network, forward and data-gradient forms: the packed
+    matrix and the fragment-major copy BITWISE, padding rows / columns included; the descriptors are laid out as the training path
+    lays them out (monoflex_amd.autograd._PackRegistry)."""
+    import numpy as np
+    from monoflex_amd import lib as L, ops
+    lib_ = L.load()
+    dtype = DT[dt]
+    E = 4 if dt == "fp32" else 8
+    g = torch.Generator().manual_seed(5)
+    chunk = lib_.mfx_pack_chunk_elems()
+    shapes = [(64, 64, 3, 0), (64, 64, 3, 1), (27, 64, 3, 0), (64, 27, 3, 1), (256, 64, 3, 0), (256, 64, 3, 1), (512, 512, 3, 0), (512, 512, 3, 1),
+              (128, 64, 3, 0), (128, 64, 3, 1), (64, 128, 1, 0), (64, 128, 1, 1), (3, 256, 1, 0), (3, 256, 1, 1), (20, 256, 1, 0), (32, 16, 3, 0),
+              (32, 16, 3, 1), (1024, 1024, 3, 0), (16, 16, 1, 0)]
+    items, descs, prefix, total = [], [], [0], 0
+    for cout, cin, k, mode in shapes:
+        w = torch.randn(cout, cin, k, k, generator=g).to(DEV)
+        rows, ck_src = (cout, cin) if mode == 0 else (cin, cout)
+        ck = max(E, (ck_src + E - 1) // E * E)
+        if k > 1:
+            ck = 1 << (ck - 1).bit_length()                      # channels per tap: a power of two for k > 1 (lookup's rule)
+        K_pad = (k * k * ck + 8 * E - 1) // (8 * E) * (8 * E)
+        cp = ops.cout_pad((rows + 15) // 16 * 16)
+        bufs = [torch.full((cp, K_pad), float("nan"), dtype=dtype, device=DEV) for _ in range(4)]       # batched packed / frag, single packed / frag
+        d = L.PackDesc()
+        d.w, d.packed, d.frag = w.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr()
+        d.Cout, d.Cin, d.kh, d.kw, d.mode, d.rows_pad, d.K_pad, d.ck = cout, cin, k, k, mode, cp, K_pad, ck
+        descs.append(bytes(d))
+        total += (cp * K_pad + chunk - 1) // chunk
+        prefix.append(total)
+        items.append((w, bufs, (cout, cin, k, mode, cp, K_pad, ck)))
+    dt_t = torch.from_numpy(np.frombuffer(b"".join(descs), dtype=np.uint8).copy()).to(DEV)
+    pt = torch.tensor(prefix, dtype=torch.int64).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib_.mfx_pack_conv_weights_batched(dt_t.data_ptr(), pt.data_ptr(), len(items), total, L.MFX_F32 if dt == "fp32" else (L.MFX_BF16 if dt == "bf16" else L.MFX_F16), st),
+            "mfx_pack_conv_weights_batched")
+    for w, bufs, (cout, cin, k, mode, cp, K_pad, ck) in items:
+        L.check(lib_.mfx_pack_conv_weight(w.data_ptr(), cout, cin, k, k, mode, bufs[2].data_ptr(), bufs[3].data_ptr(), cp, K_pad, ck,
+                                          L.MFX_F32 if dt == "fp32" else (L.MFX_BF16 if dt == "bf16" else L.MFX_F16), st), "mfx_pack_conv_weight")
+    torch.cuda.synchronize()
+    for w, bufs, meta in items:
+        view = torch.int32 if dt == "fp32" else torch.int16
+        assert torch.equal(bufs[0].view(view), bufs[2].view(view)), ("packed", meta)
+        assert torch.equal(bufs[1].view(view), bufs[3].view(view)), ("frag", meta)
+        assert not torch.isnan(bufs[0].float()).any() and not torch.isnan(bufs[1].float()).any(), meta       # every element was written
+        assert float(bufs[0].float().abs().max()) > 0
+
+
 def test_maxpool_and_upsample_grads():
     from monoflex_amd import autograd as AG
     g = torch.Generator().manual_seed(5)
