@@ -34,6 +34,7 @@ int mfx_internal_conv_wgrad(const void* x, const void* dy, float* dw, int B, int
                             void* workspace, size_t workspace_bytes, int direct);
 
 int mfx_internal_wgrad_slab_sum(const float* ws, int nslab, int Cout, int Ck, int kh, int kw, float* dw_oihw, void* stream);
+int mfx_internal_colsum_add(const void* x, float* out, long M, int C, int ld, int dtype, void* stream);      // train_kernels.hip: sums ADDED into a zeroed `out`
 
 int g_opt_dcn_bt_fuse_blocks = 170; // option "dcn_bt_fuse_blocks": workgroups per tap group of the fused kernel
 int g_opt_dcn_bt_fuse_wgrad = 1;   // option "dcn_bt_fuse_wgrad": 64 -> 64 bf16 layers accumulate grad_weight inside the sample kernel (no columns in memory)
@@ -390,8 +391,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_dx_unfix_kernel(const unsigned lo
 
 // weight (Cout,C,9) fp32 -> wT[K][Cout] (k = tap*C + c), compute dtype: the B operand of d(columns) = dy x W
 template <typename T>
-__global__ void bt_pack_weight_t(const float* __restrict__ w, T* __restrict__ wT, int Cout, int C, int* __restrict__ far_count) {
+__global__ void bt_pack_weight_t(const float* __restrict__ w, T* __restrict__ wT, int Cout, int C, int* __restrict__ far_count, float* __restrict__ dbias) {
     if (blockIdx.x == 0 && threadIdx.x < 2) far_count[threadIdx.x] = 0;       // the far-corner counter of this call (was a separate 8-byte fill launch)
+    if (blockIdx.x == 0) for (int o = threadIdx.x; o < Cout; o += blockDim.x) dbias[o] = 0.f;      // ... and the zeros the bias-gradient sums are added into (another one)
     const long total = (long)9 * C * Cout;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int o = (int)(i % Cout);
@@ -710,7 +712,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     const int K = 9 * C;
     {
         const long total = (long)K * Cout;
-        hipLaunchKernelGGL(bt_pack_weight_t<T>, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, weight, wT, Cout, C, cnt);
+        hipLaunchKernelGGL(bt_pack_weight_t<T>, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, weight, wT, Cout, C, cnt, dbias);
     }
     // d(columns)[m][k] = sum_o dy[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM on the matrix cores
     mfx_conv_desc cd = {};
@@ -776,7 +778,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     if (!fused_wgrad) rc = mfx_internal_conv_wgrad(col, dy, dweight, 1, 1, (int)M, K, C, 3, 3, 1, 0, 0, 1, (int)M, Cout, Cout, dt, 1, C, Cout, stream, 1,
                                  ws + L.wg, L.total - L.wg, 1);
     if (rc) return rc;
-    return mfx_colsum(dy, dbias, M, Cout, Cout, dt, stream);                    // grad_bias[o] = sum_m dy[m][o]
+    return mfx_internal_colsum_add(dy, dbias, M, Cout, Cout, dt, stream);        // grad_bias[o] = sum_m dy[m][o] (dbias zeroed by bt_pack_weight_t)
 }
 
 }  // namespace mfx

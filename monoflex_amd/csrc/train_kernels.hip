@@ -1194,10 +1194,17 @@ extern "C" int mfx_pack_conv_weights_batched(const mfx_pack_desc* descs_dev, con
 
 static int bn_rows_per_block(long M, int C, int dtype, int owners);
 
+// library-internal (dcn_bwd_tile.hip): column sums ADDED into `out`, which an earlier kernel of the caller has zeroed
+int mfx_internal_colsum_add(const void* x, float* out, long M, int C, int ld, int dtype, void* stream);
+
 extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int dtype, void* stream) {
     if (!x || !out) return mfx_fail(MFX_ERR_ARG, "colsum: null pointer");
+    MFX_HIP_CHECK(mfx::zero_async(out, (size_t)C * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
+    return mfx_internal_colsum_add(x, out, M, C, ld, dtype, stream);
+}
+
+int mfx_internal_colsum_add(const void* x, float* out, long M, int C, int ld, int dtype, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    MFX_HIP_CHECK(mfx::zero_async(out, (size_t)C * sizeof(float), st));
     if (M == 0) return MFX_OK;
     {
         const int E = dtype == MFX_F32 ? 4 : 8;
