@@ -22,6 +22,7 @@ ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--reps", type=int, default=6)
 ap.add_argument("--std", type=float, default=1.5)
 ap.add_argument("--opts", default="")
+ap.add_argument("--eager", action="store_true", help="plain launches, no hipGraph (rocprofv3 --pmc passes: counter collection does not survive a graph capture)")
 a = ap.parse_args()
 
 from monoflex_amd import autograd as AG, lib, ops
@@ -38,6 +39,15 @@ def timed(fn, what):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
+    if a.eager:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print("%s opts[%s] (eager): %.1f us" % (what, a.opts, e0.elapsed_time(e1) * 1e3 / a.reps))
+        return
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):

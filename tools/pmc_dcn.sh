@@ -12,7 +12,7 @@ for shp in "8 96 320 64 64" "8 48 160 128 128"; do
   i=0
   for c in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_VALU" "TA_TA_BUSY_sum TA_BUSY_avr" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/p$i -- python $R/tools/one_op.py dcnmod $shp --reps 4 > $OUT/p$i.log 2>&1
+    timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/p$i -- python $R/tools/one_op.py dcnmod $shp --reps 4 --eager > $OUT/p$i.log 2>&1
   done
   echo "== DCN module (offset conv + DCN + BN + ReLU), B H W Cin Cout = $shp" >> $R/gpurun_out/${TAG}_dcn_pmc.txt
   python $R/tools/pmc_summary.py $OUT >> $R/gpurun_out/${TAG}_dcn_pmc.txt 2>&1

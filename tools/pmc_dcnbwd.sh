@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the DCN backward group (64->64 @ 96x320, B=8, bf16): FETCH_SIZE and WRITE_SIZE in separate --pmc passes (no tracing),
 # summed over the group's kernels per backward call.  Writes gpurun_out/<tag>_dcnbwd_pmc.{txt,csv} and <tag>_dcnbwd_traffic.json.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_dcnbwd
 rm -rf $OUT; mkdir -p $OUT
@@ -9,13 +9,13 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $c --output-format csv -d $OUT/p$i -- python $R/tools/one_op.py dcnbwd 8 96 320 64 64 --reps 4 > $OUT/p$i.log 2>&1
+  timeout 150 rocprofv3 --pmc $c --output-format csv -d $OUT/p$i -- python $R/tools/one_op.py dcnbwd 8 96 320 64 64 --reps 4 --eager > $OUT/p$i.log 2>&1
 done
 python $R/tools/pmc_summary.py $OUT > $R/gpurun_out/${TAG}_dcnbwd_pmc.txt
 python - <<PY
 import csv, glob, json, collections
-group = ("conv_igemm_kernel", "dcn_bwd_sample_kernel", "dcn_bwd_tile_kernel", "dcn_bwd_far_kernel", "conv_wgrad_mfma_kernel", "wgrad_reduce_kernel",
-         "colsum_chunk_kernel", "bt_pack_weight_t", "zero_fill_kernel")
+group = ("conv_igemm_kernel", "dcn_bwd_sample_kernel", "dcn_bwd_sample_wgrad_kernel", "dcn_bwd_tile_kernel", "dcn_bwd_far_kernel", "conv_wgrad_mfma_kernel",
+         "wgrad_reduce_kernel", "colsum_chunk_kernel", "bt_pack_weight_t", "zero_fill_kernel")
 rows = []
 for f in sorted(glob.glob("$OUT/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $c --output-format csv -d $OUT/p$i -- python $R/tools/one_op.py heads --reps 4 > $OUT/p$i.log 2>&1
+  timeout 150 rocprofv3 --pmc $c --output-format csv -d $OUT/p$i -- python $R/tools/one_op.py heads --reps 4 --eager > $OUT/p$i.log 2>&1
 done
 python $R/tools/pmc_summary.py $OUT > $R/gpurun_out/${TAG}_heads_pmc.txt
 # raw per-dispatch rows of the heads kernel only (small): the CSV the bench's `traffic` comes from

@@ -63,17 +63,22 @@ def dominant_kernel_roofline(dtype, B, device, H=96, W=320, C=64, Cout=64, reps=
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype], 4)}
     traffic = traffic_source = None
     try:                                                       # PMC pass of the same group (tools/pmc_dcnbwd.sh), committed with its raw CSV
-        t = json.load(open(os.path.join(ROOT, "profiles", "r02_dcnbwd_traffic.json")))
-        if t.get("dtype") == dtype and t.get("batch") == B and (H, W, C, Cout) == (96, 320, 64, 64):
-            traffic, traffic_source = int(t["traffic_bytes"]), t["source"]
+        for tag in ("r03", "r02"):                             # the newest committed measurement
+            f = os.path.join(ROOT, "profiles", tag + "_dcnbwd_traffic.json")
+            if not os.path.exists(f):
+                continue
+            t = json.load(open(f))
+            if t.get("dtype") == dtype and t.get("batch") == B and (H, W, C, Cout) == (96, 320, 64, 64):
+                traffic, traffic_source = int(t["traffic_bytes"]), t["source"]
+            break
     except (OSError, ValueError, KeyError):
         pass
     roof.update({"kernel": "DCNv2 backward group (d(columns) GEMM, dcn_bwd_sample, dcn_bwd_tile, dcn_bwd_far, weight-gradient GEMM), %d->%d @ %dx%d, B=%d"
                            % (C, Cout, H, W, B),
                  "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops,
                  "algorithmic_bytes_per_launch": alg_bytes, "hbm_floor_ms": round(hbm_floor_ms, 4), "mfma_floor_ms": round(mfma_floor_ms, 4),
-                 "materialised_bytes_per_launch": int(2 * 2 * M * 9 * C * es),
-                 "note": "the group writes and re-reads d(columns) and the columns (2 x M x 9C each): its own traffic is ~6x the algorithmic bytes"})
+                 "materialised_bytes_per_launch": int(3 * M * 9 * C * es),
+                 "note": "the group writes d(columns) (M x 9C) once and reads it twice (fused sample + weight-gradient kernel, tile kernel); the columns are never materialised on this shape"})
     return roof
 
 
