@@ -31,7 +31,12 @@ extern "C" {
 
 /* element types of activations / packed weights */
 enum { MFX_F32 = 0, MFX_BF16 = 1, MFX_F16 = 2 /* IEEE half: every operator that takes bf16 takes it (the fused heads and the LDS-patch DCN forward are inference
-                                            * kernels in both); fp16 TRAINING needs loss scaling on the host side (engine/trainer.py) */ };
+                                            * kernels in both); fp16 TRAINING needs loss scaling on the host side (engine/trainer.py) */,
+       MFX_F16X2 = 3 /* split precision (inference GEMM kernels: conv2d, cat_conv1x1, dcn, heads_fused): activations are plain fp32 in memory (pass
+                      * MFX_F32 to every other operator), each MFMA operand element is the pair fp16(x), fp16(x - fp16(x)) and a product is
+                      * hi.hi + hi.lo + lo.hi + lo.lo on v_mfma_f32_16x16x32_f16 with fp32 accumulate: fp32-grade results (the reference computes
+                      * in fp32: src/cuda/dcn_v2_cuda.cu:58) at 4x the matrix rate of MFX_F32.  Weights arrive pre-split: every 16-byte chunk of 4
+                      * fp32 values of the MFX_F32 layouts is replaced by [4 hi halves | 4 lo halves] of the same 4 values. */ };
 /* epilogue activations */
 enum { MFX_ACT_NONE = 0, MFX_ACT_RELU = 1, MFX_ACT_LEAKY = 2 /* slope 0.01 */, MFX_ACT_DCN_OFFMASK = 3 /* sigmoid on ch 18..26 */ };
 /* error codes */
@@ -188,6 +193,8 @@ typedef struct {
     float* planar;            /* optional fp32 [B][planar_c][H*W]: branch 0's channels again, class-planar */
     int32_t B, H, W, nbranch, K_pad, ld_out, dtype, planar_c;
     int32_t ch_off[16]; int32_t c_out[16];
+    float w2_scale[16];       /* per branch: the 1x1 sums are multiplied by this before the bias (0 = 1): MFX_F16X2 weights are packed
+                               * times a power of two so that their lo halves are normal fp16 numbers, and un-scaled here */
 } mfx_heads_desc;
 int mfx_heads_fused(const mfx_heads_desc* d, void* stream);
 

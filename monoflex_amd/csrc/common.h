@@ -96,6 +96,38 @@ template <> struct ElemTraits<half_t> {
     }
 };
 
+// Split-precision element ("f16x2", parity-grade perf mode): the value lives in HBM as plain fp32 (every non-GEMM kernel is the fp32
+// one), and becomes an MFMA operand as a PAIR of IEEE halves hi = fp16(x), lo = fp16(x - hi): x = hi + lo to ~22 mantissa bits
+// (fp16 subnormals are honoured by v_mfma_f32_16x16x32_f16 on gfx950: tools/probes/split_probe.hip).  A 16-byte operand chunk holds
+// the same 4 elements as the fp32 chunk it replaces -- [h0 h1 h2 h3 | l0 l1 l2 l3] -- so every tile, patch and fragment layout of the
+// fp32 instantiation carries over byte for byte; the conversion happens once, where an operand is written to LDS (activations) or
+// packed on the host (weights).  One K chunk is two fp16 MFMAs: a.b and a.swap(b), swap = exchange of the hi and lo halves of the
+// lane's chunk (a register renaming) -> hi.hi + lo.lo + hi.lo + lo.hi = the full product, fp32 accumulate: 32 matrix-pipe cycles per
+// 16 K elements against 128 for v_mfma_f32_16x16x4_f32.
+struct f32s_t { float v; };
+template <> struct ElemTraits<f32s_t> {
+    static constexpr int ELEMS = 4;
+    static constexpr int DT = 3;
+    __device__ static __forceinline__ float load(const f32s_t* p) { return p->v; }
+    __device__ static __forceinline__ void store(f32s_t* p, float v) { p->v = v; }
+    __device__ static __forceinline__ float round(float v) { return v; }
+    __device__ static __forceinline__ void unpack(const u32x4& c, float* f) { ElemTraits<float>::unpack(c, f); }
+    __device__ static __forceinline__ u32x4 pack(const float* f) { return ElemTraits<float>::pack(f); }
+};
+
+// value chunk (as loaded from HBM / produced in registers) -> MFMA operand chunk (as written to LDS / fed to the matrix core)
+template <typename T> __device__ __forceinline__ u32x4 lds_operand(const u32x4& c) { return c; }
+template <> __device__ __forceinline__ u32x4 lds_operand<f32s_t>(const u32x4& c) {
+    const float x0 = __uint_as_float(c.x), x1 = __uint_as_float(c.y), x2 = __uint_as_float(c.z), x3 = __uint_as_float(c.w);
+    const f16x2 h01 = __builtin_convertvector((f32x2){x0, x1}, f16x2), h23 = __builtin_convertvector((f32x2){x2, x3}, f16x2);
+    const f16x2 l01 = __builtin_convertvector((f32x2){x0 - (float)h01[0], x1 - (float)h01[1]}, f16x2);
+    const f16x2 l23 = __builtin_convertvector((f32x2){x2 - (float)h23[0], x3 - (float)h23[1]}, f16x2);
+    u32x4 r;
+    r.x = __builtin_bit_cast(uint32_t, h01); r.y = __builtin_bit_cast(uint32_t, h23);
+    r.z = __builtin_bit_cast(uint32_t, l01); r.w = __builtin_bit_cast(uint32_t, l23);
+    return r;
+}
+
 // ---- MFMA step over one 16-byte K-chunk per lane -------------------------------------------
 // A fragment: lane l holds row (l&15), k-group (l>>4): 8 bf16 or 4 f32 consecutive in K.
 // D layout (both dtypes): col = lane&15, row = (lane>>4)*4 + reg.
@@ -114,6 +146,12 @@ template <> __device__ __forceinline__ void mma_chunk<float>(const u32x4& a, con
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+template <> __device__ __forceinline__ void mma_chunk<f32s_t>(const u32x4& a, const u32x4& b, f32x4& acc) {
+    const u32x4 bs = {b.z, b.w, b.x, b.y};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bs), acc, 0, 0, 0);
 }
 
 // activation codes shared with the host (include/monoflex_hip.h)

@@ -47,6 +47,7 @@ template <typename T, int WN, int FN, int WK = 1> struct HaloSmem {
 // two output values as they will be stored (identity for fp32, one packed convert for bf16)
 template <typename TO> __device__ __forceinline__ f32x2 halo_round2(float a, float b);
 template <> __device__ __forceinline__ f32x2 halo_round2<float>(float a, float b) { return f32x2{a, b}; }
+template <> __device__ __forceinline__ f32x2 halo_round2<f32s_t>(float a, float b) { return f32x2{a, b}; }
 template <> __device__ __forceinline__ f32x2 halo_round2<bf16_t>(float a, float b) {
     const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2));
     return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 const int idx = base + u * NT + tid;
-                if (idx < nchunks) *reinterpret_cast<u32x4*>(patch + (idx >> lgCPP) * PS + (idx & (CPP - 1)) * 16) = pr[u];
+                if (idx < nchunks) *reinterpret_cast<u32x4*>(patch + (idx >> lgCPP) * PS + (idx & (CPP - 1)) * 16) = lds_operand<T>(pr[u]);
             }
         }
 
@@ -441,7 +442,7 @@ static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st) {
     if (g_opt_halo == 0) return 0;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_h != 1 || d->pad_w != 1 || d->dil_w != 1) return 0;
     if (d->rowmap || d->x_pixstride != d->Ck || d->Ho != d->H || d->Wo != d->W || d->M != d->B * d->H * d->W) return 0;
-    const int elems = d->dtype == MFX_F32 ? 4 : 8;
+    const int elems = (d->dtype == MFX_F32 || d->dtype == MFX_F16X2) ? 4 : 8;
     if (d->Ck < 2 * elems || d->K_pad < 9 * d->Ck) return 0;
     const int N = d->Cout_pad;
     const int px_tiles = d->B * cdivh(d->H, kHaloRows) * cdivh(d->W, 16);
@@ -469,6 +470,7 @@ static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st) {
     }
     int rc;
     if (d->dtype == MFX_F32) rc = halo_variant<float, float>(v, d, st);
+    else if (d->dtype == MFX_F16X2) rc = halo_variant<f32s_t, f32s_t>(v, d, st);
     else if (d->dtype == MFX_F16) rc = d->out_dtype == MFX_F16 ? halo_variant<half_t, half_t>(v, d, st) : halo_variant<half_t, float>(v, d, st);
     else if (d->out_dtype == MFX_BF16) rc = halo_variant<bf16_t, bf16_t>(v, d, st);
     else rc = halo_variant<bf16_t, float>(v, d, st);

@@ -57,7 +57,7 @@ template <typename T, int BM, int NT, int KC> struct ConvALoader {
     }
     __device__ __forceinline__ void store(char* As) const {
 #pragma unroll
-        for (int i = 0; i < R; ++i) *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * kRowBytes + c * 16) = regs[i];
+        for (int i = 0; i < R; ++i) *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * kRowBytes + c * 16) = lds_operand<T>(regs[i]);
     }
 };
 
@@ -90,7 +90,7 @@ template <typename T, int BM, int NT, int KC> struct CatALoader {
     }
     __device__ __forceinline__ void store(char* As) const {
 #pragma unroll
-        for (int i = 0; i < R; ++i) *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * kRowBytes + c * 16) = regs[i];
+        for (int i = 0; i < R; ++i) *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * kRowBytes + c * 16) = lds_operand<T>(regs[i]);
     }
 };
 
@@ -167,7 +167,7 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
 #pragma unroll
             for (int e = 0; e < ELEMS; ++e)
                 o[e] = cw[i][0] * v[0][e] + cw[i][1] * v[1][e] + cw[i][2] * v[2][e] + cw[i][3] * v[3][e];
-            *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * kRowBytes + c * 16) = ElemTraits<T>::pack(o);
+            *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * kRowBytes + c * 16) = lds_operand<T>(ElemTraits<T>::pack(o));
         }
     }
 };
@@ -447,8 +447,9 @@ extern "C" long mfx_get_counter(const char* name) {
 
 extern "C" int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "conv2d: null pointer");
-    const int elems = d->dtype == MFX_F32 ? 4 : 8;
-    if (d->dtype != MFX_F32 && d->dtype != MFX_BF16 && d->dtype != MFX_F16) return mfx_fail(MFX_ERR_ARG, "conv2d: bad dtype");
+    const bool f32like = d->dtype == MFX_F32 || d->dtype == MFX_F16X2;      // fp32 storage (F16X2: split-precision MFMA operands)
+    const int elems = f32like ? 4 : 8;
+    if (!f32like && d->dtype != MFX_BF16 && d->dtype != MFX_F16) return mfx_fail(MFX_ERR_ARG, "conv2d: bad dtype");
     if (d->dtype == MFX_F16 && d->out_dtype != MFX_F16 && d->out_dtype != MFX_F32)
         return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: fp16 input needs fp16 or fp32 output");
     if (!is_pow2(d->Ck) || d->Ck < elems) return mfx_fail(MFX_ERR_ARG, "conv2d: Ck must be a power of two >= one 16-byte chunk");
@@ -457,9 +458,9 @@ extern "C" int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream) {
     if (d->Cout % oe != 0 || d->Cout > d->Cout_pad) return mfx_fail(MFX_ERR_ARG, "conv2d: Cout must be a multiple of the output chunk and <= Cout_pad");
     if (d->kh * d->kw > 64 || d->kw > 8) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: kernel too large");
     if (d->M <= 0) return MFX_OK;
-    if (d->dtype != MFX_F32 && d->out_dtype == MFX_F32 && d->res) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: residual needs out_dtype == dtype");
+    if (!f32like && d->out_dtype == MFX_F32 && d->res) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: residual needs out_dtype == dtype");
     if (d->dtype == MFX_BF16 && d->out_dtype == MFX_F16) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: bf16 input needs bf16 or fp32 output");
-    if (d->dtype == MFX_F32 && d->out_dtype != MFX_F32) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: f32 input needs f32 output");
+    if (f32like && d->out_dtype != MFX_F32) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: f32 input needs f32 output");
     if (d->stats && (!d->stats_done || d->res || d->act != MFX_ACT_NONE || d->rowmap))
         return mfx_fail(MFX_ERR_ARG, "conv2d: output statistics need stats_done and a plain (no residual / activation / row map) epilogue");
     if (d->stats_done) *d->stats_done = 0;
@@ -487,6 +488,7 @@ extern "C" int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream) {
         if (d->out_dtype != MFX_F32) return mfx_fail(MFX_ERR_UNSUPPORTED, "conv2d: f32 input needs f32 output");
         return dispatch_conv<float, float>(d, g, ep, st);
     }
+    if (d->dtype == MFX_F16X2) return dispatch_conv<f32s_t, f32s_t>(d, g, ep, st);
     if (d->dtype == MFX_F16) {
         if (d->out_dtype == MFX_F16) return dispatch_conv<half_t, half_t>(d, g, ep, st);
         return dispatch_conv<half_t, float>(d, g, ep, st);
@@ -527,7 +529,7 @@ template <typename T> static int dispatch_cat(const mfx_cat_desc* d, const CatSe
 extern "C" int mfx_cat_conv1x1_nhwc(const mfx_cat_desc* d, void* stream) {
     if (!d || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: null pointer");
     if (d->nseg < 1 || d->nseg > MFX_MAX_SEG) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: 1..9 segments");
-    const int elems = d->dtype == MFX_F32 ? 4 : 8;
+    const int elems = (d->dtype == MFX_F32 || d->dtype == MFX_F16X2) ? 4 : 8;
     if (!is_pow2(d->Cseg) || d->Cseg < 8 * elems) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: Cseg must be a power of two >= 128 bytes");
     if (d->K_pad != d->nseg * d->Cseg) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: K_pad != nseg*Cseg");
     if (d->Cout % elems != 0) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: Cout must be a multiple of the chunk");
@@ -545,6 +547,7 @@ extern "C" int mfx_cat_conv1x1_nhwc(const mfx_cat_desc* d, void* stream) {
     if (d->dtype == MFX_F32) return dispatch_cat<float>(d, s, ep, st);
     if (d->dtype == MFX_BF16) return dispatch_cat<bf16_t>(d, s, ep, st);
     if (d->dtype == MFX_F16) return dispatch_cat<half_t>(d, s, ep, st);
+    if (d->dtype == MFX_F16X2) return dispatch_cat<f32s_t>(d, s, ep, st);
     return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: bad dtype");
 }
 
@@ -601,8 +604,8 @@ template <typename T> static int dispatch_dcn(const mfx_dcn_desc* d, const DcnGe
 
 extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
     if (!d || !d->x || !d->offmask || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "dcn: null pointer");
-    const int elems = d->dtype == MFX_F32 ? 4 : 8;
-    if (d->dtype != MFX_F32 && d->dtype != MFX_BF16 && d->dtype != MFX_F16) return mfx_fail(MFX_ERR_ARG, "dcn: bad dtype");
+    const int elems = (d->dtype == MFX_F32 || d->dtype == MFX_F16X2) ? 4 : 8;
+    if (d->dtype != MFX_F32 && d->dtype != MFX_BF16 && d->dtype != MFX_F16 && d->dtype != MFX_F16X2) return mfx_fail(MFX_ERR_ARG, "dcn: bad dtype");
     if (!is_pow2(d->C) || d->C < 4 * elems) return mfx_fail(MFX_ERR_ARG, "dcn: C must be a power of two >= 64 bytes of channels");
     if (d->kh * d->kw > 9) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn: at most 9 taps (offmask row is 32 floats)");
     if (d->K_pad != d->kh * d->kw * d->C) return mfx_fail(MFX_ERR_ARG, "dcn: K_pad != kh*kw*C");
@@ -622,5 +625,6 @@ extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = 1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == MFX_F16) return dispatch_dcn<half_t>(d, g, ep, st);
+    if (d->dtype == MFX_F16X2) return dispatch_dcn<f32s_t>(d, g, ep, st);
     return d->dtype == MFX_F32 ? dispatch_dcn<float>(d, g, ep, st) : dispatch_dcn<bf16_t>(d, g, ep, st);
 }

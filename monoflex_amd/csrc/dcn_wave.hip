@@ -105,7 +105,7 @@ __global__ __launch_bounds__(WN * 64, 2) void dcn_wave_kernel(const T* __restric
             for (int q = 0; q < 4; ++q) ElemTraits<T>::unpack(gr[r][q], v[q]);
 #pragma unroll
             for (int e = 0; e < ELEMS; ++e) o[e] = cw[r][0] * v[0][e] + cw[r][1] * v[1][e] + cw[r][2] * v[2][e] + cw[r][3] * v[3][e];
-            *reinterpret_cast<u32x4*>(As + buf * (64 * kDcnRow) + ((wn * RPW + r) * 16 + gp) * kDcnRow + gc * 16) = ElemTraits<T>::pack(o);
+            *reinterpret_cast<u32x4*>(As + buf * (64 * kDcnRow) + ((wn * RPW + r) * 16 + gp) * kDcnRow + gc * 16) = lds_operand<T>(ElemTraits<T>::pack(o));
         }
     };
 
@@ -233,7 +233,7 @@ template <typename T> static int dcn_wave_variant(int v, const mfx_dcn_desc* d, 
 // returns 1 if handled, 0 to fall back to the first-generation kernel, < 0 on error
 int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st) {
     if (g_opt_dcn_wave == 0 || !d->w_frag) return 0;
-    const int elems = d->dtype == MFX_F32 ? 4 : 8;
+    const int elems = (d->dtype == MFX_F32 || d->dtype == MFX_F16X2) ? 4 : 8;
     if (d->C < 4 * elems || d->K_pad != d->kh * d->kw * d->C) return 0;
     const int N = d->Cout_pad;
     if (N % 64 != 0) return 0;
@@ -245,7 +245,7 @@ int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st) {
     if (g_opt_dcn_wave < 2 && (N % 128 != 0 || (d->B * d->Ho * d->Wo / 64) * (N / 128) < 512)) return 0;
     int v = N % 256 == 0 ? 5 : N % 128 == 0 ? 3 : 6;
     if (g_opt_dcn_wave >= 2 && g_opt_dcn_wave - 1 <= 7 && N % bn[g_opt_dcn_wave - 1] == 0) v = g_opt_dcn_wave - 1;
-    const int rc = d->dtype == MFX_F32 ? dcn_wave_variant<float>(v, d, st)
+    const int rc = d->dtype == MFX_F16X2 ? dcn_wave_variant<f32s_t>(v, d, st) : d->dtype == MFX_F32 ? dcn_wave_variant<float>(v, d, st)
                  : (d->dtype == MFX_F16 ? dcn_wave_variant<half_t>(v, d, st) : dcn_wave_variant<bf16_t>(v, d, st));
     return rc == MFX_OK ? 1 : rc;
 }

@@ -31,7 +31,7 @@ struct HeadGeom {
     int B, H, W, tiles_x, tiles_y, nbranch, ld_out, planar_c, steps, persist;
     float* planar;
 };
-struct HeadTabs { int ch_off[16]; int c_out[16]; };
+struct HeadTabs { int ch_off[16]; int c_out[16]; float w2s[16]; };
 
 // Halo patch in LDS: FOUR PLANES, one per MFMA k-group (lane >> 4).  A lane of k-group q only ever reads the 16-byte channel
 // chunks q, q+4, (q+8, q+12) of a pixel, so plane q holds exactly those, pixels PS = (chunks + 1) * 16 bytes apart (48 / 80:
@@ -70,6 +70,13 @@ template <> struct TrunkPack<float> {       // k-block = 16 trunk channels = D f
     static constexpr int KBLK = 4;
     __device__ static __forceinline__ u32x4 make(const float (&t)[kHeadFN][4], int kb) {
         return ElemTraits<float>::pack(t[kb]);
+    }
+};
+
+template <> struct TrunkPack<f32s_t> {      // as float; the four values become one split-precision operand chunk
+    static constexpr int KBLK = 4;
+    __device__ static __forceinline__ u32x4 make(const float (&t)[kHeadFN][4], int kb) {
+        return lds_operand<f32s_t>(ElemTraits<float>::pack(t[kb]));
     }
 };
 
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
                 for (int q = 0; q < PU; ++q) {
                     const int idx = base + q * NT + ptid;
                     if (idx < nchunks) *reinterpret_cast<u32x4*>(patch + (PL ? ((idx % CPP) & 3) * PLANE + (idx / CPP) * PS + ((idx % CPP) >> 2) * 16
-                                                                           : (idx / CPP) * PS + (idx % CPP) * 16)) = pr[q];
+                                                                           : (idx / CPP) * PS + (idx % CPP) * 16)) = lds_operand<T>(pr[q]);
                 }
             }
             __syncthreads();
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
 
         // ---- BN + leaky in registers; GEMM2 straight from the accumulators
         const int co = tabs.ch_off[br];
+        const float w2s = tabs.w2s[br];
         float* mine = red + wn * (kHeadRows * 16 * RLD);
         // partial 1x1 outputs of this wave: po[i][of] = D2[o = 16*of + 4*kq + r][pixel (row i, x = xl)]
         f32x4 po[FM][2];
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
                     for (int r = 0; r < 4; ++r) {
                         const int o = of * 16 + og * 4 + r;
                         if (o < cn) {
-                            const float res = sum[r] + bias2[br * 32 + o];
+                            const float res = sum[r] * w2s + bias2[br * 32 + o];
                             out[m * g.ld_out + co + o] = res;
                             if (br == 0 && g.planar && o < g.planar_c)
                                 g.planar[((size_t)b * g.planar_c + o) * g.H * g.W + (size_t)oy * g.W + ox] = res;
@@ -287,7 +295,7 @@ template <typename T, bool PL, int DBG = 0> static int launch_heads(const mfx_he
     g.steps = 9 * kHeadC / (4 * ElemTraits<T>::ELEMS);
     g.persist = 0;
     HeadTabs t;
-    for (int i = 0; i < 16; ++i) { t.ch_off[i] = d->ch_off[i]; t.c_out[i] = d->c_out[i]; }
+    for (int i = 0; i < 16; ++i) { t.ch_off[i] = d->ch_off[i]; t.c_out[i] = d->c_out[i]; t.w2s[i] = d->w2_scale[i] != 0.f ? d->w2_scale[i] : 1.f; }
     const int tiles = g.tiles_x * g.tiles_y * d->B;
     int grid = tiles;
     if (g_opt_heads_persist) {                               // two workgroups fit a CU (LDS, 2 waves per SIMD): one unit range per slot
@@ -334,5 +342,6 @@ extern "C" int mfx_heads_fused(const mfx_heads_desc* d, void* stream) {
     if (d->dtype == MFX_BF16 && g_opt_heads_dbg == 3) return launch_heads<bf16_t, false, 3>(d, st);
     if (d->dtype == MFX_BF16) return g_opt_heads_planes ? launch_heads<bf16_t, true>(d, st) : launch_heads<bf16_t, false>(d, st);
     if (d->dtype == MFX_F16) return launch_heads<half_t, false>(d, st);
+    if (d->dtype == MFX_F16X2) return launch_heads<f32s_t, false>(d, st);
     return mfx_fail(MFX_ERR_ARG, "heads_fused: bad dtype");
 }

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libmonoflex_hip.so")
 
-MFX_F32, MFX_BF16, MFX_F16 = 0, 1, 2
+MFX_F32, MFX_BF16, MFX_F16, MFX_F16X2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_DCN_OFFMASK = 0, 1, 2, 3
 MAX_SEG = 9
 
@@ -49,7 +49,7 @@ class HeadsDesc(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("w1", c_void_p), ("scale1", c_void_p), ("shift1", c_void_p), ("w2", c_void_p),
                 ("bias2", c_void_p), ("out", c_void_p), ("planar", c_void_p),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("nbranch", c_int), ("K_pad", c_int), ("ld_out", c_int),
-                ("dtype", c_int), ("planar_c", c_int), ("ch_off", c_int * 16), ("c_out", c_int * 16)]
+                ("dtype", c_int), ("planar_c", c_int), ("ch_off", c_int * 16), ("c_out", c_int * 16), ("w2_scale", ctypes.c_float * 16)]
 
 
 class KittiDesc(ctypes.Structure):

@@ -115,8 +115,8 @@ class DCN(DCNv2):
         if OFFSET_CONV_FP32[0] and x.dtype != torch.float32:    # ablation switch (tools/bf16_ablation.py): offsets from fp32 operands
             offmask = ops.conv2d(x.float(), self.packed_offset(torch.float32), out_dtype=torch.float32)
         else:
-            offmask = ops.conv2d(x, self.packed_offset(x.dtype), out_dtype=torch.float32)
-        return ops.dcn(x, offmask, self.packed_main(x.dtype, bn, act))
+            offmask = ops.conv2d(x, self.packed_offset(ops.compute_tag(self, x.dtype)), out_dtype=torch.float32)
+        return ops.dcn(x, offmask, self.packed_main(ops.compute_tag(self, x.dtype), bn, act))
 
     def forward_nhwc_train(self, x):
         """Differentiable NHWC form: offset/mask conv -> DCNv2 (gradients to x, offsets, mask logits, weight, bias)."""

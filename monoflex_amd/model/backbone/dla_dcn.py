@@ -56,6 +56,7 @@ def _train_conv_bn(x, conv, bn, act, res=None):
 
 def _conv_bn(owner, key, conv, bn, dtype, act):
     packs = owner.__dict__.setdefault("_packs", {})
+    dtype = ops.compute_tag(owner, dtype)
     k = (key, dtype)
     if k not in packs:
         scale, shift = ops.fold_bn(bn)
@@ -97,10 +98,11 @@ class Root(nn.Module):
             return AG.bn_act(AG.CatConv1x1Fn.apply(self.conv.weight, *xs), self.bn, L.ACT_RELU)
         packs = self.__dict__.setdefault("_packs", {})
         chans = tuple(t.shape[3] for t in xs)
-        k = (chans, xs[0].dtype)
+        tag = ops.compute_tag(self, xs[0].dtype)
+        k = (chans, tag)
         if k not in packs:
             scale, shift = ops.fold_bn(self.bn)
-            packs[k] = ops.pack_cat(self.conv.weight, xs[0].dtype, scale, shift, chans, act=L.ACT_RELU)
+            packs[k] = ops.pack_cat(self.conv.weight, tag, scale, shift, chans, act=L.ACT_RELU)
         return ops.cat_conv1x1(list(xs), packs[k])
 
 
@@ -183,14 +185,15 @@ class DLA(nn.Module):
         if self.training:
             return self._forward_train(images, dtype, cut)
         packs = self.__dict__.setdefault("_packs", {})
-        if ("stem", dtype) not in packs:
+        tag = ops.compute_tag(self, dtype)
+        if ("stem", tag) not in packs:
             scale, shift = ops.fold_bn(self.base_layer[1])
-            packs[("stem", dtype)] = ops.pack_stem(self.base_layer[0].weight, dtype, scale, shift)
+            packs[("stem", tag)] = ops.pack_stem(self.base_layer[0].weight, tag, scale, shift)
         B, _, H, W = images.shape
-        if dtype in (torch.bfloat16, torch.float16) and packs[("stem", dtype)].Cout == 16:
-            x = ops.stem_conv(images, packs[("stem", dtype)])                 # reads the NCHW planes directly
+        if dtype in (torch.bfloat16, torch.float16) and packs[("stem", tag)].Cout == 16:
+            x = ops.stem_conv(images, packs[("stem", tag)])                 # reads the NCHW planes directly
         else:
-            x = ops.conv2d(ops.pack_image(images, dtype), packs[("stem", dtype)], out_hw=(H, W))
+            x = ops.conv2d(ops.pack_image(images, dtype), packs[("stem", tag)], out_hw=(H, W))
         y = []
         for i in range(6):
             lvl = getattr(self, "level{}".format(i))

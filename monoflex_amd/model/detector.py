@@ -12,7 +12,8 @@ from .head.detector_head import bulid_head
 from .head.detector_predictor import make_edge_rowmap, stack_edge_fields
 
 _DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
-           "fp16": torch.float16, "float16": torch.float16}      # fp16: IEEE half activations, same MFMA rate as bf16 (training: under a loss scaler)
+           "fp16": torch.float16, "float16": torch.float16,      # fp16: IEEE half activations, same MFMA rate as bf16 (training: under a loss scaler)
+           "fp16x2": torch.float32}      # split precision (inference): fp32 activations, fp16 (hi, lo) MFMA operand pairs (ops.F16X2)
 
 
 class KeypointDetector(nn.Module):
@@ -26,9 +27,16 @@ class KeypointDetector(nn.Module):
     def set_compute_dtype(self, name):
         """'fp32' = parity mode (f32 MFMA, <=1e-3 on logits), 'bf16' = perf mode (bf16 MFMA, fp32 accumulate; inference and training),
         'fp16' = perf mode with IEEE-half activations (same MFMA rate, three more mantissa bits: ~8x closer to the reference in inference;
-        training in fp16 runs under engine.trainer.LossScaler, which do_train / GraphedTrainStep create by themselves)."""
+        training in fp16 runs under engine.trainer.LossScaler, which do_train / GraphedTrainStep create by themselves),
+        'fp16x2' = parity-grade perf mode for inference: fp32 activations in memory, every MFMA operand split into an fp16 (hi, lo)
+        pair, four fp16 products per element pair accumulated in fp32 -- fp32-grade results at 4x the fp32 matrix rate (training
+        in this mode runs the fp32 kernels)."""
         self.compute_dtype = _DTYPES[name] if isinstance(name, str) else name
         self.backbone.compute_dtype = self.compute_dtype
+        split = name == "fp16x2"
+        for m in self.modules():                                   # ops.compute_tag: which packed weights / kernels a module's eval path uses
+            m.__dict__["_mfx_split"] = split
+        self.compute_mode = name if isinstance(name, str) else {v: k for k, v in _DTYPES.items() if len(k) == 4}[name]
         return self
 
     def load_state_dict(self, *args, **kwargs):

@@ -122,12 +122,17 @@ class _predictor(nn.Module):
             sc.append(s); sh.append(b)
         K = w1[0].shape[1]
         assert K == 576 and self.head_conv == 256
-        E = 4 if dtype == torch.float32 else 8
+        E = 4 if dtype in (torch.float32, ops.F16X2) else 8
         steps = K // (4 * E)
         nb = len(trunks)
         dev = w1[0].device
+        w2_scale = None
+        if dtype == ops.F16X2:                                     # weights times a power of two per branch (ops.split_weight_scale), undone by scale1 / w2_scale
+            for i in range(len(w1)):
+                ws = ops.split_weight_scale(w1[i])
+                w1[i], sc[i] = w1[i] * ws, sc[i] / ws
         # 3x3 weights, fragment-major: [branch][wave wn 4][step][frag j 4][k-group kq 4][row nl 16][E]  (lane = kq*16+nl)
-        W1 = torch.stack(w1, 0).view(nb, 4, 4, 16, steps, 4, E).permute(0, 1, 4, 2, 5, 3, 6).contiguous().to(dtype)
+        W1 = ops.cast_operand(torch.stack(w1, 0).view(nb, 4, 4, 16, steps, 4, E).permute(0, 1, 4, 2, 5, 3, 6).contiguous(), dtype)
         w2 = torch.zeros(nb, 32, self.head_conv, device=dev)
         b2 = torch.zeros(nb, 32, device=dev)
         ch_off, c_out = [0], [self.num_classes]
@@ -144,15 +149,21 @@ class _predictor(nn.Module):
             ch_off.append(off); c_out.append(r)
             off += r
         assert off <= HM_LD
+        if dtype == ops.F16X2:
+            w2_scale = []
+            for i in range(nb):
+                ws = ops.split_weight_scale(w2[i])
+                w2[i] *= ws
+                w2_scale.append(1.0 / ws)
         # 1x1 weights, fragment-major with the K order the kernel's accumulators arrive in (heads.hip TrunkPack):
         #   bf16: [branch][wn][kb 2][of 2][g 4][o_l 16][half 2][q 4], trunk channel n = 64wn + 32kb + 16half + 4g + q
         #   f32 : [branch][wn][kb 4][of 2][g 4][o_l 16][e 4],          n = 64wn + 16kb + 4g + e
-        if dtype == torch.float32:
-            W2 = w2.view(nb, 2, 16, 4, 4, 4, 4).permute(0, 3, 4, 1, 5, 2, 6).contiguous()
+        if dtype in (torch.float32, ops.F16X2):
+            W2 = ops.cast_operand(w2.view(nb, 2, 16, 4, 4, 4, 4).permute(0, 3, 4, 1, 5, 2, 6).contiguous(), dtype)
         else:
             W2 = w2.view(nb, 2, 16, 4, 2, 2, 4, 4).permute(0, 3, 4, 1, 6, 2, 5, 7).contiguous().to(dtype)
         p = ops.PackedHeads(W1, torch.cat(sc).contiguous(), torch.cat(sh).contiguous(),
-                            W2, b2.contiguous(), K, ch_off, c_out, HM_LD)
+                            W2, b2.contiguous(), K, ch_off, c_out, HM_LD, split=dtype == ops.F16X2, w2_scale=w2_scale)
         # edge fusion: trunks of the class branch and of the 3d_offset branch at the border points
         if self.enable_edge_fusion:
             oi = self.offset_index[0]
@@ -180,7 +191,7 @@ class _predictor(nn.Module):
         edge fusion), [8:58] the 50 regression channels.  edge_indices int32 (B,L,2) (x,y), edge_lens int32 (B,)."""
         if self.training:
             raise RuntimeError("forward_nhwc is the fused eval path; training goes through forward_train")
-        p = self._pack(features.dtype)
+        p = self._pack(ops.compute_tag(self, features.dtype))
         hm, planar = ops.heads_fused(features, p, planar_classes=self.num_classes)
         self.last_cls_planar = planar                               # (B,3,H*W) class logits for the top-K kernel
         if self.enable_edge_fusion:

@@ -58,8 +58,52 @@ def _dt(dtype):
     raise TypeError("MonoFlex HIP kernels take float32, bfloat16 or float16, got %s" % dtype)
 
 
+# Compute tag of the split-precision mode (include/monoflex_hip.h MFX_F16X2): activations are ordinary float32 tensors, the GEMM
+# kernels (conv2d / cat_conv1x1 / dcn / heads_fused) multiply fp16 (hi, lo) operand pairs.  The tag travels with the PACKED WEIGHTS
+# (`pack_*(…, dtype=F16X2)` -> `.split`), which is what selects the kernel; modules learn it from `compute_tag`.
+F16X2 = "f16x2"
+
+
+def compute_tag(module, dtype):
+    """The pack / kernel tag a module uses for activations of `dtype`: F16X2 when the module was switched to the split-precision
+    mode (KeypointDetector.set_compute_dtype("fp16x2") marks every sub-module) and the activations are fp32."""
+    if dtype == torch.float32 and module.__dict__.get("_mfx_split", False):
+        return F16X2
+    return dtype
+
+
+def storage_dtype(dtype):
+    return torch.float32 if dtype == F16X2 else dtype
+
+
 def _elems(dtype):
-    return 4 if dtype == torch.float32 else 8
+    return 4 if (dtype == torch.float32 or dtype == F16X2) else 8
+
+
+def split_chunks(w):
+    """fp32 tensor (element count a multiple of 4, chunks of 4 consecutive values) -> the same shape, float32-TYPED, every 16-byte
+    chunk holding [4 hi halves | 4 lo halves] of its 4 values: hi = fp16(x), lo = fp16(x - hi) (csrc/common.h f32s_t)."""
+    w = w.detach().float().contiguous()
+    c = w.view(-1, 4)
+    hi = c.half()
+    lo = (c - hi.float()).half()
+    return torch.cat((hi, lo), 1).contiguous().view(torch.float32).view(w.shape)
+
+
+def cast_operand(w, dtype):
+    """Weights as the kernels of compute tag `dtype` read them."""
+    return split_chunks(w) if dtype == F16X2 else w.to(dtype)
+
+
+def split_weight_scale(w):
+    """Power of two s (python float) that brings max |w| * s into [2^11, 2^12): the lo halves of the scaled weights are then normal
+    fp16 numbers down to |w| = 2^-14 of the largest one (unscaled, every lo half of a |w| < 0.25 weight is an fp16 SUBNORMAL, i.e.
+    carries a 3e-8 absolute error -- ~1e-6 relative on DLA-34's weights, the largest error term of the split mode).  The kernels'
+    epilogues undo it exactly: pack_* fold 1/s into the per-channel `scale`."""
+    m = float(w.detach().abs().max())
+    if not (m > 0.0) or not math.isfinite(m):
+        return 1.0
+    return 2.0 ** (11 - math.floor(math.log2(m)))
 
 
 def _ptr(t):
@@ -113,6 +157,7 @@ class PackedConv:
     act: int
     w_frag: Optional[torch.Tensor] = None   # fragment-major copy for the LDS-halo kernel (3x3 / stride 1)
     w_frag_f16: Optional[torch.Tensor] = None   # same, IEEE fp16 (DCN LDS-patch kernel, bf16 mode)
+    split: bool = False                     # split-precision operands (F16X2): fp32 activations, MFX_F16X2 kernels
 
 
 def fragment_major(w2d, dtype):
@@ -154,7 +199,11 @@ def pack_conv(weight, dtype, scale=None, shift=None, stride=1, pad=0, act=L.ACT_
     cout = Cout if cout is None else cout
     cp = cout_pad(cout)
     w2 = weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, K)
-    w2 = _pad_rows_cols(w2, cp, K_pad).to(dtype).contiguous()
+    if dtype == F16X2:
+        ws = split_weight_scale(w2)
+        w2 = w2 * ws
+        scale = (scale.detach().float() if scale is not None else torch.ones(Cout, device=weight.device)) / ws
+    w2 = cast_operand(_pad_rows_cols(w2, cp, K_pad), dtype).contiguous()
 
     def padv(v, fill):
         if v is None:
@@ -164,7 +213,7 @@ def pack_conv(weight, dtype, scale=None, shift=None, stride=1, pad=0, act=L.ACT_
             v = torch.cat((v, v.new_full((cp - v.numel(),), fill)))
         return v.contiguous()
     wf = fragment_major(w2, dtype) if (kh == 3 and kw == 3 and stride == 1 and pad == 1) else None
-    return PackedConv(w2, padv(scale, 1.0), padv(shift, 0.0), kh, kw, stride, pad, pad, 1, Cin, cout, cp, K_pad, act, wf)
+    return PackedConv(w2, padv(scale, 1.0), padv(shift, 0.0), kh, kw, stride, pad, pad, 1, Cin, cout, cp, K_pad, act, wf, split=dtype == F16X2)
 
 
 # stem geometry: zero-padded NHWC4 image, 3 columns left / 5 right, 3 rows top/bottom
@@ -189,8 +238,11 @@ def pack_stem(weight, dtype, scale, shift, act=L.ACT_RELU):
     bk = 8 * _elems(dtype)
     K_pad = _round_up(wp.shape[1], bk)
     cp = cout_pad(Cout)
-    wp = _pad_rows_cols(wp, cp, K_pad).to(dtype).contiguous()
-    return PackedConv(wp, scale.contiguous(), shift.contiguous(), kh, kw, 1, 0, 0, dil, Ck, Cout, cp, K_pad, act)
+    if dtype == F16X2:
+        ws = split_weight_scale(wp)
+        wp, scale = wp * ws, scale.detach().float() / ws
+    wp = cast_operand(_pad_rows_cols(wp, cp, K_pad), dtype).contiguous()
+    return PackedConv(wp, scale.contiguous(), shift.contiguous(), kh, kw, 1, 0, 0, dil, Ck, Cout, cp, K_pad, act, split=dtype == F16X2)
 
 
 # --------------------------------------------------------------------------------------------
@@ -225,7 +277,7 @@ def conv2d(x, p: PackedConv, res=None, out_dtype=None, rowmap=None, x_channels=N
     d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil_w = p.kh, p.kw, p.stride, p.pad_h, p.pad_w, p.dil_w
     d.Ho, d.Wo, d.M, d.Cout, d.Cout_pad, d.K_pad = Ho, Wo, M, p.Cout, p.Cout_pad, p.K_pad
     d.ldy, d.ldres = p.Cout, (res.shape[-1] if res is not None else 0)
-    d.act, d.dtype, d.out_dtype = p.act, _dt(x.dtype), _dt(out_dtype)
+    d.act, d.dtype, d.out_dtype = p.act, (L.MFX_F16X2 if p.split else _dt(x.dtype)), _dt(out_dtype)
     if rowmap is None and M * p.Cout_pad <= SPLITK_MAX_ELEMS and p.K_pad * x.element_size() >= 2048:
         ws = _splitk_workspace(x.device)                      # small-M / long-K layers: lets the library split K
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -254,6 +306,7 @@ class PackedCat:
     Cout_pad: int
     K_pad: int
     act: int
+    split: bool = False
 
 
 def pack_cat(weight, dtype, scale, shift, src_channels, act=L.ACT_RELU):
@@ -262,8 +315,12 @@ def pack_cat(weight, dtype, scale, shift, src_channels, act=L.ACT_RELU):
     Cseg = min(src_channels)
     assert all(c % Cseg == 0 for c in src_channels) and _pow2(Cseg)
     cp = cout_pad(Cout)
-    w2 = _pad_rows_cols(weight.detach().float().reshape(Cout, Ctot), cp, Ctot).to(dtype).contiguous()
-    return PackedCat(w2, scale.contiguous(), shift.contiguous(), Cseg, Cout, cp, Ctot, act)
+    w2 = weight.detach().float().reshape(Cout, Ctot)
+    if dtype == F16X2:
+        ws = split_weight_scale(w2)
+        w2, scale = w2 * ws, scale.detach().float() / ws
+    w2 = cast_operand(_pad_rows_cols(w2, cp, Ctot), dtype).contiguous()
+    return PackedCat(w2, scale.contiguous(), shift.contiguous(), Cseg, Cout, cp, Ctot, act, split=dtype == F16X2)
 
 
 @on_tensor_device
@@ -283,7 +340,8 @@ def cat_conv1x1(srcs, p: PackedCat):
     d.w, d.res, d.y = p.w.data_ptr(), None, y.data_ptr()
     d.scale = p.scale.data_ptr() if p.scale is not None else None
     d.shift = p.shift.data_ptr() if p.shift is not None else None
-    d.M, d.Cout, d.Cout_pad, d.K_pad, d.ldy, d.ldres, d.act, d.dtype = B * H * W, p.Cout, p.Cout_pad, p.K_pad, p.Cout, 0, p.act, _dt(y.dtype)
+    d.M, d.Cout, d.Cout_pad, d.K_pad, d.ldy, d.ldres, d.act = B * H * W, p.Cout, p.Cout_pad, p.K_pad, p.Cout, 0, p.act
+    d.dtype = L.MFX_F16X2 if p.split else _dt(y.dtype)
     L.check(L.load().mfx_cat_conv1x1_nhwc(ctypes.byref(d), _stream()), "mfx_cat_conv1x1_nhwc")
     return y
 
@@ -314,7 +372,8 @@ def dcn(x, offmask, p: PackedConv):
     d.shift = p.shift.data_ptr() if p.shift is not None else None
     d.B, d.H, d.W, d.C = B, H, W, C
     d.kh, d.kw, d.stride, d.pad, d.dil = p.kh, p.kw, p.stride, p.pad_h, p.dil_w
-    d.Ho, d.Wo, d.Cout, d.Cout_pad, d.K_pad, d.ldy, d.act, d.dtype = Ho, Wo, p.Cout, p.Cout_pad, p.K_pad, p.Cout, p.act, _dt(x.dtype)
+    d.Ho, d.Wo, d.Cout, d.Cout_pad, d.K_pad, d.ldy, d.act = Ho, Wo, p.Cout, p.Cout_pad, p.K_pad, p.Cout, p.act
+    d.dtype = L.MFX_F16X2 if p.split else _dt(x.dtype)
     if B * Ho * Wo * p.Cout_pad <= SPLITK_MAX_ELEMS:           # small maps: lets the library split K over workgroups
         ws = _splitk_workspace(x.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -374,6 +433,7 @@ def pack_image(images, dtype):
     """(B,3,H,W) fp32 NCHW -> zero-padded NHWC4 (B, H+6, W+8, 4) for the stem conv."""
     _need_cuda(images)
     images = images.float().contiguous()
+    dtype = storage_dtype(dtype)
     B, C, H, W = images.shape
     assert C == 3
     y = torch.empty((B, H + 2 * STEM_PAD_H, W + STEM_PAD_WL + STEM_PAD_WR, 4), dtype=dtype, device=images.device)
@@ -406,6 +466,8 @@ class PackedHeads:
     ch_off: list
     c_out: list
     ld_out: int
+    split: bool = False
+    w2_scale: Optional[list] = None          # per branch, multiplies the 1x1 sums before the bias (split precision: 1 / the weights' packing scale)
 
 
 @on_tensor_device
@@ -420,9 +482,11 @@ def heads_fused(x, p: PackedHeads, planar_classes=0):
     d.planar, d.planar_c = (planar.data_ptr() if planar is not None else None), planar_classes
     d.x, d.w1, d.scale1, d.shift1 = x.data_ptr(), p.w1.data_ptr(), p.scale1.data_ptr(), p.shift1.data_ptr()
     d.w2, d.bias2, d.out = p.w2.data_ptr(), p.bias2.data_ptr(), out.data_ptr()
-    d.B, d.H, d.W, d.nbranch, d.K_pad, d.ld_out, d.dtype = B, H, W, len(p.c_out), p.K_pad, p.ld_out, _dt(x.dtype)
+    d.B, d.H, d.W, d.nbranch, d.K_pad, d.ld_out = B, H, W, len(p.c_out), p.K_pad, p.ld_out
+    d.dtype = L.MFX_F16X2 if p.split else _dt(x.dtype)
     for i, (o, c) in enumerate(zip(p.ch_off, p.c_out)):
         d.ch_off[i], d.c_out[i] = o, c
+        d.w2_scale[i] = p.w2_scale[i] if p.w2_scale is not None else 1.0
     L.check(L.load().mfx_heads_fused(ctypes.byref(d), _stream()), "mfx_heads_fused")
     return out, planar
 

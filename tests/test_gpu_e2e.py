@@ -97,12 +97,18 @@ def _check_against_golden(g, n, meta, hm, topk, det, valid, full):
     return dl, dr
 
 
-def test_e2e_small_vs_reference_golden_fp32():
+# the two modes that carry the north-star gate (<= 1e-3 on logits, identical top-K): "fp32" = f32 MFMA, "fp16x2" = fp32 activations with
+# split-precision (fp16 hi + lo) MFMA operands (csrc/common.h f32s_t) -- same tests, same bounds
+PARITY_MODES = ["fp32", "fp16x2"]
+
+
+@pytest.mark.parametrize("mode", PARITY_MODES)
+def test_e2e_small_vs_reference_golden_fp32(mode):
     from monoflex_amd import synthetic as S
     g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_small.npz"))
     meta = ast.literal_eval(str(g["meta"]))
     ow, oh = meta["out_w"], meta["out_h"]
-    m = _hip_model(meta["cls_bias"], "fp32", ow, oh)
+    m = _hip_model(meta["cls_bias"], mode, ow, oh)
     # both images in ONE batch: batched decode must equal the reference's per-image (B=1) decode
     imgs = torch.cat([S.synthetic_images(1, oh * 4, ow * 4, seed=s) for s in meta["seeds"]])
     det, topk, valid, hm = _run(m, imgs, [S.synthetic_target(ow, oh)] * len(meta["seeds"]))
@@ -113,24 +119,34 @@ def test_e2e_small_vs_reference_golden_fp32():
         assert len(errs) == 11 and all(e[0] <= 2e-4 and e[1] <= 1e-4 for e in errs.values()), errs
 
 
-def test_e2e_full_vs_reference_golden_fp32():
+@pytest.mark.parametrize("mode,batch", [("fp32", 1), ("fp16x2", 1), ("fp16x2", 8)])
+def test_e2e_full_vs_reference_golden_fp32(mode, batch):
+    """Full-size frame against the reference's goldens; ("fp16x2", 8) is the benchmarked shape of the split-precision mode (B=8; image 0
+    of the batch is the golden image) under the SAME gate as fp32: logits <= 1e-3, identical top-K, rows, 11 stage goldens."""
     from monoflex_amd import synthetic as S
     g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_full.npz"))
     meta = ast.literal_eval(str(g["meta"]))
-    m = _hip_model(meta["cls_bias"], "fp32")
-    imgs = S.synthetic_images(1, 384, 1280, seed=meta["seeds"][0])
-    det, topk, valid, hm = _run(m, imgs, [S.synthetic_target(320, 96)])
+    m = _hip_model(meta["cls_bias"], mode)
+    imgs = S.synthetic_images(batch, 384, 1280, seed=meta["seeds"][0])
+    det, topk, valid, hm = _run(m, imgs, [S.synthetic_target(320, 96)] * batch)
     dl, dr = _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False)
     errs = _stage_errors(g, 0, _stages(m, imgs))
-    print("full-size fp32 vs reference: max |dlogit| %.2e, max |dreg| %.2e; stages %s" % (
-        dl, dr, {k: "%.1e/%.1e" % v for k, v in errs.items()}))
+    print("full-size %s B=%d vs reference: max |dlogit| %.2e, max |dreg| %.2e; stages %s" % (
+        mode, batch, dl, dr, {k: "%.1e/%.1e" % v for k, v in errs.items()}))
+    if mode == "fp16x2":
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "fp16x2_b%d_vs_reference.json" % batch), "w") as f:
+            json.dump({"shape": "B=%d, 1280x384, fp16x2 (split-precision MFMA operands, fp32 activations)" % batch, "max_abs_dlogit": float(dl),
+                       "max_abs_dreg": float(dr), "topk_identical": True, "stage_sample_rel_err": {k: v[0] for k, v in errs.items()},
+                       "stage_abssum_rel_err": {k: v[1] for k, v in errs.items()}}, f, indent=1, sort_keys=True)
     assert len(errs) == 11 and all(e[0] <= 2e-4 and e[1] <= 1e-4 for e in errs.values()), errs
     pix = torch.as_tensor(g["img0_pix"])
     feat = _stages(m, imgs)["feature"][0].float().permute(2, 0, 1).reshape(64, -1)[:, pix].cpu().numpy()
     assert np.abs(feat - g["img0_feature_at"]).max() <= 2e-4 * max(1.0, np.abs(g["img0_feature_at"]).max())
 
 
-def test_c5_batch32_hipgraph_fp32_rows_equal_reference_golden():
+@pytest.mark.parametrize("mode", PARITY_MODES)
+def test_c5_batch32_hipgraph_fp32_rows_equal_reference_golden(mode):
     """BASELINE configs[4] per-GPU shape: batch 32 captured in ONE hipGraph (DLA + DCN + heads + top-K + decode), replayed;
     image 0 of the batch is the golden image: logits <= 1e-3, identical top-K, (N,14) rows -- the batched, graphed decode
     equals the reference's batch-1 eager decode.  Two further images of the batch are checked against their own B=1 run."""
@@ -138,7 +154,7 @@ def test_c5_batch32_hipgraph_fp32_rows_equal_reference_golden():
     from monoflex_amd.structures.params_3d import make_test_target
     g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_full.npz"))
     meta = ast.literal_eval(str(g["meta"]))
-    m = _hip_model(meta["cls_bias"], "fp32")
+    m = _hip_model(meta["cls_bias"], mode)
     B = 32
     imgs = S.synthetic_images(B, 384, 1280, seed=meta["seeds"][0]).to(DEV)
     tg = m.device_targets([make_test_target(S.synthetic_target(320, 96)) for _ in range(B)], DEV)
@@ -162,12 +178,13 @@ def test_c5_batch32_hipgraph_fp32_rows_equal_reference_golden():
         assert torch.allclose(det[n], d1[0], rtol=2e-3, atol=2e-2)          # other tile shapes at B=32: fp32 sums reorder
 
 
-def test_e2e_vs_oracle_other_seeds_fp32():
+@pytest.mark.parametrize("mode", PARITY_MODES)
+def test_e2e_vs_oracle_other_seeds_fp32(mode):
     """Fresh inputs (not in any fixture) against the CPU oracle, 96x192 frame, batch 3."""
     from monoflex_amd import synthetic as S
     from oracle import monoflex_ref as R
     ow, oh = 48, 24
-    m = _hip_model(-1.0, "fp32", ow, oh)
+    m = _hip_model(-1.0, mode, ow, oh)
     ref = R.KeypointDetectorRef().eval()
     ref.load_state_dict(S.synthetic_state_dict(ref.state_dict(), seed=0, cls_bias=-1.0))
     imgs = S.synthetic_images(3, oh * 4, ow * 4, seed=77)
