@@ -177,14 +177,21 @@ def deviation_vs_reference(out, dtype):
     mine, ref = topk[:, 1].numpy().astype(np.int64), g["img0_topk_index"]
     agree = len(set(mine.tolist()) & set(ref.tolist())) / float(len(ref))
     same_order = bool(np.array_equal(mine, ref))
+    # identical up to permutations among ranks whose REFERENCE scores are within 5e-6 of each other (the golden has one such pair, ranks
+    # 18/19, 1.7e-6 = 29 ulp apart: its order is fp32 summation-order noise; tests/test_gpu_e2e.py _same_ranking)
+    score_of = {int(i): float(s) for i, s in zip(ref, g["img0_topk_scores"])}
+    tie_order = bool(sorted(mine.tolist()) == sorted(ref.tolist()) and
+                     all(abs(score_of[int(m)] - float(s)) <= 5e-6 for m, s in zip(mine, g["img0_topk_scores"])))
     rows, want = det[valid.bool()].numpy(), g["img0_result"]
     # rows are compared where both sides decoded the same heat-map peak (same class, same order slot)
     row_delta = None
-    if rows.shape == want.shape and same_order:
-        row_delta = float(np.abs(rows - want).max())
+    if rows.shape == want.shape and (same_order or tie_order):
+        perm = [int(np.nonzero(mine == i)[0][0]) for i in ref][:len(want)] if not same_order else list(range(len(want)))
+        if max(perm) < len(rows):
+            row_delta = float(np.abs(rows[perm] - want).max())
     return {"golden": "tests/golden/e2e_full.npz (reference KeypointDetector, image seed 1000)", "dtype": dtype,
             "max_abs_dlogit": round(dl, 6), "max_abs_dreg": round(dr, 6), "topk_index_agreement": round(agree, 4),
-            "topk_identical_order": same_order, "max_abs_row_delta": row_delta,
+            "topk_identical_order": same_order, "topk_identical_up_to_reference_ties_5e-6": tie_order, "max_abs_row_delta": row_delta,
             "north_star_bar": "fp32 mode: <=1e-3 on logits, identical top-K (tests/test_gpu_e2e.py)"}
 
 

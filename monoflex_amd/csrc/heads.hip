@@ -18,6 +18,7 @@
 #include "../../include/monoflex_hip.h"
 #include "err.h"
 #include "igemm.h"
+#include <type_traits>
 
 int g_opt_heads_persist = 1;   // option "heads_persist": 1 = one workgroup per resident slot (n > 1: n workgroups), each a contiguous range of (tile, branch)
                                // units; 0 = one workgroup per tile.  B=8 bf16: 516 -> 503 us (tools/probes/heads_probe.py), bit-identical output
@@ -46,7 +47,10 @@ template <typename T, bool PL> struct HeadSmem {
     static constexpr int PLANE = PL ? ((kHeadRows + 2) * 18 * PS + 255) / 256 * 256 : 0;
     static constexpr int patch_bytes = PL ? 4 * PLANE : (kHeadRows + 2) * 18 * PS;
     static constexpr int red_ld = 20;                                   // fp32 words per pixel row of a partial-sum slice (16 + pad)
-    static constexpr int red_bytes = kHeadRows * 16 * red_ld * 4;       // one wave's slice: [128 px][20]
+    // tile rows per reduction pass: the 4-byte element types (fp32, split precision) reduce in two passes of 4 rows -- half the slices,
+    // 69 KB instead of 90 KB per workgroup, so TWO workgroups fit a CU's 160 KB (one wave per SIMD cannot hide its own latencies)
+    static constexpr int red_rows = sizeof(T) == 4 ? 4 : kHeadRows;
+    static constexpr int red_bytes = red_rows * 16 * red_ld * 4;        // one wave's slice: [red_rows * 16 px][20]
     static constexpr int bytes = patch_bytes + kHeadWaves * red_bytes;
 };
 
@@ -84,6 +88,29 @@ template <> struct TrunkPack<f32s_t> {      // as float; the four values become 
 // w2p: fragment-major 1x1 weights  [branch][wn 4][kblk][of 2][lane 64][16 B]  (K order matching TrunkPack)
 // DBG (timing probes only, results are wrong; option "heads_dbg"): bit 0 = the K loop keeps the first step's weight fragments
 // (no L2 -> register weight stream), bit 1 = it keeps the first pixel fragments (no LDS reads).
+// split precision (T = f32s_t): the K loop runs over step PAIRS.  Both operands keep their hi halves in dwords 0-1 and their lo halves in
+// dwords 2-3 of a chunk, so the hi (lo) halves of two consecutive steps form one 8-element MFMA operand [hi(step 2p) | hi(step 2p+1)]:
+// the weights arrive re-packed that way (ops.pair_steps), the pixels by two 8-byte LDS reads.  Three products per pair -- hh.hh, hh.ll,
+// ll.hh (lo.lo is below fp32 resolution) -- instead of the four of two single-step mma_chunk<f32s_t> calls: 25 % fewer MFMAs.
+__device__ __forceinline__ u32x4 lds_read_pair(const char* p, int second) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p), b = *reinterpret_cast<const uint2*>(p + second);
+    return u32x4{a.x, a.y, b.x, b.y};
+}
+__device__ __forceinline__ void mma_split3(const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+}
+// eight fp32 values -> their hi halves / lo halves as two MFMA operands
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hh, u32x4& ll) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x2 h = __builtin_convertvector((f32x2){v[2 * i], v[2 * i + 1]}, f16x2);
+        const f16x2 l = __builtin_convertvector((f32x2){v[2 * i] - (float)h[0], v[2 * i + 1] - (float)h[1]}, f16x2);
+        hh[i] = __builtin_bit_cast(uint32_t, h); ll[i] = __builtin_bit_cast(uint32_t, l);
+    }
+}
+
 template <typename T, bool PL, int DBG = 0>
 __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T* __restrict__ x, const u32x4* __restrict__ w1p,
                                                                          const float* __restrict__ scale1, const float* __restrict__ shift1,
@@ -96,7 +123,7 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
     constexpr int RLD = HeadSmem<T, PL>::red_ld;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
-    float* red = reinterpret_cast<float*>(smem + HeadSmem<T, PL>::patch_bytes);      // [4 waves][128 px][20]
+    float* red = reinterpret_cast<float*>(smem + HeadSmem<T, PL>::patch_bytes);      // [4 waves][red_rows * 16 px][20]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xl = lane & 15, kq = lane >> 4;
@@ -191,7 +218,8 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        u32x4 wb[3][FN];
+        constexpr bool SPLIT = std::is_same<T, f32s_t>::value;
+        u32x4 wb[SPLIT ? 1 : 3][FN];
         const int cn = tabs.c_out[br];
         const bool two = cn > 16;                            // second 16-row output fragment needed?
         f32x4 s4[FN], h4[FN];                                // BN scale / shift of this wave's trunk channels
@@ -206,11 +234,52 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
 #pragma unroll
             for (int j = 0; j < FN; ++j) h4[j] = *reinterpret_cast<const f32x4*>(shift1 + br * kHeadTrunk + wn * 64 + j * 16 + ko);
         };
+        // (split precision: w2f[2*kbp + hl][of] = the hi (hl 0) / lo (hl 1) operand of trunk-channel block pair kbp)
         auto load_w2 = [&](int of) {
             const u32x4* src = w2p + ((size_t)(br * kHeadWaves + wn) * KBLK) * (2 * 64) + lane;
 #pragma unroll
             for (int kb = 0; kb < KBLK; ++kb) w2f[kb][of] = src[(size_t)(kb * 2 + of) * 64];
         };
+        if constexpr (SPLIT) {
+            // weights: [pair][hi | lo][j][lane] (ops.pair_steps); ring of two pairs, fetched one pair ahead
+            u32x4 wh[2][FN], wl[2][FN];
+            auto wfetch2 = [&](int p, u32x4 (&h)[FN], u32x4 (&l)[FN]) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) { h[j] = wsrc[(size_t)((p * 2 + 0) * FN + j) * 64]; l[j] = wsrc[(size_t)((p * 2 + 1) * FN + j) * 64]; }
+            };
+            auto compute2 = [&](int p, const u32x4 (&h)[FN], const u32x4 (&l)[FN]) {
+                const int e = p * 32 + kq * 4;               // first step of the pair: (tap, channel); the second step is 16 channels on
+                const int tap = e >> 6, cl = e & 63;
+                const int th = (tap * 21846) >> 16, tw = tap - th * 3;
+                const char* ap = patch + (th * 18 + xl + tw) * PS + cl * 4;
+                u32x4 ph[2], pl[2];
+                ph[0] = lds_read_pair(ap, 64); pl[0] = lds_read_pair(ap + 8, 64);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int cur = i & 1;
+                    if (i + 1 < FM) { ph[cur ^ 1] = lds_read_pair(ap + (i + 1) * 18 * PS, 64); pl[cur ^ 1] = lds_read_pair(ap + (i + 1) * 18 * PS + 8, 64); }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, h[j]), __builtin_bit_cast(f16x8, ph[cur]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, h[j]), __builtin_bit_cast(f16x8, pl[cur]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, l[j]), __builtin_bit_cast(f16x8, ph[cur]), acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            const int npairs = steps / 2;                    // 18
+            wfetch2(0, wh[0], wl[0]);
+            for (int p = 0; p < npairs; p += 2) {
+                if (p + 1 < npairs) wfetch2(p + 1, wh[1], wl[1]);
+                compute2(p, wh[0], wl[0]);
+                if (p + 2 < npairs) wfetch2(p + 2, wh[0], wl[0]);
+                if (p + 1 < npairs) compute2(p + 1, wh[1], wl[1]);
+            }
+        } else {
         wfetch(wsrc, 0, wb[0]);
         wfetch(wsrc, 1, wb[1]);
         if (DBG & 1) wfetch(wsrc, 2, wb[2]);
@@ -222,6 +291,7 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
             if (!(DBG & 1) && s + 4 < steps) wfetch(wsrc, s + 4, wb[1]);
             compute(s + 2, wb[2]);
         }
+        }
         // (fetching these between the last steps' MFMA blocks -- their ring slots are free by then -- was built and measured: the
         // extra live registers spill, the scratch traffic shares vmcnt with the loads, 516 -> 542 us.  Not kept.)
         load_scale();
@@ -232,7 +302,7 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
         // ---- BN + leaky in registers; GEMM2 straight from the accumulators
         const int co = tabs.ch_off[br];
         const float w2s = tabs.w2s[br];
-        float* mine = red + wn * (kHeadRows * 16 * RLD);
+        float* mine;
         // partial 1x1 outputs of this wave: po[i][of] = D2[o = 16*of + 4*kq + r][pixel (row i, x = xl)]
         f32x4 po[FM][2];
 #pragma unroll
@@ -246,40 +316,58 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
                     t[j][r] = v > 0.f ? v : 0.01f * v;
                 }
             po[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; po[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int kbp = 0; kbp < KBLK / 2; ++kbp) {
+                    const float v[8] = {t[2 * kbp][0], t[2 * kbp][1], t[2 * kbp][2], t[2 * kbp][3], t[2 * kbp + 1][0], t[2 * kbp + 1][1], t[2 * kbp + 1][2], t[2 * kbp + 1][3]};
+                    u32x4 th, tl;
+                    split8(v, th, tl);
+                    mma_split3(w2f[2 * kbp][0], w2f[2 * kbp + 1][0], th, tl, po[i][0]);
+                    if (two) mma_split3(w2f[2 * kbp][1], w2f[2 * kbp + 1][1], th, tl, po[i][1]);
+                }
+            } else {
 #pragma unroll
             for (int kb = 0; kb < KBLK; ++kb) {
                 const u32x4 tb = TrunkPack<T>::make(t, kb);
                 mma_chunk<T>(w2f[kb][0], tb, po[i][0]);
                 if (two) mma_chunk<T>(w2f[kb][1], tb, po[i][1]);
             }
+            }
         }
+        constexpr int RR = HeadSmem<T, PL>::red_rows, SLICE = RR * 16 * RLD;      // rows per reduction pass, floats per wave slice
+        constexpr int PPW = RR * 16 / kHeadWaves, NIT = PPW * 4 / 64;             // pixels summed per wave per pass, items per lane
+        mine = red + wn * SLICE;
         for (int of = 0; of < (two ? 2 : 1); ++of) {         // 16 output channels per pass
-            __syncthreads();                                 // slices free (previous pass / branch fully summed)
 #pragma unroll
-            for (int i = 0; i < FM; ++i) *reinterpret_cast<f32x4*>(mine + (i * 16 + xl) * RLD + kq * 4) = po[i][of];
-            __syncthreads();
-            // wave wn sums pixels [32wn, 32wn+32): lane -> (pixel, group of 4 outputs), 2 items per lane
+            for (int half = 0; half < FM / RR; ++half) {
+                __syncthreads();                             // slices free (previous pass / branch fully summed)
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int item = it * 64 + lane;
-                const int px = wn * 32 + (item >> 2), og = item & 3;
-                f32x4 sum = *reinterpret_cast<const f32x4*>(red + px * RLD + og * 4);
+                for (int i = 0; i < RR; ++i) *reinterpret_cast<f32x4*>(mine + (i * 16 + xl) * RLD + kq * 4) = po[half * RR + i][of];
+                __syncthreads();
+                // wave wn sums pixels [PPW*wn, PPW*wn + PPW) of the pass: lane -> (pixel, group of 4 outputs)
 #pragma unroll
-                for (int w = 1; w < kHeadWaves; ++w) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(red + w * (kHeadRows * 16 * RLD) + px * RLD + og * 4);
-                    sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
-                }
-                const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
-                if (oy < g.H && ox < g.W) {
-                    const size_t m = ((size_t)b * g.H + oy) * g.W + ox;
+                for (int it = 0; it < NIT; ++it) {
+                    const int item = it * 64 + lane;
+                    const int px = wn * PPW + (item >> 2), og = item & 3;
+                    f32x4 sum = *reinterpret_cast<const f32x4*>(red + px * RLD + og * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int o = of * 16 + og * 4 + r;
-                        if (o < cn) {
-                            const float res = sum[r] * w2s + bias2[br * 32 + o];
-                            out[m * g.ld_out + co + o] = res;
-                            if (br == 0 && g.planar && o < g.planar_c)
-                                g.planar[((size_t)b * g.planar_c + o) * g.H * g.W + (size_t)oy * g.W + ox] = res;
+                    for (int w = 1; w < kHeadWaves; ++w) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(red + w * SLICE + px * RLD + og * 4);
+                        sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+                    }
+                    const int tp = half * RR * 16 + px;      // pixel of the 8 x 16 tile
+                    const int oy = y0 + (tp >> 4), ox = x0 + (tp & 15);
+                    if (oy < g.H && ox < g.W) {
+                        const size_t m = ((size_t)b * g.H + oy) * g.W + ox;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int o = of * 16 + og * 4 + r;
+                            if (o < cn) {
+                                const float res = sum[r] * w2s + bias2[br * 32 + o];
+                                out[m * g.ld_out + co + o] = res;
+                                if (br == 0 && g.planar && o < g.planar_c)
+                                    g.planar[((size_t)b * g.planar_c + o) * g.H * g.W + (size_t)oy * g.W + ox] = res;
+                            }
                         }
                     }
                 }
@@ -304,7 +392,7 @@ template <typename T, bool PL, int DBG = 0> static int launch_heads(const mfx_he
             int dev = 0, cus = 0;
             MFX_HIP_CHECK(hipGetDevice(&dev));
             MFX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            slots = cus * (2 * HeadSmem<T, PL>::bytes <= 160 * 1024 ? 2 : 1);       // fp32: one 90 KB workgroup per CU
+            slots = cus * (2 * HeadSmem<T, PL>::bytes <= 160 * 1024 ? 2 : 1);
         }
         const int want = g_opt_heads_persist > 1 ? g_opt_heads_persist : slots;      // (> 1: that many workgroups -- tests)
         if (tiles > want) { grid = want; g.persist = 1; }

@@ -127,10 +127,29 @@ class DCN(DCNv2):
         return AG.dcn_module(x, c.weight, c.bias, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
 
     def forward(self, input):
-        if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad and self.training):
-            raise NotImplementedError("DCN training path (offset conv backward) lands with the backward kernels; "
-                                      "use dcn_v2_conv / DCNv2 for a differentiable deformable conv")
-        dtype = torch.float32 if input.dtype == torch.float32 else torch.bfloat16
-        x = ops.nchw_to_nhwc(input, dtype)
-        y = self.forward_nhwc(x)
-        return ops.nhwc_to_nchw(y)
+        """(B,C,H,W) NCHW -> (B,Cout,Ho,Wo) NCHW, the reference's own call form (dcn_v2.py:118-128), differentiable with respect to
+        the input and all four parameters whenever autograd is recording (testcuda.py:169-180 `example_dconv`: forward, then
+        `error.backward()`).  One deformable group and square geometry run the NHWC operators (`AG.dcn_module`: offset/mask conv with
+        the sigmoid fused, DCNv2, both HIP backward kernels); deformable_groups > 1 goes through `dcn_v2_conv` like the reference does,
+        with the offset/mask conv on the HIP conv kernels.  The layout changes at the boundary are data movement only."""
+        from .... import autograd as AG
+        kh, kw = self.kernel_size
+        square = self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] and self.dilation[0] == self.dilation[1]
+        recording = torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not square:
+            raise RuntimeError("DCN: stride / padding / dilation must be square on this build (the MonoFlex model only builds square "
+                               "3x3 DCNs, dla_dcn.py:391; `_ext.dcn_v2_forward` reports the same)")
+        if self.deformable_groups == 1 and not recording:
+            dtype = torch.float32 if input.dtype == torch.float32 else torch.bfloat16
+            x = ops.nchw_to_nhwc(input, dtype)
+            return ops.nhwc_to_nchw(self.forward_nhwc(x))                    # fused eval kernels (no graph recorded)
+        x = input.float().permute(0, 2, 3, 1).contiguous()                   # NHWC; autograd sees the permute
+        c = self.conv_offset_mask
+        if self.deformable_groups == 1:
+            y = AG.dcn_module(x, c.weight, c.bias, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
+            return y.permute(0, 3, 1, 2).contiguous()
+        # general group count: out = conv_offset_mask(input); o1, o2, mask = chunk(out, 3); offset = cat(o1, o2); mask = sigmoid(mask)
+        out = AG.conv2d(x, c.weight, c.bias, self.stride[0], self.padding[0], out_dtype=torch.float32).permute(0, 3, 1, 2)
+        n = self.deformable_groups * kh * kw
+        offset, mask = out[:, :2 * n].contiguous(), torch.sigmoid(out[:, 2 * n:3 * n]).contiguous()
+        return dcn_v2_conv(input.float(), offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation, self.deformable_groups)

@@ -190,7 +190,7 @@ class DLA(nn.Module):
             scale, shift = ops.fold_bn(self.base_layer[1])
             packs[("stem", tag)] = ops.pack_stem(self.base_layer[0].weight, tag, scale, shift)
         B, _, H, W = images.shape
-        if dtype in (torch.bfloat16, torch.float16) and packs[("stem", tag)].Cout == 16:
+        if (dtype in (torch.bfloat16, torch.float16) or tag == ops.F16X2) and packs[("stem", tag)].Cout == 16:
             x = ops.stem_conv(images, packs[("stem", tag)])                 # reads the NCHW planes directly
         else:
             x = ops.conv2d(ops.pack_image(images, dtype), packs[("stem", tag)], out_hw=(H, W))

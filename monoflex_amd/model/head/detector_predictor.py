@@ -133,6 +133,8 @@ class _predictor(nn.Module):
                 w1[i], sc[i] = w1[i] * ws, sc[i] / ws
         # 3x3 weights, fragment-major: [branch][wave wn 4][step][frag j 4][k-group kq 4][row nl 16][E]  (lane = kq*16+nl)
         W1 = ops.cast_operand(torch.stack(w1, 0).view(nb, 4, 4, 16, steps, 4, E).permute(0, 1, 4, 2, 5, 3, 6).contiguous(), dtype)
+        if dtype == ops.F16X2:
+            W1 = ops.pair_steps(W1, 2)                              # [branch][wn][step pair][hi | lo][j][kq][nl][4]: heads.hip walks K in step pairs
         w2 = torch.zeros(nb, 32, self.head_conv, device=dev)
         b2 = torch.zeros(nb, 32, device=dev)
         ch_off, c_out = [0], [self.num_classes]
@@ -160,6 +162,8 @@ class _predictor(nn.Module):
         #   f32 : [branch][wn][kb 4][of 2][g 4][o_l 16][e 4],          n = 64wn + 16kb + 4g + e
         if dtype in (torch.float32, ops.F16X2):
             W2 = ops.cast_operand(w2.view(nb, 2, 16, 4, 4, 4, 4).permute(0, 3, 4, 1, 5, 2, 6).contiguous(), dtype)
+            if dtype == ops.F16X2:
+                W2 = ops.pair_steps(W2, 2)                          # [branch][wn][kb pair][hi | lo][of][g][o_l][4]
         else:
             W2 = w2.view(nb, 2, 16, 4, 2, 2, 4, 4).permute(0, 3, 4, 1, 6, 2, 5, 7).contiguous().to(dtype)
         p = ops.PackedHeads(W1, torch.cat(sc).contiguous(), torch.cat(sh).contiguous(),

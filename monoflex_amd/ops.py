@@ -95,6 +95,20 @@ def cast_operand(w, dtype):
     return split_chunks(w) if dtype == F16X2 else w.to(dtype)
 
 
+def pair_steps(x, dim):
+    """Split-precision fragment-major weights for the kernels that walk K in step PAIRS (csrc/heads.hip): `x` is float32-typed with
+    16-byte chunks [hi hi | lo lo] (dwords) in its last axis and the K step on axis `dim`; the result replaces that axis by
+    [pair][hi | lo] and every chunk by [its dwords of step 2p | of step 2p+1]: one 8-element fp16 MFMA operand of hi (lo) halves."""
+    sh = list(x.shape)
+    dim = dim % len(sh)
+    assert sh[-1] == 4 and sh[dim] % 2 == 0
+    lead, mid = sh[:dim], sh[dim + 1:-1]
+    nl, nm = len(lead), len(mid)
+    v = x.reshape(*lead, sh[dim] // 2, 2, *mid, 2, 2)                  # [.., pair, step in pair, mid.., hi/lo, dword]
+    perm = list(range(nl)) + [nl, nl + 2 + nm] + [nl + 2 + i for i in range(nm)] + [nl + 1, nl + 3 + nm]
+    return v.permute(*perm).contiguous().view(*lead, sh[dim] // 2, 2, *mid, 4)
+
+
 def split_weight_scale(w):
     """Power of two s (python float) that brings max |w| * s into [2^11, 2^12): the lo halves of the scaled weights are then normal
     fp16 numbers down to |w| = 2^-14 of the largest one (unscaled, every lo half of a |w| < 0.25 weight is an fp16 SUBNORMAL, i.e.
@@ -227,6 +241,16 @@ def pack_stem(weight, dtype, scale, shift, act=L.ACT_RELU):
     Cout = weight.shape[0]
     w = weight.detach().float()
     w4 = torch.cat((w, w.new_zeros(Cout, 1, 7, 7)), dim=1)              # (Cout,4,7,7)
+    if dtype == F16X2 and Cout == 16:
+        # split precision, dedicated kernel (csrc/stem.hip stem_conv7x7_split_kernel): the fp16 super-tap matrix twice -- hi halves, lo halves
+        w8 = torch.cat((w4, w4.new_zeros(Cout, 4, 7, 1)), dim=3)
+        wp = w8.permute(0, 2, 3, 1).reshape(Cout, 7, 4, 2, 4).reshape(Cout, 7 * 4 * 8)
+        ws = split_weight_scale(wp)
+        wp = wp * ws
+        hi = wp.half()
+        lo = (wp - hi.float()).half()
+        return PackedConv(torch.cat((hi, lo), 0).contiguous(), (scale.detach().float() / ws).contiguous(), shift.contiguous(), 7, 4, 1, 0, 0, 2, 8, Cout,
+                          cout_pad(Cout), wp.shape[1], act, split=True)
     if dtype in (torch.bfloat16, torch.float16):
         w8 = torch.cat((w4, w4.new_zeros(Cout, 4, 7, 1)), dim=3)        # kw 7 -> 8
         # [n][th][j][u][c] with kw = 2j+u
@@ -449,9 +473,9 @@ def stem_conv(images, p: PackedConv):
     images = images.float().contiguous()
     B, C, H, W = images.shape
     assert C == 3 and p.w.dtype in (torch.bfloat16, torch.float16) and p.Cout == 16
-    y = torch.empty((B, H, W, 16), dtype=p.w.dtype, device=images.device)
+    y = torch.empty((B, H, W, 16), dtype=torch.float32 if p.split else p.w.dtype, device=images.device)
     L.check(L.load().mfx_stem_conv7x7_nchw(_ptr(images), _ptr(p.w), _ptr(p.scale), _ptr(p.shift), _ptr(y), B, H, W, 16, p.K_pad, p.act,
-                                           _dt(p.w.dtype), _stream()), "mfx_stem_conv7x7_nchw")
+                                           L.MFX_F16X2 if p.split else _dt(p.w.dtype), _stream()), "mfx_stem_conv7x7_nchw")
     return y
 
 
@@ -565,17 +589,40 @@ def _workspace(nbytes, device):
     return ws
 
 
-@on_tensor_device
-def ext_dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg):
-    _need_cuda(input, weight, bias, offset, mask)
-    ts = [t.float().contiguous() for t in (input, weight, bias, offset, mask)]
-    x, w, b, off, msk = ts
-    B, C, H, W = x.shape
-    Cout = w.shape[0]
+def _ext_check(x, w, off, msk, kh, kw, dg):
+    """The reference's argument checks (src/cuda/dcn_v2_cuda.cu:60-84, dcn_v2.py:84-87) with its messages, as RuntimeError."""
+    C = x.shape[1]
     if w.shape[2] != kh or w.shape[3] != kw:
         raise RuntimeError("Input shape and kernel shape wont match: (%d x %d vs %d x %d)." % (kh, kw, w.shape[2], w.shape[3]))
     if w.shape[1] != C:
         raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (C, w.shape[1]))
+    if dg < 1 or C % dg != 0:
+        raise RuntimeError("dcn_v2: %d input channels cannot be split into %d deformable groups" % (C, dg))
+    if off.shape[1] != 2 * dg * kh * kw or msk.shape[1] != dg * kh * kw:
+        raise RuntimeError("dcn_v2: offset / mask must have 2*dg*kh*kw = %d / dg*kh*kw = %d channels (got %d / %d)"
+                           % (2 * dg * kh * kw, dg * kh * kw, off.shape[1], msk.shape[1]))
+
+
+@on_tensor_device
+def ext_dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg):
+    """`_ext.dcn_v2_forward` (src/dcn_v2.h:9-23): NCHW fp32 in and out.  deformable_group > 1 (the reference's own example,
+    testcuda.py:169-180, uses 2): channel group g is sampled with its own 2*kh*kw offsets and kh*kw mask channels
+    (dcn_v2_im2col_cuda.cu:147-156), so the layer is the sum over g of a one-group layer on that channel slice -- dg calls of the
+    C entry, added here.  Non-square stride / padding / dilation: the C entry reports MFX_ERR_UNSUPPORTED -> RuntimeError."""
+    _need_cuda(input, weight, bias, offset, mask)
+    ts = [t.float().contiguous() for t in (input, weight, bias, offset, mask)]
+    x, w, b, off, msk = ts
+    _ext_check(x, w, off, msk, kh, kw, dg)
+    if dg > 1:
+        Cg, kk = x.shape[1] // dg, kh * kw
+        out = None
+        for g in range(dg):
+            yg = ext_dcn_v2_forward(x[:, g * Cg:(g + 1) * Cg], w[:, g * Cg:(g + 1) * Cg], b if g == 0 else torch.zeros_like(b),
+                                    off[:, 2 * kk * g:2 * kk * (g + 1)], msk[:, kk * g:kk * (g + 1)], kh, kw, sh, sw, ph, pw, dh, dw, 1)
+            out = yg if out is None else out.add_(yg)
+        return out
+    B, C, H, W = x.shape
+    Cout = w.shape[0]
     Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
     Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
     lib_ = L.load()
@@ -589,8 +636,17 @@ def ext_dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw
 
 @on_tensor_device
 def ext_dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kh, kw, sh, sw, ph, pw, dh, dw, dg):
+    """`_ext.dcn_v2_backward` (src/dcn_v2.h:48-59) -> [grad_input, grad_offset, grad_mask, grad_weight, grad_bias]; deformable
+    groups as in the forward: the gradients of group g's channel slice / offset / mask channels come from the one-group call."""
     _need_cuda(input, weight, bias, offset, mask, grad_output)
     x, w, b, off, msk, go = [t.float().contiguous() for t in (input, weight, bias, offset, mask, grad_output)]
+    _ext_check(x, w, off, msk, kh, kw, dg)
+    if dg > 1:
+        Cg, kk = x.shape[1] // dg, kh * kw
+        parts = [ext_dcn_v2_backward(x[:, g * Cg:(g + 1) * Cg], w[:, g * Cg:(g + 1) * Cg], b, off[:, 2 * kk * g:2 * kk * (g + 1)],
+                                     msk[:, kk * g:kk * (g + 1)], go, kh, kw, sh, sw, ph, pw, dh, dw, 1) for g in range(dg)]
+        return [torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1), torch.cat([p[2] for p in parts], 1),
+                torch.cat([p[3] for p in parts], 1), parts[0][4]]
     B, C, H, W = x.shape
     Cout = w.shape[0]
     lib_ = L.load()

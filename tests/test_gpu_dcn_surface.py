@@ -1,0 +1,181 @@
+"""GPU tests of the reference's DCNv2 operator surface as the reference itself exercises it (model/backbone/DCNv2/dcn_v2.py:97-128,
+testcuda.py:69-97,169-180, src/dcn_v2.h:9-59): `DCN.forward(input)` in NCHW with autograd recording, deformable groups > 1 through
+`_ext` and `DCN`, the train-mode DeformConv(DCN -> BN -> ReLU) block, and the error behaviour of what this build narrows."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_ops import DEV, _dcn_case, _g
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_offset_conv(m, seed, std_w=1.5 / 24, std_b=0.2):
+    g = _g(seed)
+    m.conv_offset_mask.weight.data.copy_(torch.randn(m.conv_offset_mask.weight.shape, generator=g) * std_w)
+    m.conv_offset_mask.bias.data.copy_(torch.randn(m.conv_offset_mask.bias.shape, generator=g) * std_b)
+
+
+def _close(a, b, tol, what):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, "%s: max abs err %.3e (scale %.3e)" % (what, err, scale)
+
+
+def test_dcn_forward_nchw_is_differentiable_vs_oracle():
+    """`DCN(64, 64)(input)` with requires_grad, the reference's call form (dla_dcn.py:391-396): output and all five gradients against
+    the oracle module (torch offset conv + C DCNv2 forward / backward, oracle/monoflex_ref.py:50-67)."""
+    from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCN
+    from oracle import monoflex_ref as R
+    ref = R.DCN(64, 64)
+    _rand_offset_conv(ref, 3)
+    ref.bias.data.normal_(0, 0.1, generator=_g(4))
+    hip = DCN(64, 64, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
+    hip.load_state_dict(ref.state_dict())
+    hip.to(DEV).train()
+    x = torch.randn(2, 64, 20, 28, generator=_g(5))
+    tgt = torch.randn(2, 64, 20, 28, generator=_g(6))
+    xr = x.clone().requires_grad_()
+    (ref(xr) * tgt).sum().backward()
+    xh = x.to(DEV).requires_grad_()
+    out = hip(xh)
+    assert out.shape == (2, 64, 20, 28) and out.requires_grad and out.is_contiguous()
+    (out * tgt.to(DEV)).sum().backward()
+    with torch.no_grad():
+        _close(out, ref(x), 5e-5, "output")
+    _close(xh.grad, xr.grad, 2e-4, "grad_input")
+    for n, p in hip.named_parameters():
+        _close(p.grad, dict(ref.named_parameters())[n].grad, 3e-4, "grad " + n)
+    # no graph recorded -> the fused eval kernels, same values
+    with torch.no_grad():
+        _close(hip.eval()(x.to(DEV)), out, 5e-5, "eval path")
+
+
+def test_example_dconv_two_deformable_groups():
+    """testcuda.py:169-180 `example_dconv`: DCN(64, 64, deformable_groups=2), forward + `error.backward()`; checked against the C oracle
+    (which implements groups, oracle/dcn_v2_ref.c:99-124) fed by a torch offset/mask conv."""
+    from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCN
+    from oracle import dcn_ref
+    dcn = DCN(64, 64, kernel_size=(3, 3), stride=1, padding=1, deformable_groups=2)
+    _rand_offset_conv(dcn, 7)
+    assert dcn.conv_offset_mask.weight.shape[0] == 54
+    w_off, b_off, w, b = [t.detach().clone() for t in (dcn.conv_offset_mask.weight, dcn.conv_offset_mask.bias, dcn.weight, dcn.bias)]
+    dcn.to(DEV)
+    x = torch.randn(2, 64, 24, 24, generator=_g(8))
+    xh = x.to(DEV).requires_grad_()
+    output = dcn(xh)
+    target = torch.empty_like(output).uniform_(-0.01, 0.01)
+    error = (target - output).mean()
+    error.backward()
+    assert output.shape == (2, 64, 24, 24)
+
+    xr = x.clone().requires_grad_()
+    wr, br, wor, bor = [t.requires_grad_() for t in (w, b, w_off, b_off)]
+    o = F.conv2d(xr, wor, bor, 1, 1)
+    off, msk = o[:, :36], torch.sigmoid(o[:, 36:54])
+    ref = dcn_ref.dcn_v2_conv(xr, off, msk, wr, br, 1, 1, 1, 2)
+    (target.cpu() - ref).mean().backward()
+    n = float(output.numel())                                         # (the example's loss is a MEAN: gradients carry 1 / numel)
+    _close(output, ref, 5e-5, "output dg=2")
+    _close(xh.grad * n, xr.grad * n, 3e-4, "grad_input dg=2")
+    _close(dcn.weight.grad * n, wr.grad * n, 3e-4, "grad_weight dg=2")
+    _close(dcn.conv_offset_mask.weight.grad * n, wor.grad * n, 1e-3, "grad offset-conv weight dg=2")
+    _close(dcn.conv_offset_mask.bias.grad * n, bor.grad * n, 1e-3, "grad offset-conv bias dg=2")
+    _close(dcn.bias.grad * n, br.grad * n, 1e-4, "grad_bias dg=2")
+
+
+@pytest.mark.parametrize("dg", [2, 4])
+def test_ext_forward_backward_deformable_groups_vs_oracle(dg):
+    from monoflex_amd.model.backbone.DCNv2 import _ext
+    from oracle import dcn_ref
+    B, C, Co, H, W = 2, 32, 16, 10, 14
+    g = _g(30 + dg)
+    x = torch.randn(B, C, H, W, generator=g)
+    off = torch.randn(B, 18 * dg, H, W, generator=g) * 2
+    msk = torch.sigmoid(torch.randn(B, 9 * dg, H, W, generator=g))
+    w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(Co, generator=g)
+    go = torch.randn(B, Co, H, W, generator=g)
+    want = dcn_ref.dcn_v2_forward(x, w, b, off, msk, 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    got = _ext.dcn_v2_forward(*[t.to(DEV) for t in (x, w, b, off, msk)], 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    _close(got, want, 2e-5, "forward dg=%d" % dg)
+    wantb = dcn_ref.dcn_v2_backward(x, w, b, off, msk, go, 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    gotb = _ext.dcn_v2_backward(*[t.to(DEV) for t in (x, w, b, off, msk, go)], 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    for a, r, name in zip(gotb, wantb, ["grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"]):
+        assert a.shape == r.shape, name
+        _close(a, r, 1e-4, "%s dg=%d" % (name, dg))
+
+
+def test_check_gradient_on_the_dcn_module():
+    """The reference's `check_gradient_dconv` (testcuda.py:69-97: gradcheck eps 1e-3, atol 1e-4, rtol 1e-2) applied to the MODULE's own
+    forward (offset/mask conv + sigmoid + DCNv2 as one differentiable NCHW function of the input and the DCN bias; 32 -> 64 channels is
+    the narrowest DCN the NHWC kernels take: K = 9 C must fill whole 128-byte k-iterations, outputs come in 64-channel tiles)."""
+    from torch.autograd import gradcheck
+    from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCN
+    torch.manual_seed(3)
+    m = DCN(32, 64, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
+    _rand_offset_conv(m, 11, std_w=0.05, std_b=0.3)
+    m.to(DEV)
+    inp = (torch.rand(1, 32, 3, 3) * 0.01).to(DEV).requires_grad_()
+
+    def f(i, b):
+        from monoflex_amd import autograd as AG
+        c = m.conv_offset_mask
+        x = i.permute(0, 2, 3, 1).contiguous()
+        return AG.dcn_module(x, c.weight.detach(), c.bias.detach(), m.weight.detach(), b, 1, 1, 1).permute(0, 3, 1, 2)
+    assert torch.allclose(f(inp, m.bias), m(inp), atol=1e-6)              # the module's forward IS this function
+    b = m.bias.detach().clone().requires_grad_()
+    assert gradcheck(f, (inp, b), eps=1e-3, atol=1e-4, rtol=1e-2, nondet_tol=1e-5)
+
+
+def test_deformconv_block_train_mode_vs_oracle():
+    """DeformConv = DCN -> BatchNorm(batch statistics) -> ReLU (dla_dcn.py:384-396) in TRAIN mode against oracle/monoflex_ref.py:
+    output, input gradient, all parameter gradients and the BN running statistics of one step."""
+    from monoflex_amd.model.backbone.dla_dcn import DeformConv
+    from oracle import monoflex_ref as R
+    torch.manual_seed(5)
+    ref = R.DeformConv(64, 64).train()
+    _rand_offset_conv(ref.conv, 12)
+    ref.actf[0].weight.data.uniform_(0.8, 1.2); ref.actf[0].bias.data.normal_(0, 0.1)
+    hip = DeformConv(64, 64)
+    hip.load_state_dict(ref.state_dict())
+    hip.to(DEV).train()
+    x = torch.randn(2, 64, 16, 24, generator=_g(13)).relu()
+    tgt = torch.randn(2, 64, 16, 24, generator=_g(14))
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    (yr * tgt).sum().backward()
+    xh = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_()                   # the block's own interface is NHWC
+    yh = hip(xh)
+    (yh * tgt.permute(0, 2, 3, 1).to(DEV)).sum().backward()
+    _close(yh.permute(0, 3, 1, 2), yr, 1e-4, "output")
+    _close(xh.grad.permute(0, 3, 1, 2), xr.grad, 5e-4, "grad_input")
+    rp = dict(ref.named_parameters())
+    for n, p in hip.named_parameters():
+        _close(p.grad, rp[n].grad, 1e-3, "grad " + n)
+    _close(hip.actf[0].running_mean, ref.actf[0].running_mean, 1e-5, "running_mean")
+    _close(hip.actf[0].running_var, ref.actf[0].running_var, 1e-5, "running_var")
+
+
+def test_unsupported_geometry_surfaces_as_runtime_error():
+    """What this build narrows relative to src/dcn_v2.h:9-23 fails the way the reference's AT_ASSERTM failures do: RuntimeError, with
+    the reason, never a silent wrong answer or a CPU fallback."""
+    from monoflex_amd.model.backbone.DCNv2 import _ext
+    from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCN, DCNv2
+    x, off, msk, w, b = [t.to(DEV) for t in _dcn_case(1, 1, 16, 16, 8, 8)]
+    with pytest.raises(RuntimeError, match="square"):
+        _ext.dcn_v2_forward(x, w, b, off, msk, 3, 3, 1, 2, 1, 1, 1, 1, 1)                # stride_h != stride_w
+    with pytest.raises(RuntimeError, match="square"):
+        _ext.dcn_v2_backward(x, w, b, off, msk, torch.zeros(1, 16, 8, 8, device=DEV), 3, 3, 1, 1, 1, 2, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="kernel shape"):
+        _ext.dcn_v2_forward(x, w, b, off, msk, 5, 5, 1, 1, 1, 1, 1, 1, 1)                # reference: "Input shape and kernel shape wont match"
+    with pytest.raises(RuntimeError, match="kernel channels"):
+        _ext.dcn_v2_forward(x[:, :8].contiguous(), w, b, off, msk, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        DCN(16, 16, kernel_size=(3, 3), stride=(1, 2), padding=1).to(DEV)(x)
+    m = DCNv2(16, 16, (3, 3), 1, 1).to(DEV)
+    with pytest.raises(AssertionError):                                                  # dcn_v2.py:84-87
+        m(x, off[:, :16], msk)
+    with pytest.raises(RuntimeError, match="CPU"):
+        _ext.dcn_v2_forward(x.cpu(), w.cpu(), b.cpu(), off.cpu(), msk.cpu(), 3, 3, 1, 1, 1, 1, 1, 1, 1)

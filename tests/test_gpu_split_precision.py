@@ -91,9 +91,13 @@ def test_stem_and_cat_split():
     scale, shift = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1
     ref = F.relu(F.conv2d(x, w, None, 1, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
     p = ops.pack_stem(w.to(DEV), ops.F16X2, scale.to(DEV), shift.to(DEV))
-    y = ops.conv2d(ops.pack_image(x.to(DEV), ops.F16X2), p, out_hw=(20, 36))
+    y = ops.stem_conv(x.to(DEV), p)                                # the dedicated split-precision stem kernel (csrc/stem.hip)
     torch.cuda.synchronize()
+    assert y.dtype == torch.float32
     _close(_from_nhwc(y), ref, F32, 147, "split stem")
+    xb = torch.randn(1, 3, 37, 150, generator=g)                   # ragged tiles (8 x 64 blocks), three column tiles
+    refb = F.relu(F.conv2d(xb, w, None, 1, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    _close(_from_nhwc(ops.stem_conv(xb.to(DEV), p)), refb, F32, 147, "split stem, ragged")
     chans = [128, 128, 64, 128]
     xs = [torch.randn(2, c, 6, 10, generator=g) for c in chans]
     w = torch.randn(128, sum(chans), 1, 1, generator=g) / sum(chans) ** 0.5

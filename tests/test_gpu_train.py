@@ -769,7 +769,7 @@ def test_train_steps_bf16_mode(half):
         # skipping those steps, and then stays; the applied steps are counted by the growth tracker and by AdamW's own step counters
         sc, halvings = float(scaler.scale), int(round(np.log2(256.0 / float(scaler.scale))))
         assert sc in [2.0 ** k for k in range(1, 9)], sc                          # (how far it backs off differs run to run: atomics order)
-        assert 1 <= int(scaler.growth_tracker) <= n - halvings                 # (clean steps since the last overflow)
+        assert 0 <= int(scaler.growth_tracker) <= n - halvings                 # (clean steps since the last overflow; 0: the last step itself overflowed)
         assert all(int(st["step"]) == n - halvings for st in opt.state.values())
 
 
