@@ -503,7 +503,7 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dty
     loss_scale_info = {}
     if scaler is not None:                                             # fp16: the dynamic loss scale after the run and the steps AdamW applied
         applied = min(int(st["step"]) for st in opt.state.values()) if opt.state else 0
-        total = warmup + steps * len(all_s) + (3 if graphed else 0)    # (+ the eager warm-up steps GraphedTrainStep runs before capturing)
+        total = warmup + steps * len(all_s)                            # (GraphedTrainStep's capture warm-up is rolled back: it counts no steps)
         loss_scale_info = {"loss_scale": float(scaler.scale), "optimizer_steps_applied": applied, "optimizer_steps_run": total}
 
     # ---- roofline of the dominant training kernel family, timed live on one representative layer

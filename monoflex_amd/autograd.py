@@ -244,8 +244,9 @@ def _pack_weight(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, shift=None
 
 def _with_f16_fragments(p, x):
     """The DCN LDS-patch kernel (dcn_patch.hip; 64 -> 64 layers on large maps, bf16) multiplies with an IEEE fp16 copy of the
-    fragment-major weights.  bf16 -> fp16 is exact and element-wise, and both fragment layouts hold 8 elements per 16 bytes, so the
-    copy is one small cast of the bf16 fragments the step's batched packing already produced (36.9 k elements per layer): the
+    fragment-major weights.  bf16 -> fp16 is element-wise and exact for 2^-14 <= |w| <= 65504 (bf16's 8 mantissa bits fit fp16's 11; smaller
+    weights round to fp16 subnormals / zero -- an absolute error below 3e-8 --, larger ones do not occur in a network whose activations
+    are finite in fp16), and both fragment layouts hold 8 elements per 16 bytes, so the copy is one small cast of the bf16 fragments the step's batched packing already produced (36.9 k elements per layer): the
     training forward then runs the third-generation kernel on the five full-resolution layers (102 -> 75 us each) instead of the
     first-generation gather."""
     if p.w_frag is not None and p.Ck == 64 and p.Cout_pad == 64 and x.shape[0] * x.shape[1] * x.shape[2] >= 65536:

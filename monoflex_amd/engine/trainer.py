@@ -206,6 +206,12 @@ class GraphedTrainStep:
             if not torch.is_tensor(g["lr"]):
                 raise ValueError("GraphedTrainStep: the learning rate must be a device scalar (solver.build_optimizer(capturable=True)); "
                                  "a Python float would be baked into the captured optimizer step")
+        # The capture needs warm-up runs (lazy allocations, the optimizer's state tensors, RCCL's first-call setup), and those are
+        # real optimisation steps on batch 0.  They must not count: the state they touch (parameters, BN buffers incl. running
+        # statistics and num_batches_tracked, AdamW moments and step counters, the loss scale) is snapshotted here and written back
+        # IN PLACE after the capture, so the captured graphs keep their addresses and the first replay is step 1 of the run (or step
+        # k+1 of a resumed one) -- a run with the captured step follows the trajectory of the reference's loop (engine/trainer.py:103-126).
+        snap = self._snapshot_state()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -213,6 +219,40 @@ class GraphedTrainStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        try:
+            self._capture()
+        finally:
+            self._restore_state(snap)
+            torch.cuda.synchronize()
+
+    def _snapshot_state(self):
+        with torch.no_grad():
+            return {"params": [p.detach().clone() for p in self.net.parameters()],
+                    "buffers": [b.detach().clone() for b in self.net.buffers()],
+                    "opt": {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                            for p, st in self.optimizer.state.items()},
+                    "scaler": None if self.scaler is None else (self.scaler.scale.clone(), self.scaler.growth_tracker.clone())}
+
+    def _restore_state(self, snap):
+        with torch.no_grad():
+            for p, v in zip(self.net.parameters(), snap["params"]):
+                p.copy_(v)
+            for b, v in zip(self.net.buffers(), snap["buffers"]):
+                b.copy_(v)
+            for p, st in self.optimizer.state.items():
+                old = snap["opt"].get(id(p))
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        if old is not None and torch.is_tensor(old.get(k)):
+                            v.copy_(old[k])
+                        else:
+                            v.zero_()                       # created by the warm-up: AdamW's initial state (zero moments, step 0)
+            if self.scaler is not None:
+                self.scaler.scale.copy_(snap["scaler"][0])
+                self.scaler.growth_tracker.copy_(snap["scaler"][1])
+                self.scaler.found_inf.zero_()
+
+    def _capture(self):
         g0 = torch.cuda.CUDAGraph()
         self.graph_a = g0
         if not self.split:
@@ -462,7 +502,15 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
             if shapes == graphed_shapes:
                 graphed.load_batch(img_t, targets)
                 losses = graphed()
-            else:                                               # a batch of another shape (last partial batch): the eager step
+            elif graphed.split:
+                # a batch of another shape (a partial last batch) in a data-parallel run: the model is not DDP-wrapped on this path, so
+                # the reference's eager step would skip the gradient exchange and the ranks would drift apart silently.  The same
+                # segmented step runs eagerly instead -- cut backward, flat gradient buffer, one all-reduce per piece -- which issues
+                # exactly the collectives the captured step issues, so ranks that replay and ranks that fall back still meet
+                # (the loaders of this build hand every rank the same batch shape at the same iteration: data/samplers.py).
+                losses = GraphedTrainStep(model, optimizer, img_t, targets, group=graphed.group, split=True, use_graphs=False,
+                                          grad_norm_clip=clip, scaler=scaler)()
+            else:                                               # single process: the reference's eager step
                 losses, _, _ = train_step(model, optimizer, images, targets, grad_norm_clip=clip, scaler=scaler)
         else:
             losses, loss_dict, log_loss_dict = train_step(model, optimizer, images, targets, grad_norm_clip=clip, scaler=scaler)

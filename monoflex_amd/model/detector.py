@@ -91,6 +91,19 @@ class KeypointDetector(nn.Module):
         """The four pieces of `losses.backward()` over the cut forward pass, in execution order.  `cuts[name] = (maps the forward
         produced, the detached leaves the next stage consumed)`; a piece back-propagates the leaves' gradients into the maps.
         level3's map has two consumers (level4 through "level3", DLAUp through "base"): their gradients are added first."""
+        # the pieces below hard-wire DLA-34 at DOWN_RATIO 4 (first_level 2): levels 0 / 1 feed nothing but level 2, so their cut
+        # leaves carry no gradient of their own.  Another first level would hand DLAUp those maps and their gradients would be
+        # dropped silently -- refuse instead.
+        base_leaves = cuts["base"][1]
+        if len(base_leaves) != 6:
+            raise RuntimeError("backward_thunks: expected the six DLA level maps at the 'base' cut, got %d" % len(base_leaves))
+
+        def check_unused_levels():
+            for i in (0, 1):
+                if base_leaves[i].grad is not None:
+                    raise RuntimeError("backward_thunks: level%d's map received a gradient through the 'base' cut -- this cut layout "
+                                       "assumes first_level == 2 (DOWN_RATIO 4), where only levels 2..5 feed DLAUp" % i)
+
         def run(tensors, grads):
             pairs = [(t, g) for t, g in zip(tensors, grads) if g is not None and t.requires_grad]
             torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
@@ -104,6 +117,7 @@ class KeypointDetector(nn.Module):
             run(o[4:6], [l[4].grad, l[5].grad])
 
         def level3_to_stem():
+            check_unused_levels()
             o, l = cuts["base"]
             g3, gx = l[3].grad, cuts["level3"][1][0].grad
             run([o[2], o[3]], [l[2].grad, gx if g3 is None else (g3 if gx is None else g3 + gx)])

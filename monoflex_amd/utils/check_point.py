@@ -137,6 +137,9 @@ def scheduler_state_to_reference(model, optimizer, sched_sd):
     for k in _per_group_lists(sched_sd):
         if len(sched_sd[k]) == len(optimizer.param_groups) != len(names):
             out[k] = [sched_sd[k][loc[n][1]] for n in names]
+        # device-scalar learning rates (solver.build_optimizer(capturable=True)) -> floats: the reference's files hold plain numbers
+        # (a tensor lr would reach a non-capturable AdamW there, and the file would need map_location to load)
+        out[k] = [_scalar(v) for v in out[k]]
     return out
 
 

@@ -209,3 +209,14 @@ def test_saved_optimizer_state_is_in_the_reference_layout(tmp_path):
     assert torch.equal(opt.state[dict(a.named_parameters())[n]]["exp_avg"], opt_ref.state[dict(b.named_parameters())[n]]["exp_avg"])
     lrs = {g["lr"] for g in opt_ref.param_groups}
     assert lrs == {cfg.SOLVER.BASE_LR, cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR}
+    # on a GPU the learning rates are device scalars (capturable AdamW), so the scheduler's per-group lists hold tensors;
+    # the file must hold the reference's plain floats (no tensor anywhere in the scheduler part)
+    from monoflex_amd.utils import check_point as CP
+    sd = dict(sched.state_dict())
+    for k in ("base_lrs", "_last_lr"):
+        sd[k] = [torch.tensor(float(v)) for v in sd[k]]
+    out = CP.scheduler_state_to_reference(a, opt, sd)
+    for k in ("base_lrs", "_last_lr"):
+        assert len(out[k]) == 280 and all(type(v) is float for v in out[k]), k
+    assert not any(torch.is_tensor(v) for v in raw["scheduler"].values())
+    assert not any(torch.is_tensor(x) for v in raw["scheduler"].values() if isinstance(v, (list, tuple)) for x in v)

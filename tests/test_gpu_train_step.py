@@ -137,6 +137,41 @@ def test_ddp_gradients_equal_the_unwrapped_models_bitwise(nccl_world1, determini
     assert not diff, diff[:8]
 
 
+@pytest.mark.parametrize("dtype,split", [("fp32", False), ("fp16", True)])
+def test_capture_warmup_does_not_advance_the_training_state(dtype, split, nccl_world1):
+    """the eager steps GraphedTrainStep runs before capturing are rolled back -- parameters, BN running statistics and
+    num_batches_tracked, AdamW moments / step counters and the loss scale are those of the moment before construction, in the same
+    tensors (the captured graphs keep their addresses).  So replay 1 is optimisation step 1 of a fresh run, and step k+1 of a resumed one."""
+    from monoflex_amd.engine.trainer import GraphedTrainStep, LossScaler, train_step
+    from monoflex_amd.solver import build_optimizer
+    cfg = _cfg(dtype)
+    m = _model(dtype)
+    imgs, tg = _batch(m)
+    opt = build_optimizer(m, cfg, capturable=True)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    step = GraphedTrainStep(m, opt, imgs, tg, warmup=3, split=split)
+    torch.cuda.synchronize()
+    assert all(torch.equal(sd0[k], v) for k, v in m.state_dict().items()), [k for k, v in m.state_dict().items() if not torch.equal(sd0[k], v)][:5]
+    assert len(opt.state) > 250 and all(float(st["step"]) == 0 and not bool(st["exp_avg"].any()) and not bool(st["exp_avg_sq"].any())
+                                        for st in opt.state.values())
+    if step.scaler is not None:
+        assert float(step.scaler.scale) == 2.0 ** 8 and int(step.scaler.growth_tracker) == 0
+    step()
+    torch.cuda.synchronize()
+    applied = 0 if (step.scaler is not None and float(step.scaler.found_inf) != 0.0) else 1
+    assert all(float(st["step"]) == applied for st in opt.state.values())
+    nbt = [v for k, v in m.state_dict().items() if k.endswith("num_batches_tracked") and int(v) > 0]
+    assert nbt and all(int(v) == 1 for v in nbt)                            # exactly one forward pass has been counted
+    # a "resumed" run: a second capture from a stepped state leaves that state as it is
+    sd1 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    st1 = [(st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"].clone()) for st in opt.state.values()]
+    GraphedTrainStep(m, opt, imgs, tg, warmup=2, split=split, scaler=step.scaler)
+    torch.cuda.synchronize()
+    assert all(torch.equal(sd1[k], v) for k, v in m.state_dict().items())
+    assert all(torch.equal(a, st["exp_avg"]) and torch.equal(b, st["exp_avg_sq"]) and torch.equal(c, st["step"])
+               for (a, b, c), st in zip(st1, opt.state.values()))
+
+
 @pytest.mark.parametrize("split", [False, True])
 def test_graphed_train_step_equals_the_eager_step(split, nccl_world1):
     """engine.trainer.GraphedTrainStep (what `bench.py --mode train` times): one replayed step moves every parameter like one
