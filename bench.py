@@ -63,7 +63,9 @@ def parse():
     ap.add_argument("--cpu-baseline-images", type=int, default=6)
     ap.add_argument("--split", action="store_true", help="train mode: the segmented data-parallel form (cut backward, flat gradient buffer, "
                                                         "per-segment exchange, optimizer graph) also on one GPU, to price the segmentation")
-    ap.add_argument("--sync-bn", action="store_true", help="train mode, N > 1: synchronised BatchNorm statistics")
+    ap.add_argument("--sync-bn", default="auto", choices=["auto", "on", "off"],
+                    help="train mode, N > 1: synchronised BatchNorm statistics (the reference trains with USE_SYNC_BN True: runs/monoflex.yaml:59). "
+                         "auto = on whenever N > 1; the statistics collectives are captured inside the step's hipGraphs")
     ap.add_argument("--legs", default="all", choices=["all", "none"], help="infer mode: add the `train` and `fp32_parity` legs to the line")
     ap.add_argument("--repeats", type=int, default=None, help="timed regions of exactly --steps steps; the median is reported")
     ap.add_argument("--leg-timeout", type=int, default=420, help="seconds after which unfinished legs are reported as errors and the line is printed")
@@ -455,7 +457,7 @@ def cpu_train_baseline(n_steps=1):
             "sample": "%d x (B=1 forward + 11 losses + backward), oracle/monoflex_ref.py, %.1f s" % (n_steps, dt)}
 
 
-def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dtype=None):
+def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dtype=None, sync_bn=None):
     import torch
     from monoflex_amd import lib, parallel, synthetic as S
     from monoflex_amd.engine.trainer import (GraphedTrainStep, LossScaler, convert_sync_batchnorm, prepare_targets, train_step,
@@ -468,14 +470,17 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dty
     warmup = args.warmup if warmup is None else warmup
     model, _, cfg = build_model(dtype, device, train=True)
     model.heads.loss_evaluator.log_as_float = False                  # no host sync inside the step
-    if args.sync_bn and world > 1:
+    if sync_bn is None:
+        sync_bn = args.sync_bn != "off"
+    sync_bn = bool(sync_bn and world > 1)
+    if sync_bn:
         convert_sync_batchnorm(model)
     B = args.batch
     seed = parallel.shard_seed(1000, rank, B)
     imgs = S.synthetic_images(B, seed=seed).to(device)
     targets = [make_train_target(S.synthetic_train_target(seed + i)).to(device) for i in range(B)]
     targets = prepare_targets(model, targets, device)
-    graphed = not args.no_graph and not (args.sync_bn and world > 1)        # SyncBN collectives sit inside the network
+    graphed = not args.no_graph                                        # (SyncBN's statistics collectives are captured with the step)
     opt = build_optimizer(model, cfg, capturable=graphed)
     scaler = LossScaler.for_model(model, device)                       # fp16 activations: dynamic loss scaling (None otherwise)
     if scaler is not None:
@@ -519,7 +524,7 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dty
         "config": {"workload": "MonoFlex training step (fwd + 11 losses + bwd + AdamW), batch %d per GPU, 1280x384, %s activations, "
                                "fp32 parameters/gradients (BASELINE.json configs[2]/[3] per-GPU shape)" % (B, dtype),
                    "batch_per_gpu": B, "global_batch": B * world, "launch": mode,
-                   "parallelism": "dp%d" % world if world > 1 else "single GPU", "sync_bn": bool(args.sync_bn and world > 1),
+                   "parallelism": "dp%d" % world if world > 1 else "single GPU", "sync_bn": sync_bn,
                    "overlap": overlap,
                    "timing": {"repeats": len(all_s), "reported": "median repeat", "steps_per_repeat": steps,
                               "ms_per_step_each": [round(1e3 * t / steps, 4) for t in all_s]},
@@ -564,28 +569,34 @@ def main():
             import gc
             import threading
             legs = {}
+            # Inference legs first, training legs last: the data-parallel training legs are the only ones with collectives, so a hang in
+            # one (first multi-rank RCCL run of a path) costs the line nothing that was already measured.  N > 1: `train_local_bn` is the
+            # data-parallel step with rank-local BN statistics (no collective inside the graphs), `train` / `train_fp16` synchronise
+            # them like the reference (captured RCCL all-reduces); N = 1: the three coincide and `train_local_bn` is not run.
+            leg_list = [("fp32_parity", lambda: run_infer(args, rank, world, device, dtype="fp32", leg=True)),
+                        ("fp16x2_parity", lambda: run_infer(args, rank, world, device, dtype="fp16x2", leg=True)),
+                        ("pipeline", lambda: run_pipeline(args, rank, world, device)),
+                        ("fp16", lambda: run_infer(args, rank, world, device, dtype="fp16", leg=True))]
+            if world > 1:
+                leg_list.append(("train_local_bn", lambda: run_train(args, rank, world, device, steps=args.train_steps, warmup=args.train_warmup,
+                                                                     leg=True, sync_bn=False)))
+            leg_list += [("train", lambda: run_train(args, rank, world, device, steps=args.train_steps, warmup=args.train_warmup, leg=True)),
+                         ("train_fp16", lambda: run_train(args, rank, world, device, steps=args.train_steps, warmup=args.train_warmup, leg=True,
+                                                          dtype="fp16"))]
 
             def bail():
                 # a leg that hangs (first multi-rank RCCL run of the segmented exchange, a wedged capture) must not take the headline with
                 # it: after --leg-timeout seconds rank 0 prints the line with what is finished and every rank leaves
                 if rank == 0:
                     out = dict(res, **legs)
-                    out.setdefault("train", {"error": "leg did not finish within %d s" % args.leg_timeout})
-                    out.setdefault("fp32_parity", {"error": "leg did not finish within %d s" % args.leg_timeout})
-                    for k in ("fp16x2_parity", "pipeline", "fp16", "train_fp16"):
+                    for k, _ in leg_list:
                         out.setdefault(k, {"error": "leg did not finish within %d s" % args.leg_timeout})
                     print(json.dumps(out), flush=True)
                 os._exit(0)
             dog = threading.Timer(args.leg_timeout, bail)
             dog.daemon = True
             dog.start()
-            for name, fn in (("train", lambda: run_train(args, rank, world, device, steps=args.train_steps, warmup=args.train_warmup, leg=True)),
-                             ("fp32_parity", lambda: run_infer(args, rank, world, device, dtype="fp32", leg=True)),
-                             ("fp16x2_parity", lambda: run_infer(args, rank, world, device, dtype="fp16x2", leg=True)),
-                             ("pipeline", lambda: run_pipeline(args, rank, world, device)),
-                             ("fp16", lambda: run_infer(args, rank, world, device, dtype="fp16", leg=True)),
-                             ("train_fp16", lambda: run_train(args, rank, world, device, steps=args.train_steps, warmup=args.train_warmup, leg=True,
-                                                              dtype="fp16"))):
+            for name, fn in leg_list:
                 gc.collect()
                 torch.cuda.empty_cache()
                 try:

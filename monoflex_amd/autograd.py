@@ -481,11 +481,24 @@ class StemConvFn(Function):
         return None, dw, None
 
 
+_SYNC_BN_GROUP = [None]        # process group of the SyncBN statistics collectives (None: the default group); see set_sync_bn_group
+_SYNC_BN_FORCE = [False]       # tests: issue the collectives on a one-rank group too (captured-collective coverage on a single GPU)
+
+
+def set_sync_bn_group(group):
+    """Route the SyncBN statistics all-reduces through `group` (None: the default group).  engine.trainer.GraphedTrainStep gives them a
+    communicator of their own: they are CAPTURED inside the step's hipGraphs and replayed by the GPU, while the gradient slices are
+    all-reduced on the default communicator from the host between graphs -- two issue orders that must not share one communicator."""
+    _SYNC_BN_GROUP[0] = group
+
+
 def _sync_group(sync):
     """Process group for synchronised BN, or None (single process / local statistics)."""
     import torch.distributed as dist
-    if sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist.group.WORLD
+    if sync and dist.is_available() and dist.is_initialized():
+        g = _SYNC_BN_GROUP[0] if _SYNC_BN_GROUP[0] is not None else dist.group.WORLD
+        if dist.get_world_size(g) > 1 or _SYNC_BN_FORCE[0]:
+            return g
     return None
 
 
@@ -551,7 +564,7 @@ class BNActFn(Function):
         Mt = M
         if group is not None:
             import torch.distributed as dist
-            st[2 * C] = float(M)
+            st[2 * C:].fill_(float(M))                         # (a fill kernel: an indexed scalar assignment is a host copy, illegal while capturing)
             dist.all_reduce(st, group=group)
             Mt = M * dist.get_world_size(group)                # equal per-rank batches (weak scaling), no host sync
         out = torch.empty(4 * C, dtype=torch.float32, device=x.device)          # mean | rstd | scale | shift

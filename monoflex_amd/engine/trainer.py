@@ -148,8 +148,15 @@ class GraphedTrainStep:
     dead parameters (`dead_parameter_names`) never get a gradient and are left out of the buffer.  Static inputs: the image batch
     and the PreparedTargets given at construction; `load_batch` overwrites them in place between replays.  The learning rate is a
     device scalar (solver.build_optimizer(capturable=True)), so schedulers keep working between replays.  `use_graphs=False` runs
-    the same pieces eagerly (CPU / gloo tests of the segmented exchange).  SyncBN puts collectives inside the network and keeps
-    the eager path (bench.py --sync-bn); the graphed step normalises with rank-local batch statistics (per-GPU batch 8)."""
+    the same pieces eagerly (CPU / gloo tests of the segmented exchange).
+
+    SyncBN (tools/plain_train_net.py:131-132, runs/monoflex.yaml:59 USE_SYNC_BN True) stays on this fast path: a synchronised BN layer
+    is statistics kernel -> all-reduce of [sum, sum of squares, rows] -> finalize + apply (and reduce -> all-reduce of [sum g, sum g.xhat]
+    -> apply on the way back), and those 2 x 57 small collectives are CAPTURED with the kernels around them -- RCCL collectives replay from
+    a hipGraph -- so they cost their latency on the device and nothing on the host.  Each is a true data dependency of the next layer
+    (layer l+1 reads the output normalised with layer l's global statistics), so they cannot be batched; they run on a communicator of
+    their own (`autograd.set_sync_bn_group`), because the gradient slices are all-reduced on the default communicator in host order
+    between graph launches."""
 
     def __init__(self, model, optimizer, images, targets, group=None, comm_chunks=None, warmup=3, split=None, use_graphs=None,
                  grad_norm_clip=-1.0, scaler="auto"):
@@ -169,6 +176,12 @@ class GraphedTrainStep:
         self.graph_a = None                                            # (kept: the first captured graph)
         self.overlap = False
         self.nseg = 1
+        self.sync_bn = self.world > 1 and any(getattr(mod, "sync_bn", False) or isinstance(mod, torch.nn.SyncBatchNorm) for mod in self.net.modules())
+        self.bn_group = None
+        if self.sync_bn and (images.is_cuda if use_graphs is None else bool(use_graphs)) and dist.get_backend(group) == "nccl":
+            from .. import autograd as AG
+            self.bn_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None)    # (collective: every rank constructs the step)
+            AG.set_sync_bn_group(self.bn_group)
         if self.split:
             dead = set(dead_parameter_names(self.net))
             named = [(n, p) for n, p in self.net.named_parameters() if p.requires_grad and n not in dead]
@@ -471,9 +484,9 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
     t0 = time.time()
     loss_v = None
     # The fast step: when the loader hands over device-encoded batches of one static shape (DeviceLoader: `fields`), the optimizer
-    # was built capturable (solver.build_optimizer does that on a GPU) and BN statistics are rank-local, the whole step is replayed
-    # from hipGraphs (GraphedTrainStep: ~3.5x less wall time than the eager launches, gradient exchange overlapped with backward);
-    # every later batch is copied into the captured buffers.  Anything else (DDP-wrapped model, SyncBN, CPU tensors, ragged
+    # was built capturable (solver.build_optimizer does that on a GPU), the whole step is replayed from hipGraphs (GraphedTrainStep:
+    # ~3.5x less wall time than the eager launches, gradient exchange overlapped with backward, SyncBN's statistics collectives
+    # captured); every later batch is copied into the captured buffers.  Anything else (DDP-wrapped model, CPU tensors, ragged
     # shapes) takes the eager step, the reference's literal loop.
     graphed, graphed_shapes = None, None
     scaler = LossScaler.for_model(net, device) if torch.device(device).type == "cuda" else None     # fp16 activations: dynamic loss scaling
@@ -482,8 +495,7 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
         if arguments.get("loss_scaler"):                             # resumed run: continue from the checkpointed scale
             scaler.load_state_dict(arguments["loss_scaler"])
     want_graph = bool(cfg.SOLVER.get("GRAPHED_STEP", True)) and not hasattr(model, "module") \
-        and all(g.get("capturable", False) and torch.is_tensor(g["lr"]) for g in optimizer.param_groups) \
-        and not any(getattr(mod, "sync_bn", False) or isinstance(mod, torch.nn.SyncBatchNorm) for mod in net.modules())
+        and all(g.get("capturable", False) and torch.is_tensor(g["lr"]) for g in optimizer.param_groups)
     if want_graph and hasattr(net, "heads") and hasattr(net.heads, "loss_evaluator"):
         net.heads.loss_evaluator.log_as_float = False                   # (logged values stay device scalars: no host sync inside the step)
     for data, iteration in zip(data_loader, range(start_iter, max_iter)):

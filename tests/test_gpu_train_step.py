@@ -361,6 +361,143 @@ def test_segmented_graphed_step_on_two_ranks_sharing_the_gpu():
     assert f0 == f1 and f0 > 0 and b0 == b1 and len(b0) == 4 and b0[0][0] == 0 and all(b0[k][1] == b0[k + 1][0] for k in range(3))
 
 
+def test_sync_bn_collectives_are_captured_in_the_graphed_step(nccl_world1, deterministic):
+    """SyncBN on the fast path: with every BN marked synchronised, the step's 2 x 57 statistics all-reduces are issued INSIDE the captured
+    graphs (here on the one-rank RCCL group, forced: a one-rank job normally skips them) and the replayed step equals the same step run
+    eagerly, to the bit, over two steps -- parameters, BN running statistics, AdamW moments."""
+    from monoflex_amd import autograd as AG
+    from monoflex_amd.engine.trainer import GraphedTrainStep, convert_sync_batchnorm, train_step
+    from monoflex_amd.solver import build_optimizer
+    import torch.distributed as dist
+    cfg = _cfg("bf16")
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append((t.numel(), torch.cuda.is_current_stream_capturing()))
+        return real(t, *a, **k)
+    AG._SYNC_BN_FORCE[0] = True
+    dist.all_reduce = counting
+    try:
+        b = _model("bf16")
+        assert convert_sync_batchnorm(b) > 50
+        imgs, tg = _batch(b)
+        opt_b = build_optimizer(b, cfg, capturable=True)
+        step = GraphedTrainStep(b, opt_b, imgs, tg, warmup=2)
+        captured = [n for n, cap in calls if cap]
+        assert len(captured) >= 2 * 50 and max(captured) <= 2 * 512 + 1, (len(captured), max(captured or [0]))   # one per BN each way, 2C(+1) floats
+        torch.cuda.synchronize()
+        a = _model("bf16", seed=5)
+        convert_sync_batchnorm(a)
+        a.load_state_dict({k: v.detach().clone() for k, v in b.state_dict().items()})
+        opt_a = build_optimizer(a, cfg, capturable=True)
+        opt_a.load_state_dict(copy.deepcopy(opt_b.state_dict()))
+        n_before = len(calls)
+        for it in range(2):
+            loss_b = step().clone()
+            assert len(calls) == n_before                            # replays issue nothing from the host
+            loss_a = train_step(a, opt_a, imgs, tg)[0]
+            n_before = len(calls)
+            torch.cuda.synchronize()
+            assert torch.equal(loss_a, loss_b), (it, float(loss_a), float(loss_b))
+            sa, sb = a.state_dict(), b.state_dict()
+            diff = [k for k in sa if not torch.equal(sa[k], sb[k])]
+            assert not diff, (it, diff[:8])
+    finally:
+        dist.all_reduce = real
+        AG._SYNC_BN_FORCE[0] = False
+
+
+def _sync_bn_worker(rank, world, port, out):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from monoflex_amd import autograd as AG, lib as L
+    L.set_deterministic(True)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(4, 12, 20, 64, generator=g)
+    r = torch.randn(4, 12, 20, 64, generator=g)
+    t = torch.randn(4, 12, 20, 64, generator=g)
+    bn = torch.nn.BatchNorm2d(64).to(DEV).train()
+    bn.weight.data.copy_(torch.rand(64, generator=g) + 0.5); bn.bias.data.copy_(torch.randn(64, generator=g) * 0.1)
+    bn.sync_bn = True
+    sl = slice(2 * rank, 2 * rank + 2) if world > 1 else slice(0, 4)
+    xs = x[sl].to(DEV).requires_grad_()
+    rs = r[sl].to(DEV).requires_grad_()
+    y = AG.bn_act(xs, bn, L.ACT_RELU, rs)
+    (y * t[sl].to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    # (numpy: pickled by value -- a tensor would travel as a shared-memory handle that dies with this process)
+    out.put((rank,) + tuple(v.detach().float().cpu().numpy() for v in (y, xs.grad, rs.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var))
+            + (int(bn.num_batches_tracked),))
+    dist.destroy_process_group()
+
+
+def test_sync_bn_two_ranks_equal_one_process_on_the_whole_batch():
+    """SyncBatchNorm semantics (tools/plain_train_net.py:131-132) of the HIP BN operator with world_size 2: two ranks x B=2 (two processes
+    on this GPU, gloo) produce the outputs, input / residual gradients and running statistics of ONE process on the B=4 batch, and their
+    rank-local gamma / beta gradients SUM to the whole-batch ones (the gradient exchange averages parameter gradients afterwards)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world in (2, 1):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_sync_bn_worker, args=(r, world, port, q)) for r in range(world)]
+        [p.start() for p in ps]
+        got = sorted((q.get(timeout=300) for _ in ps), key=lambda v: v[0])
+        [p.join(timeout=60) for p in ps]
+        assert all(p.exitcode == 0 for p in ps)
+        res[world] = got
+    tt = lambda row: tuple(torch.from_numpy(v) if isinstance(v, np.ndarray) else v for v in row)
+    (_, y0, dx0, dr0, dg0, db0, rm0, rv0, n0), (_, y1, dx1, dr1, dg1, db1, rm1, rv1, n1) = tt(res[2][0]), tt(res[2][1])
+    (_, y, dx, dr, dg, db, rm, rv, n) = tt(res[1][0])
+    close = lambda u, v, tol=2e-5: float((u - v).abs().max()) <= tol * max(1.0, float(v.abs().max()))
+    assert close(torch.cat((y0, y1)), y) and close(torch.cat((dx0, dx1)), dx, 1e-4) and close(torch.cat((dr0, dr1)), dr)
+    assert close(dg0 + dg1, dg, 1e-4) and close(db0 + db1, db, 1e-4)
+    assert close(rm0, rm) and close(rm1, rm) and close(rv0, rv) and close(rv1, rv) and n0 == n1 == n == 1
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_sync_bn_graphed_step_on_two_gpus_over_rccl():
+    """First multi-GPU box: the graphed data-parallel step with SyncBN (captured RCCL statistics collectives on their own communicator,
+    gradient slices on the default one) on two GPUs; after two replays both ranks hold bit-identical parameters and BN running statistics."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_sync_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted((q.get(timeout=900) for _ in ps), key=lambda t: t[0])
+    [p.join(timeout=120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (_, l0, d0, s0, sync0), (_, l1, d1, s1, sync1) = res
+    assert sync0 and sync1 and all(np.isfinite(l0 + l1)) and d0 == d1 and s0 == s1
+
+
+def _sync_rccl_worker(rank, world, port, out):
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from monoflex_amd import lib as L
+    from monoflex_amd.engine.trainer import GraphedTrainStep, convert_sync_batchnorm
+    from monoflex_amd.solver import build_optimizer
+    L.set_deterministic(True)
+    m = _model("bf16").to("cuda:%d" % rank)
+    convert_sync_batchnorm(m)
+    imgs, tg = _batch(m, B=2, seed0=20 + 10 * rank)
+    imgs = imgs.to("cuda:%d" % rank)
+    opt = build_optimizer(m, _cfg("bf16"), capturable=True)
+    step = GraphedTrainStep(m, opt, imgs, tg, warmup=2)
+    losses = [float(step()) for _ in range(2)]
+    torch.cuda.synchronize()
+    digest = torch.stack([p.detach().double().sum() for p in m.parameters()]).cpu().tolist()
+    stats = torch.stack([b.detach().double().sum() for n, b in m.named_buffers() if "running_" in n and ".heads." not in "." + n]).cpu().tolist()
+    out.put((rank, losses, digest, stats, bool(step.sync_bn and step.bn_group is not None)))
+    dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_regression_heads_at_object_centres_equal_the_dense_heads(dtype, deterministic):
     """csrc/head_sparse.hip: seven regression branches evaluated (and differentiated) at the object centres only, against the
