@@ -277,7 +277,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 int try_conv_halo(const mfx_conv_desc* d, hipStream_t st, int* stats_ran);   // conv_halo.hip
 extern int g_opt_halo, g_opt_halo_cg, g_opt_dcn_wave, g_opt_dcn_patch, g_opt_dcn_patch_fn8, g_opt_dcn_wgrad_m;
 }
-extern long g_cnt_dcn_bt_fused;
+extern long g_cnt_dcn_bt_fused, g_cnt_dcn_bt_fly;
+extern int g_opt_dcn_bt_fly;
 extern int g_opt_dcn_bt_fuse_min_chunks, g_opt_dcn_bt_fuse_blocks, g_opt_dcn_bt_fuse_wgrad, g_opt_heads_planes, g_opt_heads_persist, g_opt_heads_dbg, g_opt_dcn_bt_cs, g_opt_dcn_bt_cs_wgs, g_opt_dcn_bt_dbg, g_opt_wgrad_tr, g_opt_wgrad_tr_blocks, g_opt_bn_blocks, g_opt_bn_apply_blocks, g_opt_wgrad_patch, g_opt_wgrad_patch_blocks, g_opt_wgrad_patch_waves;
 extern int g_opt_topk_strips;                                                                                           // decode.hip (global namespace)
 extern int g_opt_wgrad_mfma, g_opt_wgrad_blocks, g_opt_wgrad_ws, g_opt_wgrad_ws_blocks;                                   // train_kernels.hip (global namespace)
@@ -424,6 +425,7 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "heads_persist") g_opt_heads_persist = value;
     else if (n == "heads_dbg") g_opt_heads_dbg = value;
     else if (n == "dcn_bt_fuse_wgrad") g_opt_dcn_bt_fuse_wgrad = value;
+    else if (n == "dcn_bt_fly") g_opt_dcn_bt_fly = value;
     else if (n == "dcn_bt_fuse_blocks") g_opt_dcn_bt_fuse_blocks = value > 0 ? value : 170;
     else if (n == "deterministic") g_opt_det = value ? 1 : 0;
     else if (n == "dcn_bt_fuse_min_chunks") g_opt_dcn_bt_fuse_min_chunks = value < 1 ? 1 : value;
@@ -442,6 +444,7 @@ extern "C" long mfx_get_counter(const char* name) {
     if (!name) return mfx_fail(MFX_ERR_ARG, "get_counter: null name");
     const std::string n(name);
     if (n == "dcn_bt_fused") return g_cnt_dcn_bt_fused;
+    if (n == "dcn_bt_fly") return g_cnt_dcn_bt_fly;
     return mfx_fail(MFX_ERR_ARG, "get_counter: unknown counter");
 }
 

@@ -37,6 +37,8 @@ int mfx_internal_wgrad_slab_sum(const float* ws, int nslab, int Cout, int Ck, in
 int mfx_internal_colsum_add(const void* x, float* out, long M, int C, int ld, int dtype, void* stream);      // train_kernels.hip: sums ADDED into a zeroed `out`
 
 int g_opt_dcn_bt_fuse_blocks = 170; // option "dcn_bt_fuse_blocks": workgroups per tap group of the fused kernel
+int g_opt_dcn_bt_fly = 1;          // option "dcn_bt_fly": 64 -> 64 16-bit layers rebuild d(columns) from dy inside both consumers (no [M][9C] matrix in memory)
+long g_cnt_dcn_bt_fly = 0;         // counter "dcn_bt_fly": backward calls that took the gcol-free form
 int g_opt_dcn_bt_fuse_wgrad = 1;   // option "dcn_bt_fuse_wgrad": 64 -> 64 bf16 layers accumulate grad_weight inside the sample kernel (no columns in memory)
 int g_opt_dcn_bt_fuse_min_chunks = 1024; // option "dcn_bt_fuse_min_chunks": fewer 32-pixel chunks than this keep the unfused kernels (tests lower it)
 long g_cnt_dcn_bt_fused = 0;   // counter "dcn_bt_fused": launches of dcn_bwd_sample_wgrad_kernel since process start
@@ -676,6 +678,517 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const T* __re
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Third generation for the 64 -> 64 layers (16-bit maps): d(columns) is never written.  (Round 3: the [M][9C] matrix dy x W^T
+// -- 283 MB per 64 -> 64 @ 8x96x320 layer -- was written once and read by both consumers, 2.05 GB of traffic for 189 MB of
+// algorithmic bytes.)  Both consumers now rebuild what they need from dy (31 MB, cache-resident) on the matrix cores:
+//
+//   * grad_input:  dx[p][c] = sum_{(m,t,corner) on p} w * sum_o dy[m][o] W[o][t,c]  =  sum_t  z_t[p][:] . W_t,
+//     z_t[p][o] = sum_{(m,t,corner) on p} w * dy[m][o]:  the bilinear SPLAT of dy (same per-pixel corner lists as before, gathered rows
+//     are 128-byte dy rows instead of d(columns) rows), then nine small GEMMs (128 pixels x 64 o) . (64 o x 64 c) per tile on the MFMA.
+//     The lists are filled tap by tap (one barrier per tap), so a pixel's list is tap-sorted and its lane group walks one segment per tap.
+//   * grad_offset / grad_mask / grad_weight (dcn_bwd_sample_wgrad_fly_kernel): the 32-pixel chunk's d(columns) for the workgroup's
+//     three taps = W_tg (192 x 64) . dy_chunk^T (64 x 32) -- 12 MFMAs per wave -- goes to a 12 KB LDS tile the samples read.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int FZ_LCAP = 62;
+
+template <typename T>                                         // bf16_t / half_t, C = Cout = 64
+__global__ __launch_bounds__(256) void dcn_bwd_tile_fly_kernel(const float* __restrict__ om, const T* __restrict__ dy, const T* __restrict__ wT,
+                                                              BtGeom g, T* __restrict__ dx, int* __restrict__ far_count,
+                                                              u32x4* __restrict__ far_list, int far_cap) {
+    using EN = BtEntry<T>;
+    constexpr int LCAP = FZ_LCAP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* lists = reinterpret_cast<uint32_t*>(smem);                       // [BT_NPIX][LCAP], tap-sorted per pixel
+    int* counts = reinterpret_cast<int*>(smem + BT_NPIX * LCAP * 4);           // [BT_NPIX]
+    uint2* fstage = reinterpret_cast<uint2*>(smem + BT_NPIX * LCAP * 4 + BT_NPIX * 4);   // [BT_FCAP]
+    __shared__ int fcount, fbase;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sl = lane >> 3, cl = lane & 7;                                   // pixel slot in the wave, 8-channel group
+    const int l16 = lane & 15, kq = lane >> 4;
+    int tile = blockIdx.x;
+    const int tx = tile % g.tiles_x; tile /= g.tiles_x;
+    const int ty = tile % g.tiles_y; const int b = tile / g.tiles_y;
+    const int ty0 = ty * BT_TH, tx0 = tx * BT_TW;
+    const int HW = g.H * g.W;
+    const long mb = (long)b * HW;
+
+    for (int i = tid; i < BT_NPIX; i += 256) counts[i] = 0;
+    if (tid == 0) fcount = 0;
+    __syncthreads();
+
+    auto far_entry = [&](int slot, size_t m, int tap, int hc, int wc, uint32_t wbits) {
+        if (slot < far_cap) far_list[slot] = u32x4{(uint32_t)m, ((uint32_t)hc << 16) | ((uint32_t)wc << 4) | (uint32_t)tap, wbits, 0u};
+    };
+    auto to_far = [&](size_t m, int my, int mx, int tap, int q, int hc, int wc, float w) {
+        const int fs = atomicAdd(&fcount, 1);
+        if (fs < BT_FCAP) fstage[fs] = uint2{((uint32_t)q << 28) | ((uint32_t)my << 16) | ((uint32_t)mx << 4) | (uint32_t)tap, __float_as_uint(w)};
+        else far_entry(atomicAdd(far_count, 1), m, tap, hc, wc, __float_as_uint(w));
+    };
+
+    // ---------------- phase 1: bin the (sample, corner) pairs of the candidate window by target pixel, ONE TAP AT A TIME ----------------
+    static_assert(BT_CH * BT_CW == 3 * 256, "three candidate pixels per thread");
+    {
+        // the window's raw offset / mask rows stay in registers across the nine taps (re-reading three values per (pixel, tap) from L1
+        // measured slower: 176 vs 111 us for this phase alone)
+        float o[3][28];
+        bool valid[3];
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+            const int cp = round * 256 + tid;
+            const int wy = cp / BT_CW, wx = cp - wy * BT_CW;
+            const int my = ty0 - BT_D + wy, mx = tx0 - BT_D + wx;
+            valid[round] = my >= 0 && my < g.H && mx >= 0 && mx < g.W && !(g.dbg & 4);
+            const float* r = om + (size_t)(mb + (long)(valid[round] ? my : 0) * g.W + (valid[round] ? mx : 0)) * 32;
+#pragma unroll
+            for (int q4 = 0; q4 < 28; q4 += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(r + q4);
+                o[round][q4] = t[0]; o[round][q4 + 1] = t[1]; o[round][q4 + 2] = t[2]; o[round][q4 + 3] = t[3];
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int th = tap / 3, tw = tap - th * 3;
+#pragma unroll
+            for (int round = 0; round < 3; ++round) {
+                if (!valid[round]) continue;
+                const int cp = round * 256 + tid;
+                const int wy = cp / BT_CW, wx = cp - wy * BT_CW;
+                const int my = ty0 - BT_D + wy, mx = tx0 - BT_D + wx;
+                const bool own = wy >= BT_D && wy < BT_D + BT_TH && wx >= BT_D && wx < BT_D + BT_TW;
+                const size_t m = (size_t)(mb + (long)my * g.W + mx);
+                const float h = (float)(my - 1 + th) + o[round][2 * tap], w = (float)(mx - 1 + tw) + o[round][2 * tap + 1];
+                const float mask = o[round][18 + tap];
+                if (!(h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W) || mask == 0.f) continue;
+                const float hf = floorf(h), wf = floorf(w);
+                const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw;
+                const int h0 = (int)hf, w0 = (int)wf;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int hc = h0 + (q >> 1), wc = w0 + (q & 1);
+                    const float wq = ((q >> 1) ? lh : hh) * ((q & 1) ? lw : hw) * mask;
+                    if (hc < 0 || hc >= g.H || wc < 0 || wc >= g.W || wq == 0.f) continue;
+                    const int ly = hc - ty0, lx = wc - tx0;
+                    if (ly >= 0 && ly < BT_TH && lx >= 0 && lx < BT_TW) {
+                        const int p = ly * BT_TW + lx;
+                        const int slot = atomicAdd(&counts[p], 1);
+                        if (slot < LCAP) lists[p * LCAP + slot] = EN::make(wy, wx, tap, wq);
+                        else to_far(m, my, mx, tap, q, hc, wc, wq);
+                    } else if (own) {
+                        const int cty0 = (hc / BT_TH) * BT_TH, ctx0 = (wc / BT_TW) * BT_TW;
+                        const bool near = my >= cty0 - BT_D && my < cty0 + BT_TH + BT_D && mx >= ctx0 - BT_D && mx < ctx0 + BT_TW + BT_D;
+                        if (!near) to_far(m, my, mx, tap, q, hc, wc, wq);
+                    }
+                }
+            }
+            __syncthreads();                                                  // every entry of tap `tap` is in its list before the first of tap + 1
+        }
+    }
+    {   // flush the staged far corners
+        const int nf = min(fcount, BT_FCAP);
+        if (nf > 0) {
+            if (tid == 0) fbase = atomicAdd(far_count, nf);
+            __syncthreads();
+            for (int i = tid; i < nf; i += 256) {
+                const uint2 en = fstage[i];
+                const int q = (int)(en.x >> 28), emy = (int)((en.x >> 16) & 0xfff), emx = (int)((en.x >> 4) & 0xfff), etap = (int)(en.x & 15);
+                const size_t m = (size_t)(mb + (long)emy * g.W + emx);
+                const SampGeo sg = samp_geo(g, om + m * 32, emy, emx, etap);
+                far_entry(fbase + i, m, etap, sg.h0 + (q >> 1), sg.w0 + (q & 1), en.y);
+            }
+        }
+    }
+
+    // ---------------- phase 3: per tap, splat dy into z_t (registers -> LDS), then z_t . W_t on the matrix cores ----------------
+    // lane group (wv, sl) owns pixels p = pass * 32 + wv * 8 + sl, pass 0..3; cursor[pass] walks that pixel's tap-sorted list
+    int cur[4], cnt[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) { cur[ps] = 0; cnt[ps] = min(counts[ps * 32 + wv * 8 + sl], LCAP); }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T* dyb = dy + (size_t)mb * 64 + cl * 8;
+    const int wbase_y = ty0 - BT_D, wbase_x = tx0 - BT_D;
+
+    for (int tap = 0; tap < ((g.dbg & 1) ? 0 : 9); ++tap) {
+        // W_t fragments (B operand: row n = input channel c, k = output channel o): L2 -> registers, in flight during the splat
+        u32x4 wf[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[j][ks] = (g.dbg & 16) ? u32x4{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4*>(wT + (size_t)(tap * 64 + j * 16 + l16) * 64 + ks * 32 + kq * 8);
+        // half-round h = passes 2h, 2h + 1 = the 16 pixels of MFMA fragment h: the first four entries of both pixels are gathered together
+        // (eight independent dy rows in flight per lane group; a segment has ~4 entries, so this is usually all of it)
+#pragma unroll
+        for (int hf_ = 0; hf_ < 2; ++hf_) {
+            float z[2][8];
+            bool more[2];
+            {
+                uint32_t en[2][4]; bool ok[2][4]; Raw8<T> gr[2][4];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int ps = 2 * hf_ + q;
+                    const uint32_t* lp = lists + (ps * 32 + wv * 8 + sl) * LCAP;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = cur[ps] + u;
+                        en[q][u] = e < cnt[ps] ? lp[e] : 0xffffffffu;
+                        ok[q][u] = e < cnt[ps] && (int)((en[q][u] >> 18) & 15) == tap;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int wy = (int)(en[q][u] >> 27), wx = (int)((en[q][u] >> 22) & 31);
+                        if (ok[q][u]) gr[q][u].load(dyb + ((size_t)(wbase_y + wy) * g.W + (wbase_x + wx)) * 64);
+                        else gr[q][u].zero();
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int ps = 2 * hf_ + q;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) z[q][k] = 0.f;
+                    int nok = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (ok[q][u]) {
+                            int wy, wx, t_; float w;
+                            EN::read(en[q][u], wy, wx, t_, w);
+                            float gq[8];
+                            gr[q][u].unpack(gq);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) z[q][k] += w * gq[k];
+                            ++nok;
+                        }
+                    }
+                    cur[ps] += nok;
+                    more[q] = nok == 4;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ps = 2 * hf_ + q;
+                const uint32_t* lp = lists + (ps * 32 + wv * 8 + sl) * LCAP;
+                while (more[q]) {                                             // longer segments: four more entries per round
+                    uint32_t en[4]; bool ok[4]; float w[4]; Raw8<T> gr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = cur[ps] + u;
+                        en[u] = e < cnt[ps] ? lp[e] : 0xffffffffu;
+                        ok[u] = e < cnt[ps] && (int)((en[u] >> 18) & 15) == tap;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int wy, wx, t_;
+                        EN::read(en[u], wy, wx, t_, w[u]);
+                        if (ok[u]) gr[u].load(dyb + ((size_t)(wbase_y + wy) * g.W + (wbase_x + wx)) * 64);
+                        else gr[u].zero();
+                    }
+                    int nok = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (ok[u]) {
+                            float gq[8];
+                            gr[u].unpack(gq);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) z[q][k] += w[u] * gq[k];
+                            ++nok;
+                        }
+                    }
+                    cur[ps] += nok;
+                    more[q] = nok == 4;
+                }
+            }
+            // z_t of the fragment's 16 pixels is in this wave's registers as (pixel slot sl, 8-output group cl) x two passes; the MFMA wants
+            // (pixel l16, k-group kq) per k-step: lane (l16, kq) of k-step ks takes the packed dwords of lane (l16 & 7) * 8 + 4 ks + kq, from the
+            // first pass for l16 < 8 and from the second otherwise.  Two ds_bpermute per dword (one per pass register, the destination
+            // picks) -- no LDS tile, no barrier: the waves of a workgroup never wait for each other in this phase.
+            const u32x4 pk0 = ElemTraits<T>::pack(z[0]), pk1 = ElemTraits<T>::pack(z[1]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int src = (((l16 & 7) << 3) + ks * 4 + kq) << 2;
+                u32x4 af;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (g.dbg & 8) { af[d] = pk0[d] ^ pk1[d]; continue; }
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pk0[d]);
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pk1[d]);
+                    af[d] = (l16 & 8) ? hi : lo;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma_chunk<T>(af, wf[j][ks], acc[hf_][j]);
+            }
+        }
+    }
+
+    // ---------------- epilogue: acc (row = pixel, col = channel) -> wave-private stage -> one 16-byte store per 8 channels ----------------
+    // accumulator row 16 i + q of this wave = pixel (pass 2 i + (q >> 3), slot q & 7) = tile pixel (2 i + (q >> 3)) * 32 + wv * 8 + (q & 7)
+    __syncthreads();                                                          // every wave is done with the lists (the stages below overlay them)
+    float* stage = reinterpret_cast<float*>(smem) + wv * (32 * 68);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(i * 16 + kq * 4 + r) * 68 + j * 16 + l16] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = it * 64 + lane, row = item >> 3, c8 = item & 7;
+        const int p = (row >> 3) * 32 + wv * 8 + (row & 7);
+        const int y = ty0 + p / BT_TW, xx = tx0 + (p % BT_TW);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(stage + row * 68 + c8 * 8), bq = *reinterpret_cast<const f32x4*>(stage + row * 68 + c8 * 8 + 4);
+        const float v[8] = {a[0], a[1], a[2], a[3], bq[0], bq[1], bq[2], bq[3]};
+        if (y < g.H && xx < g.W) bt_store8<T>(dx + ((size_t)b * HW + (size_t)y * g.W + xx) * 64 + c8 * 8, v);
+    }
+}
+
+// far corners of the gcol-free form: the d(columns) row of the entry's (sample, tap) is rebuilt from dy and W (64 x 64 MACs per entry,
+// eight lanes x eight channels) and added into the finished dx with (packed 16-bit) atomics
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_bwd_far_fly_kernel(const T* __restrict__ dy, const T* __restrict__ wT, const u32x4* __restrict__ far_list,
+                                                             const int* __restrict__ far_count, int far_cap, BtGeom g, T* __restrict__ dx) {
+    const int n = min(*far_count, far_cap);
+    const int HW = g.H * g.W, cl = threadIdx.x & 7;
+    for (long e = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 3; e < n; e += ((long)gridDim.x * blockDim.x) >> 3) {
+        const u32x4 en = far_list[e];
+        const size_t m = en.x;
+        const int hc = (int)(en.y >> 16), wc = (int)((en.y >> 4) & 0xfff), tap = (int)(en.y & 15);
+        const float w = __uint_as_float(en.z);
+        const size_t bimg = m / HW;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const T* dr = dy + m * 64;
+        for (int o8 = 0; o8 < 64; o8 += 8) {
+            float d[8];
+            bt_load8<T>(dr + o8, d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                                    // channel c = cl * 8 + k: row (tap, c) of wT, eight consecutive o
+                float wv8[8];
+                bt_load8<T>(wT + (size_t)(tap * 64 + cl * 8 + k) * 64 + o8, wv8);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[k] += d[q] * wv8[q];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] *= w;
+        bt_atomic_add8(dx + (bimg * HW + (size_t)hc * g.W + wc) * 64 + cl * 8, a);
+    }
+}
+
+
+// dcn_bwd_sample_wgrad_kernel without the d(columns) operand: per 32-pixel chunk the workgroup first multiplies
+// g^T = W_tg (192 (tap, c) rows x 64 o) . dy_chunk^T (64 o x 32 px) on the matrix cores -- wave wv owns rows 48 wv .. +48: three
+// A fragments of W (held in registers for the whole launch) x two B fragments of the chunk's dy rows (plain 16-byte reads of the tile
+// the weight-gradient MFMAs read transposed) -- and writes it to an LDS tile [pixel][192] in the activation dtype (the rounding the
+// d(columns) GEMM applied); the samples then take their 8-channel piece of it with one ds_read_b128.  Three barriers per chunk
+// instead of one; no 283 MB read.
+constexpr int SG_ROW = 3 * 64 * 2 + 16;                                      // bytes of one pixel row of the g tile (400: conflict-free 16-byte reads)
+constexpr int SG_TILE = SF_PX * SG_ROW;                                      // 12.5 KB
+
+// WG = true: the chunk's d(columns) tile is also written out (coalesced 16-byte stores, 12 KB per chunk and tap group) for the tile kernel
+// that gathers d(columns) rows -- the separate d(columns) GEMM (111 us for 64 -> 64 @ 8x96x320) and its re-read here disappear, the
+// tile kernel's read stays.
+template <typename T, bool WG>                                              // T = bf16_t or half_t
+__global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_fly_kernel(const T* __restrict__ x, const float* __restrict__ om,
+                                                                      const T* __restrict__ wT, const T* __restrict__ dy, BtGeom g,
+                                                                      int chunks_per_block, int nchunks, float* __restrict__ graw,
+                                                                      float* __restrict__ ws, T* __restrict__ gcol) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * SF_STAGE + SG_TILE];
+    char* gt = lds + 2 * SF_STAGE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sl = lane >> 3, cl = lane & 7;                                  // sample slot in the wave, 8-channel group
+    const int tg = blockIdx.y;                                                // taps 3*tg .. 3*tg+2
+    const int HW = g.H * g.W, cpr = g.W / SF_PX;                              // chunks per row (W is a multiple of 32)
+    const int c_begin = blockIdx.x * chunks_per_block, c_end = min(c_begin + chunks_per_block, nchunks);
+    const int c0 = cl * 8;
+
+    f32x4 acc[4][SF_TAPS];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < SF_TAPS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l16 = lane & 15, gq = lane >> 4;
+    const uint32_t lane_off = (uint32_t)((4 * gq + (l16 >> 2)) * 32 + (l16 & 3) * 8);
+    const uint32_t lds_a = (uint32_t)(uintptr_t)lds;
+    auto tr2 = [](uint32_t a) {
+        uint64_t l, h;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l), "=&v"(h) : "v"(a) : "memory");
+        return u32x4{(uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32)};
+    };
+    // W fragments of this wave's 48 (tap, c) rows: A operand, row n = 48 wv + 16 j + l16 of the tap group, k = o
+    u32x4 wfr[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            wfr[j][ks] = *reinterpret_cast<const u32x4*>(wT + (size_t)(tg * 192 + wv * 48 + j * 16 + l16) * 64 + ks * 32 + gq * 8);
+
+    struct Loc { bool ok; int my, px, tap; size_t m; const T* xb; int mx; };
+    auto locate = [&](int ch, int it) {
+        Loc q;
+        q.ok = ch < c_end;
+        const int chc = q.ok ? ch : c_begin;
+        const int row = chc / cpr, x_begin = (chc - row * cpr) * SF_PX;
+        const int b = row / g.H;
+        q.my = row - b * g.H;
+        const int s = it * 32 + wv * 8 + sl;
+        q.px = s / 3; q.tap = tg * SF_TAPS + (s - q.px * 3);
+        q.mx = x_begin + q.px;
+        q.m = (size_t)b * HW + (size_t)q.my * g.W + q.mx;
+        q.xb = x + (size_t)b * HW * g.C;
+        return q;
+    };
+    struct Pre { float oh, ow, mk; };
+    auto prefetch = [&](const Loc& q) {
+        Pre p = {0.f, 0.f, 0.f};
+        if (q.ok) { const float* r = om + q.m * 32; p.oh = r[2 * q.tap]; p.ow = r[2 * q.tap + 1]; p.mk = r[18 + q.tap]; }
+        return p;
+    };
+    struct Geo { bool inside; int h0, w0; float lh, lw, mask; };
+    auto geo = [&](const Loc& q, const Pre& p) {
+        Geo e;
+        const int th = (q.tap * 11) >> 5, tw = q.tap - th * 3;
+        const float h = (float)(q.my - 1 + th) + p.oh, w = (float)(q.mx - 1 + tw) + p.ow;
+        e.mask = p.mk;
+        e.inside = q.ok && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
+        const float hf = floorf(h), wf = floorf(w);
+        e.lh = h - hf; e.lw = w - wf;
+        e.h0 = (int)fminf(fmaxf(hf, -4.f), 32000.f); e.w0 = (int)fminf(fmaxf(wf, -4.f), 32000.f);
+        return e;
+    };
+    struct Raw4 { Raw8<T> v[4]; };
+    auto issue = [&](const Loc& q, const Geo& e) {
+        Raw4 r;
+        if (e.inside) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int hc = e.h0 + (c >> 1), wc = e.w0 + (c & 1);
+                if (hc >= 0 && hc < g.H && wc >= 0 && wc < g.W) r.v[c].load(q.xb + ((size_t)hc * g.W + wc) * g.C + c0);
+                else r.v[c].zero();
+            }
+        }
+        return r;
+    };
+    auto dy_rows = [&](int ch) {                                             // this thread's 16 bytes of the chunk's dy rows (Cout = 64)
+        const int chc = ch < c_end ? ch : c_begin;
+        const int row = chc / cpr, x_begin = (chc - row * cpr) * SF_PX;
+        const int b = row / g.H, my = row - b * g.H;
+        const size_t m0 = (size_t)b * HW + (size_t)my * g.W + x_begin;
+        return *reinterpret_cast<const u32x4*>(dy + (m0 + (tid >> 3)) * 64 + (tid & 7) * 8);
+    };
+    Loc l0 = locate(c_begin, 0), l1 = locate(c_begin, 1);
+    Geo e0 = geo(l0, prefetch(l0));
+    Raw4 r0 = issue(l0, e0);
+    Pre p1 = prefetch(l1);
+    u32x4 dyv = dy_rows(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        char* stage = lds + ((ch - c_begin) & 1) * SF_STAGE;
+        // dy rows of the chunk: [o sub][pixel][32 B]  (this stage's previous readers -- the MFMAs of chunk ch - 2 -- are two barriers back)
+        *reinterpret_cast<u32x4*>(stage + (SF_BT + ((tid & 7) >> 1)) * SF_TILE + (tid >> 3) * 32 + (tid & 1) * 16) = dyv;
+        dyv = dy_rows(ch + 1);                                                // next chunk's rows: in flight through this one
+        __syncthreads();                                                      // dy rows visible; every wave is done reading the g tile of the previous chunk
+        {   // g^T rows 48 wv .. +48 = W . dy^T  ->  gt[pixel][192]
+            f32x4 ga[3][2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ga[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 df[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)                                  // B operand: pixel i*16 + l16, o = ks*32 + gq*8 .. +8 -> sub-tile 2ks + (gq>>1), half gq&1
+                    df[i] = *reinterpret_cast<const u32x4*>(stage + (SF_BT + 2 * ks + (gq >> 1)) * SF_TILE + (i * 16 + l16) * 32 + (gq & 1) * 16);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) mma_chunk<T>(wfr[j][ks], df[i], ga[j][i]);
+            }
+            // D: row = (tap, c) index 48 wv + 16 j + 4 gq + r, col = pixel i*16 + l16: four consecutive channels of one pixel per lane
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    bt_store4<T>(reinterpret_cast<T*>(gt + (i * 16 + l16) * SG_ROW + (wv * 48 + j * 16 + gq * 4) * 2), ga[j][i]);
+        }
+        __syncthreads();                                                      // g tile complete
+        if constexpr (WG) {                                                   // 32 pixels x 24 chunks of 16 bytes = three per thread
+            const int row = ch / cpr, x_begin = (ch - row * cpr) * SF_PX;
+            const int b = row / g.H, my = row - b * g.H;
+            const size_t m0 = (size_t)b * HW + (size_t)my * g.W + x_begin;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int idx = i * 256 + tid, px = idx / 24, c16 = idx - px * 24;
+                *reinterpret_cast<u32x4*>(gcol + (m0 + px) * g.Kp + tg * 192 + c16 * 8) = *reinterpret_cast<const u32x4*>(gt + px * SG_ROW + c16 * 16);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const Loc l2 = it == 0 ? locate(ch, 2) : locate(ch + 1, it - 1);          // the sample after next
+            const Pre p2 = prefetch(l2);
+            const Geo e1 = geo(l1, p1);
+            const Raw4 r1 = issue(l1, e1);
+            {   // blend sample l0 (always inside this chunk)
+                const int tl = l0.tap - tg * SF_TAPS;
+                float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float gh = 0.f, gw = 0.f, gm = 0.f;
+                if (e0.inside) {
+                    float gc[8], v0[8], v1[8], v2[8], v3[8];
+                    bt_load8<T>(reinterpret_cast<const T*>(gt + l0.px * SG_ROW + (tl * 64 + c0) * 2), gc);
+                    r0.v[0].unpack(v0); r0.v[1].unpack(v1); r0.v[2].unpack(v2); r0.v[3].unpack(v3);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float d10 = v1[k] - v0[k], d32 = v3[k] - v2[k];
+                        const float top = v0[k] + e0.lw * d10, bot = v2[k] + e0.lw * d32;
+                        const float dh = bot - top, val = top + e0.lh * dh, dw = d10 + e0.lh * (d32 - d10);
+                        cv[k] = e0.mask * val;
+                        gm += gc[k] * val; gh += gc[k] * dh; gw += gc[k] * dw;
+                    }
+                }
+                *reinterpret_cast<u32x4*>(stage + (tl * 4 + (cl >> 1)) * SF_TILE + l0.px * 32 + (cl & 1) * 16) = ElemTraits<T>::pack(cv);
+                gh = bt_group_sum<8>(gh); gw = bt_group_sum<8>(gw); gm = bt_group_sum<8>(gm);
+                if (cl == 0) {
+                    float* o = graw + l0.m * 32;
+                    o[2 * l0.tap] = gh * e0.mask; o[2 * l0.tap + 1] = gw * e0.mask; o[18 + l0.tap] = gm * e0.mask * (1.f - e0.mask);
+                    if (l0.tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
+                }
+            }
+            l0 = l1; e0 = e1; r0 = r1; l1 = l2; p1 = p2;
+        }
+        __syncthreads();                                                      // column tile complete
+        {
+            const uint32_t sb = lds_a + (uint32_t)(((ch - c_begin) & 1) * SF_STAGE);
+            u32x4 df[4], cf[SF_TAPS];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) df[i] = tr2(sb + (uint32_t)((SF_BT + i) * SF_TILE) + lane_off);
+#pragma unroll
+            for (int j = 0; j < SF_TAPS; ++j) cf[j] = tr2(sb + (uint32_t)((wv * SF_TAPS + j) * SF_TILE) + lane_off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < SF_TAPS; ++j) mma_chunk<T>(df[i], cf[j], acc[i][j]);
+        }
+    }
+    float* slab = ws + (size_t)blockIdx.x * (64 * 576);
+#pragma unroll
+    for (int j = 0; j < SF_TAPS; ++j) {
+        const int t = wv * SF_TAPS + j, tl = t >> 2, sub = t & 3;
+        const int k = (tg * SF_TAPS + tl) * 64 + sub * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(size_t)(i * 16 + (lane >> 4) * 4 + r) * 576 + k] = acc[i][j][r];
+    }
+}
+
 static inline size_t bt_al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct BtLayout { size_t wT, gcol, col, cnt, flist, wg, total; long far_cap; };
@@ -714,6 +1227,44 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
         const long total = (long)K * Cout;
         hipLaunchKernelGGL(bt_pack_weight_t<T>, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, st, weight, wT, Cout, C, cnt, dbias);
     }
+    BtGeom g;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.tiles_x = (W + BT_TW - 1) / BT_TW; g.tiles_y = (H + BT_TH - 1) / BT_TH; g.Kp = K;
+    g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg;
+    if constexpr (!std::is_same<T, float>::value) {
+        // gcol-free form (third generation): 64 -> 64, 16-bit, the shapes the fused sample + weight-gradient kernel takes
+        const long nchunks = M / SF_PX;
+        const size_t slab_bytes = (size_t)64 * 576 * sizeof(float);
+        if (g_opt_dcn_bt_fly && g_opt_dcn_bt_fuse_wgrad && !g_opt_det && C == 64 && Cout == 64 && W % SF_PX == 0 &&
+            nchunks >= g_opt_dcn_bt_fuse_min_chunks && L.total - L.wg >= 128 * slab_bytes) {
+            int nblk = (int)std::min<long>(g_opt_dcn_bt_fuse_blocks, (long)((L.total - L.wg) / slab_bytes));
+            const int cpb = (int)((nchunks + nblk - 1) / nblk);
+            nblk = (int)((nchunks + cpb - 1) / cpb);
+            float* slabs = reinterpret_cast<float*>(ws + L.wg);
+            const bool write_gcol = g_opt_dcn_bt_fly == 2;                   // 2: d(columns) written by the sample kernel, gathered by the second-generation tile kernel
+            if (write_gcol)
+                hipLaunchKernelGGL((dcn_bwd_sample_wgrad_fly_kernel<T, true>), dim3((unsigned)nblk, 3), dim3(256), 0, st, x, offmask, (const T*)wT, dy, g, cpb, (int)nchunks,
+                                   d_raw, slabs, gcol);
+            else
+                hipLaunchKernelGGL((dcn_bwd_sample_wgrad_fly_kernel<T, false>), dim3((unsigned)nblk, 3), dim3(256), 0, st, x, offmask, (const T*)wT, dy, g, cpb, (int)nchunks,
+                                   d_raw, slabs, (T*)nullptr);
+            MFX_HIP_CHECK(hipGetLastError());
+            ++g_cnt_dcn_bt_fused; ++g_cnt_dcn_bt_fly;
+            int rc2 = mfx_internal_wgrad_slab_sum(slabs, nblk, Cout, C, 3, 3, dweight, stream);
+            if (rc2) return rc2;
+            if (write_gcol) {
+                const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * B), 1u);
+                const size_t smem = (size_t)BT_NPIX * BtEntry<T>::LCAP * sizeof(typename BtEntry<T>::type) + (size_t)BT_NPIX * 4 + (size_t)BT_FCAP * 8;
+                hipLaunchKernelGGL((dcn_bwd_tile_kernel<T, 8>), grid, dim3(256), smem, st, offmask, (const T*)gcol, g, dx, cnt, flist, far_cap);
+                hipLaunchKernelGGL(dcn_bwd_far_kernel<T>, dim3(1024), dim3(256), 0, st, (const T*)gcol, (const u32x4*)flist, (const int*)cnt, far_cap, g, dx);
+            } else {
+            const size_t smem = (size_t)BT_NPIX * FZ_LCAP * 4 + (size_t)BT_NPIX * 4 + (size_t)BT_FCAP * 8;      // 36 KB: four workgroups per CU (the epilogue's 4 x 8.7 KB stages overlay it)
+            hipLaunchKernelGGL(dcn_bwd_tile_fly_kernel<T>, dim3((unsigned)(g.tiles_x * g.tiles_y * B)), dim3(256), smem, st, offmask, dy, (const T*)wT, g, dx, cnt, flist, far_cap);
+            hipLaunchKernelGGL(dcn_bwd_far_fly_kernel<T>, dim3(1024), dim3(256), 0, st, dy, (const T*)wT, (const u32x4*)flist, (const int*)cnt, far_cap, g, dx);
+            }
+            MFX_HIP_CHECK(hipGetLastError());
+            return mfx_internal_colsum_add(dy, dbias, M, Cout, Cout, dt, stream);
+        }
+    }
     // d(columns)[m][k] = sum_o dy[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM on the matrix cores
     mfx_conv_desc cd = {};
     cd.x = dy; cd.w = wT; cd.y = gcol;
@@ -722,9 +1273,6 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     cd.act = MFX_ACT_NONE; cd.dtype = dt; cd.out_dtype = dt;
     int rc = mfx_conv2d_nhwc(&cd, stream);
     if (rc) return rc;
-    BtGeom g;
-    g.B = B; g.H = H; g.W = W; g.C = C; g.tiles_x = (W + BT_TW - 1) / BT_TW; g.tiles_y = (H + BT_TH - 1) / BT_TH; g.Kp = K;
-    g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg;
     BtGeom gs = g;                                             // the sample kernel loops its slices inside a lane group: widest slice
     // tile kernel: one workgroup per (tile, slice).  On the small maps 128-channel slices leave the chip under-filled
     // (256ch@24x80: 240 workgroups), so those take 64-channel slices (the binning is repeated per slice, the gathers are not)

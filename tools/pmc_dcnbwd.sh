@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the DCN backward group (64->64 @ 96x320, B=8, bf16): FETCH_SIZE and WRITE_SIZE in separate --pmc passes (no tracing),
 # summed over the group's kernels per backward call.  Writes gpurun_out/<tag>_dcnbwd_pmc.{txt,csv} and <tag>_dcnbwd_traffic.json.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_dcnbwd
 rm -rf $OUT; mkdir -p $OUT
@@ -15,6 +15,7 @@ python $R/tools/pmc_summary.py $OUT > $R/gpurun_out/${TAG}_dcnbwd_pmc.txt
 python - <<PY
 import csv, glob, json, collections
 group = ("conv_igemm_kernel", "dcn_bwd_sample_kernel", "dcn_bwd_sample_wgrad_kernel", "dcn_bwd_tile_kernel", "dcn_bwd_far_kernel", "conv_wgrad_mfma_kernel",
+         "dcn_bwd_sample_wgrad_fly_kernel", "dcn_bwd_tile_fly_kernel", "dcn_bwd_far_fly_kernel",
          "wgrad_reduce_kernel", "colsum_chunk_kernel", "bt_pack_weight_t", "zero_fill_kernel")
 rows = []
 for f in sorted(glob.glob("$OUT/**/*counter_collection.csv", recursive=True)):
@@ -30,7 +31,7 @@ with open("$R/gpurun_out/${TAG}_dcnbwd_pmc.csv", "w", newline="") as f:
 tot = collections.defaultdict(float); calls = collections.Counter()
 for r in rows:
     tot[r["Counter_Name"]] += float(r["Counter_Value"])
-    if "dcn_bwd_tile_kernel" in r["Kernel_Name"]:
+    if "dcn_bwd_tile" in r["Kernel_Name"]:
         calls[r["Counter_Name"]] += 1
 n = max(1, min(calls.values()) if calls else 1)                     # backward calls seen by every pass (one tile kernel per call)
 fs, ws = tot["FETCH_SIZE"] / n, tot["WRITE_SIZE"] / n

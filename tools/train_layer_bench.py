@@ -63,7 +63,7 @@ def dominant_kernel_roofline(dtype, B, device, H=96, W=320, C=64, Cout=64, reps=
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype], 4)}
     traffic = traffic_source = None
     try:                                                       # PMC pass of the same group (tools/pmc_dcnbwd.sh), committed with its raw CSV
-        for tag in ("r03", "r02"):                             # the newest committed measurement
+        for tag in ("r04", "r03", "r02"):                      # the newest committed measurement
             f = os.path.join(ROOT, "profiles", tag + "_dcnbwd_traffic.json")
             if not os.path.exists(f):
                 continue
@@ -73,12 +73,13 @@ def dominant_kernel_roofline(dtype, B, device, H=96, W=320, C=64, Cout=64, reps=
             break
     except (OSError, ValueError, KeyError):
         pass
-    roof.update({"kernel": "DCNv2 backward group (d(columns) GEMM, dcn_bwd_sample, dcn_bwd_tile, dcn_bwd_far, weight-gradient GEMM), %d->%d @ %dx%d, B=%d"
+    roof.update({"kernel": "DCNv2 backward group (dcn_bwd_sample_wgrad_fly, dcn_bwd_tile_fly, dcn_bwd_far_fly, slab sum, bias sums), %d->%d @ %dx%d, B=%d"
                            % (C, Cout, H, W, B),
                  "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops,
                  "algorithmic_bytes_per_launch": alg_bytes, "hbm_floor_ms": round(hbm_floor_ms, 4), "mfma_floor_ms": round(mfma_floor_ms, 4),
-                 "materialised_bytes_per_launch": int(3 * M * 9 * C * es),
-                 "note": "the group writes d(columns) (M x 9C) once and reads it twice (fused sample + weight-gradient kernel, tile kernel); the columns are never materialised on this shape"})
+                 "materialised_bytes_per_launch": 0,
+                 "note": "r04: neither d(columns) nor the columns are materialised on this shape -- both consumers rebuild d(columns) from dy on the "
+                         "matrix cores (csrc/dcn_bwd_tile.hip, third generation; option dcn_bt_fly = 0 restores the d(columns) GEMM of r03: 2.05 GB per call)"})
     return roof
 
 
