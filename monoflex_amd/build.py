@@ -15,6 +15,8 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libmonoflex_hip.so")
 SOURCES = ["capi.hip", "conv_kernels.hip", "conv_halo.hip", "misc_kernels.hip", "stem.hip", "heads.hip", "decode.hip", "dcn_wave.hip", "dcn_patch.hip", "dcn_ext.hip", "dcn_bwd.hip", "dcn_bwd_tile.hip", "train_kernels.hip", "wgrad_tr.hip", "loss_kernels.hip", "head_sparse.hip", "kitti_encode.hip", "kitti_eval.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+if os.environ.get("MFX_PROBES") == "1":      # probe build: compiles the timing-probe switches in (options heads_dbg / dcn_bt_dbg: wrong results by design)
+    FLAGS.append("-DMFX_PROBES")
 # the target encoder reproduces numpy's twice-rounded float32/float64 arithmetic: no fused multiply-add there
 EXTRA_FLAGS = {"kitti_encode.hip": ["-ffp-contract=off"], "kitti_eval.hip": ["-ffp-contract=off"]}
 

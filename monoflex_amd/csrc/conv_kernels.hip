@@ -418,12 +418,17 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "dcn_patch") g_opt_dcn_patch = value;
     else if (n == "dcn_patch_fn8") g_opt_dcn_patch_fn8 = value;
     else if (n == "topk_strips") g_opt_topk_strips = value;
+#ifdef MFX_PROBES
     else if (n == "dcn_bt_dbg") g_opt_dcn_bt_dbg = value;
+    else if (n == "heads_dbg") g_opt_heads_dbg = value;
+#else
+    else if (n == "dcn_bt_dbg" || n == "heads_dbg")
+        return mfx_fail(MFX_ERR_UNSUPPORTED, "set_option: timing-probe switches (wrong results by design) exist in probe builds only: MFX_PROBES=1 python -m monoflex_amd.build");
+#endif
     else if (n == "wgrad_tr") g_opt_wgrad_tr = value;
     else if (n == "bn_blocks") g_opt_bn_blocks = value;
     else if (n == "heads_planes") g_opt_heads_planes = value;
     else if (n == "heads_persist") g_opt_heads_persist = value;
-    else if (n == "heads_dbg") g_opt_heads_dbg = value;
     else if (n == "dcn_bt_fuse_wgrad") g_opt_dcn_bt_fuse_wgrad = value;
     else if (n == "dcn_bt_fly") g_opt_dcn_bt_fly = value;
     else if (n == "dcn_bt_fuse_blocks") g_opt_dcn_bt_fuse_blocks = value > 0 ? value : 170;

@@ -46,6 +46,13 @@ int g_opt_dcn_bt_cs = 0;       // option "dcn_bt_cs": channel slice of the tile 
 int g_opt_dcn_bt_cs_wgs = 1000; // option "dcn_bt_cs_wgs": below this many 128-channel workgroups the tile kernel takes 64-channel slices
 int g_opt_dcn_bt_dbg = 0;      // option "dcn_bt_dbg": experiment switches of dcn_bwd_tile_kernel (0 in production)
 
+// experiment switches (skip a phase, drop an operand stream: timing probes with WRONG results) exist in probe builds only
+#ifdef MFX_PROBES
+#define BT_PROBE(g, bits) ((g).dbg & (bits))
+#else
+#define BT_PROBE(g, bits) false
+#endif
+
 namespace mfx {
 
 constexpr int BT_TH = 8, BT_TW = 16, BT_D = 8, BT_NPIX = BT_TH * BT_TW;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const float* __restri
     // Own samples (window pixel inside the tile): corners in the tile are listed; corners elsewhere are left to the owner of
     // their tile unless this pixel lies outside that tile's window ("far").  Ring samples: only corners inside the tile.
     static_assert(BT_CH * BT_CW == 3 * 256, "three candidate pixels per thread");
-    for (int round = 0; round < ((g.dbg & 4) ? 0 : 3); ++round) {
+    for (int round = 0; round < (BT_PROBE(g, 4) ? 0 : 3); ++round) {
         const int cp = round * 256 + tid;
         const int wy = cp / BT_CW, wx = cp - wy * BT_CW;
         const int my = ty0 - BT_D + wy, mx = tx0 - BT_D + wx;
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const float* __restri
     }
 
     // ---------------- phase 3: every target pixel's lane group walks its list, accumulates in registers, stores once ----------------
-    for (int p = wv * SPW + sl; p < ((g.dbg & 1) ? 0 : BT_NPIX); p += 4 * SPW) {
+    for (int p = wv * SPW + sl; p < (BT_PROBE(g, 1) ? 0 : BT_NPIX); p += 4 * SPW) {
         const int y = ty0 + p / BT_TW, xx = tx0 + (p % BT_TW);
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int n = min(counts[p], LCAP);
@@ -741,7 +748,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_fly_kernel(const float* __re
             const int cp = round * 256 + tid;
             const int wy = cp / BT_CW, wx = cp - wy * BT_CW;
             const int my = ty0 - BT_D + wy, mx = tx0 - BT_D + wx;
-            valid[round] = my >= 0 && my < g.H && mx >= 0 && mx < g.W && !(g.dbg & 4);
+            valid[round] = my >= 0 && my < g.H && mx >= 0 && mx < g.W && !BT_PROBE(g, 4);
             const float* r = om + (size_t)(mb + (long)(valid[round] ? my : 0) * g.W + (valid[round] ? mx : 0)) * 32;
 #pragma unroll
             for (int q4 = 0; q4 < 28; q4 += 4) {
@@ -815,14 +822,14 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_fly_kernel(const float* __re
     const T* dyb = dy + (size_t)mb * 64 + cl * 8;
     const int wbase_y = ty0 - BT_D, wbase_x = tx0 - BT_D;
 
-    for (int tap = 0; tap < ((g.dbg & 1) ? 0 : 9); ++tap) {
+    for (int tap = 0; tap < (BT_PROBE(g, 1) ? 0 : 9); ++tap) {
         // W_t fragments (B operand: row n = input channel c, k = output channel o): L2 -> registers, in flight during the splat
         u32x4 wf[4][2];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                wf[j][ks] = (g.dbg & 16) ? u32x4{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4*>(wT + (size_t)(tap * 64 + j * 16 + l16) * 64 + ks * 32 + kq * 8);
+                wf[j][ks] = BT_PROBE(g, 16) ? u32x4{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4*>(wT + (size_t)(tap * 64 + j * 16 + l16) * 64 + ks * 32 + kq * 8);
         // half-round h = passes 2h, 2h + 1 = the 16 pixels of MFMA fragment h: the first four entries of both pixels are gathered together
         // (eight independent dy rows in flight per lane group; a segment has ~4 entries, so this is usually all of it)
 #pragma unroll
@@ -917,7 +924,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_fly_kernel(const float* __re
                 u32x4 af;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    if (g.dbg & 8) { af[d] = pk0[d] ^ pk1[d]; continue; }
+                    if (BT_PROBE(g, 8)) { af[d] = pk0[d] ^ pk1[d]; continue; }
                     const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pk0[d]);
                     const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pk1[d]);
                     af[d] = (l16 & 8) ? hi : lo;

@@ -22,7 +22,7 @@
 
 int g_opt_heads_persist = 1;   // option "heads_persist": 1 = one workgroup per resident slot (n > 1: n workgroups), each a contiguous range of (tile, branch)
                                // units; 0 = one workgroup per tile.  B=8 bf16: 516 -> 503 us (tools/probes/heads_probe.py), bit-identical output
-int g_opt_heads_dbg = 0;       // option "heads_dbg": timing probes of the bf16 kernel (see DBG below); results are wrong
+int g_opt_heads_dbg = 0;       // option "heads_dbg": timing probes of the bf16 kernel (see DBG below); results are wrong -- compiled in with -DMFX_PROBES only
 
 namespace mfx {
 
@@ -425,9 +425,11 @@ extern "C" int mfx_heads_fused(const mfx_heads_desc* d, void* stream) {
     if (d->B * d->H * d->W == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == MFX_F32) return g_opt_heads_planes ? launch_heads<float, true>(d, st) : launch_heads<float, false>(d, st);
+#ifdef MFX_PROBES      /* timing probes with WRONG results (tools/probes/heads_probe.py): only in a probe build (MFX_PROBES=1 python -m monoflex_amd.build) */
     if (d->dtype == MFX_BF16 && g_opt_heads_dbg == 1) return launch_heads<bf16_t, false, 1>(d, st);
     if (d->dtype == MFX_BF16 && g_opt_heads_dbg == 2) return launch_heads<bf16_t, false, 2>(d, st);
     if (d->dtype == MFX_BF16 && g_opt_heads_dbg == 3) return launch_heads<bf16_t, false, 3>(d, st);
+#endif
     if (d->dtype == MFX_BF16) return g_opt_heads_planes ? launch_heads<bf16_t, true>(d, st) : launch_heads<bf16_t, false>(d, st);
     if (d->dtype == MFX_F16) return launch_heads<half_t, false>(d, st);
     if (d->dtype == MFX_F16X2) return launch_heads<f32s_t, false>(d, st);
