@@ -42,7 +42,9 @@ TRAIN_GFLOP_PER_IMG = 3 * FWD_GFLOP_PER_IMG          # dgrad + wgrad 
 HEADS_GFLOP_PER_IMG = 2 * 41.185    # Appendix A: 9 x (3x3 64->256 + 1x1) per image
 PEAK_BF16_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_F32_TFLOPS = 157.3
-HEADS_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_heads_traffic.json")      # PMC passes of the persistent-launch kernel now in HEAD (tools/pmc_heads.sh r03)
+# PMC passes of the heads kernel (tools/pmc_heads.sh <tag>): the newest committed measurement (the bf16 kernel is unchanged since r03)
+HEADS_TRAFFIC_JSON = next((f for f in (os.path.join(ROOT, "profiles", t + "_heads_traffic.json") for t in ("r04", "r03")) if os.path.exists(f)),
+                          os.path.join(ROOT, "profiles", "r03_heads_traffic.json"))
 
 
 def parse():
@@ -418,6 +420,42 @@ def run_pipeline(args, rank, world, device, dtype=None):
             valid_host.copy_(valid, non_blocking=True)
             torch.cuda.synchronize()
         el2, n2, _ = timed_repeats(run_model_d2h, args.steps, 3, B * args.steps, device)
+
+        # the overlapped feeder a serving loop would run: two pinned staging buffers and two device pixel buffers; while the graph of batch k
+        # replays, the host packs batch k + 1 and a copy stream uploads it; the host waits only for the rows of batch k - 1 (two batches in flight)
+        host2 = [host, torch.empty_like(host).pin_memory()]
+        pix2 = [pixels, torch.empty_like(pixels)]
+        rows2 = [rows_host, torch.empty_like(rows_host).pin_memory()]
+        val2 = [valid_host, torch.empty_like(valid_host).pin_memory()]
+        copy_stream = torch.cuda.Stream()
+        uploaded = [torch.cuda.Event(), torch.cuda.Event()]
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        cur = torch.cuda.current_stream()
+        for e in done + consumed:
+            e.record(cur)
+        it2 = [0]
+
+        def run_overlapped():
+            k = it2[0]; it2[0] += 1
+            s_ = k & 1
+            done[s_].synchronize()                                # the rows of batch k - 2 (same slot) are on the host: its buffers are free
+            host2[s_].numpy().reshape(B, stride)[:, :nbytes][:] = frames[k % pool].reshape(B, nbytes)
+            copy_stream.wait_event(consumed[s_])                  # (the pre-processing kernel that read pix2[s_] two batches ago has run)
+            with torch.cuda.stream(copy_stream):
+                pix2[s_].copy_(host2[s_], non_blocking=True)
+                uploaded[s_].record(copy_stream)
+            cur.wait_event(uploaded[s_])
+            lib.check(L.mfx_kitti_preprocess_u8(pix2[s_].data_ptr(), offsets.data_ptr(), img_wh.data_ptr(), flip.data_ptr(), images.data_ptr(), B, 1280, 384,
+                                                mean, std, ctypes.c_void_p(cur.cuda_stream)), "mfx_kitti_preprocess_u8")
+            consumed[s_].record(cur)
+            graph.replay()
+            rows2[s_].copy_(det, non_blocking=True)
+            val2[s_].copy_(valid, non_blocking=True)
+            done[s_].record(cur)
+        for _ in range(4):
+            run_overlapped()
+        el3, n3, all3 = timed_repeats(run_overlapped, args.steps, 3, B * args.steps, device)
     if rank != 0:
         return None
     return {"metric": "images/sec at 1280x384, forward+decode fed from the host every step (fresh uint8 frames -> H2D -> device "
@@ -428,6 +466,10 @@ def run_pipeline(args, rank, world, device, dtype=None):
             "detections_last_step": int(valid_host.sum()),
             "reference_timed_region": {"what": "model + D2H + synchronize per batch, input already on the device (engine/inference.py:35-43)",
                                        "value": round(n2 / el2, 2), "unit": "images/s", "ms_per_step": round(1e3 * el2 / args.steps, 4)},
+            "overlapped": {"what": "the same work with two batches in flight: the host packs and a copy stream uploads batch k + 1 while the graph of batch k "
+                                   "replays; the host waits for the rows of batch k - 1 only",
+                           "value": round(n3 / el3, 2), "unit": "images/s", "ms_per_step": round(1e3 * el3 / args.steps, 4),
+                           "ms_per_step_each": [round(1e3 * t / args.steps, 4) for t in all3]},
             "timing": {"repeats": len(all_s), "reported": "median repeat", "ms_per_step_each": [round(1e3 * t / args.steps, 4) for t in all_s]}}
 
 
