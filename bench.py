@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- images/sec of the MonoFlex hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train] [--batch B] [--dtype bf16|fp16|fp32]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train] [--batch B] [--dtype bf16|fp16|fp32|fp16x2]
 
 --mode infer (default; BASELINE configs[1] / C5 with --batch 32): one "step" = DLA-34 + DCNv2 + all heads forward +
     NMS / top-K / 3D decode over one batch of synthetic 1280x384 images already resident in HBM, replayed from one hipGraph.
@@ -15,6 +15,10 @@ The default run (`python bench.py --gpus N`, what the driver records) carries th
 top level is the forward+decode number (bf16, configs[1]); `"train"` is a short graphed run of the training step (fwd + loss +
 bwd + AdamW, data parallel for N > 1: the metric's "fwd+bwd img/s") with its own roofline object; `"fp32_parity"` is the mode
 that meets the north-star tolerance (<= 1e-3 on logits, identical top-K against the reference's goldens) timed the same way;
+`"fp16x2_parity"` meets the same tolerance on the fp16 matrix pipe (fp32 activations, every MFMA operand an fp16 (hi, lo) pair);
+`"pipeline"` feeds the captured step from host frames every step (H2D, device pre-processing and the D2H of the rows inside the timed region:
+what the reference's evaluation loop times, engine/inference.py:35-43, plus the feeding); N > 1 adds `"train_local_bn"` (rank-local BN
+statistics) before `"train"` (SyncBN like the reference, its collectives captured in the step's graphs);
 `"fp16"` is the same measurement with IEEE-half activations (same kernels instantiated for fp16, same MFMA rate; its deviation from
 the reference is 4-8x smaller than bf16's -- the headline stays bf16 because BASELINE.json configs[1] names bf16);
 `"train_fp16"` is the training step with fp16 activations under the dynamic loss scaler (BASELINE configs[3]'s "fp16 MFMA path";
