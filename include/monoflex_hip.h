@@ -156,14 +156,31 @@ typedef struct {
                                  which samples and multiplies in fp16 (3x3, stride 1, pad 1, C % 64 == 0)            */
     void* workspace;          /* optional fp32 scratch for split-K on small maps (>= 9*M*Cout_pad*4 bytes to allow every split) */
     int64_t workspace_bytes;
+    /* The module's own offset/mask conv (reference dcn_v2.py:118-122: 3x3 / stride 1 / pad 1 on the SAME input, 27 channels padded to 32,
+     * sigmoid on channels 18..26), optional: where the LDS-patch kernel runs it computes the offsets itself -- no separate conv launch, no
+     * offmask round trip (mfx_dcn_fuses_offset_conv tells; `offmask` may then be NULL).  Elsewhere these fields are ignored and
+     * `offmask` must hold the conv's output. */
+    const void* off_w_frag_f16;   /* fragment-major IEEE fp16 weights [2][18][64 lanes][16 B] of that conv (K = 9 * 64)                      */
+    const float* off_shift;       /* its bias, fp32 [32] (27 values, then zeros)                                                          */
+    float* offmask_out;           /* optional: the fused kernel also writes the rows it computed, fp32 [B*H*W][32] (the backward pass reads them) */
 } mfx_dcn_desc;
 int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream);
+/* 1 when mfx_dcn_nhwc(d) will compute the offsets inside the kernel from off_w_frag_f16 / off_shift (d->offmask is not read), else 0 */
+int mfx_dcn_fuses_offset_conv(const mfx_dcn_desc* d);
 
 /* DLA stem in bf16 mode: 7x7 / stride 1 / pad 3 conv of the fp32 NCHW image batch (B,3,H,W) -> NHWC (B,H,W,16) bf16 with
  * scale/shift (folded BN) + activation (dla_dcn.py:268-272).  Reads the image planes directly (no padded NHWC copy);
  * w: bf16 [16][K_pad], K = 7 rows x 4 super-taps x (2 pixels x 4 channels) as built by the host packer. */
 int mfx_stem_conv7x7_nchw(const float* images, const void* w, const float* scale, const float* shift, void* y,
                           int B, int H, int W, int Cout, int K_pad, int act, int dtype, void* stream);
+
+/* DLA F1 in one kernel (inference, 16-bit maps): stem 7x7 (3 -> 16) -> level0 3x3 (16 -> 16) -> level1 3x3 / stride 2 (16 -> 32), each + folded
+ * BN + ReLU (dla_dcn.py:268-276, 312-331); both full-resolution 16-channel maps stay in LDS, only the (B, H/2, W/2, 32) map is written.
+ * w_stem [16][stem_kpad] (the stem kernel's super-tap order, 224 used), w_l0 [16][160], w_l1 [32][160] with k = tap*16 + c (zero beyond 144), all in `dtype`
+ * (MFX_BF16 / MFX_F16); H, W even. */
+int mfx_f1_fused(const float* images, const void* w_stem, const float* sc_stem, const float* sh_stem,
+                 const void* w_l0, const float* sc_l0, const float* sh_l0, const void* w_l1, const float* sc_l1, const float* sh_l1,
+                 void* y, int B, int H, int W, int stem_kpad /* row length of w_stem, >= 224 */, int dtype, void* stream);
 
 /* 2x2/stride-2 max pooling (dla_dcn.py:237-238), NHWC, C % (16 bytes) == 0 */
 int mfx_maxpool2x2_nhwc(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);

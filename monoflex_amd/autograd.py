@@ -249,7 +249,7 @@ def _with_f16_fragments(p, x):
     are finite in fp16), and both fragment layouts hold 8 elements per 16 bytes, so the copy is one small cast of the bf16 fragments the step's batched packing already produced (36.9 k elements per layer): the
     training forward then runs the third-generation kernel on the five full-resolution layers (102 -> 75 us each) instead of the
     first-generation gather."""
-    if p.w_frag is not None and p.Ck == 64 and p.Cout_pad == 64 and x.shape[0] * x.shape[1] * x.shape[2] >= 65536:
+    if p.w_frag is not None and p.Ck == 64 and p.Cout_pad in (32, 64) and x.shape[0] * x.shape[1] * x.shape[2] >= 65536:      # (32: the module's offset/mask conv, run inside that kernel)
         if p.w.dtype == torch.bfloat16:
             p.w_frag_f16 = p.w_frag.to(torch.float16)
         elif p.w.dtype == torch.float16:
@@ -755,13 +755,14 @@ class DCNModuleFn(Function):
         sh = _padded_bias(b_off, cp)
         po = _pack_weight(w_off, x.dtype, 0, cpad, Cin, 1, 1, 1, sh)
         po.act = L.ACT_DCN_OFFMASK
-        om = ops.conv2d(x, po, out_dtype=torch.float32)                       # offsets | sigmoid(mask logits), (B,H,W,32) fp32
         Cout = weight.shape[0]
         cpm = ops.cout_pad(Cout)
         shift = None
         if bias is not None:
             shift = _padded_bias(bias, cpm)
-        y = ops.dcn(x, om, _with_f16_fragments(_pack_weight(weight, x.dtype, 0, Cout, weight.shape[1], 1, 1, 1, shift), x))
+        pm = _with_f16_fragments(_pack_weight(weight, x.dtype, 0, Cout, weight.shape[1], 1, 1, 1, shift), x)
+        # offsets | sigmoid(mask logits), (B,H,W,32) fp32: from the offset conv, or written by the DCN kernel that ran it (ops.dcn_module)
+        y, om = ops.dcn_module(x, _with_f16_fragments(po, x) if n_off == 27 else po, pm, need_offmask=True)
         ctx.save_for_backward(x, om, w_off, weight)
         ctx.n_off = n_off
         return y

@@ -285,6 +285,8 @@ extern int g_opt_wgrad_mfma, g_opt_wgrad_blocks, g_opt_wgrad_ws, g_opt_wgrad_ws_
 namespace mfx {
 int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st);      // dcn_wave.hip
 int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st);     // dcn_patch.hip
+bool dcn_patch_fuses_offset_conv(const mfx_dcn_desc* d);
+extern int g_opt_dcn_fuse_off;
 
 // tuning overrides (mfx_set_option): 0 = automatic
 int g_opt_conv_tile = 0, g_opt_dcn_tile = 0, g_opt_cat_tile = 0, g_opt_kc = 0;
@@ -417,6 +419,7 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "dcn_wave") g_opt_dcn_wave = value;
     else if (n == "dcn_patch") g_opt_dcn_patch = value;
     else if (n == "dcn_patch_fn8") g_opt_dcn_patch_fn8 = value;
+    else if (n == "dcn_fuse_off") g_opt_dcn_fuse_off = value;
     else if (n == "topk_strips") g_opt_topk_strips = value;
 #ifdef MFX_PROBES
     else if (n == "dcn_bt_dbg") g_opt_dcn_bt_dbg = value;
@@ -610,8 +613,11 @@ template <typename T> static int dispatch_dcn(const mfx_dcn_desc* d, const DcnGe
 }
 }  // namespace mfx
 
+extern "C" int mfx_dcn_fuses_offset_conv(const mfx_dcn_desc* d) { return (d && d->x && dcn_patch_fuses_offset_conv(d)) ? 1 : 0; }
+
 extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
-    if (!d || !d->x || !d->offmask || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "dcn: null pointer");
+    if (!d || !d->x || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "dcn: null pointer");
+    if (!d->offmask && !dcn_patch_fuses_offset_conv(d)) return mfx_fail(MFX_ERR_ARG, "dcn: offmask is NULL (the offset conv is computed inside the kernel only where mfx_dcn_fuses_offset_conv says so)");
     const int elems = (d->dtype == MFX_F32 || d->dtype == MFX_F16X2) ? 4 : 8;
     if (d->dtype != MFX_F32 && d->dtype != MFX_BF16 && d->dtype != MFX_F16 && d->dtype != MFX_F16X2) return mfx_fail(MFX_ERR_ARG, "dcn: bad dtype");
     if (!is_pow2(d->C) || d->C < 4 * elems) return mfx_fail(MFX_ERR_ARG, "dcn: C must be a power of two >= 64 bytes of channels");

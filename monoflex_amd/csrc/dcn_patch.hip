@@ -59,9 +59,18 @@ template <typename TX> __device__ __forceinline__ u32x4 to_h8(const u32x4& v);
 template <> __device__ __forceinline__ u32x4 to_h8<bf16_t>(const u32x4& v) { return bf8_to_h8(v); }
 template <> __device__ __forceinline__ u32x4 to_h8<half_t>(const u32x4& v) { return v; }
 
-template <int FN, int FM, int R = 3, int CS = 64, bool PD = false, typename TX = bf16_t>
+// OF = true (r04): the module's 27-channel offset/mask conv (3x3 / stride 1 / pad 1 on the SAME input, reference dcn_v2.py:118-122) runs
+// inside this kernel.  Phase 0 stages the tile's 18 x 18 x 64-channel neighbourhood in the (still unused) patch memory, every wave
+// multiplies its own 64 pixels x 32 channels x K = 576 on the matrix cores (144 MFMAs, fp16 weights fragment-major from L2), adds the
+// bias, applies the sigmoid to the nine mask channels and transposes the accumulators through a 2.3 KB wave-private LDS buffer so that
+// each pixel's owner lane holds its 27 values in registers -- exactly what the separate conv's output row gave it.  That removes
+// the 27.5 us offset conv launch, its 31 MB output and this kernel's row loads; the rows are written out only when a caller needs
+// them (training: the backward pass).
+struct DcnOffArgs { const u32x4* wfm; const float* shift; float* om_out; };
+
+template <int FN, int FM, int R = 3, int CS = 64, bool PD = false, typename TX = bf16_t, bool OF = false>
 __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const TX* __restrict__ x, const float* __restrict__ om,
-                                                          const u32x4* __restrict__ wfm, DcnPGeom g, EpiArgs ep) {
+                                                          const u32x4* __restrict__ wfm, DcnPGeom g, EpiArgs ep, DcnOffArgs oa) {
     using SM = DcnPSmem<FM, R, CS, PD>;
     constexpr int kPW = SM::PW, PB = SM::PB, NC = SM::NC, KS = CS / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const TX* __restrict_
     const int yo = ty0 + wv * FM + gi, xo = tx0 + xl;
     const bool own_ok = yo < g.H && xo < g.W;
     float omv[27];
-    {
+    if constexpr (!OF) {
         const float* r = om + ((size_t)(b * g.H + min(yo, g.H - 1)) * g.W + min(xo, g.W - 1)) * 32;
 #pragma unroll
         for (int q = 0; q < 24; q += 4) {
@@ -91,6 +100,73 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const TX* __restrict_
             omv[q] = t[0]; omv[q + 1] = t[1]; omv[q + 2] = t[2]; omv[q + 3] = t[3];
         }
         omv[24] = r[24]; omv[25] = r[25]; omv[26] = r[26];
+    } else {
+        static_assert(FM == 4, "owner lanes: one pixel per lane needs FM == 4");
+        constexpr int ZW = 18, ZPS = 144;                                     // neighbourhood width, bytes per pixel (64 x fp16 + 16: conflict-free b128)
+        constexpr int ZBYTES = (4 * FM + 2) * ZW * ZPS, TLD = 36;
+        float* tbuf = reinterpret_cast<float*>(smem + ((ZBYTES + 63) & ~63)) + wv * (16 * TLD);
+        // ---- phase 0a: tile + 1 pixel, all 64 channels, zero outside the image (the conv's zero padding)
+        for (int idx = tid; idx < (4 * FM + 2) * ZW * 8; idx += 256) {
+            const int p = idx >> 3, col = idx & 7;
+            const int ry = p / ZW, rx = p - ry * ZW;
+            const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
+                v = to_h8<TX>(*reinterpret_cast<const u32x4*>(xb + ((size_t)gy * g.W + gx) * g.C + col * 8));
+            *reinterpret_cast<u32x4*>(smem + p * ZPS + (col << 4)) = v;
+        }
+        f32x4 ao[FM][2];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) { ao[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ao[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // weight fragments: ring of six steps, five in flight (a step is only 8 MFMAs = 53 ns of matrix-pipe time per wave against an L2 round
+        // trip of ~0.5 us: one step of look-ahead left every step waiting on its weights, 17 of the phase's ~25 us)
+        constexpr int OR = 6;
+        u32x4 ow[OR][2];
+        const u32x4* owl = oa.wfm + lane;                                     // [nf 2][step 18][lane 64]
+#pragma unroll
+        for (int u = 0; u < OR - 1; ++u) { ow[u][0] = owl[(0 * 18 + u) * 64]; ow[u][1] = owl[(1 * 18 + u) * 64]; }
+        __syncthreads();
+        // ---- phase 0b: 18 k-steps of 32 (tap = s / 2, channels 32 (s & 1) + 8 kq ..)
+#pragma unroll
+        for (int s_ = 0; s_ < 18; ++s_) {
+            if (s_ + OR - 1 < 18) { ow[(s_ + OR - 1) % OR][0] = owl[(0 * 18 + s_ + OR - 1) * 64]; ow[(s_ + OR - 1) % OR][1] = owl[(1 * 18 + s_ + OR - 1) * 64]; }
+            const int tap = s_ >> 1, th = tap / 3, tw = tap - th * 3;
+            const char* ap = smem + ((wv * FM + th) * ZW + xl + tw) * ZPS + ((s_ & 1) * 32 + kq * 8) * 2;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const u32x4 af = *reinterpret_cast<const u32x4*>(ap + i * ZW * ZPS);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    ao[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, af), __builtin_bit_cast(h8_t, ow[s_ % OR][j]), ao[i][j], 0, 0, 0);
+            }
+        }
+        // ---- phase 0c: + bias, sigmoid on the mask channels, accumulator fragment -> the pixel's owner lane
+        const float b0 = oa.shift[xl], b1 = oa.shift[16 + xl];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v0 = ao[i][0][r] + b0, v1 = ao[i][1][r] + b1;           // channels xl and 16 + xl of pixel 4 kq + r
+                if (xl >= 2) v1 = 1.f / (1.f + __expf(-v1));                    // 18 .. 26 (27 .. 31 are padding)
+                tbuf[(kq * 4 + r) * TLD + xl] = v0;
+                tbuf[(kq * 4 + r) * TLD + 16 + xl] = (xl < 11) ? v1 : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (kq == i) {                                                    // gi == kq for FM == 4: these sixteen lanes own fragment i's pixels
+#pragma unroll
+                for (int q = 0; q < 24; q += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(tbuf + xl * TLD + q);
+                    omv[q] = t[0]; omv[q + 1] = t[1]; omv[q + 2] = t[2]; omv[q + 3] = t[3];
+                }
+                omv[24] = tbuf[xl * TLD + 24]; omv[25] = tbuf[xl * TLD + 25]; omv[26] = tbuf[xl * TLD + 26];
+                if (oa.om_out && own_ok) {
+                    float* o = oa.om_out + ((size_t)(b * g.H + yo) * g.W + xo) * 32;
+#pragma unroll
+                    for (int q = 0; q < 32; q += 4) *reinterpret_cast<f32x4*>(o + q) = *reinterpret_cast<const f32x4*>(tbuf + xl * TLD + q);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 
     f32x4 acc[FM][FN];
@@ -188,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const TX* __restrict_
     const int nslice = g.C / CS;
     for (int sl = 0; sl < nslice; ++sl) {
         const int c0 = sl * CS;
-        if (sl) __syncthreads();                              // previous slice fully consumed
+        if (OF || sl) __syncthreads();                        // previous slice (or the offset conv's neighbourhood) fully consumed
         // ---- patch load: pix x 8 columns of 16 bytes (bf16 -> fp16), zero outside the image
         for (int idx = tid; idx < SM::pix * NC; idx += 256) {
             const int p = idx / NC, col = idx % NC;
@@ -270,19 +346,23 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const TX* __restrict_
 int g_opt_dcn_patch_fn8 = 1;
 int g_opt_dcn_patch = 1;     // 0 = off, 1 = automatic, 2 = force (FM 4), 3 = force FM 2, 4 = force FM 1, 5-7 = wide margin FM 4/2/1, 8 = padded layout
 
-template <int FN, int FM, int R = 3, int CS = 64, bool PD = false, typename TX = bf16_t>
+template <int FN, int FM, int R = 3, int CS = 64, bool PD = false, typename TX = bf16_t, bool OF = false>
 static int launch_dcn_patch_t(const mfx_dcn_desc* d, hipStream_t st);
+
+int g_opt_dcn_fuse_off = 1;  // option "dcn_fuse_off": 1 = the LDS-patch kernel computes the offset/mask conv itself where the caller supplies its weights
 
 template <int FN, int FM, int R = 3, int CS = 64, bool PD = false>
 static int launch_dcn_patch(const mfx_dcn_desc* d, hipStream_t st) {
-    if constexpr (FN == 4 && FM == 4 && R == 7 && CS == 32 && PD) {      // the production variant exists for fp16 maps too
-        if (d->dtype == MFX_F16) return launch_dcn_patch_t<FN, FM, R, CS, PD, half_t>(d, st);
+    if constexpr (FN == 4 && FM == 4 && R == 7 && CS == 32 && PD) {      // the production variant exists for fp16 maps too, and with the offset conv inside
+        const bool of = g_opt_dcn_fuse_off && d->off_w_frag_f16 && d->off_shift && d->C == 64;
+        if (d->dtype == MFX_F16) return of ? launch_dcn_patch_t<FN, FM, R, CS, PD, half_t, true>(d, st) : launch_dcn_patch_t<FN, FM, R, CS, PD, half_t>(d, st);
+        if (d->dtype == MFX_BF16 && of) return launch_dcn_patch_t<FN, FM, R, CS, PD, bf16_t, true>(d, st);
     }
     if (d->dtype != MFX_BF16) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn patch: this variant is built for bf16 maps only");
     return launch_dcn_patch_t<FN, FM, R, CS, PD, bf16_t>(d, st);
 }
 
-template <int FN, int FM, int R, int CS, bool PD, typename TX>
+template <int FN, int FM, int R, int CS, bool PD, typename TX, bool OF>
 static int launch_dcn_patch_t(const mfx_dcn_desc* d, hipStream_t st) {
     DcnPGeom g;
     g.B = d->B; g.H = d->H; g.W = d->W; g.C = d->C;
@@ -295,13 +375,28 @@ static int launch_dcn_patch_t(const mfx_dcn_desc* d, hipStream_t st) {
     constexpr int smem = DcnPSmem<FM, R, CS, PD>::bytes;
     static bool attr_done = false;
     if (!attr_done) {
-        MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_patch_kernel<FN, FM, R, CS, PD, TX>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_patch_kernel<FN, FM, R, CS, PD, TX, OF>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    hipLaunchKernelGGL((dcn_patch_kernel<FN, FM, R, CS, PD, TX>), dim3(tiles), dim3(256), smem, st, reinterpret_cast<const TX*>(d->x), d->offmask,
-                       reinterpret_cast<const u32x4*>(d->w_frag_f16), g, ep);
+    DcnOffArgs oa;
+    oa.wfm = reinterpret_cast<const u32x4*>(d->off_w_frag_f16); oa.shift = d->off_shift; oa.om_out = d->offmask_out;
+    if (!OF && !d->offmask) return mfx_fail(MFX_ERR_ARG, "dcn: offmask is NULL and this kernel does not compute the offsets itself");
+    hipLaunchKernelGGL((dcn_patch_kernel<FN, FM, R, CS, PD, TX, OF>), dim3(tiles), dim3(256), smem, st, reinterpret_cast<const TX*>(d->x), d->offmask,
+                       reinterpret_cast<const u32x4*>(d->w_frag_f16), g, ep, oa);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
+}
+
+// the automatic choice of the production variant (64 -> 64 on large maps, 16-bit): also where the offset conv can be fused
+static bool dcn_patch_auto(const mfx_dcn_desc* d) {
+    if (g_opt_dcn_patch != 1 || !d->w_frag_f16 || (d->dtype != MFX_BF16 && d->dtype != MFX_F16)) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dil != 1 || d->Ho != d->H || d->Wo != d->W) return false;
+    if (d->C % 64 != 0 || d->K_pad != 9 * d->C || d->Cout_pad % 64 != 0) return false;
+    return d->C == 64 && d->Cout_pad == 64 && (long)d->B * d->H * d->W >= 65536;
+}
+
+bool dcn_patch_fuses_offset_conv(const mfx_dcn_desc* d) {
+    return g_opt_dcn_fuse_off && d->off_w_frag_f16 && d->off_shift && dcn_patch_auto(d);
 }
 
 // returns 1 if handled, 0 to fall through to the older kernels, < 0 on error

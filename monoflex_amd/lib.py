@@ -42,7 +42,8 @@ class DcnDesc(ctypes.Structure):
                 ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad", c_int), ("dil", c_int),
                 ("Ho", c_int), ("Wo", c_int), ("Cout", c_int), ("Cout_pad", c_int), ("K_pad", c_int),
                 ("ldy", c_int), ("act", c_int), ("dtype", c_int), ("w_frag_f16", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64)]
+                ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64),
+                ("off_w_frag_f16", c_void_p), ("off_shift", c_void_p), ("offmask_out", c_void_p)]
 
 
 class HeadsDesc(ctypes.Structure):
@@ -99,6 +100,7 @@ SYMBOLS = {
     "mfx_abi_version": (_I, []),
     "mfx_last_error": (ctypes.c_char_p, []),
     "mfx_stem_conv7x7_nchw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mfx_f1_fused": (_I, [_P] * 11 + [_I, _I, _I, _I, _I, _P]),
     "mfx_set_option": (_I, [ctypes.c_char_p, _I]),
     "mfx_get_counter": (ctypes.c_long, [ctypes.c_char_p]),
     "mfx_dcn_v2_workspace_bytes": (_S, [_I] * 14),
@@ -113,6 +115,7 @@ SYMBOLS = {
     "mfx_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_pack_image_nhwc4": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_heads_fused": (_I, [ctypes.POINTER(HeadsDesc), _P]),
+    "mfx_dcn_fuses_offset_conv": (_I, [ctypes.POINTER(DcnDesc)]),
     "mfx_edge_scatter_add": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
     "mfx_decode_topk_workspace_bytes": (_S, [_I, _I, _I]),
     "mfx_decode_topk": (_I, [_P, ctypes.c_long, ctypes.c_long, ctypes.c_long, _I, _I, _I, _I, _I, _P, _P, _P, _S, _P]),

@@ -92,8 +92,9 @@ class DCN(DCNv2):
         key = ("off", dtype)
         if key not in self._packs:
             c = self.conv_offset_mask
-            self._packs[key] = ops.pack_conv(c.weight, dtype, None, c.bias, stride=self.stride[0], pad=self.padding[0],
-                                             act=L.ACT_DCN_OFFMASK, cout=32)
+            p = ops.pack_conv(c.weight, dtype, None, c.bias, stride=self.stride[0], pad=self.padding[0],
+                              act=L.ACT_DCN_OFFMASK, cout=32)
+            self._packs[key] = ops.add_f16_fragments(p, c.weight)            # fp16 fragments: the LDS-patch DCN kernel can run this conv itself
         return self._packs[key]
 
     def packed_main(self, dtype, bn=None, act=L.ACT_NONE):
@@ -115,7 +116,8 @@ class DCN(DCNv2):
         if OFFSET_CONV_FP32[0] and x.dtype != torch.float32:    # ablation switch (tools/bf16_ablation.py): offsets from fp32 operands
             offmask = ops.conv2d(x.float(), self.packed_offset(torch.float32), out_dtype=torch.float32)
         else:
-            offmask = ops.conv2d(x, self.packed_offset(ops.compute_tag(self, x.dtype)), out_dtype=torch.float32)
+            tag = ops.compute_tag(self, x.dtype)
+            return ops.dcn_module(x, self.packed_offset(tag), self.packed_main(tag, bn, act))[0]
         return ops.dcn(x, offmask, self.packed_main(ops.compute_tag(self, x.dtype), bn, act))
 
     def forward_nhwc_train(self, x):

@@ -190,6 +190,18 @@ class DLA(nn.Module):
             scale, shift = ops.fold_bn(self.base_layer[1])
             packs[("stem", tag)] = ops.pack_stem(self.base_layer[0].weight, tag, scale, shift)
         B, _, H, W = images.shape
+        if FUSE_F1[0] and dtype in (torch.bfloat16, torch.float16) and tag == dtype and packs[("stem", tag)].Cout == 16 \
+                and len(self.level0) == 3 and len(self.level1) == 3 and H % 2 == 0 and W % 2 == 0 and self.channels[:2] == [16, 32]:
+            # stem -> level0 -> level1 in one kernel: the two full-resolution 16-channel maps never reach memory.  Nothing downstream reads
+            # them (DLAUp starts at level 2, first_level = 2), so y[0] is None on this path (FUSE_F1[0] = False brings it back: tests of the
+            # per-stage goldens)
+            x = ops.f1_fused(images, packs[("stem", tag)], _conv_bn(self.level0, "c0", self.level0[0], self.level0[1], dtype, L.ACT_RELU),
+                             _conv_bn(self.level1, "c0", self.level1[0], self.level1[1], dtype, L.ACT_RELU))
+            y = [None, x]
+            for i in range(2, 6):
+                x = getattr(self, "level{}".format(i))(x)
+                y.append(x)
+            return y
         if (dtype in (torch.bfloat16, torch.float16) or tag == ops.F16X2) and packs[("stem", tag)].Cout == 16:
             x = ops.stem_conv(images, packs[("stem", tag)])                 # reads the NCHW planes directly
         else:
@@ -318,6 +330,8 @@ def _idaup_forward_parallel_proj(self, layers, startp, endp, packs):
         t = ops.upsample_add(proj[k - 1], packs[k], up.stride[0], skip=layers[i - 1])
         layers[i] = getattr(self, "node_" + str(k))(t)
 
+
+FUSE_F1 = [os.environ.get("MFX_FUSE_F1", "1") == "1"]         # inference, 16-bit maps: stem + level0 + level1 as one kernel (csrc/f1_fused.hip)
 
 IDAUp._forward_parallel_proj = _idaup_forward_parallel_proj
 PARALLEL_PROJ = [__import__("os").environ.get("MFX_PARALLEL_PROJ", "0") == "1"]     # measured neutral at B = 8 (3.18-3.21 vs 3.20 ms/step): off

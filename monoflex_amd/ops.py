@@ -381,15 +381,12 @@ def add_f16_fragments(p: PackedConv, weight):
     return p
 
 
-@on_tensor_device
-def dcn(x, offmask, p: PackedConv):
-    """Fused DCNv2 + scale/shift + act.  x (B,H,W,C) NHWC, offmask fp32 (B,Ho,Wo,32)."""
-    _need_cuda(x, offmask)
+def _dcn_desc(x, offmask, p: PackedConv, y, off: Optional[PackedConv] = None, offmask_out=None):
     B, H, W, C = x.shape
-    Ho, Wo = offmask.shape[1], offmask.shape[2]
-    y = torch.empty((B, Ho, Wo, p.Cout), dtype=x.dtype, device=x.device)
+    Ho, Wo = y.shape[1], y.shape[2]
     d = L.DcnDesc()
-    d.x, d.offmask, d.w, d.y = x.data_ptr(), offmask.data_ptr(), p.w.data_ptr(), y.data_ptr()
+    d.x, d.w, d.y = x.data_ptr(), p.w.data_ptr(), y.data_ptr()
+    d.offmask = offmask.data_ptr() if offmask is not None else None
     d.w_frag = p.w_frag.data_ptr() if p.w_frag is not None else None
     d.w_frag_f16 = p.w_frag_f16.data_ptr() if p.w_frag_f16 is not None else None
     d.scale = p.scale.data_ptr() if p.scale is not None else None
@@ -398,11 +395,44 @@ def dcn(x, offmask, p: PackedConv):
     d.kh, d.kw, d.stride, d.pad, d.dil = p.kh, p.kw, p.stride, p.pad_h, p.dil_w
     d.Ho, d.Wo, d.Cout, d.Cout_pad, d.K_pad, d.ldy, d.act = Ho, Wo, p.Cout, p.Cout_pad, p.K_pad, p.Cout, p.act
     d.dtype = L.MFX_F16X2 if p.split else _dt(x.dtype)
+    if off is not None and off.w_frag_f16 is not None and off.shift is not None and off.Cout_pad == 32 and off.K_pad == 9 * C:
+        d.off_w_frag_f16, d.off_shift = off.w_frag_f16.data_ptr(), off.shift.data_ptr()
+        d.offmask_out = offmask_out.data_ptr() if offmask_out is not None else None
+    return d
+
+
+@on_tensor_device
+def dcn(x, offmask, p: PackedConv):
+    """Fused DCNv2 + scale/shift + act.  x (B,H,W,C) NHWC, offmask fp32 (B,Ho,Wo,32)."""
+    _need_cuda(x, offmask)
+    B = x.shape[0]
+    Ho, Wo = offmask.shape[1], offmask.shape[2]
+    y = torch.empty((B, Ho, Wo, p.Cout), dtype=x.dtype, device=x.device)
+    d = _dcn_desc(x, offmask, p, y)
     if B * Ho * Wo * p.Cout_pad <= SPLITK_MAX_ELEMS:           # small maps: lets the library split K over workgroups
         ws = _splitk_workspace(x.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     L.check(L.load().mfx_dcn_nhwc(ctypes.byref(d), _stream()), "mfx_dcn_nhwc")
     return y
+
+
+@on_tensor_device
+def dcn_module(x, p_off: PackedConv, p: PackedConv, need_offmask=False):
+    """The DCN module of the reference (dcn_v2.py:118-128): offset/mask conv (27 -> 32 channels, fp32 out, sigmoid on the mask channels)
+    followed by the fused DCNv2.  Where the library's LDS-patch kernel takes the layer (mfx_dcn_fuses_offset_conv: 64 -> 64 on large
+    16-bit maps) the offset conv runs INSIDE it -- one launch, the (B,H,W,32) offset map exists only if `need_offmask` (training: the
+    backward pass reads it).  -> (y, offmask or None)"""
+    _need_cuda(x)
+    B, H, W, C = x.shape
+    if p.stride == 1 and p.pad_h == 1 and p.kh == 3 and p.kw == 3:
+        y = torch.empty((B, H, W, p.Cout), dtype=x.dtype, device=x.device)
+        om = torch.empty((B, H, W, 32), dtype=torch.float32, device=x.device) if need_offmask else None
+        d = _dcn_desc(x, None, p, y, off=p_off, offmask_out=om)
+        if d.off_w_frag_f16 and L.load().mfx_dcn_fuses_offset_conv(ctypes.byref(d)):
+            L.check(L.load().mfx_dcn_nhwc(ctypes.byref(d), _stream()), "mfx_dcn_nhwc")
+            return y, om
+    om = conv2d(x, p_off, out_dtype=torch.float32)
+    return dcn(x, om, p), om
 
 
 @on_tensor_device
@@ -476,6 +506,28 @@ def stem_conv(images, p: PackedConv):
     y = torch.empty((B, H, W, 16), dtype=torch.float32 if p.split else p.w.dtype, device=images.device)
     L.check(L.load().mfx_stem_conv7x7_nchw(_ptr(images), _ptr(p.w), _ptr(p.scale), _ptr(p.shift), _ptr(y), B, H, W, 16, p.K_pad, p.act,
                                            L.MFX_F16X2 if p.split else _dt(p.w.dtype), _stream()), "mfx_stem_conv7x7_nchw")
+    return y
+
+
+@on_tensor_device
+def f1_fused(images, p_stem: PackedConv, p_l0: PackedConv, p_l1: PackedConv):
+    """(B,3,H,W) fp32 NCHW -> level1 map (B,H/2,W/2,32): stem + level0 + level1 (each conv + folded BN + ReLU) in one kernel (csrc/f1_fused.hip);
+    the packs are the ones the three separate launches use (pack_stem, pack_conv)."""
+    _need_cuda(images)
+    images = images.float().contiguous()
+    B, C, H, W = images.shape
+    dt = p_stem.w.dtype
+    assert C == 3 and dt in (torch.bfloat16, torch.float16) and p_stem.Cout == 16 and p_l0.Cout == 16 and p_l1.Cout == 32 and p_l1.stride == 2
+    key = "_f1_w160"
+    for p in (p_l0, p_l1):                                          # [Cout][160] slice of the K-padded (tap, channel) matrix, cached on the pack
+        if not hasattr(p, key):
+            assert p.K_pad >= 160 and p.Ck == 16
+            setattr(p, key, p.w[:, :160].contiguous())
+    y = torch.empty((B, H // 2, W // 2, 32), dtype=dt, device=images.device)
+    L.check(L.load().mfx_f1_fused(_ptr(images), _ptr(p_stem.w), _ptr(p_stem.scale), _ptr(p_stem.shift),
+                                  _ptr(getattr(p_l0, key)), _ptr(p_l0.scale), _ptr(p_l0.shift),
+                                  _ptr(getattr(p_l1, key)), _ptr(p_l1.scale), _ptr(p_l1.shift),
+                                  _ptr(y), B, H, W, p_stem.K_pad, _dt(dt), _stream()), "mfx_f1_fused")
     return y
 
 

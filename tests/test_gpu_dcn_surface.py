@@ -179,3 +179,56 @@ def test_unsupported_geometry_surfaces_as_runtime_error():
         m(x, off[:, :16], msk)
     with pytest.raises(RuntimeError, match="CPU"):
         _ext.dcn_v2_forward(x.cpu(), w.cpu(), b.cpu(), off.cpu(), msk.cpu(), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+
+
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,H,W,std", [(8, 96, 320, 2.0), (3, 150, 150, 5.0)])
+def test_dcn_module_with_the_offset_conv_inside_the_kernel(B, H, W, std, half):
+    """`ops.dcn_module` on the shapes the LDS-patch kernel takes (64 -> 64 on large 16-bit maps): the kernel runs the module's 27-channel
+    offset/mask conv itself (csrc/dcn_patch.hip, OF = true).  Against the two-launch form on the same operands: the offset rows it writes
+    (fp32 (B,H,W,32): offsets, sigmoid(mask), zero padding) agree to the rounding of a differently ordered fp32 sum, the outputs to what that
+    offset difference moves; and the module against the oracle (torch offset conv + C DCNv2) at the bf16 / fp16 bar of the unfused path.
+    Ragged tiles (150 x 150) and samples leaving the patch (sigma 5 px) included."""
+    from monoflex_amd import lib as L, ops
+    from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCN
+    from oracle import monoflex_ref as R
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[half]
+    g = _g(91)
+    ref = R.DCN(64, 64)
+    with torch.no_grad():
+        ref.weight.copy_((torch.randn(ref.weight.shape, generator=g) * 0.05).to(dt).float())
+        ref.bias.copy_(torch.randn(64, generator=g) * 0.1)
+        ref.conv_offset_mask.weight.copy_((torch.randn(ref.conv_offset_mask.weight.shape, generator=g) * (0.3 / 24)).to(dt).float())
+        bb = torch.randn(27, generator=g) * std
+        bb[18:] = torch.randn(9, generator=g)
+        ref.conv_offset_mask.bias.copy_(bb)
+    m = DCN(64, 64, kernel_size=(3, 3), stride=1, padding=1)
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV).eval()
+    x = torch.randn(B, 64, H, W, generator=g).to(dt).float()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)
+    lib_ = L.load()
+    p_off, p_main = m.packed_offset(dt), m.packed_main(dt)
+    assert p_off.w_frag_f16 is not None
+    before = None
+    try:
+        L.check(lib_.mfx_set_option(b"dcn_fuse_off", 0), "opt")
+        y0, om0 = ops.dcn_module(xd, p_off, p_main, need_offmask=True)
+        L.check(lib_.mfx_set_option(b"dcn_fuse_off", 1), "opt")
+        d = ops._dcn_desc(xd, None, p_main, torch.empty_like(y0), off=p_off)
+        assert lib_.mfx_dcn_fuses_offset_conv(__import__("ctypes").byref(d)) == 1
+        y1, om1 = ops.dcn_module(xd, p_off, p_main, need_offmask=True)
+        y2, om2 = ops.dcn_module(xd, p_off, p_main)                       # inference form: no offset map leaves the kernel
+        torch.cuda.synchronize()
+    finally:
+        lib_.mfx_set_option(b"dcn_fuse_off", 1)
+    assert om2 is None and torch.equal(y1, y2)
+    assert float((om1 - om0).abs().max()) < 2e-3 * max(1.0, float(om0.abs().max())), float((om1 - om0).abs().max())
+    assert float(om1[..., 27:].abs().max()) == 0.0 and bool(((om1[..., 18:27] > 0) & (om1[..., 18:27] < 1)).all())
+    rel01 = float((y1.float() - y0.float()).norm() / y0.float().norm())
+    assert rel01 < 5e-3, rel01
+    with torch.no_grad():
+        want = ref(x)
+    rel = float((y1.float().permute(0, 3, 1, 2).cpu() - want).norm() / want.norm())
+    rel0 = float((y0.float().permute(0, 3, 1, 2).cpu() - want).norm() / want.norm())
+    assert rel < 3e-2 and rel < 1.5 * rel0 + 1e-3, (rel, rel0)

@@ -45,13 +45,19 @@ def _run(m, imgs, tgts):
 def _stages(m, imgs):
     """The tensors the reference's forward hooks recorded (oracle/gen_golden.py:run_case): base level outputs, DLAUp outputs,
     the backbone feature -- as NHWC device tensors of the whole batch."""
+    from monoflex_amd.model.backbone import dla_dcn
     bb = m.backbone
-    with torch.no_grad():
-        base = bb.base(imgs.to(DEV), bb.compute_dtype)
-        up = bb.dla_up(list(base))
-        y = [up[i] for i in range(bb.last_level - bb.first_level)]
-        bb.ida_up(y, 0, len(y))
-    torch.cuda.synchronize()
+    fuse = dla_dcn.FUSE_F1[0]
+    dla_dcn.FUSE_F1[0] = False            # the 16-bit modes run stem + level0 + level1 as one kernel (level0's map never exists): per-stage goldens need it
+    try:
+        with torch.no_grad():
+            base = bb.base(imgs.to(DEV), bb.compute_dtype)
+            up = bb.dla_up(list(base))
+            y = [up[i] for i in range(bb.last_level - bb.first_level)]
+            bb.ida_up(y, 0, len(y))
+        torch.cuda.synchronize()
+    finally:
+        dla_dcn.FUSE_F1[0] = fuse
     out = {"base%d" % i: t for i, t in enumerate(base)}
     out.update({"dlaup%d" % i: t for i, t in enumerate(up)})
     out["feature"] = y[-1]

@@ -538,3 +538,38 @@ def test_halo_conv_k_split_wide_variants(dtype, C, Cout, variants):
             assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), v
     finally:
         L.check(lib_.mfx_set_option(b"halo", 1), "opt")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W", [(2, 48, 96), (1, 38, 74), (1, 384, 1280)])
+def test_f1_fused_equals_three_launches_and_torch(dtype, B, H, W):
+    """csrc/f1_fused.hip: stem 7x7 -> level0 3x3 -> level1 3x3 / s2 (each + folded BN + ReLU) in one kernel, both full-resolution maps in LDS,
+    against (a) the three separate launches on the same packed operands (same 16-bit roundings of both intermediate maps; the sums are
+    ordered differently, so single values move by an ulp of the storage type) and (b) torch fp32 convs with the intermediates rounded to the
+    storage type.  Ragged level1 tiles (19 x 37 outputs), image borders (zero padding of all three convs), and the bench's frame size."""
+    ops, L = _ops()
+    g = _g(61)
+    img = torch.randn(B, 3, H, W, generator=g)
+    rnd = lambda t: t.to(dtype).float()                                    # noqa: E731
+    w7 = rnd(torch.randn(16, 3, 7, 7, generator=g) / 147 ** 0.5)
+    w0 = rnd(torch.randn(16, 16, 3, 3, generator=g) / 12.0)
+    w1 = rnd(torch.randn(32, 16, 3, 3, generator=g) / 12.0)
+    bn = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1) for c in (16, 16, 32)]
+    ps = ops.pack_stem(w7.to(DEV), dtype, bn[0][0].to(DEV), bn[0][1].to(DEV))
+    p0 = ops.pack_conv(w0.to(DEV), dtype, bn[1][0].to(DEV), bn[1][1].to(DEV), stride=1, pad=1, act=L.ACT_RELU)
+    p1 = ops.pack_conv(w1.to(DEV), dtype, bn[2][0].to(DEV), bn[2][1].to(DEV), stride=2, pad=1, act=L.ACT_RELU)
+    x = img.to(DEV)
+    got = ops.f1_fused(x, ps, p0, p1)
+    want_hip = ops.conv2d(ops.conv2d(ops.stem_conv(x, ps), p0), p1)
+    torch.cuda.synchronize()
+    assert got.shape == want_hip.shape == (B, H // 2, W // 2, 32) and got.dtype == dtype
+    a, b_ = got.float().cpu(), want_hip.float().cpu()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert float((a - b_).norm() / b_.norm()) < 3 * eps, float((a - b_).norm() / b_.norm())
+    assert float((a - b_).abs().max()) <= 8 * eps * max(1.0, float(b_.abs().max()))
+    aff = lambda t, i: F.relu(t * bn[i][0].view(1, -1, 1, 1) + bn[i][1].view(1, -1, 1, 1))      # noqa: E731
+    r = rnd(aff(F.conv2d(rnd(img), w7, None, 1, 3), 0))
+    r = rnd(aff(F.conv2d(r, w0, None, 1, 1), 1))
+    r = aff(F.conv2d(r, w1, None, 2, 1), 2)
+    ref = r.permute(0, 2, 3, 1)
+    assert float((a - ref).norm() / ref.norm()) < 4 * eps, float((a - ref).norm() / ref.norm())

@@ -69,7 +69,7 @@ def base_levels(dts):
 
 def step(base_dt, up_dt, head_dt, off32):
     DV.OFFSET_CONV_FP32[0] = off32
-    x = [t.to(up_dt) for t in (base_levels(base_dt) if isinstance(base_dt, tuple) else bb.base(images, base_dt))]
+    x = [t.to(up_dt) if t is not None else None for t in (base_levels(base_dt) if isinstance(base_dt, tuple) else bb.base(images, base_dt))]
     x = bb.dla_up(list(x))
     y = [x[i] for i in range(bb.last_level - bb.first_level)]
     bb.ida_up(y, 0, len(y))
