@@ -126,6 +126,10 @@ typedef struct {
     float* stats;
     int stats_ncopy;
     int* stats_done;
+    /* optional, dtype MFX_F16X2 only: w_frag with its K steps re-packed in pairs, [Cout_pad/16][K_pad/(128 B)][hi | lo][64 lanes][16 B], a lane's
+     * chunk = [its two hi (lo) dwords of step 2p | of step 2p+1] (one 8-element fp16 MFMA operand).  Lets the LDS-halo kernel form three
+     * products per step pair instead of four (Ck >= 32). */
+    const void* w_frag_pair;
 } mfx_conv_desc;
 int mfx_conv2d_nhwc(const mfx_conv_desc* d, void* stream);
 

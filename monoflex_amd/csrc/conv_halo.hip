@@ -58,7 +58,11 @@ template <> __device__ __forceinline__ f32x2 halo_round2<half_t>(float a, float 
     return f32x2{(float)h[0], (float)h[1]};
 }
 
-template <typename T, typename TO, int WN, int FN, int WK = 1, bool ST = false>
+// PR (split precision only, channel groups of >= 32): the K loop walks step PAIRS.  Both operands keep their hi halves in dwords 0-1 and their
+// lo halves in dwords 2-3 of a chunk, so the hi (lo) halves of two consecutive steps form ONE 8-element fp16 MFMA operand: the weights arrive
+// re-packed that way (`wfm` = mfx_conv_desc.w_frag_pair, ops.pair_steps), the pixels by two 8-byte LDS reads 16 channels apart.  Three
+// products per pair -- hi.hi, lo.hi, hi.lo (lo.lo is below fp32 resolution) -- instead of the four of two mma_chunk<f32s_t> calls.
+template <typename T, typename TO, int WN, int FN, int WK = 1, bool ST = false, bool PR = false>
 __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                                       const u32x4* __restrict__ wfm, HaloGeom g, EpiArgs ep) {
     constexpr int NT = WN * WK * 64, FM = kHaloRows;
@@ -148,6 +152,63 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
             }
         }
 
+        if constexpr (PR) {
+            // pair p of this group = steps (2p, 2p+1): 32 consecutive channels of one tap (CG % 32 == 0: a pair never straddles taps, and
+            // 9 * CG / 16 steps is even: no padding pairs)
+            auto wfetch2 = [&](int p, u32x4 (&h)[FN], u32x4 (&l)[FN]) {
+                const int e0 = p * 32;
+                const int tap0 = e0 >> g.lgCG;
+                const int st = (tap0 * g.C + grp * g.CG + (e0 & (g.CG - 1))) >> 4;          // global 16-element step index (even)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) { h[j] = wfl[((size_t)j * fsteps + st) * 64]; l[j] = wfl[((size_t)j * fsteps + st + 1) * 64]; }
+            };
+            constexpr int RP = FN == 2 ? 3 : 2;
+            u32x4 wh[RP][FN], wl[RP][FN];
+            const int np = g.steps_per_group >> 1;
+            const int nl = np > wk ? (np - wk + WK - 1) / WK : 0;
+            auto P = [&](int j) { return wk + j * WK; };
+#pragma unroll
+            for (int u = 0; u < RP - 1; ++u)
+                if (u < nl) wfetch2(P(u), wh[u], wl[u]);
+            __syncthreads();                                      // patch visible to all waves
+            auto compute2 = [&](int p, const u32x4 (&h)[FN], const u32x4 (&l)[FN]) {
+                const int e = p * 32 + kq * 4;
+                const int tap = e >> g.lgCG, cl = e & (g.CG - 1);
+                const int th = (tap * 21846) >> 16, tw = tap - th * 3;
+                const char* ap = patch + (th * 18 + xl + tw) * PS + cl * 4;
+                auto rd = [&](const char* q) {
+                    const uint2 a = *reinterpret_cast<const uint2*>(q), b = *reinterpret_cast<const uint2*>(q + 64);
+                    return u32x4{a.x, a.y, b.x, b.y};
+                };
+                u32x4 ph[2], pl[2];
+                ph[0] = rd(ap); pl[0] = rd(ap + 8);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int cur = i & 1;
+                    if (i + 1 < FM) { ph[cur ^ 1] = rd(ap + (i + 1) * 18 * PS); pl[cur ^ 1] = rd(ap + (i + 1) * 18 * PS + 8); }
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ph[cur]), __builtin_bit_cast(f16x8, h[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, pl[cur]), __builtin_bit_cast(f16x8, h[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ph[cur]), __builtin_bit_cast(f16x8, l[j]), acc[i][j], 0, 0, 0);
+                }
+            };
+            int s = 0;
+            for (; s + RP <= nl; s += RP) {
+#pragma unroll
+                for (int u = 0; u < RP; ++u) {
+                    if (s + u + RP - 1 < nl) wfetch2(P(s + u + RP - 1), wh[(u + RP - 1) % RP], wl[(u + RP - 1) % RP]);
+                    compute2(P(s + u), wh[u], wl[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RP - 1; ++u)
+                if (s + u < nl) compute2(P(s + u), wh[u], wl[u]);
+        } else {
         // lane's K chunk at step s: e = s*4*ELEMS + kq*ELEMS -> (tap, local channel)
         auto wfetch = [&](int s, u32x4 (&bf)[FN]) {
             const int e = s * (4 * ELEMS) + kq * ELEMS;
@@ -212,6 +273,7 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
 #pragma unroll
         for (int u = 0; u < RING - 1; ++u)                    // < RING steps left; their fragments are already in flight
             if (s + u < nl) compute(S(s + u), wb[u]);
+        }
     }
 
     // ---- K-split: partial accumulators -> LDS (the patch is dead), wave wk sums and finishes rows wk*RW .. +RW
@@ -352,6 +414,7 @@ static inline int ilog2h(int v) { int l = 0; while ((1 << l) < v) ++l; return l;
 
 int g_opt_halo = 1;          // 0 = generic kernel only, 1 = automatic, >= 2 = force variant (value - 1)
 int g_opt_halo_cg = 0;       // max channels per patch pass (0 = default)
+int g_opt_halo_pair = 1;     // option "halo_pair": split precision walks K in step pairs where mfx_conv_desc.w_frag_pair is given (0 = two mma_chunk per pair)
 
 template <typename T, typename TO, int WN, int FN, int WK = 1, bool ST = false>
 static int launch_halo_st(const mfx_conv_desc* d, hipStream_t st);
@@ -387,13 +450,27 @@ static int launch_halo_st(const mfx_conv_desc* d, hipStream_t st) {
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
     ep.stats = ST ? d->stats : nullptr; ep.stats_ncopy = d->stats_ncopy > 0 ? d->stats_ncopy : 1;
     const int smem = SM::total(g.CG);
+    const int tiles = g.tiles_n * g.tiles_x * g.tiles_y * d->B;
+    if constexpr (std::is_same<T, f32s_t>::value && !ST) {
+        if (g_opt_halo_pair && d->w_frag_pair && g.CG % 32 == 0) {       // split precision: the pair-walking K loop (3 products per pair)
+            auto kp = conv3x3_wave_kernel<T, TO, WN, FN, WK, false, true>;
+            static int attr_smem_p = 0;
+            if (smem > 64 * 1024 && smem > attr_smem_p) {
+                MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                attr_smem_p = smem;
+            }
+            hipLaunchKernelGGL(kp, dim3(tiles), dim3(WN * WK * 64), smem, st, reinterpret_cast<const T*>(d->x), reinterpret_cast<const T*>(d->w),
+                               reinterpret_cast<const u32x4*>(d->w_frag_pair), g, ep);
+            MFX_HIP_CHECK(hipGetLastError());
+            return MFX_OK;
+        }
+    }
     auto k = conv3x3_wave_kernel<T, TO, WN, FN, WK, ST>;
     static int attr_smem = 0;
     if (smem > 64 * 1024 && smem > attr_smem) {
         MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_smem = smem;
     }
-    const int tiles = g.tiles_n * g.tiles_x * g.tiles_y * d->B;
     hipLaunchKernelGGL(k, dim3(tiles), dim3(WN * WK * 64), smem, st, reinterpret_cast<const T*>(d->x), reinterpret_cast<const T*>(d->w),
                        reinterpret_cast<const u32x4*>(d->w_frag), g, ep);
     MFX_HIP_CHECK(hipGetLastError());

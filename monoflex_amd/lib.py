@@ -24,7 +24,7 @@ class ConvDesc(ctypes.Structure):
                 ("Ho", c_int), ("Wo", c_int), ("M", c_int), ("Cout", c_int), ("Cout_pad", c_int), ("K_pad", c_int),
                 ("ldy", c_int), ("ldres", c_int), ("act", c_int), ("dtype", c_int), ("out_dtype", c_int),
                 ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64),
-                ("stats", c_void_p), ("stats_ncopy", c_int), ("stats_done", ctypes.POINTER(c_int))]
+                ("stats", c_void_p), ("stats_ncopy", c_int), ("stats_done", ctypes.POINTER(c_int)), ("w_frag_pair", c_void_p)]
 
 
 class CatDesc(ctypes.Structure):

@@ -190,7 +190,7 @@ class DLA(nn.Module):
             scale, shift = ops.fold_bn(self.base_layer[1])
             packs[("stem", tag)] = ops.pack_stem(self.base_layer[0].weight, tag, scale, shift)
         B, _, H, W = images.shape
-        if FUSE_F1[0] and dtype in (torch.bfloat16, torch.float16) and tag == dtype and packs[("stem", tag)].Cout == 16 \
+        if FUSE_F1[0] and ((dtype in (torch.bfloat16, torch.float16) and tag == dtype) or tag == ops.F16X2) and packs[("stem", tag)].Cout == 16 \
                 and len(self.level0) == 3 and len(self.level1) == 3 and H % 2 == 0 and W % 2 == 0 and self.channels[:2] == [16, 32]:
             # stem -> level0 -> level1 in one kernel: the two full-resolution 16-channel maps never reach memory.  Nothing downstream reads
             # them (DLAUp starts at level 2, first_level = 2), so y[0] is None on this path (FUSE_F1[0] = False brings it back: tests of the

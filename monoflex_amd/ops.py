@@ -171,6 +171,7 @@ class PackedConv:
     act: int
     w_frag: Optional[torch.Tensor] = None   # fragment-major copy for the LDS-halo kernel (3x3 / stride 1)
     w_frag_f16: Optional[torch.Tensor] = None   # same, IEEE fp16 (DCN LDS-patch kernel, bf16 mode)
+    w_frag_pair: Optional[torch.Tensor] = None  # split precision: w_frag with its K steps paired (pair_steps; mfx_conv_desc.w_frag_pair)
     split: bool = False                     # split-precision operands (F16X2): fp32 activations, MFX_F16X2 kernels
 
 
@@ -227,7 +228,10 @@ def pack_conv(weight, dtype, scale=None, shift=None, stride=1, pad=0, act=L.ACT_
             v = torch.cat((v, v.new_full((cp - v.numel(),), fill)))
         return v.contiguous()
     wf = fragment_major(w2, dtype) if (kh == 3 and kw == 3 and stride == 1 and pad == 1) else None
-    return PackedConv(w2, padv(scale, 1.0), padv(shift, 0.0), kh, kw, stride, pad, pad, 1, Cin, cout, cp, K_pad, act, wf, split=dtype == F16X2)
+    pk = PackedConv(w2, padv(scale, 1.0), padv(shift, 0.0), kh, kw, stride, pad, pad, 1, Cin, cout, cp, K_pad, act, wf, split=dtype == F16X2)
+    if wf is not None and dtype == F16X2 and Cin >= 32:
+        pk.w_frag_pair = pair_steps(wf, 1)
+    return pk
 
 
 # stem geometry: zero-padded NHWC4 image, 3 columns left / 5 right, 3 rows top/bottom
@@ -294,6 +298,7 @@ def conv2d(x, p: PackedConv, res=None, out_dtype=None, rowmap=None, x_channels=N
     d.w, d.scale, d.shift = p.w.data_ptr(), (p.scale.data_ptr() if p.scale is not None else None), \
         (p.shift.data_ptr() if p.shift is not None else None)
     d.w_frag = p.w_frag.data_ptr() if p.w_frag is not None else None
+    d.w_frag_pair = p.w_frag_pair.data_ptr() if p.w_frag_pair is not None else None
     d.res = res.data_ptr() if res is not None else None
     d.y = y.data_ptr()
     d.rowmap = rowmap.data_ptr() if rowmap is not None else None
@@ -516,8 +521,10 @@ def f1_fused(images, p_stem: PackedConv, p_l0: PackedConv, p_l1: PackedConv):
     _need_cuda(images)
     images = images.float().contiguous()
     B, C, H, W = images.shape
-    dt = p_stem.w.dtype
-    assert C == 3 and dt in (torch.bfloat16, torch.float16) and p_stem.Cout == 16 and p_l0.Cout == 16 and p_l1.Cout == 32 and p_l1.stride == 2
+    split = p_stem.split                                            # split precision: fp32 map out, (hi, lo) fp16 operand pairs
+    dt = torch.float32 if split else p_stem.w.dtype
+    assert C == 3 and (split or dt in (torch.bfloat16, torch.float16)) and p_stem.Cout == 16 and p_l0.Cout == 16 and p_l1.Cout == 32 and p_l1.stride == 2
+    assert p_l0.split == split and p_l1.split == split
     key = "_f1_w160"
     for p in (p_l0, p_l1):                                          # [Cout][160] slice of the K-padded (tap, channel) matrix, cached on the pack
         if not hasattr(p, key):
@@ -527,7 +534,7 @@ def f1_fused(images, p_stem: PackedConv, p_l0: PackedConv, p_l1: PackedConv):
     L.check(L.load().mfx_f1_fused(_ptr(images), _ptr(p_stem.w), _ptr(p_stem.scale), _ptr(p_stem.shift),
                                   _ptr(getattr(p_l0, key)), _ptr(p_l0.scale), _ptr(p_l0.shift),
                                   _ptr(getattr(p_l1, key)), _ptr(p_l1.scale), _ptr(p_l1.shift),
-                                  _ptr(y), B, H, W, p_stem.K_pad, _dt(dt), _stream()), "mfx_f1_fused")
+                                  _ptr(y), B, H, W, p_stem.K_pad, L.MFX_F16X2 if split else _dt(dt), _stream()), "mfx_f1_fused")
     return y
 
 

@@ -83,6 +83,71 @@ def test_conv3x3_halo_variants_split(variant):
     _close(_from_nhwc(y), ref, F32, Cin * 9, "split halo variant %d" % variant)
 
 
+@pytest.mark.parametrize("shape", [(32, 32, 3), (32, 64, 7), (128, 128, 8), (128, 64, 13), (256, 256, 12), (256, 32, 11), (16, 16, 2)])
+def test_conv3x3_halo_pair_walk_vs_step_walk(shape):
+    """The LDS-halo kernel's pair-walking K loop (three products per step pair, mfx_conv_desc.w_frag_pair; Cin >= 32) against the same
+    kernel walking single steps (option halo_pair = 0: four products per pair) and against fp64 torch -- one and several channel groups,
+    K-split variants.  Cin = 16 has no pairs (a pair would straddle taps) and must keep the step walk."""
+    ops, L = _ops()
+    lib_ = L.load()
+    Cin, Cout, variant = shape
+    g = _g(900 + Cin + Cout)
+    H, W = 21, 35
+    x = torch.randn(2, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1) * scale.view(1, -1, 1, 1).double() + shift.view(1, -1, 1, 1).double()
+    p = ops.pack_conv(w.to(DEV), ops.F16X2, scale.to(DEV), shift.to(DEV), stride=1, pad=1, act=0)
+    assert (p.w_frag_pair is not None) == (Cin >= 32)
+    outs = []
+    L.check(lib_.mfx_set_option(b"halo", variant), "opt")
+    try:
+        for pair in (1, 0):
+            L.check(lib_.mfx_set_option(b"halo_pair", pair), "opt")
+            outs.append(_from_nhwc(ops.conv2d(_to_nhwc(x, F32), p)))
+            torch.cuda.synchronize()
+    finally:
+        lib_.mfx_set_option(b"halo", 1)
+        lib_.mfx_set_option(b"halo_pair", 1)
+    for y in outs:
+        _close(y, ref.float(), F32, Cin * 9, "split halo pair walk %s" % (shape,))
+    e_pair, e_step = (float((y.double().cpu() - ref).abs().max()) for y in outs)
+    assert e_pair <= 2 * e_step + 1e-6, "pair walk error %.3e vs step walk %.3e" % (e_pair, e_step)
+    if Cin < 32:
+        assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 38, 74), (1, 384, 1280)])
+def test_f1_fused_split_vs_three_launches_and_torch(B, H, W):
+    """csrc/f1_fused.hip in split precision: stem 7x7 -> level0 3x3 -> level1 3x3 / s2 in one kernel (fp32 image in, fp32 level1 map out, both
+    full-resolution maps as (hi, lo) fp16 pairs in LDS) against the three separate split-precision launches on the same packs and against
+    fp64 torch: the fp32-grade bound of the mode, ragged tiles and image borders included."""
+    ops, L = _ops()
+    g = _g(62)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w7 = torch.randn(16, 3, 7, 7, generator=g) / 147 ** 0.5
+    w0 = torch.randn(16, 16, 3, 3, generator=g) / 12.0
+    w1 = torch.randn(32, 16, 3, 3, generator=g) / 12.0
+    bn = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1) for c in (16, 16, 32)]
+    ps = ops.pack_stem(w7.to(DEV), ops.F16X2, bn[0][0].to(DEV), bn[0][1].to(DEV))
+    p0 = ops.pack_conv(w0.to(DEV), ops.F16X2, bn[1][0].to(DEV), bn[1][1].to(DEV), stride=1, pad=1, act=L.ACT_RELU)
+    p1 = ops.pack_conv(w1.to(DEV), ops.F16X2, bn[2][0].to(DEV), bn[2][1].to(DEV), stride=2, pad=1, act=L.ACT_RELU)
+    x = img.to(DEV)
+    got = ops.f1_fused(x, ps, p0, p1)
+    want_hip = ops.conv2d(ops.conv2d(ops.stem_conv(x, ps), p0), p1)
+    torch.cuda.synchronize()
+    assert got.shape == want_hip.shape == (B, H // 2, W // 2, 32) and got.dtype == torch.float32
+    aff = lambda t, i: F.relu(t * bn[i][0].view(1, -1, 1, 1).double() + bn[i][1].view(1, -1, 1, 1).double())      # noqa: E731
+    r = aff(F.conv2d(img.double(), w7.double(), None, 1, 3), 0)
+    r = aff(F.conv2d(r, w0.double(), None, 1, 1), 1)
+    ref = aff(F.conv2d(r, w1.double(), None, 2, 1), 2).permute(0, 2, 3, 1)
+    a, b_ = got.double().cpu(), want_hip.double().cpu()
+    scale = float(ref.abs().max())
+    e_f, e_3 = float((a - ref).abs().max()) / scale, float((b_ - ref).abs().max()) / scale
+    assert e_f < 2e-6, "fused split F1: max err / max |ref| = %.3e (three launches: %.3e)" % (e_f, e_3)
+    assert float((a - b_).abs().max()) / scale < 2e-6
+
+
 def test_stem_and_cat_split():
     ops, L = _ops()
     g = _g(11)
