@@ -543,6 +543,12 @@ static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st) {
         if (N % 256 == 0 && Ck <= 64 && px_tiles >= 1500) v = 5;
         else v = (Ck >= 256 || px_tiles * (N / 128) < 300) ? 11 : 7;
     } else v = 6;
+    if (d->dtype == MFX_F16X2 && N == 32) {
+        // split precision (three MFMAs per step pair, 49 KB fp32 patches): the 27-channel DCN offset/mask convs take the 4-way K split on
+        // every map size -- B = 8 step 6.27 -> 6.20 ms, same box (bench.py --dtype fp16x2); the same move for N = 64 (v12) and N % 128 (v11)
+        // measured +-0.01 ms and is not made
+        v = 8;
+    }
     if (g_opt_halo >= 2) {
         const int f = g_opt_halo - 1, bn = variant_bn(f);
         if (bn && N % bn == 0 && (bn >= 64) == (N >= 64)) v = f;

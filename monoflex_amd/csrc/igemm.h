@@ -11,6 +11,7 @@
 // barrier per k-iteration.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace mfx {
 
@@ -98,6 +99,35 @@ __device__ __forceinline__ void gemm_mainloop(ALoader& al, WeightLoader<T, BN, W
         const bool more = (k + 1) < nk;
         if (more) { al.load(k0 + k + 1); bl.load(k0 + k + 1); }
 
+        if constexpr (std::is_same<T, f32s_t>::value && KC == 8) {
+            // split precision, two sub-steps per k-iteration: walk them as ONE pair.  A chunk is [hi hi | lo lo] (dwords), so the hi (lo) halves
+            // of the lane's chunks of both sub-steps form one 8-element fp16 operand (two 8-byte LDS reads 64 bytes apart), and the pair costs
+            // three products -- hi.hi, lo.hi, hi.lo -- instead of the four of two mma_chunk<f32s_t> calls
+            auto rd = [](const char* q) {
+                const uint2 a = *reinterpret_cast<const uint2*>(q), b = *reinterpret_cast<const uint2*>(q + 64);
+                return u32x4{a.x, a.y, b.x, b.y};
+            };
+            u32x4 ah[FM], al_[FM], bh[FN], bl_[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) { ah[i] = rd(cur + a_off + i * 16 * kRowBytes); al_[i] = rd(cur + a_off + i * 16 * kRowBytes + 8); }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) { bh[j] = rd(cur + b_off + j * 16 * kRowBytes); bl_[j] = rd(cur + b_off + j * 16 * kRowBytes + 8); }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al_[i]), __builtin_bit_cast(f16x8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bl_[j]), acc[i][j], 0, 0, 0);
+        } else
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks) {               // 64 bytes of K per sub-step
             u32x4 af[FM], bf[FN];

@@ -164,7 +164,11 @@ def test_e2e_full_vs_reference_golden_fp32(mode, batch):
     m = _hip_model(meta["cls_bias"], mode)
     imgs = S.synthetic_images(batch, 384, 1280, seed=meta["seeds"][0])
     det, topk, valid, hm = _run(m, imgs, [S.synthetic_target(320, 96)] * batch)
-    dl, dr = _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False, tie_tol=0.0 if batch == 1 else TIE_TOL)
+    # fp32 at B = 1 is the golden's own configuration: the identical sequence.  Every other shape / MFMA type may order the one 1.7e-6 pair
+    # of the reference's own scores either way (see _same_ranking)
+    tie_tol = 0.0 if (mode == "fp32" and batch == 1) else TIE_TOL
+    identical = bool(np.array_equal(topk[0][:, 1].numpy().astype(np.int64), g["img0_topk_index"]))
+    dl, dr = _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False, tie_tol=tie_tol)
     errs = _stage_errors(g, 0, _stages(m, imgs))
     print("full-size %s B=%d vs reference: max |dlogit| %.2e, max |dreg| %.2e; stages %s" % (
         mode, batch, dl, dr, {k: "%.1e/%.1e" % v for k, v in errs.items()}))
@@ -172,7 +176,7 @@ def test_e2e_full_vs_reference_golden_fp32(mode, batch):
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "fp16x2_b%d_vs_reference.json" % batch), "w") as f:
             json.dump({"shape": "B=%d, 1280x384, fp16x2 (split-precision MFMA operands, fp32 activations)" % batch, "max_abs_dlogit": float(dl),
-                       "max_abs_dreg": float(dr), "topk_identical": True if batch == 1 else "up to reference-side ties <= %g" % TIE_TOL, "stage_sample_rel_err": {k: v[0] for k, v in errs.items()},
+                       "max_abs_dreg": float(dr), "topk_identical": True if identical else "up to reference-side ties <= %g" % TIE_TOL, "stage_sample_rel_err": {k: v[0] for k, v in errs.items()},
                        "stage_abssum_rel_err": {k: v[1] for k, v in errs.items()}}, f, indent=1, sort_keys=True)
     assert len(errs) == 11 and all(e[0] <= 2e-4 and e[1] <= 1e-4 for e in errs.values()), errs
     pix = torch.as_tensor(g["img0_pix"])
