@@ -182,7 +182,9 @@ def deviation_vs_reference(out, dtype):
     pix = torch.as_tensor(g["img0_pix"])
     dl = float(np.abs(hm[..., :3].permute(2, 0, 1).reshape(3, -1)[:, pix].numpy() - g["img0_cls_logits_at"]).max())
     dr = float(np.abs(hm[..., 8:58].permute(2, 0, 1).reshape(50, -1)[:, pix].numpy() - g["img0_reg_at"]).max())
-    mine, ref = topk[:, 1].numpy().astype(np.int64), g["img0_topk_index"]
+    # a peak = (class, pixel): one pixel can rank for two classes
+    mine = topk[:, 2].numpy().astype(np.int64) * (1 << 20) + topk[:, 1].numpy().astype(np.int64)
+    ref = g["img0_topk_cls"].astype(np.int64) * (1 << 20) + g["img0_topk_index"].astype(np.int64)
     agree = len(set(mine.tolist()) & set(ref.tolist())) / float(len(ref))
     same_order = bool(np.array_equal(mine, ref))
     # identical up to permutations among ranks whose REFERENCE scores are within 5e-6 of each other (the golden has one such pair, ranks

@@ -24,6 +24,7 @@ namespace mfx {
 
 struct HaloGeom {
     int B, H, W, C, lgCG, CG, ngroups;     // CG = channels per patch pass (power of two), ngroups = C / CG
+    int S, PW, PH, Ho, Wo;                 // stride (1 or 2); patch = PH x PW input pixels = (7 S + 3) x (15 S + 3); output map
     int tiles_x, tiles_y, tiles_n, K_pad;  // weight row length (elements); K index = tap*C + c
     int steps_per_group;                   // ceil(9*CG / (4*ELEMS)): 64-byte K steps per channel group
 };
@@ -35,10 +36,10 @@ template <typename T, int WN, int FN, int WK = 1> struct HaloSmem {
     static constexpr int stage_bytes = 16 * stage_ld * 4;                     // per wave
     static constexpr int reduce_bytes = WN * (WK - 1) * kHaloRows * FN * 64 * 16;          // split-K: partials of the rows a wave does not finish itself
     static __host__ __device__ constexpr int patch_stride(int CG) { return CG * (int)sizeof(T) + 16; }
-    static __host__ __device__ constexpr int patch_bytes(int CG) { return (kHaloRows + 2) * 18 * patch_stride(CG); }
+    static __host__ __device__ constexpr int patch_bytes(int CG, int S = 1) { return ((kHaloRows - 1) * S + 3) * (15 * S + 3) * patch_stride(CG); }
     // the K-split reduction reuses the patch memory once the K loop is over
-    static __host__ __device__ constexpr int main_bytes(int CG) { return patch_bytes(CG) > reduce_bytes ? patch_bytes(CG) : reduce_bytes; }
-    static __host__ __device__ constexpr int total(int CG) { return main_bytes(CG) + WN * WK * stage_bytes; }
+    static __host__ __device__ constexpr int main_bytes(int CG, int S = 1) { return patch_bytes(CG, S) > reduce_bytes ? patch_bytes(CG, S) : reduce_bytes; }
+    static __host__ __device__ constexpr int total(int CG, int S = 1) { return main_bytes(CG, S) + WN * WK * stage_bytes; }
 };
 
 // WK > 1: WK waves share each output slice and split the K steps among themselves (step s belongs to wave s % WK); their
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
 
     const int PS = SM::patch_stride(g.CG);
     char* patch = smem;
-    float* stage = reinterpret_cast<float*>(smem + SM::main_bytes(g.CG) + wave * SM::stage_bytes);
+    float* stage = reinterpret_cast<float*>(smem + SM::main_bytes(g.CG, g.S) + wave * SM::stage_bytes);
+    const int PW = g.PW, rowb = g.S * g.PW * PS;             // patch width (pixels); bytes between the patch rows of consecutive output rows
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
                     const int px = it / GPR_, ng = it - px * GPR_;
                     const int oy = y0 + i, ox = x0 + px, gn = n0 + ng * OE_;
                     u32x4 z = {0u, 0u, 0u, 0u};
-                    if (it < 16 * GPR_ && oy < g.H && ox < g.W && gn < ep.Cout)
-                        z = *reinterpret_cast<const u32x4*>(res_ + (((size_t)b * g.H + oy) * g.W + ox) * ep.ldres + gn);
+                    if (it < 16 * GPR_ && oy < g.Ho && ox < g.Wo && gn < ep.Cout)
+                        z = *reinterpret_cast<const u32x4*>(res_ + (((size_t)b * g.Ho + oy) * g.Wo + ox) * ep.ldres + gn);
                     rpre[i][q] = z;
                 }
         }
@@ -127,9 +129,9 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
 
     for (int grp = 0; grp < g.ngroups; ++grp) {
         if (grp > 0) __syncthreads();                         // every wave is done reading the previous patch
-        // ---- halo patch: 10 x 18 pixels x CG channels
+        // ---- halo patch: PH x PW input pixels (10 x 18 at stride 1, 17 x 33 at stride 2) x CG channels
         const T* xg = x + (size_t)b * g.H * g.W * g.C + grp * g.CG;
-        const int nchunks = (kHaloRows + 2) * 18 * CPP;
+        const int nchunks = g.PH * PW * CPP;
         // batches of PU independent loads per lane (all in flight together), then the LDS writes
         constexpr int PU = FN >= 4 ? 4 : 8;
         for (int base = 0; base < nchunks; base += NT * PU) {
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
             for (int u = 0; u < PU; ++u) {
                 const int idx = base + u * NT + tid;
                 const int pix = idx >> lgCPP, ch = idx & (CPP - 1);
-                const int py = pix / 18, px = pix - py * 18;
-                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                const int py = pix / PW, px = pix - py * PW;
+                const int iy = y0 * g.S - 1 + py, ix = x0 * g.S - 1 + px;
                 u32x4 z = {0u, 0u, 0u, 0u};
                 if (idx < nchunks && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
                     z = *reinterpret_cast<const u32x4*>(xg + ((size_t)iy * g.W + ix) * g.C + ch * ELEMS);
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
                 const int e = p * 32 + kq * 4;
                 const int tap = e >> g.lgCG, cl = e & (g.CG - 1);
                 const int th = (tap * 21846) >> 16, tw = tap - th * 3;
-                const char* ap = patch + (th * 18 + xl + tw) * PS + cl * 4;
+                const char* ap = patch + (th * PW + xl * g.S + tw) * PS + cl * 4;
                 auto rd = [&](const char* q) {
                     const uint2 a = *reinterpret_cast<const uint2*>(q), b = *reinterpret_cast<const uint2*>(q + 64);
                     return u32x4{a.x, a.y, b.x, b.y};
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int cur = i & 1;
-                    if (i + 1 < FM) { ph[cur ^ 1] = rd(ap + (i + 1) * 18 * PS); pl[cur ^ 1] = rd(ap + (i + 1) * 18 * PS + 8); }
+                    if (i + 1 < FM) { ph[cur ^ 1] = rd(ap + (i + 1) * rowb); pl[cur ^ 1] = rd(ap + (i + 1) * rowb + 8); }
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ph[cur]), __builtin_bit_cast(f16x8, h[j]), acc[i][j], 0, 0, 0);
@@ -254,10 +256,10 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
             const int cl = e & (g.CG - 1);
             tap = tap > 8 ? 8 : tap;                          // K padding: weights are zero there, keep the address valid
             const int th = (tap * 21846) >> 16, tw = tap - th * 3;
-            const char* ap = patch + (th * 18 + xl + tw) * PS + cl * (int)sizeof(T);
+            const char* ap = patch + (th * PW + xl * g.S + tw) * PS + cl * (int)sizeof(T);
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const u32x4 af = *reinterpret_cast<const u32x4*>(ap + i * 18 * PS);
+                const u32x4 af = *reinterpret_cast<const u32x4*>(ap + i * rowb);
 #pragma unroll
                 for (int j = 0; j < FN; ++j) mma_chunk<T>(af, bf[j], acc[i][j]);
             }
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
     for (int ii = 0; ii < RW; ++ii) {
         const int i = WK > 1 ? wk * RW + ii : ii;             // output row of accumulator slot ii
         // D layout: col n = lane&15, row (pixel x) = (lane>>4)*4 + r
-        const bool row_in = y0 + i < g.H;
+        const bool row_in = y0 + i < g.Ho;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             float v[4];
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
                     f32x2 vr = halo_round2<TO>(v[r], v[r + 1]);
-                    if (px + r + 1 >= g.W) { if (px + r >= g.W) vr[0] = 0.f; vr[1] = 0.f; }      // ragged right edge only
+                    if (px + r + 1 >= g.Wo) { if (px + r >= g.Wo) vr[0] = 0.f; vr[1] = 0.f; }      // ragged right edge only
                     st_s[j] += vr; st_q[j] += vr * vr;
                 }
             }
@@ -365,8 +367,8 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
             if (it >= 16 * GPR) continue;
             const int px = it / GPR, ng = it - px * GPR;
             const int ox = x0 + px, gn = n0 + ng * OE;
-            if (oy < g.H && ox < g.W && gn < ep.Cout) {
-                const size_t gm = ((size_t)b * g.H + oy) * g.W + ox;
+            if (oy < g.Ho && ox < g.Wo && gn < ep.Cout) {
+                const size_t gm = ((size_t)b * g.Ho + oy) * g.Wo + ox;
                 float v[OE];
 #pragma unroll
                 for (int e = 0; e < OE; e += 4) {
@@ -414,6 +416,7 @@ static inline int ilog2h(int v) { int l = 0; while ((1 << l) < v) ++l; return l;
 
 int g_opt_halo = 1;          // 0 = generic kernel only, 1 = automatic, >= 2 = force variant (value - 1)
 int g_opt_halo_cg = 0;       // max channels per patch pass (0 = default)
+int g_opt_halo_s2 = 1;       // option "halo_s2": 0 = stride-2 3x3 convs stay on the generic implicit-GEMM kernel
 int g_opt_halo_pair = 1;     // option "halo_pair": split precision walks K in step pairs where mfx_conv_desc.w_frag_pair is given (0 = two mma_chunk per pair)
 
 template <typename T, typename TO, int WN, int FN, int WK = 1, bool ST = false>
@@ -441,15 +444,18 @@ static int launch_halo_st(const mfx_conv_desc* d, hipStream_t st) {
     // 512-byte channel rows: 256 bf16 / 128 f32.  Split precision: 64 channels (a 49 KB patch instead of 95 KB: two workgroups per CU;
     // B = 8 step 6.58 -> 6.42 ms, `halo_cg` A/B on MI355X)
     int cg_max = g_opt_halo_cg > 0 ? g_opt_halo_cg : (std::is_same<T, f32s_t>::value ? 64 : 512 / (int)sizeof(T));
+    g.S = d->stride; g.PW = 15 * g.S + 3; g.PH = (kHaloRows - 1) * g.S + 3; g.Ho = d->Ho; g.Wo = d->Wo;
+    // stride 2: the 17 x 33 patch is 3.1x the stride-1 one -- 64-byte channel groups keep it at 45 KB (three workgroups per CU)
+    if (g.S == 2 && g_opt_halo_cg <= 0) cg_max = 64 / (int)sizeof(T);
     if (cg_max < 2 * ELEMS) cg_max = 2 * ELEMS;
     g.CG = d->Ck < cg_max ? d->Ck : cg_max; g.lgCG = ilog2h(g.CG); g.ngroups = d->Ck / g.CG;
-    g.tiles_x = cdivh(d->W, 16); g.tiles_y = cdivh(d->H, kHaloRows); g.tiles_n = d->Cout_pad / BN; g.K_pad = d->K_pad;
+    g.tiles_x = cdivh(d->Wo, 16); g.tiles_y = cdivh(d->Ho, kHaloRows); g.tiles_n = d->Cout_pad / BN; g.K_pad = d->K_pad;
     g.steps_per_group = cdivh(9 * g.CG, 4 * ELEMS);
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
     ep.stats = ST ? d->stats : nullptr; ep.stats_ncopy = d->stats_ncopy > 0 ? d->stats_ncopy : 1;
-    const int smem = SM::total(g.CG);
+    const int smem = SM::total(g.CG, g.S);
     const int tiles = g.tiles_n * g.tiles_x * g.tiles_y * d->B;
     if constexpr (std::is_same<T, f32s_t>::value && !ST) {
         if (g_opt_halo_pair && d->w_frag_pair && g.CG % 32 == 0) {       // split precision: the pair-walking K loop (3 products per pair)
@@ -519,12 +525,13 @@ int try_conv_halo(const mfx_conv_desc* d, hipStream_t st, int* stats_ran) {
 
 static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st) {
     if (g_opt_halo == 0) return 0;
-    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_h != 1 || d->pad_w != 1 || d->dil_w != 1) return 0;
-    if (d->rowmap || d->x_pixstride != d->Ck || d->Ho != d->H || d->Wo != d->W || d->M != d->B * d->H * d->W) return 0;
+    if (d->kh != 3 || d->kw != 3 || (d->stride != 1 && d->stride != 2) || d->pad_h != 1 || d->pad_w != 1 || d->dil_w != 1) return 0;
+    if (d->stride == 2 && !g_opt_halo_s2) return 0;
+    if (d->rowmap || d->x_pixstride != d->Ck || d->Ho != (d->H - 1) / d->stride + 1 || d->Wo != (d->W - 1) / d->stride + 1 || d->M != d->B * d->Ho * d->Wo) return 0;
     const int elems = (d->dtype == MFX_F32 || d->dtype == MFX_F16X2) ? 4 : 8;
     if (d->Ck < 2 * elems || d->K_pad < 9 * d->Ck) return 0;
     const int N = d->Cout_pad;
-    const int px_tiles = d->B * cdivh(d->H, kHaloRows) * cdivh(d->W, 16);
+    const int px_tiles = d->B * cdivh(d->Ho, kHaloRows) * cdivh(d->Wo, 16);
     // variant table from tools/conv_probe.py on MI355X (profiles/r01_*): two or four waves share a patch,
     // 32 output channels per wave; narrow outputs on small maps split N further to get more waves in flight
     // variant table from tools/conv_bench.py on MI355X, B = 8 (graph replay, us; profiles/r02_conv_variants.md):

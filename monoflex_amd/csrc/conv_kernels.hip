@@ -275,7 +275,7 @@ static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 int try_conv_halo(const mfx_conv_desc* d, hipStream_t st, int* stats_ran);   // conv_halo.hip
-extern int g_opt_halo, g_opt_halo_cg, g_opt_halo_pair, g_opt_dcn_wave, g_opt_dcn_patch, g_opt_dcn_patch_fn8, g_opt_dcn_wgrad_m;
+extern int g_opt_halo, g_opt_halo_cg, g_opt_halo_pair, g_opt_halo_s2, g_opt_dcn_wave, g_opt_dcn_patch, g_opt_dcn_patch_fn8, g_opt_dcn_wgrad_m;
 }
 extern long g_cnt_dcn_bt_fused, g_cnt_dcn_bt_fly;
 extern int g_opt_dcn_bt_fly;
@@ -417,6 +417,7 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "halo") g_opt_halo = value;
     else if (n == "halo_cg") g_opt_halo_cg = value;
     else if (n == "halo_pair") g_opt_halo_pair = value;
+    else if (n == "halo_s2") g_opt_halo_s2 = value;
     else if (n == "dcn_wave") g_opt_dcn_wave = value;
     else if (n == "dcn_patch") g_opt_dcn_patch = value;
     else if (n == "dcn_patch_fn8") g_opt_dcn_patch_fn8 = value;

@@ -227,7 +227,7 @@ def pack_conv(weight, dtype, scale=None, shift=None, stride=1, pad=0, act=L.ACT_
         if v.numel() < cp:
             v = torch.cat((v, v.new_full((cp - v.numel(),), fill)))
         return v.contiguous()
-    wf = fragment_major(w2, dtype) if (kh == 3 and kw == 3 and stride == 1 and pad == 1) else None
+    wf = fragment_major(w2, dtype) if (kh == 3 and kw == 3 and stride in (1, 2) and pad == 1) else None
     pk = PackedConv(w2, padv(scale, 1.0), padv(shift, 0.0), kh, kw, stride, pad, pad, 1, Cin, cout, cp, K_pad, act, wf, split=dtype == F16X2)
     if wf is not None and dtype == F16X2 and Cin >= 32:
         pk.w_frag_pair = pair_steps(wf, 1)

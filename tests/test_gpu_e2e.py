@@ -252,9 +252,11 @@ def _perf_mode_vs_reference(dtype, stage_bound, abssum_bound, dlogit_bound, dreg
     reg = hm[0][..., 8:58].permute(2, 0, 1).reshape(50, -1)[:, pix].numpy()
     dl = float(np.abs(logits - g["img0_cls_logits_at"]).max())
     dr = float(np.abs(reg - g["img0_reg_at"]).max() / max(1.0, np.abs(g["img0_reg_at"]).max()))
-    mine, ref = topk[0][:, 1].numpy().astype(np.int64), g["img0_topk_index"]
+    # a peak = (class, pixel): one pixel can rank for two classes, and their decoded rows differ (class-mean dimensions)
+    mine = topk[0][:, 2].numpy().astype(np.int64) * (1 << 20) + topk[0][:, 1].numpy().astype(np.int64)
+    ref = g["img0_topk_cls"].astype(np.int64) * (1 << 20) + g["img0_topk_index"].astype(np.int64)
     agree = len(set(mine.tolist()) & set(ref.tolist())) / 50.0
-    # decoded rows of the peaks both sides found (matched by heat-map index), relative to the row magnitudes
+    # decoded rows of the peaks both sides found (matched by class and heat-map index), relative to the row magnitudes
     ref_rows = {int(i): r for i, r in zip(ref[:len(g["img0_result"])], g["img0_result"])}
     rows = det[0][valid[0].bool()].numpy()
     deltas = [np.abs(r - ref_rows[int(i)]) / np.maximum(np.abs(ref_rows[int(i)]), 1.0) for i, r in zip(mine, rows) if int(i) in ref_rows]

@@ -40,10 +40,10 @@ for ev in prof.events():
         continue
     frame = "?"
     for fr in ev.stack:
-        if "monoflex_amd" in fr:
-            frame = fr.split("monoflex_amd/")[-1][:90]
+        if ("autograd.py" in fr or "trainer.py" in fr or "/model/" in fr or "ops.py" in fr or "loss" in fr) and "torch/" not in fr:
+            frame = fr.split("/")[-1][:60]
             break
-    k = (ev.name, frame + " " + str(ev.input_shapes)[:110])
+    k = (ev.name, frame + " " + str(ev.input_shapes)[:70])
     by[k][0] += t
     by[k][1] += 1
 tot = sum(v[0] for v in by.values())
