@@ -42,7 +42,7 @@ def test_ctypes_struct_layout_matches_header_sizes(tmp_path):
     sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True).stdout.split()]
     for (name, mirror), size in zip(pairs, sizes):
         assert ctypes.sizeof(mirror) == size, (name, ctypes.sizeof(mirror), size)
-    assert ctypes.sizeof(L.ConvDesc) == 8 * 8 + 22 * 4 + 16 + 8 + 8 + 8      # ... + statistics pointer, copies (+pad), done pointer
+    assert ctypes.sizeof(L.ConvDesc) == 8 * 8 + 22 * 4 + 16 + 8 + 8 + 8 + 8  # ... + statistics pointer, copies (+pad), done pointer, paired fragments (r04)
 
 
 def test_reference_yaml_drives_the_config():
