@@ -1,0 +1,223 @@
+"""Regression branches of the TRAINING step without their dense 256-channel maps (reference model/head/detector_predictor.py:125-169).
+
+A regression branch is  conv3x3(64 -> 256, no bias) -> ABN(batch statistics, leaky 0.01) -> 1x1 heads,  and the loss reads its output at the
+object centres only (layers/utils.py:120-145).  The dense map y = W * x is needed for exactly two things: the batch statistics of the ABN
+and -- in the backward pass -- the statistics' own gradient, which reaches every pixel.  Both are functions of the PATCH GRAM MATRIX of the
+shared input x (the backbone feature map):
+
+    x_p(px) in R^576      the 3x3 x 64-channel patch around pixel px (zero outside the image)
+    m = sum_px x_p(px),   G = sum_px x_p(px) x_p(px)^T                      (576, 576 x 576; ONE pair for all branches)
+    sum_px y   = W m,     sum_px y^2 = diag(W G W^T)                         -> mean, variance of every branch's 256 channels
+    y(r)       = W x_p(r)                                                    at the N object rows only
+
+so the forward pass needs no dense conv, and the backward pass -- d loss / d G -- is ONE 5x5 64 -> 64 convolution of x for all branches
+together instead of a dense BN pass, a 256 -> 64 data-gradient conv and a 64 -> 256 weight-gradient pass PER BRANCH (seven branches: about
+2.2 ms of the 21 ms step at B = 8).  The arithmetic is exact, not an approximation: BN's backward is  dy = (gamma/sigma) (dz - mean(dz) - xhat
+mean(dz xhat)),  dz is zero away from the objects, and the two mean terms are precisely the gradients that flow through `mean` and `var` here.
+
+How G is built.  With Omega+ = the image grown by one pixel,  sum_{px in Omega+} x_p(px) x_p(px)^T  depends on the tap displacement only:
+block (t1, t2) is the autocorrelation R[t2 - t1] = sum_q x[q] x[q + d]^T, 25 matrices of 64 x 64 = the weight gradient of a 5x5 convolution
+with x as input AND as output gradient (one launch of the library's weight-gradient kernel).  G = that minus the Gram matrix of the patches
+centred on the one-pixel FRAME around the image (B x 2 (H + W + 2) rows, a small GEMM) -- which is also the whole of the border handling.
+The small algebra (576-wide matrices, N <= a few hundred object rows) runs as torch ops on fp32 tensors inside the node and is differentiated
+by torch; the two dense pieces are library launches (mfx_conv_wgrad_oihw forward, a 5x5 mfx_conv2d_nhwc backward)."""
+import torch
+import torch.nn.functional as F_
+
+from . import autograd as AG
+from . import lib as L
+from . import ops
+
+_GEOM = {}
+
+
+def _geometry(B, H, W, device):
+    """Static index tables of one map shape: frame-pixel patches (gather indices + validity), their inverse for the gradient (per border pixel
+    the <= 5 (frame pixel, tap) entries that touch it, so the scatter is a gather with a fixed summation order), the tap-pair -> displacement
+    selection matrix."""
+    key = (B, H, W, str(device))
+    if key in _GEOM:
+        return _GEOM[key]
+    py = torch.cat((torch.full((W + 2,), -1), torch.full((W + 2,), H), torch.arange(H), torch.arange(H)))
+    px = torch.cat((torch.arange(-1, W + 1), torch.arange(-1, W + 1), torch.full((H,), -1), torch.full((H,), W)))
+    nf = py.numel()
+    ty = torch.tensor([-1, -1, -1, 0, 0, 0, 1, 1, 1])
+    tx = torch.tensor([-1, 0, 1, -1, 0, 1, -1, 0, 1])
+    qy, qx = py.view(nf, 1) + ty.view(1, 9), px.view(nf, 1) + tx.view(1, 9)
+    valid = (qy >= 0) & (qy < H) & (qx >= 0) & (qx < W)
+    flat = (qy.clamp(0, H - 1) * W + qx.clamp(0, W - 1))
+    b_off = (torch.arange(B) * H * W).view(B, 1, 1)
+    idx_f = (flat.view(1, nf, 9) + b_off).reshape(B * nf, 9)
+    val_f = valid.view(1, nf, 9).expand(B, nf, 9).reshape(B * nf, 9)
+    # inverse: border pixel q <- entries (frame row, tap) with frame + tap == q
+    entries = {}
+    for r in range(nf):
+        for t in range(9):
+            if bool(valid[r, t]):
+                entries.setdefault(int(flat[r, t]), []).append(r * 9 + t)
+    ring = sorted(entries)
+    width = max(len(v) for v in entries.values())
+    F_rows = B * nf
+    inv = torch.full((B, len(ring), width), F_rows * 9, dtype=torch.long)            # F_rows * 9 = the appended zero row
+    for j, q in enumerate(ring):
+        for k, e in enumerate(entries[q]):
+            inv[:, j, k] = e + torch.arange(B) * nf * 9
+    ring_idx = (torch.tensor(ring).view(1, -1) + (torch.arange(B) * H * W).view(B, 1)).reshape(-1)
+    sel = torch.zeros(81, 25)
+    for t1 in range(9):
+        for t2 in range(9):
+            dy, dx = int(ty[t2] - ty[t1]), int(tx[t2] - tx[t1])
+            sel[t1 * 9 + t2, (dy + 2) * 5 + dx + 2] = 1.0
+    g = dict(idx_f=idx_f.to(device), val_f=val_f.to(device), inv=inv.view(-1, width).to(device), ring_idx=ring_idx.to(device),
+             sel=sel.to(device), ty=ty.to(device), tx=tx.to(device), nf=nf)
+    _GEOM[key] = g
+    return g
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """Sum over the SyncBN group, differentiable (the gradient of a sum over ranks is the sum of the ranks' gradients)."""
+
+    @staticmethod
+    def forward(ctx, t, group):
+        import torch.distributed as dist
+        ctx.group = group
+        out = t.clone()
+        dist.all_reduce(out, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        g = g.clone()
+        dist.all_reduce(g, group=ctx.group)
+        return g, None
+
+
+def _autocorr5(x):
+    """R[a][b][kh][kw] = sum_q x[q][a] * x~[q + (kh - 2, kw - 2)][b]  (fp32; x~ = x with zeros outside the image): the weight gradient of a
+    5x5 / pad 2 convolution whose input and output gradient are both x."""
+    B, H, W, C = x.shape
+    dw = torch.empty(C, C, 5, 5, dtype=torch.float32, device=x.device)
+    ws = ops._splitk_workspace(x.device)
+    L.check(L.load().mfx_conv_wgrad_oihw(ops._ptr(x), ops._ptr(x), ops._ptr(dw), B, H, W, C, C, 5, 5, 1, 2, 2, H, W, C, C, C, C, ops._dt(x.dtype),
+                                         ops._ptr(ws), ws.numel() * 4, ops._stream()), "mfx_conv_wgrad_oihw")
+    return dw
+
+
+class GramRegHeadsFn(torch.autograd.Function):
+    """(x, rows, per-branch trunk weights / ABN gamma, beta / stacked 1x1 weights, biases) -> fp32 [N][ld_out] table of the branches' outputs at
+    the object rows (branch i at columns [offs[i], offs[i] + k_i)), as SparseRegHeadsFn returns it -- without the dense trunk maps."""
+
+    @staticmethod
+    def forward(ctx, x, rows, abns, offs, ld_out, sync, *ts):
+        nb = len(abns)
+        ws_, gammas, betas, w2s, b2s = (ts[i * nb:(i + 1) * nb] for i in range(5))
+        x = AG._c(x)
+        B, H, W, C = x.shape
+        M = B * H * W
+        dev = x.device
+        geo = _geometry(B, H, W, dev)
+        xf = x.view(M, C)
+        with torch.no_grad():
+            R5 = _autocorr5(x)
+            S0 = AG._colsum(x)
+            A_f = (xf[geo["idx_f"]] * geo["val_f"].unsqueeze(-1).to(x.dtype)).reshape(-1, 9 * C).float()
+            bidx = rows[:, 57].long().clamp(0, B - 1)
+            cx, cy = rows[:, 2].long().clamp(0, W - 1), rows[:, 3].long().clamp(0, H - 1)
+            qy, qx = cy.view(-1, 1) + geo["ty"].view(1, 9), cx.view(-1, 1) + geo["tx"].view(1, 9)
+            val_o = ((qy >= 0) & (qy < H) & (qx >= 0) & (qx < W))
+            idx_o = (bidx.view(-1, 1) * H + qy.clamp(0, H - 1)) * W + qx.clamp(0, W - 1)
+            A_o = (xf[idx_o] * val_o.unsqueeze(-1).to(x.dtype)).reshape(-1, 9 * C).float()
+        group = AG._sync_group(sync)
+        leaves = [t.detach().requires_grad_(True) for t in (R5, A_f, A_o, S0)]
+        params = [None if t is None else t.detach().requires_grad_(t.requires_grad) for t in ts]
+        pw, pg, pb, pw2, pb2 = (params[i * nb:(i + 1) * nb] for i in range(5))
+        with torch.enable_grad():
+            R5l, A_fl, A_ol, S0l = leaves
+            # weights as the matrix cores would see them in this compute mode (16-bit modes round them), K order = (tap, channel)
+            Wk = torch.cat([(w.to(x.dtype).float() if x.dtype != torch.float32 else w.float()).permute(0, 2, 3, 1).reshape(w.shape[0], 9 * C) for w in pw], 0)
+            Gp = (geo["sel"] @ R5l.permute(2, 3, 0, 1).reshape(25, C * C)).view(9, 9, C, C).permute(0, 2, 1, 3).reshape(9 * C, 9 * C)
+            G = Gp - A_fl.t() @ A_fl
+            m = S0l.repeat(9) - A_fl.sum(0)
+            sums = torch.cat((Wk @ m, ((Wk @ G) * Wk).sum(1)))
+            Mt = M
+            if group is not None:
+                import torch.distributed as dist
+                sums = _AllReduceSum.apply(sums, group)
+                Mt = M * dist.get_world_size(group)
+            nch = Wk.shape[0]
+            mean = sums[:nch] / Mt
+            var = (sums[nch:] / Mt - mean * mean).clamp_min(0.0)
+            eps = torch.cat([torch.full((w.shape[0],), float(a.eps), device=dev) for w, a in zip(pw, abns)])
+            rstd = torch.rsqrt(var + eps)
+            gam, bet = torch.cat([g.float() for g in pg]), torch.cat([b.float() for b in pb])
+            Y_o = A_ol @ Wk.t()
+            act = F_.leaky_relu((Y_o - mean) * (rstd * gam) + bet, 0.01)
+            pieces, col, c0 = [], 0, 0
+            for i in range(nb):
+                k, cw = pw2[i].shape[0], pw[i].shape[0]
+                o = act[:, c0:c0 + cw] @ pw2[i].float().reshape(k, cw).t()
+                if pb2[i] is not None:
+                    o = o + pb2[i].float()
+                if offs[i] > col:
+                    pieces.append(o.new_zeros(o.shape[0], offs[i] - col))
+                pieces.append(o)
+                col, c0 = offs[i] + k, c0 + cw
+            if col < ld_out:
+                pieces.append(act.new_zeros(act.shape[0], ld_out - col))
+            out = torch.cat(pieces, 1) * (rows[:, 0] > 0).to(act.dtype).view(-1, 1)          # empty slots of the object table read as zero rows
+        with torch.no_grad():                                         # running statistics: momentum update with the unbiased variance
+            unb = var * (float(Mt) / max(Mt - 1, 1))
+            c0 = 0
+            rms, rvs, means, vars_, nbts = [], [], [], [], []
+            for w, a in zip(pw, abns):
+                cw = w.shape[0]
+                if a.track_running_stats and a.running_mean is not None:
+                    rms.append(a.running_mean); rvs.append(a.running_var)
+                    means.append(mean[c0:c0 + cw].to(a.running_mean.dtype)); vars_.append(unb[c0:c0 + cw].to(a.running_var.dtype))
+                    if a.num_batches_tracked is not None:
+                        nbts.append(a.num_batches_tracked)
+                c0 += cw
+            if rms:
+                mom = abns[0].momentum if abns[0].momentum is not None else 0.1
+                torch._foreach_lerp_(rms, means, mom)
+                torch._foreach_lerp_(rvs, vars_, mom)
+                if nbts:
+                    torch._foreach_add_(nbts, 1)
+        ctx.graph = (out, leaves, params)
+        ctx.save_for_backward(x, idx_o, val_o)
+        ctx.nb = nb
+        return out.detach()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x, idx_o, val_o = ctx.saved_tensors
+        out, leaves, params = ctx.graph
+        ctx.graph = None
+        B, H, W, C = x.shape
+        M = B * H * W
+        geo = _geometry(B, H, W, x.device)
+        wanted = leaves + [p for p in params if p is not None and p.requires_grad]
+        grads = torch.autograd.grad(out, wanted, dout.float(), allow_unused=True)
+        dR5, dA_f, dA_o, dS0 = grads[:4]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dense part: R[a][b][d] appears with x[q][a] x[q+d][b] -> dx[q][a] = sum_{d,b} (dR[a][b][d] + dR[b][a][-d]) x[q+d][b]: a 5x5 conv of x;
+            # the gradient of S0 = sum_q x[q] is the same vector at every pixel: the conv's per-channel shift
+            Kx = dR5 + dR5.permute(1, 0, 2, 3).flip(2, 3)
+            p = ops.pack_conv(Kx, x.dtype, None, dS0, stride=1, pad=2)
+            dx = ops.conv2d(x, p)
+            dxf = dx.view(M, C)
+            ext = torch.cat((dA_f.reshape(-1, C), dA_f.new_zeros(1, C)), 0)
+            dxf.index_add_(0, geo["ring_idx"], ext[geo["inv"]].sum(1).to(dx.dtype))          # border pixels: unique indices, fixed order
+            dAo = (dA_o.view(-1, 9, C) * val_o.unsqueeze(-1)).to(dx.dtype)
+            for t in range(9):                                       # one tap at a time: distinct objects -> distinct pixels per call
+                dxf.index_add_(0, idx_o[:, t], dAo[:, t])
+        it = iter(grads[4:])
+        pg = [next(it) if (p is not None and p.requires_grad) else None for p in params]
+        return (dx, None, None, None, None, None, *pg)
+
+
+def gram_reg_heads(x, rows, abns, offs, ld_out, trunk_ws, gammas, betas, w2s, b2s, sync=True):
+    return GramRegHeadsFn.apply(x, rows, tuple(abns), tuple(offs), ld_out, sync, *trunk_ws, *gammas, *betas, *w2s, *b2s)

@@ -22,6 +22,11 @@ HM_LD = 64          # fp32 head map row: [0:3] class logits, [8:58] regression c
 REG_OFF = 8
 
 
+# training: the sparse regression branches through the patch Gram matrix (gram_heads.py) instead of seven dense trunk maps; MFX_GRAM_HEADS=0 or
+# GRAM_HEADS[0] = False brings the dense trunks back (tests compare the two)
+GRAM_HEADS = [__import__("os").environ.get("MFX_GRAM_HEADS", "1") != "0"]
+
+
 class InPlaceABN(nn.Module):
     """Parameter holder for the head's fused BN + leaky_relu(0.01): the parameter / buffer names of a BatchNorm2d
     (weight, bias, running_mean, running_var, num_batches_tracked -- the stand-in the golden fixtures were recorded
@@ -227,7 +232,11 @@ class _predictor(nn.Module):
         oi = self.offset_index[0]
         sparse = object_rows is not None
         feats, outs, sp = [], [], []
-        ys = AG.fanout_conv(features, [t[0].weight for t in trunks], 1)         # nine trunk convs, one summed gradient for `features`
+        # the sparse regression branches need no dense trunk map at all when their statistics come from the input's patch Gram matrix
+        # (monoflex_amd/gram_heads.py); the class head (dense focal loss) and the 3d_offset head (edge fusion) keep theirs
+        gram = sparse and GRAM_HEADS[0]
+        dense_ids = [bi for bi in range(len(trunks)) if not (gram and bi != 0 and bi - 1 != oi)]
+        ys = dict(zip(dense_ids, AG.fanout_conv(features, [trunks[bi][0].weight for bi in dense_ids], 1)))   # one summed gradient for `features`
         fuse_nodes = self.enable_edge_fusion and self.fused_edge_nodes
         edge_rows = {}
         if self.enable_edge_fusion:
@@ -241,9 +250,9 @@ class _predictor(nn.Module):
         for bi, (t, heads) in enumerate(zip(trunks, lasts)):
             w = heads[0].weight if len(heads) == 1 else torch.cat([h.weight for h in heads], 0)
             b = heads[0].bias if len(heads) == 1 else torch.cat([h.bias for h in heads], 0)
-            y, done = ys[bi], False
+            y, done = ys.get(bi), False
             if sparse and bi != 0 and bi - 1 != oi:
-                sp.append((bi - 1, y, t[1], w, b, done))
+                sp.append((bi - 1, y, t[1], w, b, done, t[0].weight))
                 feats.append(None); outs.append(None)
                 continue
             f = AG.bn_act(y, t[1], L.ACT_LEAKY, stats_done=done)
@@ -293,9 +302,15 @@ class _predictor(nn.Module):
         # gathered regression table in the reference's channel order
         starts = [sum(sum(c) for c in self.regression_channel_cfg[:i]) for i in range(len(self.regression_channel_cfg))]
         rows = object_rows
-        tab = AG.SparseRegHeadsFn.apply(rows, tuple(e[2] for e in sp), tuple(starts[e[0]] for e in sp), 50, tuple(e[5] for e in sp),
-                                        *[e[1] for e in sp], *[e[2].weight for e in sp], *[e[2].bias for e in sp],
-                                        *[e[3] for e in sp], *[e[4] for e in sp])
+        if gram:
+            from monoflex_amd.gram_heads import gram_reg_heads
+            tab = gram_reg_heads(features, rows, [e[2] for e in sp], [starts[e[0]] for e in sp], 50, [e[6] for e in sp],
+                                 [e[2].weight for e in sp], [e[2].bias for e in sp], [e[3] for e in sp], [e[4] for e in sp],
+                                 sync=any(bool(getattr(e[2], "sync_bn", False)) for e in sp))
+        else:
+            tab = AG.SparseRegHeadsFn.apply(rows, tuple(e[2] for e in sp), tuple(starts[e[0]] for e in sp), 50, tuple(e[5] for e in sp),
+                                            *[e[1] for e in sp], *[e[2].weight for e in sp], *[e[2].bias for e in sp],
+                                            *[e[3] for e in sp], *[e[4] for e in sp])
         bidx, cx, cy = rows[:, 57].long().clamp(0, B - 1), rows[:, 2].long().clamp(0, W - 1), rows[:, 3].long().clamp(0, H - 1)
         lo, n_off = starts[oi], sum(self.regression_channel_cfg[oi])
         # the dense 3d_offset head at the centres (index_select: its gradient is one index_add_, no sort as behind advanced indexing)

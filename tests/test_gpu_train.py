@@ -288,6 +288,81 @@ def test_sparse_regression_heads_function_vs_torch(dt):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+def test_gram_regression_heads_vs_torch(dt):
+    """GramRegHeadsFn (monoflex_amd/gram_heads.py): conv3x3(64 -> 256) -> train-mode BN -> leaky(0.01) -> 1x1 heads at the object centres, with the
+    BN statistics and their gradients taken from the input's patch Gram matrix instead of dense trunk maps -- against torch running the dense
+    layers on the same (rounded) inputs: output rows, running statistics and EVERY gradient (feature map, trunk weights, ABN weight / bias, 1x1
+    weights / biases).  Objects on the image border and corners, two objects on one pixel, neighbouring objects, empty slots."""
+    from monoflex_amd.gram_heads import gram_reg_heads
+    from monoflex_amd.model.head.detector_predictor import InPlaceABN
+    dtype = DT[dt]
+    g = torch.Generator().manual_seed(29)
+    B, H, W, Cin, C, N = 2, 12, 20, 64, 256, 20
+    ks, offs = (4, 20, 3), (0, 6, 26)
+    rows = torch.zeros(N, 72)
+    rows[:, 0] = (torch.rand(N, generator=g) > 0.2).float()
+    rows[:, 57] = torch.randint(0, B, (N,), generator=g).float()
+    rows[:, 2] = torch.randint(0, W, (N,), generator=g).float()
+    rows[:, 3] = torch.randint(0, H, (N,), generator=g).float()
+    rows[0, 2:4] = torch.tensor([0.0, 0.0]); rows[1, 2:4] = torch.tensor([W - 1.0, H - 1.0]); rows[2, 2:4] = torch.tensor([0.0, 5.0])
+    rows[3] = rows[5]; rows[6] = rows[5]; rows[6, 2] = rows[5, 2] + (1.0 if rows[5, 2] < W - 1 else -1.0)       # same pixel; a neighbour
+    rows[[0, 1, 2, 3, 5, 6], 0] = 1.0
+    dout = torch.randn(N, 50, generator=g)
+    x = (torch.randn(B, H, W, Cin, generator=g) * 0.8 + 0.1).to(dtype)
+    wt = [torch.randn(C, Cin, 3, 3, generator=g) / 24.0 for _ in ks]
+    abns_r, w2s, b2s = [], [], []
+    for k in ks:
+        m = torch.nn.BatchNorm2d(C)
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(C, generator=g) + 0.5); m.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        abns_r.append(m)
+        w2s.append(torch.randn(k, C, 1, 1, generator=g) * 0.1)
+        b2s.append(torch.randn(k, generator=g) * 0.1)
+    rnd = (lambda t: t.to(dtype).float()) if dt != "fp32" else (lambda t: t)
+    # torch reference: the dense layers in fp64 on the inputs the device path sees
+    xr = x.double().permute(0, 3, 1, 2).clone().requires_grad_()
+    ref_wt = [rnd(w).double().clone().requires_grad_() for w in wt]
+    ref_w = [w.double().clone().requires_grad_() for w in w2s]
+    ref_b = [b.double().clone().requires_grad_() for b in b2s]
+    bi, cy, cx, valid = rows[:, 57].long(), rows[:, 3].long(), rows[:, 2].long(), rows[:, 0].double()
+    tot, outs_ref = 0, []
+    for i, k in enumerate(ks):
+        bn = abns_r[i].double()
+        a = F.leaky_relu(bn(F.conv2d(xr, ref_wt[i], None, 1, 1)), 0.01)
+        o = F.conv2d(a, ref_w[i], ref_b[i]).permute(0, 2, 3, 1)[bi, cy, cx] * valid[:, None]
+        outs_ref.append(o)
+        tot = tot + (o * dout[:, offs[i]:offs[i] + k].double()).sum()
+    tot.backward()
+    # device
+    abns_d = []
+    for m in abns_r:
+        h = InPlaceABN(C)
+        h.load_state_dict({k_: v for k_, v in torch.nn.BatchNorm2d(C).state_dict().items()})
+        with torch.no_grad():
+            h.weight.copy_(m.weight.float()); h.bias.copy_(m.bias.float())
+        abns_d.append(h.to(DEV))
+    xd = x.to(DEV).requires_grad_()
+    wtd = [w.to(DEV).requires_grad_() for w in wt]
+    wd = [w.to(DEV).requires_grad_() for w in w2s]
+    bd = [b.to(DEV).requires_grad_() for b in b2s]
+    out = gram_reg_heads(xd, rows.to(DEV), abns_d, offs, 50, wtd, [h.weight for h in abns_d], [h.bias for h in abns_d], wd, bd, sync=False)
+    (out * dout.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    tol = 2e-2 if dt != "fp32" else 2e-3
+    dx_ref = xr.grad.permute(0, 2, 3, 1).float()
+    assert _rel(xd.grad.float().cpu(), dx_ref) < tol, ("dx", _rel(xd.grad.float().cpu(), dx_ref))
+    for i, k in enumerate(ks):
+        assert _rel(out[:, offs[i]:offs[i] + k].cpu(), outs_ref[i].detach().float()) < tol, ("out", i)
+        assert _rel(wtd[i].grad.cpu(), ref_wt[i].grad.float()) < tol, ("dW", i, _rel(wtd[i].grad.cpu(), ref_wt[i].grad.float()))
+        assert _rel(abns_d[i].weight.grad.cpu(), abns_r[i].weight.grad.float()) < tol and _rel(abns_d[i].bias.grad.cpu(), abns_r[i].bias.grad.float()) < tol, i
+        assert _rel(wd[i].grad.cpu(), ref_w[i].grad.float()) < tol and _rel(bd[i].grad.cpu(), ref_b[i].grad.float()) < tol, i
+        assert _rel(abns_d[i].running_var.cpu(), abns_r[i].running_var.float()) < 1e-3 and _rel(abns_d[i].running_mean.cpu(), abns_r[i].running_mean.float()) < 1e-3
+        assert int(abns_d[i].num_batches_tracked) == 1
+    unused = [c for c in range(50) if not any(o <= c < o + k for o, k in zip(offs, ks))]
+    assert float(out[:, unused].abs().max()) == 0.0 and float(out[rows[:, 0] == 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("cin,cout,H,W,k,stride", [(64, 64, 24, 40, 3, 1), (64, 256, 40, 72, 3, 1), (256, 64, 13, 37, 3, 1), (128, 128, 9, 20, 3, 1),
                                                    (16, 16, 32, 64, 3, 1), (32, 32, 31, 45, 3, 1), (512, 512, 6, 10, 3, 1), (64, 128, 24, 40, 3, 2),
                                                    (64, 128, 24, 40, 1, 1)])
