@@ -29,6 +29,15 @@ from . import lib as L
 from . import ops
 
 _GEOM = {}
+_TAP = None        # probe hook (tools/probes/gram_graph_probe3.py): dict name -> persistent buffer
+
+
+def _tap(name, t):
+    if _TAP is not None:
+        t = t.detach()
+        if name not in _TAP:
+            _TAP[name] = torch.empty_like(t)
+        torch.add(t, 0.0, out=_TAP[name])
 
 
 def _geometry(B, H, W, device):
@@ -68,10 +77,37 @@ def _geometry(B, H, W, device):
         for t2 in range(9):
             dy, dx = int(ty[t2] - ty[t1]), int(tx[t2] - tx[t1])
             sel[t1 * 9 + t2, (dy + 2) * 5 + dx + 2] = 1.0
+    vy = ((torch.arange(H).view(H, 1) + ty.view(1, 9)) >= 0) & ((torch.arange(H).view(H, 1) + ty.view(1, 9)) < H)       # [H][9]: tap row inside?
+    vx = ((torch.arange(W).view(W, 1) + tx.view(1, 9)) >= 0) & ((torch.arange(W).view(W, 1) + tx.view(1, 9)) < W)
     g = dict(idx_f=idx_f.to(device), val_f=val_f.to(device), inv=inv.view(-1, width).to(device), ring_idx=ring_idx.to(device),
-             sel=sel.to(device), ty=ty.to(device), tx=tx.to(device), nf=nf)
+             sel=sel.to(device), ty=ty.to(device), tx=tx.to(device), nf=nf, vy=vy.to(device), vx=vx.to(device),
+             tap_off=(ty * W + tx).to(device), ones_f=torch.ones(1, B * nf, device=device), lin=torch.tensor([float(H * W), float(W), 1.0], device=device),
+             hi=torch.tensor([B - 1.0, H - 1.0, W - 1.0], device=device), cols=torch.tensor([57, 3, 2], device=device))
     _GEOM[key] = g
     return g
+
+
+_STATIC = {}
+
+
+def _static(abns, cws, ks, offs, ld_out, has_b, device):
+    """Per head configuration: the ABNs' eps as one vector; where each branch's 1x1 weights / biases sit in the [ld_out x channels] matrix."""
+    key = (tuple(id(a) for a in abns), tuple(cws), tuple(ks), tuple(offs), ld_out, tuple(has_b), str(device))
+    if key in _STATIC:
+        return _STATIC[key]
+    nch = sum(cws)
+    eps = torch.cat([torch.full((cw,), float(a.eps)) for cw, a in zip(cws, abns)]).to(device)
+    pos, bpos, c0 = [], [], 0
+    for cw, k, off, hb in zip(cws, ks, offs, has_b):
+        r = torch.arange(k).view(k, 1) + off
+        c = torch.arange(cw).view(1, cw) + c0
+        pos.append((r * nch + c).reshape(-1))
+        if hb:
+            bpos.append(torch.arange(k) + off)
+        c0 += cw
+    st = dict(eps=eps, w2_pos=torch.cat(pos).to(device), b2_pos=torch.cat(bpos).to(device) if bpos else None)
+    _STATIC[key] = st
+    return st
 
 
 class _AllReduceSum(torch.autograd.Function):
@@ -81,14 +117,14 @@ class _AllReduceSum(torch.autograd.Function):
     def forward(ctx, t, group):
         import torch.distributed as dist
         ctx.group = group
-        out = t.clone()
+        out = t + 0.0                                         # (a kernel, not a device-to-device copy node: see GramRegHeadsFn)
         dist.all_reduce(out, group=group)
         return out
 
     @staticmethod
     def backward(ctx, g):
         import torch.distributed as dist
-        g = g.clone()
+        g = g + 0.0
         dist.all_reduce(g, group=ctx.group)
         return g, None
 
@@ -122,12 +158,14 @@ class GramRegHeadsFn(torch.autograd.Function):
             R5 = _autocorr5(x)
             S0 = AG._colsum(x)
             A_f = (xf[geo["idx_f"]] * geo["val_f"].unsqueeze(-1).to(x.dtype)).reshape(-1, 9 * C).float()
-            bidx = rows[:, 57].long().clamp(0, B - 1)
-            cx, cy = rows[:, 2].long().clamp(0, W - 1), rows[:, 3].long().clamp(0, H - 1)
-            qy, qx = cy.view(-1, 1) + geo["ty"].view(1, 9), cx.view(-1, 1) + geo["tx"].view(1, 9)
-            val_o = ((qy >= 0) & (qy < H) & (qx >= 0) & (qx < W))
-            idx_o = (bidx.view(-1, 1) * H + qy.clamp(0, H - 1)) * W + qx.clamp(0, W - 1)
+            # object rows -> (image, cy, cx) clamped, flat pixel, per-tap validity from the static row / column tables
+            byx = torch.minimum(rows.index_select(1, geo["cols"]).clamp_min(0.0), geo["hi"])
+            pix = (byx @ geo["lin"]).long()
+            yx = byx.long()
+            val_o = geo["vy"][yx[:, 1]] & geo["vx"][yx[:, 2]]
+            idx_o = (pix.view(-1, 1) + geo["tap_off"].view(1, 9)).clamp(0, M - 1)
             A_o = (xf[idx_o] * val_o.unsqueeze(-1).to(x.dtype)).reshape(-1, 9 * C).float()
+        _tap("R5", R5); _tap("S0", S0); _tap("A_f", A_f); _tap("A_o", A_o)
         group = AG._sync_group(sync)
         leaves = [t.detach().requires_grad_(True) for t in (R5, A_f, A_o, S0)]
         params = [None if t is None else t.detach().requires_grad_(t.requires_grad) for t in ts]
@@ -135,11 +173,18 @@ class GramRegHeadsFn(torch.autograd.Function):
         with torch.enable_grad():
             R5l, A_fl, A_ol, S0l = leaves
             # weights as the matrix cores would see them in this compute mode (16-bit modes round them), K order = (tap, channel)
-            Wk = torch.cat([(w.to(x.dtype).float() if x.dtype != torch.float32 else w.float()).permute(0, 2, 3, 1).reshape(w.shape[0], 9 * C) for w in pw], 0)
+            Wc = torch.cat([w.float() for w in pw], 0)
+            if x.dtype != torch.float32:
+                Wc = Wc.to(x.dtype).float()
+            Wk = Wc.permute(0, 2, 3, 1).reshape(Wc.shape[0], 9 * C)
             Gp = (geo["sel"] @ R5l.permute(2, 3, 0, 1).reshape(25, C * C)).view(9, 9, C, C).permute(0, 2, 1, 3).reshape(9 * C, 9 * C)
             G = Gp - A_fl.t() @ A_fl
-            m = S0l.repeat(9) - A_fl.sum(0)
+            # (column sums as a GEMV, not A_fl.sum(0): torch's multi-block reductions zero their semaphores with a memset, and memset nodes are
+            # not reliably ordered against kernel nodes when a hipGraph is replayed on this platform -- csrc/fill.h; measured: the sum came out
+            # wrong from the second replay on)
+            m = S0l.repeat(9) - (geo["ones_f"] @ A_fl).view(-1)
             sums = torch.cat((Wk @ m, ((Wk @ G) * Wk).sum(1)))
+            _tap("Wk", Wk); _tap("Gp", Gp); _tap("G", G); _tap("m", m); _tap("sums", sums)
             Mt = M
             if group is not None:
                 import torch.distributed as dist
@@ -148,24 +193,22 @@ class GramRegHeadsFn(torch.autograd.Function):
             nch = Wk.shape[0]
             mean = sums[:nch] / Mt
             var = (sums[nch:] / Mt - mean * mean).clamp_min(0.0)
-            eps = torch.cat([torch.full((w.shape[0],), float(a.eps), device=dev) for w, a in zip(pw, abns)])
-            rstd = torch.rsqrt(var + eps)
+            st = _static(abns, [w.shape[0] for w in pw], [w.shape[0] for w in pw2], offs, ld_out, [b is not None for b in pb2], dev)
+            rstd = torch.rsqrt(var + st["eps"])
             gam, bet = torch.cat([g.float() for g in pg]), torch.cat([b.float() for b in pb])
             Y_o = A_ol @ Wk.t()
             act = F_.leaky_relu((Y_o - mean) * (rstd * gam) + bet, 0.01)
-            pieces, col, c0 = [], 0, 0
-            for i in range(nb):
-                k, cw = pw2[i].shape[0], pw[i].shape[0]
-                o = act[:, c0:c0 + cw] @ pw2[i].float().reshape(k, cw).t()
-                if pb2[i] is not None:
-                    o = o + pb2[i].float()
-                if offs[i] > col:
-                    pieces.append(o.new_zeros(o.shape[0], offs[i] - col))
-                pieces.append(o)
-                col, c0 = offs[i] + k, c0 + cw
-            if col < ld_out:
-                pieces.append(act.new_zeros(act.shape[0], ld_out - col))
-            out = torch.cat(pieces, 1) * (rows[:, 0] > 0).to(act.dtype).view(-1, 1)          # empty slots of the object table read as zero rows
+            # all 1x1 heads as ONE [ld_out x channels] matrix: the branches' weights scattered to their (row block, column block) positions
+            w2flat = torch.cat([w.float().reshape(-1) for w in pw2])
+            # (torch.full, not torch.zeros: a zero fill of a fresh tensor is a memset node inside a hipGraph capture, and those are not
+            # reliably ordered against kernel nodes on replay here -- csrc/fill.h)
+            W2 = torch.full((ld_out * nch,), 0.0, dtype=torch.float32, device=dev).scatter_(0, st["w2_pos"], w2flat).view(ld_out, nch)
+            out = act @ W2.t()
+            if st["b2_pos"] is not None:
+                b2flat = torch.cat([b.float() for b in pb2 if b is not None])
+                out = out + torch.full((ld_out,), 0.0, dtype=torch.float32, device=dev).scatter_(0, st["b2_pos"], b2flat)
+            _tap("Y_o", Y_o); _tap("act", act); _tap("W2", W2); _tap("out_pre", out)
+            out = out * (rows[:, 0] > 0).to(act.dtype).view(-1, 1)          # empty slots of the object table read as zero rows
         with torch.no_grad():                                         # running statistics: momentum update with the unbiased variance
             unb = var * (float(Mt) / max(Mt - 1, 1))
             c0 = 0
@@ -209,11 +252,14 @@ class GramRegHeadsFn(torch.autograd.Function):
             p = ops.pack_conv(Kx, x.dtype, None, dS0, stride=1, pad=2)
             dx = ops.conv2d(x, p)
             dxf = dx.view(M, C)
-            ext = torch.cat((dA_f.reshape(-1, C), dA_f.new_zeros(1, C)), 0)
+            ext = torch.cat((dA_f.reshape(-1, C), dA_f.new_full((1, C), 0.0)), 0)
             dxf.index_add_(0, geo["ring_idx"], ext[geo["inv"]].sum(1).to(dx.dtype))          # border pixels: unique indices, fixed order
             dAo = (dA_o.view(-1, 9, C) * val_o.unsqueeze(-1)).to(dx.dtype)
-            for t in range(9):                                       # one tap at a time: distinct objects -> distinct pixels per call
-                dxf.index_add_(0, idx_o[:, t], dAo[:, t])
+            if torch.are_deterministic_algorithms_enabled():        # lib.set_deterministic(True)
+                for t in range(9):                                   # one tap at a time: distinct objects -> distinct pixels per call, fixed order
+                    dxf.index_add_(0, idx_o[:, t], dAo[:, t])
+            else:
+                dxf.index_add_(0, idx_o.reshape(-1), dAo.reshape(-1, C))
         it = iter(grads[4:])
         pg = [next(it) if (p is not None and p.requires_grad) else None for p in params]
         return (dx, None, None, None, None, None, *pg)

@@ -389,7 +389,7 @@ def test_conv_epilogue_accumulates_the_bn_statistics(cin, cout, H, W, k, stride,
         try:
             xd, wd = x.clone().requires_grad_(), w.clone().requires_grad_()
             y, done = AG.conv2d_bn_stats(xd, wd, None, stride, k // 2, bn)
-            assert done == ((not off) and k == 3 and stride == 1), done
+            assert done == ((not off) and k == 3), done               # (the LDS-halo kernel takes stride 2 since r04)
             z = AG.bn_act(y, bn, L.ACT_RELU, stats_done=done)
             z.float().square().sum().backward()
             out.append((z.detach().float(), xd.grad.float(), wd.grad, bn.weight.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()))
