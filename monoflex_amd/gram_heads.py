@@ -249,7 +249,10 @@ class GramRegHeadsFn(torch.autograd.Function):
             # dense part: R[a][b][d] appears with x[q][a] x[q+d][b] -> dx[q][a] = sum_{d,b} (dR[a][b][d] + dR[b][a][-d]) x[q+d][b]: a 5x5 conv of x;
             # the gradient of S0 = sum_q x[q] is the same vector at every pixel: the conv's per-channel shift
             Kx = dR5 + dR5.permute(1, 0, 2, 3).flip(2, 3)
-            p = ops.pack_conv(Kx, x.dtype, None, dS0, stride=1, pad=2)
+            # these are gradients of SUMS over every pixel: ~1e-9 .. 1e-6, below fp16's normal range.  The conv runs on Kx / max |Kx| and its
+            # epilogue multiplies the maximum back in (device scalars, no host sync; row maxima first: single-block reductions, see above)
+            amax = Kx.abs().reshape(C, -1).amax(1).amax().clamp_min(1e-30)
+            p = ops.pack_conv(Kx / amax, x.dtype, amax.expand(C), dS0, stride=1, pad=2)
             dx = ops.conv2d(x, p)
             dxf = dx.view(M, C)
             ext = torch.cat((dA_f.reshape(-1, C), dA_f.new_full((1, C), 0.0)), 0)
