@@ -145,7 +145,7 @@ class GramRegHeadsFn(torch.autograd.Function):
     the object rows (branch i at columns [offs[i], offs[i] + k_i)), as SparseRegHeadsFn returns it -- without the dense trunk maps."""
 
     @staticmethod
-    def forward(ctx, x, rows, abns, offs, ld_out, sync, *ts):
+    def forward(ctx, x, rows, abns, offs, ld_out, sync, extra_branch, extra_rows, *ts):
         nb = len(abns)
         ws_, gammas, betas, w2s, b2s = (ts[i * nb:(i + 1) * nb] for i in range(5))
         x = AG._c(x)
@@ -165,13 +165,18 @@ class GramRegHeadsFn(torch.autograd.Function):
             val_o = geo["vy"][yx[:, 1]] & geo["vx"][yx[:, 2]]
             idx_o = (pix.view(-1, 1) + geo["tap_off"].view(1, 9)).clamp(0, M - 1)
             A_o = (xf[idx_o] * val_o.unsqueeze(-1).to(x.dtype)).reshape(-1, 9 * C).float()
+            if extra_rows is not None:                               # a second row set (flat pixel indices): branch `extra_branch`'s ACTIVATION there
+                ey, ex = (extra_rows // W) % H, extra_rows % W
+                val_e = geo["vy"][ey] & geo["vx"][ex]
+                idx_e = (extra_rows.view(-1, 1) + geo["tap_off"].view(1, 9)).clamp(0, M - 1)
+                A_e = (xf[idx_e] * val_e.unsqueeze(-1).to(x.dtype)).reshape(-1, 9 * C).float()
         _tap("R5", R5); _tap("S0", S0); _tap("A_f", A_f); _tap("A_o", A_o)
         group = AG._sync_group(sync)
-        leaves = [t.detach().requires_grad_(True) for t in (R5, A_f, A_o, S0)]
+        leaves = [t.detach().requires_grad_(True) for t in ((R5, A_f, A_o, S0) + ((A_e,) if extra_rows is not None else ()))]
         params = [None if t is None else t.detach().requires_grad_(t.requires_grad) for t in ts]
         pw, pg, pb, pw2, pb2 = (params[i * nb:(i + 1) * nb] for i in range(5))
         with torch.enable_grad():
-            R5l, A_fl, A_ol, S0l = leaves
+            R5l, A_fl, A_ol, S0l = leaves[:4]
             # weights as the matrix cores would see them in this compute mode (16-bit modes round them), K order = (tap, channel)
             Wc = torch.cat([w.float() for w in pw], 0)
             if x.dtype != torch.float32:
@@ -209,6 +214,11 @@ class GramRegHeadsFn(torch.autograd.Function):
                 out = out + torch.full((ld_out,), 0.0, dtype=torch.float32, device=dev).scatter_(0, st["b2_pos"], b2flat)
             _tap("Y_o", Y_o); _tap("act", act); _tap("W2", W2); _tap("out_pre", out)
             out = out * (rows[:, 0] > 0).to(act.dtype).view(-1, 1)          # empty slots of the object table read as zero rows
+            act_e = None
+            if extra_rows is not None:
+                c0 = sum(w.shape[0] for w in pw[:extra_branch]); c1 = c0 + pw[extra_branch].shape[0]
+                Y_e = leaves[4] @ Wk[c0:c1].t()
+                act_e = F_.leaky_relu((Y_e - mean[c0:c1]) * (rstd[c0:c1] * gam[c0:c1]) + bet[c0:c1], 0.01)
         with torch.no_grad():                                         # running statistics: momentum update with the unbiased variance
             unb = var * (float(Mt) / max(Mt - 1, 1))
             c0 = 0
@@ -227,23 +237,31 @@ class GramRegHeadsFn(torch.autograd.Function):
                 torch._foreach_lerp_(rvs, vars_, mom)
                 if nbts:
                     torch._foreach_add_(nbts, 1)
-        ctx.graph = (out, leaves, params)
+        ctx.graph = (out, act_e, leaves, params)
+        if extra_rows is not None:
+            ctx.save_for_backward(x, idx_o, val_o, idx_e, val_e)
+            return out.detach(), act_e.detach().to(x.dtype)
         ctx.save_for_backward(x, idx_o, val_o)
-        ctx.nb = nb
-        return out.detach()
+        return out.detach(), None
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dout):
-        x, idx_o, val_o = ctx.saved_tensors
-        out, leaves, params = ctx.graph
+    def backward(ctx, dout, dact_e):
+        x, idx_o, val_o = ctx.saved_tensors[:3]
+        out, act_e, leaves, params = ctx.graph
         ctx.graph = None
         B, H, W, C = x.shape
         M = B * H * W
         geo = _geometry(B, H, W, x.device)
         wanted = leaves + [p for p in params if p is not None and p.requires_grad]
-        grads = torch.autograd.grad(out, wanted, dout.float(), allow_unused=True)
+        if act_e is not None:
+            if dact_e is None:
+                dact_e = torch.full_like(act_e, 0.0)
+            grads = torch.autograd.grad([out, act_e], wanted, [dout.float(), dact_e.float()], allow_unused=True)
+        else:
+            grads = torch.autograd.grad(out, wanted, dout.float(), allow_unused=True)
         dR5, dA_f, dA_o, dS0 = grads[:4]
+        nl = len(leaves)
         dx = None
         if ctx.needs_input_grad[0]:
             # dense part: R[a][b][d] appears with x[q][a] x[q+d][b] -> dx[q][a] = sum_{d,b} (dR[a][b][d] + dR[b][a][-d]) x[q+d][b]: a 5x5 conv of x;
@@ -263,10 +281,14 @@ class GramRegHeadsFn(torch.autograd.Function):
                     dxf.index_add_(0, idx_o[:, t], dAo[:, t])
             else:
                 dxf.index_add_(0, idx_o.reshape(-1), dAo.reshape(-1, C))
-        it = iter(grads[4:])
+            if act_e is not None and grads[4] is not None:
+                idx_e, val_e = ctx.saved_tensors[3:5]
+                dxf.index_add_(0, idx_e.reshape(-1), (grads[4].view(-1, 9, C) * val_e.unsqueeze(-1)).to(dx.dtype).reshape(-1, C))
+        it = iter(grads[nl:])
         pg = [next(it) if (p is not None and p.requires_grad) else None for p in params]
-        return (dx, None, None, None, None, None, *pg)
+        return (dx, None, None, None, None, None, None, None, *pg)
 
 
-def gram_reg_heads(x, rows, abns, offs, ld_out, trunk_ws, gammas, betas, w2s, b2s, sync=True):
-    return GramRegHeadsFn.apply(x, rows, tuple(abns), tuple(offs), ld_out, sync, *trunk_ws, *gammas, *betas, *w2s, *b2s)
+def gram_reg_heads(x, rows, abns, offs, ld_out, trunk_ws, gammas, betas, w2s, b2s, sync=True, extra_branch=-1, extra_rows=None):
+    """-> (table [N][ld_out], activation rows of branch `extra_branch` at the flat pixel indices `extra_rows` in x's dtype, or None)."""
+    return GramRegHeadsFn.apply(x, rows, tuple(abns), tuple(offs), ld_out, sync, extra_branch, extra_rows, *trunk_ws, *gammas, *betas, *w2s, *b2s)

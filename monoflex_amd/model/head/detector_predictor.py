@@ -25,6 +25,7 @@ REG_OFF = 8
 # training: the sparse regression branches through the patch Gram matrix (gram_heads.py) instead of seven dense trunk maps; MFX_GRAM_HEADS=0 or
 # GRAM_HEADS[0] = False brings the dense trunks back (tests compare the two)
 GRAM_HEADS = [__import__("os").environ.get("MFX_GRAM_HEADS", "1") != "0"]
+GRAM_OFFSET = [__import__("os").environ.get("MFX_GRAM_OFFSET", "1") != "0"]       # the 3d_offset branch in that sparse set too (its edge fusion reads gathered rows)
 
 
 class InPlaceABN(nn.Module):
@@ -235,9 +236,13 @@ class _predictor(nn.Module):
         # the sparse regression branches need no dense trunk map at all when their statistics come from the input's patch Gram matrix
         # (monoflex_amd/gram_heads.py); the class head (dense focal loss) and the 3d_offset head (edge fusion) keep theirs
         gram = sparse and GRAM_HEADS[0]
-        dense_ids = [bi for bi in range(len(trunks)) if not (gram and bi != 0 and bi - 1 != oi)]
-        ys = dict(zip(dense_ids, AG.fanout_conv(features, [trunks[bi][0].weight for bi in dense_ids], 1)))   # one summed gradient for `features`
         fuse_nodes = self.enable_edge_fusion and self.fused_edge_nodes
+        # ... and the 3d_offset branch joins them where the edge fusion reads its trunk through the gathered-rows node: the fusion needs the
+        # trunk ACTIVATION at the <= L + 2 edge-sequence pixels of every image, the loss needs the head at the object centres -- both sparse
+        gram_off = gram and GRAM_OFFSET[0] and (fuse_nodes or not self.enable_edge_fusion)
+        is_sparse = lambda bi: sparse and bi != 0 and (bi - 1 != oi or gram_off)                      # noqa: E731
+        dense_ids = [bi for bi in range(len(trunks)) if not (gram and is_sparse(bi))]
+        ys = dict(zip(dense_ids, AG.fanout_conv(features, [trunks[bi][0].weight for bi in dense_ids], 1)))   # one summed gradient for `features`
         edge_rows = {}
         if self.enable_edge_fusion:
             if edge_indices is None:
@@ -251,7 +256,7 @@ class _predictor(nn.Module):
             w = heads[0].weight if len(heads) == 1 else torch.cat([h.weight for h in heads], 0)
             b = heads[0].bias if len(heads) == 1 else torch.cat([h.bias for h in heads], 0)
             y, done = ys.get(bi), False
-            if sparse and bi != 0 and bi - 1 != oi:
+            if is_sparse(bi):
                 sp.append((bi - 1, y, t[1], w, b, done, t[0].weight))
                 feats.append(None); outs.append(None)
                 continue
@@ -273,6 +278,11 @@ class _predictor(nn.Module):
                 xy = edge_indices[:, pos].long()
                 bidx = torch.arange(B, device=features.device).view(B, 1).expand(B, Lmax + 2)
             new = []
+            gram_tab = None
+            if gram_off:
+                # the sparse set as ONE node: the (N, 50) table of all eight regression branches at the object centres + the 3d_offset trunk's
+                # activation at the edge-sequence pixels (its edge-fusion input)
+                gram_tab, edge_rows[1 + oi] = self._gram_table(features, object_rows, sp, rowmap if fuse_nodes else None, oi)
             for bi_f, f, seq, base in ((0, feats[0], self.trunc_heatmap_conv, cls), (1 + oi, feats[1 + oi], self.trunc_offset_conv, regs[oi])):
                 if fuse_nodes:
                     e = edge_rows[bi_f].view(B, 1, Lmax + 2, self.head_conv)
@@ -284,6 +294,10 @@ class _predictor(nn.Module):
                 o = AG.conv2d(h1, c3.weight.unsqueeze(2), c3.bias, 1, 0, out_dtype=torch.float32).view(B, Lmax, -1)
                 lo = 0 if base is cls else sum(self.regression_channel_cfg[oi][:oj])
                 co = o.shape[-1]
+                if fuse_nodes and base is None:                 # (3d_offset in the sparse set: its fused edge rows are merged into the table below)
+                    o_off, lo_off = o, sum(sum(c) for c in self.regression_channel_cfg[:oi]) + lo
+                    new.append(None)
+                    continue
                 if fuse_nodes:
                     new.append(AG.EdgeScatterAddFn.apply(base, o, edge_indices, edge_lens, lo, rows_center, valid_l))
                     continue
@@ -302,11 +316,29 @@ class _predictor(nn.Module):
         # gathered regression table in the reference's channel order
         starts = [sum(sum(c) for c in self.regression_channel_cfg[:i]) for i in range(len(self.regression_channel_cfg))]
         rows = object_rows
+        if gram_off:
+            if gram_tab is None:                                 # (no edge fusion: the table alone)
+                gram_tab, _ = self._gram_table(features, rows, sp, None, oi)
+            elif fuse_nodes:
+                # an object centre that is a border pixel receives that pixel's fused edge output (valid border pixels are unique per image):
+                # slot map pixel -> edge position, -1 elsewhere; invalid positions write to a dummy slot
+                Lmax = edge_indices.shape[1]
+                npx = B * H * W
+                ok = valid_l.view(-1) > 0
+                slot = torch.full((npx + 1,), -1, dtype=torch.long, device=features.device)
+                slot.scatter_(0, torch.where(ok, rows_center, torch.full_like(rows_center, npx)), torch.arange(B * Lmax, device=features.device))
+                bidx, cx, cy = rows[:, 57].long().clamp(0, B - 1), rows[:, 2].long().clamp(0, W - 1), rows[:, 3].long().clamp(0, H - 1)
+                e_idx = slot[(bidx * H + cy) * W + cx]
+                hit = (e_idx >= 0) & (rows[:, 0] > 0)
+                co = o_off.shape[-1]
+                add = o_off.reshape(B * Lmax, co).float()[e_idx.clamp_min(0)] * hit.unsqueeze(1).to(torch.float32)
+                gram_tab = torch.cat((gram_tab[:, :lo_off], gram_tab[:, lo_off:lo_off + co] + add, gram_tab[:, lo_off + co:]), dim=1)
+            return cls, gram_tab
         if gram:
             from monoflex_amd.gram_heads import gram_reg_heads
-            tab = gram_reg_heads(features, rows, [e[2] for e in sp], [starts[e[0]] for e in sp], 50, [e[6] for e in sp],
-                                 [e[2].weight for e in sp], [e[2].bias for e in sp], [e[3] for e in sp], [e[4] for e in sp],
-                                 sync=any(bool(getattr(e[2], "sync_bn", False)) for e in sp))
+            tab, _ = gram_reg_heads(features, rows, [e[2] for e in sp], [starts[e[0]] for e in sp], 50, [e[6] for e in sp],
+                                    [e[2].weight for e in sp], [e[2].bias for e in sp], [e[3] for e in sp], [e[4] for e in sp],
+                                    sync=any(bool(getattr(e[2], "sync_bn", False)) for e in sp))
         else:
             tab = AG.SparseRegHeadsFn.apply(rows, tuple(e[2] for e in sp), tuple(starts[e[0]] for e in sp), 50, tuple(e[5] for e in sp),
                                             *[e[1] for e in sp], *[e[2].weight for e in sp], *[e[2].bias for e in sp],
@@ -316,6 +348,16 @@ class _predictor(nn.Module):
         # the dense 3d_offset head at the centres (index_select: its gradient is one index_add_, no sort as behind advanced indexing)
         off_rows = regs[oi].reshape(-1, regs[oi].shape[-1]).index_select(0, (bidx * H + cy) * W + cx)[:, :n_off]
         return cls, torch.cat((tab[:, :lo], off_rows, tab[:, lo + n_off:]), dim=1)
+
+    def _gram_table(self, features, rows, sp, edge_rowmap, oi):
+        """All sparse branches in `sp` through monoflex_amd/gram_heads.py: (table (N, 50), the 3d_offset trunk's activation rows at `edge_rowmap`)."""
+        from monoflex_amd.gram_heads import gram_reg_heads
+        starts = [sum(sum(c) for c in self.regression_channel_cfg[:i]) for i in range(len(self.regression_channel_cfg))]
+        jb = [k for k, e in enumerate(sp) if e[0] == oi]
+        return gram_reg_heads(features, rows, [e[2] for e in sp], [starts[e[0]] for e in sp], 50, [e[6] for e in sp],
+                              [e[2].weight for e in sp], [e[2].bias for e in sp], [e[3] for e in sp], [e[4] for e in sp],
+                              sync=any(bool(getattr(e[2], "sync_bn", False)) for e in sp),
+                              extra_branch=jb[0] if (edge_rowmap is not None and jb) else -1, extra_rows=edge_rowmap if jb else None)
 
     def forward(self, features, targets, object_rows=None):
         """Reference surface: features (B,64,H,W) (any strides) + targets -> {'cls','reg'} NCHW views.  Training with

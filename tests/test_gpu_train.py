@@ -345,7 +345,7 @@ def test_gram_regression_heads_vs_torch(dt):
     wtd = [w.to(DEV).requires_grad_() for w in wt]
     wd = [w.to(DEV).requires_grad_() for w in w2s]
     bd = [b.to(DEV).requires_grad_() for b in b2s]
-    out = gram_reg_heads(xd, rows.to(DEV), abns_d, offs, 50, wtd, [h.weight for h in abns_d], [h.bias for h in abns_d], wd, bd, sync=False)
+    out, _ = gram_reg_heads(xd, rows.to(DEV), abns_d, offs, 50, wtd, [h.weight for h in abns_d], [h.bias for h in abns_d], wd, bd, sync=False)
     (out * dout.to(DEV)).sum().backward()
     torch.cuda.synchronize()
     tol = 2e-2 if dt != "fp32" else 2e-3

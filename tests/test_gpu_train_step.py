@@ -137,6 +137,41 @@ def test_ddp_gradients_equal_the_unwrapped_models_bitwise(nccl_world1, determini
     assert not diff, diff[:8]
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-3), ("bf16", 8e-2)])
+def test_gram_heads_step_equals_the_dense_heads_step(dtype, tol, deterministic):
+    """The whole model, one forward + loss + backward, with the sparse regression branches through the feature map's patch Gram matrix
+    (monoflex_amd/gram_heads.py: all eight regression branches incl. 3d_offset, whose edge fusion reads the trunk at the edge pixels) and with
+    the dense trunks (GRAM_HEADS off: dense convs + SparseRegHeadsFn + the dense 3d_offset head): the same eleven losses and the same gradient
+    for EVERY parameter (fp32: to rounding; bf16: the dense path rounds the trunk maps to bf16, the Gram path does not).  Fixed-order
+    reductions on both sides (without them two runs of the SAME path differ by per cents in the DCN offset weights: float atomics)."""
+    from monoflex_amd.model.head import detector_predictor as DP
+    res = []
+    for on in (True, False):
+        DP.GRAM_HEADS[0] = on
+        try:
+            m = _model(dtype)
+            imgs, tg = _batch(m, B=3)
+            ld, _ = m(imgs, tg)
+            sum(ld.values()).backward()
+            torch.cuda.synchronize()
+            res.append(({k: float(v) for k, v in ld.items()}, {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None},
+                        {k: v.detach().float().clone() for k, v in m.state_dict().items() if "running" in k}))
+        finally:
+            DP.GRAM_HEADS[0] = True
+    (la, ga, ra), (lb, gb, rb) = res
+    assert set(ga) == set(gb) and len(ga) > 250
+    for k in la:
+        assert abs(la[k] - lb[k]) <= tol * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    # norm-relative per parameter, with a floor of 1e-5 (bf16: 2e-3) of the largest gradient norm: a conv / DCN bias in front of a train-mode BN has an exactly
+    # zero gradient, what is computed for it is rounding noise
+    gmax = max(float(v.norm()) for v in gb.values())
+    floor = (1e-5 if dtype == "fp32" else 2e-3) * gmax
+    worst = max((float((ga[n] - gb[n]).norm()) / max(float(gb[n].norm()), floor), n) for n in gb)
+    assert worst[0] < (10 * tol if dtype == "fp32" else 0.35), worst                    # (bf16: two roundings of a 256-channel map apart)
+    rw = max(float((ra[k] - rb[k]).abs().max() / rb[k].abs().max().clamp(min=1e-6)) for k in rb)
+    assert rw < (1e-3 if dtype == "fp32" else 3e-2), rw
+
+
 @pytest.mark.parametrize("dtype,split", [("fp32", False), ("fp16", True)])
 def test_capture_warmup_does_not_advance_the_training_state(dtype, split, nccl_world1):
     """the eager steps GraphedTrainStep runs before capturing are rolled back -- parameters, BN running statistics and

@@ -27,7 +27,7 @@ for dt in (torch.float32,):
     def run():
         for t in leaves:
             t.grad = None
-        out = gram_reg_heads(x, rows, abns, offs, 50, wt, [a.weight for a in abns], [a.bias for a in abns], w2, b2, sync=False)
+        out, _ = gram_reg_heads(x, rows, abns, offs, 50, wt, [a.weight for a in abns], [a.bias for a in abns], w2, b2, sync=False)
         (out * dout).sum().backward()
         return out, [t.grad for t in leaves]
     s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
