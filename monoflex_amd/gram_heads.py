@@ -29,15 +29,6 @@ from . import lib as L
 from . import ops
 
 _GEOM = {}
-_TAP = None        # probe hook (tools/probes/gram_graph_probe3.py): dict name -> persistent buffer
-
-
-def _tap(name, t):
-    if _TAP is not None:
-        t = t.detach()
-        if name not in _TAP:
-            _TAP[name] = torch.empty_like(t)
-        torch.add(t, 0.0, out=_TAP[name])
 
 
 def _geometry(B, H, W, device):
@@ -129,6 +120,22 @@ class _AllReduceSum(torch.autograd.Function):
         return g, None
 
 
+class _RowAffine(torch.autograd.Function):
+    """z[r][c] = y[r][c] * s[c] + t[c].  Written out because autograd's gradient of the two broadcasts is a column sum over ALL rows (thousands,
+    with the edge rows), i.e. one of torch's multi-block reductions -- see the note at `m` in GramRegHeadsFn.forward; here both are GEMVs."""
+
+    @staticmethod
+    def forward(ctx, y, s, t):
+        ctx.save_for_backward(y, s)
+        return y * s + t
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, s = ctx.saved_tensors
+        ones = torch.full((1, y.shape[0]), 1.0, dtype=dz.dtype, device=dz.device)
+        return dz * s, (ones @ (dz * y)).view(-1), (ones @ dz).view(-1)
+
+
 def _autocorr5(x):
     """R[a][b][kh][kw] = sum_q x[q][a] * x~[q + (kh - 2, kw - 2)][b]  (fp32; x~ = x with zeros outside the image): the weight gradient of a
     5x5 / pad 2 convolution whose input and output gradient are both x."""
@@ -170,7 +177,6 @@ class GramRegHeadsFn(torch.autograd.Function):
                 val_e = geo["vy"][ey] & geo["vx"][ex]
                 idx_e = (extra_rows.view(-1, 1) + geo["tap_off"].view(1, 9)).clamp(0, M - 1)
                 A_e = (xf[idx_e] * val_e.unsqueeze(-1).to(x.dtype)).reshape(-1, 9 * C).float()
-        _tap("R5", R5); _tap("S0", S0); _tap("A_f", A_f); _tap("A_o", A_o)
         group = AG._sync_group(sync)
         leaves = [t.detach().requires_grad_(True) for t in ((R5, A_f, A_o, S0) + ((A_e,) if extra_rows is not None else ()))]
         params = [None if t is None else t.detach().requires_grad_(t.requires_grad) for t in ts]
@@ -189,7 +195,6 @@ class GramRegHeadsFn(torch.autograd.Function):
             # wrong from the second replay on)
             m = S0l.repeat(9) - (geo["ones_f"] @ A_fl).view(-1)
             sums = torch.cat((Wk @ m, ((Wk @ G) * Wk).sum(1)))
-            _tap("Wk", Wk); _tap("Gp", Gp); _tap("G", G); _tap("m", m); _tap("sums", sums)
             Mt = M
             if group is not None:
                 import torch.distributed as dist
@@ -202,7 +207,9 @@ class GramRegHeadsFn(torch.autograd.Function):
             rstd = torch.rsqrt(var + st["eps"])
             gam, bet = torch.cat([g.float() for g in pg]), torch.cat([b.float() for b in pb])
             Y_o = A_ol @ Wk.t()
-            act = F_.leaky_relu((Y_o - mean) * (rstd * gam) + bet, 0.01)
+            sc = rstd * gam                                          # BN as one per-channel affine map
+            sh = bet - mean * sc
+            act = F_.leaky_relu(_RowAffine.apply(Y_o, sc, sh), 0.01)
             # all 1x1 heads as ONE [ld_out x channels] matrix: the branches' weights scattered to their (row block, column block) positions
             w2flat = torch.cat([w.float().reshape(-1) for w in pw2])
             # (torch.full, not torch.zeros: a zero fill of a fresh tensor is a memset node inside a hipGraph capture, and those are not
@@ -212,13 +219,12 @@ class GramRegHeadsFn(torch.autograd.Function):
             if st["b2_pos"] is not None:
                 b2flat = torch.cat([b.float() for b in pb2 if b is not None])
                 out = out + torch.full((ld_out,), 0.0, dtype=torch.float32, device=dev).scatter_(0, st["b2_pos"], b2flat)
-            _tap("Y_o", Y_o); _tap("act", act); _tap("W2", W2); _tap("out_pre", out)
             out = out * (rows[:, 0] > 0).to(act.dtype).view(-1, 1)          # empty slots of the object table read as zero rows
             act_e = None
             if extra_rows is not None:
                 c0 = sum(w.shape[0] for w in pw[:extra_branch]); c1 = c0 + pw[extra_branch].shape[0]
                 Y_e = leaves[4] @ Wk[c0:c1].t()
-                act_e = F_.leaky_relu((Y_e - mean[c0:c1]) * (rstd[c0:c1] * gam[c0:c1]) + bet[c0:c1], 0.01)
+                act_e = F_.leaky_relu(_RowAffine.apply(Y_e, sc[c0:c1], sh[c0:c1]), 0.01)
         with torch.no_grad():                                         # running statistics: momentum update with the unbiased variance
             unb = var * (float(Mt) / max(Mt - 1, 1))
             c0 = 0
