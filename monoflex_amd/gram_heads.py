@@ -83,7 +83,7 @@ _STATIC = {}
 
 def _static(abns, cws, ks, offs, ld_out, has_b, device):
     """Per head configuration: the ABNs' eps as one vector; where each branch's 1x1 weights / biases sit in the [ld_out x channels] matrix."""
-    key = (tuple(id(a) for a in abns), tuple(cws), tuple(ks), tuple(offs), ld_out, tuple(has_b), str(device))
+    key = (tuple(float(a.eps) for a in abns), tuple(cws), tuple(ks), tuple(offs), ld_out, tuple(has_b), str(device))
     if key in _STATIC:
         return _STATIC[key]
     nch = sum(cws)
@@ -266,7 +266,7 @@ class GramRegHeadsFn(torch.autograd.Function):
             grads = torch.autograd.grad([out, act_e], wanted, [dout.float(), dact_e.float()], allow_unused=True)
         else:
             grads = torch.autograd.grad(out, wanted, dout.float(), allow_unused=True)
-        dR5, dA_f, dA_o, dS0 = grads[:4]
+        dR5, dA_f, dA_o, dS0 = (g if g is not None else torch.full_like(t, 0.0) for g, t in zip(grads[:4], leaves[:4]))   # (None: unused leaf)
         nl = len(leaves)
         dx = None
         if ctx.needs_input_grad[0]:
