@@ -353,3 +353,41 @@ def test_bench_respawns_itself_under_torchrun_for_n_ranks(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--mode", "train"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _gram_sync_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from monoflex_amd.gram_heads import _AllReduceSum
+    torch.manual_seed(7)
+    x = torch.randn(4, 6, 5, 3, dtype=torch.float64)                     # the GLOBAL batch; rank r owns images 2r, 2r+1
+    w = torch.randn(8, 3, 3, 3, dtype=torch.float64)
+    y_loc = torch.nn.functional.conv2d(x[2 * rank:2 * rank + 2].permute(0, 3, 1, 2), w, None, 1, 1)
+    sums_loc = torch.cat((y_loc.sum((0, 2, 3)), (y_loc * y_loc).sum((0, 2, 3)))).requires_grad_()
+    sums = _AllReduceSum.apply(sums_loc, dist.group.WORLD)
+    coef = torch.arange(1, 17, dtype=torch.float64) * (rank + 1)            # every rank's loss weighs the global sums its own way
+    (sums * coef).sum().backward()
+    out.put((rank, sums.detach().numpy().tolist(), sums_loc.grad.numpy().tolist()))
+    dist.destroy_process_group()
+
+
+def test_gram_heads_statistics_all_reduce_is_differentiable_over_two_ranks():
+    """monoflex_amd/gram_heads._AllReduceSum (the SyncBN form of the Gram-matrix heads' [sum y, sum y^2]): forward = the global-batch sums on every
+    rank, backward = the SUM of the ranks' upstream gradients (each rank's loss depends on every rank's local sums)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gram_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    torch.manual_seed(7)
+    x = torch.randn(4, 6, 5, 3, dtype=torch.float64)
+    w = torch.randn(8, 3, 3, 3, dtype=torch.float64)
+    y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, None, 1, 1)
+    want = torch.cat((y.sum((0, 2, 3)), (y * y).sum((0, 2, 3))))
+    gwant = torch.arange(1, 17, dtype=torch.float64) * 3.0                  # coef of rank 0 + coef of rank 1
+    for _, sums, grad in res:
+        assert torch.allclose(torch.tensor(sums, dtype=torch.float64), want, atol=1e-9)
+        assert torch.allclose(torch.tensor(grad, dtype=torch.float64), gwant, atol=1e-12)
