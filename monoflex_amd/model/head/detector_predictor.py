@@ -323,13 +323,7 @@ class _predictor(nn.Module):
                 # an object centre that is a border pixel receives that pixel's fused edge output (valid border pixels are unique per image):
                 # slot map pixel -> edge position, -1 elsewhere; invalid positions write to a dummy slot
                 Lmax = edge_indices.shape[1]
-                npx = B * H * W
-                ok = valid_l.view(-1) > 0
-                slot = torch.full((npx + 1,), -1, dtype=torch.long, device=features.device)
-                slot.scatter_(0, torch.where(ok, rows_center, torch.full_like(rows_center, npx)), torch.arange(B * Lmax, device=features.device))
-                bidx, cx, cy = rows[:, 57].long().clamp(0, B - 1), rows[:, 2].long().clamp(0, W - 1), rows[:, 3].long().clamp(0, H - 1)
-                e_idx = slot[(bidx * H + cy) * W + cx]
-                hit = (e_idx >= 0) & (rows[:, 0] > 0)
+                e_idx, hit = edge_position_of_rows(rows, rows_center, valid_l, B, H, W)
                 co = o_off.shape[-1]
                 add = o_off.reshape(B * Lmax, co).float()[e_idx.clamp_min(0)] * hit.unsqueeze(1).to(torch.float32)
                 gram_tab = torch.cat((gram_tab[:, :lo_off], gram_tab[:, lo_off:lo_off + co] + add, gram_tab[:, lo_off + co:]), dim=1)
@@ -378,6 +372,20 @@ class _predictor(nn.Module):
         hm = self.forward_nhwc(x, ei, el)
         cls = torch.sigmoid(hm[..., :self.num_classes]).clamp(min=1e-4, max=1 - 1e-4).permute(0, 3, 1, 2)
         return {'cls': cls, 'reg': hm[..., REG_OFF:REG_OFF + 50].permute(0, 3, 1, 2), 'hm_nhwc': hm, 'cls_planar': self.last_cls_planar}
+
+
+def edge_position_of_rows(rows, rows_center, valid_l, B, H, W):
+    """For every row of the object table (fp32 [N, 72]: column 0 valid flag, 57 image, 2 / 3 centre x / y): the flat edge-sequence position
+    b * L + l whose border pixel IS the object's centre pixel, and whether there is one.  `rows_center` = flat pixel of every (b, l),
+    `valid_l` = (l < edge_len[b]); the valid border pixels of an image are unique, invalid positions are written to a dummy slot.
+    Static shapes, no host sync (used inside the captured training step)."""
+    npx = B * H * W
+    ok = valid_l.reshape(-1) > 0
+    slot = torch.full((npx + 1,), -1, dtype=torch.long, device=rows.device)
+    slot.scatter_(0, torch.where(ok, rows_center, torch.full_like(rows_center, npx)), torch.arange(rows_center.numel(), device=rows.device))
+    bidx, cx, cy = rows[:, 57].long().clamp(0, B - 1), rows[:, 2].long().clamp(0, W - 1), rows[:, 3].long().clamp(0, H - 1)
+    e_idx = slot[(bidx * H + cy) * W + cx]
+    return e_idx, (e_idx >= 0) & (rows[:, 0] > 0)
 
 
 def make_edge_rowmap(edge_indices, H, W):

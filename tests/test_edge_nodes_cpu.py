@@ -136,3 +136,38 @@ def test_padded_bias_registry_follows_the_parameter():
     del b, p1
     gc.collect()
     assert len(reg.entries) == n0
+
+
+def test_edge_position_of_rows_matches_a_python_loop():
+    """detector_predictor.edge_position_of_rows (the 3d_offset branch in the sparse set: an object whose centre is a border pixel receives that
+    pixel's fused edge output): against a loop over objects and edge positions; padding positions beyond edge_len never match."""
+    import torch
+    from monoflex_amd.model.head.detector_predictor import edge_position_of_rows, make_edge_rowmap
+    g = torch.Generator().manual_seed(9)
+    B, H, W, Lmax, N = 3, 8, 12, 2 * (8 + 12), 14
+    edge_indices = torch.zeros(B, Lmax, 2, dtype=torch.int32)
+    edge_lens = torch.tensor([2 * (H + W) - 4, 17, 0], dtype=torch.int32)
+    border = [(x, 0) for x in range(W)] + [(W - 1, y) for y in range(1, H)] + [(x, H - 1) for x in range(W - 2, -1, -1)] + [(0, y) for y in range(H - 2, 0, -1)]
+    for b in range(B):
+        for l in range(int(edge_lens[b])):
+            edge_indices[b, l, 0], edge_indices[b, l, 1] = border[l]
+    rm = make_edge_rowmap(edge_indices, H, W).long()
+    rows_center = rm.view(B, Lmax + 2)[:, 1:-1].reshape(-1)
+    valid_l = (torch.arange(Lmax).view(1, Lmax) < edge_lens.view(B, 1)).float().unsqueeze(-1)
+    rows = torch.zeros(N, 72)
+    rows[:, 0] = (torch.rand(N, generator=g) > 0.2).float()
+    rows[:, 57] = torch.randint(0, B, (N,), generator=g).float()
+    rows[:, 2] = torch.randint(0, W, (N,), generator=g).float()
+    rows[:, 3] = torch.randint(0, H, (N,), generator=g).float()
+    rows[0, :4] = torch.tensor([1.0, 0.0, 0.0, 0.0]); rows[0, 57] = 0                       # corner pixel (0, 0) of image 0: edge position 0
+    rows[1, 0], rows[1, 57], rows[1, 2], rows[1, 3] = 1.0, 1.0, float(W - 1), float(H - 1)  # border pixel of image 1 beyond its edge_len
+    rows[2, 0], rows[2, 57], rows[2, 2], rows[2, 3] = 1.0, 2.0, 0.0, 0.0                    # image 2 has no edge points: padding must not match
+    e_idx, hit = edge_position_of_rows(rows, rows_center, valid_l, B, H, W)
+    for r in range(N):
+        b, x, y = int(rows[r, 57]), int(rows[r, 2]), int(rows[r, 3])
+        want = [b * Lmax + l for l in range(int(edge_lens[b])) if (int(edge_indices[b, l, 0]), int(edge_indices[b, l, 1])) == (x, y)]
+        if want and rows[r, 0] > 0:
+            assert bool(hit[r]) and int(e_idx[r]) == want[0], r
+        else:
+            assert not bool(hit[r]), r
+    assert bool(hit[0]) and int(e_idx[0]) == 0 and not bool(hit[2])
