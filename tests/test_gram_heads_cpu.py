@@ -73,3 +73,79 @@ def test_autocorrelation_gradient_is_the_symmetrised_5x5_kernel():
     K = dR + dR.permute(1, 0, 2, 3).flip(2, 3)
     dx = F.conv2d(x.detach().permute(0, 3, 1, 2), K, None, 1, 2).permute(0, 2, 3, 1)
     assert torch.allclose(dx, x.grad, atol=1e-10)
+
+
+def test_gram_reg_heads_node_end_to_end_on_cpu(monkeypatch):
+    """The WHOLE GramRegHeadsFn (forward table, extra activation rows, running statistics, every gradient) on the CPU against the dense layers in
+    fp64 torch, with the node's three library launches swapped for torch equivalents (the 5x5 autocorrelation, the column sums, the 5x5
+    gradient conv): the node's algebra and index plumbing are checked by the CPU suite, the launches themselves by the -m gpu tests."""
+    from types import SimpleNamespace
+    from monoflex_amd.model.head.detector_predictor import InPlaceABN
+    monkeypatch.setattr(GH, "_autocorr5", lambda x: _autocorr5(x.double()).float())
+    monkeypatch.setattr(GH.AG, "_colsum", lambda t: t.reshape(-1, t.shape[-1]).double().sum(0).float())
+    monkeypatch.setattr(GH.AG, "_c", lambda t: t.contiguous())
+    monkeypatch.setattr(GH.ops, "pack_conv", lambda w, dt, scale, shift, stride, pad: SimpleNamespace(w=w, scale=scale, shift=shift, pad=pad))
+
+    def conv2d(x, p):
+        y = F.conv2d(x.permute(0, 3, 1, 2).double(), p.w.double(), None, 1, p.pad) * p.scale.double().view(1, -1, 1, 1) + p.shift.double().view(1, -1, 1, 1)
+        return y.permute(0, 2, 3, 1).float().contiguous()
+    monkeypatch.setattr(GH.ops, "conv2d", conv2d)
+
+    g = torch.Generator().manual_seed(31)
+    B, H, W, Cin, C, N, R2 = 2, 7, 9, 8, 16, 10, 23
+    ks, offs = (3, 5), (0, 4)
+    rows = torch.zeros(N, 72)
+    rows[:, 0] = 1.0; rows[7:, 0] = 0.0
+    rows[:, 57] = torch.randint(0, B, (N,), generator=g).float()
+    rows[:, 2] = torch.randint(0, W, (N,), generator=g).float(); rows[:, 3] = torch.randint(0, H, (N,), generator=g).float()
+    rows[0, 2:4] = torch.tensor([0.0, 0.0]); rows[1, 2:4] = torch.tensor([W - 1.0, H - 1.0]); rows[2] = rows[3]
+    erows = torch.randint(0, B * H * W, (R2,), generator=g)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    wt = [torch.randn(C, Cin, 3, 3, generator=g) / 8.0 for _ in ks]
+    w2 = [torch.randn(k, C, 1, 1, generator=g) * 0.3 for k in ks]
+    b2 = [torch.randn(k, generator=g) * 0.1 for k in ks]
+    dout, dae = torch.randn(N, 10, generator=g), torch.randn(R2, C, generator=g) * 0.1
+    abns = [InPlaceABN(C) for _ in ks]
+    for a in abns:
+        with torch.no_grad():
+            a.weight.copy_(torch.rand(C, generator=g) + 0.5); a.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    # dense reference (fp64)
+    xr = x.double().permute(0, 3, 1, 2).clone().requires_grad_()
+    rw = [w.double().clone().requires_grad_() for w in wt]
+    rw2 = [w.double().clone().requires_grad_() for w in w2]
+    rb2 = [b.double().clone().requires_grad_() for b in b2]
+    bns = []
+    for a in abns:
+        m = torch.nn.BatchNorm2d(C).double()
+        with torch.no_grad():
+            m.weight.copy_(a.weight.double()); m.bias.copy_(a.bias.double())
+        bns.append(m)
+    bi, cy, cx, valid = rows[:, 57].long(), rows[:, 3].long(), rows[:, 2].long(), rows[:, 0].double()
+    tot, outs = 0, []
+    for i, k in enumerate(ks):
+        act = F.leaky_relu(bns[i](F.conv2d(xr, rw[i], None, 1, 1)), 0.01)
+        o = F.conv2d(act, rw2[i], rb2[i]).permute(0, 2, 3, 1)[bi, cy, cx] * valid[:, None]
+        outs.append(o)
+        tot = tot + (o * dout[:, offs[i]:offs[i] + k].double()).sum()
+        if i == 1:
+            ae_ref = act.permute(0, 2, 3, 1).reshape(-1, C)[erows]
+            tot = tot + (ae_ref * dae.double()).sum()
+    tot.backward()
+    # the node
+    xd = x.clone().requires_grad_()
+    dw = [w.clone().requires_grad_() for w in wt]
+    dw2 = [w.clone().requires_grad_() for w in w2]
+    db2 = [b.clone().requires_grad_() for b in b2]
+    out, ae = GH.gram_reg_heads(xd, rows, abns, offs, 10, dw, [a.weight for a in abns], [a.bias for a in abns], dw2, db2, sync=False,
+                                extra_branch=1, extra_rows=erows)
+    ((out * dout).sum() + (ae * dae).sum()).backward()
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp(min=1e-20))      # noqa: E731
+    assert rel(ae, ae_ref.detach()) < 1e-4
+    assert rel(xd.grad, xr.grad.permute(0, 2, 3, 1)) < 2e-4, rel(xd.grad, xr.grad.permute(0, 2, 3, 1))
+    for i, k in enumerate(ks):
+        assert rel(out[:, offs[i]:offs[i] + k], outs[i].detach()) < 1e-4
+        assert rel(dw[i].grad, rw[i].grad) < 2e-4 and rel(dw2[i].grad, rw2[i].grad) < 2e-4 and rel(db2[i].grad, rb2[i].grad) < 2e-4
+        assert rel(abns[i].weight.grad, bns[i].weight.grad) < 2e-4 and rel(abns[i].bias.grad, bns[i].bias.grad) < 2e-4
+        assert rel(abns[i].running_var, bns[i].running_var) < 1e-4 and rel(abns[i].running_mean, bns[i].running_mean) < 1e-4
+        assert int(abns[i].num_batches_tracked) == 1
+    assert float(out[rows[:, 0] == 0].abs().max()) == 0.0 and float(out[:, 3].abs().max()) == 0.0          # empty slots; the unused column
