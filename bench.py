@@ -534,7 +534,9 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dty
     if scaler is not None:
         scaler.attach(opt)
     if graphed:
-        step = GraphedTrainStep(model, opt, imgs, targets, split=True if args.split else None, scaler=scaler)
+        # (the bench opts in to the CAPTURED SyncBN collectives -- library default: eager -- because this leg runs behind the watchdog and
+        # after `train_local_bn`, whose graphs hold no collective)
+        step = GraphedTrainStep(model, opt, imgs, targets, split=True if args.split else None, scaler=scaler, graph_sync_bn=True)
         mode = "hipGraph (fwd+loss+bwd+AdamW)" if not step.split else \
             "%d hipGraphs (fwd+loss+bwd piece 0 | bwd pieces 1..%d), RCCL all-reduce of piece k's slice of the flat fp32 gradient buffer on a " \
             "comm stream while piece k+1 runs | hipGraph AdamW" % (len(step.graphs), len(step.graphs) - 1)

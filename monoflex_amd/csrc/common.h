@@ -168,16 +168,26 @@ __device__ __forceinline__ float apply_act(float v, int act, int n) {
 // channels 18..26 only: chunks outside that range skip the exp entirely (the epilogue is serial per wave, so 32 exp
 // per pixel cost as much as the whole K loop of a 64 -> 27 conv).
 template <int OE> __device__ __forceinline__ void apply_act_chunk(float (&v)[OE], int act, int gn) {
+    // one wave-uniform branch per chunk, then straight-line VALU.  (r05: written as a per-element call of apply_act the fully unrolled
+    // loop compiled to a scalar compare-and-branch ladder PER ELEMENT -- ~10 instructions per value, the epilogue of a 16-bit conv as long
+    // as its K loop; same arithmetic, same bits.)
     if (act == ACT_NONE) return;
+    if (act == ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < OE; ++e) v[e] = fmaxf(v[e], 0.f);
+        return;
+    }
+    if (act == ACT_LEAKY) {
+#pragma unroll
+        for (int e = 0; e < OE; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+        return;
+    }
     if (act == ACT_DCN_OFFMASK) {
         if (gn + OE <= 18 || gn >= 27) return;
 #pragma unroll
         for (int e = 0; e < OE; ++e)
             if (gn + e >= 18 && gn + e < 27) v[e] = 1.f / (1.f + __expf(-v[e]));
-        return;
     }
-#pragma unroll
-    for (int e = 0; e < OE; ++e) v[e] = apply_act(v[e], act, gn + e);
 }
 
 // XCD-aware tile order: block b runs on XCD b%8 (observed, speed only); give every XCD a contiguous

@@ -1,0 +1,319 @@
+// 3x3 / stride-1 / pad-1 convolution on 16-bit maps, second form of the LDS-halo kernel (conv_halo.hip): the SAME decomposition
+// (8 x 16-pixel tile, halo patch staged once in LDS, wave-private output slices, fragment-major weights L2 -> registers, K-split
+// waves, wave-private epilogue) with every piece of geometry a COMPILE-TIME constant and the K loop written as an explicit
+// software pipeline.
+//
+// Why (round 5, ISA of conv3x3_wave_kernel<bf16, bf16, 2, 2, 1>, `hipcc --save-temps`): with the channel group, patch width and
+// weight row length as run-time values, one K step of that kernel is 16 MFMAs inside ~60 other instructions -- per step three
+// v_mul_lo_u32 and a dozen VALU to rebuild the lane's patch address from (tap, channel), two exec-masked branch diamonds around the
+// weight fetch (null-pointer / K-padding tests), 64-bit VALU address arithmetic per weight load -- and two scheduling accidents
+// that follow from the control flow: `s_waitcnt vmcnt(0)` at the top of EVERY step (the branches hide the load count from the
+// waitcnt pass, so the five-deep weight ring drains to empty each step and every step exposes one full L2 round trip) and
+// `s_waitcnt lgkmcnt(1)` in front of every MFMA pair (pixel fragments are read one pair = 34 cycles ahead of their use against an
+// LDS round trip of 64-128).  The kernel was instruction-issue- and latency-bound by its own address code, not by a hardware unit
+// (profiles/r03_conv_halo_probes.md: no unit above 25 % busy).
+//
+// Here <CG, CT, WN, FN, WK> are template parameters, so
+//   * a pixel-fragment read is `ds_read_b128 v, v_lane offset:imm` -- the lane's patch base is computed once per workgroup;
+//   * a weight-fragment fetch is `global_load_dwordx4 v, v_lane16, s[base] offset:imm` against a wave-uniform base advanced by SALU;
+//   * the K loop is fully unrolled and branch-free (the waitcnt pass counts exactly: vmcnt(2 FN) / lgkmcnt(4) waits);
+//   * pixel fragments are read HALF A STEP (8 FN MFMAs = 136+ cycles) ahead of their use into two 4-row register sets, weights two
+//     steps ahead through a 3-deep ring; `sched_barrier`s pin that order;
+//   * BN scale / shift are fetched before the K loop instead of at the head of the epilogue.
+// Same K order, same accumulation order, same epilogue arithmetic as conv3x3_wave_kernel: outputs are bit-identical
+// (tests/test_gpu_ops.py::test_conv_cw_kernel_is_bit_identical_to_the_halo_kernel).
+//
+// Reference layers: model/backbone/dla_dcn.py:84-98 (BasicBlock conv1 / conv2 of levels 2-5), 246-259 (Tree).
+#include "../../include/monoflex_hip.h"
+#include "err.h"
+#include "igemm.h"
+#include <type_traits>
+
+namespace mfx {
+
+struct CwGeom { int B, H, W, tiles_x, tiles_y, tiles_n; };
+
+constexpr int kCwRows = 8, kCwPW = 18, kCwPH = 10;
+
+template <int CG, int WN, int FN, int WK> struct CwSmem {
+    static constexpr int PS = CG * 2 + 16;                                    // patch pixel stride: 16 consecutive pixels on 16 distinct 16-byte bank slots
+    static constexpr int patch_bytes = kCwPH * kCwPW * PS;
+    static constexpr int stage_ld = FN * 16 + 4;
+    static constexpr int stage_bytes = 16 * stage_ld * 4;
+    static constexpr int reduce_bytes = WN * (WK - 1) * kCwRows * FN * 64 * 16;
+    static constexpr int main_bytes = patch_bytes > reduce_bytes ? patch_bytes : reduce_bytes;
+    static constexpr int total = main_bytes + WN * WK * stage_bytes;
+};
+
+// CG = channels per patch pass, CT = input channels of the layer (a multiple of CG), WN x FN x 16 = output channels per workgroup,
+// WK = waves sharing an output slice (they take the K steps round-robin); OCC = waves per SIMD the register allocation must admit
+template <typename T, int CG, int CT, int WN, int FN, int WK, int OCC>
+__global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* __restrict__ x, const u32x4* __restrict__ wfm, CwGeom g, EpiArgs ep) {
+    static_assert(sizeof(T) == 2, "16-bit maps");
+    constexpr int NT = WN * WK * 64, FM = kCwRows, PW = kCwPW, PH = kCwPH;
+    using SM = CwSmem<CG, WN, FN, WK>;
+    constexpr int PS = SM::PS, CPP = CG / 8;
+    constexpr int KS = CG / 32;                       // 64-byte K steps per tap and channel group
+    constexpr int NG = CT / CG, FSTEPS = 9 * CT / 32; // channel groups; steps per fragment row of the fragment-major weights
+    constexpr int SPG = 9 * KS, NL = SPG / WK;        // steps per group; steps per wave and group
+    static_assert(KS % WK == 0 && CT % CG == 0 && FM % WK == 0, "K split must divide the steps of a tap and the rows");
+    constexpr int BN = WN * FN * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wk = wave / WN;
+    const int xl = lane & 15, kq = lane >> 4;
+
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % g.tiles_n; tile /= g.tiles_n;
+    const int tx = tile % g.tiles_x; tile /= g.tiles_x;
+    const int ty = tile % g.tiles_y; const int b = tile / g.tiles_y;
+    const int x0 = tx * 16, y0 = ty * kCwRows, n0 = tn * BN + wn * (FN * 16);
+
+    char* patch = smem;
+    float* stage = reinterpret_cast<float*>(smem + SM::main_bytes + wave * SM::stage_bytes);
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // BN scale / shift of this lane's output columns: in flight during the whole K loop
+    float sc[FN], sh[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        sc[j] = ep.scale ? ep.scale[n0 + j * 16 + xl] : 1.f;
+        sh[j] = ep.shift ? ep.shift[n0 + j * 16 + xl] : 0.f;
+    }
+
+    // lane's patch base: pixel column xl, K chunk kq of the wave's first step (wave wk starts at step wk of every tap)
+    const char* abase = patch + xl * PS + kq * 16 + wk * 64;
+    const uint32_t loff = (uint32_t)lane * 16u;
+    const T* xb = x + (size_t)b * g.H * g.W * CT;
+
+    for (int grp = 0; grp < NG; ++grp) {
+        if (grp > 0) __syncthreads();                         // every wave is done reading the previous patch
+        // ---- halo patch: 10 x 18 input pixels x CG channels, zero outside the image.  Branch-free: every lane loads from a CLAMPED (always
+        // valid) address and the out-of-image chunks are zeroed by a select, so all of a lane's loads are in flight together (as exec-masked
+        // branch diamonds the compiler serialised some of them behind `s_waitcnt vmcnt(0)`); 32-bit element offsets against the image base
+        {
+            constexpr int nchunks = PH * PW * CPP;
+            constexpr int PU = (nchunks + NT - 1) / NT < 12 ? (nchunks + NT - 1) / NT : 12;
+            const T* xg = xb + grp * CG;
+#pragma unroll
+            for (int base = 0; base < nchunks; base += NT * PU) {
+                u32x4 pr[PU];
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    int idx = base + u * NT + tid;
+                    if (base + u * NT + NT > nchunks) idx = idx < nchunks ? idx : nchunks - 1;
+                    const int pix = idx / CPP, ch = idx % CPP;
+                    const int py = pix / PW, px = pix - py * PW;
+                    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                    const bool in = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                    const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
+                    const u32x4 z = *reinterpret_cast<const u32x4*>(xg + (uint32_t)((cy * g.W + cx) * CT + ch * 8));
+                    pr[u] = in ? z : u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int idx = base + u * NT + tid;
+                    if (base + u * NT + NT <= nchunks || idx < nchunks) *reinterpret_cast<u32x4*>(patch + (idx / CPP) * PS + (idx % CPP) * 16) = pr[u];
+                }
+            }
+        }
+
+        // wave-uniform base of this wave's weight fragments: fragment row n0/16, step (grp * KS + wk) of tap 0
+        const char* wbase = reinterpret_cast<const char*>(wfm) + ((size_t)(n0 >> 4) * FSTEPS + grp * KS + wk) * 1024;
+        // step m of this wave: q = m * WK (+ wk, folded into the bases) -> tap q / KS, K step q % KS inside the tap
+        auto bload = [&](int m, u32x4 (&bf)[FN]) {
+            const int q = m * WK, tap = q / KS, ks = q % KS;
+            const int st = tap * (CT / 32) + ks;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(wbase + ((size_t)j * FSTEPS + st) * 1024 + loff);
+        };
+        auto aread = [&](int m, int i) -> u32x4 {
+            const int q = m * WK, tap = q / KS, ks = q % KS;
+            const int th = tap / 3, tw = tap - th * 3;
+            return *reinterpret_cast<const u32x4*>(abase + ((th + i) * PW + tw) * PS + ks * 64);
+        };
+
+        constexpr int RING = 3;
+        u32x4 wb[RING][FN];
+        bload(0, wb[0]);
+        if (NL > 1) bload(1, wb[1]);
+        __syncthreads();                                      // patch visible to all waves
+
+        u32x4 a0[4], a1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a0[i] = aread(0, i);
+#pragma unroll
+        for (int m = 0; m < NL; ++m) {
+            if (m + 2 < NL) bload(m + 2, wb[(m + 2) % RING]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a1[i] = aread(m, 4 + i);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma_chunk<T>(a0[i], wb[m % RING][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m + 1 < NL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a0[i] = aread(m + 1, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma_chunk<T>(a1[i], wb[m % RING][j], acc[4 + i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- K-split: partial accumulators -> LDS (the patch is dead), wave wk sums and finishes rows wk*RW .. +RW
+    constexpr int RW = FM / WK;
+    if constexpr (WK > 1) {
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+        for (int dst = 0; dst < WK; ++dst) {
+            if (dst == wk) continue;
+            const int slot = wk < dst ? wk : wk - 1;
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    red[((((wn * WK + dst) * (WK - 1) + slot) * RW + r) * FN + j) * 64 + lane] = acc[dst * RW + r][j];
+        }
+        __syncthreads();
+        f32x4 own[RW][FN];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < WK; ++q) if (q == wk) t = acc[q * RW + r][j];
+#pragma unroll
+                for (int slot = 0; slot < WK - 1; ++slot) t += red[((((wn * WK + wk) * (WK - 1) + slot) * RW + r) * FN + j) * 64 + lane];
+                own[r][j] = t;
+            }
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[r][j] = own[r][j];
+    }
+
+    // ---- epilogue, wave-private: accumulator row-fragment -> stage -> 16-byte stores (conv_halo.hip's arithmetic, bit for bit).
+    // The residual chunks of ALL the wave's rows are fetched up front (the K loop's fragment registers are dead by now, so they cost no
+    // occupancy): one exposed memory round trip per tile instead of one per output row; 32-bit element offsets.
+    constexpr int LDS_ = SM::stage_ld;
+    constexpr int OE = 8;
+    constexpr int GPR = FN * 16 / OE;
+    constexpr int RITEMS = (16 * GPR + 63) / 64;
+    const T* res = reinterpret_cast<const T*>(ep.res);
+    T* y = reinterpret_cast<T*>(ep.y);
+    const uint32_t pix0 = (uint32_t)((b * g.H + y0) * g.W + x0);            // first pixel of the tile (32-bit: M * ld < 2^31 checked by the launcher)
+    u32x4 rres[RW][RITEMS];
+    if (res) {
+#pragma unroll
+        for (int ii = 0; ii < RW; ++ii) {
+            const int i = WK > 1 ? wk * RW + ii : ii;
+#pragma unroll
+            for (int q = 0; q < RITEMS; ++q) {
+                const int it = q * 64 + lane;
+                const int px = it / GPR, ng = it - px * GPR;
+                const bool ok = (16 * GPR % 64 == 0 || it < 16 * GPR) && y0 + i < g.H && x0 + px < g.W && n0 + ng * OE < ep.Cout;
+                u32x4 z = {0u, 0u, 0u, 0u};
+                if (ok) z = *reinterpret_cast<const u32x4*>(res + (pix0 + (uint32_t)(i * g.W + px)) * (uint32_t)ep.ldres + (uint32_t)(n0 + ng * OE));
+                rres[ii][q] = z;
+            }
+        }
+    }
+#pragma unroll
+    for (int ii = 0; ii < RW; ++ii) {
+        const int i = WK > 1 ? wk * RW + ii : ii;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[((lane >> 4) * 4 + r) * LDS_ + j * 16 + xl] = acc[ii][j][r] * sc[j] + sh[j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < RITEMS; ++q) {
+            const int it = q * 64 + lane;
+            const int px = it / GPR, ng = it - px * GPR;
+            const int gn = n0 + ng * OE;
+            const bool ok = (16 * GPR % 64 == 0 || it < 16 * GPR) && y0 + i < g.H && x0 + px < g.W && gn < ep.Cout;
+            if (ok) {
+                float v[OE];
+#pragma unroll
+                for (int e = 0; e < OE; e += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(stage + px * LDS_ + ng * OE + e);
+                    v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+                }
+                if (res) {
+                    float rv[OE];
+                    ElemTraits<T>::unpack(rres[ii][q], rv);
+#pragma unroll
+                    for (int e = 0; e < OE; ++e) v[e] += rv[e];
+                }
+                apply_act_chunk<OE>(v, ep.act, gn);
+                *reinterpret_cast<u32x4*>(y + (pix0 + (uint32_t)(i * g.W + px)) * (uint32_t)ep.ldy + (uint32_t)gn) = ElemTraits<T>::pack(v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int g_opt_halo_cw = 1;       // option "halo_cw": 0 = conv3x3_wave_kernel only, 1 = this kernel where an instantiation exists, 2 / 3 = experimental register budgets
+
+template <typename T, int CG, int CT, int WN, int FN, int WK, int OCC>
+static int launch_cw(const mfx_conv_desc* d, hipStream_t st) {
+    using SM = CwSmem<CG, WN, FN, WK>;
+    constexpr int BN = WN * FN * 16;
+    CwGeom g;
+    g.B = d->B; g.H = d->H; g.W = d->W;
+    g.tiles_x = (d->W + 15) / 16; g.tiles_y = (d->H + kCwRows - 1) / kCwRows; g.tiles_n = d->Cout_pad / BN;
+    EpiArgs ep;
+    ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
+    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
+    auto k = conv3x3_cw_kernel<T, CG, CT, WN, FN, WK, OCC>;
+    constexpr int smem = SM::total;
+    static bool attr_done = false;
+    if (!attr_done && smem > 64 * 1024) {
+        MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    const int tiles = g.tiles_n * g.tiles_x * g.tiles_y * d->B;
+    hipLaunchKernelGGL(k, dim3(tiles), dim3(WN * WK * 64), smem, st, reinterpret_cast<const T*>(d->x), reinterpret_cast<const u32x4*>(d->w_frag), g, ep);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+template <typename T, int OCC> static int cw_shape(const mfx_conv_desc* d, int v, hipStream_t st) {
+    const int C = d->Ck;
+    if (v == 6 && C == 64) return launch_cw<T, 64, 64, 2, 2, 1, OCC>(d, st);
+    if (v == 7 && C == 128) return launch_cw<T, 128, 128, 4, 2, 1, OCC>(d, st);
+    if (v == 7 && C == 64) return launch_cw<T, 64, 64, 4, 2, 1, OCC>(d, st);
+    if (v == 11 && C == 256) return launch_cw<T, 256, 256, 4, 2, 2, OCC>(d, st);
+    if (v == 11 && C == 512) return launch_cw<T, 256, 512, 4, 2, 2, OCC>(d, st);
+    return 1;                                                 // no instantiation: the caller falls back
+}
+
+// returns MFX_OK (0) if this kernel ran, 1 if there is no instantiation for the shape / variant (caller runs conv3x3_wave_kernel), < 0 on error.
+// `v` is conv_halo.hip's variant number (6: 2 waves x 32 channels, 7: 4 x 32, 11: 4 x 32 with a 2-way K split)
+int try_conv_cw(const mfx_conv_desc* d, int v, hipStream_t st) {
+    if (!g_opt_halo_cw || !d->w_frag || d->stats || d->stride != 1) return 1;
+    if (d->out_dtype != d->dtype || (d->dtype != MFX_BF16 && d->dtype != MFX_F16)) return 1;
+    if (d->K_pad != 9 * d->Ck || d->Cout % 8 != 0 || d->act == MFX_ACT_DCN_OFFMASK) return 1;
+    if ((long long)d->M * (d->ldy > d->ldres ? d->ldy : d->ldres) >= (1ll << 31) || (long long)d->H * d->W * d->Ck >= (1ll << 31)) return 1;      // 32-bit element offsets
+    if (v == 6 && d->Cout_pad % 64 != 0) return 1;
+    if ((v == 7 || v == 11) && d->Cout_pad % 128 != 0) return 1;
+    if (d->dtype == MFX_F16) return cw_shape<half_t, 2>(d, v, st);
+    if (g_opt_halo_cw == 2) return cw_shape<bf16_t, 3>(d, v, st);
+    return cw_shape<bf16_t, 2>(d, v, st);
+}
+
+}  // namespace mfx

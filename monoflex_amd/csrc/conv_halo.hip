@@ -422,6 +422,8 @@ int g_opt_halo_pair = 1;     // option "halo_pair": split precision walks K in s
 template <typename T, typename TO, int WN, int FN, int WK = 1, bool ST = false>
 static int launch_halo_st(const mfx_conv_desc* d, hipStream_t st);
 
+int try_conv_cw(const mfx_conv_desc* d, int v, hipStream_t st);      // conv_cw.hip: 0 = ran, 1 = no instantiation, < 0 = error
+
 static bool g_halo_stats_ran = false;    // set by the launch that ran a statistics-accumulating instantiation (read by try_conv_halo)
 
 // statistics-accumulating instantiations exist for output tiles up to 128 channels wide (wider ones are atomic-bound there,
@@ -559,6 +561,11 @@ static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st) {
     if (g_opt_halo >= 2) {
         const int f = g_opt_halo - 1, bn = variant_bn(f);
         if (bn && N % bn == 0 && (bn >= 64) == (N >= 64)) v = f;
+    }
+    if ((d->dtype == MFX_BF16 || d->dtype == MFX_F16) && g_opt_halo_cg <= 0) {
+        // compile-time-geometry form of the same decomposition (conv_cw.hip): bit-identical output
+        const int r = try_conv_cw(d, v, st);
+        if (r <= 0) return r == 0 ? 1 : r;
     }
     int rc;
     if (d->dtype == MFX_F32) rc = halo_variant<float, float>(v, d, st);

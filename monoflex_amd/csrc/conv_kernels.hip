@@ -226,8 +226,7 @@ __global__ void splitk_finalize_kernel(const float* __restrict__ ws, int ksplit,
 #pragma unroll
             for (int e = 0; e < OE; ++e) v[e] += rv[e];
         }
-#pragma unroll
-        for (int e = 0; e < OE; ++e) v[e] = apply_act(v[e], act, n + e);
+        apply_act_chunk<OE>(v, act, n);
         *reinterpret_cast<u32x4*>(y + (size_t)m * ldy + n) = ElemTraits<TO>::pack(v);
     }
 }
@@ -275,6 +274,7 @@ static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 int try_conv_halo(const mfx_conv_desc* d, hipStream_t st, int* stats_ran);   // conv_halo.hip
+extern int g_opt_halo_cw;
 extern int g_opt_halo, g_opt_halo_cg, g_opt_halo_pair, g_opt_halo_s2, g_opt_dcn_wave, g_opt_dcn_patch, g_opt_dcn_patch_fn8, g_opt_dcn_wgrad_m;
 }
 extern long g_cnt_dcn_bt_fused, g_cnt_dcn_bt_fly;
@@ -416,6 +416,7 @@ extern "C" int mfx_set_option(const char* name, int value) {
     else if (n == "dcn_wgrad_m") g_opt_dcn_wgrad_m = value < 64 ? 64 : value;
     else if (n == "halo") g_opt_halo = value;
     else if (n == "halo_cg") g_opt_halo_cg = value;
+    else if (n == "halo_cw") g_opt_halo_cw = value;
     else if (n == "halo_pair") g_opt_halo_pair = value;
     else if (n == "halo_s2") g_opt_halo_s2 = value;
     else if (n == "dcn_wave") g_opt_dcn_wave = value;

@@ -577,8 +577,7 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restri
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] += r[e];
         }
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = apply_act(v[e], act, 0);
+        apply_act_chunk<E>(v, act, 0);
         *reinterpret_cast<u32x4*>(y + i * E) = ElemTraits<T>::pack(v);
     }
 }
@@ -771,8 +770,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_fused_kernel(const T* __restri
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] += r[e];
         }
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = apply_act(v[e], act, 0);
+        apply_act_chunk<E>(v, act, 0);
         *reinterpret_cast<u32x4*>(y + i * E) = ElemTraits<T>::pack(v);
     };
     long i = blockIdx.x * (long)blockDim.x + tid;

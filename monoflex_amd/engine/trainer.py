@@ -6,6 +6,8 @@ with the backward kernels.  The reference wraps with find_unused_parameters=True
 level3/level4 `project` conv + BN, dead in DLA's Tree.forward) never receive a gradient, which makes DDP walk the
 autograd graph every iteration; here those six are excluded statically, so no per-iteration graph traversal happens
 and no bucket ever waits for them."""
+import os
+
 import torch
 
 DEAD_PARAMETER_SUFFIXES = ("base.level3.project.0.weight", "base.level3.project.1.weight", "base.level3.project.1.bias",
@@ -159,7 +161,7 @@ class GraphedTrainStep:
     between graph launches."""
 
     def __init__(self, model, optimizer, images, targets, group=None, comm_chunks=None, warmup=3, split=None, use_graphs=None,
-                 grad_norm_clip=-1.0, scaler="auto"):
+                 grad_norm_clip=-1.0, scaler="auto", graph_sync_bn=None):
         import torch.distributed as dist
         self.model, self.optimizer, self.images, self.targets = model, optimizer, images, targets
         self.net = model.module if hasattr(model, "module") else model
@@ -178,10 +180,23 @@ class GraphedTrainStep:
         self.nseg = 1
         self.sync_bn = self.world > 1 and any(getattr(mod, "sync_bn", False) or isinstance(mod, torch.nn.SyncBatchNorm) for mod in self.net.modules())
         self.bn_group = None
-        if self.sync_bn and (images.is_cuda if use_graphs is None else bool(use_graphs)) and dist.get_backend(group) == "nccl":
-            from .. import autograd as AG
-            self.bn_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None)    # (collective: every rank constructs the step)
-            AG.set_sync_bn_group(self.bn_group)
+        # SyncBN on more than one rank: the CAPTURED form (statistics all-reduces inside the hipGraphs on a second communicator while the
+        # host all-reduces gradient slices on the default one) has only ever run on a one-rank RCCL group inside this build's sessions (one GPU
+        # per box).  Until a multi-GPU run has passed it is OPT-IN -- graph_sync_bn=True or MFX_GRAPH_SYNC_BN=1 -- and needs the nccl
+        # backend (a gloo collective cannot be captured); otherwise a SyncBN model takes the same pieces eagerly (use_graphs False: every
+        # collective on the default communicator, in stream order).  bench.py's `train` legs opt in (they run behind a watchdog, after the
+        # `train_local_bn` leg that has no collective inside its graphs).
+        if graph_sync_bn is None:
+            graph_sync_bn = os.environ.get("MFX_GRAPH_SYNC_BN", "0") == "1"
+        self.graph_sync_bn = False
+        if self.sync_bn and self.use_graphs:
+            if graph_sync_bn and dist.get_backend(group) == "nccl":
+                from .. import autograd as AG
+                self.bn_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None)    # (collective: every rank constructs the step)
+                AG.set_sync_bn_group(self.bn_group)
+                self.graph_sync_bn = True
+            else:
+                self.use_graphs = False
         if self.split:
             dead = set(dead_parameter_names(self.net))
             named = [(n, p) for n, p in self.net.named_parameters() if p.requires_grad and n not in dead]
@@ -400,6 +415,33 @@ class GraphedTrainStep:
         self._update()
         return loss
 
+    def eager_on(self, images, targets):
+        """The same step run EAGERLY on a batch of another shape (a partial last batch of a data-parallel run) with this object's flat
+        gradient buffer, views, scaler and communicator: exactly the collectives of a replay, so ranks that replay and ranks that fall back
+        still meet.  (the fallback used to build a fresh GraphedTrainStep -- an 84 MB buffer and a re-attached scaler -- per batch.)"""
+        if not self.split:
+            raise RuntimeError("eager_on: only the segmented (data-parallel) step has an eager form that shares its buffers")
+        keep = (self.images, self.targets)
+        self.images, self.targets = images, targets
+        try:
+            self.loss = self._eager()
+        finally:
+            self.images, self.targets = keep
+        return self.loss
+
+    def close(self):
+        """Detach the process-wide SyncBN communicator this step installed (autograd.set_sync_bn_group)."""
+        if self.bn_group is not None:
+            from .. import autograd as AG
+            AG.set_sync_bn_group(None)
+            self.bn_group = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                                 # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def load_batch(self, images, targets=None):
         self.images.copy_(images, non_blocking=True)
         if targets is not None:
@@ -510,7 +552,9 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
             if graphed is None:
                 graphed = GraphedTrainStep(model, optimizer, img_t.clone(), _clone_targets(targets), grad_norm_clip=clip, scaler=scaler)
                 graphed_shapes = shapes
-                logger.info("training step captured as hipGraphs (%d graph(s), overlap %s)", len(graphed.graphs) + (graphed.graph_b is not None), graphed.overlap)
+                logger.info("training step: %s (%d graph(s), overlap %s, SyncBN %s)", "captured as hipGraphs" if graphed.use_graphs else "eager pieces",
+                            len(graphed.graphs) + (graphed.graph_b is not None), graphed.overlap,
+                            "off" if not graphed.sync_bn else ("captured collectives" if graphed.graph_sync_bn else "eager collectives (MFX_GRAPH_SYNC_BN=1 captures them)"))
             if shapes == graphed_shapes:
                 graphed.load_batch(img_t, targets)
                 losses = graphed()
@@ -520,8 +564,7 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
                 # segmented step runs eagerly instead -- cut backward, flat gradient buffer, one all-reduce per piece -- which issues
                 # exactly the collectives the captured step issues, so ranks that replay and ranks that fall back still meet
                 # (the loaders of this build hand every rank the same batch shape at the same iteration: data/samplers.py).
-                losses = GraphedTrainStep(model, optimizer, img_t, targets, group=graphed.group, split=True, use_graphs=False,
-                                          grad_norm_clip=clip, scaler=scaler)()
+                losses = graphed.eager_on(img_t, targets)
             else:                                               # single process: the reference's eager step
                 losses, _, _ = train_step(model, optimizer, images, targets, grad_norm_clip=clip, scaler=scaler)
         else:
@@ -548,4 +591,6 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
                           output_folder=os.path.join(cfg.OUTPUT_DIR, "inference_{}".format(iteration), name))
             model.train()
             comm.synchronize()
+    if graphed is not None:
+        graphed.close()                                              # (the SyncBN communicator it may have installed process-wide)
     return loss_v

@@ -573,3 +573,34 @@ def test_f1_fused_equals_three_launches_and_torch(dtype, B, H, W):
     r = aff(F.conv2d(r, w1, None, 2, 1), 2)
     ref = r.permute(0, 2, 3, 1)
     assert float((a - ref).norm() / ref.norm()) < 4 * eps, float((a - ref).norm() / ref.norm())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,Cout,B,H,W", [(64, 64, 2, 24, 48), (64, 64, 1, 13, 37), (64, 128, 1, 19, 33), (128, 128, 2, 16, 32), (128, 128, 1, 13, 37),
+                                          (256, 256, 2, 16, 32), (256, 256, 1, 11, 21), (512, 512, 2, 12, 40), (512, 512, 1, 9, 17)])
+def test_conv_cw_kernel_is_bit_identical_to_the_halo_kernel(dtype, C, Cout, B, H, W):
+    """csrc/conv_cw.hip (compile-time geometry, software-pipelined K loop, branch-free patch load, residual prefetch) keeps the K order, the
+    accumulation order and the epilogue arithmetic of conv3x3_wave_kernel: same bits, with and without the residual, ReLU / LeakyReLU / no
+    activation, full and ragged tiles, one and two channel groups, K-split waves (reference layers: dla_dcn.py:84-98)."""
+    ops, L = _ops()
+    g = _g(131)
+    x = torch.randn(B, H, W, C, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+    res = torch.randn(B, H, W, Cout, generator=g).to(dtype).to(DEV)
+    lib_ = L.load()
+    try:
+        for act in (L.ACT_RELU, L.ACT_LEAKY, L.ACT_NONE):
+            p = ops.pack_conv(w, dtype, (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV), stride=1, pad=1, act=act)
+            for r in (res, None):
+                L.check(lib_.mfx_set_option(b"halo_cw", 0), "opt")
+                want = ops.conv2d(x, p, res=r)
+                L.check(lib_.mfx_set_option(b"halo_cw", 1), "opt")
+                got = ops.conv2d(x, p, res=r)
+                assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (act, r is not None)
+                L.check(lib_.mfx_set_option(b"halo", 0), "opt")              # and the generic implicit-GEMM kernel agrees to rounding
+                gen = ops.conv2d(x, p, res=r)
+                L.check(lib_.mfx_set_option(b"halo", 1), "opt")
+                assert float((got.float() - gen.float()).abs().max()) <= 2e-2 * max(1.0, float(gen.float().abs().max()))
+    finally:
+        L.check(lib_.mfx_set_option(b"halo_cw", 1), "opt")
+        L.check(lib_.mfx_set_option(b"halo", 1), "opt")

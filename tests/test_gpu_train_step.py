@@ -525,7 +525,7 @@ def _sync_rccl_worker(rank, world, port, out):
     imgs, tg = _batch(m, B=2, seed0=20 + 10 * rank)
     imgs = imgs.to("cuda:%d" % rank)
     opt = build_optimizer(m, _cfg("bf16"), capturable=True)
-    step = GraphedTrainStep(m, opt, imgs, tg, warmup=2)
+    step = GraphedTrainStep(m, opt, imgs, tg, warmup=2, graph_sync_bn=True)      # (opt-in: the library default runs a SyncBN step's pieces eagerly)
     losses = [float(step()) for _ in range(2)]
     torch.cuda.synchronize()
     digest = torch.stack([p.detach().double().sum() for p in m.parameters()]).cpu().tolist()

@@ -391,3 +391,60 @@ def test_gram_heads_statistics_all_reduce_is_differentiable_over_two_ranks():
     for _, sums, grad in res:
         assert torch.allclose(torch.tensor(sums, dtype=torch.float64), want, atol=1e-9)
         assert torch.allclose(torch.tensor(grad, dtype=torch.float64), gwant, atol=1e-12)
+
+
+def _syncbn_gate_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from monoflex_amd import autograd as AG, parallel
+    from monoflex_amd.engine.trainer import GraphedTrainStep
+    parallel.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    m = _ToyStaged()
+    m.bn = torch.nn.BatchNorm1d(4)                                       # (never run: the step only looks for the flag)
+    m.bn.sync_bn = True
+    for p in m.bn.parameters():
+        p.requires_grad_(False)
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.1)
+    xs = torch.arange(36, dtype=torch.float32).view(6, 6) / 10
+    # a SyncBN model on two ranks with graphs REQUESTED and the captured collectives opted in, on a backend that cannot capture them:
+    # the step must take its pieces eagerly and must not install a process-wide SyncBN communicator
+    step = GraphedTrainStep(m, opt, xs[2 * rank:2 * rank + 2].clone(), None, use_graphs=True, graph_sync_bn=True)
+    gated = (step.sync_bn, step.use_graphs, step.graph_sync_bn, step.bn_group is None, AG._SYNC_BN_GROUP[0] is None)
+    step()
+    flat_a = step.flat.clone()
+    w_a = {n: p.detach().clone() for n, p in m.named_parameters()}
+    # a batch of ANOTHER shape through the same object's buffers (the partial-last-batch fallback of do_train)
+    flat_id = step.flat.data_ptr()
+    step.eager_on(xs[4 + rank:5 + rank].clone(), None)
+    same_buffer = step.flat.data_ptr() == flat_id and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(step.params, step.views))
+    step.close()
+    out.put((rank, gated, flat_a.tolist(), step.flat.tolist(), same_buffer, {n: p.detach().tolist() for n, p in m.named_parameters() if p.requires_grad},
+             {n: v.tolist() for n, v in w_a.items() if m.get_parameter(n).requires_grad}))
+    dist.destroy_process_group()
+
+
+def test_sync_bn_step_without_opt_in_or_without_rccl_runs_its_pieces_eagerly_and_eager_on_shares_the_buffers():
+    """ADVICE r4 (engine/trainer.py): (a) the captured SyncBN collectives are opt-in AND need the nccl backend -- a gloo group falls back to
+    the eager pieces even when asked, installs no second communicator; (b) `eager_on` runs an odd-shaped batch through the SAME flat
+    gradient buffer (no fresh step object per batch) and both ranks still meet: equal averaged gradients, equal parameters afterwards."""
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    ps = [ctx.Process(target=_syncbn_gate_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted((q.get(timeout=120) for _ in ps), key=lambda t: t[0])
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    for rank, gated, flat_a, flat_b, same_buffer, w_end, w_mid in res:
+        assert gated == (True, False, False, True, True), gated
+        assert same_buffer
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and res[0][2] != res[0][3]           # averaged gradients agree on both steps
+    assert res[0][5] == res[1][5] and res[0][6] == res[1][6] and res[0][5] != res[0][6]           # parameters in lock step, and they moved
+    # the second step's gradient is the mean over the two ranks' single rows
+    torch.manual_seed(0)
+    m = _ToyStaged()
+    m.load_state_dict({k: torch.tensor(v) for k, v in res[0][6].items()}, strict=False)
+    xs = torch.arange(36, dtype=torch.float32).view(6, 6) / 10
+    (sum(m(xs[4:5])[0].values()) + sum(m(xs[5:6])[0].values())).backward()
+    by_name = dict(m.named_parameters())
+    want = torch.cat([by_name[n].grad.flatten() for n in ("head.weight", "head.bias", "mid.weight", "mid.bias", "stem.weight", "stem.bias")]) / 2
+    assert torch.allclose(torch.tensor(res[0][3]), want, atol=1e-6)
