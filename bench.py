@@ -75,16 +75,18 @@ def parse():
     ap.add_argument("--legs", default="all", choices=["all", "none"], help="infer mode: add the `train` and `fp32_parity` legs to the line")
     ap.add_argument("--repeats", type=int, default=None, help="timed regions of exactly --steps steps; the median is reported")
     ap.add_argument("--leg-timeout", type=int, default=420, help="seconds after which unfinished legs are reported as errors and the line is printed")
-    ap.add_argument("--train-steps", type=int, default=10)
-    ap.add_argument("--train-warmup", type=int, default=3)
+    ap.add_argument("--train-steps", type=int, default=50, help="timed steps per repeat of the `train` legs (SURVEY 8d: >= 50 timed iterations)")
+    ap.add_argument("--train-warmup", type=int, default=10)
+    ap.add_argument("--train-repeats", type=int, default=3, help="timed regions of the `train` legs; the median is reported")
+    ap.add_argument("--train-batches", type=int, default=4, help="distinct synthetic batches rotated through the training step")
     ap.add_argument("--opts", default="", help="library tuning options k=v,... (mfx_set_option), for experiments")
     a = ap.parse_args()
     if a.steps is None:
-        a.steps = 30 if a.mode == "infer" else 10
+        a.steps = 30 if a.mode == "infer" else 50
     if a.warmup is None:
-        a.warmup = 5 if a.mode == "infer" else 3
+        a.warmup = 5 if a.mode == "infer" else 10
     if a.repeats is None:
-        a.repeats = 5 if a.mode == "infer" else 1
+        a.repeats = 5 if a.mode == "infer" else 3
     return a
 
 
@@ -216,6 +218,78 @@ def _hip_event_ms(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+# SURVEY section 8d / Appendix A, GMAC per 1280x384 image: F1 (stem + level0 + level1) 2.85, DLA levels 2-5 (3x3, 1x1 project, Root) 27.25,
+# the 16 DCN modules (3x3 main GEMM 13.3 + 27-channel offset/mask conv 4.36 + depthwise up-sampling 0.05) 17.71, the nine heads 41.185
+FAMILY_GMAC_PER_IMG = {"f1": 2.85, "trunk_levels_2_5": 30.097 - 2.85, "dcn_modules": 17.666 + 0.049, "heads": 41.185}
+
+
+def _graph_replay_ms(fn, reps=10):
+    """Average GPU time of `fn` (a capturable sequence of launches): ONE capture, `reps` replays between two HIP events on the replay stream."""
+    import torch
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def family_rooflines(model, images, tg, dtype, B, heads_ms):
+    """Per kernel FAMILY of the forward step, timed live: each stage of the network is captured alone (single stream, whole batch) and
+    replayed between HIP events; a family's time is the difference of two nested stages.  `frac` = algorithmic FLOPs / time /
+    the dense 16-bit MFMA peak (fp32 mode: the f32 MFMA peak) -- the figures VERDICT r4 asked to see beside the heads kernel's."""
+    import torch
+    from monoflex_amd import lib as L, ops
+    from monoflex_amd.model.backbone import dla_dcn as D
+    bb = model.backbone
+    base = bb.base
+    cd = bb.compute_dtype
+    with torch.no_grad():
+        t_total = _graph_replay_ms(lambda: model.detect_device(images, *tg))
+        t_backbone = _graph_replay_ms(lambda: bb.forward_nhwc(images))
+        t_base = _graph_replay_ms(lambda: base(images, cd))
+        tag = ops.compute_tag(base, cd)
+        packs = base.__dict__.get("_packs", {})
+        t_f1 = None
+        if D.FUSE_F1[0] and ("stem", tag) in packs and (tag == ops.F16X2 or tag in (torch.bfloat16, torch.float16)):
+            p0 = D._conv_bn(base.level0, "c0", base.level0[0], base.level0[1], cd, L.ACT_RELU)
+            p1 = D._conv_bn(base.level1, "c0", base.level1[0], base.level1[1], cd, L.ACT_RELU)
+            t_f1 = _graph_replay_ms(lambda: ops.f1_fused(images, packs[("stem", tag)], p0, p1))
+    peak = PEAK_F32_TFLOPS if dtype == "fp32" else PEAK_BF16_TFLOPS
+    rows = []
+
+    def row(name, ms, what):
+        gf = 2.0 * FAMILY_GMAC_PER_IMG[name] * B if name in FAMILY_GMAC_PER_IMG else None
+        rows.append({"family": name, "kernels": what, "us_per_step": round(1e3 * ms, 1), "gflop": None if gf is None else round(gf, 1),
+                     "tflops": None if gf is None else round(gf / ms, 1), "frac": None if gf is None else round(gf / ms / peak, 4)})
+    row("heads", heads_ms, "heads_fused_kernel (nine 3x3 64->256 + ABN + 1x1 branches)")
+    row("dcn_modules", t_backbone - t_base, "16 x (offset/mask conv + DCNv2 + BN + ReLU), 8 x up-sample + skip add (DLAUp / IDAUp)")
+    if t_f1 is not None:
+        row("trunk_levels_2_5", t_base - t_f1, "3x3 / stride-2 / 1x1 / Root concat convs + BN + ReLU + residual, max-pools of DLA levels 2-5")
+        row("f1", t_f1, "f1_fused_kernel (stem 7x7 -> level0 -> level1)")
+    else:
+        rows.append({"family": "base", "kernels": "stem + DLA levels 0-5", "us_per_step": round(1e3 * t_base, 1), "gflop": round(2 * 30.097 * B, 1),
+                     "tflops": round(2 * 30.097 * B / t_base, 1), "frac": round(2 * 30.097 * B / t_base / peak, 4)})
+    row("edge_fusion_and_decode", t_total - t_backbone - heads_ms, "edge row convs + scatter, NMS / top-K / 3D decode (latency-bound, no FLOP figure)")
+    return {"timing": "each stage captured alone on one stream (whole batch) and replayed 10x between HIP events; nested stages subtracted",
+            "single_stream_step_us": round(1e3 * t_total, 1), "peak_tflops": peak, "families": rows}
+
+
 def heads_traffic(dtype, B):
     """HBM bytes per heads launch from the committed PMC pass (rocprofv3 cannot run inside the bench)."""
     if os.path.exists(HEADS_TRAFFIC_JSON):
@@ -294,12 +368,26 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
             hm = torch.cat(hm)
             out = (det, topk, valid, hm)
         if leg:
+            feat = model.backbone.forward_nhwc(images)
+            pk = model.heads.predictor._pack(ops.compute_tag(model.heads.predictor, feat.dtype))
+            for _ in range(3):
+                ops.heads_fused(feat, pk)
+            heads_ms = _hip_event_ms(lambda: ops.heads_fused(feat, pk), 20)
+            fam = family_rooflines(model, images, tg, dtype, B, heads_ms)
             if rank != 0:
                 return None
-            return {"metric": "images/sec at 1280x384, DLA-34+DCNv2 forward+decode (%s)"
+            peak = PEAK_F32_TFLOPS if dtype == "fp32" else PEAK_BF16_TFLOPS
+            achieved = HEADS_GFLOP_PER_IMG * B / heads_ms
+            leg_roof = {"kernel": "heads_fused_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": None, "avg_launch_ms": round(heads_ms, 4),
+                        "algorithmic_flops_per_launch": HEADS_GFLOP_PER_IMG * B * 1e9,
+                        **({"mfma_products_per_multiply": 3, "frac_of_issued_mfma_work": round(3 * achieved / peak, 4)} if dtype == "fp16x2" else {})}
+            return {"roofline": leg_roof, "roofline_families": fam,
+                    "metric": "images/sec at 1280x384, DLA-34+DCNv2 forward+decode (%s)"
                               % ("the mode inside the north-star tolerance, f32 MFMA" if dtype == "fp32" else
                                  "inside the north-star tolerance: fp32 activations, split-precision fp16 (hi, lo) MFMA operands, fp32 accumulate"
                                  if dtype == "fp16x2" else
+                                 "BASELINE.json configs[4] (C5): batch 32 per GPU, hipGraph-captured DLA+DCN+heads+top-K" if B == 32 and dtype == "bf16" else
                                  "IEEE-half activations: the bf16 mode's kernels and speed, 4-8x closer to the reference"),
                     "value": round(n_img / elapsed, 2), "unit": "images/s", "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                     "steps": args.steps, "dtype": dtype, "batch_per_gpu": B, "launch": mode,
@@ -312,9 +400,10 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
             ops.heads_fused(feat, pk)
         heads_ms = _hip_event_ms(lambda: ops.heads_fused(feat, pk), 20)
 
+        fam = family_rooflines(model, images, tg, dtype, B, heads_ms)
     if rank != 0:
         return None
-    peak = PEAK_F32_TFLOPS if dtype == "fp32" else PEAK_BF16_TFLOPS          # (dense fp16 MFMA = the bf16 rate; fp16x2 issues 4 fp16 products per multiply)
+    peak = PEAK_F32_TFLOPS if dtype == "fp32" else PEAK_BF16_TFLOPS          # (dense fp16 MFMA = the bf16 rate; fp16x2 issues 3 fp16 products per multiply)
     achieved = HEADS_GFLOP_PER_IMG * B / heads_ms                # GFLOP / ms = TFLOP/s
     traffic, traffic_source = heads_traffic(dtype, B)
     res = {
@@ -338,7 +427,8 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "avg_launch_ms": round(heads_ms, 4),
                      "algorithmic_flops_per_launch": HEADS_GFLOP_PER_IMG * B * 1e9,
-                     **({"mfma_products_per_multiply": 4, "frac_of_issued_mfma_work": round(4 * achieved / peak, 4)} if dtype == "fp16x2" else {})},
+                     **({"mfma_products_per_multiply": 3, "frac_of_issued_mfma_work": round(3 * achieved / peak, 4)} if dtype == "fp16x2" else {})},
+        "roofline_families": fam,
     }
     if not args.no_cpu_baseline and world == 1:
         try:
@@ -525,9 +615,18 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dty
         convert_sync_batchnorm(model)
     B = args.batch
     seed = parallel.shard_seed(1000, rank, B)
-    imgs = S.synthetic_images(B, seed=seed).to(device)
-    targets = [make_train_target(S.synthetic_train_target(seed + i)).to(device) for i in range(B)]
-    targets = prepare_targets(model, targets, device)
+    # `nbatch` DISTINCT synthetic batches (images, objects, edge sequences), rotated step by step: the captured step's static buffers are
+    # overwritten in place before every replay (GraphedTrainStep.load_batch -- what do_train does with the loader's batches), inside the
+    # timed region
+    nbatch = max(1, int(args.train_batches))
+    batches = []
+    for k in range(nbatch):
+        sk = seed + 7919 * k
+        im_k = S.synthetic_images(B, seed=sk).to(device)
+        tg_k = prepare_targets(model, [make_train_target(S.synthetic_train_target(sk + i)).to(device) for i in range(B)], device)
+        batches.append((im_k, tg_k))
+    from monoflex_amd.engine.trainer import _clone_targets
+    imgs, targets = batches[0][0].clone(), _clone_targets(batches[0][1])       # the step's private static buffers (captured addresses)
     graphed = not args.no_graph                                        # (SyncBN's statistics collectives are captured with the step)
     opt = build_optimizer(model, cfg, capturable=graphed)
     scaler = LossScaler.for_model(model, device)                       # fp16 activations: dynamic loss scaling (None otherwise)
@@ -546,13 +645,25 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dty
 
         def step():
             return train_step(net, opt, imgs, targets, scaler=scaler)[0]
+    it = [0]
+    if graphed:
+        def run_one():
+            if nbatch > 1:
+                step.load_batch(*batches[it[0] % nbatch])
+            it[0] += 1
+            return step()
+    else:
+        def run_one():
+            im_k, tg_k = batches[it[0] % nbatch]
+            it[0] += 1
+            return train_step(net, opt, im_k, tg_k, scaler=scaler)[0]
     for _ in range(warmup):
-        loss = step()
+        loss = run_one()
     last = [loss]
 
     def run():
-        last[0] = step()
-    elapsed, n_img, all_s = timed_repeats(run, steps, 1 if leg else args.repeats, B * steps, device)
+        last[0] = run_one()
+    elapsed, n_img, all_s = timed_repeats(run, steps, args.train_repeats if leg else max(args.repeats, 1), B * steps, device)
     loss_v = float(last[0])
     overlap = bool(getattr(step, "overlap", False))
     loss_scale_info = {}
@@ -573,7 +684,7 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dty
         "dtype": dtype, "data": "synthetic",
         "config": {"workload": "MonoFlex training step (fwd + 11 losses + bwd + AdamW), batch %d per GPU, 1280x384, %s activations, "
                                "fp32 parameters/gradients (BASELINE.json configs[2]/[3] per-GPU shape)" % (B, dtype),
-                   "batch_per_gpu": B, "global_batch": B * world, "launch": mode,
+                   "batch_per_gpu": B, "global_batch": B * world, "launch": mode, "distinct_batches_rotated": nbatch,
                    "parallelism": "dp%d" % world if world > 1 else "single GPU", "sync_bn": sync_bn,
                    "overlap": overlap,
                    "timing": {"repeats": len(all_s), "reported": "median repeat", "steps_per_repeat": steps,
@@ -623,7 +734,11 @@ def main():
             # one (first multi-rank RCCL run of a path) costs the line nothing that was already measured.  N > 1: `train_local_bn` is the
             # data-parallel step with rank-local BN statistics (no collective inside the graphs), `train` / `train_fp16` synchronise
             # them like the reference (captured RCCL all-reduces); N = 1: the three coincide and `train_local_bn` is not run.
-            leg_list = [("fp32_parity", lambda: run_infer(args, rank, world, device, dtype="fp32", leg=True)),
+            import copy
+            args_b32 = copy.copy(args)
+            args_b32.batch = 32                                          # BASELINE.json configs[4] (C5): batch 32 per GPU, hipGraph, bf16
+            leg_list = [("b32", lambda: run_infer(args_b32, rank, world, device, dtype="bf16", leg=True)),
+                        ("fp32_parity", lambda: run_infer(args, rank, world, device, dtype="fp32", leg=True)),
                         ("fp16x2_parity", lambda: run_infer(args, rank, world, device, dtype="fp16x2", leg=True)),
                         ("pipeline", lambda: run_pipeline(args, rank, world, device)),
                         ("fp16", lambda: run_infer(args, rank, world, device, dtype="fp16", leg=True))]
@@ -642,7 +757,7 @@ def main():
                     for k, _ in leg_list:
                         out.setdefault(k, {"error": "leg did not finish within %d s" % args.leg_timeout})
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(3)                                               # the line is complete as far as it goes; a hung leg is NOT a clean run
             dog = threading.Timer(args.leg_timeout, bail)
             dog.daemon = True
             dog.start()
