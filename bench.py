@@ -62,9 +62,11 @@ def parse():
                     help="activation dtype (parameters, gradients and accumulators are fp32); fp16 training runs under the dynamic loss scaler; "
                          "fp16x2 (inference) = fp32 activations, every MFMA operand an fp16 (hi, lo) pair: fp32-grade results on the fp16 matrix pipe")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of captured hipGraphs")
-    ap.add_argument("--streams", type=int, default=2, help="inference: run the batch as this many sub-batches on forked streams inside the one "
-                                                           "captured step (independent sub-batches overlap their under-filled launches and tails; "
-                                                           "B=8: 3.10 -> 3.02 ms/step with 2, 3.16 with 4; 1 = one stream)")
+    ap.add_argument("--streams", type=int, default=0, help="inference: run the batch as this many sub-batches on forked streams inside the one "
+                                                           "captured step (independent sub-batches overlap their under-filled launches and tails). "
+                                                           "0 = per mode: 1 for the 16-bit modes (r05, B=8: 2.635 ms with 1, 2.680 with 2 -- the round's "
+                                                           "faster 3x3 / DCN kernels fill the chip from one 8-image launch), 2 for fp32 / fp16x2 "
+                                                           "(6.18 vs 6.70 ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-images", type=int, default=6)
     ap.add_argument("--split", action="store_true", help="train mode: the segmented data-parallel form (cut backward, flat gradient buffer, "
@@ -260,6 +262,9 @@ def family_rooflines(model, images, tg, dtype, B, heads_ms):
     base = bb.base
     cd = bb.compute_dtype
     with torch.no_grad():
+        feat = bb.forward_nhwc(images)
+        pk = model.heads.predictor._pack(ops.compute_tag(model.heads.predictor, feat.dtype))
+        heads_ms = _graph_replay_ms(lambda: ops.heads_fused(feat, pk))       # (same clock as the other stages: replayed, not eager launches)
         t_total = _graph_replay_ms(lambda: model.detect_device(images, *tg))
         t_backbone = _graph_replay_ms(lambda: bb.forward_nhwc(images))
         t_base = _graph_replay_ms(lambda: base(images, cd))
@@ -309,6 +314,7 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
     lib.load()
     model, sd, _ = build_model(dtype, device)
     B = args.batch
+    nstreams = args.streams if args.streams > 0 else (1 if dtype in ("bf16", "fp16") else 2)
     images = S.synthetic_images(B, 384, 1280, seed=parallel.shard_seed(1000, rank, B)).to(device)   # resident in HBM
     targets = [make_test_target(S.synthetic_target(320, 96)) for _ in range(B)]
     tg = model.device_targets(targets, device)
@@ -316,10 +322,10 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
     def step():
         return model.detect_device(images, *tg)
 
-    if args.streams > 1 and B % args.streams == 0 and B // args.streams >= 2 and not args.no_graph:
+    if nstreams > 1 and B % nstreams == 0 and B // nstreams >= 2 and not args.no_graph:
         # the batch as `streams` sub-batches on forked streams inside ONE step / one graph: independent sub-batches overlap their
         # under-filled launches (level 4/5 convs and DCNs run 120-240 workgroups on 256 CUs at B = 8) and their tails
-        ns = args.streams
+        ns = nstreams
         if B % ns:
             raise SystemExit("--streams must divide --batch")
         per = B // ns
@@ -416,7 +422,7 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
                    "timing": {"repeats": len(all_s), "reported": "median repeat", "steps_per_repeat": args.steps,
                               "ms_per_step_each": [round(1e3 * t / args.steps, 4) for t in all_s]},
                    "batch_per_gpu": B, "launch": mode, "parallelism": "replicas x%d (no collective on the inference path)" % world,
-                   "sub_batch_streams": args.streams if (args.streams > 1 and B % args.streams == 0 and B // args.streams >= 2 and not args.no_graph) else 1,
+                   "sub_batch_streams": nstreams if (nstreams > 1 and B % nstreams == 0 and B // nstreams >= 2 and not args.no_graph) else 1,
                    "model_tflops_per_s": round(FWD_GFLOP_PER_IMG * n_img / elapsed / 1e3, 2),
                    "detections_last_step": int(valid.sum().item()),
                    "h2d_excluded": True, "d2h_excluded": True,

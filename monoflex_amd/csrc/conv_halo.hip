@@ -142,10 +142,12 @@ __global__ __launch_bounds__(WN * WK * 64, 2) void conv3x3_wave_kernel(const T* 
                 const int pix = idx >> lgCPP, ch = idx & (CPP - 1);
                 const int py = pix / PW, px = pix - py * PW;
                 const int iy = y0 * g.S - 1 + py, ix = x0 * g.S - 1 + px;
-                u32x4 z = {0u, 0u, 0u, 0u};
-                if (idx < nchunks && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-                    z = *reinterpret_cast<const u32x4*>(xg + ((size_t)iy * g.W + ix) * g.C + ch * ELEMS);
-                pr[u] = z;
+                // (r05: branch-free -- a clamped, always valid address and a select; as `if (inside) load` the compiler serialised some of the
+                // batch's loads behind s_waitcnt vmcnt(0))
+                const bool in = idx < nchunks && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
+                const u32x4 zz = *reinterpret_cast<const u32x4*>(xg + ((size_t)cy * g.W + cx) * g.C + ch * ELEMS);
+                pr[u] = in ? zz : u32x4{0u, 0u, 0u, 0u};
             }
 #pragma unroll
             for (int u = 0; u < PU; ++u) {

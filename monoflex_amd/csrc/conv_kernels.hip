@@ -50,9 +50,10 @@ template <typename T, int BM, int NT, int KC> struct ConvALoader {
         for (int i = 0; i < R; ++i) {
             const int ih = ih0[i] + th, iw = iw0[i] + tw * g.dil_w;
             const bool v = ok[i] && tap_ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-            u32x4 z = {0u, 0u, 0u, 0u};
-            if (v) z = *reinterpret_cast<const u32x4*>(x + (size_t)(pix0[i] + ih * g.W + iw) * g.x_pixstride + ci);
-            regs[i] = z;
+            // (branch-free: clamped address + select, so the R loads of a k-iteration are all in flight together)
+            const int ihc = min(max(ih, 0), g.H - 1), iwc = min(max(iw, 0), g.W - 1);
+            const u32x4 z = *reinterpret_cast<const u32x4*>(x + (size_t)(pix0[i] + ihc * g.W + iwc) * g.x_pixstride + ci);
+            regs[i] = v ? z : u32x4{0u, 0u, 0u, 0u};
         }
     }
     __device__ __forceinline__ void store(char* As) const {
@@ -83,9 +84,8 @@ template <typename T, int BM, int NT, int KC> struct CatALoader {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int m = m0 + r0 + RPP * i;
-            u32x4 z = {0u, 0u, 0u, 0u};
-            if (m < s->M) z = *reinterpret_cast<const u32x4*>(base + (size_t)m * st);
-            regs[i] = z;
+            const u32x4 z = *reinterpret_cast<const u32x4*>(base + (size_t)min(m, s->M - 1) * st);
+            regs[i] = m < s->M ? z : u32x4{0u, 0u, 0u, 0u};
         }
     }
     __device__ __forceinline__ void store(char* As) const {
@@ -109,9 +109,18 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
     const T* x; const float* om; DcnGeom g; int c, r0, cur_tap;
     int oh_[R], ow_[R], pix0[R], mrow[R]; bool ok[R];
     int coff[R][4]; float cw[R][4];
+    float nom[R][3]; int nom_tap;                             // offsets / mask of tap `nom_tap`, fetched one tap ahead of their use (r05)
     u32x4 regs[R][4];
+    __device__ __forceinline__ void om_fetch(int tap) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float* o = om + (size_t)mrow[i] * 32;
+            nom[i][0] = o[2 * tap]; nom[i][1] = o[2 * tap + 1]; nom[i][2] = o[18 + tap];
+        }
+        nom_tap = tap;
+    }
     __device__ __forceinline__ void init(const T* x_, const float* om_, const DcnGeom& g_, int m0, int tid) {
-        x = x_; om = om_; g = g_; c = tid % KC; r0 = tid / KC; cur_tap = -1;
+        x = x_; om = om_; g = g_; c = tid % KC; r0 = tid / KC; cur_tap = -1; nom_tap = -1;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int m = m0 + r0 + RPP * i;
@@ -126,10 +135,14 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
     }
     __device__ __forceinline__ void tap_setup(int tap) {
         const int th = (tap * g.inv_kw) >> 16, tw = tap - th * g.kw;
+        if (nom_tap != tap) om_fetch(tap);                    // (first tap of the workgroup, or of a K split that starts mid-way)
+        float cur[R][3];
+#pragma unroll
+        for (int i = 0; i < R; ++i) { cur[i][0] = nom[i][0]; cur[i][1] = nom[i][1]; cur[i][2] = nom[i][2]; }
+        if (tap + 1 < g.kh * g.kw) om_fetch(tap + 1);         // in flight while this tap's corners are gathered and multiplied
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const float* o = om + (size_t)mrow[i] * 32;
-            const float dh = o[2 * tap], dw = o[2 * tap + 1], mk = o[18 + tap];
+            const float dh = cur[i][0], dw = cur[i][1], mk = cur[i][2];
             const float h = (float)(oh_[i] * g.stride - g.pad + th * g.dil) + dh;
             const float w = (float)(ow_[i] * g.stride - g.pad + tw * g.dil) + dw;
             const bool inside = ok[i] && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;

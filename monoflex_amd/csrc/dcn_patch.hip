@@ -106,14 +106,32 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const TX* __restrict_
         constexpr int ZBYTES = (4 * FM + 2) * ZW * ZPS, TLD = 36;
         float* tbuf = reinterpret_cast<float*>(smem + ((ZBYTES + 63) & ~63)) + wv * (16 * TLD);
         // ---- phase 0a: tile + 1 pixel, all 64 channels, zero outside the image (the conv's zero padding)
-        for (int idx = tid; idx < (4 * FM + 2) * ZW * 8; idx += 256) {
-            const int p = idx >> 3, col = idx & 7;
-            const int ry = p / ZW, rx = p - ry * ZW;
-            const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
-                v = to_h8<TX>(*reinterpret_cast<const u32x4*>(xb + ((size_t)gy * g.W + gx) * g.C + col * 8));
-            *reinterpret_cast<u32x4*>(smem + p * ZPS + (col << 4)) = v;
+        // (r05: branch-free -- clamped, always valid addresses, out-of-image chunks zeroed by a select -- and unrolled in batches of ZU loads:
+        // as `if (inside) load` in a rolled loop every iteration was load -> s_waitcnt vmcnt(0) -> convert -> ds_write, eleven exposed
+        // memory round trips per thread)
+        {
+            constexpr int ZN = (4 * FM + 2) * ZW * 8, ZU = 6;
+#pragma unroll
+            for (int base = 0; base < ZN; base += 256 * ZU) {
+                u32x4 zr[ZU];
+#pragma unroll
+                for (int u = 0; u < ZU; ++u) {
+                    int idx = base + u * 256 + tid;
+                    if (base + u * 256 + 256 > ZN) idx = idx < ZN ? idx : ZN - 1;
+                    const int p = idx >> 3, col = idx & 7;
+                    const int ry = p / ZW, rx = p - ry * ZW;
+                    const int gy = ty0 - 1 + ry, gx = tx0 - 1 + rx;
+                    const bool in = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+                    const int cy = min(max(gy, 0), g.H - 1), cx = min(max(gx, 0), g.W - 1);
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (uint32_t)((cy * g.W + cx) * g.C + col * 8));
+                    zr[u] = in ? v : u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int u = 0; u < ZU; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    if (base + u * 256 + 256 <= ZN || idx < ZN) *reinterpret_cast<u32x4*>(smem + (idx >> 3) * ZPS + ((idx & 7) << 4)) = to_h8<TX>(zr[u]);
+                }
+            }
         }
         f32x4 ao[FM][2];
 #pragma unroll
@@ -266,14 +284,33 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(const TX* __restrict_
         const int c0 = sl * CS;
         if (OF || sl) __syncthreads();                        // previous slice (or the offset conv's neighbourhood) fully consumed
         // ---- patch load: pix x 8 columns of 16 bytes (bf16 -> fp16), zero outside the image
-        for (int idx = tid; idx < SM::pix * NC; idx += 256) {
-            const int p = idx / NC, col = idx % NC;
-            const int ry = p / kPW, rx = p - ry * kPW;
-            const int gy = py0 + ry, gx = px0 + rx;
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W)
-                v = to_h8<TX>(*reinterpret_cast<const u32x4*>(xb + ((size_t)gy * g.W + gx) * g.C + c0 + col * 8));
-            *reinterpret_cast<u32x4*>(smem + (PD ? p * PB + (col << 4) : ((p * PB + ((p & (NC - 1)) << 4)) ^ (col << 4)))) = v;
+        // (r05: branch-free and in batches of PLU loads in flight -- see phase 0a; the rolled `if (inside) load` loop waited for every single
+        // load: 16 exposed round trips per thread and slice, the 18 us "patch load" line of profiles/r03_dcn_patch_probes.md)
+        {
+            constexpr int PN = SM::pix * NC, PLU = 8;
+#pragma unroll
+            for (int base = 0; base < PN; base += 256 * PLU) {
+                u32x4 pr[PLU];
+#pragma unroll
+                for (int u = 0; u < PLU; ++u) {
+                    int idx = base + u * 256 + tid;
+                    if (base + u * 256 + 256 > PN) idx = idx < PN ? idx : PN - 1;
+                    const int p = idx / NC, col = idx % NC;
+                    const int ry = p / kPW, rx = p - ry * kPW;
+                    const int gy = py0 + ry, gx = px0 + rx;
+                    const bool in = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+                    const int cy = min(max(gy, 0), g.H - 1), cx = min(max(gx, 0), g.W - 1);
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + (uint32_t)((cy * g.W + cx) * g.C + c0 + col * 8));
+                    pr[u] = in ? v : u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int u = 0; u < PLU; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    const int p = idx / NC, col = idx % NC;
+                    if (base + u * 256 + 256 <= PN || idx < PN)
+                        *reinterpret_cast<u32x4*>(smem + (PD ? p * PB + (col << 4) : ((p * PB + ((p & (NC - 1)) << 4)) ^ (col << 4)))) = to_h8<TX>(pr[u]);
+                }
+            }
         }
         // weights of the slice's first two steps while the patch lands
         constexpr int RD = FN >= 8 ? 2 : 3;                   // weight ring depth (registers: RD*FN*4)

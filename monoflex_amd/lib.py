@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libmonoflex_hip.so")
+LIB_PATH = os.environ.get("MFX_LIB_PATH") or os.path.join(HERE, "csrc", "libmonoflex_hip.so")      # (MFX_LIB_PATH: another BUILD of the same library, for A/B timing of kernel revisions: tools/*_bench.py)
 
 MFX_F32, MFX_BF16, MFX_F16, MFX_F16X2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_DCN_OFFMASK = 0, 1, 2, 3
