@@ -433,6 +433,44 @@ typedef struct mfx_head_sparse_desc {
     void* arena; size_t arena_bytes;
 } mfx_head_sparse_desc;
 int mfx_head_sparse_fwd(const mfx_head_sparse_desc* d, void* stream);
+/* The same regression branches WITHOUT their dense trunk maps: batch statistics from the patch Gram matrix of the shared 64-channel input,
+ * trunk values at the object rows (and, for branch `extra_branch`, at `Ne` edge-sequence pixels) only -- csrc/gram_heads.hip, the hand-written
+ * forward and backward of monoflex_amd/gram_heads.py (reference model/head/detector_predictor.py:125-165).  One descriptor for the whole node;
+ * the host calls the phases in order and runs the library's own launches between them:
+ *   0: A = gathered 3x3 patches of [frame rows | object rows | edge rows] ([F+N+Ne][576], activation type), Wkc / WkT = the trunk weights as one matrix
+ *      -> host: P = A_f^T A_f (mfx_conv_wgrad_oihw), csA = column sums of A_f, R5 = the displacement rows -2, -1, 0 of the 5x5 autocorrelation of x
+ *         ([64][64][3][5]; the other two rows follow from R[a][b][d] = R[b][a][-d]), S0 = column sums of x
+ *   1: G, m, Tm = Wk G (f32 MFMA), sums = [Wk m | diag(Wk G Wk^T)]          -> host: all-reduce of `sums` when the ABNs are synchronised
+ *   2: statistics + running statistics, Y / act rows, out = 1x1 heads
+ *   3: row gradients (d y as hi + lo halves), d W2 / d b2, d gamma / d beta, ds = [d s1 | d s2]      -> host: all-reduce of `ds` (SyncBN)
+ *   4: scal[0] = max |d s2|, Dw16 = d s2 / scal[0] * Wk, d m                -> host: dGs = Dw16^T Wkc (mfx_conv_wgrad_oihw)
+ *   5: 5x5 kernel Kx (normalised, OIHW fp32) + its epilogue vectors, d A_frame, d A rows      -> host: pack Kx, dx = conv5x5(x), dwo / dwe = d y^T A
+ *   6: dx += border pixels (fixed order) + object / edge rows (packed 16-bit atomics)
+ *   7: trunk weight gradients dwt[b] (256, 64, 3, 3) fp32
+ * dtype MFX_BF16 / MFX_F16 (fp32 activations keep the torch form). */
+typedef struct mfx_gram_desc {
+    const void* x; const float* rows; const long long* extra_rows;
+    int B, H, W, C, N, Ne, F, nbranch, extra_branch, ld_out, dtype, nring, ring_width, arena_bytes;   /* arena: [dsum 2 CH | scal 4 | d W2 | d b2] fp32, contiguous from `dsum`, cleared by phase 3 */
+    float momentum, Mt;
+    const void* wk[MFX_HEAD_MAX_BRANCH];                       /* packed trunk weights [256][576], k = tap * 64 + c */
+    const float* gamma[MFX_HEAD_MAX_BRANCH]; const float* beta[MFX_HEAD_MAX_BRANCH];
+    const float* w2[MFX_HEAD_MAX_BRANCH]; const float* b2[MFX_HEAD_MAX_BRANCH];
+    float* run_mean[MFX_HEAD_MAX_BRANCH]; float* run_var[MFX_HEAD_MAX_BRANCH]; long long* nbt[MFX_HEAD_MAX_BRANCH];
+    float* dgamma[MFX_HEAD_MAX_BRANCH]; float* dbeta[MFX_HEAD_MAX_BRANCH]; float* dw2[MFX_HEAD_MAX_BRANCH]; float* db2[MFX_HEAD_MAX_BRANCH];
+    float* dwt[MFX_HEAD_MAX_BRANCH];
+    float eps[MFX_HEAD_MAX_BRANCH];
+    int k[MFX_HEAD_MAX_BRANCH], off[MFX_HEAD_MAX_BRANCH];
+    /* forward buffers */
+    void* A; void* Wkc; void* WkT;
+    const float* R5; const float* S0; const float* P; const float* csA;
+    float* G; float* m; float* Tm; float* sums; float* stat; float* Y; float* Ye; float* act; void* act_e; float* out;
+    /* backward buffers */
+    const float* dout; const void* dact_e;
+    void* dYh; void* dYl; void* dYeh; void* dYel;
+    float* dsum; float* ds; float* scal; void* Dw16; float* dm; const float* dGs; float* Kx; void* Gn16; float* cscale; float* cshift;
+    float* dAf; float* dArows; void* dx; const long long* ring_inv; const long long* ring_idx; const float* dwo; const float* dwe;
+} mfx_gram_desc;
+int mfx_gram_heads(const mfx_gram_desc* d, int phase, void* stream);
 int mfx_head_sparse_bwd(const mfx_head_sparse_desc* d, void* stream);
 /* Batch statistics of a train-mode BN without applying it: mean / rstd (C floats each), running statistics and
  * num_batches_tracked updated as mfx_bn_train_fwd does; `scratch` as there (zero before, zero after). */

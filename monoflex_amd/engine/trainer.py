@@ -445,8 +445,13 @@ class GraphedTrainStep:
     def load_batch(self, images, targets=None):
         self.images.copy_(images, non_blocking=True)
         if targets is not None:
-            for dst, src in zip(_target_tensors(self.targets), _target_tensors(targets)):
-                dst.copy_(src, non_blocking=True)
+            dsts, srcs = _target_tensors(self.targets), _target_tensors(targets)
+            if dsts and dsts[0].is_cuda and all(s.is_cuda and s.dtype == d_.dtype and s.shape == d_.shape for s, d_ in zip(srcs, dsts)):
+                # one multi-tensor copy per dtype instead of ~20 device-to-device memcpy launches (8 us of host gap each in front of every replay)
+                torch._foreach_copy_(dsts, srcs)
+            else:
+                for dst, src in zip(dsts, srcs):
+                    dst.copy_(src, non_blocking=True)
 
     def __call__(self):
         if not self.use_graphs:

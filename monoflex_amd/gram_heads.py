@@ -21,6 +21,8 @@ with x as input AND as output gradient (one launch of the library's weight-gradi
 centred on the one-pixel FRAME around the image (B x 2 (H + W + 2) rows, a small GEMM) -- which is also the whole of the border handling.
 The small algebra (576-wide matrices, N <= a few hundred object rows) runs as torch ops on fp32 tensors inside the node and is differentiated
 by torch; the two dense pieces are library launches (mfx_conv_wgrad_oihw forward, a 5x5 mfx_conv2d_nhwc backward)."""
+import ctypes
+
 import torch
 import torch.nn.functional as F_
 
@@ -295,6 +297,171 @@ class GramRegHeadsFn(torch.autograd.Function):
         return (dx, None, None, None, None, None, None, None, *pg)
 
 
+# ---- the same node as HIP kernels (csrc/gram_heads.hip): 16-bit activations on the GPU; everything else keeps the torch form above ----------
+HIP_NODE = [__import__("os").environ.get("MFX_GRAM_HIP", "1") != "0"]
+
+
+def _autocorr5_rows(x):
+    """The displacement rows dy = -2, -1, 0 of the 5x5 autocorrelation: R[a][b][kh][kw] = sum_q x[q][a] * x~[q + (kh - 2, kw - 2)][b], kh in 0..2 --
+    the weight gradient of a 3x5 convolution (padding 2 x 2, outputs on the input grid) whose input and output gradient are both x.  The rows
+    dy = 1, 2 are R[b][a][-d] (the same products), so 15 instead of 25 taps are computed (csrc/gram_heads.hip gram_build_kernel)."""
+    B, H, W, C = x.shape
+    dw = torch.empty(C, C, 3, 5, dtype=torch.float32, device=x.device)
+    ws = ops._splitk_workspace(x.device)
+    L.check(L.load().mfx_conv_wgrad_oihw(ops._ptr(x), ops._ptr(x), ops._ptr(dw), B, H, W, C, C, 3, 5, 1, 2, 2, H, W, C, C, C, C, ops._dt(x.dtype),
+                                         ops._ptr(ws), ws.numel() * 4, ops._stream()), "mfx_conv_wgrad_oihw")
+    return dw
+
+
+def _dense_wgrad(xm, dym, out):
+    """out[o][c] = sum_r dym[r][o] * xm[r][c]  (fp32): the library's weight-gradient launch on two dense row-major 16-bit matrices."""
+    R, Kc = xm.shape
+    Co = dym.shape[1]
+    ws = ops._splitk_workspace(xm.device)
+    L.check(L.load().mfx_conv_wgrad_oihw(ops._ptr(xm), ops._ptr(dym), ops._ptr(out), 1, 1, R, Kc, Kc, 1, 1, 1, 0, 0, 1, R, Co, Co, Co, Kc, ops._dt(xm.dtype),
+                                         ops._ptr(ws), ws.numel() * 4, ops._stream()), "mfx_conv_wgrad_oihw")
+    return out
+
+
+class GramRegHeadsHipFn(torch.autograd.Function):
+    """GramRegHeadsFn with every torch op replaced by a kernel of csrc/gram_heads.hip or a library launch (autocorrelation, column sums, the three
+    weight-gradient-shaped GEMMs, the 5x5 data-gradient conv): no `at::native` kernel, no vendor GEMM inside the node; the backward is written
+    out by hand there.  SyncBN: the two small all-reduces ([sum y | sum y^2] forward, their gradients backward) stay torch.distributed calls."""
+
+    @staticmethod
+    def forward(ctx, x, rows, abns, offs, ld_out, sync, extra_branch, extra_rows, *ts):
+        nb = len(abns)
+        ws_, gammas, betas, w2s, b2s = (ts[i * nb:(i + 1) * nb] for i in range(5))
+        x = AG._c(x)
+        rows = AG._c(rows)
+        B, H, W, C = x.shape
+        M, dev, dt = B * H * W, x.device, x.dtype
+        geo = _geometry(B, H, W, dev)
+        N = rows.shape[0]
+        Ne = int(extra_rows.numel()) if (extra_rows is not None and extra_branch >= 0) else 0
+        F, CH = B * geo["nf"], 256 * nb
+        f32 = dict(dtype=torch.float32, device=dev)
+        d = L.GramDesc()
+        d.x, d.rows = x.data_ptr(), rows.data_ptr()
+        er = AG._c(extra_rows.long()) if Ne else None
+        d.extra_rows = er.data_ptr() if Ne else None
+        d.B, d.H, d.W, d.C, d.N, d.Ne, d.F, d.nbranch = B, H, W, C, N, Ne, F, nb
+        d.extra_branch, d.ld_out, d.dtype = (extra_branch if Ne else -1), ld_out, ops._dt(dt)
+        keep = [er]
+        packs = [AG._pack_weight(w, dt, 0, 256, C, 1, 1, 1) for w in ws_]          # [256][576], k = tap * 64 + c: the step's batched packing
+        w2c = [AG._c(w.detach().float().view(w.shape[0], -1)) for w in w2s]
+        b2c = [None if b is None else AG._c(b.detach().float()) for b in b2s]
+        for i in range(nb):
+            assert packs[i].K_pad == 9 * C and packs[i].w.shape[0] == 256
+            d.wk[i] = packs[i].w.data_ptr()
+            d.gamma[i], d.beta[i] = gammas[i].data_ptr(), betas[i].data_ptr()
+            d.w2[i] = w2c[i].data_ptr()
+            d.b2[i] = b2c[i].data_ptr() if b2c[i] is not None else None
+            d.eps[i], d.k[i], d.off[i] = float(abns[i].eps), int(w2c[i].shape[0]), int(offs[i])
+            a = abns[i]
+            if a.track_running_stats and a.running_mean is not None:
+                d.run_mean[i], d.run_var[i] = a.running_mean.data_ptr(), a.running_var.data_ptr()
+                d.nbt[i] = a.num_batches_tracked.data_ptr() if a.num_batches_tracked is not None else None
+        d.momentum = float(abns[0].momentum if abns[0].momentum is not None else 0.1)
+        A = torch.empty((F + N + Ne, 9 * C), dtype=dt, device=dev)
+        Wkc, WkT = torch.empty((CH, 9 * C), dtype=dt, device=dev), torch.empty((9 * C, CH), dtype=dt, device=dev)
+        d.A, d.Wkc, d.WkT = A.data_ptr(), Wkc.data_ptr(), WkT.data_ptr()
+        lib_, st = L.load(), ops._stream
+        L.check(lib_.mfx_gram_heads(ctypes.byref(d), 0, st()), "mfx_gram_heads(0)")
+        R5, S0 = _autocorr5_rows(x), AG._colsum(x)
+        P = _dense_wgrad(A[:F], A[:F], torch.empty((9 * C, 9 * C), **f32))
+        csA = AG._colsum(A[:F])
+        G, m, Tm = torch.empty((9 * C, 9 * C), **f32), torch.empty(9 * C, **f32), torch.empty((CH, 9 * C), **f32)
+        sums, stat = torch.empty(2 * CH, **f32), torch.empty(5 * CH, **f32)
+        d.R5, d.S0, d.P, d.csA, d.G, d.m, d.Tm, d.sums, d.stat = (t.data_ptr() for t in (R5, S0, P, csA, G, m, Tm, sums, stat))
+        L.check(lib_.mfx_gram_heads(ctypes.byref(d), 1, st()), "mfx_gram_heads(1)")
+        group = AG._sync_group(sync)
+        Mt = M
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=group)
+            Mt = M * dist.get_world_size(group)
+        d.Mt = float(Mt)
+        Y, act, out = torch.empty((N, CH), **f32), torch.empty((N, CH), **f32), torch.empty((N, ld_out), **f32)
+        Ye = torch.empty((max(Ne, 1), 256), **f32)
+        act_e = torch.empty((max(Ne, 1), 256), dtype=dt, device=dev)
+        d.Y, d.act, d.out, d.Ye, d.act_e = Y.data_ptr(), act.data_ptr(), out.data_ptr(), Ye.data_ptr(), act_e.data_ptr()
+        covered = sorted((int(o), int(o) + int(w.shape[0])) for o, w in zip(offs, w2c))
+        if covered[0][0] != 0 or covered[-1][1] != ld_out or any(a[1] != b[0] for a, b in zip(covered, covered[1:])):
+            out.fill_(0.0)                                     # (columns no branch of this call owns: the caller overwrites them)
+        L.check(lib_.mfx_gram_heads(ctypes.byref(d), 2, st()), "mfx_gram_heads(2)")
+        ctx.desc, ctx.group, ctx.geo = d, group, geo
+        ctx.keep = keep + [x, rows, packs, w2c, b2c, A, Wkc, WkT, R5, S0, P, csA, G, m, Tm, sums, stat, Y, act, Ye, act_e, list(gammas), list(betas)]
+        ctx.shapes = ([w.shape for w in ws_], [w.shape for w in w2s], [None if b is None else b.shape for b in b2s], nb, Ne, F, CH, N)
+        return out, (act_e[:Ne] if Ne else None)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout, dact_e):
+        d, geo = ctx.desc, ctx.geo
+        wshapes, w2shapes, b2shapes, nb, Ne, F, CH, N = ctx.shapes
+        x = ctx.keep[1]
+        A = ctx.keep[6]
+        Wkc = ctx.keep[7]
+        dev, dt = x.device, x.dtype
+        B, H, W, C = x.shape
+        f32 = dict(dtype=torch.float32, device=dev)
+        dout = AG._c(dout.float())
+        dae = AG._c(dact_e.to(dt)) if (dact_e is not None and Ne) else None
+        d.dout, d.dact_e = dout.data_ptr(), (dae.data_ptr() if dae is not None else None)
+        dYh, dYl = torch.empty((max(N, 1), CH), dtype=dt, device=dev), torch.empty((max(N, 1), CH), dtype=dt, device=dev)
+        dYeh, dYel = torch.empty((max(Ne, 1), 256), dtype=dt, device=dev), torch.empty((max(Ne, 1), 256), dtype=dt, device=dev)
+        # one arena, cleared by ONE fill inside phase 3: [d sc | d sh] sums, the four scalars, every branch's d W2 and d b2 (all accumulated into)
+        ks = [int(d.k[i]) for i in range(nb)]
+        arena = torch.empty(2 * CH + 4 + sum(k * 256 for k in ks) + sum(k for k, sh_ in zip(ks, b2shapes) if sh_ is not None), **f32)
+        dsum, scal, o = arena[:2 * CH], arena[2 * CH:2 * CH + 4], 2 * CH + 4
+        dw2, db2 = [], []
+        for k in ks:
+            dw2.append(arena[o:o + k * 256].view(k, 256)); o += k * 256
+        for k, sh_ in zip(ks, b2shapes):
+            db2.append(None if sh_ is None else arena[o:o + k]); o += 0 if sh_ is None else k
+        d.arena_bytes = arena.numel() * 4
+        ds = torch.empty(2 * CH, **f32)
+        dgam = [torch.empty(256, **f32) for _ in range(nb)]
+        dbet = [torch.empty(256, **f32) for _ in range(nb)]
+        dwt = [torch.empty((256, C, 3, 3), **f32) for _ in range(nb)]
+        for i in range(nb):
+            d.dgamma[i], d.dbeta[i], d.dw2[i], d.dwt[i] = dgam[i].data_ptr(), dbet[i].data_ptr(), dw2[i].data_ptr(), dwt[i].data_ptr()
+            d.db2[i] = db2[i].data_ptr() if db2[i] is not None else None
+        d.dYh, d.dYl, d.dYeh, d.dYel, d.dsum, d.ds, d.scal = (t.data_ptr() for t in (dYh, dYl, dYeh, dYel, dsum, ds, scal))
+        lib_, st = L.load(), ops._stream
+        L.check(lib_.mfx_gram_heads(ctypes.byref(d), 3, st()), "mfx_gram_heads(3)")
+        if ctx.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(ds, group=ctx.group)
+        Dw16, dm = torch.empty((CH, 9 * C), dtype=dt, device=dev), torch.empty(9 * C, **f32)
+        d.Dw16, d.dm = Dw16.data_ptr(), dm.data_ptr()
+        L.check(lib_.mfx_gram_heads(ctypes.byref(d), 4, st()), "mfx_gram_heads(4)")
+        dGs = _dense_wgrad(Wkc, Dw16, torch.empty((9 * C, 9 * C), **f32))
+        Kx, Gn16 = torch.empty((C, C, 5, 5), **f32), torch.empty((9 * C, 9 * C), dtype=dt, device=dev)
+        cscale, cshift = torch.empty(C, **f32), torch.empty(C, **f32)
+        dAf, dArows = torch.empty((max(F, 1), 9 * C), **f32), torch.empty((max(N + Ne, 1), 9 * C), **f32)
+        d.dGs, d.Kx, d.Gn16, d.cscale, d.cshift, d.dAf, d.dArows = (t.data_ptr() for t in (dGs, Kx, Gn16, cscale, cshift, dAf, dArows))
+        L.check(lib_.mfx_gram_heads(ctypes.byref(d), 5, st()), "mfx_gram_heads(5)")
+        p = AG._pack_weight(Kx, dt, 0, C, C, 1, 2, 2)           # one library launch (a temporary: packed now)
+        p.scale, p.shift = cscale, cshift
+        dx = ops.conv2d(x, p)
+        d.dx = dx.data_ptr()
+        d.ring_inv, d.ring_idx = geo["inv"].data_ptr(), geo["ring_idx"].data_ptr()
+        d.nring, d.ring_width = int(geo["ring_idx"].numel()), int(geo["inv"].shape[1])
+        L.check(lib_.mfx_gram_heads(ctypes.byref(d), 6, st()), "mfx_gram_heads(6)")
+        dwo = _dense_wgrad(A[F:F + N], dYh[:N], torch.empty((CH, 9 * C), **f32)) if N else torch.zeros((CH, 9 * C), **f32)
+        dwe = _dense_wgrad(A[F + N:F + N + Ne], dYeh[:Ne], torch.empty((256, 9 * C), **f32)) if Ne else None
+        d.dwo, d.dwe = dwo.data_ptr(), (dwe.data_ptr() if dwe is not None else None)
+        L.check(lib_.mfx_gram_heads(ctypes.byref(d), 7, st()), "mfx_gram_heads(7)")
+        ctx.keep = None
+        g_w2 = [dw2[i].view(w2shapes[i]) for i in range(nb)]
+        return (dx if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None, *dwt, *dgam, *dbet, *g_w2, *db2)
+
+
 def gram_reg_heads(x, rows, abns, offs, ld_out, trunk_ws, gammas, betas, w2s, b2s, sync=True, extra_branch=-1, extra_rows=None):
     """-> (table [N][ld_out], activation rows of branch `extra_branch` at the flat pixel indices `extra_rows` in x's dtype, or None)."""
+    if HIP_NODE[0] and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.shape[-1] == 64 and not torch.are_deterministic_algorithms_enabled() \
+            and all(w.shape[0] == 256 and tuple(w.shape[1:]) == (64, 3, 3) for w in trunk_ws) and len(trunk_ws) <= 8:
+        return GramRegHeadsHipFn.apply(x, rows, tuple(abns), tuple(offs), ld_out, sync, extra_branch, extra_rows, *trunk_ws, *gammas, *betas, *w2s, *b2s)
     return GramRegHeadsFn.apply(x, rows, tuple(abns), tuple(offs), ld_out, sync, extra_branch, extra_rows, *trunk_ws, *gammas, *betas, *w2s, *b2s)

@@ -83,6 +83,17 @@ class HeadSparseDesc(ctypes.Structure):                         # mfx_head_spars
         [(n, c_void_p * HEAD_MAX_BRANCH) for n in ("sums", "dw2", "db2", "dx")] + [("arena", c_void_p), ("arena_bytes", c_size_t)]
 
 
+class GramDesc(ctypes.Structure):                               # mfx_gram_desc (csrc/gram_heads.hip)
+    _fields_ = [("x", c_void_p), ("rows", c_void_p), ("extra_rows", c_void_p)] + \
+        [(n, c_int) for n in ("B", "H", "W", "C", "N", "Ne", "F", "nbranch", "extra_branch", "ld_out", "dtype", "nring", "ring_width", "arena_bytes")] + \
+        [("momentum", c_float), ("Mt", c_float)] + \
+        [(n, c_void_p * HEAD_MAX_BRANCH) for n in ("wk", "gamma", "beta", "w2", "b2", "run_mean", "run_var", "nbt", "dgamma", "dbeta", "dw2", "db2", "dwt")] + \
+        [("eps", c_float * HEAD_MAX_BRANCH), ("k", c_int * HEAD_MAX_BRANCH), ("off", c_int * HEAD_MAX_BRANCH)] + \
+        [(n, c_void_p) for n in ("A", "Wkc", "WkT", "R5", "S0", "P", "csA", "G", "m", "Tm", "sums", "stat", "Y", "Ye", "act", "act_e", "out",
+                                 "dout", "dact_e", "dYh", "dYl", "dYeh", "dYel", "dsum", "ds", "scal", "Dw16", "dm", "dGs", "Kx", "Gn16", "cscale", "cshift",
+                                 "dAf", "dArows", "dx", "ring_inv", "ring_idx", "dwo", "dwe")]
+
+
 OBJ_ROW, OBJ_TERMS, OBJ_VALUES = 72, 10, 24                    # MFX_OBJ_ROW / MFX_OBJ_TERMS / MFX_OBJ_VALUES
 
 
@@ -134,6 +145,7 @@ SYMBOLS = {
     "mfx_pack_conv_weights_batched": (_I, [_P, _P, _I, ctypes.c_longlong, _I, _P]),
     "mfx_head_sparse_fwd": (_I, [ctypes.POINTER(HeadSparseDesc), _P]),
     "mfx_head_sparse_bwd": (_I, [ctypes.POINTER(HeadSparseDesc), _P]),
+    "mfx_gram_heads": (_I, [ctypes.POINTER(GramDesc), _I, _P]),
     "mfx_bn_train_stats": (_I, [_P] * 6 + [_F, _F, ctypes.c_long, _I, _I, _P, _P, _P, _I, _P]),
     "mfx_bn_scratch_bytes": (_S, []),
     "mfx_bn_ncopy": (_I, [_I]),

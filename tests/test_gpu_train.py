@@ -1173,3 +1173,74 @@ def test_fused_object_loss_inside_a_wider_map_and_weighted_terms():
     assert float((wide.grad[..., 8:58] - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
     for k, v in zip(('depth_MAE', 'center_MAE', '02_MAE', '13_MAE', 'lower_MAE', 'hard_MAE', 'soft_MAE', 'mean_MAE'), logged[3:11].tolist()):
         assert abs(v - logs[k]) <= 1e-4 * max(1.0, abs(logs[k])), k
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("with_edge", [False, True])
+def test_gram_heads_hip_node_equals_the_torch_node(dt, with_edge):
+    """csrc/gram_heads.hip + GramRegHeadsHipFn (hand-written forward and backward: no torch op, no vendor GEMM inside the node) against
+    GramRegHeadsFn (the torch-differentiated form, itself pinned to fp64 dense layers above and on the CPU): table, edge activation rows,
+    running statistics and every gradient -- feature map, trunk weights, ABN weight / bias, 1x1 weights / biases -- on border / coincident /
+    empty object rows and, `with_edge`, the 3d_offset branch's activation at edge-sequence pixels (duplicates included).
+    Reference: model/head/detector_predictor.py:125-165."""
+    from monoflex_amd import gram_heads as GH
+    from monoflex_amd.model.head.detector_predictor import InPlaceABN
+    dtype = DT[dt]
+    g = torch.Generator().manual_seed(31)
+    B, H, W, Cin, C, N = 2, 14, 22, 64, 256, 24
+    ks, offs = (4, 2, 20, 3), (0, 4, 6, 26)
+    rows = torch.zeros(N, 72)
+    rows[:, 0] = (torch.rand(N, generator=g) > 0.2).float()
+    rows[:, 57] = torch.randint(0, B, (N,), generator=g).float()
+    rows[:, 2] = torch.randint(0, W, (N,), generator=g).float()
+    rows[:, 3] = torch.randint(0, H, (N,), generator=g).float()
+    rows[0, 2:4] = torch.tensor([0.0, 0.0]); rows[1, 2:4] = torch.tensor([W - 1.0, H - 1.0]); rows[3] = rows[5]
+    rows[[0, 1, 3, 5], 0] = 1.0
+    x = (torch.randn(B, H, W, Cin, generator=g) * 0.8 + 0.1).to(dtype)
+    wt = [torch.randn(C, Cin, 3, 3, generator=g) / 24.0 for _ in ks]
+    w2 = [torch.randn(k, C, 1, 1, generator=g) * 0.1 for k in ks]
+    b2 = [torch.randn(k, generator=g) * 0.1 for k in ks]
+    gam = [torch.rand(C, generator=g) + 0.5 for _ in ks]
+    bet = [torch.randn(C, generator=g) * 0.3 for _ in ks]
+    dout = torch.randn(N, 50, generator=g)
+    extra = None
+    if with_edge:                                              # border pixels of both images, with repeats (replicate padding of the edge sequence)
+        pix = [b * H * W + y * W + 0 for b in range(B) for y in range(H)] + [b * H * W + 0 * W + xx for b in range(B) for xx in range(W)]
+        extra = torch.tensor(pix + pix[:5] + [pix[-1]] * 3, dtype=torch.long)
+        dact = torch.randn(extra.numel(), C, generator=g)
+    res = {}
+    for hip in (False, True):
+        GH.HIP_NODE[0] = hip
+        try:
+            abns = []
+            for i in range(len(ks)):
+                h = InPlaceABN(C).to(DEV)
+                with torch.no_grad():
+                    h.weight.copy_(gam[i]); h.bias.copy_(bet[i])
+                abns.append(h)
+            xd = x.to(DEV).requires_grad_()
+            wtd = [w.to(DEV).requires_grad_() for w in wt]
+            wd = [w.to(DEV).requires_grad_() for w in w2]
+            bd = [b.to(DEV).requires_grad_() for b in b2]
+            out, ae = GH.gram_reg_heads(xd, rows.to(DEV), abns, offs, 50, wtd, [h.weight for h in abns], [h.bias for h in abns], wd, bd, sync=False,
+                                        extra_branch=1 if with_edge else -1, extra_rows=extra.to(DEV) if with_edge else None)
+            loss = (out * dout.to(DEV)).sum()
+            if with_edge:
+                loss = loss + (ae.float() * dact.to(DEV)).sum()
+            loss.backward()
+            torch.cuda.synchronize()
+            res[hip] = dict(out=out.detach().float().cpu(), ae=None if ae is None else ae.detach().float().cpu(), dx=xd.grad.float().cpu(),
+                            dw=[w.grad.cpu() for w in wtd], dg=[h.weight.grad.cpu() for h in abns], db=[h.bias.grad.cpu() for h in abns],
+                            dw2=[w.grad.cpu() for w in wd], db2=[b.grad.cpu() for b in bd],
+                            rm=[h.running_mean.cpu() for h in abns], rv=[h.running_var.cpu() for h in abns], nbt=[int(h.num_batches_tracked) for h in abns])
+        finally:
+            GH.HIP_NODE[0] = True
+    a, b_ = res[True], res[False]
+    assert _rel(a["out"], b_["out"]) < 2e-3, ("out", _rel(a["out"], b_["out"]))
+    if with_edge:
+        assert _rel(a["ae"], b_["ae"]) < 1.5e-2, ("act_e", _rel(a["ae"], b_["ae"]))          # (both rounded to the 16-bit type)
+    assert _rel(a["dx"], b_["dx"]) < 2e-2, ("dx", _rel(a["dx"], b_["dx"]))
+    for i in range(len(ks)):
+        for key, tol in (("dw", 1e-2), ("dg", 5e-3), ("db", 5e-3), ("dw2", 2e-3), ("db2", 1e-4), ("rm", 1e-4), ("rv", 1e-3)):
+            assert _rel(a[key][i], b_[key][i]) < tol, (key, i, _rel(a[key][i], b_[key][i]))
+    assert a["nbt"] == b_["nbt"] == [1] * len(ks)

@@ -31,7 +31,7 @@ def test_ctypes_struct_layout_matches_header_sizes(tmp_path):
     from monoflex_amd import lib as L
     pairs = [("mfx_conv_desc", L.ConvDesc), ("mfx_dcn_desc", L.DcnDesc), ("mfx_cat_desc", L.CatDesc), ("mfx_heads_desc", L.HeadsDesc),
              ("mfx_pack_desc", L.PackDesc), ("mfx_object_loss_cfg", L.ObjectLossCfg), ("mfx_head_sparse_desc", L.HeadSparseDesc),
-             ("mfx_kitti_desc", L.KittiDesc), ("mfx_kitti_eval_desc", L.KittiEvalDesc)]
+             ("mfx_gram_desc", L.GramDesc), ("mfx_kitti_desc", L.KittiDesc), ("mfx_kitti_eval_desc", L.KittiEvalDesc)]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) {\n%s\nreturn 0; }\n'
                    % (os.path.join(ROOT, "include", "monoflex_hip.h"),
@@ -151,7 +151,8 @@ def test_ctypes_layouts_equal_the_c_compilers(tmp_path):
     import subprocess
     from monoflex_amd import lib as L
     pairs = {"mfx_conv_desc": L.ConvDesc, "mfx_cat_desc": L.CatDesc, "mfx_dcn_desc": L.DcnDesc, "mfx_heads_desc": L.HeadsDesc,
-             "mfx_kitti_desc": L.KittiDesc, "mfx_kitti_eval_desc": L.KittiEvalDesc}
+             "mfx_kitti_desc": L.KittiDesc, "mfx_kitti_eval_desc": L.KittiEvalDesc, "mfx_gram_desc": L.GramDesc,
+             "mfx_head_sparse_desc": L.HeadSparseDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "monoflex_hip.h"', 'int main(void) {']
     for cname, ct in pairs.items():
         lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
