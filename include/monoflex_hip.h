@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define MFX_ABI_VERSION 1
+#define MFX_ABI_VERSION 2      /* r05: mfx_conv_desc / mfx_dcn_desc / mfx_heads_desc grew in r04 (paired fragments, fused offset conv, w2_scale, MFX_F16X2), mfx_dcn_desc again
+                                * (per-axis geometry), mfx_gram_desc is new: a caller built against version 1 is rejected instead of being read past its structs */
 
 /* element types of activations / packed weights */
 enum { MFX_F32 = 0, MFX_BF16 = 1, MFX_F16 = 2 /* IEEE half: every operator that takes bf16 takes it (the fused heads and the LDS-patch DCN forward are inference
@@ -68,9 +69,10 @@ size_t mfx_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, 
                                   int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                                   int backward);
 
-/* output (B,Cout,Ho,Wo) = bias + W * (mask . bilinear(input @ offsets))   -- src/dcn_v2.h:9-23.
- * deformable_group must be 1 (the only value MonoFlex uses, dla_dcn.py:391), stride_h == stride_w,
- * dil_h == dil_w; otherwise MFX_ERR_UNSUPPORTED. */
+/* output (B,Cout,Ho,Wo) = bias + W * (mask . bilinear(input @ offsets))   -- src/dcn_v2.h:9-23, as general as the reference's entry:
+ * any deformable_group dividing C (channel group g is sampled with its own 2*kh*kw offset and kh*kw mask channels,
+ * src/cuda/dcn_v2_im2col_cuda.cu:147-156: the groups are looped INSIDE this call, their outputs summed), per-axis stride / padding / dilation.
+ * kh * kw <= 9 (the offset row of the NHWC kernels holds nine taps). */
 int mfx_dcn_v2_forward(const float* input, const float* weight, const float* bias,
                        const float* offset, const float* mask, float* output,
                        int B, int C, int H, int W, int Cout, int kh, int kw,
@@ -167,6 +169,9 @@ typedef struct {
     const void* off_w_frag_f16;   /* fragment-major IEEE fp16 weights [2][18][64 lanes][16 B] of that conv (K = 9 * 64)                      */
     const float* off_shift;       /* its bias, fp32 [32] (27 values, then zeros)                                                          */
     float* offmask_out;           /* optional: the fused kernel also writes the rows it computed, fp32 [B*H*W][32] (the backward pass reads them) */
+    /* per-axis geometry (reference src/dcn_v2.h:9-23 takes stride_h/w, pad_h/w, dilation_h/w): nonsquare = 1 -> `stride`, `pad`, `dil` are the
+     * ROW values and the three fields below the COLUMN values (generic gather kernel); 0 -> they are ignored (square geometry) */
+    int32_t nonsquare, stride_w, pad_w, dil_w;
 } mfx_dcn_desc;
 int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream);
 /* 1 when mfx_dcn_nhwc(d) will compute the offsets inside the kernel from off_w_frag_f16 / off_shift (d->offmask is not read), else 0 */

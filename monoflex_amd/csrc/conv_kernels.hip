@@ -94,7 +94,7 @@ template <typename T, int BM, int NT, int KC> struct CatALoader {
     }
 };
 
-struct DcnGeom { int H, W, C, lgC, Ho, Wo, kh, kw, inv_kw, stride, pad, dil, M; };
+struct DcnGeom { int H, W, C, lgC, Ho, Wo, kh, kw, inv_kw, stride, pad, dil, M, stride_w, pad_w, dil_w; };      // stride / pad / dil: rows; *_w: columns
 
 // Deformable sampler: A[m][(tap,c)] = mask * bilinear(x[b,:,:,c] at (oh*s-p+th*d+dh, ow*s-p+tw*d+dw)).
 // In NHWC the four corners are contiguous channel vectors, so every lane gathers 4 x 16 bytes and
@@ -144,7 +144,7 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
         for (int i = 0; i < R; ++i) {
             const float dh = cur[i][0], dw = cur[i][1], mk = cur[i][2];
             const float h = (float)(oh_[i] * g.stride - g.pad + th * g.dil) + dh;
-            const float w = (float)(ow_[i] * g.stride - g.pad + tw * g.dil) + dw;
+            const float w = (float)(ow_[i] * g.stride_w - g.pad_w + tw * g.dil_w) + dw;
             const bool inside = ok[i] && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
             const float hf = floorf(h), wf = floorf(w);
             const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
@@ -643,8 +643,10 @@ extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
     DcnGeom g;
     g.H = d->H; g.W = d->W; g.C = d->C; g.lgC = ilog2(d->C); g.Ho = d->Ho; g.Wo = d->Wo; g.kh = d->kh; g.kw = d->kw;
     g.inv_kw = (65536 + d->kw - 1) / d->kw; g.stride = d->stride; g.pad = d->pad; g.dil = d->dil; g.M = d->B * d->Ho * d->Wo;
+    g.stride_w = d->nonsquare ? d->stride_w : d->stride; g.pad_w = d->nonsquare ? d->pad_w : d->pad; g.dil_w = d->nonsquare ? d->dil_w : d->dil;
+    if (d->nonsquare && (d->stride_w < 1 || d->dil_w < 1 || d->pad_w < 0)) return mfx_fail(MFX_ERR_ARG, "dcn: bad per-axis geometry");
     if (g.M <= 0) return MFX_OK;
-    {
+    if (!d->nonsquare) {                                      // (the LDS-patch / wave kernels are built for square geometry)
         int h = try_dcn_patch(d, reinterpret_cast<hipStream_t>(stream));
         if (h != 0) return h < 0 ? h : MFX_OK;
         h = try_dcn_wave(d, reinterpret_cast<hipStream_t>(stream));

@@ -28,7 +28,7 @@ template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t* p) {
     return f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
 }
 
-struct BwdGeom { int B, H, W, Cp, lgC, Ho, Wo, kh, kw, kk, stride, pad, dil, M, K, Kp, Coutp; };
+struct BwdGeom { int B, H, W, Cp, lgC, Ho, Wo, kh, kw, kk, stride, pad, dil, M, K, Kp, Coutp, stride_w, pad_w, dil_w; };      // stride / pad / dil: rows; *_w: columns
 
 struct TapGeo { int off[4]; float w[4]; float lh, lw, hh, hw; bool inside; bool cv[4]; };
 
@@ -37,7 +37,7 @@ __device__ __forceinline__ TapGeo tap_geometry(const BwdGeom& g, const float* om
     TapGeo t;
     const int th = tap / g.kw, tw = tap - th * g.kw;
     const float h = (float)(oh * g.stride - g.pad + th * g.dil) + om_row[2 * tap];
-    const float w = (float)(ow * g.stride - g.pad + tw * g.dil) + om_row[2 * tap + 1];
+    const float w = (float)(ow * g.stride_w - g.pad_w + tw * g.dil_w) + om_row[2 * tap + 1];
     t.inside = h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
     const float hf = floorf(h), wf = floorf(w);
     const int h0 = (int)hf, w0 = (int)wf, h1 = h0 + 1, w1 = w0 + 1;
@@ -241,11 +241,12 @@ static BwdLayout bwd_layout(const BwdGeom& g) {
     L.total = o;
     return L;
 }
-static BwdGeom bwd_geom(int B, int C, int H, int W, int Cout, int kh, int kw, int s, int p, int d) {
+static BwdGeom bwd_geom(int B, int C, int H, int W, int Cout, int kh, int kw, int s, int p, int d, int sw = -1, int pw = -1, int dw = -1) {
     BwdGeom g;
     g.B = B; g.H = H; g.W = W; g.Cp = next_pow2_(C < 16 ? 16 : C); g.lgC = 0; while ((1 << g.lgC) < g.Cp) ++g.lgC;
     g.kh = kh; g.kw = kw; g.kk = kh * kw; g.stride = s; g.pad = p; g.dil = d;
-    g.Ho = (H + 2 * p - (d * (kh - 1) + 1)) / s + 1; g.Wo = (W + 2 * p - (d * (kw - 1) + 1)) / s + 1;
+    g.stride_w = sw < 0 ? s : sw; g.pad_w = pw < 0 ? p : pw; g.dil_w = dw < 0 ? d : dw;
+    g.Ho = (H + 2 * p - (d * (kh - 1) + 1)) / s + 1; g.Wo = (W + 2 * g.pad_w - (g.dil_w * (kw - 1) + 1)) / g.stride_w + 1;
     g.M = B * g.Ho * g.Wo; g.K = g.kk * g.Cp; g.Kp = ((g.K + 63) / 64) * 64;
     g.Coutp = next_pow2_(Cout < 64 ? 64 : Cout);
     return g;
@@ -283,34 +284,22 @@ static int dcn_bwd_core(const T* x, const float* om, const T* wT, const T* go, T
     return MFX_OK;
 }
 
-extern "C" size_t mfx_dcn_v2_backward_workspace_bytes_(int B, int C, int H, int W, int Cout, int kh, int kw, int s, int p, int d) {
-    return bwd_layout(bwd_geom(B, C, H, W, Cout, kh, kw, s, p, d)).total;
+extern "C" size_t mfx_dcn_v2_backward_workspace_bytes_(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
+    return bwd_layout(bwd_geom(B, C, H, W, Cout, kh, kw, sh, ph, dh, sw, pw, dw)).total;
 }
 
-extern "C" int mfx_dcn_v2_backward(const float* input, const float* weight, const float* bias,
-                                   const float* offset, const float* mask, const float* grad_output,
-                                   float* grad_input, float* grad_offset, float* grad_mask,
-                                   float* grad_weight, float* grad_bias,
-                                   int B, int C, int H, int W, int Cout, int kh, int kw,
-                                   int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
-                                   int deformable_group, void* workspace, size_t workspace_bytes, void* stream) {
-    (void)bias;
-    if (!input || !weight || !offset || !mask || !grad_output || !grad_input || !grad_offset || !grad_mask || !grad_weight || !grad_bias)
-        return mfx_fail(MFX_ERR_ARG, "dcn_v2_backward: null pointer");
-    if (deformable_group != 1) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_v2_backward: deformable_group must be 1");
-    if (stride_h != stride_w || dil_h != dil_w || pad_h != pad_w) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_v2_backward: square stride/pad/dilation only");
-    if (kh * kw > 9) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_v2_backward: at most 9 taps");
-    const BwdGeom g = bwd_geom(B, C, H, W, Cout, kh, kw, stride_h, pad_h, dil_h);
-    if (g.Ho <= 0 || g.Wo <= 0) return mfx_fail(MFX_ERR_ARG, "dcn_v2_backward: empty output");
+int mfx_internal_ext_slice(const float* src, float* dst, int B, int Cs, int cs0, int Cd, int cd0, int Cg, int HW, int accumulate, void* stream);   // dcn_ext.hip
+
+// one deformable group: contiguous NCHW fp32 operands and gradients
+static int backward_one(const float* input, const float* weight, const float* offset, const float* mask, const float* grad_output,
+                        float* grad_input, float* grad_offset, float* grad_mask, float* grad_weight, float* grad_bias,
+                        int B, int C, int Cout, const BwdGeom& g, char* ws, void* stream) {
     const BwdLayout L = bwd_layout(g);
-    if (!workspace || workspace_bytes < L.total) return mfx_fail(MFX_ERR_WORKSPACE, "dcn_v2_backward: workspace too small");
-    if (g.M == 0) return MFX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    char* ws = reinterpret_cast<char*>(workspace);
     float* x = (float*)(ws + L.x); float* om = (float*)(ws + L.om); float* wT = (float*)(ws + L.wT);
     float* go = (float*)(ws + L.go); float* gcol = (float*)(ws + L.gcol); float* gx = (float*)(ws + L.gx);
     float* gom = (float*)(ws + L.gom); float* gwp = (float*)(ws + L.gwp); float* gb = (float*)(ws + L.gb);
-    const int HWo = g.Ho * g.Wo;
+    const int HWo = g.Ho * g.Wo, H = g.H, W = g.W;
 
     int rc = mfx_nchw_to_nhwc(input, x, B, C, H, W, g.Cp, MFX_F32, stream);
     if (rc) return rc;
@@ -330,8 +319,61 @@ extern "C" int mfx_dcn_v2_backward(const float* input, const float* weight, cons
     if (rc) return rc;
     hipLaunchKernelGGL(bwd_unpack_offmask, BWD_GRID((long)g.M * 3 * g.kk), dim3(256), 0, st, gom, grad_offset, grad_mask, B, HWo, g.kk);
     hipLaunchKernelGGL(bwd_unpack_weight, BWD_GRID((long)Cout * C * g.kk), dim3(256), 0, st, gwp, grad_weight, Cout, C, g.kk, g.Cp, g.K);
-    MFX_HIP_CHECK(mfx::copy_async(grad_bias, gb, (size_t)Cout * 4, st));
+    if (grad_bias) MFX_HIP_CHECK(mfx::copy_async(grad_bias, gb, (size_t)Cout * 4, st));
     MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
+extern "C" size_t mfx_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw,
+                                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int backward);
+
+extern "C" int mfx_dcn_v2_backward(const float* input, const float* weight, const float* bias,
+                                   const float* offset, const float* mask, const float* grad_output,
+                                   float* grad_input, float* grad_offset, float* grad_mask,
+                                   float* grad_weight, float* grad_bias,
+                                   int B, int C, int H, int W, int Cout, int kh, int kw,
+                                   int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                                   int deformable_group, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)bias;
+    if (!input || !weight || !offset || !mask || !grad_output || !grad_input || !grad_offset || !grad_mask || !grad_weight || !grad_bias)
+        return mfx_fail(MFX_ERR_ARG, "dcn_v2_backward: null pointer");
+    const int dg = deformable_group;
+    if (dg < 1 || C % dg != 0) return mfx_fail(MFX_ERR_ARG, "dcn_v2_backward: deformable_group must divide the input channels");
+    if (stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1 || pad_h < 0 || pad_w < 0) return mfx_fail(MFX_ERR_ARG, "dcn_v2_backward: bad stride / padding / dilation");
+    if (kh * kw > 9) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_v2_backward: at most 9 taps");
+    const int Cg = C / dg, kk = kh * kw;
+    const BwdGeom g = bwd_geom(B, Cg, H, W, Cout, kh, kw, stride_h, pad_h, dil_h, stride_w, pad_w, dil_w);
+    if (g.Ho <= 0 || g.Wo <= 0) return mfx_fail(MFX_ERR_ARG, "dcn_v2_backward: empty output");
+    if (!workspace || workspace_bytes < mfx_dcn_v2_workspace_bytes(B, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, 1))
+        return mfx_fail(MFX_ERR_WORKSPACE, "dcn_v2_backward: workspace too small (mfx_dcn_v2_workspace_bytes)");
+    if (g.M == 0) return MFX_OK;
+    char* ws = reinterpret_cast<char*>(workspace);
+    if (dg == 1) return backward_one(input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, grad_bias, B, C, Cout, g, ws, stream);
+    // deformable groups: group g's channel slice of the input / weight and its offset / mask channels give that slice's gradients (the output
+    // gradient is shared); grad_bias is the same sum for every group
+    const int HW = H * W, HWo = g.Ho * g.Wo;
+    auto a256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    char* t = ws + mfx_dcn_v2_backward_workspace_bytes_(B, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w);
+    float* xg = (float*)t; t += a256((size_t)B * C * HW * 4);
+    float* wg = (float*)t; t += a256((size_t)Cout * C * kk * 4);
+    float* og = (float*)t; t += a256((size_t)B * 2 * kk * HWo * 4);
+    float* mg = (float*)t; t += a256((size_t)B * kk * HWo * 4);
+    float* gxg = (float*)t; t += a256((size_t)B * C * HW * 4);
+    float* gwg = (float*)t; t += a256((size_t)Cout * C * kk * 4);
+    float* gog = (float*)t; t += a256((size_t)B * 2 * kk * HWo * 4);
+    float* gmg = (float*)t;
+    int rc;
+    for (int q = 0; q < dg; ++q) {
+        if ((rc = mfx_internal_ext_slice(input, xg, B, C, q * Cg, Cg, 0, Cg, HW, 0, stream))) return rc;
+        if ((rc = mfx_internal_ext_slice(weight, wg, Cout, C, q * Cg, Cg, 0, Cg, kk, 0, stream))) return rc;
+        if ((rc = mfx_internal_ext_slice(offset, og, B, dg * 2 * kk, q * 2 * kk, 2 * kk, 0, 2 * kk, HWo, 0, stream))) return rc;
+        if ((rc = mfx_internal_ext_slice(mask, mg, B, dg * kk, q * kk, kk, 0, kk, HWo, 0, stream))) return rc;
+        if ((rc = backward_one(xg, wg, og, mg, grad_output, gxg, gog, gmg, gwg, q == 0 ? grad_bias : nullptr, B, Cg, Cout, g, ws, stream))) return rc;
+        if ((rc = mfx_internal_ext_slice(gxg, grad_input, B, Cg, 0, C, q * Cg, Cg, HW, 0, stream))) return rc;
+        if ((rc = mfx_internal_ext_slice(gwg, grad_weight, Cout, Cg, 0, C, q * Cg, Cg, kk, 0, stream))) return rc;
+        if ((rc = mfx_internal_ext_slice(gog, grad_offset, B, 2 * kk, 0, dg * 2 * kk, q * 2 * kk, 2 * kk, HWo, 0, stream))) return rc;
+        if ((rc = mfx_internal_ext_slice(gmg, grad_mask, B, kk, 0, dg * kk, q * kk, kk, HWo, 0, stream))) return rc;
+    }
     return MFX_OK;
 }
 

@@ -43,7 +43,8 @@ class DcnDesc(ctypes.Structure):
                 ("Ho", c_int), ("Wo", c_int), ("Cout", c_int), ("Cout_pad", c_int), ("K_pad", c_int),
                 ("ldy", c_int), ("act", c_int), ("dtype", c_int), ("w_frag_f16", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64),
-                ("off_w_frag_f16", c_void_p), ("off_shift", c_void_p), ("offmask_out", c_void_p)]
+                ("off_w_frag_f16", c_void_p), ("off_shift", c_void_p), ("offmask_out", c_void_p),
+                ("nonsquare", c_int), ("stride_w", c_int), ("pad_w", c_int), ("dil_w", c_int)]
 
 
 class HeadsDesc(ctypes.Structure):
@@ -189,7 +190,7 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.mfx_abi_version() != 1:
+    if lib.mfx_abi_version() != 2:
         raise RuntimeError("libmonoflex_hip.so ABI version mismatch")
     _lib = lib
     return lib

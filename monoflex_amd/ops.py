@@ -664,22 +664,13 @@ def _ext_check(x, w, off, msk, kh, kw, dg):
 
 @on_tensor_device
 def ext_dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg):
-    """`_ext.dcn_v2_forward` (src/dcn_v2.h:9-23): NCHW fp32 in and out.  deformable_group > 1 (the reference's own example,
-    testcuda.py:169-180, uses 2): channel group g is sampled with its own 2*kh*kw offsets and kh*kw mask channels
-    (dcn_v2_im2col_cuda.cu:147-156), so the layer is the sum over g of a one-group layer on that channel slice -- dg calls of the
-    C entry, added here.  Non-square stride / padding / dilation: the C entry reports MFX_ERR_UNSUPPORTED -> RuntimeError."""
+    """`_ext.dcn_v2_forward` (src/dcn_v2.h:9-23): NCHW fp32 in and out; ONE call of the C entry, which is as general as the reference's:
+    deformable groups (its own example uses 2, testcuda.py:169-180) are looped inside `mfx_dcn_v2_forward` (group g = channel slice g with its
+    own 2*kh*kw offset and kh*kw mask channels, dcn_v2_im2col_cuda.cu:147-156), stride / padding / dilation are per axis."""
     _need_cuda(input, weight, bias, offset, mask)
     ts = [t.float().contiguous() for t in (input, weight, bias, offset, mask)]
     x, w, b, off, msk = ts
     _ext_check(x, w, off, msk, kh, kw, dg)
-    if dg > 1:
-        Cg, kk = x.shape[1] // dg, kh * kw
-        out = None
-        for g in range(dg):
-            yg = ext_dcn_v2_forward(x[:, g * Cg:(g + 1) * Cg], w[:, g * Cg:(g + 1) * Cg], b if g == 0 else torch.zeros_like(b),
-                                    off[:, 2 * kk * g:2 * kk * (g + 1)], msk[:, kk * g:kk * (g + 1)], kh, kw, sh, sw, ph, pw, dh, dw, 1)
-            out = yg if out is None else out.add_(yg)
-        return out
     B, C, H, W = x.shape
     Cout = w.shape[0]
     Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
@@ -696,16 +687,10 @@ def ext_dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw
 @on_tensor_device
 def ext_dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kh, kw, sh, sw, ph, pw, dh, dw, dg):
     """`_ext.dcn_v2_backward` (src/dcn_v2.h:48-59) -> [grad_input, grad_offset, grad_mask, grad_weight, grad_bias]; deformable
-    groups as in the forward: the gradients of group g's channel slice / offset / mask channels come from the one-group call."""
+    groups and per-axis geometry inside the C entry, as in the forward."""
     _need_cuda(input, weight, bias, offset, mask, grad_output)
     x, w, b, off, msk, go = [t.float().contiguous() for t in (input, weight, bias, offset, mask, grad_output)]
     _ext_check(x, w, off, msk, kh, kw, dg)
-    if dg > 1:
-        Cg, kk = x.shape[1] // dg, kh * kw
-        parts = [ext_dcn_v2_backward(x[:, g * Cg:(g + 1) * Cg], w[:, g * Cg:(g + 1) * Cg], b, off[:, 2 * kk * g:2 * kk * (g + 1)],
-                                     msk[:, kk * g:kk * (g + 1)], go, kh, kw, sh, sw, ph, pw, dh, dw, 1) for g in range(dg)]
-        return [torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1), torch.cat([p[2] for p in parts], 1),
-                torch.cat([p[3] for p in parts], 1), parts[0][4]]
     B, C, H, W = x.shape
     Cout = w.shape[0]
     lib_ = L.load()

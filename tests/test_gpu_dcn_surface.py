@@ -164,15 +164,11 @@ def test_unsupported_geometry_surfaces_as_runtime_error():
     from monoflex_amd.model.backbone.DCNv2 import _ext
     from monoflex_amd.model.backbone.DCNv2.dcn_v2 import DCN, DCNv2
     x, off, msk, w, b = [t.to(DEV) for t in _dcn_case(1, 1, 16, 16, 8, 8)]
-    with pytest.raises(RuntimeError, match="square"):
-        _ext.dcn_v2_forward(x, w, b, off, msk, 3, 3, 1, 2, 1, 1, 1, 1, 1)                # stride_h != stride_w
-    with pytest.raises(RuntimeError, match="square"):
-        _ext.dcn_v2_backward(x, w, b, off, msk, torch.zeros(1, 16, 8, 8, device=DEV), 3, 3, 1, 1, 1, 2, 1, 1, 1)
     with pytest.raises(RuntimeError, match="kernel shape"):
         _ext.dcn_v2_forward(x, w, b, off, msk, 5, 5, 1, 1, 1, 1, 1, 1, 1)                # reference: "Input shape and kernel shape wont match"
     with pytest.raises(RuntimeError, match="kernel channels"):
         _ext.dcn_v2_forward(x[:, :8].contiguous(), w, b, off, msk, 3, 3, 1, 1, 1, 1, 1, 1, 1)
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError):                                                    # (the MODULE with its own offset conv stays square; `_ext` / DCNv2 are general)
         DCN(16, 16, kernel_size=(3, 3), stride=(1, 2), padding=1).to(DEV)(x)
     m = DCNv2(16, 16, (3, 3), 1, 1).to(DEV)
     with pytest.raises(AssertionError):                                                  # dcn_v2.py:84-87
@@ -232,3 +228,34 @@ def test_dcn_module_with_the_offset_conv_inside_the_kernel(B, H, W, std, half):
     rel = float((y1.float().permute(0, 3, 1, 2).cpu() - want).norm() / want.norm())
     rel0 = float((y0.float().permute(0, 3, 1, 2).cpu() - want).norm() / want.norm())
     assert rel < 3e-2 and rel < 1.5 * rel0 + 1e-3, (rel, rel0)
+
+
+@pytest.mark.parametrize("geom", [(3, 3, 1, 2, 1, 1, 1, 1), (3, 3, 2, 1, 1, 2, 1, 1), (3, 3, 1, 1, 2, 1, 2, 1), (3, 2, 1, 1, 1, 0, 1, 1), (1, 3, 2, 1, 0, 1, 1, 2)])
+@pytest.mark.parametrize("dg", [1, 2])
+def test_ext_boundary_per_axis_geometry_and_groups_in_one_c_call(geom, dg):
+    """`mfx_dcn_v2_forward / _backward` are as general as src/dcn_v2.h:9-23, 48-59: stride_h != stride_w, pad_h != pad_w, dil_h != dil_w,
+    non-square kernels (<= 9 taps) and deformable groups -- ONE call of the C entry each (the binding passes `deformable_group` through) --
+    against the C oracle (src/cpu/dcn_v2_im2col_cpu.cpp:27-329 restated), forward and all five gradients."""
+    from monoflex_amd.model.backbone.DCNv2 import _ext
+    from oracle import dcn_ref
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    g = _g(40 + dg)
+    B, C, Cout, H, W = 2, 16 * dg, 24, 11, 14
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    kk = kh * kw
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Cout, C, kh, kw, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g) * 0.1
+    off = torch.randn(B, 2 * dg * kk, Ho, Wo, generator=g) * 1.5
+    msk = torch.sigmoid(torch.randn(B, dg * kk, Ho, Wo, generator=g))
+    go = torch.randn(B, Cout, Ho, Wo, generator=g)
+    want = dcn_ref.dcn_v2_forward(x, w, b, off, msk, kh, kw, sh, sw, ph, pw, dh, dw, dg)
+    got = _ext.dcn_v2_forward(*[t.to(DEV) for t in (x, w, b, off, msk)], kh, kw, sh, sw, ph, pw, dh, dw, dg)
+    assert got.shape == want.shape == (B, Cout, Ho, Wo)
+    _close(got, want, 2e-5, "forward %s dg=%d" % (geom, dg))
+    wantb = dcn_ref.dcn_v2_backward(x, w, b, off, msk, go, kh, kw, sh, sw, ph, pw, dh, dw, dg)
+    gotb = _ext.dcn_v2_backward(*[t.to(DEV) for t in (x, w, b, off, msk, go)], kh, kw, sh, sw, ph, pw, dh, dw, dg)
+    for a, r, name in zip(gotb, wantb, ["grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"]):
+        assert a.shape == r.shape, name
+        _close(a, r, 1e-4, "%s %s dg=%d" % (name, geom, dg))
