@@ -55,6 +55,8 @@ const char* mfx_last_error(void);
  * unit ranges, n > 1 = n workgroups, 0 = one workgroup per tile), "heads_planes", "heads_dbg" (timing probes: wrong results).
  * Unknown names return MFX_ERR_ARG. */
 int mfx_set_option(const char* name, int value);
+/* every switch back to its load-time value (what a test harness calls between tests) */
+int mfx_reset_options(void);
 /* Dispatch counters since process start, so a test can assert WHICH kernel variant a call took: "dcn_bt_fused" = launches of the
  * fused sample + weight-gradient kernel of mfx_dcn_backward_v2 (selected for bf16 / fp16, C = Cout = 64, W % 32 == 0 and at least
  * option "dcn_bt_fuse_min_chunks" (default 1024) 32-pixel chunks).  Unknown names return MFX_ERR_ARG (negative). */

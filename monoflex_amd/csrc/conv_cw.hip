@@ -47,7 +47,7 @@ template <int CG, int WN, int FN, int WK> struct CwSmem {
 
 // CG = channels per patch pass, CT = input channels of the layer (a multiple of CG), WN x FN x 16 = output channels per workgroup,
 // WK = waves sharing an output slice (they take the K steps round-robin); OCC = waves per SIMD the register allocation must admit
-template <typename T, int CG, int CT, int WN, int FN, int WK, int OCC>
+template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC>
 __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* __restrict__ x, const u32x4* __restrict__ wfm, CwGeom g, EpiArgs ep) {
     static_assert(sizeof(T) == 2, "16-bit maps");
     constexpr int NT = WN * WK * 64, FM = kCwRows, PW = kCwPW, PH = kCwPH;
@@ -210,11 +210,12 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
     // The residual chunks of ALL the wave's rows are fetched up front (the K loop's fragment registers are dead by now, so they cost no
     // occupancy): one exposed memory round trip per tile instead of one per output row; 32-bit element offsets.
     constexpr int LDS_ = SM::stage_ld;
-    constexpr int OE = 8;
+    constexpr int OE = ElemTraits<TO>::ELEMS;                 // output elements per 16-byte store: 8 (16-bit maps) / 4 (fp32: the DCN offset / mask conv)
     constexpr int GPR = FN * 16 / OE;
     constexpr int RITEMS = (16 * GPR + 63) / 64;
-    const T* res = reinterpret_cast<const T*>(ep.res);
-    T* y = reinterpret_cast<T*>(ep.y);
+    constexpr bool kRes = std::is_same<T, TO>::value;         // residual operand: same type as the output (the launcher rejects the other case)
+    const T* res = kRes ? reinterpret_cast<const T*>(ep.res) : nullptr;
+    TO* y = reinterpret_cast<TO*>(ep.y);
     const uint32_t pix0 = (uint32_t)((b * g.H + y0) * g.W + x0);            // first pixel of the tile (32-bit: M * ld < 2^31 checked by the launcher)
     u32x4 rres[RW][RITEMS];
     if (res) {
@@ -253,23 +254,25 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
                     const f32x4 t = *reinterpret_cast<const f32x4*>(stage + px * LDS_ + ng * OE + e);
                     v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
                 }
-                if (res) {
-                    float rv[OE];
-                    ElemTraits<T>::unpack(rres[ii][q], rv);
+                if constexpr (kRes) {
+                    if (res) {
+                        float rv[OE];
+                        ElemTraits<T>::unpack(rres[ii][q], rv);
 #pragma unroll
-                    for (int e = 0; e < OE; ++e) v[e] += rv[e];
+                        for (int e = 0; e < OE; ++e) v[e] += rv[e];
+                    }
                 }
                 apply_act_chunk<OE>(v, ep.act, gn);
-                *reinterpret_cast<u32x4*>(y + (pix0 + (uint32_t)(i * g.W + px)) * (uint32_t)ep.ldy + (uint32_t)gn) = ElemTraits<T>::pack(v);
+                *reinterpret_cast<u32x4*>(y + (pix0 + (uint32_t)(i * g.W + px)) * (uint32_t)ep.ldy + (uint32_t)gn) = ElemTraits<TO>::pack(v);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-int g_opt_halo_cw = 1;       // option "halo_cw": 0 = conv3x3_wave_kernel only, 1 = this kernel where an instantiation exists, 2 / 3 = experimental register budgets
+int g_opt_halo_cw = 1;       // option "halo_cw": 0 = conv3x3_wave_kernel only, 1 = this kernel where an instantiation exists
 
-template <typename T, int CG, int CT, int WN, int FN, int WK, int OCC>
+template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC>
 static int launch_cw(const mfx_conv_desc* d, hipStream_t st) {
     using SM = CwSmem<CG, WN, FN, WK>;
     constexpr int BN = WN * FN * 16;
@@ -279,7 +282,7 @@ static int launch_cw(const mfx_conv_desc* d, hipStream_t st) {
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
-    auto k = conv3x3_cw_kernel<T, CG, CT, WN, FN, WK, OCC>;
+    auto k = conv3x3_cw_kernel<T, TO, CG, CT, WN, FN, WK, OCC>;
     constexpr int smem = SM::total;
     static bool attr_done = false;
     if (!attr_done && smem > 64 * 1024) {
@@ -294,25 +297,42 @@ static int launch_cw(const mfx_conv_desc* d, hipStream_t st) {
 
 template <typename T, int OCC> static int cw_shape(const mfx_conv_desc* d, int v, hipStream_t st) {
     const int C = d->Ck;
-    if (v == 6 && C == 64) return launch_cw<T, 64, 64, 2, 2, 1, OCC>(d, st);
-    if (v == 7 && C == 128) return launch_cw<T, 128, 128, 4, 2, 1, OCC>(d, st);
-    if (v == 7 && C == 64) return launch_cw<T, 64, 64, 4, 2, 1, OCC>(d, st);
-    if (v == 11 && C == 256) return launch_cw<T, 256, 256, 4, 2, 2, OCC>(d, st);
-    if (v == 11 && C == 512) return launch_cw<T, 256, 512, 4, 2, 2, OCC>(d, st);
+    if (v == 6 && C == 64) return launch_cw<T, T, 64, 64, 2, 2, 1, OCC>(d, st);
+    if (v == 7 && C == 128) return launch_cw<T, T, 128, 128, 4, 2, 1, OCC>(d, st);
+    if (v == 7 && C == 64) return launch_cw<T, T, 64, 64, 4, 2, 1, OCC>(d, st);
+    if (v == 11 && C == 256) return launch_cw<T, T, 256, 256, 4, 2, 2, OCC>(d, st);
+    if (v == 11 && C == 512) return launch_cw<T, T, 256, 512, 4, 2, 2, OCC>(d, st);
     return 1;                                                 // no instantiation: the caller falls back
 }
 
+// the 27-channel DCN offset / mask convs of the wide layers (fp32 out, sigmoid on the mask channels, N = 32): one output slice per workgroup,
+// four waves share it and split K (conv_halo.hip's variants 8 = 32 channels per workgroup, 10 = 16)
+template <typename T> static int cw_shape_f32out(const mfx_conv_desc* d, int v, hipStream_t st) {
+    const int C = d->Ck;
+    if (v == 8 && C == 128) return launch_cw<T, float, 128, 128, 1, 2, 4, 2>(d, st);
+    if (v == 8 && C == 256) return launch_cw<T, float, 256, 256, 1, 2, 4, 2>(d, st);
+    if (v == 8 && C == 512) return launch_cw<T, float, 256, 512, 1, 2, 4, 2>(d, st);
+    if (v == 10 && C == 128) return launch_cw<T, float, 128, 128, 1, 1, 4, 2>(d, st);
+    if (v == 10 && C == 256) return launch_cw<T, float, 256, 256, 1, 1, 4, 2>(d, st);
+    if (v == 10 && C == 512) return launch_cw<T, float, 256, 512, 1, 1, 4, 2>(d, st);
+    return 1;
+}
+
 // returns MFX_OK (0) if this kernel ran, 1 if there is no instantiation for the shape / variant (caller runs conv3x3_wave_kernel), < 0 on error.
-// `v` is conv_halo.hip's variant number (6: 2 waves x 32 channels, 7: 4 x 32, 11: 4 x 32 with a 2-way K split)
+// `v` is conv_halo.hip's variant number (6: 2 waves x 32 channels, 7: 4 x 32, 11: 4 x 32 with a 2-way K split; 8 / 10: one slice, 4-way K split)
 int try_conv_cw(const mfx_conv_desc* d, int v, hipStream_t st) {
     if (!g_opt_halo_cw || !d->w_frag || d->stats || d->stride != 1) return 1;
-    if (d->out_dtype != d->dtype || (d->dtype != MFX_BF16 && d->dtype != MFX_F16)) return 1;
-    if (d->K_pad != 9 * d->Ck || d->Cout % 8 != 0 || d->act == MFX_ACT_DCN_OFFMASK) return 1;
+    if (d->dtype != MFX_BF16 && d->dtype != MFX_F16) return 1;
+    if (d->K_pad != 9 * d->Ck) return 1;
     if ((long long)d->M * (d->ldy > d->ldres ? d->ldy : d->ldres) >= (1ll << 31) || (long long)d->H * d->W * d->Ck >= (1ll << 31)) return 1;      // 32-bit element offsets
+    if (d->out_dtype == MFX_F32) {
+        if (d->res || d->Cout % 4 != 0 || d->Cout_pad != 32 || (v != 8 && v != 10)) return 1;
+        return d->dtype == MFX_F16 ? cw_shape_f32out<half_t>(d, v, st) : cw_shape_f32out<bf16_t>(d, v, st);
+    }
+    if (d->out_dtype != d->dtype || d->Cout % 8 != 0 || d->act == MFX_ACT_DCN_OFFMASK) return 1;
     if (v == 6 && d->Cout_pad % 64 != 0) return 1;
     if ((v == 7 || v == 11) && d->Cout_pad % 128 != 0) return 1;
     if (d->dtype == MFX_F16) return cw_shape<half_t, 2>(d, v, st);
-    if (g_opt_halo_cw == 2) return cw_shape<bf16_t, 3>(d, v, st);
     return cw_shape<bf16_t, 2>(d, v, st);
 }
 

@@ -4,6 +4,8 @@
 #include "err.h"
 #include "igemm.h"
 #include <string>
+#include <utility>
+#include <vector>
 #include <type_traits>
 
 namespace mfx {
@@ -413,54 +415,56 @@ static int dispatch_conv(const mfx_conv_desc* d, const ConvGeom& g, const EpiArg
 
 using namespace mfx;
 
+// option name -> the process-wide switch it sets (nullptr: unknown)
+static int* option_slot(const std::string& n) {
+    static const std::pair<const char*, int*> table[] = {
+        {"conv_tile", &g_opt_conv_tile}, {"dcn_tile", &g_opt_dcn_tile}, {"cat_tile", &g_opt_cat_tile}, {"kc", &g_opt_kc}, {"ksplit", &g_opt_ksplit},
+        {"dcn_ksplit", &g_opt_dcn_ksplit}, {"wgrad_mfma", &g_opt_wgrad_mfma}, {"wgrad_blocks", &g_opt_wgrad_blocks}, {"wgrad_ws", &g_opt_wgrad_ws},
+        {"wgrad_ws_blocks", &g_opt_wgrad_ws_blocks}, {"dcn_wgrad_m", &g_opt_dcn_wgrad_m}, {"halo", &g_opt_halo}, {"halo_cg", &g_opt_halo_cg},
+        {"halo_cw", &g_opt_halo_cw}, {"halo_pair", &g_opt_halo_pair}, {"halo_s2", &g_opt_halo_s2}, {"dcn_wave", &g_opt_dcn_wave}, {"dcn_patch", &g_opt_dcn_patch},
+        {"dcn_patch_fn8", &g_opt_dcn_patch_fn8}, {"dcn_fuse_off", &g_opt_dcn_fuse_off}, {"topk_strips", &g_opt_topk_strips},
+#ifdef MFX_PROBES
+        {"dcn_bt_dbg", &g_opt_dcn_bt_dbg}, {"heads_dbg", &g_opt_heads_dbg},
+#endif
+        {"wgrad_tr", &g_opt_wgrad_tr}, {"bn_blocks", &g_opt_bn_blocks}, {"heads_planes", &g_opt_heads_planes}, {"heads_persist", &g_opt_heads_persist},
+        {"dcn_bt_fuse_wgrad", &g_opt_dcn_bt_fuse_wgrad}, {"dcn_bt_fly", &g_opt_dcn_bt_fly}, {"dcn_bt_fuse_blocks", &g_opt_dcn_bt_fuse_blocks},
+        {"deterministic", &g_opt_det}, {"dcn_bt_fuse_min_chunks", &g_opt_dcn_bt_fuse_min_chunks}, {"dcn_bt_cs", &g_opt_dcn_bt_cs},
+        {"dcn_bt_cs_wgs", &g_opt_dcn_bt_cs_wgs}, {"bn_apply_blocks", &g_opt_bn_apply_blocks}, {"wgrad_patch", &g_opt_wgrad_patch},
+        {"wgrad_patch_waves", &g_opt_wgrad_patch_waves}, {"wgrad_patch_blocks", &g_opt_wgrad_patch_blocks}, {"wgrad_tr_blocks", &g_opt_wgrad_tr_blocks}};
+    for (const auto& e : table)
+        if (n == e.first) return e.second;
+    return nullptr;
+}
+
+// the value every switch had before anyone touched it (recorded at the first mfx_set_option of that switch): mfx_reset_options() puts them back
+static std::vector<std::pair<int*, int>>& option_defaults() { static std::vector<std::pair<int*, int>> v; return v; }
+
 extern "C" int mfx_set_option(const char* name, int value) {
     if (!name) return mfx_fail(MFX_ERR_ARG, "set_option: null name");
     const std::string n(name);
-    if (n == "conv_tile") g_opt_conv_tile = value;
-    else if (n == "dcn_tile") g_opt_dcn_tile = value;
-    else if (n == "cat_tile") g_opt_cat_tile = value;
-    else if (n == "kc") g_opt_kc = value;
-    else if (n == "ksplit") g_opt_ksplit = value;
-    else if (n == "dcn_ksplit") g_opt_dcn_ksplit = value;
-    else if (n == "wgrad_mfma") g_opt_wgrad_mfma = value;
-    else if (n == "wgrad_blocks") g_opt_wgrad_blocks = value;
-    else if (n == "wgrad_ws") g_opt_wgrad_ws = value;
-    else if (n == "wgrad_ws_blocks") g_opt_wgrad_ws_blocks = value;
-    else if (n == "dcn_wgrad_m") g_opt_dcn_wgrad_m = value < 64 ? 64 : value;
-    else if (n == "halo") g_opt_halo = value;
-    else if (n == "halo_cg") g_opt_halo_cg = value;
-    else if (n == "halo_cw") g_opt_halo_cw = value;
-    else if (n == "halo_pair") g_opt_halo_pair = value;
-    else if (n == "halo_s2") g_opt_halo_s2 = value;
-    else if (n == "dcn_wave") g_opt_dcn_wave = value;
-    else if (n == "dcn_patch") g_opt_dcn_patch = value;
-    else if (n == "dcn_patch_fn8") g_opt_dcn_patch_fn8 = value;
-    else if (n == "dcn_fuse_off") g_opt_dcn_fuse_off = value;
-    else if (n == "topk_strips") g_opt_topk_strips = value;
-#ifdef MFX_PROBES
-    else if (n == "dcn_bt_dbg") g_opt_dcn_bt_dbg = value;
-    else if (n == "heads_dbg") g_opt_heads_dbg = value;
-#else
-    else if (n == "dcn_bt_dbg" || n == "heads_dbg")
+#ifndef MFX_PROBES
+    if (n == "dcn_bt_dbg" || n == "heads_dbg")
         return mfx_fail(MFX_ERR_UNSUPPORTED, "set_option: timing-probe switches (wrong results by design) exist in probe builds only: MFX_PROBES=1 python -m monoflex_amd.build");
 #endif
-    else if (n == "wgrad_tr") g_opt_wgrad_tr = value;
-    else if (n == "bn_blocks") g_opt_bn_blocks = value;
-    else if (n == "heads_planes") g_opt_heads_planes = value;
-    else if (n == "heads_persist") g_opt_heads_persist = value;
-    else if (n == "dcn_bt_fuse_wgrad") g_opt_dcn_bt_fuse_wgrad = value;
-    else if (n == "dcn_bt_fly") g_opt_dcn_bt_fly = value;
-    else if (n == "dcn_bt_fuse_blocks") g_opt_dcn_bt_fuse_blocks = value > 0 ? value : 170;
-    else if (n == "deterministic") g_opt_det = value ? 1 : 0;
-    else if (n == "dcn_bt_fuse_min_chunks") g_opt_dcn_bt_fuse_min_chunks = value < 1 ? 1 : value;
-    else if (n == "dcn_bt_cs") g_opt_dcn_bt_cs = value;
-    else if (n == "dcn_bt_cs_wgs") g_opt_dcn_bt_cs_wgs = value;
-    else if (n == "bn_apply_blocks") g_opt_bn_apply_blocks = value;
-    else if (n == "wgrad_patch") g_opt_wgrad_patch = value;
-    else if (n == "wgrad_patch_waves") g_opt_wgrad_patch_waves = value;
-    else if (n == "wgrad_patch_blocks") g_opt_wgrad_patch_blocks = value < 1 ? 1 : value;
-    else if (n == "wgrad_tr_blocks") g_opt_wgrad_tr_blocks = value < 1 ? 1 : value;
-    else return mfx_fail(MFX_ERR_ARG, "set_option: unknown option");
+    int* slot = option_slot(n);
+    if (!slot) return mfx_fail(MFX_ERR_ARG, "set_option: unknown option");
+    auto& defs = option_defaults();
+    bool seen = false;
+    for (const auto& e : defs) seen = seen || e.first == slot;
+    if (!seen) defs.emplace_back(slot, *slot);
+    if (n == "dcn_wgrad_m") value = value < 64 ? 64 : value;
+    else if (n == "dcn_bt_fuse_blocks") value = value > 0 ? value : 170;
+    else if (n == "deterministic") value = value ? 1 : 0;
+    else if (n == "dcn_bt_fuse_min_chunks" || n == "wgrad_patch_blocks" || n == "wgrad_tr_blocks") value = value < 1 ? 1 : value;
+    *slot = value;
+    return MFX_OK;
+}
+
+// Every tuning / debug switch back to the value it had at load time.  The switches are process-wide (one host thread drives the library:
+// see the threading note in the header), so a test that forces a kernel variant and fails half-way would otherwise leak it into the next test
+// (tests/conftest.py calls this after every GPU test).
+extern "C" int mfx_reset_options(void) {
+    for (const auto& e : option_defaults()) *e.first = e.second;
     return MFX_OK;
 }
 

@@ -114,6 +114,7 @@ SYMBOLS = {
     "mfx_stem_conv7x7_nchw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_f1_fused": (_I, [_P] * 11 + [_I, _I, _I, _I, _I, _P]),
     "mfx_set_option": (_I, [ctypes.c_char_p, _I]),
+    "mfx_reset_options": (_I, []),
     "mfx_get_counter": (ctypes.c_long, [ctypes.c_char_p]),
     "mfx_dcn_v2_workspace_bytes": (_S, [_I] * 14),
     "mfx_dcn_v2_forward": (_I, [_P] * 6 + [_I] * 14 + [_P, _S, _P]),

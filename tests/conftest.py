@@ -26,3 +26,21 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _library_options_do_not_leak(request):
+    """The library's tuning switches are process-wide (mfx_set_option): a GPU test that forces a kernel variant and fails half-way must not
+    hand it to the next test -- every switch goes back to its load-time value after each gpu-marked test (hygiene)."""
+    yield
+    if "gpu" in request.keywords:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                from monoflex_amd import lib as L
+                was_det = torch.are_deterministic_algorithms_enabled()
+                L.load().mfx_reset_options()
+                if was_det:                                       # (a module-scoped `deterministic` fixture owns that switch: keep both halves in step)
+                    L.load().mfx_set_option(b"deterministic", 1)
+        except Exception:                                         # noqa: BLE001  (no library on a CPU-only run)
+            pass

@@ -1,0 +1,3 @@
+mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd $R
+timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider > gpurun_out/r05_full_gpu_tests.log 2>&1; tail -5 gpurun_out/r05_full_gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
