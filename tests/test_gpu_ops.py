@@ -604,3 +604,31 @@ def test_conv_cw_kernel_is_bit_identical_to_the_halo_kernel(dtype, C, Cout, B, H
     finally:
         L.check(lib_.mfx_set_option(b"halo_cw", 1), "opt")
         L.check(lib_.mfx_set_option(b"halo", 1), "opt")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,B,H,W,variant", [(128, 2, 16, 32, 8), (128, 1, 13, 37, 10), (256, 2, 16, 32, 10), (256, 1, 11, 21, 8), (512, 2, 12, 40, 10),
+                                             (512, 1, 9, 17, 8)])
+def test_conv_cw_offset_mask_conv_is_bit_identical_to_the_halo_kernel(dtype, C, B, H, W, variant):
+    """The 27-channel DCN offset / mask conv of the wide layers (dcn_v2.py:104-122: fp32 out, bias, sigmoid on channels 18..26, N padded to 32) on
+    conv3x3_cw_kernel's one-slice / four-way K-split instantiations: same bits as conv3x3_wave_kernel's variants 8 and 10."""
+    ops, L = _ops()
+    g = _g(141)
+    x = torch.randn(B, H, W, C, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(27, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+    bias = torch.randn(27, generator=g).to(DEV)
+    p = ops.pack_conv(w, dtype, None, bias, stride=1, pad=1, act=L.ACT_DCN_OFFMASK, cout=32)
+    lib_ = L.load()
+    try:
+        L.check(lib_.mfx_set_option(b"halo", variant + 1), "opt")
+        L.check(lib_.mfx_set_option(b"halo_cw", 0), "opt")
+        want = ops.conv2d(x, p, out_dtype=torch.float32)
+        L.check(lib_.mfx_set_option(b"halo_cw", 1), "opt")
+        got = ops.conv2d(x, p, out_dtype=torch.float32)
+        assert got.dtype == torch.float32 and torch.equal(got.view(torch.int32), want.view(torch.int32))
+        ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.to(dtype).float(), bias, padding=1).permute(0, 2, 3, 1)
+        ref = torch.cat((ref[..., :18], torch.sigmoid(ref[..., 18:27])), -1)
+        assert float((got[..., :27] - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    finally:
+        L.check(lib_.mfx_set_option(b"halo_cw", 1), "opt")
+        L.check(lib_.mfx_set_option(b"halo", 1), "opt")
