@@ -31,13 +31,15 @@
 
 namespace mfx {
 
-struct CwGeom { int B, H, W, tiles_x, tiles_y, tiles_n; };
+struct CwGeom { int B, H, W, Ho, Wo, tiles_x, tiles_y, tiles_n; };      // H x W: input map, Ho x Wo: output map (= H x W at stride 1)
 
-constexpr int kCwRows = 8, kCwPW = 18, kCwPH = 10;
+constexpr int kCwRows = 8;
 
-template <int CG, int WN, int FN, int WK> struct CwSmem {
+// patch of an 8 x 16 output tile at stride S: (7 S + 3) x (15 S + 3) input pixels (10 x 18, or 17 x 33 at stride 2)
+template <int CG, int WN, int FN, int WK, int S = 1> struct CwSmem {
     static constexpr int PS = CG * 2 + 16;                                    // patch pixel stride: 16 consecutive pixels on 16 distinct 16-byte bank slots
-    static constexpr int patch_bytes = kCwPH * kCwPW * PS;
+    static constexpr int PH = (kCwRows - 1) * S + 3, PW = 15 * S + 3;
+    static constexpr int patch_bytes = PH * PW * PS;
     static constexpr int stage_ld = FN * 16 + 4;
     static constexpr int stage_bytes = 16 * stage_ld * 4;
     static constexpr int reduce_bytes = WN * (WK - 1) * kCwRows * FN * 64 * 16;
@@ -47,11 +49,11 @@ template <int CG, int WN, int FN, int WK> struct CwSmem {
 
 // CG = channels per patch pass, CT = input channels of the layer (a multiple of CG), WN x FN x 16 = output channels per workgroup,
 // WK = waves sharing an output slice (they take the K steps round-robin); OCC = waves per SIMD the register allocation must admit
-template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC>
+template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC, int S = 1>
 __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* __restrict__ x, const u32x4* __restrict__ wfm, CwGeom g, EpiArgs ep) {
     static_assert(sizeof(T) == 2, "16-bit maps");
-    constexpr int NT = WN * WK * 64, FM = kCwRows, PW = kCwPW, PH = kCwPH;
-    using SM = CwSmem<CG, WN, FN, WK>;
+    using SM = CwSmem<CG, WN, FN, WK, S>;
+    constexpr int NT = WN * WK * 64, FM = kCwRows, PW = SM::PW, PH = SM::PH;
     constexpr int PS = SM::PS, CPP = CG / 8;
     constexpr int KS = CG / 32;                       // 64-byte K steps per tap and channel group
     constexpr int NG = CT / CG, FSTEPS = 9 * CT / 32; // channel groups; steps per fragment row of the fragment-major weights
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
     }
 
     // lane's patch base: pixel column xl, K chunk kq of the wave's first step (wave wk starts at step wk of every tap)
-    const char* abase = patch + xl * PS + kq * 16 + wk * 64;
+    const char* abase = patch + xl * S * PS + kq * 16 + wk * 64;
     const uint32_t loff = (uint32_t)lane * 16u;
     const T* xb = x + (size_t)b * g.H * g.W * CT;
 
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
                     if (base + u * NT + NT > nchunks) idx = idx < nchunks ? idx : nchunks - 1;
                     const int pix = idx / CPP, ch = idx % CPP;
                     const int py = pix / PW, px = pix - py * PW;
-                    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                    const int iy = y0 * S - 1 + py, ix = x0 * S - 1 + px;
                     const bool in = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
                     const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
                     const u32x4 z = *reinterpret_cast<const u32x4*>(xg + (uint32_t)((cy * g.W + cx) * CT + ch * 8));
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
         auto aread = [&](int m, int i) -> u32x4 {
             const int q = m * WK, tap = q / KS, ks = q % KS;
             const int th = tap / 3, tw = tap - th * 3;
-            return *reinterpret_cast<const u32x4*>(abase + ((th + i) * PW + tw) * PS + ks * 64);
+            return *reinterpret_cast<const u32x4*>(abase + ((th + i * S) * PW + tw) * PS + ks * 64);
         };
 
         constexpr int RING = 3;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
     constexpr bool kRes = std::is_same<T, TO>::value;         // residual operand: same type as the output (the launcher rejects the other case)
     const T* res = kRes ? reinterpret_cast<const T*>(ep.res) : nullptr;
     TO* y = reinterpret_cast<TO*>(ep.y);
-    const uint32_t pix0 = (uint32_t)((b * g.H + y0) * g.W + x0);            // first pixel of the tile (32-bit: M * ld < 2^31 checked by the launcher)
+    const uint32_t pix0 = (uint32_t)((b * g.Ho + y0) * g.Wo + x0);            // first pixel of the tile (32-bit: M * ld < 2^31 checked by the launcher)
     u32x4 rres[RW][RITEMS];
     if (res) {
 #pragma unroll
@@ -226,9 +228,9 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
             for (int q = 0; q < RITEMS; ++q) {
                 const int it = q * 64 + lane;
                 const int px = it / GPR, ng = it - px * GPR;
-                const bool ok = (16 * GPR % 64 == 0 || it < 16 * GPR) && y0 + i < g.H && x0 + px < g.W && n0 + ng * OE < ep.Cout;
+                const bool ok = (16 * GPR % 64 == 0 || it < 16 * GPR) && y0 + i < g.Ho && x0 + px < g.Wo && n0 + ng * OE < ep.Cout;
                 u32x4 z = {0u, 0u, 0u, 0u};
-                if (ok) z = *reinterpret_cast<const u32x4*>(res + (pix0 + (uint32_t)(i * g.W + px)) * (uint32_t)ep.ldres + (uint32_t)(n0 + ng * OE));
+                if (ok) z = *reinterpret_cast<const u32x4*>(res + (pix0 + (uint32_t)(i * g.Wo + px)) * (uint32_t)ep.ldres + (uint32_t)(n0 + ng * OE));
                 rres[ii][q] = z;
             }
         }
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
             const int it = q * 64 + lane;
             const int px = it / GPR, ng = it - px * GPR;
             const int gn = n0 + ng * OE;
-            const bool ok = (16 * GPR % 64 == 0 || it < 16 * GPR) && y0 + i < g.H && x0 + px < g.W && gn < ep.Cout;
+            const bool ok = (16 * GPR % 64 == 0 || it < 16 * GPR) && y0 + i < g.Ho && x0 + px < g.Wo && gn < ep.Cout;
             if (ok) {
                 float v[OE];
 #pragma unroll
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
                     }
                 }
                 apply_act_chunk<OE>(v, ep.act, gn);
-                *reinterpret_cast<u32x4*>(y + (pix0 + (uint32_t)(i * g.W + px)) * (uint32_t)ep.ldy + (uint32_t)gn) = ElemTraits<TO>::pack(v);
+                *reinterpret_cast<u32x4*>(y + (pix0 + (uint32_t)(i * g.Wo + px)) * (uint32_t)ep.ldy + (uint32_t)gn) = ElemTraits<TO>::pack(v);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -272,17 +274,17 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
 
 int g_opt_halo_cw = 1;       // option "halo_cw": 0 = conv3x3_wave_kernel only, 1 = this kernel where an instantiation exists
 
-template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC>
+template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC, int S = 1>
 static int launch_cw(const mfx_conv_desc* d, hipStream_t st) {
-    using SM = CwSmem<CG, WN, FN, WK>;
+    using SM = CwSmem<CG, WN, FN, WK, S>;
     constexpr int BN = WN * FN * 16;
     CwGeom g;
-    g.B = d->B; g.H = d->H; g.W = d->W;
-    g.tiles_x = (d->W + 15) / 16; g.tiles_y = (d->H + kCwRows - 1) / kCwRows; g.tiles_n = d->Cout_pad / BN;
+    g.B = d->B; g.H = d->H; g.W = d->W; g.Ho = d->Ho; g.Wo = d->Wo;
+    g.tiles_x = (d->Wo + 15) / 16; g.tiles_y = (d->Ho + kCwRows - 1) / kCwRows; g.tiles_n = d->Cout_pad / BN;
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
-    auto k = conv3x3_cw_kernel<T, TO, CG, CT, WN, FN, WK, OCC>;
+    auto k = conv3x3_cw_kernel<T, TO, CG, CT, WN, FN, WK, OCC, S>;
     constexpr int smem = SM::total;
     static bool attr_done = false;
     if (!attr_done && smem > 64 * 1024) {
@@ -305,6 +307,17 @@ template <typename T, int OCC> static int cw_shape(const mfx_conv_desc* d, int v
     return 1;                                                 // no instantiation: the caller falls back
 }
 
+// the four stride-2 convs that open DLA levels 2-5 (dla_dcn.py:84-98 conv1 of the first BasicBlock): 17 x 33 patches; 32-channel groups keep a
+// patch at 45 KB where no wave splits K, the K-split variant needs two steps per tap (64-channel groups, 81 KB: one workgroup per CU)
+template <typename T> static int cw_shape_s2(const mfx_conv_desc* d, int v, hipStream_t st) {
+    const int C = d->Ck;
+    if (v == 6 && C == 32) return launch_cw<T, T, 32, 32, 2, 2, 1, 2, 2>(d, st);
+    if (v == 7 && C == 64) return launch_cw<T, T, 32, 64, 4, 2, 1, 2, 2>(d, st);
+    if (v == 11 && C == 128) return launch_cw<T, T, 64, 128, 4, 2, 2, 2, 2>(d, st);
+    if (v == 11 && C == 256) return launch_cw<T, T, 64, 256, 4, 2, 2, 2, 2>(d, st);
+    return 1;
+}
+
 // the 27-channel DCN offset / mask convs of the wide layers (fp32 out, sigmoid on the mask channels, N = 32): one output slice per workgroup,
 // four waves share it and split K (conv_halo.hip's variants 8 = 32 channels per workgroup, 10 = 16)
 template <typename T> static int cw_shape_f32out(const mfx_conv_desc* d, int v, hipStream_t st) {
@@ -321,17 +334,18 @@ template <typename T> static int cw_shape_f32out(const mfx_conv_desc* d, int v, 
 // returns MFX_OK (0) if this kernel ran, 1 if there is no instantiation for the shape / variant (caller runs conv3x3_wave_kernel), < 0 on error.
 // `v` is conv_halo.hip's variant number (6: 2 waves x 32 channels, 7: 4 x 32, 11: 4 x 32 with a 2-way K split; 8 / 10: one slice, 4-way K split)
 int try_conv_cw(const mfx_conv_desc* d, int v, hipStream_t st) {
-    if (!g_opt_halo_cw || !d->w_frag || d->stats || d->stride != 1) return 1;
+    if (!g_opt_halo_cw || !d->w_frag || d->stats || (d->stride != 1 && d->stride != 2)) return 1;
     if (d->dtype != MFX_BF16 && d->dtype != MFX_F16) return 1;
     if (d->K_pad != 9 * d->Ck) return 1;
     if ((long long)d->M * (d->ldy > d->ldres ? d->ldy : d->ldres) >= (1ll << 31) || (long long)d->H * d->W * d->Ck >= (1ll << 31)) return 1;      // 32-bit element offsets
     if (d->out_dtype == MFX_F32) {
-        if (d->res || d->Cout % 4 != 0 || d->Cout_pad != 32 || (v != 8 && v != 10)) return 1;
+        if (d->stride != 1 || d->res || d->Cout % 4 != 0 || d->Cout_pad != 32 || (v != 8 && v != 10)) return 1;
         return d->dtype == MFX_F16 ? cw_shape_f32out<half_t>(d, v, st) : cw_shape_f32out<bf16_t>(d, v, st);
     }
     if (d->out_dtype != d->dtype || d->Cout % 8 != 0 || d->act == MFX_ACT_DCN_OFFMASK) return 1;
     if (v == 6 && d->Cout_pad % 64 != 0) return 1;
     if ((v == 7 || v == 11) && d->Cout_pad % 128 != 0) return 1;
+    if (d->stride == 2) return d->dtype == MFX_F16 ? cw_shape_s2<half_t>(d, v, st) : cw_shape_s2<bf16_t>(d, v, st);
     if (d->dtype == MFX_F16) return cw_shape<half_t, 2>(d, v, st);
     return cw_shape<bf16_t, 2>(d, v, st);
 }

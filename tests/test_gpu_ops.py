@@ -632,3 +632,35 @@ def test_conv_cw_offset_mask_conv_is_bit_identical_to_the_halo_kernel(dtype, C, 
     finally:
         L.check(lib_.mfx_set_option(b"halo_cw", 1), "opt")
         L.check(lib_.mfx_set_option(b"halo", 1), "opt")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,Cout,B,H,W,exact", [(32, 64, 2, 96, 160, True), (32, 64, 1, 45, 75, True), (64, 128, 2, 48, 64, True), (64, 128, 1, 27, 39, True),
+                                                (128, 256, 2, 24, 40, False), (128, 256, 1, 21, 35, False), (256, 512, 2, 24, 40, False)])
+def test_conv_cw_stride2_equals_the_halo_kernel(dtype, C, Cout, B, H, W, exact):
+    """The stride-2 convs that open DLA levels 2-5 (dla_dcn.py:84-98) on conv3x3_cw_kernel's 17 x 33-patch instantiations against
+    conv3x3_wave_kernel: same bits where no wave splits K (same channel groups, same step order); the K-split variants hand other steps to
+    each wave (two 64-channel steps per tap instead of a round-robin over 32-channel groups), i.e. the same products in another fp32
+    summation order -- equal to rounding.  Even and odd map sizes, ragged tiles, BN + ReLU epilogue, and the generic kernel as a third opinion."""
+    ops, L = _ops()
+    g = _g(151)
+    x = torch.randn(B, H, W, C, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+    p = ops.pack_conv(w, dtype, (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV), stride=2, pad=1, act=L.ACT_RELU)
+    lib_ = L.load()
+    try:
+        L.check(lib_.mfx_set_option(b"halo_cw", 0), "opt")
+        want = ops.conv2d(x, p)
+        L.check(lib_.mfx_set_option(b"halo_cw", 1), "opt")
+        got = ops.conv2d(x, p)
+        assert got.shape == (B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout)
+        if exact:
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+        else:
+            assert float((got.float() - want.float()).abs().max()) <= 1.6e-2 * max(1.0, float(want.float().abs().max()))      # one 16-bit ulp of the largest value
+        L.check(lib_.mfx_set_option(b"halo", 0), "opt")
+        gen = ops.conv2d(x, p)
+        assert float((got.float() - gen.float()).abs().max()) <= 2e-2 * max(1.0, float(gen.float().abs().max()))
+    finally:
+        L.check(lib_.mfx_set_option(b"halo_cw", 1), "opt")
+        L.check(lib_.mfx_set_option(b"halo", 1), "opt")
