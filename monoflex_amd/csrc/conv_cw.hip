@@ -56,7 +56,7 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
     constexpr int NT = WN * WK * 64, FM = kCwRows, PW = SM::PW, PH = SM::PH;
     constexpr int PS = SM::PS, CPP = CG / 8;
     constexpr int KS = CG / 32;                       // 64-byte K steps per tap and channel group
-    constexpr int NG = CT / CG, FSTEPS = 9 * CT / 32; // channel groups; steps per fragment row of the fragment-major weights
+    constexpr int NG = CT / CG, FSTEPS = (9 * CT + 63) / 64 * 2;   // channel groups; steps per fragment row of the fragment-major weights (K padded to 128 bytes)
     constexpr int SPG = 9 * KS, NL = SPG / WK;        // steps per group; steps per wave and group
     static_assert(KS % WK == 0 && CT % CG == 0 && FM % WK == 0, "K split must divide the steps of a tap and the rows");
     constexpr int BN = WN * FN * 16;
@@ -336,7 +336,7 @@ template <typename T> static int cw_shape_f32out(const mfx_conv_desc* d, int v, 
 int try_conv_cw(const mfx_conv_desc* d, int v, hipStream_t st) {
     if (!g_opt_halo_cw || !d->w_frag || d->stats || (d->stride != 1 && d->stride != 2)) return 1;
     if (d->dtype != MFX_BF16 && d->dtype != MFX_F16) return 1;
-    if (d->K_pad != 9 * d->Ck) return 1;
+    if (d->K_pad != (9 * d->Ck + 63) / 64 * 64) return 1;
     if ((long long)d->M * (d->ldy > d->ldres ? d->ldy : d->ldres) >= (1ll << 31) || (long long)d->H * d->W * d->Ck >= (1ll << 31)) return 1;      // 32-bit element offsets
     if (d->out_dtype == MFX_F32) {
         if (d->stride != 1 || d->res || d->Cout % 4 != 0 || d->Cout_pad != 32 || (v != 8 && v != 10)) return 1;

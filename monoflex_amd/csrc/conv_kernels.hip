@@ -111,18 +111,8 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
     const T* x; const float* om; DcnGeom g; int c, r0, cur_tap;
     int oh_[R], ow_[R], pix0[R], mrow[R]; bool ok[R];
     int coff[R][4]; float cw[R][4];
-    float nom[R][3]; int nom_tap;                             // offsets / mask of tap `nom_tap`, fetched one tap ahead of their use (r05)
-    u32x4 regs[R][4];
-    __device__ __forceinline__ void om_fetch(int tap) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const float* o = om + (size_t)mrow[i] * 32;
-            nom[i][0] = o[2 * tap]; nom[i][1] = o[2 * tap + 1]; nom[i][2] = o[18 + tap];
-        }
-        nom_tap = tap;
-    }
     __device__ __forceinline__ void init(const T* x_, const float* om_, const DcnGeom& g_, int m0, int tid) {
-        x = x_; om = om_; g = g_; c = tid % KC; r0 = tid / KC; cur_tap = -1; nom_tap = -1;
+        x = x_; om = om_; g = g_; c = tid % KC; r0 = tid / KC; cur_tap = -1;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int m = m0 + r0 + RPP * i;
@@ -137,14 +127,12 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
     }
     __device__ __forceinline__ void tap_setup(int tap) {
         const int th = (tap * g.inv_kw) >> 16, tw = tap - th * g.kw;
-        if (nom_tap != tap) om_fetch(tap);                    // (first tap of the workgroup, or of a K split that starts mid-way)
-        float cur[R][3];
-#pragma unroll
-        for (int i = 0; i < R; ++i) { cur[i][0] = nom[i][0]; cur[i][1] = nom[i][1]; cur[i][2] = nom[i][2]; }
-        if (tap + 1 < g.kh * g.kw) om_fetch(tap + 1);         // in flight while this tap's corners are gathered and multiplied
+        // (r05: fetching the NEXT tap's offsets one tap ahead measured neutral in bf16 and -2.8 % in the split-precision instantiation -- six
+        // more live registers per row; the offset rows are L2-resident and other workgroups cover the dependent load.  Not kept.)
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const float dh = cur[i][0], dw = cur[i][1], mk = cur[i][2];
+            const float* o = om + (size_t)mrow[i] * 32;
+            const float dh = o[2 * tap], dw = o[2 * tap + 1], mk = o[18 + tap];
             const float h = (float)(oh_[i] * g.stride - g.pad + th * g.dil) + dh;
             const float w = (float)(ow_[i] * g.stride_w - g.pad_w + tw * g.dil_w) + dw;
             const bool inside = ok[i] && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;

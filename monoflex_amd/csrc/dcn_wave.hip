@@ -69,23 +69,11 @@ __global__ __launch_bounds__(WN * 64, 2) void dcn_wave_kernel(const T* __restric
         omr[r] = om + (size_t)pm * 32;
     }
     int coff[RPW][4]; float cw[RPW][4];
-    // offsets / mask of the NEXT tap are fetched one tap ahead (r05): read where they are used, every tap change put a dependent global
-    // round trip (offset row -> corner addresses -> corner loads) on the workgroup's critical path
-    float nom[RPW][3];
-    auto omfetch = [&](int tap) {
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) { nom[r][0] = omr[r][2 * tap]; nom[r][1] = omr[r][2 * tap + 1]; nom[r][2] = omr[r][18 + tap]; }
-    };
-    const int ntaps = g.kh * g.kw;
     auto geom = [&](int tap) {
         const int th = (tap * g.inv_kw) >> 16, tw = tap - th * g.kw;
-        float cur[RPW][3];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) { cur[r][0] = nom[r][0]; cur[r][1] = nom[r][1]; cur[r][2] = nom[r][2]; }
-        if (tap + 1 < ntaps) omfetch(tap + 1);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            const float dh = cur[r][0], dw = cur[r][1], mk = cur[r][2];
+            const float dh = omr[r][2 * tap], dw = omr[r][2 * tap + 1], mk = omr[r][18 + tap];
             const float h = (float)(oh_[r] * g.stride - g.pad + th * g.dil) + dh;
             const float w = (float)(ow_[r] * g.stride - g.pad + tw * g.dil) + dw;
             const bool inside = mok[r] && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
@@ -156,7 +144,6 @@ __global__ __launch_bounds__(WN * 64, 2) void dcn_wave_kernel(const T* __restric
 
     const int ns = g.fsteps;                                  // kh*kw*C / (4*ELEMS)
     u32x4 wb[3][FN];
-    omfetch(0);
     geom(0);
     gload(0);
     wfetch(0, wb[0]);

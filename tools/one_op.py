@@ -5,6 +5,7 @@
   one_op.py dcn     B H W Cin Cout [--opts k=v,...] [--reps 10] [--std 1.5]          fused DCN forward (given offsets)
   one_op.py dcnmod  B H W Cin Cout [--opts ...] [--reps 10] [--std 1.5]              DCN module: offset conv + DCN + BN + ReLU
   one_op.py dcnbwd  B H W Cin Cout [--opts ...] [--reps 5]  [--std 1.5] [--dtype bf16]   NHWC DCN backward
+  one_op.py conv    B H W Cin Cout [--opts ...] [--reps 10]                          3x3 / stride 1 conv + BN + residual + ReLU (trunk layer)
 """
 import argparse
 import os
@@ -15,7 +16,7 @@ sys.path.insert(0, ROOT)
 import torch
 
 ap = argparse.ArgumentParser()
-ap.add_argument("op", choices=["heads", "dcn", "dcnmod", "dcnbwd"])
+ap.add_argument("op", choices=["heads", "dcn", "dcnmod", "dcnbwd", "conv"])
 ap.add_argument("shape", nargs="*", type=int)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--dtype", default="bf16")
@@ -79,7 +80,11 @@ else:
     B, H, W, Ci, Co = a.shape
     x = torch.randn(B, H, W, Ci, device="cuda").relu().to(dt)
     w = torch.randn(Co, Ci, 3, 3, device="cuda") * (1.0 / (3 * Ci ** 0.5))
-    if a.op == "dcn":
+    if a.op == "conv":
+        r = torch.randn(B, H, W, Co, device="cuda").to(dt)
+        p = ops.pack_conv(w, dt, torch.rand(Co, device="cuda") + 0.5, torch.randn(Co, device="cuda"), stride=1, pad=1, act=1)
+        timed(lambda: ops.conv2d(x, p, res=r), "conv3x3 %dx%dx%d %d->%d" % (B, H, W, Ci, Co))
+    elif a.op == "dcn":
         om = torch.zeros(B, H, W, 32, device="cuda")
         om[..., :18] = torch.randn(B, H, W, 18, device="cuda") * a.std
         om[..., 18:27] = torch.rand(B, H, W, 9, device="cuda")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the DCN backward group (64->64 @ 96x320, B=8, bf16): FETCH_SIZE and WRITE_SIZE in separate --pmc passes (no tracing),
 # summed over the group's kernels per backward call.  Writes gpurun_out/<tag>_dcnbwd_pmc.{txt,csv} and <tag>_dcnbwd_traffic.json.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_dcnbwd
 rm -rf $OUT; mkdir -p $OUT
