@@ -111,6 +111,7 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
     const T* x; const float* om; DcnGeom g; int c, r0, cur_tap;
     int oh_[R], ow_[R], pix0[R], mrow[R]; bool ok[R];
     int coff[R][4]; float cw[R][4];
+    u32x4 regs[R][4];
     __device__ __forceinline__ void init(const T* x_, const float* om_, const DcnGeom& g_, int m0, int tid) {
         x = x_; om = om_; g = g_; c = tid % KC; r0 = tid / KC; cur_tap = -1;
 #pragma unroll
