@@ -110,7 +110,7 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
     static_assert(BM % RPP == 0, "BM must be a multiple of the rows covered per pass");
     const T* x; const float* om; DcnGeom g; int c, r0, cur_tap;
     int oh_[R], ow_[R], pix0[R], mrow[R]; bool ok[R];
-    int coff[R][4]; float cw[R][4];
+    uint32_t cofb[R][4]; float cw[R][4];      // byte offsets of the four (clamped) corner rows' chunk c (the launch checks the tensor is < 4 GB)
     u32x4 regs[R][4];
     __device__ __forceinline__ void init(const T* x_, const float* om_, const DcnGeom& g_, int m0, int tid) {
         x = x_; om = om_; g = g_; c = tid % KC; r0 = tid / KC; cur_tap = -1;
@@ -130,6 +130,7 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
         const int th = (tap * g.inv_kw) >> 16, tw = tap - th * g.kw;
         // (r05: fetching the NEXT tap's offsets one tap ahead measured neutral in bf16 and -2.8 % in the split-precision instantiation -- six
         // more live registers per row; the offset rows are L2-resident and other workgroups cover the dependent load.  Not kept.)
+        const uint32_t rowb = (uint32_t)g.C * sizeof(T), cb = (uint32_t)c * 16;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const float* o = om + (size_t)mrow[i] * 32;
@@ -144,22 +145,23 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
             const bool l0 = w0 >= 0, l1 = w1 <= g.W - 1;
             const int ch0 = min(max(h0, 0), g.H - 1), ch1 = min(max(h1, 0), g.H - 1);
             const int cw0 = min(max(w0, 0), g.W - 1), cw1 = min(max(w1, 0), g.W - 1);
-            coff[i][0] = pix0[i] + ch0 * g.W + cw0; cw[i][0] = (t0 && l0) ? hh * hw_ * mk : 0.f;
-            coff[i][1] = pix0[i] + ch0 * g.W + cw1; cw[i][1] = (t0 && l1) ? hh * lw * mk : 0.f;
-            coff[i][2] = pix0[i] + ch1 * g.W + cw0; cw[i][2] = (t1 && l0) ? lh * hw_ * mk : 0.f;
-            coff[i][3] = pix0[i] + ch1 * g.W + cw1; cw[i][3] = (t1 && l1) ? lh * lw * mk : 0.f;
+            cofb[i][0] = (uint32_t)(pix0[i] + ch0 * g.W + cw0) * rowb + cb; cw[i][0] = (t0 && l0) ? hh * hw_ * mk : 0.f;
+            cofb[i][1] = (uint32_t)(pix0[i] + ch0 * g.W + cw1) * rowb + cb; cw[i][1] = (t0 && l1) ? hh * lw * mk : 0.f;
+            cofb[i][2] = (uint32_t)(pix0[i] + ch1 * g.W + cw0) * rowb + cb; cw[i][2] = (t1 && l0) ? lh * hw_ * mk : 0.f;
+            cofb[i][3] = (uint32_t)(pix0[i] + ch1 * g.W + cw1) * rowb + cb; cw[i][3] = (t1 && l1) ? lh * lw * mk : 0.f;
         }
     }
     __device__ __forceinline__ void load(int kiter) {
         const int e = kiter * (KC * ELEMS);
-        const int ci = (e & (g.C - 1)) + c * ELEMS;
+        const uint32_t kb = (uint32_t)(e & (g.C - 1)) * sizeof(T);   // byte offset of this k-iteration's channels inside a row
         const int tap = e >> g.lgC;
         if (tap != cur_tap) { tap_setup(tap); cur_tap = tap; } // wave-uniform: a new tap starts (or a K split starts mid-way)
+        const char* xk = reinterpret_cast<const char*>(x) + kb;     // wave-uniform base (scalar registers) + 32-bit lane offset
 #pragma unroll
         for (int i = 0; i < R; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                regs[i][q] = *reinterpret_cast<const u32x4*>(x + (size_t)coff[i][q] * g.C + ci);
+                regs[i][q] = *reinterpret_cast<const u32x4*>(xk + cofb[i][q]);
     }
     // blend weights cw[] were (re)computed by the load() that filled regs[]: load(k+1) -> mma(k) -> store(k+1)
     __device__ __forceinline__ void store(char* As) const {
@@ -168,9 +170,15 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
             float v[4][ELEMS], o[ELEMS];
 #pragma unroll
             for (int q = 0; q < 4; ++q) ElemTraits<T>::unpack(regs[i][q], v[q]);
+            // two channels per instruction (v_pk_mul_f32 / v_pk_fma_f32: packed fp32 runs at twice the scalar rate on CDNA3/4)
 #pragma unroll
-            for (int e = 0; e < ELEMS; ++e)
-                o[e] = cw[i][0] * v[0][e] + cw[i][1] * v[1][e] + cw[i][2] * v[2][e] + cw[i][3] * v[3][e];
+            for (int e = 0; e < ELEMS; e += 2) {
+                f32x2 t = (f32x2){v[0][e], v[0][e + 1]} * cw[i][0];
+                t = __builtin_elementwise_fma((f32x2){v[1][e], v[1][e + 1]}, (f32x2){cw[i][1], cw[i][1]}, t);
+                t = __builtin_elementwise_fma((f32x2){v[2][e], v[2][e + 1]}, (f32x2){cw[i][2], cw[i][2]}, t);
+                t = __builtin_elementwise_fma((f32x2){v[3][e], v[3][e + 1]}, (f32x2){cw[i][3], cw[i][3]}, t);
+                o[e] = t[0]; o[e + 1] = t[1];
+            }
             *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * kRowBytes + c * 16) = lds_operand<T>(ElemTraits<T>::pack(o));
         }
     }
@@ -289,6 +297,8 @@ extern int g_opt_wgrad_mfma, g_opt_wgrad_blocks, g_opt_wgrad_ws, g_opt_wgrad_ws_
 namespace mfx {
 int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st);      // dcn_wave.hip
 int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st);     // dcn_patch.hip
+int try_dcn_cq(const mfx_dcn_desc* d, hipStream_t st);        // dcn_cq.hip
+extern int g_opt_dcn_cq;
 bool dcn_patch_fuses_offset_conv(const mfx_dcn_desc* d);
 extern int g_opt_dcn_fuse_off;
 
@@ -410,7 +420,7 @@ static int* option_slot(const std::string& n) {
         {"conv_tile", &g_opt_conv_tile}, {"dcn_tile", &g_opt_dcn_tile}, {"cat_tile", &g_opt_cat_tile}, {"kc", &g_opt_kc}, {"ksplit", &g_opt_ksplit},
         {"dcn_ksplit", &g_opt_dcn_ksplit}, {"wgrad_mfma", &g_opt_wgrad_mfma}, {"wgrad_blocks", &g_opt_wgrad_blocks}, {"wgrad_ws", &g_opt_wgrad_ws},
         {"wgrad_ws_blocks", &g_opt_wgrad_ws_blocks}, {"dcn_wgrad_m", &g_opt_dcn_wgrad_m}, {"halo", &g_opt_halo}, {"halo_cg", &g_opt_halo_cg},
-        {"halo_cw", &g_opt_halo_cw}, {"halo_pair", &g_opt_halo_pair}, {"halo_s2", &g_opt_halo_s2}, {"dcn_wave", &g_opt_dcn_wave}, {"dcn_patch", &g_opt_dcn_patch},
+        {"halo_cw", &g_opt_halo_cw}, {"halo_pair", &g_opt_halo_pair}, {"halo_s2", &g_opt_halo_s2}, {"dcn_wave", &g_opt_dcn_wave}, {"dcn_patch", &g_opt_dcn_patch}, {"dcn_cq", &g_opt_dcn_cq},
         {"dcn_patch_fn8", &g_opt_dcn_patch_fn8}, {"dcn_fuse_off", &g_opt_dcn_fuse_off}, {"topk_strips", &g_opt_topk_strips},
 #ifdef MFX_PROBES
         {"dcn_bt_dbg", &g_opt_dcn_bt_dbg}, {"heads_dbg", &g_opt_heads_dbg},
@@ -639,8 +649,12 @@ extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
     g.stride_w = d->nonsquare ? d->stride_w : d->stride; g.pad_w = d->nonsquare ? d->pad_w : d->pad; g.dil_w = d->nonsquare ? d->dil_w : d->dil;
     if (d->nonsquare && (d->stride_w < 1 || d->dil_w < 1 || d->pad_w < 0)) return mfx_fail(MFX_ERR_ARG, "dcn: bad per-axis geometry");
     if (g.M <= 0) return MFX_OK;
+    if ((size_t)d->B * d->H * d->W * d->C * (elems == 8 ? 2 : 4) >= ((size_t)1 << 32))
+        return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn: input tensor of 4 GB or more (the gather kernels address it with 32-bit byte offsets)");
     if (!d->nonsquare) {                                      // (the LDS-patch / wave kernels are built for square geometry)
         int h = try_dcn_patch(d, reinterpret_cast<hipStream_t>(stream));
+        if (h != 0) return h < 0 ? h : MFX_OK;
+        h = try_dcn_cq(d, reinterpret_cast<hipStream_t>(stream));
         if (h != 0) return h < 0 ? h : MFX_OK;
         h = try_dcn_wave(d, reinterpret_cast<hipStream_t>(stream));
         if (h != 0) return h < 0 ? h : MFX_OK;

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(WN * 64, 2) void dcn_wave_kernel(const T* __restric
         pix0[r] = b * g.H * g.W;
         omr[r] = om + (size_t)pm * 32;
     }
-    int coff[RPW][4]; float cw[RPW][4];
+    uint32_t cofb[RPW][4]; float cw[RPW][4];      // byte offsets of the corner rows' chunk gc (tensor < 4 GB: checked at launch)
+    const uint32_t rowb = (uint32_t)g.C * sizeof(T), chb = (uint32_t)gc * 16;
     auto geom = [&](int tap) {
         const int th = (tap * g.inv_kw) >> 16, tw = tap - th * g.kw;
 #pragma unroll
@@ -83,19 +84,19 @@ __global__ __launch_bounds__(WN * 64, 2) void dcn_wave_kernel(const T* __restric
             const bool t0 = inside && h0 >= 0, t1 = inside && h1 <= g.H - 1, l0 = w0 >= 0, l1 = w1 <= g.W - 1;
             const int ch0 = min(max(h0, 0), g.H - 1), ch1 = min(max(h1, 0), g.H - 1);
             const int cw0 = min(max(w0, 0), g.W - 1), cw1 = min(max(w1, 0), g.W - 1);
-            coff[r][0] = pix0[r] + ch0 * g.W + cw0; cw[r][0] = (t0 && l0) ? hh * hw_ * mk : 0.f;
-            coff[r][1] = pix0[r] + ch0 * g.W + cw1; cw[r][1] = (t0 && l1) ? hh * lw * mk : 0.f;
-            coff[r][2] = pix0[r] + ch1 * g.W + cw0; cw[r][2] = (t1 && l0) ? lh * hw_ * mk : 0.f;
-            coff[r][3] = pix0[r] + ch1 * g.W + cw1; cw[r][3] = (t1 && l1) ? lh * lw * mk : 0.f;
+            cofb[r][0] = (uint32_t)(pix0[r] + ch0 * g.W + cw0) * rowb + chb; cw[r][0] = (t0 && l0) ? hh * hw_ * mk : 0.f;
+            cofb[r][1] = (uint32_t)(pix0[r] + ch0 * g.W + cw1) * rowb + chb; cw[r][1] = (t0 && l1) ? hh * lw * mk : 0.f;
+            cofb[r][2] = (uint32_t)(pix0[r] + ch1 * g.W + cw0) * rowb + chb; cw[r][2] = (t1 && l0) ? lh * hw_ * mk : 0.f;
+            cofb[r][3] = (uint32_t)(pix0[r] + ch1 * g.W + cw1) * rowb + chb; cw[r][3] = (t1 && l1) ? lh * lw * mk : 0.f;
         }
     };
     u32x4 gr[RPW][4];
     auto gload = [&](int s) {                                 // corners of step s (tap = s / spt, channel block s % spt)
-        const int c0 = (s % g.spt) * (4 * ELEMS) + gc * ELEMS;
+        const char* xk = reinterpret_cast<const char*>(x) + (s % g.spt) * 64;      // wave-uniform base + 32-bit lane offset
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) gr[r][q] = *reinterpret_cast<const u32x4*>(x + (size_t)coff[r][q] * g.C + c0);
+            for (int q = 0; q < 4; ++q) gr[r][q] = *reinterpret_cast<const u32x4*>(xk + cofb[r][q]);
     };
     auto gstore = [&](int buf) {                              // blend (fp32) and write this lane's chunk of its A-tile rows
 #pragma unroll
@@ -104,7 +105,13 @@ __global__ __launch_bounds__(WN * 64, 2) void dcn_wave_kernel(const T* __restric
 #pragma unroll
             for (int q = 0; q < 4; ++q) ElemTraits<T>::unpack(gr[r][q], v[q]);
 #pragma unroll
-            for (int e = 0; e < ELEMS; ++e) o[e] = cw[r][0] * v[0][e] + cw[r][1] * v[1][e] + cw[r][2] * v[2][e] + cw[r][3] * v[3][e];
+            for (int e = 0; e < ELEMS; e += 2) {               // two channels per instruction (v_pk_mul_f32 / v_pk_fma_f32)
+                f32x2 t = (f32x2){v[0][e], v[0][e + 1]} * cw[r][0];
+                t = __builtin_elementwise_fma((f32x2){v[1][e], v[1][e + 1]}, (f32x2){cw[r][1], cw[r][1]}, t);
+                t = __builtin_elementwise_fma((f32x2){v[2][e], v[2][e + 1]}, (f32x2){cw[r][2], cw[r][2]}, t);
+                t = __builtin_elementwise_fma((f32x2){v[3][e], v[3][e + 1]}, (f32x2){cw[r][3], cw[r][3]}, t);
+                o[e] = t[0]; o[e + 1] = t[1];
+            }
             *reinterpret_cast<u32x4*>(As + buf * (64 * kDcnRow) + ((wn * RPW + r) * 16 + gp) * kDcnRow + gc * 16) = lds_operand<T>(ElemTraits<T>::pack(o));
         }
     };

@@ -464,6 +464,38 @@ def test_offset_conv_k_split_waves(dtype, B, H, W, C):
         L.check(lib_.mfx_set_option(b"halo", 1), "opt")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,C,Cout,H,W,off_std", [(2, 64, 64, 20, 40, 1.5), (1, 128, 64, 33, 47, 3.0), (2, 256, 128, 12, 24, 2.0), (1, 512, 256, 7, 19, 6.0)])
+def test_dcn_corner_quad_kernels_match_the_blend_first_kernel(dtype, B, C, Cout, H, W, off_std):
+    """csrc/dcn_cq.hip (off by default: measured slower): the bilinear blend done by the matrix cores' accumulation
+    (acc += w_q * (W . x_q) over the four un-blended corner rows), register-ring form (option dcn_cq = 2) and LDS-DMA form (3), against the
+    library's blend-first gather kernel on the same inputs.  The corner-quad forms never round the blended sample to 16 bits, so they
+    agree with the blend-first kernel to that rounding (and are the closer of the two to the fp32 evaluation of the same op).  Ragged
+    pixel tiles, several output-channel tiles, one to four weight slabs per tap, offsets that leave the image (std 6 on a 7 x 19 map)."""
+    from monoflex_amd import lib as L, ops
+    g = _g(71)
+    x = torch.randn(B, H, W, C, generator=g).to(dtype).to(DEV)
+    om = torch.zeros(B, H, W, 32)
+    om[..., :18] = torch.randn(B, H, W, 18, generator=g) * off_std
+    om[..., 18:27] = torch.rand(B, H, W, 9, generator=g)
+    om = om.to(DEV)
+    w = torch.randn(Cout, C, 3, 3, generator=g) * (1.0 / (3 * C ** 0.5))
+    p = ops.pack_conv(w.to(DEV), dtype, torch.rand(Cout, generator=g).to(DEV) + 0.5, torch.randn(Cout, generator=g).to(DEV),
+                      stride=1, pad=1, act=L.ACT_RELU)
+    ops.add_f16_fragments(p, w)
+    p32 = ops.pack_conv(w.to(dtype).float().to(DEV), torch.float32, p.scale, p.shift, stride=1, pad=1, act=L.ACT_RELU)
+    lib_ = L.load()
+    L.check(lib_.mfx_set_option(b"dcn_patch", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_wave", 0), "opt")
+    ref = ops.dcn(x.float(), om, p32).cpu()                  # fp32 kernel on the same 16-bit-rounded operands
+    want = ops.dcn(x, om, p).float().cpu()
+    e_blend = float((want - ref).abs().mean())
+    for v in (2, 3):
+        L.check(lib_.mfx_set_option(b"dcn_cq", v), "opt")
+        got = ops.dcn(x, om, p).float().cpu()
+        assert float((got - want).abs().max()) <= 2e-2 * max(1.0, float(want.abs().max())), v
+        assert float((got - ref).abs().mean()) <= 1.05 * e_blend + 1e-6, (v, float((got - ref).abs().mean()), e_blend)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,C,Cout,H,W", [(2, 512, 256, 12, 40), (2, 256, 128, 24, 40), (1, 128, 64, 17, 23)])
 def test_dcn_split_k_matches_single_pass(dtype, B, C, Cout, H, W):
