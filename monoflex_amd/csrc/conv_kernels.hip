@@ -128,7 +128,9 @@ template <typename T, int BM, int NT, int KC> struct DcnALoader {
     }
     __device__ __forceinline__ void tap_setup(int tap) {
         const int th = (tap * g.inv_kw) >> 16, tw = tap - th * g.kw;
-        // (r05: fetching the NEXT tap's offsets one tap ahead measured neutral in bf16 and -2.8 % in the split-precision instantiation -- six
+        // (r05: running the gather TWO k-iterations ahead -- a second register stage, branch-free steady loop, the blend of k+1 under the loads of k+2 --
+    // measured 46.3 -> 48.0 us on 128 -> 64 @ 48x160 and worse where the extra 16-32 registers cost a wave per SIMD; tools/r05_call18.sh.  Not kept.)
+    // (r05: fetching the NEXT tap's offsets one tap ahead measured neutral in bf16 and -2.8 % in the split-precision instantiation -- six
         // more live registers per row; the offset rows are L2-resident and other workgroups cover the dependent load.  Not kept.)
         const uint32_t rowb = (uint32_t)g.C * sizeof(T), cb = (uint32_t)c * 16;
 #pragma unroll
