@@ -36,24 +36,27 @@ struct CwGeom { int B, H, W, Ho, Wo, tiles_x, tiles_y, tiles_n; };      // H x W
 constexpr int kCwRows = 8;
 
 // patch of an 8 x 16 output tile at stride S: (7 S + 3) x (15 S + 3) input pixels (10 x 18, or 17 x 33 at stride 2)
-template <int CG, int WN, int FN, int WK, int S = 1> struct CwSmem {
+template <int CG, int WN, int FN, int WK, int S = 1, int ROWS = kCwRows> struct CwSmem {
     static constexpr int PS = CG * 2 + 16;                                    // patch pixel stride: 16 consecutive pixels on 16 distinct 16-byte bank slots
-    static constexpr int PH = (kCwRows - 1) * S + 3, PW = 15 * S + 3;
+    static constexpr int PH = (ROWS - 1) * S + 3, PW = 15 * S + 3;
     static constexpr int patch_bytes = PH * PW * PS;
     static constexpr int stage_ld = FN * 16 + 4;
     static constexpr int stage_bytes = 16 * stage_ld * 4;
-    static constexpr int reduce_bytes = WN * (WK - 1) * kCwRows * FN * 64 * 16;
+    static constexpr int reduce_bytes = WN * (WK - 1) * ROWS * FN * 64 * 16;
     static constexpr int main_bytes = patch_bytes > reduce_bytes ? patch_bytes : reduce_bytes;
     static constexpr int total = main_bytes + WN * WK * stage_bytes;
 };
 
 // CG = channels per patch pass, CT = input channels of the layer (a multiple of CG), WN x FN x 16 = output channels per workgroup,
 // WK = waves sharing an output slice (they take the K steps round-robin); OCC = waves per SIMD the register allocation must admit
-template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC, int S = 1>
+// ROWS = output rows of a tile (8; 6 for maps whose height is a multiple of 6 but not of 8 -- the 12 x 40 level-5 maps: 2 x 3 tiles of 6 x 16 instead of
+// 2 x 3 tiles of 8 x 16, a quarter less matrix work)
+template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC, int S = 1, int ROWS = kCwRows>
 __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* __restrict__ x, const u32x4* __restrict__ wfm, CwGeom g, EpiArgs ep) {
     static_assert(sizeof(T) == 2, "16-bit maps");
-    using SM = CwSmem<CG, WN, FN, WK, S>;
-    constexpr int NT = WN * WK * 64, FM = kCwRows, PW = SM::PW, PH = SM::PH;
+    static_assert(ROWS % 2 == 0, "the K loop reads the pixel fragments in two half-tiles");
+    using SM = CwSmem<CG, WN, FN, WK, S, ROWS>;
+    constexpr int NT = WN * WK * 64, FM = ROWS, HR = ROWS / 2, PW = SM::PW, PH = SM::PH;
     constexpr int PS = SM::PS, CPP = CG / 8;
     constexpr int KS = CG / 32;                       // 64-byte K steps per tap and channel group
     constexpr int NG = CT / CG, FSTEPS = (9 * CT + 63) / 64 * 2;   // channel groups; steps per fragment row of the fragment-major weights (K padded to 128 bytes)
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
     const int tn = tile % g.tiles_n; tile /= g.tiles_n;
     const int tx = tile % g.tiles_x; tile /= g.tiles_x;
     const int ty = tile % g.tiles_y; const int b = tile / g.tiles_y;
-    const int x0 = tx * 16, y0 = ty * kCwRows, n0 = tn * BN + wn * (FN * 16);
+    const int x0 = tx * 16, y0 = ty * ROWS, n0 = tn * BN + wn * (FN * 16);
 
     char* patch = smem;
     float* stage = reinterpret_cast<float*>(smem + SM::main_bytes + wave * SM::stage_bytes);
@@ -147,29 +150,29 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
         if (NL > 1) bload(1, wb[1]);
         __syncthreads();                                      // patch visible to all waves
 
-        u32x4 a0[4], a1[4];
+        u32x4 a0[HR], a1[HR];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a0[i] = aread(0, i);
+        for (int i = 0; i < HR; ++i) a0[i] = aread(0, i);
 #pragma unroll
         for (int m = 0; m < NL; ++m) {
             if (m + 2 < NL) bload(m + 2, wb[(m + 2) % RING]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a1[i] = aread(m, 4 + i);
+            for (int i = 0; i < HR; ++i) a1[i] = aread(m, HR + i);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < HR; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) mma_chunk<T>(a0[i], wb[m % RING][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
             if (m + 1 < NL) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a0[i] = aread(m + 1, i);
+                for (int i = 0; i < HR; ++i) a0[i] = aread(m + 1, i);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < HR; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) mma_chunk<T>(a1[i], wb[m % RING][j], acc[4 + i][j]);
+                for (int j = 0; j < FN; ++j) mma_chunk<T>(a1[i], wb[m % RING][j], acc[HR + i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -274,17 +277,17 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
 
 int g_opt_halo_cw = 1;       // option "halo_cw": 0 = conv3x3_wave_kernel only, 1 = this kernel where an instantiation exists
 
-template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC, int S = 1>
+template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC, int S = 1, int ROWS = kCwRows>
 static int launch_cw(const mfx_conv_desc* d, hipStream_t st) {
-    using SM = CwSmem<CG, WN, FN, WK, S>;
+    using SM = CwSmem<CG, WN, FN, WK, S, ROWS>;
     constexpr int BN = WN * FN * 16;
     CwGeom g;
     g.B = d->B; g.H = d->H; g.W = d->W; g.Ho = d->Ho; g.Wo = d->Wo;
-    g.tiles_x = (d->Wo + 15) / 16; g.tiles_y = (d->Ho + kCwRows - 1) / kCwRows; g.tiles_n = d->Cout_pad / BN;
+    g.tiles_x = (d->Wo + 15) / 16; g.tiles_y = (d->Ho + ROWS - 1) / ROWS; g.tiles_n = d->Cout_pad / BN;
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
-    auto k = conv3x3_cw_kernel<T, TO, CG, CT, WN, FN, WK, OCC, S>;
+    auto k = conv3x3_cw_kernel<T, TO, CG, CT, WN, FN, WK, OCC, S, ROWS>;
     constexpr int smem = SM::total;
     static bool attr_done = false;
     if (!attr_done && smem > 64 * 1024) {
@@ -297,13 +300,16 @@ static int launch_cw(const mfx_conv_desc* d, hipStream_t st) {
     return MFX_OK;
 }
 
+int g_opt_cw_rows6 = 1;      // option "cw_rows6": 0 = 8-row tiles everywhere
+static inline bool cw_rows6(const mfx_conv_desc* d) { return g_opt_cw_rows6 && d->Ho % 6 == 0 && d->Ho % 8 != 0 && d->Ho <= 48; }
+
 template <typename T, int OCC> static int cw_shape(const mfx_conv_desc* d, int v, hipStream_t st) {
     const int C = d->Ck;
     if (v == 6 && C == 64) return launch_cw<T, T, 64, 64, 2, 2, 1, OCC>(d, st);
     if (v == 7 && C == 128) return launch_cw<T, T, 128, 128, 4, 2, 1, OCC>(d, st);
     if (v == 7 && C == 64) return launch_cw<T, T, 64, 64, 4, 2, 1, OCC>(d, st);
     if (v == 11 && C == 256) return launch_cw<T, T, 256, 256, 4, 2, 2, OCC>(d, st);
-    if (v == 11 && C == 512) return launch_cw<T, T, 256, 512, 4, 2, 2, OCC>(d, st);
+    if (v == 11 && C == 512) return cw_rows6(d) ? launch_cw<T, T, 256, 512, 4, 2, 2, OCC, 1, 6>(d, st) : launch_cw<T, T, 256, 512, 4, 2, 2, OCC>(d, st);
     return 1;                                                 // no instantiation: the caller falls back
 }
 
@@ -314,7 +320,7 @@ template <typename T> static int cw_shape_s2(const mfx_conv_desc* d, int v, hipS
     if (v == 6 && C == 32) return launch_cw<T, T, 32, 32, 2, 2, 1, 2, 2>(d, st);
     if (v == 7 && C == 64) return launch_cw<T, T, 32, 64, 4, 2, 1, 2, 2>(d, st);
     if (v == 11 && C == 128) return launch_cw<T, T, 64, 128, 4, 2, 2, 2, 2>(d, st);
-    if (v == 11 && C == 256) return launch_cw<T, T, 64, 256, 4, 2, 2, 2, 2>(d, st);
+    if (v == 11 && C == 256) return cw_rows6(d) ? launch_cw<T, T, 64, 256, 4, 2, 2, 2, 2, 6>(d, st) : launch_cw<T, T, 64, 256, 4, 2, 2, 2, 2>(d, st);
     return 1;
 }
 
@@ -324,7 +330,7 @@ template <typename T> static int cw_shape_f32out(const mfx_conv_desc* d, int v, 
     const int C = d->Ck;
     if (v == 8 && C == 128) return launch_cw<T, float, 128, 128, 1, 2, 4, 2>(d, st);
     if (v == 8 && C == 256) return launch_cw<T, float, 256, 256, 1, 2, 4, 2>(d, st);
-    if (v == 8 && C == 512) return launch_cw<T, float, 256, 512, 1, 2, 4, 2>(d, st);
+    if (v == 8 && C == 512) return launch_cw<T, float, 256, 512, 1, 2, 4, 2>(d, st);      // (8 rows x 4-way K split: 6 rows do not divide)
     if (v == 10 && C == 128) return launch_cw<T, float, 128, 128, 1, 1, 4, 2>(d, st);
     if (v == 10 && C == 256) return launch_cw<T, float, 256, 256, 1, 1, 4, 2>(d, st);
     if (v == 10 && C == 512) return launch_cw<T, float, 256, 512, 1, 1, 4, 2>(d, st);

@@ -131,12 +131,15 @@ class Tree(nn.Module):
             self.project = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, bias=False),
                                          nn.BatchNorm2d(out_channels, momentum=BN_MOMENTUM))
 
-    def forward(self, x, residual=None, children=None):       # dla_dcn.py:246-259
+    def forward(self, x, residual=None, children=None, bottom=None):       # dla_dcn.py:246-259
         children = [] if children is None else children
-        if self.training:
-            bottom = AG.MaxPool2x2Fn.apply(x) if self.downsample else x
-        else:
-            bottom = ops.maxpool2x2(x) if self.downsample else x
+        # `bottom`: a levels > 1 Tree and its nested tree1 both max-pool the SAME x (dla_dcn.py:248 runs twice on level3 / level4); the outer
+        # one hands its result down instead (r05: two of the six pooling launches of a pass, and of their backward, gone)
+        if bottom is None:
+            if self.training:
+                bottom = AG.MaxPool2x2Fn.apply(x) if self.downsample else x
+            else:
+                bottom = ops.maxpool2x2(x) if self.downsample else x
         if self.levels == 1:
             # a levels>1 Tree hands `residual` to a nested Tree that recomputes its own:
             # the outer level3/level4 `project` output is dead in the reference (its parameters never get a
@@ -149,7 +152,10 @@ class Tree(nn.Module):
                 residual = ops.conv2d(bottom, _conv_bn(self, "proj", self.project[0], self.project[1], x.dtype, L.ACT_NONE))
         if self.level_root:
             children.append(bottom)
-        x1 = self.tree1(x, residual)
+        if self.levels > 1 and isinstance(self.tree1, Tree) and self.tree1.downsample is not None and self.downsample is not None:
+            x1 = self.tree1(x, residual, bottom=bottom)
+        else:
+            x1 = self.tree1(x, residual)
         if self.levels == 1:
             x2 = self.tree2(x1)
             return self.root(x2, x1, *children)

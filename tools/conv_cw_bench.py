@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B of the two LDS-halo 3x3 conv kernels on the trunk's layer shapes: conv3x3_wave_kernel (option halo_cw=0) against conv3x3_cw_kernel
 (halo_cw=1; 2 = its 3-waves-per-SIMD register budget), BN + residual + ReLU epilogue, 20 launches per hipGraph replay, bf16.
-usage: python tools/conv_cw_bench.py [B=8]   -> markdown table on stdout"""
+usage: python tools/conv_cw_bench.py [B=8] [k=v,...]   -> markdown table on stdout"""
 import os
 import sys
 
@@ -12,6 +12,8 @@ from monoflex_amd import lib, ops
 
 L = lib.load()
 B0 = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+for kv in filter(None, (sys.argv[2] if len(sys.argv) > 2 else "").split(",")):      # extra library options, k=v,...
+    lib.check(L.mfx_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])), "opt")
 SHAPES = [(96, 320, 64, 64), (48, 160, 128, 128), (24, 80, 256, 256), (12, 40, 512, 512), (96, 320, 64, 128)]
 N = 20
 
