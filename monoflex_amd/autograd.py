@@ -95,7 +95,7 @@ class _PackRegistry:
             K_pad = (kh * kw * ck + 8 * E - 1) // (8 * E) * (8 * E)
             cp = ops.cout_pad(rows)
             packed = torch.empty((cp, K_pad), dtype=dtype, device=weight.device)
-            frag = torch.empty_like(packed) if (kh == 3 and kw == 3 and stride == 1 and pad_h == 1 and pad_w == 1) else None
+            frag = torch.empty_like(packed) if (kh == 3 and kw == 3 and stride in (1, 2) and pad_h == 1 and pad_w == 1) else None
             e = dict(ref=None, ptr=weight.data_ptr(), version=-1, packed=packed, frag=frag, cp=cp, K_pad=K_pad,
                      shape=(Cout, Cin, kh, kw), mode=mode, ck=ck, fp32=weight.dtype == torch.float32)
             if register:

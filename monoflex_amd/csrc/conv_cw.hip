@@ -51,7 +51,8 @@ template <int CG, int WN, int FN, int WK, int S = 1, int ROWS = kCwRows> struct 
 // WK = waves sharing an output slice (they take the K steps round-robin); OCC = waves per SIMD the register allocation must admit
 // ROWS = output rows of a tile (8; 6 for maps whose height is a multiple of 6 but not of 8 -- the 12 x 40 level-5 maps: 2 x 3 tiles of 6 x 16 instead of
 // 2 x 3 tiles of 8 x 16, a quarter less matrix work)
-template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC, int S = 1, int ROWS = kCwRows>
+// ST: train-mode BN statistics of the stored values accumulated by the epilogue (mfx_conv_desc.stats; conv_halo.hip's arithmetic)
+template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC, int S = 1, int ROWS = kCwRows, bool ST = false>
 __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* __restrict__ x, const u32x4* __restrict__ wfm, CwGeom g, EpiArgs ep) {
     static_assert(sizeof(T) == 2, "16-bit maps");
     static_assert(ROWS % 2 == 0, "the K loop reads the pixel fragments in two half-tiles");
@@ -222,6 +223,9 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
     const T* res = kRes ? reinterpret_cast<const T*>(ep.res) : nullptr;
     TO* y = reinterpret_cast<TO*>(ep.y);
     const uint32_t pix0 = (uint32_t)((b * g.Ho + y0) * g.Wo + x0);            // first pixel of the tile (32-bit: M * ld < 2^31 checked by the launcher)
+    f32x2 st_s[FN], st_q[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) { st_s[j] = f32x2{0.f, 0.f}; st_q[j] = f32x2{0.f, 0.f}; }
     u32x4 rres[RW][RITEMS];
     if (res) {
 #pragma unroll
@@ -242,9 +246,25 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
     for (int ii = 0; ii < RW; ++ii) {
         const int i = WK > 1 ? wk * RW + ii : ii;
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j) {
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[((lane >> 4) * 4 + r) * LDS_ + j * 16 + xl] = acc[ii][j][r] * sc[j] + sh[j];
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[ii][j][r] * sc[j] + sh[j];
+                stage[((lane >> 4) * 4 + r) * LDS_ + j * 16 + xl] = v[r];
+            }
+            if constexpr (ST) {
+                if (y0 + i < g.Ho) {                          // every lane sums its column over its pixels, of the values AS STORED
+                    const int px = x0 + (lane >> 4) * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        f32x2 vr = {ElemTraits<TO>::round(v[r]), ElemTraits<TO>::round(v[r + 1])};
+                        if (px + r + 1 >= g.Wo) { if (px + r >= g.Wo) vr[0] = 0.f; vr[1] = 0.f; }      // ragged right edge only
+                        st_s[j] += vr; st_q[j] += vr * vr;
+                    }
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < RITEMS; ++q) {
@@ -273,11 +293,22 @@ __global__ __launch_bounds__(WN * WK * 64, OCC) void conv3x3_cw_kernel(const T* 
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (ST) {                                       // the four pixel groups of the wave meet by shuffles, lanes 0..15 add into the layer's scratch
+        float* sp = ep.stats + (size_t)(blockIdx.x % ep.stats_ncopy) * 2 * ep.Cout;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            float a = st_s[j][0] + st_s[j][1], q = st_q[j][0] + st_q[j][1];
+            a += __shfl_xor(a, 16); q += __shfl_xor(q, 16);
+            a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
+            const int n = n0 + j * 16 + xl;
+            if (lane < 16 && n < ep.Cout) { unsafeAtomicAdd(sp + n, a); unsafeAtomicAdd(sp + ep.Cout + n, q); }
+        }
+    }
 }
 
 int g_opt_halo_cw = 1;       // option "halo_cw": 0 = conv3x3_wave_kernel only, 1 = this kernel where an instantiation exists
 
-template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC, int S = 1, int ROWS = kCwRows>
+template <typename T, typename TO, int CG, int CT, int WN, int FN, int WK, int OCC, int S = 1, int ROWS = kCwRows, bool ST = false>
 static int launch_cw(const mfx_conv_desc* d, hipStream_t st) {
     using SM = CwSmem<CG, WN, FN, WK, S, ROWS>;
     constexpr int BN = WN * FN * 16;
@@ -287,7 +318,8 @@ static int launch_cw(const mfx_conv_desc* d, hipStream_t st) {
     EpiArgs ep;
     ep.scale = d->scale; ep.shift = d->shift; ep.res = d->res; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = d->ldres;
     ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = g.tiles_n;
-    auto k = conv3x3_cw_kernel<T, TO, CG, CT, WN, FN, WK, OCC, S, ROWS>;
+    ep.stats = ST ? d->stats : nullptr; ep.stats_ncopy = d->stats_ncopy > 0 ? d->stats_ncopy : 1;
+    auto k = conv3x3_cw_kernel<T, TO, CG, CT, WN, FN, WK, OCC, S, ROWS, ST>;
     constexpr int smem = SM::total;
     static bool attr_done = false;
     if (!attr_done && smem > 64 * 1024) {
@@ -305,6 +337,17 @@ static inline bool cw_rows6(const mfx_conv_desc* d) { return g_opt_cw_rows6 && d
 
 template <typename T, int OCC> static int cw_shape(const mfx_conv_desc* d, int v, hipStream_t st) {
     const int C = d->Ck;
+    if (d->stats) {                                           // training forward: statistics epilogue (outputs up to 128 channels wide)
+        if (v == 6 && C == 64) return launch_cw<T, T, 64, 64, 2, 2, 1, OCC, 1, kCwRows, true>(d, st);
+        if (v == 7 && C == 128) return launch_cw<T, T, 128, 128, 4, 2, 1, OCC, 1, kCwRows, true>(d, st);
+        return 1;
+    }
+    // 32 input channels: the data gradients of the DCN modules' 27-channel offset / mask convs (training)
+    if (v == 6 && C == 32) return launch_cw<T, T, 32, 32, 2, 2, 1, OCC>(d, st);
+    if ((v == 7 || v == 11) && C == 32) return launch_cw<T, T, 32, 32, 4, 2, 1, OCC>(d, st);
+    if (v == 12 && C == 128) return launch_cw<T, T, 128, 128, 2, 2, 2, OCC>(d, st);
+    if (v == 13 && C == 256) return launch_cw<T, T, 256, 256, 2, 2, 4, OCC>(d, st);
+    if (v == 5 && C == 64) return launch_cw<T, T, 64, 64, 4, 4, 1, OCC>(d, st);
     if (v == 6 && C == 64) return launch_cw<T, T, 64, 64, 2, 2, 1, OCC>(d, st);
     if (v == 7 && C == 128) return launch_cw<T, T, 128, 128, 4, 2, 1, OCC>(d, st);
     if (v == 7 && C == 64) return launch_cw<T, T, 64, 64, 4, 2, 1, OCC>(d, st);
@@ -317,6 +360,11 @@ template <typename T, int OCC> static int cw_shape(const mfx_conv_desc* d, int v
 // patch at 45 KB where no wave splits K, the K-split variant needs two steps per tap (64-channel groups, 81 KB: one workgroup per CU)
 template <typename T> static int cw_shape_s2(const mfx_conv_desc* d, int v, hipStream_t st) {
     const int C = d->Ck;
+    if (d->stats) {
+        if (v == 6 && C == 32) return launch_cw<T, T, 32, 32, 2, 2, 1, 2, 2, kCwRows, true>(d, st);
+        if (v == 7 && C == 64) return launch_cw<T, T, 32, 64, 4, 2, 1, 2, 2, kCwRows, true>(d, st);
+        return 1;
+    }
     if (v == 6 && C == 32) return launch_cw<T, T, 32, 32, 2, 2, 1, 2, 2>(d, st);
     if (v == 7 && C == 64) return launch_cw<T, T, 32, 64, 4, 2, 1, 2, 2>(d, st);
     if (v == 11 && C == 128) return launch_cw<T, T, 64, 128, 4, 2, 2, 2, 2>(d, st);
@@ -340,7 +388,8 @@ template <typename T> static int cw_shape_f32out(const mfx_conv_desc* d, int v, 
 // returns MFX_OK (0) if this kernel ran, 1 if there is no instantiation for the shape / variant (caller runs conv3x3_wave_kernel), < 0 on error.
 // `v` is conv_halo.hip's variant number (6: 2 waves x 32 channels, 7: 4 x 32, 11: 4 x 32 with a 2-way K split; 8 / 10: one slice, 4-way K split)
 int try_conv_cw(const mfx_conv_desc* d, int v, hipStream_t st) {
-    if (!g_opt_halo_cw || !d->w_frag || d->stats || (d->stride != 1 && d->stride != 2)) return 1;
+    if (!g_opt_halo_cw || !d->w_frag || (d->stride != 1 && d->stride != 2)) return 1;
+    if (d->stats && (d->out_dtype != d->dtype || d->Cout_pad > 128)) return 1;
     if (d->dtype != MFX_BF16 && d->dtype != MFX_F16) return 1;
     if (d->K_pad != (9 * d->Ck + 63) / 64 * 64) return 1;
     if ((long long)d->M * (d->ldy > d->ldres ? d->ldy : d->ldres) >= (1ll << 31) || (long long)d->H * d->W * d->Ck >= (1ll << 31)) return 1;      // 32-bit element offsets
@@ -349,8 +398,9 @@ int try_conv_cw(const mfx_conv_desc* d, int v, hipStream_t st) {
         return d->dtype == MFX_F16 ? cw_shape_f32out<half_t>(d, v, st) : cw_shape_f32out<bf16_t>(d, v, st);
     }
     if (d->out_dtype != d->dtype || d->Cout % 8 != 0 || d->act == MFX_ACT_DCN_OFFMASK) return 1;
-    if (v == 6 && d->Cout_pad % 64 != 0) return 1;
+    if ((v == 6 || v == 12 || v == 13) && d->Cout_pad % 64 != 0) return 1;
     if ((v == 7 || v == 11) && d->Cout_pad % 128 != 0) return 1;
+    if (v == 5 && d->Cout_pad % 256 != 0) return 1;
     if (d->stride == 2) return d->dtype == MFX_F16 ? cw_shape_s2<half_t>(d, v, st) : cw_shape_s2<bf16_t>(d, v, st);
     if (d->dtype == MFX_F16) return cw_shape<half_t, 2>(d, v, st);
     return cw_shape<bf16_t, 2>(d, v, st);

@@ -18,6 +18,8 @@
 #include "../../include/monoflex_hip.h"
 #include "err.h"
 #include "igemm.h"
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 namespace mfx {
@@ -567,7 +569,11 @@ static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st) {
     if ((d->dtype == MFX_BF16 || d->dtype == MFX_F16) && g_opt_halo_cg <= 0) {
         // compile-time-geometry form of the same decomposition (conv_cw.hip): bit-identical output
         const int r = try_conv_cw(d, v, st);
+        if (r == 0 && d->stats) g_halo_stats_ran = true;
         if (r <= 0) return r == 0 ? 1 : r;
+        static const bool trace = getenv("MFX_TRACE_CW") != nullptr;      // which layers stay on the run-time-geometry kernel
+        if (trace) fprintf(stderr, "cw-fallback v=%d Ck=%d Cout=%d/%d s=%d HxW=%dx%d B=%d stats=%d out=%d res=%d act=%d\n", v, d->Ck, d->Cout, d->Cout_pad, d->stride,
+                           d->H, d->W, d->B, d->stats ? 1 : 0, d->out_dtype, d->res ? 1 : 0, d->act);
     }
     int rc;
     if (d->dtype == MFX_F32) rc = halo_variant<float, float>(v, d, st);

@@ -639,6 +639,62 @@ def test_conv_cw_kernel_is_bit_identical_to_the_halo_kernel(dtype, C, Cout, B, H
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("v,C,Cout,stride,exact", [(6, 32, 64, 1, True), (7, 32, 128, 1, True), (11, 32, 256, 1, False), (12, 128, 64, 1, True), (13, 256, 64, 1, True),
+                                                   (5, 64, 256, 1, True)])
+def test_conv_cw_training_shapes_equal_the_halo_kernel(dtype, v, C, Cout, stride, exact):
+    """conv3x3_cw_kernel's instantiations for the layers only the training step has (r05: `MFX_TRACE_CW=1` lists what stays on the run-time-geometry
+    kernel): 32 input channels (data gradients of the DCN modules' 27-channel offset / mask convs, accumulated into an existing gradient = the
+    residual input), the K-split 128 -> 64 and 256 -> 64 forms, 64 -> 256 with four fragments per wave.  Variant forced with option `halo`;
+    same bits as conv3x3_wave_kernel except where the two kernels split K differently (variant 11 at 32 channels: one step per tap)."""
+    ops, L = _ops()
+    g = _g(161)
+    B, H, W = 2, 21, 35
+    x = torch.randn(B, H, W, C, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+    res = torch.randn(B, H, W, Cout, generator=g).to(dtype).to(DEV)
+    p = ops.pack_conv(w, dtype, None, None, stride=stride, pad=1, act=L.ACT_NONE)
+    lib_ = L.load()
+    L.check(lib_.mfx_set_option(b"halo", v + 1), "opt")
+    for r in (res, None):
+        L.check(lib_.mfx_set_option(b"halo_cw", 0), "opt")
+        want = ops.conv2d(x, p, res=r)
+        L.check(lib_.mfx_set_option(b"halo_cw", 1), "opt")
+        got = ops.conv2d(x, p, res=r)
+        if exact:
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), r is not None
+        else:
+            assert float((got.float() - want.float()).abs().max()) <= 1.6e-2 * max(1.0, float(want.float().abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("v,C,Cout,stride,H,W", [(6, 64, 64, 1, 21, 35), (7, 128, 128, 1, 16, 48), (6, 32, 64, 2, 45, 75), (7, 64, 128, 2, 48, 64)])
+def test_conv_cw_statistics_epilogue_equals_the_halo_kernel(dtype, v, C, Cout, stride, H, W):
+    """Train-mode BN statistics of the conv's output from conv3x3_cw_kernel's own epilogue (mfx_conv_desc.stats): the stored map has the same bits as
+    conv3x3_wave_kernel's, the per-channel sums and sums of squares agree with it to fp32 summation order and with a torch reduction of the stored map."""
+    ops, L = _ops()
+    g = _g(171)
+    B = 2
+    x = torch.randn(B, H, W, C, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+    p = ops.pack_conv(w, dtype, None, None, stride=stride, pad=1, act=L.ACT_NONE)
+    lib_ = L.load()
+    ncopy = lib_.mfx_bn_ncopy(Cout)
+    L.check(lib_.mfx_set_option(b"halo", v + 1), "opt")
+    outs = {}
+    for cw in (0, 1):
+        L.check(lib_.mfx_set_option(b"halo_cw", cw), "opt")
+        st = torch.zeros(ncopy, 2 * Cout, device=DEV)
+        y = ops.conv2d(x, p, stats=st)
+        assert ops.conv2d.last_stats_done
+        outs[cw] = (y, st.sum(0).cpu())
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+    yf = outs[1][0].float().reshape(-1, Cout)
+    ref = torch.cat([yf.sum(0), (yf * yf).sum(0)]).cpu()
+    for cw in (0, 1):
+        assert torch.allclose(outs[cw][1], ref, rtol=2e-4, atol=2e-3), (cw, float((outs[cw][1] - ref).abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("C,B,H,W,variant", [(128, 2, 16, 32, 8), (128, 1, 13, 37, 10), (256, 2, 16, 32, 10), (256, 1, 11, 21, 8), (512, 2, 12, 40, 10),
                                              (512, 1, 9, 17, 8)])
 def test_conv_cw_offset_mask_conv_is_bit_identical_to_the_halo_kernel(dtype, C, B, H, W, variant):
