@@ -398,6 +398,7 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
                                  "IEEE-half activations: the bf16 mode's kernels and speed, 4-8x closer to the reference"),
                     "value": round(n_img / elapsed, 2), "unit": "images/s", "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                     "steps": args.steps, "dtype": dtype, "batch_per_gpu": B, "launch": mode,
+                    **({"operand_range_ok": bool(lib.f16x2_range_ok())} if dtype == "fp16x2" else {}),     # the split mode's one precondition: |activation| <= 65504
                     "vs_reference": deviation_vs_reference(out, dtype)}
 
         # ---- roofline of the dominant kernel (fused heads: 46 % of the forward FLOPs), HIP events on the launch stream
@@ -429,6 +430,7 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
                    "h2d_excluded": True, "d2h_excluded": True,
                    "timed_region": "graph replays only: the fp32 image batch is already in HBM and the (B,50,14) rows stay "
                                    "on the device (the reference's timer includes the D2H, engine/inference.py:35-43)",
+                   **({"operand_range_ok": bool(lib.f16x2_range_ok())} if dtype == "fp16x2" else {}),
                    "vs_reference": deviation_vs_reference(out, dtype)},
         "roofline": {"kernel": "heads_fused_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,

@@ -62,6 +62,11 @@ int mfx_reset_options(void);
  * option "dcn_bt_fuse_min_chunks" (default 1024) 32-pixel chunks).  Unknown names return MFX_ERR_ARG (negative). */
 long mfx_get_counter(const char* name);
 
+/* Range sentinel of the split-precision mode (dtype MFX_F16X2: fp32 activations become fp16 (hi, lo) MFMA operand pairs; hi overflows above
+ * 65504): 1 if any activation converted since the last reset was outside fp16's range or not finite, 0 if none, < 0 on error; `reset` clears the
+ * flag.  Blocking device read: synchronise the streams that ran the kernels first. */
+int mfx_f16x2_range_check(int reset);
+
 /* ------------------------------------------------------------------------------------------
  * (1) reference `_ext` boundary
  * ------------------------------------------------------------------------------------------ */

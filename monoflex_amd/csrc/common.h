@@ -117,8 +117,24 @@ template <> struct ElemTraits<f32s_t> {
 
 // value chunk (as loaded from HBM / produced in registers) -> MFMA operand chunk (as written to LDS / fed to the matrix core)
 template <typename T> __device__ __forceinline__ u32x4 lds_operand(const u32x4& c) { return c; }
+// Range sentinel of the split-precision mode: hi = fp16(x) overflows for |x| > 65504 (and a NaN / Inf stays one).  Every activation becomes an MFMA
+// operand through lds_operand<f32s_t>, so the check lives here: one max chain per chunk and a branch that is never taken on a healthy network.
+// Device globals are per translation unit without relocatable device code: each TU that converts operands has its own flag and registers an accessor
+// (MFX_RANGE_FLAG_ACCESSOR); mfx_f16x2_range_check() in capi.hip ORs them.
+static __device__ __attribute__((unused)) unsigned int mfx_tu_range_flag = 0;
+#define MFX_RANGE_FLAG_ACCESSOR(tag)                                                                                   \
+    int mfx_range_flag_##tag(int reset) {                                                                              \
+        unsigned int v = 0, z = 0;                                                                                     \
+        if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(mfx::mfx_tu_range_flag), sizeof(v)) != hipSuccess) return -1;           \
+        if (reset && v && hipMemcpyToSymbol(HIP_SYMBOL(mfx::mfx_tu_range_flag), &z, sizeof(z)) != hipSuccess) return -1; \
+        return (int)v;                                                                                                 \
+    }
 template <> __device__ __forceinline__ u32x4 lds_operand<f32s_t>(const u32x4& c) {
     const float x0 = __uint_as_float(c.x), x1 = __uint_as_float(c.y), x2 = __uint_as_float(c.z), x3 = __uint_as_float(c.w);
+#ifndef MFX_NO_RANGE_CHECK
+    // (on the bit patterns: |x| as an unsigned integer orders like the float and puts Inf / NaN above every finite value -- fmaxf would drop a NaN)
+    if (max(max(c.x & 0x7fffffffu, c.y & 0x7fffffffu), max(c.z & 0x7fffffffu, c.w & 0x7fffffffu)) > 0x477fe000u) atomicOr(&mfx_tu_range_flag, 1u);
+#endif
     const f16x2 h01 = __builtin_convertvector((f32x2){x0, x1}, f16x2), h23 = __builtin_convertvector((f32x2){x2, x3}, f16x2);
     const f16x2 l01 = __builtin_convertvector((f32x2){x0 - (float)h01[0], x1 - (float)h01[1]}, f16x2);
     const f16x2 l23 = __builtin_convertvector((f32x2){x2 - (float)h23[0], x3 - (float)h23[1]}, f16x2);

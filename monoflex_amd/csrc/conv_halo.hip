@@ -585,3 +585,5 @@ static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st) {
 }
 
 }  // namespace mfx
+
+MFX_RANGE_FLAG_ACCESSOR(conv_halo)      // split-precision range sentinel of this translation unit (common.h)

@@ -669,3 +669,5 @@ extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
     if (d->dtype == MFX_F16X2) return dispatch_dcn<f32s_t>(d, g, ep, st);
     return d->dtype == MFX_F32 ? dispatch_dcn<float>(d, g, ep, st) : dispatch_dcn<bf16_t>(d, g, ep, st);
 }
+
+MFX_RANGE_FLAG_ACCESSOR(conv_kernels)      // split-precision range sentinel of this translation unit (common.h)

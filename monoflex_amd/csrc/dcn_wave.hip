@@ -258,3 +258,5 @@ int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st) {
 }
 
 }  // namespace mfx
+
+MFX_RANGE_FLAG_ACCESSOR(dcn_wave)      // split-precision range sentinel of this translation unit (common.h)

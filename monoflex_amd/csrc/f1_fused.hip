@@ -437,3 +437,5 @@ extern "C" int mfx_f1_fused(const float* images, const void* w_stem, const float
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
+
+MFX_RANGE_FLAG_ACCESSOR(f1_fused)      // split-precision range sentinel of this translation unit (common.h)

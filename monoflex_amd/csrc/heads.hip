@@ -438,3 +438,5 @@ extern "C" int mfx_heads_fused(const mfx_heads_desc* d, void* stream) {
     if (d->dtype == MFX_F16X2) return launch_heads<f32s_t, false>(d, st);
     return mfx_fail(MFX_ERR_ARG, "heads_fused: bad dtype");
 }
+
+MFX_RANGE_FLAG_ACCESSOR(heads)      // split-precision range sentinel of this translation unit (common.h)

@@ -187,3 +187,5 @@ extern "C" int mfx_stem_conv7x7_nchw(const float* images, const void* w, const f
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
 }
+
+MFX_RANGE_FLAG_ACCESSOR(stem)      // split-precision range sentinel of this translation unit (common.h)

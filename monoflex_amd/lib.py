@@ -116,6 +116,7 @@ SYMBOLS = {
     "mfx_set_option": (_I, [ctypes.c_char_p, _I]),
     "mfx_reset_options": (_I, []),
     "mfx_get_counter": (ctypes.c_long, [ctypes.c_char_p]),
+    "mfx_f16x2_range_check": (ctypes.c_int, [ctypes.c_int]),
     "mfx_dcn_v2_workspace_bytes": (_S, [_I] * 14),
     "mfx_dcn_v2_forward": (_I, [_P] * 6 + [_I] * 14 + [_P, _S, _P]),
     "mfx_dcn_v2_backward": (_I, [_P] * 11 + [_I] * 14 + [_P, _S, _P]),
@@ -195,6 +196,18 @@ def load():
         raise RuntimeError("libmonoflex_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def f16x2_range_ok(reset=True):
+    """Split-precision mode (MODEL.COMPUTE_DTYPE fp16x2): True if every activation turned into an fp16 (hi, lo) operand pair since the last reset was
+    finite and inside fp16's range (|x| <= 65504) -- the mode's one numerical precondition.  Synchronises the device."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    rc = load().mfx_f16x2_range_check(1 if reset else 0)
+    if rc < 0:
+        check(rc, "mfx_f16x2_range_check")
+    return rc == 0
 
 
 def set_deterministic(on=True):

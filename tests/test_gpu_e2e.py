@@ -173,6 +173,8 @@ def test_e2e_full_vs_reference_golden_fp32(mode, batch):
     print("full-size %s B=%d vs reference: max |dlogit| %.2e, max |dreg| %.2e; stages %s" % (
         mode, batch, dl, dr, {k: "%.1e/%.1e" % v for k, v in errs.items()}))
     if mode == "fp16x2":
+        from monoflex_amd import lib as L_
+        assert L_.f16x2_range_ok(), "an activation left fp16's range on its way into an MFMA operand pair"      # the mode's one precondition
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "fp16x2_b%d_vs_reference.json" % batch), "w") as f:
             json.dump({"shape": "B=%d, 1280x384, fp16x2 (split-precision MFMA operands, fp32 activations)" % batch, "max_abs_dlogit": float(dl),

@@ -125,6 +125,29 @@ def test_root_cat_conv1x1(dtype):
     _close(_from_nhwc(y), ref, dtype, sum(chans), "root cat conv")
 
 
+def test_split_precision_range_sentinel_trips_on_an_overflowing_activation():
+    """mfx_f16x2_range_check: the split-precision mode turns fp32 activations into fp16 (hi, lo) operand pairs, hi = fp16(x) overflows above 65504.  A healthy
+    input leaves the flag clear; one activation of 7e4 (or a NaN) anywhere in a conv's input sets it, for the LDS-halo kernel and for the generic one; reset clears."""
+    ops, L = _ops()
+    lib_ = L.load()
+    g = _g(181)
+    x = torch.randn(1, 12, 20, 64, generator=g).to(DEV)
+    w3 = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV)
+    w1 = (torch.randn(64, 64, 1, 1, generator=g) / 8).to(DEV)
+    p3 = ops.pack_conv(w3, ops.F16X2, None, None, stride=1, pad=1, act=L.ACT_RELU)
+    p1 = ops.pack_conv(w1, ops.F16X2, None, None, stride=1, pad=0, act=L.ACT_RELU)
+    L.f16x2_range_ok()                                        # clear whatever earlier tests left
+    for p in (p3, p1):
+        ops.conv2d(x, p)
+        assert L.f16x2_range_ok()
+        for bad in (7.0e4, float("nan"), -float("inf")):
+            xb = x.clone(); xb[0, 5, 7, 3] = bad
+            ops.conv2d(xb, p)
+            assert not L.f16x2_range_ok(reset=False)
+            assert not L.f16x2_range_ok()                     # still set; this call resets
+            assert L.f16x2_range_ok()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool_and_upsample(dtype):
     ops, L = _ops()
