@@ -287,8 +287,9 @@ def test_sparse_regression_heads_function_vs_torch(dt):
     assert float(out[:, unused].abs().max()) == 0.0 and float(out[rows[:, 0] == 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("offset", [False, True])
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
-def test_gram_regression_heads_vs_torch(dt):
+def test_gram_regression_heads_vs_torch(dt, offset):
     """GramRegHeadsFn (monoflex_amd/gram_heads.py): conv3x3(64 -> 256) -> train-mode BN -> leaky(0.01) -> 1x1 heads at the object centres, with the
     BN statistics and their gradients taken from the input's patch Gram matrix instead of dense trunk maps -- against torch running the dense
     layers on the same (rounded) inputs: output rows, running statistics and EVERY gradient (feature map, trunk weights, ABN weight / bias, 1x1
@@ -310,6 +311,11 @@ def test_gram_regression_heads_vs_torch(dt):
     dout = torch.randn(N, 50, generator=g)
     x = (torch.randn(B, H, W, Cin, generator=g) * 0.8 + 0.1).to(dtype)
     wt = [torch.randn(C, Cin, 3, 3, generator=g) / 24.0 for _ in ks]
+    if offset:
+        # |mean| >> std in the trunk pre-activation (mean ~ 10, std ~ 0.8: mean^2 / var ~ 150): the Gram path's variance is E[y^2] - E[y]^2 from fp32 sums
+        # finalised in double, i.e. its relative error is eps * (1 + mean^2 / var) -- this case would show a cancellation problem
+        x = (x.float() + 1.5).to(dtype)
+        wt = [w + 0.01 for w in wt]
     abns_r, w2s, b2s = [], [], []
     for k in ks:
         m = torch.nn.BatchNorm2d(C)
