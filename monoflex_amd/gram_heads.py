@@ -40,6 +40,8 @@ def _geometry(B, H, W, device):
     key = (B, H, W, str(device))
     if key in _GEOM:
         return _GEOM[key]
+    if len(_GEOM) >= 8:                                       # a training run sees one or two map shapes; never let the tables pile up
+        _GEOM.clear()
     py = torch.cat((torch.full((W + 2,), -1), torch.full((W + 2,), H), torch.arange(H), torch.arange(H)))
     px = torch.cat((torch.arange(-1, W + 1), torch.arange(-1, W + 1), torch.full((H,), -1), torch.full((H,), W)))
     nf = py.numel()
@@ -88,6 +90,8 @@ def _static(abns, cws, ks, offs, ld_out, has_b, device):
     key = (tuple(float(a.eps) for a in abns), tuple(cws), tuple(ks), tuple(offs), ld_out, tuple(has_b), str(device))
     if key in _STATIC:
         return _STATIC[key]
+    if len(_STATIC) >= 8:
+        _STATIC.clear()
     nch = sum(cws)
     eps = torch.cat([torch.full((cw,), float(a.eps)) for cw, a in zip(cws, abns)]).to(device)
     pos, bpos, c0 = [], [], 0

@@ -1036,9 +1036,9 @@ def test_dcn_fused_sample_wgrad_kernel_vs_oracle(H, W, off_std, min_chunks, half
     try:
         if min_chunks is not None:
             L.check(lib_.mfx_set_option(b"dcn_bt_fuse_min_chunks", min_chunks), "opt")
-        # four forms of the same backward: "fly2" = the fused sample + weight-gradient kernel rebuilds d(columns) from dy on the matrix
-        # cores and writes it for the tile kernel (no d(columns) GEMM, no re-read; the default), "fly" = nothing materialised at all (the
-        # tile kernel splats dy and multiplies by W per tap), 1 = the fused kernel reading a d(columns) GEMM's output, 0 = five launches
+        # four forms of the same backward: "fly2" (option dcn_bt_fly = 2) = the fused sample + weight-gradient kernel rebuilds d(columns) from dy on
+        # the matrix cores and writes it for the tile kernel (no d(columns) GEMM, no re-read), "fly" (= 1, THE DEFAULT) = nothing materialised at all
+        # (the tile kernel splats dy and multiplies by W per tap), 1 = the fused kernel reading a d(columns) GEMM's output, 0 = five launches
         for form in ("fly2", "fly", 1, 0):
             L.check(lib_.mfx_set_option(b"dcn_bt_fuse_wgrad", 0 if form == 0 else 1), "opt")
             L.check(lib_.mfx_set_option(b"dcn_bt_fly", {"fly2": 2, "fly": 1}.get(form, 0)), "opt")
