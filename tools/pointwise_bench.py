@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The 1x1 "project" convs and Root nodes of DLA levels 2-5 (dla_dcn.py:195-203, 268-276) alone, B = 8, bf16, 10 launches per hipGraph replay: the LDS-tiled
-kernels with their loads one k-iteration ahead (option igemm_pf = 0) and two ahead (igemm_pf = 2), bit-compared, with the HBM time of the algorithmic bytes.
-usage: python tools/pointwise_bench.py [B=8]"""
+kernels against the HBM time of the algorithmic bytes; with extra library options (k=v,...) a second column times that setting and bit-compares it.
+usage: python tools/pointwise_bench.py [B=8] [k=v,...]"""
 import os
 import sys
 
@@ -12,6 +12,7 @@ from monoflex_amd import lib, ops
 
 L = lib.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+OPTS = [kv.split("=") for kv in filter(None, (sys.argv[2] if len(sys.argv) > 2 else "").split(","))]
 dt = torch.bfloat16
 LAYERS = [("level2 project", 96, 320, [32], 64, 0), ("level2 root", 96, 320, [64, 64], 64, 1), ("level3 project", 48, 160, [64], 128, 0),
           ("level3 tree1 root", 48, 160, [128, 128], 128, 1), ("level3 root", 48, 160, [128, 128, 64, 128], 128, 1), ("level4 project", 24, 80, [128], 256, 0),
@@ -39,7 +40,7 @@ def timed(fn):
     return e0.elapsed_time(e1) / (5 * N) * 1e3
 
 
-print("| layer (B=%d) | K -> N | one ahead us | two ahead us | HBM time us | same bits |" % B)
+print("| layer (B=%d) | K -> N | default us | with options us | HBM time us | same bits |" % B)
 print("|---|---|---|---|---|---|")
 tot = [0.0, 0.0, 0.0]
 for (name, H, W, chans, Co, act) in LAYERS:
@@ -56,7 +57,10 @@ for (name, H, W, chans, Co, act) in LAYERS:
         fn = lambda: ops.cat_conv1x1(xs, p)
     res = {}
     for pf in (0, 2):
-        lib.check(L.mfx_set_option(b"igemm_pf", pf), "opt")
+        lib.check(L.mfx_reset_options(), "reset")
+        if pf:
+            for k_, v_ in OPTS:
+                lib.check(L.mfx_set_option(k_.encode(), int(v_)), "opt")
         y = fn().clone()
         res[pf] = (timed(fn), y)
     floor = (B * H * W * (K + Co) * 2 + Co * K * 2) / 6.3e12 * 1e6
