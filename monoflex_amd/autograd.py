@@ -92,7 +92,8 @@ class _PackRegistry:
             E = 4 if dtype == torch.float32 else 8
             if (ck & (ck - 1) and kh * kw > 1) or ck < E or ck % E:
                 raise ValueError("conv operand: channels per tap must be a power of two >= %d (any multiple of %d for 1x1), got %d" % (E, E, ck))
-            K_pad = (kh * kw * ck + 8 * E - 1) // (8 * E) * (8 * E)
+            kr = 8 * E if kh * kw * ck >= 8 * E else 4 * E      # (a 64-byte K stays 64 bytes: ops.pack_conv)
+            K_pad = (kh * kw * ck + kr - 1) // kr * kr
             cp = ops.cout_pad(rows)
             packed = torch.empty((cp, K_pad), dtype=dtype, device=weight.device)
             frag = torch.empty_like(packed) if (kh == 3 and kw == 3 and stride in (1, 2) and pad_h == 1 and pad_w == 1) else None

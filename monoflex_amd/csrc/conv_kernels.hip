@@ -410,6 +410,7 @@ static int dispatch_conv(const mfx_conv_desc* d, const ConvGeom& g, const EpiArg
     const int N = d->Cout_pad;
     if (N != 16 && N != 32 && N % 64 != 0) return mfx_fail(MFX_ERR_ARG, "conv2d: Cout_pad must be 16, 32 or a multiple of 64");
     int tile = pick_conv_tile(d->M, N);
+    if (d->kh * d->kw == 1 && N == 64) tile = T_64x64;          // short-K pointwise layers: more, smaller workgroups (r05 sweep, profiles/r05_pointwise_tiles.md)
     if (g_opt_conv_tile && tile_fits(g_opt_conv_tile, N)) tile = g_opt_conv_tile;
     const int elems = ElemTraits<T>::ELEMS;
     const bool kc8_ok = d->K_pad % (8 * elems) == 0;
@@ -553,6 +554,7 @@ template <typename T> static int dispatch_cat(const mfx_cat_desc* d, const CatSe
     const int N = d->Cout_pad;
     if (N % 64 != 0) return mfx_fail(MFX_ERR_ARG, "cat_conv1x1: Cout_pad must be a multiple of 64");
     int tile = pick_conv_tile(d->M, N);
+    if (N == 64) tile = T_64x64;                                 // (level-2 Root: 24.5 -> 20.3 us)
     if (g_opt_cat_tile && tile_fits(g_opt_cat_tile, N)) tile = g_opt_cat_tile;
     switch (tile) {
         case T_128x64: return launch_cat<T, 128, 64, 4, 1, 8>(d, s, ep, st);

@@ -208,8 +208,10 @@ def pack_conv(weight, dtype, scale=None, shift=None, stride=1, pad=0, act=L.ACT_
     Cout, Cin, kh, kw = weight.shape
     if not _pow2(Cin) or Cin < _elems(dtype):
         raise ValueError("pack_conv: Cin must be a power of two >= %d (got %d)" % (_elems(dtype), Cin))
-    bk = 8 * _elems(dtype)                      # 128 bytes of K: lets the kernel run 64- or 128-byte k-iterations
     K = kh * kw * Cin
+    # 128 bytes of K lets the kernel run 64- or 128-byte k-iterations; a K of 64 bytes (the 32 -> 64 1x1 "project" conv of DLA level 2 in 16-bit modes) stays at
+    # 64: padded to 128 the generic kernel loaded every row twice as wide as it is (19.3 -> 13.4 us at 8 x 96 x 320, tools/pointwise_bench.py)
+    bk = 8 * _elems(dtype) if K >= 8 * _elems(dtype) else 4 * _elems(dtype)
     K_pad = _round_up(K, bk)
     cout = Cout if cout is None else cout
     cp = cout_pad(cout)
