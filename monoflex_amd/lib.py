@@ -195,6 +195,10 @@ def load():
     if lib.mfx_abi_version() != 2:
         raise RuntimeError("libmonoflex_hip.so ABI version mismatch")
     _lib = lib
+    # MFX_OPTIONS="name=value,name=value": library tuning switches for this process (mfx_set_option; A/B sweeps of an unmodified bench.py / training script)
+    for kv in filter(None, os.environ.get("MFX_OPTIONS", "").split(",")):
+        k, _, v = kv.partition("=")
+        check(lib.mfx_set_option(k.strip().encode(), int(v)), "MFX_OPTIONS: %s" % kv)
     return lib
 
 
