@@ -715,6 +715,33 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dty
     return res
 
 
+def order_line(res, seen, world):
+    """The ONE line in the order a truncated capture keeps best: the contract's keys, the roofline / CPU-baseline objects, then every leg's headline
+    number as a top-level scalar (so a driver that parses the line has them even when it drops nested objects: VERDICT r5 item 8), the ranks that met,
+    the legs themselves, and the long per-family blob last."""
+    head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline", "cpu_baseline"]
+    out = {k: res[k] for k in head if k in res}
+
+    def leg_val(name, key="value"):
+        v = res.get(name)
+        return v.get(key) if isinstance(v, dict) and "error" not in v else None
+    scal = {"b32_images_per_s": leg_val("b32"), "fp16x2_images_per_s": leg_val("fp16x2_parity"), "fp32_images_per_s": leg_val("fp32_parity"),
+            "fp16_images_per_s": leg_val("fp16"), "train_images_per_s": leg_val("train"), "train_ms_per_step": leg_val("train", "ms_per_step"),
+            "train_fp16_images_per_s": leg_val("train_fp16"), "train_local_bn_images_per_s": leg_val("train_local_bn")}
+    out.update({k: v for k, v in scal.items() if v is not None})
+    out["rccl_ranks"] = len(seen)
+    out["ranks_seen"] = seen
+    tail = ("roofline_families",)
+    for k, v in res.items():
+        if k not in out and k not in tail:
+            out[k] = v
+    for k in tail:
+        if k in res:
+            out[k] = res[k]
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -758,6 +785,8 @@ def main():
                          ("train_fp16", lambda: run_train(args, rank, world, device, steps=args.train_steps, warmup=args.train_warmup, leg=True,
                                                           dtype="fp16"))]
 
+            seen_early = parallel.ranks_seen(device)                    # (before the legs: the watchdog's line carries it too)
+
             def bail():
                 # a leg that hangs (first multi-rank RCCL run of the segmented exchange, a wedged capture) must not take the headline with
                 # it: after --leg-timeout seconds rank 0 prints the line with what is finished and every rank leaves
@@ -765,7 +794,7 @@ def main():
                     out = dict(res, **legs)
                     for k, _ in leg_list:
                         out.setdefault(k, {"error": "leg did not finish within %d s" % args.leg_timeout})
-                    print(json.dumps(out), flush=True)
+                    print(json.dumps(order_line(out, seen_early, world)), flush=True)
                 os._exit(3)                                               # the line is complete as far as it goes; a hung leg is NOT a clean run
             dog = threading.Timer(args.leg_timeout, bail)
             dog.daemon = True
@@ -780,8 +809,9 @@ def main():
             dog.cancel()
             if rank == 0:
                 res.update(legs)
+    seen = parallel.ranks_seen(device)                                     # all-gather inside the job: which ranks really met (every rank calls it)
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(order_line(res, seen, world)))
     if world > 1:
         torch.distributed.destroy_process_group()
 

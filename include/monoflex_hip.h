@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MFX_ABI_VERSION 2      /* r05: mfx_conv_desc / mfx_dcn_desc / mfx_heads_desc grew in r04 (paired fragments, fused offset conv, w2_scale, MFX_F16X2), mfx_dcn_desc again
+#define MFX_ABI_VERSION 3      /* r06: mfx_dcn_desc.w_pair_f16 (fourth-generation DCN kernel).  r05: mfx_conv_desc / mfx_dcn_desc / mfx_heads_desc grew in r04 (paired fragments, fused offset conv, w2_scale, MFX_F16X2), mfx_dcn_desc again
                                 * (per-axis geometry), mfx_gram_desc is new: a caller built against version 1 is rejected instead of being read past its structs */
 
 /* element types of activations / packed weights */
@@ -57,6 +57,9 @@ const char* mfx_last_error(void);
 int mfx_set_option(const char* name, int value);
 /* every switch back to its load-time value (what a test harness calls between tests) */
 int mfx_reset_options(void);
+/* the current values become the load-time values mfx_reset_options() restores (called once by the host after it applied the process's own
+ * switches, e.g. MFX_OPTIONS from the environment) */
+int mfx_commit_options(void);
 /* Dispatch counters since process start, so a test can assert WHICH kernel variant a call took: "dcn_bt_fused" = launches of the
  * fused sample + weight-gradient kernel of mfx_dcn_backward_v2 (selected for bf16 / fp16, C = Cout = 64, W % 32 == 0 and at least
  * option "dcn_bt_fuse_min_chunks" (default 1024) 32-pixel chunks).  Unknown names return MFX_ERR_ARG (negative). */
@@ -71,10 +74,14 @@ int mfx_f16x2_range_check(int reset);
  * (1) reference `_ext` boundary
  * ------------------------------------------------------------------------------------------ */
 
-/* Scratch bytes mfx_dcn_v2_forward / _backward need for the given shape. */
+/* Scratch bytes mfx_dcn_v2_forward / _backward need for the given shape: an upper bound over every deformable_group. */
 size_t mfx_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw,
                                   int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                                   int backward);
+/* The same for a known deformable_group -- what the entries check against: one group needs none of the group loop's temporaries (about half). */
+size_t mfx_dcn_v2_workspace_bytes_g(int B, int C, int H, int W, int Cout, int kh, int kw,
+                                    int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                                    int deformable_group, int backward);
 
 /* output (B,Cout,Ho,Wo) = bias + W * (mask . bilinear(input @ offsets))   -- src/dcn_v2.h:9-23, as general as the reference's entry:
  * any deformable_group dividing C (channel group g is sampled with its own 2*kh*kw offset and kh*kw mask channels,
@@ -179,10 +186,23 @@ typedef struct {
     /* per-axis geometry (reference src/dcn_v2.h:9-23 takes stride_h/w, pad_h/w, dilation_h/w): nonsquare = 1 -> `stride`, `pad`, `dil` are the
      * ROW values and the three fields below the COLUMN values (generic gather kernel); 0 -> they are ignored (square geometry) */
     int32_t nonsquare, stride_w, pad_w, dil_w;
+    /* optional (16-bit modes, 3x3 / stride 1 / pad 1, Cout_pad == 64): the weights as IEEE fp16 in the fourth-generation LDS kernel's K order --
+     * 16-channel slices, five k-steps per slice, k-step j = taps (2j, 2j + 1) x 16 channels (tap 9 = zeros): [Cout_pad / 16][C / 16 * 5][64 lanes][16 B],
+     * lane (kq, n) holding tap 2j + (kq >> 1), channels 16 s + 8 (kq & 1) .. + 7 of output channel 16 nf + n (ops.dcn_pair_fragments).  Needs
+     * w_frag_f16 as well (samples that leave the LDS patch are multiplied with that one). */
+    const void* w_pair_f16;
 } mfx_dcn_desc;
 int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream);
 /* 1 when mfx_dcn_nhwc(d) will compute the offsets inside the kernel from off_w_frag_f16 / off_shift (d->offmask is not read), else 0 */
 int mfx_dcn_fuses_offset_conv(const mfx_dcn_desc* d);
+
+/* DCNv2 as "project, then sample" (r06; 3x3 / stride 1 / pad 1 / dilation 1, 16-bit maps), the sampling half.  Bilinear interpolation commutes with the
+ * contraction over input channels, so the module (dcn_v2_im2col_cuda.cu:125-195 + dcn_v2_cuda.cu:139-163) is
+ *     y[m][n] = act(scale[n] * sum_tap mask[m,tap] * bilinear(P[:, :, tap*N + n] @ p(m,tap)) + shift[n]),    P = the 1x1 convolution of the input with the
+ * DCN weights regrouped as [(tap, n)][c] (one mfx_conv2d_nhwc call, C -> 9 N, no scale / shift / activation).  P: [B*H*W][9*N] in `dtype`;
+ * offmask as for mfx_dcn_nhwc; N in {64, 128, 256}; corners outside the image contribute zero; fp32 accumulation. */
+int mfx_dcn_sample_nhwc(const void* P, const float* offmask, const float* scale, const float* shift, void* y,
+                        int B, int H, int W, int N, int ldy, int act, int dtype, void* stream);
 
 /* DLA stem in bf16 mode: 7x7 / stride 1 / pad 3 conv of the fp32 NCHW image batch (B,3,H,W) -> NHWC (B,H,W,16) bf16 with
  * scale/shift (folded BN) + activation (dla_dcn.py:268-272).  Reads the image planes directly (no padded NHWC copy);

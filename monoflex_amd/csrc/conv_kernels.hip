@@ -304,8 +304,9 @@ extern int g_opt_wgrad_mfma, g_opt_wgrad_blocks, g_opt_wgrad_ws, g_opt_wgrad_ws_
 namespace mfx {
 int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st);      // dcn_wave.hip
 int try_dcn_patch(const mfx_dcn_desc* d, hipStream_t st);     // dcn_patch.hip
-int try_dcn_cq(const mfx_dcn_desc* d, hipStream_t st);        // dcn_cq.hip
-extern int g_opt_dcn_cq;
+int try_dcn_lds(const mfx_dcn_desc* d, hipStream_t st);       // dcn_lds.hip
+bool dcn_lds_fuses_offset_conv(const mfx_dcn_desc* d);
+extern int g_opt_dcn_lds, g_opt_dcn_lds_rows;
 bool dcn_patch_fuses_offset_conv(const mfx_dcn_desc* d);
 extern int g_opt_dcn_fuse_off;
 
@@ -428,7 +429,7 @@ static int* option_slot(const std::string& n) {
         {"conv_tile", &g_opt_conv_tile}, {"dcn_tile", &g_opt_dcn_tile}, {"cat_tile", &g_opt_cat_tile}, {"kc", &g_opt_kc}, {"ksplit", &g_opt_ksplit},
         {"dcn_ksplit", &g_opt_dcn_ksplit}, {"wgrad_mfma", &g_opt_wgrad_mfma}, {"wgrad_blocks", &g_opt_wgrad_blocks}, {"wgrad_ws", &g_opt_wgrad_ws},
         {"wgrad_ws_blocks", &g_opt_wgrad_ws_blocks}, {"dcn_wgrad_m", &g_opt_dcn_wgrad_m}, {"halo", &g_opt_halo}, {"halo_cg", &g_opt_halo_cg},
-        {"halo_cw", &g_opt_halo_cw}, {"cw_rows6", &g_opt_cw_rows6}, {"halo_pair", &g_opt_halo_pair}, {"halo_s2", &g_opt_halo_s2}, {"dcn_wave", &g_opt_dcn_wave}, {"dcn_patch", &g_opt_dcn_patch}, {"dcn_cq", &g_opt_dcn_cq},
+        {"halo_cw", &g_opt_halo_cw}, {"cw_rows6", &g_opt_cw_rows6}, {"halo_pair", &g_opt_halo_pair}, {"halo_s2", &g_opt_halo_s2}, {"dcn_wave", &g_opt_dcn_wave}, {"dcn_patch", &g_opt_dcn_patch}, {"dcn_lds", &g_opt_dcn_lds}, {"dcn_lds_rows", &g_opt_dcn_lds_rows},
         {"dcn_patch_fn8", &g_opt_dcn_patch_fn8}, {"dcn_fuse_off", &g_opt_dcn_fuse_off}, {"topk_strips", &g_opt_topk_strips},
 #ifdef MFX_PROBES
         {"dcn_bt_dbg", &g_opt_dcn_bt_dbg}, {"heads_dbg", &g_opt_heads_dbg},
@@ -472,6 +473,14 @@ extern "C" int mfx_set_option(const char* name, int value) {
 // (tests/conftest.py calls this after every GPU test).
 extern "C" int mfx_reset_options(void) {
     for (const auto& e : option_defaults()) *e.first = e.second;
+    return MFX_OK;
+}
+
+// The CURRENT values become the ones mfx_reset_options() restores.  The host calls this once after it has applied the process's own switches
+// (MFX_OPTIONS in the environment, monoflex_amd/lib.py), so that "load-time value" means "after the environment" and an `MFX_OPTIONS=... pytest`
+// sweep keeps its switches across the per-test resets.
+extern "C" int mfx_commit_options(void) {
+    for (auto& e : option_defaults()) e.second = *e.first;
     return MFX_OK;
 }
 
@@ -641,11 +650,12 @@ template <typename T> static int dispatch_dcn(const mfx_dcn_desc* d, const DcnGe
 }
 }  // namespace mfx
 
-extern "C" int mfx_dcn_fuses_offset_conv(const mfx_dcn_desc* d) { return (d && d->x && dcn_patch_fuses_offset_conv(d)) ? 1 : 0; }
+static bool dcn_fuses_offset_conv(const mfx_dcn_desc* d) { return dcn_lds_fuses_offset_conv(d) || dcn_patch_fuses_offset_conv(d); }
+extern "C" int mfx_dcn_fuses_offset_conv(const mfx_dcn_desc* d) { return (d && d->x && dcn_fuses_offset_conv(d)) ? 1 : 0; }
 
 extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->y) return mfx_fail(MFX_ERR_ARG, "dcn: null pointer");
-    if (!d->offmask && !dcn_patch_fuses_offset_conv(d)) return mfx_fail(MFX_ERR_ARG, "dcn: offmask is NULL (the offset conv is computed inside the kernel only where mfx_dcn_fuses_offset_conv says so)");
+    if (!d->offmask && !dcn_fuses_offset_conv(d)) return mfx_fail(MFX_ERR_ARG, "dcn: offmask is NULL (the offset conv is computed inside the kernel only where mfx_dcn_fuses_offset_conv says so)");
     const int elems = (d->dtype == MFX_F32 || d->dtype == MFX_F16X2) ? 4 : 8;
     if (d->dtype != MFX_F32 && d->dtype != MFX_BF16 && d->dtype != MFX_F16 && d->dtype != MFX_F16X2) return mfx_fail(MFX_ERR_ARG, "dcn: bad dtype");
     if (!is_pow2(d->C) || d->C < 4 * elems) return mfx_fail(MFX_ERR_ARG, "dcn: C must be a power of two >= 64 bytes of channels");
@@ -661,9 +671,9 @@ extern "C" int mfx_dcn_nhwc(const mfx_dcn_desc* d, void* stream) {
     if ((size_t)d->B * d->H * d->W * d->C * (elems == 8 ? 2 : 4) >= ((size_t)1 << 32))
         return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn: input tensor of 4 GB or more (the gather kernels address it with 32-bit byte offsets)");
     if (!d->nonsquare) {                                      // (the LDS-patch / wave kernels are built for square geometry)
-        int h = try_dcn_patch(d, reinterpret_cast<hipStream_t>(stream));
+        int h = try_dcn_lds(d, reinterpret_cast<hipStream_t>(stream));
         if (h != 0) return h < 0 ? h : MFX_OK;
-        h = try_dcn_cq(d, reinterpret_cast<hipStream_t>(stream));
+        h = try_dcn_patch(d, reinterpret_cast<hipStream_t>(stream));
         if (h != 0) return h < 0 ? h : MFX_OK;
         h = try_dcn_wave(d, reinterpret_cast<hipStream_t>(stream));
         if (h != 0) return h < 0 ? h : MFX_OK;

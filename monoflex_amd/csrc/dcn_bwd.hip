@@ -324,8 +324,8 @@ static int backward_one(const float* input, const float* weight, const float* of
     return MFX_OK;
 }
 
-extern "C" size_t mfx_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw,
-                                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int backward);
+extern "C" size_t mfx_dcn_v2_workspace_bytes_g(int B, int C, int H, int W, int Cout, int kh, int kw,
+                                               int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int deformable_group, int backward);
 
 extern "C" int mfx_dcn_v2_backward(const float* input, const float* weight, const float* bias,
                                    const float* offset, const float* mask, const float* grad_output,
@@ -344,8 +344,8 @@ extern "C" int mfx_dcn_v2_backward(const float* input, const float* weight, cons
     const int Cg = C / dg, kk = kh * kw;
     const BwdGeom g = bwd_geom(B, Cg, H, W, Cout, kh, kw, stride_h, pad_h, dil_h, stride_w, pad_w, dil_w);
     if (g.Ho <= 0 || g.Wo <= 0) return mfx_fail(MFX_ERR_ARG, "dcn_v2_backward: empty output");
-    if (!workspace || workspace_bytes < mfx_dcn_v2_workspace_bytes(B, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, 1))
-        return mfx_fail(MFX_ERR_WORKSPACE, "dcn_v2_backward: workspace too small (mfx_dcn_v2_workspace_bytes)");
+    if (!workspace || workspace_bytes < mfx_dcn_v2_workspace_bytes_g(B, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, dg, 1))
+        return mfx_fail(MFX_ERR_WORKSPACE, "dcn_v2_backward: workspace too small (mfx_dcn_v2_workspace_bytes_g)");
     if (g.M == 0) return MFX_OK;
     char* ws = reinterpret_cast<char*>(workspace);
     if (dg == 1) return backward_one(input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, grad_bias, B, C, Cout, g, ws, stream);

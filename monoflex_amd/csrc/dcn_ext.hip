@@ -106,12 +106,22 @@ static size_t group_tmp_bytes(int B, int C, int H, int W, int Cout, int kk, int 
 
 extern "C" size_t mfx_dcn_v2_backward_workspace_bytes_(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw);  // dcn_bwd.hip
 
+extern "C" size_t mfx_dcn_v2_workspace_bytes_g(int B, int C, int H, int W, int Cout, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                                               int dil_h, int dil_w, int deformable_group, int backward);
 extern "C" size_t mfx_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw,
                                              int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                                              int backward) {
+    return mfx_dcn_v2_workspace_bytes_g(B, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, /*deformable_group (any)*/ 2, backward);
+}
+
+// the same for a known group count: one deformable group (the only value the model uses) needs none of the group loop's temporaries -- about
+// half of the bound above at full size; the entries check against THIS size
+extern "C" size_t mfx_dcn_v2_workspace_bytes_g(int B, int C, int H, int W, int Cout, int kh, int kw,
+                                               int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                                               int deformable_group, int backward) {
     const DcnExtDims d = make_dims(B, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w);
     const size_t one = backward ? mfx_dcn_v2_backward_workspace_bytes_(B, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w) : d.total_fwd;
-    return one + group_tmp_bytes(B, C, H, W, Cout, kh * kw, d.Ho > 0 ? d.Ho : 0, d.Wo > 0 ? d.Wo : 0, backward);
+    return one + (deformable_group > 1 ? group_tmp_bytes(B, C, H, W, Cout, kh * kw, d.Ho > 0 ? d.Ho : 0, d.Wo > 0 ? d.Wo : 0, backward) : 0);
 }
 
 static int check_ext_args(int C, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg) {
@@ -159,8 +169,8 @@ extern "C" int mfx_dcn_v2_forward(const float* input, const float* weight, const
     const int dg = deformable_group, Cg = C / dg, kk = kh * kw;
     const DcnExtDims d = make_dims(B, Cg, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w);
     if (d.Ho <= 0 || d.Wo <= 0) return mfx_fail(MFX_ERR_ARG, "dcn_v2_forward: empty output");
-    if (!workspace || workspace_bytes < mfx_dcn_v2_workspace_bytes(B, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, 0))
-        return mfx_fail(MFX_ERR_WORKSPACE, "dcn_v2_forward: workspace too small (mfx_dcn_v2_workspace_bytes)");
+    if (!workspace || workspace_bytes < mfx_dcn_v2_workspace_bytes_g(B, C, H, W, Cout, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, dg, 0))
+        return mfx_fail(MFX_ERR_WORKSPACE, "dcn_v2_forward: workspace too small (mfx_dcn_v2_workspace_bytes_g)");
     if (d.M == 0) return MFX_OK;
     char* ws = reinterpret_cast<char*>(workspace);
     if (dg == 1) return forward_one(input, weight, bias, offset, mask, output, d, ws, stream);

@@ -433,7 +433,8 @@ static bool dcn_patch_auto(const mfx_dcn_desc* d) {
 }
 
 bool dcn_patch_fuses_offset_conv(const mfx_dcn_desc* d) {
-    return g_opt_dcn_fuse_off && d->off_w_frag_f16 && d->off_shift && dcn_patch_auto(d);
+    // (per-axis geometry goes to the generic gather kernel, which reads `offmask`: never claim the offset conv for it)
+    return g_opt_dcn_fuse_off && !d->nonsquare && d->off_w_frag_f16 && d->off_shift && dcn_patch_auto(d);
 }
 
 // returns 1 if handled, 0 to fall through to the older kernels, < 0 on error

@@ -429,16 +429,28 @@ class GraphedTrainStep:
             self.images, self.targets = keep
         return self.loss
 
-    def close(self):
-        """Detach the process-wide SyncBN communicator this step installed (autograd.set_sync_bn_group)."""
-        if self.bn_group is not None:
-            from .. import autograd as AG
+    def close(self, destroy=True):
+        """Detach and destroy the SyncBN communicator this step installed (autograd.set_sync_bn_group).  The global is process-wide: it is cleared
+        only while it still IS this object's group -- a newer step (re-capture, a second GraphedTrainStep in a bench / test) that installed its own
+        must not lose it when the older object is collected."""
+        group, self.bn_group = getattr(self, "bn_group", None), None
+        if group is None:
+            return
+        from .. import autograd as AG
+        if AG._SYNC_BN_GROUP[0] is group:
             AG.set_sync_bn_group(None)
-            self.bn_group = None
-
-    def __del__(self):
+        if not destroy:                                                   # (garbage collection runs at different times on different ranks: only an explicit close() tears the communicator down)
+            return
         try:
-            self.close()
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                dist.destroy_process_group(group)
+        except Exception:                                                 # noqa: BLE001  (backend already torn down)
+            pass
+
+    def __del__(self):                                                    # identity-guarded (see close): collecting an old step never touches a newer one's group
+        try:
+            self.close(destroy=False)
         except Exception:                                                 # noqa: BLE001  (interpreter shutdown)
             pass
 

@@ -404,6 +404,8 @@ class GramRegHeadsHipFn(torch.autograd.Function):
     def backward(ctx, dout, dact_e):
         d, geo = ctx.desc, ctx.geo
         wshapes, w2shapes, b2shapes, nb, Ne, F, CH, N = ctx.shapes
+        if ctx.keep is None:
+            raise RuntimeError("GramRegHeadsHipFn: backward ran twice (retain_graph=True): the node releases its saved buffers after the first pass")
         x = ctx.keep[1]
         A = ctx.keep[6]
         Wkc = ctx.keep[7]
@@ -465,7 +467,17 @@ class GramRegHeadsHipFn(torch.autograd.Function):
 
 def gram_reg_heads(x, rows, abns, offs, ld_out, trunk_ws, gammas, betas, w2s, b2s, sync=True, extra_branch=-1, extra_rows=None):
     """-> (table [N][ld_out], activation rows of branch `extra_branch` at the flat pixel indices `extra_rows` in x's dtype, or None)."""
-    if HIP_NODE[0] and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.shape[-1] == 64 and not torch.are_deterministic_algorithms_enabled() \
-            and all(w.shape[0] == 256 and tuple(w.shape[1:]) == (64, 3, 3) for w in trunk_ws) and len(trunk_ws) <= 8:
+    def f32c(t):
+        return t is not None and t.dtype == torch.float32 and t.is_contiguous()
+    # everything the C entry (mfx_gram_heads) requires -- a configuration outside it takes the torch node instead of failing with MFX_ERR_ARG (ADVICE r5):
+    # 256 trunk channels per branch, <= 32 outputs per 1x1 head with a 256-wide fp32 weight, fp32 contiguous ABN parameters / running statistics, ONE
+    # momentum for all branches (the node applies abns[0]'s; eps is per branch)
+    hip_ok = (HIP_NODE[0] and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.shape[-1] == 64 and not torch.are_deterministic_algorithms_enabled()
+              and all(w.shape[0] == 256 and tuple(w.shape[1:]) == (64, 3, 3) for w in trunk_ws) and len(trunk_ws) <= 8
+              and all(w.shape[0] <= 32 and w.shape[1] == 256 and w.numel() == w.shape[0] * 256 for w in w2s)
+              and all(f32c(t) for t in list(gammas) + list(betas))
+              and all(f32c(a.running_mean) and f32c(a.running_var) for a in abns)
+              and len({a.momentum for a in abns}) == 1)
+    if hip_ok:
         return GramRegHeadsHipFn.apply(x, rows, tuple(abns), tuple(offs), ld_out, sync, extra_branch, extra_rows, *trunk_ws, *gammas, *betas, *w2s, *b2s)
     return GramRegHeadsFn.apply(x, rows, tuple(abns), tuple(offs), ld_out, sync, extra_branch, extra_rows, *trunk_ws, *gammas, *betas, *w2s, *b2s)

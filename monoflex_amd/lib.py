@@ -44,7 +44,7 @@ class DcnDesc(ctypes.Structure):
                 ("ldy", c_int), ("act", c_int), ("dtype", c_int), ("w_frag_f16", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64),
                 ("off_w_frag_f16", c_void_p), ("off_shift", c_void_p), ("offmask_out", c_void_p),
-                ("nonsquare", c_int), ("stride_w", c_int), ("pad_w", c_int), ("dil_w", c_int)]
+                ("nonsquare", c_int), ("stride_w", c_int), ("pad_w", c_int), ("dil_w", c_int), ("w_pair_f16", c_void_p)]
 
 
 class HeadsDesc(ctypes.Structure):
@@ -115,14 +115,17 @@ SYMBOLS = {
     "mfx_f1_fused": (_I, [_P] * 11 + [_I, _I, _I, _I, _I, _P]),
     "mfx_set_option": (_I, [ctypes.c_char_p, _I]),
     "mfx_reset_options": (_I, []),
+    "mfx_commit_options": (_I, []),
     "mfx_get_counter": (ctypes.c_long, [ctypes.c_char_p]),
     "mfx_f16x2_range_check": (ctypes.c_int, [ctypes.c_int]),
     "mfx_dcn_v2_workspace_bytes": (_S, [_I] * 14),
+    "mfx_dcn_v2_workspace_bytes_g": (_S, [_I] * 15),
     "mfx_dcn_v2_forward": (_I, [_P] * 6 + [_I] * 14 + [_P, _S, _P]),
     "mfx_dcn_v2_backward": (_I, [_P] * 11 + [_I] * 14 + [_P, _S, _P]),
     "mfx_conv2d_nhwc": (_I, [ctypes.POINTER(ConvDesc), _P]),
     "mfx_cat_conv1x1_nhwc": (_I, [ctypes.POINTER(CatDesc), _P]),
     "mfx_dcn_nhwc": (_I, [ctypes.POINTER(DcnDesc), _P]),
+    "mfx_dcn_sample_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_maxpool2x2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mfx_upsample_add_nhwc": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -192,13 +195,14 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.mfx_abi_version() != 2:
+    if lib.mfx_abi_version() != 3:
         raise RuntimeError("libmonoflex_hip.so ABI version mismatch")
     _lib = lib
     # MFX_OPTIONS="name=value,name=value": library tuning switches for this process (mfx_set_option; A/B sweeps of an unmodified bench.py / training script)
     for kv in filter(None, os.environ.get("MFX_OPTIONS", "").split(",")):
         k, _, v = kv.partition("=")
         check(lib.mfx_set_option(k.strip().encode(), int(v)), "MFX_OPTIONS: %s" % kv)
+    check(lib.mfx_commit_options(), "mfx_commit_options")      # mfx_reset_options() now restores the values AFTER the environment's switches
     return lib
 
 

@@ -6,6 +6,7 @@ only; every arithmetic op below runs in libmonoflex_hip.so.  Weight packing (don
 `prepare`) uses torch indexing ops -- it is not on the hot path.
 """
 import ctypes
+import os
 import math
 from dataclasses import dataclass
 from typing import Optional
@@ -172,6 +173,8 @@ class PackedConv:
     w_frag: Optional[torch.Tensor] = None   # fragment-major copy for the LDS-halo kernel (3x3 / stride 1)
     w_frag_f16: Optional[torch.Tensor] = None   # same, IEEE fp16 (DCN LDS-patch kernel, bf16 mode)
     w_frag_pair: Optional[torch.Tensor] = None  # split precision: w_frag with its K steps paired (pair_steps; mfx_conv_desc.w_frag_pair)
+    w_pair_f16: Optional[torch.Tensor] = None   # IEEE fp16, tap-pair K order of the fourth-generation DCN kernel (dcn_pair_fragments; mfx_dcn_desc.w_pair_f16)
+    ps: Optional["PackedConv"] = None           # DCN as project-then-sample: the same weights as ONE 1x1 conv C -> 9*Cout (rows (tap, n)); built on first use (dcn_ps_pack)
     split: bool = False                     # split-precision operands (F16X2): fp32 activations, MFX_F16X2 kernels
 
 
@@ -377,8 +380,25 @@ def cat_conv1x1(srcs, p: PackedCat):
     return y
 
 
+def dcn_pair_fragments(weight, cout_pad):
+    """(Cout, Cin, 3, 3) -> the fourth-generation DCN kernel's fp16 weights (csrc/dcn_lds.hip, mfx_dcn_desc.w_pair_f16): the input channels in slices
+    of 16, five MFMA k-steps (K = 32) per slice, k-step j = taps (2j, 2j + 1) x the slice's 16 channels (the tenth tap is zeros); fragment-major
+    [cout_pad / 16][Cin / 16 * 5][4 kq][16 n][8]: lane (kq, n) holds tap 2j + (kq >> 1), channels 16 s + 8 (kq & 1) .. + 7 of output channel 16 nf + n."""
+    Cout, Cin, kh, kw = weight.shape
+    assert kh == 3 and kw == 3 and Cin % 16 == 0 and cout_pad % 16 == 0
+    w = weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
+    wp = w.new_zeros(cout_pad, 10, Cin)
+    wp[:Cout, :9] = w
+    wp = wp.view(cout_pad, 5, 2, Cin // 16, 2, 8).permute(0, 3, 1, 2, 4, 5)      # (n, slice, step, tap parity, channel half, 8)
+    w2d = wp.reshape(cout_pad, (Cin // 16) * 5 * 32).to(torch.float16).contiguous()
+    return fragment_major(w2d, torch.float16)
+
+
 def add_f16_fragments(p: PackedConv, weight):
-    """Attach the fp16 fragment-major weights the DCN LDS-patch kernel multiplies with (bf16 mode, 3x3/s1/p1)."""
+    """Attach the fp16 fragment-major weights the DCN LDS-patch kernels multiply with (bf16 / fp16 mode, 3x3/s1/p1)."""
+    if p.w_frag is not None and p.w.dtype in (torch.float16, torch.bfloat16) and p.kh == 3 and p.kw == 3 and p.Cout_pad == 64 \
+            and weight.shape[1] % 16 == 0 and not p.split:
+        p.w_pair_f16 = dcn_pair_fragments(weight.to(p.w.device), p.Cout_pad)
     if p.w_frag is not None and p.w.dtype == torch.float16:
         p.w_frag_f16 = p.w_frag                                  # fp16 mode: the fragments already are IEEE fp16
     elif p.w_frag is not None and p.w.dtype == torch.bfloat16:
@@ -396,6 +416,7 @@ def _dcn_desc(x, offmask, p: PackedConv, y, off: Optional[PackedConv] = None, of
     d.offmask = offmask.data_ptr() if offmask is not None else None
     d.w_frag = p.w_frag.data_ptr() if p.w_frag is not None else None
     d.w_frag_f16 = p.w_frag_f16.data_ptr() if p.w_frag_f16 is not None else None
+    d.w_pair_f16 = p.w_pair_f16.data_ptr() if p.w_pair_f16 is not None else None
     d.scale = p.scale.data_ptr() if p.scale is not None else None
     d.shift = p.shift.data_ptr() if p.shift is not None else None
     d.B, d.H, d.W, d.C = B, H, W, C
@@ -423,6 +444,42 @@ def dcn(x, offmask, p: PackedConv):
     return y
 
 
+# DCN as "project, then sample" (csrc/dcn_ps.hip): which layers take it.  The projected map holds 9 * Cout values per pixel and is written and read back;
+# measured at B = 8 (profiles/r06_dcn_ps.md): it beats the fused gather kernels where that map is <= 18 MB (512 -> 256 @ 12 x 40: 49 -> 39 us,
+# 256 -> 64 @ 24 x 80: 30 -> 24 us) and loses from 35 MB up (the projection GEMM is bound by writing the map: 70.8 MB take 33-47 us with this library's
+# 1x1 kernel AND with the vendor's GEMM), so the byte limit below keeps it to the two small-map channel-reducing modules.
+DCN_PS = [os.environ.get("MFX_DCN_PS", "1") != "0"]      # MFX_DCN_PS=0: every layer on the fused gather kernels (A/B)
+DCN_PS_MAX_BYTES = [24 << 20]
+
+
+def dcn_ps_pack(p: PackedConv):
+    """The DCN weights [Cout][(tap, c)] as a 1x1 conv C -> 9 * Cout whose output row is [(tap, n)] (no scale / shift / activation: those follow the sampling)."""
+    if p.ps is None:
+        C = p.K_pad // 9
+        w = p.w[:p.Cout].view(p.Cout, 9, C).permute(1, 0, 2).reshape(9 * p.Cout, C, 1, 1)
+        p.ps = pack_conv(w, p.w.dtype, None, None, stride=1, pad=0, act=L.ACT_NONE)
+    return p.ps
+
+
+def dcn_ps_applies(x, p: PackedConv):
+    B, H, W, C = x.shape
+    return (DCN_PS[0] and x.dtype in (torch.bfloat16, torch.float16) and not p.split and p.kh == 3 and p.kw == 3 and p.stride == 1 and p.pad_h == 1
+            and p.dil_w == 1 and p.K_pad == 9 * C and C >= 128 and p.Cout == p.Cout_pad and p.Cout in (64, 128, 256)
+            and B * H * W * 9 * p.Cout * 2 <= DCN_PS_MAX_BYTES[0])
+
+
+@on_tensor_device
+def dcn_ps(x, offmask, p: PackedConv):
+    """DCNv2 + scale/shift + act as two launches: the 1x1 projection of the whole map (dense GEMM), then the bilinear sampling of the projected map."""
+    _need_cuda(x, offmask)
+    B, H, W, C = x.shape
+    proj = conv2d(x, dcn_ps_pack(p))                            # (B, H, W, 9 * Cout), rows [(tap, n)]
+    y = torch.empty((B, H, W, p.Cout), dtype=x.dtype, device=x.device)
+    L.check(L.load().mfx_dcn_sample_nhwc(_ptr(proj), _ptr(offmask), _ptr(p.scale), _ptr(p.shift), _ptr(y), B, H, W, p.Cout, p.Cout, p.act,
+                                         _dt(x.dtype), _stream()), "mfx_dcn_sample_nhwc")
+    return y
+
+
 @on_tensor_device
 def dcn_module(x, p_off: PackedConv, p: PackedConv, need_offmask=False):
     """The DCN module of the reference (dcn_v2.py:118-128): offset/mask conv (27 -> 32 channels, fp32 out, sigmoid on the mask channels)
@@ -439,6 +496,8 @@ def dcn_module(x, p_off: PackedConv, p: PackedConv, need_offmask=False):
             L.check(L.load().mfx_dcn_nhwc(ctypes.byref(d), _stream()), "mfx_dcn_nhwc")
             return y, om
     om = conv2d(x, p_off, out_dtype=torch.float32)
+    if dcn_ps_applies(x, p):
+        return dcn_ps(x, om, p), om
     return dcn(x, om, p), om
 
 
@@ -678,7 +737,7 @@ def ext_dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw
     Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
     Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
     lib_ = L.load()
-    nbytes = lib_.mfx_dcn_v2_workspace_bytes(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, 0)
+    nbytes = lib_.mfx_dcn_v2_workspace_bytes_g(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, 0)
     ws = _workspace(nbytes, x.device)
     out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     L.check(lib_.mfx_dcn_v2_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(off), _ptr(msk), _ptr(out), B, C, H, W, Cout, kh, kw,
@@ -696,7 +755,7 @@ def ext_dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kh, kw, 
     B, C, H, W = x.shape
     Cout = w.shape[0]
     lib_ = L.load()
-    nbytes = lib_.mfx_dcn_v2_workspace_bytes(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, 1)
+    nbytes = lib_.mfx_dcn_v2_workspace_bytes_g(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, 1)
     ws = _workspace(nbytes, x.device)
     gi, gw, gb = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
     goff, gm = torch.empty_like(off), torch.empty_like(msk)

@@ -46,6 +46,17 @@ def aggregate_throughput(elapsed_s, images_local, device="cpu"):
     return images_local / elapsed_s, elapsed_s, int(round(images_local))
 
 
+def ranks_seen(device="cpu"):
+    """The ranks that answered an all-gather on the default process group (RCCL on GPUs), sorted: proof, inside the job, of how many processes took part
+    (a record that says n_gpus = 8 should also say which eight ranks met).  [0] for a single process."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device=device)
+        out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, mine)
+        return sorted(int(t.item()) for t in out)
+    return [0]
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -46,6 +46,21 @@ from oracle import dcn_ref
 GOLD = os.path.join(REPO, "tests", "golden")
 
 
+def use_reference_packages():
+    """The reference's top-level packages (`model`, `config`, `data`, ...) are namespace packages (no __init__.py), and a regular package of the same
+    name anywhere on sys.path wins over a namespace portion -- the repository root holds such packages since r04 (the reference's import names aliased
+    to monoflex_amd.*, monoflex_amd/_alias.py).  Bind the names to the REFERENCE's directories explicitly, so that everything imported below really is
+    the reference's code (asserted in build_reference)."""
+    import importlib.machinery
+    import importlib.util
+    for name in ("config", "model", "solver", "engine", "data", "utils", "structures"):
+        spec = importlib.machinery.PathFinder.find_spec(name, [REF])
+        assert spec is not None and name not in sys.modules, name
+        if spec.loader is None:                                   # namespace package: would lose to the repository's regular package of that name
+            sys.modules[name] = importlib.util.module_from_spec(spec)
+        # (a regular package of the reference -- config, solver -- is found first anyway once REF precedes the repository on sys.path)
+
+
 def install_stubs():
     yacs = types.ModuleType("yacs"); yacs_cfg = types.ModuleType("yacs.config")
     yacs_cfg.CfgNode = CfgNode; yacs.config = yacs_cfg
@@ -90,6 +105,7 @@ def install_stubs():
             return torch.div(a, b, rounding_mode='floor')
         return _td(a, b)
     torch.Tensor.__truediv__ = _truediv
+    use_reference_packages()
 
 
 def build_reference(out_w, out_h):
@@ -102,6 +118,8 @@ def build_reference(out_w, out_h):
     cfg.DATASETS.TEST_SPLIT = "test"
     cfg.INPUT.WIDTH_TRAIN, cfg.INPUT.HEIGHT_TRAIN = out_w * 4, out_h * 4
     from model.detector import KeypointDetector
+    import model.detector as _md
+    assert os.path.abspath(_md.__file__).startswith(REF + os.sep), "not the reference's model package: " + _md.__file__
     model = KeypointDetector(cfg).eval()
     return cfg, model
 
@@ -134,7 +152,22 @@ def checksum(t):
                 idx=idx.numpy(), samples=t[idx].float().numpy(), shape=np.array(list(t.shape)))
 
 
-def run_case(name, out_w, out_h, seeds, cls_bias, store_full):
+MIN_GAP = 1e-4      # smallest allowed distance between neighbours among the top-51 reference scores of a full-size golden image
+
+
+def top_gap(logits, k=51):
+    """Smallest gap between consecutive scores among the k best peaks of the reference's NMS-ed heat map (model/layers/utils.py:39-58: sigmoid, clamp,
+    3x3 max-pool, `hmax == heat`).  k = 51: the 50 detections plus the first one left out -- a near-tie at the cut changes the SET, not only the order."""
+    heat = torch.clamp(torch.sigmoid(logits.float()), min=1e-4, max=1 - 1e-4)
+    hmax = torch.nn.functional.max_pool2d(heat[None], 3, 1, 1)[0]
+    sc = torch.topk((heat * (hmax == heat).float()).flatten(), k).values
+    return float((sc[:-1] - sc[1:]).min())
+
+
+def run_case(name, out_w, out_h, seeds, cls_bias, store_full, n_images=None):
+    """`n_images` set: `seeds` is a candidate stream; the first n_images whose top-51 reference scores are pairwise >= MIN_GAP apart are kept (SURVEY
+    section 7 'hard parts': a golden image must not contain a near-tie -- the order of a 1.7e-6 pair is decided by the summation order of a 50-layer fp32
+    network, not by the detector, and every tile shape would round it its own way)."""
     cfg, model = build_reference(out_w, out_h)
     sd = S.synthetic_state_dict(model.state_dict(), seed=0, cls_bias=cls_bias)
     model.load_state_dict(sd)
@@ -159,14 +192,25 @@ def run_case(name, out_w, out_h, seeds, cls_bias, store_full):
         lambda m, i, o: rec.__setitem__("pred", {k: v.detach().clone() for k, v in o.items()}))
 
     out = {}
-    meta = dict(case=name, out_w=out_w, out_h=out_h, seeds=list(seeds), weight_seed=0, cls_bias=cls_bias,
+    meta = dict(case=name, out_w=out_w, out_h=out_h, seeds=[], weight_seed=0, cls_bias=cls_bias,
                 ext="oracle/dcn_v2_ref.c (reference _ext unbuildable: TH/TH.h)",
                 inplace_abn="stub BatchNorm2d(eps=1e-5)+leaky_relu(0.01)", torch=torch.__version__)
-    for n, seed in enumerate(seeds):
+    kept, n = [], -1
+    for seed in seeds:
+        if n_images is not None and len(kept) == n_images:
+            break
         img = S.synthetic_images(1, out_h * 4, out_w * 4, seed=seed)
         tgt = S.synthetic_target(out_w, out_h)
         with torch.no_grad():
             result, eval_utils, vis = model(img, [reference_target(tgt)])
+        if n_images is not None:
+            gap = top_gap(rec["cls_logits"][0])
+            if gap < MIN_GAP:
+                print(name, "seed", seed, "rejected: smallest gap among the top-51 reference scores %.2e < %.0e" % (gap, MIN_GAP))
+                continue
+            out["img%d_top51_min_gap" % len(kept)] = np.array(gap)
+        kept.append(seed)
+        n += 1
         p = "img%d_" % n
         for i, t in enumerate(rec["base"]):
             for k, v in checksum(t).items():
@@ -194,6 +238,10 @@ def run_case(name, out_w, out_h, seeds, cls_bias, store_full):
         out[p + "result"] = result.numpy()
         print(name, "img", n, "detections", tuple(result.shape), "top score %.4f" % float(sc[0]))
     dp.sigmoid_hm, di.select_topk = orig_sig, orig_topk
+    meta["seeds"] = [int(s_) for s_ in kept]
+    if n_images is not None:
+        assert len(kept) == n_images, "candidate seeds exhausted"
+        meta["min_gap_top51"] = MIN_GAP
     out["meta"] = np.array(repr(meta))
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 
@@ -620,4 +668,7 @@ if __name__ == "__main__":
     if "decode" in which:
         run_decode_cases()
     if "full" in which:
-        run_case("e2e_full", 320, 96, seeds=(1000,), cls_bias=-1.0, store_full=False)
+        # BASELINE configs[0]'s four seeded images (1000 ..; a seed whose top-51 scores hold a near-tie is skipped) and one image at the
+        # reference's default class bias -log(1/0.01 - 1) (detector_predictor.py:43: nothing passes the 0.2 threshold there -- the zero-detection path at full size)
+        run_case("e2e_full", 320, 96, seeds=range(1000, 1040), cls_bias=-1.0, store_full=False, n_images=4)
+        run_case("e2e_full_default_bias", 320, 96, seeds=range(1000, 1040), cls_bias=-float(np.log(1 / 0.01 - 1)), store_full=False, n_images=1)

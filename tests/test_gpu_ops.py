@@ -487,36 +487,89 @@ def test_offset_conv_k_split_waves(dtype, B, H, W, C):
         L.check(lib_.mfx_set_option(b"halo", 1), "opt")
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,C,Cout,H,W,off_std", [(2, 64, 64, 20, 40, 1.5), (1, 128, 64, 33, 47, 3.0), (2, 256, 128, 12, 24, 2.0), (1, 512, 256, 7, 19, 6.0)])
-def test_dcn_corner_quad_kernels_match_the_blend_first_kernel(dtype, B, C, Cout, H, W, off_std):
-    """csrc/dcn_cq.hip (off by default: measured slower): the bilinear blend done by the matrix cores' accumulation
-    (acc += w_q * (W . x_q) over the four un-blended corner rows), register-ring form (option dcn_cq = 2) and LDS-DMA form (3), against the
-    library's blend-first gather kernel on the same inputs.  The corner-quad forms never round the blended sample to 16 bits, so they
-    agree with the blend-first kernel to that rounding (and are the closer of the two to the fp32 evaluation of the same op).  Ragged
-    pixel tiles, several output-channel tiles, one to four weight slabs per tap, offsets that leave the image (std 6 on a 7 x 19 map)."""
+def _dcn_case(B, C, Cout, H, W, off_std, dtype, far_frac=0.0, seed=71):
     from monoflex_amd import lib as L, ops
-    g = _g(71)
-    x = torch.randn(B, H, W, C, generator=g).to(dtype).to(DEV)
+    g = _g(seed)
+    x = torch.randn(B, H, W, C, generator=g).relu().to(dtype).to(DEV)
     om = torch.zeros(B, H, W, 32)
     om[..., :18] = torch.randn(B, H, W, 18, generator=g) * off_std
+    if far_frac > 0:                                           # a sprinkle of wild offsets: samples that leave the LDS patch, some of them the image
+        wild = torch.rand(B, H, W, 18, generator=g) < far_frac
+        om[..., :18] = torch.where(wild, torch.randn(B, H, W, 18, generator=g) * 40.0, om[..., :18])
     om[..., 18:27] = torch.rand(B, H, W, 9, generator=g)
     om = om.to(DEV)
     w = torch.randn(Cout, C, 3, 3, generator=g) * (1.0 / (3 * C ** 0.5))
-    p = ops.pack_conv(w.to(DEV), dtype, torch.rand(Cout, generator=g).to(DEV) + 0.5, torch.randn(Cout, generator=g).to(DEV),
+    p = ops.pack_conv(w.to(DEV), dtype, torch.rand(Cout, generator=g).to(DEV) + 0.5, torch.randn(Cout, generator=g).to(DEV) * 0.1,
                       stride=1, pad=1, act=L.ACT_RELU)
     ops.add_f16_fragments(p, w)
     p32 = ops.pack_conv(w.to(dtype).float().to(DEV), torch.float32, p.scale, p.shift, stride=1, pad=1, act=L.ACT_RELU)
+    return x, om, p, p32
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows", [16, 8])
+@pytest.mark.parametrize("B,C,Cout,H,W,off_std,far", [(2, 64, 64, 32, 48, 1.5, 0.0), (1, 64, 64, 20, 40, 2.5, 0.02), (2, 128, 64, 48, 64, 3.0, 0.01),
+                                                      (1, 64, 64, 16, 16, 12.0, 0.0), (1, 256, 64, 9, 21, 2.0, 0.05)])
+def test_dcn_lds_kernel_matches_the_gather_kernel(dtype, rows, B, C, Cout, H, W, off_std, far):
+    """csrc/dcn_lds.hip (r06, fourth generation: LDS patch + geometry table + branch-free sampling loop, far pass from global memory), both tile
+    heights, against the library's gather kernel and its fp32 kernel on the same values: in-patch samples, samples that leave the patch or the
+    image (the far pass: `far` = fraction of wild offsets; std 12 on a 16 x 16 map = mostly far), partial tiles, 4 to 16 channel slices."""
+    from monoflex_amd import lib as L, ops
+    x, om, p, p32 = _dcn_case(B, C, Cout, H, W, off_std, dtype, far)
+    assert p.w_pair_f16 is not None
+    lib_ = L.load()
+    L.check(lib_.mfx_set_option(b"dcn_lds", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_patch", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_wave", 0), "opt")
+    ref = ops.dcn(x.float(), om, p32).cpu()                   # fp32 kernel on the same 16-bit-rounded operands
+    want = ops.dcn(x, om, p).float().cpu()
+    L.check(lib_.mfx_set_option(b"dcn_lds", 2), "opt"); L.check(lib_.mfx_set_option(b"dcn_lds_rows", rows), "opt")
+    got = ops.dcn(x, om, p).float().cpu()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    assert float((got - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().mean()) <= 1.5 * float((want - ref).abs().mean()) + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,C,Cout,H,W", [(2, 512, 256, 12, 40), (2, 256, 64, 24, 80), (1, 128, 64, 13, 37), (1, 256, 128, 7, 9)])
+def test_dcn_project_then_sample_matches_the_gather_kernel(dtype, B, C, Cout, H, W):
+    """DCN as two launches (ops.dcn_ps: the 1x1 projection C -> 9 Cout of the whole map, then csrc/dcn_ps.hip samples the projected map -- bilinear
+    interpolation commutes with the contraction over channels) against the fused gather kernel and the fp32 kernel: the same op up to the 16-bit
+    rounding of the projected map; odd map sizes (partial pixel blocks), offsets that leave the image."""
+    from monoflex_amd import lib as L, ops
+    x, om, p, p32 = _dcn_case(B, C, Cout, H, W, 3.0, dtype, 0.02, seed=73)
     lib_ = L.load()
     L.check(lib_.mfx_set_option(b"dcn_patch", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_wave", 0), "opt")
-    ref = ops.dcn(x.float(), om, p32).cpu()                  # fp32 kernel on the same 16-bit-rounded operands
+    ref = ops.dcn(x.float(), om, p32).cpu()
     want = ops.dcn(x, om, p).float().cpu()
-    e_blend = float((want - ref).abs().mean())
-    for v in (2, 3):
-        L.check(lib_.mfx_set_option(b"dcn_cq", v), "opt")
-        got = ops.dcn(x, om, p).float().cpu()
-        assert float((got - want).abs().max()) <= 2e-2 * max(1.0, float(want.abs().max())), v
-        assert float((got - ref).abs().mean()) <= 1.05 * e_blend + 1e-6, (v, float((got - ref).abs().mean()), e_blend)
+    got = ops.dcn_ps(x, om, p).float().cpu()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert float((got - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().mean()) <= 1.25 * float((want - ref).abs().mean()) + 1e-6
+    assert ops.dcn_ps_applies(x, p) == (B * H * W * 9 * Cout * 2 <= ops.DCN_PS_MAX_BYTES[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows", [16, 8])
+def test_dcn_lds_module_with_the_offset_conv_inside(dtype, rows):
+    """The 64 -> 64 module as ONE launch of dcn_lds_kernel<OF> (offset / mask conv of the tile inside, phase 0) against the two-launch form
+    (offset conv, then the gather kernel), at a size the automatic choice takes (B H W >= 65536) and with partial tiles."""
+    from monoflex_amd import lib as L
+    from monoflex_amd.model.backbone.dla_dcn import DeformConv
+    lib_ = L.load()
+    torch.manual_seed(5)
+    for (B, H, W) in ((3, 100, 232), (8, 96, 320)):
+        x = torch.randn(B, H, W, 64, device=DEV).relu().to(dtype)
+        m = DeformConv(64, 64).eval().to(DEV)
+        torch.nn.init.normal_(m.conv.conv_offset_mask.weight, std=2.5 / (0.7 * (9 * 64) ** 0.5))
+        with torch.no_grad():
+            L.check(lib_.mfx_set_option(b"dcn_lds", 1), "opt"); L.check(lib_.mfx_set_option(b"dcn_lds_rows", rows), "opt")
+            got = m(x).float().cpu()
+            L.check(lib_.mfx_set_option(b"dcn_lds", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_patch", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_wave", 0), "opt")
+            want = m(x).float().cpu()
+        L.check(lib_.mfx_reset_options(), "reset")
+        tol = 3e-2 if dtype == torch.bfloat16 else 6e-3         # (the offsets themselves come from two differently rounded convs)
+        frac_bad = float(((got - want).abs() > tol * want.abs().clamp(min=1.0)).float().mean())
+        assert frac_bad <= 1e-4, frac_bad
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

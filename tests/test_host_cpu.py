@@ -21,7 +21,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(cdll, name), name
     cdll.mfx_abi_version.restype = ctypes.c_int
-    assert cdll.mfx_abi_version() == 2                                   # r05: descriptor structs grew (see MFX_ABI_VERSION in the header)
+    assert cdll.mfx_abi_version() == 3                                   # r06: mfx_dcn_desc.w_pair_f16 (see MFX_ABI_VERSION in the header)
 
 
 def test_ctypes_struct_layout_matches_header_sizes(tmp_path):

@@ -25,7 +25,8 @@ def _worker(rank, world, port, out):
     imgs = S.synthetic_images(count, 8, 16, seed=parallel.shard_seed(1000, rank, 3))
     parallel.barrier()
     rate, elapsed, total = parallel.aggregate_throughput(0.5 + rank, images_local=count)     # rank 1 is the slow one
-    out.put((rank, first, count, float(imgs.sum()), rate, elapsed, total))
+    seen = parallel.ranks_seen()                                                               # the all-gather bench.py's line carries
+    out.put((rank, first, count, float(imgs.sum()), rate, elapsed, total, seen))
     dist.destroy_process_group()
 
 
@@ -38,15 +39,38 @@ def test_two_rank_sharding_and_timing_reduction():
     res = sorted(q.get(timeout=120) for _ in ps)
     [p.join(timeout=60) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
-    (_, f0, c0, s0, rate0, el0, tot0), (_, f1, c1, s1, rate1, el1, tot1) = res
+    (_, f0, c0, s0, rate0, el0, tot0, seen0), (_, f1, c1, s1, rate1, el1, tot1, seen1) = res
+    assert seen0 == seen1 == [0, 1]                          # both ranks answered the all-gather
     assert (f0, c0, f1, c1) == (0, 3, 3, 2)                  # contiguous, disjoint, covers the 5 images
     assert s0 != s1                                          # disjoint synthetic streams
     assert el0 == el1 == 1.5 and tot0 == tot1 == 5           # max over ranks, sum over ranks
     assert abs(rate0 - 5 / 1.5) < 1e-9 and rate0 == rate1
 
 
+def test_bench_line_order_puts_leg_scalars_and_ranks_before_the_long_blobs():
+    """every leg's headline number is a top-level scalar, `ranks_seen` / `rccl_ranks` are in the line, and the per-family blob comes
+    last (a truncated capture of the line keeps the numbers)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    res = {"metric": "m", "value": 1.0, "unit": "images/s", "n_gpus": 2, "steps": 3, "warmup": 1, "ms_per_step": 2.0, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "config": {"workload": "w"}, "roofline": {"frac": 0.5},
+           "roofline_families": {"heads": {"x": 1}}, "cpu_baseline": {"value": 0.5}, "b32": {"value": 10.0}, "fp16x2_parity": {"value": 4.0},
+           "fp32_parity": {"error": "boom"}, "train": {"value": 7.0, "ms_per_step": 18.0}}
+    out = bench.order_line(res, [0, 1], 2)
+    keys = list(out)
+    assert keys[:13] == ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"]
+    assert out["b32_images_per_s"] == 10.0 and out["fp16x2_images_per_s"] == 4.0 and out["train_ms_per_step"] == 18.0 and out["train_images_per_s"] == 7.0
+    assert "fp32_images_per_s" not in out                    # a failed leg has no number; its error object stays
+    assert out["fp32_parity"] == {"error": "boom"} and out["rccl_ranks"] == 2 and out["ranks_seen"] == [0, 1]
+    assert keys[-1] == "roofline_families" and keys.index("b32_images_per_s") < keys.index("b32")
+    assert set(res) <= set(out)
+
+
 def test_single_process_is_passthrough():
     from monoflex_amd import parallel
+    assert parallel.ranks_seen() == [0]
     assert parallel.image_shard(0, 1, 8) == (0, 8)
     rate, el, tot = parallel.aggregate_throughput(2.0, 16)
     assert (rate, el, tot) == (8.0, 2.0, 16)

@@ -15,6 +15,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 STD = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
 for kv in filter(None, (sys.argv[3] if len(sys.argv) > 3 else "").split(",")):
     k, v = kv.split("=")
+    if k == "dcn_ps":                                  # host-side switch: DCN as project-then-sample (ops.dcn_ps) in the module column
+        ops.DCN_PS[0] = bool(int(v))
+        continue
     lib.check(L.mfx_set_option(k.encode(), int(v)), "opt")
 SHAPES = [(12, 40, 512, 256, 1), (24, 80, 256, 256, 1), (24, 80, 256, 128, 2), (48, 160, 128, 128, 2), (48, 160, 128, 64, 4), (24, 80, 256, 64, 1),
           (96, 320, 64, 64, 5)]
