@@ -174,40 +174,58 @@ def cpu_baseline(sd, n_images):
     return out
 
 
+def golden_meta():
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_full.npz"))
+    return g, ast.literal_eval(str(g["meta"]))
+
+
+def bench_images(B, rank, device):
+    """Rank r's synthetic batch.  Rank 0's first images are the frames of tests/golden/e2e_full.npz (the reference's own outputs exist for them: every
+    timed mode reports its deviation from the reference on exactly what it was timed on); all other frames are drawn from disjoint seed streams."""
+    import torch
+    from monoflex_amd import parallel, synthetic as S
+    seeds = [parallel.shard_seed(3000, rank, B) + i for i in range(B)]
+    if rank == 0:
+        gold = list(golden_meta()[1]["seeds"])[:B]
+        seeds[:len(gold)] = gold
+    return torch.cat([S.synthetic_images(1, 384, 1280, seed=s_) for s_ in seeds]).to(device)
+
+
 def deviation_vs_reference(out, dtype):
-    """Image 0 of rank 0's batch is the image of tests/golden/e2e_full.npz (seed 1000, same weights): how far the
-    benchmarked mode is from the REFERENCE's own outputs (logits at 512 + 50 pixels, top-K set, (N,14) rows)."""
+    """Images 0 .. 3 of rank 0's batch are the frames of tests/golden/e2e_full.npz (same weights): how far the benchmarked mode is from the
+    REFERENCE's own outputs (logits at ~560 pixels per image, the top-K sequence, (N,14) rows), worst case over the golden images in the batch."""
     import numpy as np
     import torch
-    g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_full.npz"))
-    meta = ast.literal_eval(str(g["meta"]))
-    if meta["seeds"][0] != 1000 or meta["cls_bias"] != -1.0:
+    g, meta = golden_meta()
+    if meta["cls_bias"] != -1.0:
         return None
-    det, topk, valid, hm = [t[0].float().cpu() for t in out]
-    pix = torch.as_tensor(g["img0_pix"])
-    dl = float(np.abs(hm[..., :3].permute(2, 0, 1).reshape(3, -1)[:, pix].numpy() - g["img0_cls_logits_at"]).max())
-    dr = float(np.abs(hm[..., 8:58].permute(2, 0, 1).reshape(50, -1)[:, pix].numpy() - g["img0_reg_at"]).max())
-    # a peak = (class, pixel): one pixel can rank for two classes
-    mine = topk[:, 2].numpy().astype(np.int64) * (1 << 20) + topk[:, 1].numpy().astype(np.int64)
-    ref = g["img0_topk_cls"].astype(np.int64) * (1 << 20) + g["img0_topk_index"].astype(np.int64)
-    agree = len(set(mine.tolist()) & set(ref.tolist())) / float(len(ref))
-    same_order = bool(np.array_equal(mine, ref))
-    # identical up to permutations among ranks whose REFERENCE scores are within 5e-6 of each other (the golden has one such pair, ranks
-    # 18/19, 1.7e-6 = 29 ulp apart: its order is fp32 summation-order noise; tests/test_gpu_e2e.py _same_ranking)
-    score_of = {int(i): float(s) for i, s in zip(ref, g["img0_topk_scores"])}
-    tie_order = bool(sorted(mine.tolist()) == sorted(ref.tolist()) and
-                     all(abs(score_of[int(m)] - float(s)) <= 5e-6 for m, s in zip(mine, g["img0_topk_scores"])))
-    rows, want = det[valid.bool()].numpy(), g["img0_result"]
-    # rows are compared where both sides decoded the same heat-map peak (same class, same order slot)
-    row_delta = None
-    if rows.shape == want.shape and (same_order or tie_order):
-        perm = [int(np.nonzero(mine == i)[0][0]) for i in ref][:len(want)] if not same_order else list(range(len(want)))
-        if max(perm) < len(rows):
-            row_delta = float(np.abs(rows[perm] - want).max())
-    return {"golden": "tests/golden/e2e_full.npz (reference KeypointDetector, image seed 1000)", "dtype": dtype,
+    nb = int(out[0].shape[0])
+    ngold = min(nb, len(meta["seeds"]))
+    dl = dr = 0.0
+    agree, same_order, row_delta = 1.0, True, 0.0
+    for n in range(ngold):
+        det, topk, valid, hm = [t[n].float().cpu() for t in out]
+        p_ = "img%d_" % n
+        pix = torch.as_tensor(g[p_ + "pix"])
+        dl = max(dl, float(np.abs(hm[..., :3].permute(2, 0, 1).reshape(3, -1)[:, pix].numpy() - g[p_ + "cls_logits_at"]).max()))
+        dr = max(dr, float(np.abs(hm[..., 8:58].permute(2, 0, 1).reshape(50, -1)[:, pix].numpy() - g[p_ + "reg_at"]).max()))
+        # a peak = (class, pixel): one pixel can rank for two classes
+        mine = topk[:, 2].numpy().astype(np.int64) * (1 << 20) + topk[:, 1].numpy().astype(np.int64)
+        ref = g[p_ + "topk_cls"].astype(np.int64) * (1 << 20) + g[p_ + "topk_index"].astype(np.int64)
+        agree = min(agree, len(set(mine.tolist()) & set(ref.tolist())) / float(len(ref)))
+        same = bool(np.array_equal(mine, ref))
+        same_order = same_order and same
+        rows, want = det[valid.bool()].numpy(), g[p_ + "result"]
+        if same and rows.shape == want.shape and row_delta is not None:
+            row_delta = max(row_delta, float(np.abs(rows - want).max())) if len(want) else row_delta
+        else:
+            row_delta = None                                   # rows are compared only where both sides decoded the same peaks in the same order
+    return {"golden": "tests/golden/e2e_full.npz (reference KeypointDetector, image seeds %s; no two of a frame's top-51 peaks closer than 4e-4 in logit units)"
+                      % meta["seeds"][:ngold], "dtype": dtype, "golden_images_in_batch": ngold,
             "max_abs_dlogit": round(dl, 6), "max_abs_dreg": round(dr, 6), "topk_index_agreement": round(agree, 4),
-            "topk_identical_order": same_order, "topk_identical_up_to_reference_ties_5e-6": tie_order, "max_abs_row_delta": row_delta,
-            "north_star_bar": "fp32 mode: <=1e-3 on logits, identical top-K (tests/test_gpu_e2e.py)"}
+            "topk_identical_order": same_order, "max_abs_row_delta": row_delta,
+            "north_star_bar": "fp32 / fp16x2 modes: <=1e-3 on logits, identical top-K sequence (tests/test_gpu_e2e.py)"}
 
 
 def _hip_event_ms(fn, reps):
@@ -316,7 +334,7 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
     model, sd, _ = build_model(dtype, device)
     B = args.batch
     nstreams = args.streams if args.streams > 0 else (1 if dtype in ("bf16", "fp16") else 2)
-    images = S.synthetic_images(B, 384, 1280, seed=parallel.shard_seed(1000, rank, B)).to(device)   # resident in HBM
+    images = bench_images(B, rank, device)                   # resident in HBM; rank 0: the golden frames first
     targets = [make_test_target(S.synthetic_target(320, 96)) for _ in range(B)]
     tg = model.device_targets(targets, device)
 

@@ -248,6 +248,10 @@ typedef struct {
     int32_t ch_off[16]; int32_t c_out[16];
     float w2_scale[16];       /* per branch: the 1x1 sums are multiplied by this before the bias (0 = 1): MFX_F16X2 weights are packed
                                * times a power of two so that their lo halves are normal fp16 numbers, and un-scaled here */
+    /* optional (MFX_BF16 / MFX_F16; option "heads_mfma32"): the packs of the v_mfma_f32_32x32x16 form of the kernel --
+     * w1_32 [nbranch][wn 4][K-step 36][rb 2][64 lanes][8]: lane (row = lane & 31, h = lane >> 5) = 3x3 weights of trunk channel 64 wn + 32 rb + row, k = 16 s + 8 h ..;
+     * w2_32 [nbranch][wn 4][rb 2][t 2][64 lanes][8]: lane (o, h) = W2[o][64 wn + 32 rb + 16 t + 8 (e >> 2) + 4 h + (e & 3)] (rows >= c_out zero) */
+    const void* w1_32; const void* w2_32;
 } mfx_heads_desc;
 int mfx_heads_fused(const mfx_heads_desc* d, void* stream);
 

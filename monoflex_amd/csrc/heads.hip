@@ -22,6 +22,7 @@
 
 int g_opt_heads_persist = 1;   // option "heads_persist": 1 = one workgroup per resident slot (n > 1: n workgroups), each a contiguous range of (tile, branch)
                                // units; 0 = one workgroup per tile.  B=8 bf16: 516 -> 503 us (tools/probes/heads_probe.py), bit-identical output
+int g_opt_heads_mfma32 = 0;    // option "heads_mfma32": 1 = the v_mfma_f32_32x32x16 form of the kernel where the caller supplies its packs (mfx_heads_desc.w1_32 / w2_32)
 int g_opt_heads_dbg = 0;       // option "heads_dbg": timing probes of the bf16 kernel (see DBG below); results are wrong -- compiled in with -DMFX_PROBES only
 
 namespace mfx {
@@ -379,6 +380,213 @@ __global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused_kernel(const T
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The same kernel on v_mfma_f32_32x32x16 (r06; 16-bit element types).  Per wave the tile is still 64 trunk channels x 128 pixels of
+// one branch: 2 row blocks of 32 channels x 4 column blocks of 32 pixels (two adjacent tile rows), 8 MFMAs of 32 cycles per 16 K (the 16x16x32 form
+// issues 32 MFMAs of 16 cycles per 32 K: the same operand bytes per FLOP -- 4 weight fragments and 8 pixel fragments per 32 K either way, the tile
+// decides that, not the instruction -- but half the instruction issues, and the microarchitecture guide measures the 32x32 shape at its exact 32-cycle
+// cadence where the 16x16 one needs ~17).  D layout: lane (c = lane & 31 pixel, h = lane >> 5) holds rows 8 (r >> 2) + 4 h + (r & 3): sixteen trunk
+// channels of one pixel per row block, whose registers 8t .. 8t + 7 ARE the B operand of GEMM2's K-step t (W2 is packed in that K order), so the
+// trunk still never leaves the registers.  w1p32: [branch][wn 4][K-step 36][rb 2][lane 64][16 B], lane (row, h) = weights of channel 64 wn + 32 rb + row,
+// k = 16 s + 8 h ..; w2p32: [branch][wn][rb 2][t 2][lane 64][16 B], lane (o, h) = W2[o][64 wn + 32 rb + 16 t + 8 (e >> 2) + 4 h + (e & 3)].
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <typename T> __device__ __forceinline__ f32x16 mma32(const u32x4& a, const u32x4& b, const f32x16& c);
+template <> __device__ __forceinline__ f32x16 mma32<bf16_t>(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mma32<half_t>(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kHeadWaves * 64, 2) void heads_fused32_kernel(const T* __restrict__ x, const u32x4* __restrict__ w1p, const float* __restrict__ scale1,
+                                                                          const float* __restrict__ shift1, const u32x4* __restrict__ w2p,
+                                                                          const float* __restrict__ bias2, float* __restrict__ out, HeadGeom g, HeadTabs tabs) {
+    constexpr int NT = kHeadWaves * 64;
+    constexpr int PS = HeadSmem<T, false>::PS, RLD = HeadSmem<T, false>::red_ld;
+    constexpr int NB = 4, RB = 2, KS = 36;                  // pixel blocks (32 px), row blocks (32 channels) per wave, K-steps of 16
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;
+    float* red = reinterpret_cast<float*>(smem + HeadSmem<T, false>::patch_bytes);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+
+    const int wg = g.persist ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const long long units = (long long)g.tiles_x * g.tiles_y * g.B * g.nbranch;
+    const int u0 = (int)(units * wg / gridDim.x), u1 = (int)(units * (wg + 1) / gridDim.x);
+    if (u0 >= u1) return;
+
+    int cur_tile = -1, b = 0, x0 = 0, y0 = 0;
+    // lane part of a pixel-fragment address: pixel (row c >> 4 of the block's two, column c & 15), channel chunk h of the K-step
+    const char* lb = patch + ((c >> 4) * 18 + (c & 15)) * PS + h * 16;
+    for (int u = u0; u < u1; ++u) {
+        const int tile_u = u / g.nbranch, br = u - tile_u * g.nbranch;
+        if (tile_u != cur_tile) {
+            if (cur_tile >= 0) __syncthreads();
+            cur_tile = tile_u;
+            int ptid = tid;
+            asm volatile("" : "+v"(ptid));
+            int tile = tile_u;
+            const int tx = tile % g.tiles_x; tile /= g.tiles_x;
+            const int ty = tile % g.tiles_y; b = tile / g.tiles_y;
+            x0 = tx * 16; y0 = ty * kHeadRows;
+            constexpr int CPP = kHeadC * (int)sizeof(T) / 16;
+            constexpr int nchunks = (kHeadRows + 2) * 18 * CPP;
+            const T* xg = x + (size_t)b * g.H * g.W * kHeadC;
+            constexpr int PU = 4;
+            for (int base = 0; base < nchunks; base += NT * PU) {
+                u32x4 pr[PU];
+#pragma unroll
+                for (int q = 0; q < PU; ++q) {
+                    const int idx = base + q * NT + ptid;
+                    const int pix = idx / CPP, ch = idx - pix * CPP;
+                    const int py = pix / 18, px = pix - py * 18;
+                    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                    u32x4 z = {0u, 0u, 0u, 0u};
+                    if (idx < nchunks && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                        z = *reinterpret_cast<const u32x4*>(xg + ((size_t)iy * g.W + ix) * kHeadC + ch * 8);
+                    pr[q] = z;
+                }
+#pragma unroll
+                for (int q = 0; q < PU; ++q) {
+                    const int idx = base + q * NT + ptid;
+                    if (idx < nchunks) *reinterpret_cast<u32x4*>(patch + (idx / CPP) * PS + (idx % CPP) * 16) = pr[q];
+                }
+            }
+            __syncthreads();
+        }
+
+        f32x16 acc[NB][RB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // ---- GEMM1: D[rb][blk] rows = trunk channels 64 wn + 32 rb + .., cols = the block's 32 pixels.  Fully unrolled: every LDS offset is an immediate.
+        const u32x4* wsrc = w1p + ((size_t)(br * kHeadWaves + wn) * KS) * (RB * 64) + lane;
+        constexpr int WR = 6;                                 // weight ring: K-steps in flight (2 fragments each): 5 ahead x 256 MFMA cycles (36 % 6 == 0)
+        u32x4 wb[WR][RB];
+#pragma unroll
+        for (int s = 0; s < WR - 1; ++s)
+#pragma unroll
+            for (int j = 0; j < RB; ++j) wb[s][j] = wsrc[(size_t)(s * RB + j) * 64];
+        u32x4 pf[2][NB];
+        auto pread = [&](int s, u32x4 (&dst)[NB]) {
+            const int tap = s >> 2, th = tap / 3, tw = tap - th * 3;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) dst[i] = *reinterpret_cast<const u32x4*>(lb + ((2 * i + th) * 18 + tw) * PS + 32 * (s & 3));
+        };
+        pread(0, pf[0]);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + WR - 1 < KS) {
+#pragma unroll
+                for (int j = 0; j < RB; ++j) wb[(s + WR - 1) % WR][j] = wsrc[(size_t)((s + WR - 1) * RB + j) * 64];
+            }
+            if (s + 1 < KS) pread(s + 1, pf[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < RB; ++j) acc[i][j] = mma32<T>(wb[s % WR][j], pf[s & 1][i], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- BN + leaky in registers; GEMM2 straight from the accumulators
+        const int cn = tabs.c_out[br];
+        const bool two = cn > 16;
+        u32x4 w2f[RB][2];
+        {
+            const u32x4* src = w2p + ((size_t)(br * kHeadWaves + wn) * (RB * 2)) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) w2f[j][t] = src[(size_t)(j * 2 + t) * 64];
+        }
+        const int co = tabs.ch_off[br];
+        const float w2s = tabs.w2s[br];
+        f32x16 po[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) po[i][r] = 0.f;
+        // row block by row block: the block's 16 scale / shift values per lane live only while its accumulators are consumed (all 32 at once, next to
+        // 128 accumulator and 64 output registers, spilled)
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            f32x4 s4[4], h4[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int ch = br * kHeadTrunk + wn * 64 + j * 32 + gq * 8 + h * 4;
+                s4[gq] = *reinterpret_cast<const f32x4*>(scale1 + ch);
+                h4[gq] = *reinterpret_cast<const f32x4*>(shift1 + ch);
+            }
+            // (t outside i: consecutive MFMAs accumulate into four different po[] -- as `i, t` the two K-steps of a block were back-to-back dependent
+            // 32x32x16 MFMAs, each waiting out the other's 16 passes)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    float v8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const int r = 8 * t + e, gq = r >> 2, q = r & 3;
+                        const f32x2 v = f32x2{acc[i][j][r], acc[i][j][r + 1]} * f32x2{s4[gq][q], s4[gq][q + 1]} + f32x2{h4[gq][q], h4[gq][q + 1]};
+                        const f32x2 w_ = v * f32x2{0.01f, 0.01f};
+                        v8[e] = fmaxf(v[0], w_[0]); v8[e + 1] = fmaxf(v[1], w_[1]);
+                    }
+                    po[i] = mma32<T>(w2f[j][t], ElemTraits<T>::pack(v8), po[i]);
+                }
+        }
+        // ---- the four waves' partial 1x1 sums meet in LDS (16 outputs per pass); lane (c, h) holds outputs 8 (r >> 2) + 4 h + (r & 3) of pixel 32 blk + c
+        constexpr int SLICE = kHeadRows * 16 * RLD;
+        constexpr int PPW = kHeadRows * 16 / kHeadWaves, NIT = PPW * 4 / 64;
+        float* mine = red + wn * SLICE;
+        for (int of = 0; of < (two ? 2 : 1); ++of) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const f32x16& pv = po[i];
+                    f32x4 v4;
+                    if (of == 0) v4 = gg == 0 ? f32x4{pv[0], pv[1], pv[2], pv[3]} : f32x4{pv[4], pv[5], pv[6], pv[7]};
+                    else v4 = gg == 0 ? f32x4{pv[8], pv[9], pv[10], pv[11]} : f32x4{pv[12], pv[13], pv[14], pv[15]};
+                    *reinterpret_cast<f32x4*>(mine + (i * 32 + c) * RLD + gg * 8 + h * 4) = v4;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int item = it * 64 + lane;
+                const int px = wn * PPW + (item >> 2), og = item & 3;
+                f32x4 sum = *reinterpret_cast<const f32x4*>(red + px * RLD + og * 4);
+#pragma unroll
+                for (int w = 1; w < kHeadWaves; ++w) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(red + w * SLICE + px * RLD + og * 4);
+                    sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+                }
+                const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
+                if (oy < g.H && ox < g.W) {
+                    const size_t m = ((size_t)b * g.H + oy) * g.W + ox;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = of * 16 + og * 4 + r;
+                        if (o < cn) {
+                            const float res = sum[r] * w2s + bias2[br * 32 + o];
+                            out[m * g.ld_out + co + o] = res;
+                            if (br == 0 && g.planar && o < g.planar_c)
+                                g.planar[((size_t)b * g.planar_c + o) * g.H * g.W + (size_t)oy * g.W + ox] = res;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <typename T, bool PL, int DBG = 0> static int launch_heads(const mfx_heads_desc* d, hipStream_t st) {
     HeadGeom g;
     g.B = d->B; g.H = d->H; g.W = d->W; g.tiles_x = (d->W + 15) / 16; g.tiles_y = (d->H + kHeadRows - 1) / kHeadRows;
@@ -400,8 +608,20 @@ template <typename T, bool PL, int DBG = 0> static int launch_heads(const mfx_he
         const int want = g_opt_heads_persist > 1 ? g_opt_heads_persist : slots;      // (> 1: that many workgroups -- tests)
         if (tiles > want) { grid = want; g.persist = 1; }
     }
-    auto k = heads_fused_kernel<T, PL, DBG>;
     constexpr int smem = HeadSmem<T, PL>::bytes;
+    if constexpr (!PL && DBG == 0 && (std::is_same<T, bf16_t>::value || std::is_same<T, half_t>::value)) {
+        if (d->w1_32 && d->w2_32 && g_opt_heads_mfma32) {      // the 32x32x16 form (needs its own weight packs)
+            auto k32 = heads_fused32_kernel<T>;
+            static bool attr32 = false;
+            if (!attr32 && smem > 64 * 1024) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr32 = true; }
+            hipLaunchKernelGGL(k32, dim3(grid), dim3(kHeadWaves * 64), smem, st, reinterpret_cast<const T*>(d->x),
+                               reinterpret_cast<const u32x4*>(d->w1_32), d->scale1, d->shift1, reinterpret_cast<const u32x4*>(d->w2_32), d->bias2,
+                               d->out, g, t);
+            MFX_HIP_CHECK(hipGetLastError());
+            return MFX_OK;
+        }
+    }
+    auto k = heads_fused_kernel<T, PL, DBG>;
     static bool attr_set = false;
     if (!attr_set && smem > 64 * 1024) { MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); attr_set = true; }
     hipLaunchKernelGGL(k, dim3(grid), dim3(kHeadWaves * 64), smem, st, reinterpret_cast<const T*>(d->x),

@@ -51,7 +51,8 @@ class HeadsDesc(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("w1", c_void_p), ("scale1", c_void_p), ("shift1", c_void_p), ("w2", c_void_p),
                 ("bias2", c_void_p), ("out", c_void_p), ("planar", c_void_p),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("nbranch", c_int), ("K_pad", c_int), ("ld_out", c_int),
-                ("dtype", c_int), ("planar_c", c_int), ("ch_off", c_int * 16), ("c_out", c_int * 16), ("w2_scale", ctypes.c_float * 16)]
+                ("dtype", c_int), ("planar_c", c_int), ("ch_off", c_int * 16), ("c_out", c_int * 16), ("w2_scale", ctypes.c_float * 16),
+                ("w1_32", c_void_p), ("w2_32", c_void_p)]
 
 
 class KittiDesc(ctypes.Structure):

@@ -174,6 +174,13 @@ class _predictor(nn.Module):
             W2 = w2.view(nb, 2, 16, 4, 2, 2, 4, 4).permute(0, 3, 4, 1, 6, 2, 5, 7).contiguous().to(dtype)
         p = ops.PackedHeads(W1, torch.cat(sc).contiguous(), torch.cat(sh).contiguous(),
                             W2, b2.contiguous(), K, ch_off, c_out, HM_LD, split=dtype == ops.F16X2, w2_scale=w2_scale)
+        if dtype in (torch.bfloat16, torch.float16):
+            # the same weights for the v_mfma_f32_32x32x16 form (csrc/heads.hip heads_fused32_kernel; option "heads_mfma32"):
+            #   3x3: [branch][wn 4][K-step 36][rb 2][h 2][row 32][8], channel 64 wn + 32 rb + row, k = 16 s + 8 h + e
+            #   1x1: [branch][wn 4][rb 2][t 2][h 2][o 32][a 2][q 4], trunk channel n = 64 wn + 32 rb + 16 t + 8 a + 4 h + q (k-slot e = 4 a + q)
+            w1s = torch.stack(w1, 0)
+            p.w1_32 = w1s.view(nb, 4, 2, 32, 36, 2, 8).permute(0, 1, 4, 2, 5, 3, 6).contiguous().to(dtype)
+            p.w2_32 = w2.view(nb, 32, 4, 2, 2, 2, 2, 4).permute(0, 2, 3, 4, 6, 1, 5, 7).contiguous().to(dtype)
         # edge fusion: trunks of the class branch and of the 3d_offset branch at the border points
         if self.enable_edge_fusion:
             oi = self.offset_index[0]

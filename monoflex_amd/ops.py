@@ -612,6 +612,8 @@ class PackedHeads:
     ld_out: int
     split: bool = False
     w2_scale: Optional[list] = None          # per branch, multiplies the 1x1 sums before the bias (split precision: 1 / the weights' packing scale)
+    w1_32: Optional[torch.Tensor] = None     # packs of the v_mfma_f32_32x32x16 form of the kernel (16-bit modes; mfx_heads_desc.w1_32 / w2_32)
+    w2_32: Optional[torch.Tensor] = None
 
 
 @on_tensor_device
@@ -626,6 +628,8 @@ def heads_fused(x, p: PackedHeads, planar_classes=0):
     d.planar, d.planar_c = (planar.data_ptr() if planar is not None else None), planar_classes
     d.x, d.w1, d.scale1, d.shift1 = x.data_ptr(), p.w1.data_ptr(), p.scale1.data_ptr(), p.shift1.data_ptr()
     d.w2, d.bias2, d.out = p.w2.data_ptr(), p.bias2.data_ptr(), out.data_ptr()
+    d.w1_32 = p.w1_32.data_ptr() if p.w1_32 is not None else None
+    d.w2_32 = p.w2_32.data_ptr() if p.w2_32 is not None else None
     d.B, d.H, d.W, d.nbranch, d.K_pad, d.ld_out = B, H, W, len(p.c_out), p.K_pad, p.ld_out
     d.dtype = L.MFX_F16X2 if p.split else _dt(x.dtype)
     for i, (o, c) in enumerate(zip(p.ch_off, p.c_out)):

@@ -152,16 +152,20 @@ def checksum(t):
                 idx=idx.numpy(), samples=t[idx].float().numpy(), shape=np.array(list(t.shape)))
 
 
-MIN_GAP = 1e-4      # smallest allowed distance between neighbours among the top-51 reference scores of a full-size golden image
+MIN_GAP = 4e-4      # smallest allowed distance, in LOGIT units, between neighbours among the top-51 reference peaks of a full-size golden image
+                    # (= 1e-4 in score units at sigmoid's steepest point, the bar VERDICT r5 item 4 names; in logit units it also applies to the
+                    # default-bias image, whose scores live near 0.01 where the sigmoid is 25 x flatter)
 
 
 def top_gap(logits, k=51):
-    """Smallest gap between consecutive scores among the k best peaks of the reference's NMS-ed heat map (model/layers/utils.py:39-58: sigmoid, clamp,
-    3x3 max-pool, `hmax == heat`).  k = 51: the 50 detections plus the first one left out -- a near-tie at the cut changes the SET, not only the order."""
+    """Smallest gap between consecutive peaks among the k best of the reference's NMS-ed heat map (model/layers/utils.py:39-58: sigmoid, clamp,
+    3x3 max-pool, `hmax == heat`), in logit units (score gap / s(1 - s)).  k = 51: the 50 detections plus the first one left out -- a near-tie at the
+    cut changes the SET, not only the order.  The HIP path's fp32-grade modes reproduce the reference's logits to ~2.5e-5: a 4e-4 gap is 16 x that."""
     heat = torch.clamp(torch.sigmoid(logits.float()), min=1e-4, max=1 - 1e-4)
     hmax = torch.nn.functional.max_pool2d(heat[None], 3, 1, 1)[0]
-    sc = torch.topk((heat * (hmax == heat).float()).flatten(), k).values
-    return float((sc[:-1] - sc[1:]).min())
+    sc = torch.topk((heat * (hmax == heat).float()).flatten(), k).values.double()
+    mid = 0.5 * (sc[:-1] + sc[1:])
+    return float(((sc[:-1] - sc[1:]) / (mid * (1 - mid))).min())
 
 
 def run_case(name, out_w, out_h, seeds, cls_bias, store_full, n_images=None):
@@ -206,7 +210,7 @@ def run_case(name, out_w, out_h, seeds, cls_bias, store_full, n_images=None):
         if n_images is not None:
             gap = top_gap(rec["cls_logits"][0])
             if gap < MIN_GAP:
-                print(name, "seed", seed, "rejected: smallest gap among the top-51 reference scores %.2e < %.0e" % (gap, MIN_GAP))
+                print(name, "seed", seed, "rejected: smallest logit gap among the top-51 reference peaks %.2e < %.0e" % (gap, MIN_GAP))
                 continue
             out["img%d_top51_min_gap" % len(kept)] = np.array(gap)
         kept.append(seed)
@@ -241,7 +245,7 @@ def run_case(name, out_w, out_h, seeds, cls_bias, store_full, n_images=None):
     meta["seeds"] = [int(s_) for s_ in kept]
     if n_images is not None:
         assert len(kept) == n_images, "candidate seeds exhausted"
-        meta["min_gap_top51"] = MIN_GAP
+        meta["min_logit_gap_top51"] = MIN_GAP
     out["meta"] = np.array(repr(meta))
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 
@@ -670,5 +674,5 @@ if __name__ == "__main__":
     if "full" in which:
         # BASELINE configs[0]'s four seeded images (1000 ..; a seed whose top-51 scores hold a near-tie is skipped) and one image at the
         # reference's default class bias -log(1/0.01 - 1) (detector_predictor.py:43: nothing passes the 0.2 threshold there -- the zero-detection path at full size)
-        run_case("e2e_full", 320, 96, seeds=range(1000, 1040), cls_bias=-1.0, store_full=False, n_images=4)
-        run_case("e2e_full_default_bias", 320, 96, seeds=range(1000, 1040), cls_bias=-float(np.log(1 / 0.01 - 1)), store_full=False, n_images=1)
+        run_case("e2e_full", 320, 96, seeds=range(1000, 1400), cls_bias=-1.0, store_full=False, n_images=4)
+        run_case("e2e_full_default_bias", 320, 96, seeds=range(1000, 1400), cls_bias=-float(np.log(1 / 0.01 - 1)), store_full=False, n_images=1)

@@ -81,20 +81,20 @@ def _stage_errors(g, n, stages, image=0):
     return errs
 
 
-def _same_ranking(mine, ref, ref_scores, tie_tol):
-    """`mine` is the reference's top-K ranking `ref`, up to permutations among entries whose REFERENCE scores lie within `tie_tol` of each
-    other (tie_tol 0: the identical sequence).  The reference's own fp32 scores carry ~1e-5 of rounding noise; the full-size golden has one
-    pair (ranks 18/19) 1.7e-6 apart -- 29 ulp -- whose order is decided by the summation order of a 50-layer fp32 network, not by the
-    detector: every tile shape / batch size / MFMA type rounds that pair its own way."""
-    if np.array_equal(mine, ref):
-        return True
-    if tie_tol <= 0 or sorted(mine.tolist()) != sorted(ref.tolist()):
-        return False
-    score_of = {int(i): float(s) for i, s in zip(ref, ref_scores)}              # (keys: class * 2^20 + pixel index -- unique per peak)
-    return all(abs(score_of[int(m)] - float(s)) <= tie_tol for m, s in zip(mine, ref_scores))
+def S_target():
+    from monoflex_amd import synthetic as S
+    return S.synthetic_target(320, 96)
 
 
-def _check_against_golden(g, n, meta, hm, topk, det, valid, full, tie_tol=0.0):
+def _golden_batch(meta, batch, height=384, width=1280):
+    """A batch whose first images are the golden's own (meta["seeds"], in order); the rest are fresh frames."""
+    from monoflex_amd import synthetic as S
+    seeds = list(meta["seeds"])[:batch]
+    seeds += [2000 + i for i in range(batch - len(seeds))]
+    return torch.cat([S.synthetic_images(1, height, width, seed=s_) for s_ in seeds]), min(batch, len(meta["seeds"]))
+
+
+def _check_against_golden(g, n, meta, hm, topk, det, valid, full):
     p = "img%d_" % n
     logits = hm[..., :3].permute(2, 0, 1)
     reg = hm[..., 8:58].permute(2, 0, 1)
@@ -106,18 +106,9 @@ def _check_against_golden(g, n, meta, hm, topk, det, valid, full, tie_tol=0.0):
         dl = np.abs(logits.reshape(3, -1)[:, pix].numpy() - g[p + "cls_logits_at"]).max()
         dr = np.abs(reg.reshape(50, -1)[:, pix].numpy() - g[p + "reg_at"]).max()
     assert dl <= 1e-3 and dr <= 1e-3, "logits differ from the reference by %.3e / %.3e (bar 1e-3)" % (dl, dr)
-    mine = topk[:, 1].numpy().astype(np.int64)
-    if tie_tol <= 0:
-        assert np.array_equal(mine, g[p + "topk_index"]), "top-K indices differ"
-    else:
-        # a peak = (class, pixel): the same pixel can rank for two classes
-        mk = topk[:, 2].numpy().astype(np.int64) * (1 << 20) + mine
-        rk = g[p + "topk_cls"].astype(np.int64) * (1 << 20) + g[p + "topk_index"].astype(np.int64)
-        assert _same_ranking(mk, rk, g[p + "topk_scores"], tie_tol), "top-K indices differ"
-        # (rows below are compared in the reference's order: a near-tie swap permutes two rows, nothing else)
-        order = np.array([int(np.nonzero(mk == k)[0][0]) for k in rk])
-        topk, det, valid = topk[order], det[order], valid[order]
-    assert np.array_equal(topk[:, 1].numpy().astype(np.int64), g[p + "topk_index"])
+    # the identical SEQUENCE of peaks, at every batch size and in every parity mode: the full-size goldens hold no pair of peaks closer than 4e-4 in
+    # logit units among their top 51 (oracle/gen_golden.py MIN_GAP; r05's fixture had a 1.7e-6 pair and this check a tolerance for it)
+    assert np.array_equal(topk[:, 1].numpy().astype(np.int64), g[p + "topk_index"]), "top-K indices differ"
     assert np.array_equal(topk[:, 2].numpy(), g[p + "topk_cls"])
     assert np.array_equal(topk[:, 3].numpy(), g[p + "topk_ys"]) and np.array_equal(topk[:, 4].numpy(), g[p + "topk_xs"])
     assert np.abs(topk[:, 0].numpy() - g[p + "topk_scores"]).max() < 1e-4
@@ -125,11 +116,6 @@ def _check_against_golden(g, n, meta, hm, topk, det, valid, full, tie_tol=0.0):
     assert res.shape == g[p + "result"].shape
     assert np.allclose(res, g[p + "result"], rtol=2e-3, atol=2e-2), np.abs(res - g[p + "result"]).max()
     return dl, dr
-
-
-# ranks whose reference scores are closer than this may come out in either order at shapes other than the golden's own B = 1 run
-# (see _same_ranking; the next-closest pair of the full-size golden is 3.0e-5 apart)
-TIE_TOL = 5e-6
 
 
 # the two modes that carry the north-star gate (<= 1e-3 on logits, identical top-K): "fp32" = f32 MFMA, "fp16x2" = fp32 activations with
@@ -154,50 +140,64 @@ def test_e2e_small_vs_reference_golden_fp32(mode):
         assert len(errs) == 11 and all(e[0] <= 2e-4 and e[1] <= 1e-4 for e in errs.values()), errs
 
 
-@pytest.mark.parametrize("mode,batch", [("fp32", 1), ("fp16x2", 1), ("fp16x2", 8)])
+@pytest.mark.parametrize("mode,batch", [("fp32", 1), ("fp32", 8), ("fp16x2", 1), ("fp16x2", 8)])
 def test_e2e_full_vs_reference_golden_fp32(mode, batch):
-    """Full-size frame against the reference's goldens; ("fp16x2", 8) is the benchmarked shape of the split-precision mode (B=8; image 0
-    of the batch is the golden image) under the SAME gate as fp32: logits <= 1e-3, identical top-K, rows, 11 stage goldens."""
-    from monoflex_amd import synthetic as S
+    """Full-size frames against the reference's goldens (BASELINE configs[0]'s four seeded images): every golden image in the batch
+    (one at B = 1, all four at B = 8 -- the benchmarked shape) under the same gate in both parity modes: logits <= 1e-3, the IDENTICAL top-K
+    sequence, (N, 14) rows, 11 stage goldens."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_full.npz"))
     meta = ast.literal_eval(str(g["meta"]))
     m = _hip_model(meta["cls_bias"], mode)
-    imgs = S.synthetic_images(batch, 384, 1280, seed=meta["seeds"][0])
-    det, topk, valid, hm = _run(m, imgs, [S.synthetic_target(320, 96)] * batch)
-    # fp32 at B = 1 is the golden's own configuration: the identical sequence.  Every other shape / MFMA type may order the one 1.7e-6 pair
-    # of the reference's own scores either way (see _same_ranking)
-    tie_tol = 0.0 if (mode == "fp32" and batch == 1) else TIE_TOL
-    identical = bool(np.array_equal(topk[0][:, 1].numpy().astype(np.int64), g["img0_topk_index"]))
-    dl, dr = _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False, tie_tol=tie_tol)
-    errs = _stage_errors(g, 0, _stages(m, imgs))
-    print("full-size %s B=%d vs reference: max |dlogit| %.2e, max |dreg| %.2e; stages %s" % (
-        mode, batch, dl, dr, {k: "%.1e/%.1e" % v for k, v in errs.items()}))
+    imgs, ngold = _golden_batch(meta, batch)
+    det, topk, valid, hm = _run(m, imgs, [S_target()] * batch)
+    stages = _stages(m, imgs)
+    worst = {"dl": 0.0, "dr": 0.0}
+    for n in range(ngold):
+        assert float(g["img%d_top51_min_gap" % n]) >= 4e-4                 # the fixture's own property (logit units)
+        dl, dr = _check_against_golden(g, n, meta, hm[n], topk[n], det[n], valid[n], full=False)
+        worst["dl"], worst["dr"] = max(worst["dl"], float(dl)), max(worst["dr"], float(dr))
+        errs = _stage_errors(g, n, stages, image=n)
+        assert len(errs) == 11 and all(e[0] <= 2e-4 and e[1] <= 1e-4 for e in errs.values()), (n, errs)
+        pix = torch.as_tensor(g["img%d_pix" % n])
+        feat = stages["feature"][n].float().permute(2, 0, 1).reshape(64, -1)[:, pix].cpu().numpy()
+        assert np.abs(feat - g["img%d_feature_at" % n]).max() <= 2e-4 * max(1.0, np.abs(g["img%d_feature_at" % n]).max())
+    print("full-size %s B=%d vs reference (%d golden images): max |dlogit| %.2e, max |dreg| %.2e" % (mode, batch, ngold, worst["dl"], worst["dr"]))
     if mode == "fp16x2":
         from monoflex_amd import lib as L_
         assert L_.f16x2_range_ok(), "an activation left fp16's range on its way into an MFMA operand pair"      # the mode's one precondition
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "fp16x2_b%d_vs_reference.json" % batch), "w") as f:
-            json.dump({"shape": "B=%d, 1280x384, fp16x2 (split-precision MFMA operands, fp32 activations)" % batch, "max_abs_dlogit": float(dl),
-                       "max_abs_dreg": float(dr), "topk_identical": True if identical else "up to reference-side ties <= %g" % TIE_TOL, "stage_sample_rel_err": {k: v[0] for k, v in errs.items()},
-                       "stage_abssum_rel_err": {k: v[1] for k, v in errs.items()}}, f, indent=1, sort_keys=True)
-    assert len(errs) == 11 and all(e[0] <= 2e-4 and e[1] <= 1e-4 for e in errs.values()), errs
-    pix = torch.as_tensor(g["img0_pix"])
-    feat = _stages(m, imgs)["feature"][0].float().permute(2, 0, 1).reshape(64, -1)[:, pix].cpu().numpy()
-    assert np.abs(feat - g["img0_feature_at"]).max() <= 2e-4 * max(1.0, np.abs(g["img0_feature_at"]).max())
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "%s_b%d_vs_reference.json" % (mode, batch)), "w") as f:
+        json.dump({"shape": "B=%d, 1280x384, %s; golden images %s of tests/golden/e2e_full.npz" % (batch, mode, meta["seeds"][:ngold]),
+                   "max_abs_dlogit": worst["dl"], "max_abs_dreg": worst["dr"], "topk_identical_sequence": True, "golden_images_checked": ngold},
+                  f, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("mode", PARITY_MODES)
+def test_e2e_full_default_class_bias_vs_reference_golden(mode):
+    """the reference's DEFAULT class bias -log(1/0.01 - 1) (detector_predictor.py:43) at full size -- scores near 0.01, three peaks
+    above the 0.2 detection threshold: the partial-detection path (detector_infer.py:106-113) on a real frame, identical top-K sequence included."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_full_default_bias.npz"))
+    meta = ast.literal_eval(str(g["meta"]))
+    assert abs(meta["cls_bias"] + 4.59512) < 1e-4 and 0 < g["img0_result"].shape[0] < 50
+    m = _hip_model(meta["cls_bias"], mode)
+    imgs, _ = _golden_batch(meta, 1)
+    det, topk, valid, hm = _run(m, imgs, [S_target()])
+    _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False)
 
 
 @pytest.mark.parametrize("mode", PARITY_MODES)
 def test_c5_batch32_hipgraph_fp32_rows_equal_reference_golden(mode):
     """BASELINE configs[4] per-GPU shape: batch 32 captured in ONE hipGraph (DLA + DCN + heads + top-K + decode), replayed;
-    image 0 of the batch is the golden image: logits <= 1e-3, identical top-K, (N,14) rows -- the batched, graphed decode
-    equals the reference's batch-1 eager decode.  Two further images of the batch are checked against their own B=1 run."""
+    images 0-3 of the batch are the four golden images: logits <= 1e-3, identical top-K sequence, (N,14) rows -- the batched, graphed
+    decode equals the reference's batch-1 eager decode.  Two further images of the batch are checked against their own B=1 run."""
     from monoflex_amd import synthetic as S
     from monoflex_amd.structures.params_3d import make_test_target
     g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_full.npz"))
     meta = ast.literal_eval(str(g["meta"]))
     m = _hip_model(meta["cls_bias"], mode)
     B = 32
-    imgs = S.synthetic_images(B, 384, 1280, seed=meta["seeds"][0]).to(DEV)
+    imgs, ngold = _golden_batch(meta, B)
+    imgs = imgs.to(DEV)
     tg = m.device_targets([make_test_target(S.synthetic_target(320, 96)) for _ in range(B)], DEV)
     with torch.no_grad():
         side = torch.cuda.Stream()
@@ -212,7 +212,8 @@ def test_c5_batch32_hipgraph_fp32_rows_equal_reference_golden(mode):
         graph.replay(); graph.replay()
     torch.cuda.synchronize()
     det, topk, valid, hm = [t.cpu() for t in out]
-    _check_against_golden(g, 0, meta, hm[0], topk[0], det[0], valid[0], full=False, tie_tol=TIE_TOL)
+    for n in range(ngold):                                   # all four golden images, the identical top-K sequence included
+        _check_against_golden(g, n, meta, hm[n], topk[n], det[n], valid[n], full=False)
     for n in (13, 31):
         d1, t1, v1, h1 = _run(m, imgs[n:n + 1].cpu(), [S.synthetic_target(320, 96)])
         assert torch.equal(topk[n][:, 1], t1[0][:, 1]) and torch.equal(valid[n], v1[0])
@@ -245,7 +246,7 @@ def _perf_mode_vs_reference(dtype, stage_bound, abssum_bound, dlogit_bound, dreg
     g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_full.npz"))
     meta = ast.literal_eval(str(g["meta"]))
     m = _hip_model(meta["cls_bias"], dtype)
-    imgs = S.synthetic_images(8, 384, 1280, seed=meta["seeds"][0])
+    imgs, _ = _golden_batch(meta, 8)
     tgts = [S.synthetic_target(320, 96)] * 8
     det, topk, valid, hm = _run(m, imgs, tgts)
     errs = _stage_errors(g, 0, _stages(m, imgs))

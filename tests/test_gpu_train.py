@@ -702,8 +702,9 @@ def _full_size_rows(gdev, gref):
     return rows
 
 
+@pytest.mark.parametrize("det", [False, True])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_full_size_training_step_vs_oracle(dtype):
+def test_full_size_training_step_vs_oracle(dtype, det):
     """`model(images, targets)` + backward at the benchmarked size (B = 2, 1280 x 384) against the oracle network in fp32 (CPU,
     train-mode BN, C restatement of the reference DCN backward) with the same loss module on the same inputs.
 
@@ -726,20 +727,27 @@ def test_full_size_training_step_vs_oracle(dtype):
     el = torch.as_tensor([int(t["edge_len"]) for t in tg])
     lib_ = L.load()
     fused0 = lib_.mfx_get_counter(b"dcn_bt_fused")
-    loss_dict, _ = m(imgs.to(DEV), [t.to(DEV) for t in targets])
-    sum(loss_dict.values()).backward()
-    torch.cuda.synchronize()
-    assert lib_.mfx_get_counter(b"dcn_bt_fused") - fused0 == (5 if dtype == "bf16" else 0)
+    # det: the library's fixed-order reductions (lib.set_deterministic) -- the run-to-run spread of the atomics is gone, so the ORIGINAL bounds of
+    # this test (0.28 / 0.997, loosened in r04 to 0.45 / 0.995 for that spread) hold again and are asserted in this mode
+    L.set_deterministic(det)
+    try:
+        loss_dict, _ = m(imgs.to(DEV), [t.to(DEV) for t in targets])
+        sum(loss_dict.values()).backward()
+        torch.cuda.synchronize()
+    finally:
+        L.set_deterministic(False)
+    if not det:
+        assert lib_.mfx_get_counter(b"dcn_bt_fused") - fused0 == (5 if dtype == "bf16" else 0)
     om = ref.forward_maps(imgs, ei, el)
     want, _ = m.heads.loss_evaluator(om, targets)
     assert set(loss_dict) == set(want) and len(want) == 11
     worst_loss = max(abs(float(loss_dict[k]) - float(want[k])) / max(1.0, abs(float(want[k]))) for k in want)
-    print("full-size %s step vs oracle: worst relative loss deviation %.3e" % (dtype, worst_loss),
+    print("full-size %s step vs oracle (deterministic %s): worst relative loss deviation %.3e" % (dtype, det, worst_loss),
           {k: (round(float(loss_dict[k]), 5), round(float(want[k]), 5)) for k in want})
     # bf16: a randomly initialised DLA-34 under batch-statistics BN amplifies rounding differences from level to level, and the
     # BN statistics are summed with atomics, so the figure moves from run to run: 0.14 ... 0.33 observed over repeated runs on MI355X (r03 / r04;
     # one loss term sits on a kink); the layer-by-layer test (test_gpu_train_fullsize.py) is where the 16-bit arithmetic is pinned
-    assert worst_loss < (3e-4 if dtype == "fp32" else 0.45), worst_loss
+    assert worst_loss < (3e-4 if dtype == "fp32" else (0.28 if det else 0.45)), worst_loss
     if dtype == "bf16":
         assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
         return
@@ -748,7 +756,7 @@ def test_full_size_training_step_vs_oracle(dtype):
     for r in rows:
         print("   %-70s cos %.5f  rel %.3e" % r)
     assert len(rows) >= 29
-    assert min(r[1] for r in rows) > 0.995, min(rows, key=lambda r: r[1])      # (0.9962 ... 0.9988 over repeated runs: atomics' summation order)
+    assert min(r[1] for r in rows) > (0.997 if det else 0.995), min(rows, key=lambda r: r[1])      # (0.9962 ... 0.9988 over repeated runs without `det`: atomics' summation order)
     assert max(r[2] for r in rows) < 0.1, max(rows, key=lambda r: r[2])
 
 
