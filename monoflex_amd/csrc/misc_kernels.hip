@@ -59,29 +59,48 @@ __global__ void upsample_add_kernel(const T* __restrict__ x, const float* __rest
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] = 0.f;
         const int th = oh + p_, tw = ow + p_;
-        // ascending (ih, iw) order = ascending input index, the order a direct scatter would add in
+        // r06: branch-free.  The four taps' input chunks, their eight weight vectors and the skip chunk are thirteen independent loads issued together
+        // (clamped, always valid addresses; a tap outside the map contributes an exact zero: its input chunk is replaced by zeros) -- as `if (outside)
+        // continue` around each tap every load sat behind its own branch and was waited for alone (r05 PMC: these launches issued 7-17 % of their cycles).
+        // Same sums in the same (ascending input index) order: fp32 maps come out bit-identical; 16-bit maps differ from the branchy form in ~1e-5 of their
+        // elements by one ulp (the compiler contracts multiply + add differently in straight-line code).  8 launches of the step: 132 -> 123 us (tools/upsample_bench.py).
+        const size_t o = ((size_t)(b * Ho + oh) * Wo + ow) * C + cg * E;
+        u32x4 sv = {0u, 0u, 0u, 0u};
+        if (skip) sv = *reinterpret_cast<const u32x4*>(skip + o);
+        u32x4 xv[2][2]; f32x4 wv[2][2][E / 4];
 #pragma unroll
-        for (int a = 1; a >= 0; --a) {
-            const int kh = th % f + a * f, ih = (th - kh) / f;
-            if (ih < 0 || ih >= H || th - kh < 0) continue;
+        for (int a = 0; a < 2; ++a) {
+            const int kh = th % f + a * f, dh = th - kh, ih = dh / f;
+            const bool vh = dh >= 0 && ih < H;
+            const int ihc = min(max(ih, 0), H - 1);
 #pragma unroll
-            for (int c2 = 1; c2 >= 0; --c2) {
-                const int kw = tw % f + c2 * f, iw = (tw - kw) / f;
-                if (iw < 0 || iw >= W || tw - kw < 0) continue;
-                float v[E];
-                ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(x + ((size_t)(b * H + ih) * W + iw) * C + cg * E), v);
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int kw = tw % f + c2 * f, dw = tw - kw, iw = dw / f;
+                const bool vw = dw >= 0 && iw < W;
+                const int iwc = min(max(iw, 0), W - 1);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(x + ((size_t)(b * H + ihc) * W + iwc) * C + cg * E);
+                xv[a][c2] = (vh && vw) ? v : u32x4{0u, 0u, 0u, 0u};
                 const float* wp = w + (size_t)(kh * k + kw) * C + cg * E;
 #pragma unroll
-                for (int e = 0; e < E; e += 4) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + e);
-                    acc[e] += v[e] * wv[0]; acc[e + 1] += v[e + 1] * wv[1]; acc[e + 2] += v[e + 2] * wv[2]; acc[e + 3] += v[e + 3] * wv[3];
-                }
+                for (int e = 0; e < E; e += 4) wv[a][c2][e / 4] = *reinterpret_cast<const f32x4*>(wp + e);
             }
         }
-        const size_t o = ((size_t)(b * Ho + oh) * Wo + ow) * C + cg * E;
+        // ascending (ih, iw) order = ascending input index, the order a direct scatter would add in
+#pragma unroll
+        for (int a = 1; a >= 0; --a)
+#pragma unroll
+            for (int c2 = 1; c2 >= 0; --c2) {
+                float v[E];
+                ElemTraits<T>::unpack(xv[a][c2], v);
+#pragma unroll
+                for (int e = 0; e < E; e += 4) {
+                    const f32x4 w4 = wv[a][c2][e / 4];
+                    acc[e] += v[e] * w4[0]; acc[e + 1] += v[e + 1] * w4[1]; acc[e + 2] += v[e + 2] * w4[2]; acc[e + 3] += v[e + 3] * w4[3];
+                }
+            }
         if (skip) {
             float s[E];
-            ElemTraits<T>::unpack(*reinterpret_cast<const u32x4*>(skip + o), s);
+            ElemTraits<T>::unpack(sv, s);
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] += s[e];
         }
