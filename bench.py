@@ -333,7 +333,10 @@ def run_infer(args, rank, world, device, dtype=None, leg=False):
     lib.load()
     model, sd, _ = build_model(dtype, device)
     B = args.batch
-    nstreams = args.streams if args.streams > 0 else (1 if dtype in ("bf16", "fp16") else 2)
+    # sub-batches on forked streams inside the one graph: 16-bit modes fill the chip from one 8-image stream (r05: 2.635 vs 2.680 ms; r06 kernels: 2.468 / 2.474
+    # vs 2.470 / 2.459 ms -- a wash), but at B = 32 two 16-image streams overlap one another's launch tails: 8.37 -> 7.83 ms (3825 -> 4085 img/s; four
+    # streams 7.99), profiles/r06_streams.md
+    nstreams = args.streams if args.streams > 0 else ((2 if B >= 16 else 1) if dtype in ("bf16", "fp16") else 2)
     images = bench_images(B, rank, device)                   # resident in HBM; rank 0: the golden frames first
     targets = [make_test_target(S.synthetic_target(320, 96)) for _ in range(B)]
     tg = model.device_targets(targets, device)

@@ -461,6 +461,286 @@ extern "C" int mfx_dcn_lds_probe_read(unsigned long long* host, int n) {
 namespace mfx {
 #endif
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Split precision (MFX_F16X2: fp32 maps, fp16 (hi, lo) MFMA operand pairs -- the mode that carries the north-star gate): the same kernel with an fp32
+// patch.  What changes against the 16-bit form above:
+//   * patch pixel = 16 channels x 4 bytes + 16 pad = 80 B; 8 x 16 tile grown by 8 = 24 x 32 pixels = 60 KB; the table holds (lh, lw, mask, base) as
+//     fp32 (16 bytes, ONE ds_read_b128 per fragment) -- fp16 blend weights would cap the result at 11 bits; 79 KB: two workgroups per CU;
+//   * a lane's 8 k-slots are 32 bytes per corner (two ds_read_b128); the four-corner blend runs in fp32 (v_pk_fma_f32), its result is split into
+//     hi = fp16(s), lo = fp16(s - hi) by common.h's lds_operand<f32s_t> (range sentinel included) and multiplied as hi.Whi + hi.Wlo + lo.Whi;
+//   * weights: w_pair_f16 / w_frag_f16 each hold TWO consecutive arrays -- the hi halves, then the lo halves of the weights times the pack's power-of-two
+//     scale (ops.split_weight_scale; the epilogue's `scale` already carries its inverse);
+//   * offsets come from the module's separate (split-precision) offset conv; no fused phase 0; the next slice's patch is loaded after the current one is
+//     consumed (no register prefetch: 12 chunks per thread would not fit next to two corner sets of 32 registers).
+// Reference arithmetic is fp32 (src/cuda/dcn_v2_cuda.cu:58); measured parity: tests/test_gpu_ops.py::test_dcn_lds_split_kernel_matches_the_fp32_kernel.
+template <int R>
+__global__ __launch_bounds__(256, 2) void dcn_lds_split_kernel(const float* __restrict__ x, const float* __restrict__ om, const u32x4* __restrict__ wpair,
+                                                              const u32x4* __restrict__ wfar, size_t pair_lo, size_t far_lo, DcnLGeom g, EpiArgs ep) {
+    constexpr int TR = 8, FM = 2, FN = 4, NPIX = TR * 16, OWN = 2, TPT = 5;
+    constexpr int PW = 16 + 2 * (R + 1), PH = TR + 2 * (R + 1), PB = 80, ROWB = PW * PB;
+    constexpr int patch_bytes = PW * PH * PB, NG = 9 * NPIX, GT_OFF = patch_bytes;       // table: 16-byte entries {lh, lw, mask, base}
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xl = lane & 15, kq = lane >> 4;
+
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = tile % g.tiles_x; tile /= g.tiles_x;
+    const int ty = tile % g.tiles_y, b = tile / g.tiles_y;
+    const int ty0 = ty * TR, tx0 = tx * 16;
+    const int py0 = ty0 - (R + 1), px0 = tx0 - (R + 1);
+    const float* xb = x + (size_t)b * g.H * g.W * g.C;
+    const char* xbb = reinterpret_cast<const char*>(xb);
+
+    const int oi = kq % FM, tg = kq / FM;
+    const int opix = (wv * FM + oi) * 16 + xl;
+    const int yo = ty0 + wv * FM + oi, xo = tx0 + xl;
+    const bool own_ok = yo < g.H && xo < g.W;
+
+    // patch chunks: 768 pixels x 4 chunks of 16 bytes per slice, 12 per thread: chunk idx = u*256 + tid: pixel idx >> 2, column idx & 3
+    constexpr int PU = PW * PH * 4 / 256;
+    static_assert(PW * PH * 4 % 256 == 0, "patch chunks per thread");
+    auto patch_load = [&](int sl) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x4 pr[PU / 2];
+#pragma unroll
+            for (int u = 0; u < PU / 2; ++u) {
+                const int idx = (half * (PU / 2) + u) * 256 + tid, p = idx >> 2, col = idx & 3;
+                const int ry = p / PW, rx = p - ry * PW;
+                const int gy = py0 + ry, gx = px0 + rx;
+                const bool in = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+                const int cy = min(max(gy, 0), g.H - 1), cx = min(max(gx, 0), g.W - 1);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(xbb + (uint32_t)(((cy * g.W + cx) * g.C + sl * 16 + col * 4) * 4));
+                pr[u] = in ? v : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < PU / 2; ++u) {
+                const int idx = (half * (PU / 2) + u) * 256 + tid;
+                *reinterpret_cast<u32x4*>(smem + (idx >> 2) * PB + (idx & 3) * 16) = pr[u];
+            }
+        }
+    };
+
+    // ---- phase G: geometry of this lane's taps -> table
+    {
+        const float* r = om + ((size_t)(b * g.H + min(yo, g.H - 1)) * g.W + min(xo, g.W - 1)) * 32;
+        const int tap0 = TPT * tg;
+        float odh[TPT], odw[TPT], omk[TPT];
+#pragma unroll
+        for (int tt = 0; tt < TPT; ++tt) {
+            const int tap = min(tap0 + tt, 8);
+            odh[tt] = r[2 * tap]; odw[tt] = r[2 * tap + 1]; omk[tt] = r[18 + tap];
+        }
+        patch_load(0);
+#pragma unroll
+        for (int tt = 0; tt < TPT; ++tt) {
+            const int tap = tap0 + tt;
+            const bool has = tap < 9;
+            const float mk = (own_ok && has) ? omk[tt] : 0.f;
+            const int th = tap / 3, tw = tap - th * 3;
+            const float h = (float)(yo - 1 + th) + odh[tt], w = (float)(xo - 1 + tw) + odw[tt];
+            const bool inside = h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
+            const float hf = floorf(h), wf_ = floorf(w);
+            const float m_ = inside ? mk : 0.f;
+            const int h0 = (int)fminf(fmaxf(hf, -24.f), 30000.f), w0 = (int)fminf(fmaxf(wf_, -24.f), 30000.f);
+            const int ry = h0 - py0, rx = w0 - px0;
+            const bool in_patch = ry >= 0 && ry + 1 < PH && rx >= 0 && rx + 1 < PW;
+            const bool far = m_ != 0.f && !in_patch;
+            uint32_t base = in_patch ? (uint32_t)((ry * PW + rx) * PB) : 0u;
+            if (far) base = 0x80000000u | (uint32_t)(h0 + 32) | ((uint32_t)(w0 + 32) << 16);
+            // the mask of a far sample is stored NEGATED: the loop clamps it to zero, the far pass takes its magnitude
+            if (has) *reinterpret_cast<f32x4*>(smem + GT_OFF + (tap * NPIX + opix) * 16) = f32x4{h - hf, w - wf_, far ? -m_ : m_, __uint_as_float(base)};
+        }
+        if (tid < FM) *reinterpret_cast<f32x4*>(smem + GT_OFF + (NG + 16 * tid) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    unsigned long long farm[TPT];
+    __syncthreads();
+    {   // far masks from the table (the ballot needs every lane's own entries: re-read them -- after the barrier they are all there)
+#pragma unroll
+        for (int tt = 0; tt < TPT; ++tt) {
+            const int tap = TPT * tg + tt;
+            const float mk = tap < 9 ? reinterpret_cast<const float*>(smem + GT_OFF + (min(tap, 8) * NPIX + opix) * 16)[2] : 0.f;
+            farm[tt] = __builtin_amdgcn_ballot_w64(mk < 0.f);
+        }
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int gent = (kq >> 1) * NPIX + wv * (FM * 16) + xl;
+    const int gt_a = GT_OFF + gent * 16;
+    const int gt_z = (kq >> 1) ? GT_OFF + (NG - 8 * NPIX) * 16 : gt_a;
+    const int ccol = (kq & 1) * 32;
+    const u32x4* wph = wpair + lane;
+    const u32x4* wpl = wpair + pair_lo + lane;
+    auto wfetch = [&](int step, u32x4 (&wh)[FN], u32x4 (&wl)[FN]) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { wh[j] = wph[((size_t)j * g.fsteps_pair + step) * 64]; wl[j] = wpl[((size_t)j * g.fsteps_pair + step) * 64]; }
+    };
+    u32x4 wqh[2][FN], wql[2][FN];
+    wfetch(0, wqh[0], wql[0]);
+
+    constexpr int NF = 5 * FM;
+    for (int sl = 0; sl < g.nslice; ++sl) {
+        f32x4 gv[3];
+        u32x4 cv[2][4][2];
+        auto geo_read = [&](int f, int slot) {
+            const int j = f / FM, i = f % FM;
+            gv[slot] = j < 4 ? *reinterpret_cast<const f32x4*>(smem + gt_a + (2 * NPIX * j + 16 * i) * 16)
+                             : *reinterpret_cast<const f32x4*>(smem + gt_z + (8 * NPIX + 16 * i) * 16);
+        };
+        auto corner_read = [&](int slot_g, int slot_c) {
+            const int base = max((int)__float_as_uint(gv[slot_g][3]), 0) + ccol;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cv[slot_c][q][0] = *reinterpret_cast<const u32x4*>(smem + base + (q >> 1) * ROWB + (q & 1) * PB);
+                cv[slot_c][q][1] = *reinterpret_cast<const u32x4*>(smem + base + (q >> 1) * ROWB + (q & 1) * PB + 16);
+            }
+        };
+        // fp32 blend of the lane's 8 k-slots, then the (hi, lo) split: -> the two MFMA A operands
+        auto blend = [&](int slot_g, int slot_c, u32x4& ah, u32x4& al) {
+            const float lh = gv[slot_g][0], lw = gv[slot_g][1], m_ = fmaxf(gv[slot_g][2], 0.f);
+            const float hh = 1.f - lh, hw_ = 1.f - lw;
+            const float w0 = hh * hw_ * m_, w1 = hh * lw * m_, w2 = lh * hw_ * m_, w3 = lh * lw * m_;
+            u32x4 sp[2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    f32x2 t = f32x2{__uint_as_float(cv[slot_c][0][c2][e]), __uint_as_float(cv[slot_c][0][c2][e + 1])} * w0;
+                    t = __builtin_elementwise_fma(f32x2{__uint_as_float(cv[slot_c][1][c2][e]), __uint_as_float(cv[slot_c][1][c2][e + 1])}, f32x2{w1, w1}, t);
+                    t = __builtin_elementwise_fma(f32x2{__uint_as_float(cv[slot_c][2][c2][e]), __uint_as_float(cv[slot_c][2][c2][e + 1])}, f32x2{w2, w2}, t);
+                    t = __builtin_elementwise_fma(f32x2{__uint_as_float(cv[slot_c][3][c2][e]), __uint_as_float(cv[slot_c][3][c2][e + 1])}, f32x2{w3, w3}, t);
+                    o[e] = t[0]; o[e + 1] = t[1];
+                }
+                sp[c2] = lds_operand<f32s_t>(ElemTraits<float>::pack(o));       // [h0 h1 | h2 h3 | l0 l1 | l2 l3]
+            }
+            ah = u32x4{sp[0].x, sp[0].y, sp[1].x, sp[1].y};
+            al = u32x4{sp[0].z, sp[0].w, sp[1].z, sp[1].w};
+        };
+        geo_read(0, 0);
+        geo_read(1, 1);
+        corner_read(0, 0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int j = f / FM, i = f % FM;
+            if (i == 0) wfetch(min(sl * 5 + j + 1, g.fsteps_pair - 1), wqh[(j + 1) & 1], wql[(j + 1) & 1]);
+            if (f + 2 < NF) geo_read(f + 2, (f + 2) % 3);
+            if (f + 1 < NF) corner_read((f + 1) % 3, (f + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 ah, al;
+            blend(f % 3, f & 1, ah, al);
+#pragma unroll
+            for (int n = 0; n < FN; ++n) {
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lh8_t, ah), __builtin_bit_cast(lh8_t, wqh[j & 1][n]), acc[i][n], 0, 0, 0);
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lh8_t, ah), __builtin_bit_cast(lh8_t, wql[j & 1][n]), acc[i][n], 0, 0, 0);
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lh8_t, al), __builtin_bit_cast(lh8_t, wqh[j & 1][n]), acc[i][n], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int n = 0; n < FN; ++n) { wqh[0][n] = wqh[1][n]; wql[0][n] = wql[1][n]; }
+        __syncthreads();                                      // every wave is done with this slice's patch
+        if (sl + 1 < g.nslice) {
+            patch_load(sl + 1);
+            __syncthreads();
+        }
+    }
+
+    float sc[FN], sh[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        sc[j] = ep.scale ? ep.scale[j * 16 + xl] : 1.f;
+        sh[j] = ep.shift ? ep.shift[j * 16 + xl] : 0.f;
+    }
+    // ---- far pass (exact global gather, same arithmetic): wave-uniform masks from phase G
+    {
+        unsigned long long any = 0;
+#pragma unroll
+        for (int tt = 0; tt < TPT; ++tt) any |= farm[tt];
+        if (any) {
+            const u32x4* wfh = wfar + lane;
+            const u32x4* wfl = wfar + far_lo + lane;
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ftt = tap % TPT, ftg = tap / TPT;
+                unsigned long long fm_ = 0;
+#pragma unroll
+                for (int t = 0; t < TPT; ++t) fm_ = (t == ftt) ? farm[t] : fm_;
+                fm_ >>= (ftg * FM) * 16;
+                if (!(fm_ & 0xffffffffull)) continue;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    if (!((fm_ >> (16 * i)) & 0xffffull)) continue;
+                    const f32x4 ge = *reinterpret_cast<const f32x4*>(smem + GT_OFF + (tap * NPIX + (wv * FM + i) * 16 + xl) * 16);
+                    const uint32_t gbase = __float_as_uint(ge[3]);
+                    const bool isfar = ge[2] < 0.f;
+                    const int h0 = (int)(gbase & 0xffffu) - 32, w0 = (int)((gbase >> 16) & 0x7fffu) - 32;
+                    const float m_ = isfar ? -ge[2] : 0.f, lh = ge[0], lw = ge[1], hh = 1.f - lh, hw_ = 1.f - lw;
+                    const float wq4[4] = {hh * hw_ * m_, hh * lw * m_, lh * hw_ * m_, lh * lw * m_};
+                    for (int ks = 0; ks < g.cpt_far; ++ks) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int hc = h0 + (q >> 1), wc = w0 + (q & 1);
+                            const bool ok = isfar && hc >= 0 && hc < g.H && wc >= 0 && wc < g.W;
+                            if (ok) {
+                                const float* p = xb + ((size_t)hc * g.W + wc) * g.C + ks * 32 + kq * 8;
+                                const f32x4 a = *reinterpret_cast<const f32x4*>(p), c4 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { o[e] = fmaf(wq4[q], a[e], o[e]); o[4 + e] = fmaf(wq4[q], c4[e], o[4 + e]); }
+                            }
+                        }
+                        const float o0[4] = {o[0], o[1], o[2], o[3]}, o1[4] = {o[4], o[5], o[6], o[7]};
+                        const u32x4 s0 = lds_operand<f32s_t>(ElemTraits<float>::pack(o0)), s1 = lds_operand<f32s_t>(ElemTraits<float>::pack(o1));
+                        const u32x4 ah = {s0.x, s0.y, s1.x, s1.y}, al = {s0.z, s0.w, s1.z, s1.w};
+#pragma unroll
+                        for (int n = 0; n < FN; ++n) {
+                            const size_t wi = ((size_t)n * g.fsteps_far + tap * g.cpt_far + ks) * 64;
+                            const u32x4 wh = wfh[wi], wl = wfl[wi];
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lh8_t, ah), __builtin_bit_cast(lh8_t, wh), acc[i][n], 0, 0, 0);
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lh8_t, ah), __builtin_bit_cast(lh8_t, wl), acc[i][n], 0, 0, 0);
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lh8_t, al), __builtin_bit_cast(lh8_t, wh), acc[i][n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: per-wave staging in the (dead) patch memory, fp32 rows out
+    constexpr int LDS_ = FN * 16 + 4;
+    float* stage = reinterpret_cast<float*>(smem) + wv * (16 * LDS_);
+    float* y = reinterpret_cast<float*>(ep.y);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(kq * 4 + r) * LDS_ + j * 16 + xl] = acc[i][j][r] * sc[j] + sh[j];
+        __builtin_amdgcn_wave_barrier();
+        const int yg = ty0 + wv * FM + i;
+        for (int it = lane; it < 16 * 16; it += 64) {                        // 16 pixels x 16 chunks of 4 channels
+            const int px = it >> 4, ng = it & 15;
+            const int gx = tx0 + px, gn = ng * 4;
+            if (yg < g.H && gx < g.W && gn < ep.Cout) {
+                float v[4];
+                const f32x4 t = *reinterpret_cast<const f32x4*>(stage + px * LDS_ + gn);
+                v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+                apply_act_chunk<4>(v, ep.act, gn);
+                *reinterpret_cast<f32x4*>(y + ((size_t)(b * g.H + yg) * g.W + gx) * ep.ldy + gn) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int g_opt_dcn_lds = 1;       // option "dcn_lds": 0 = off, 1 = automatic (64 -> 64 on large 16-bit maps), 2 = wherever the kernel applies
 int g_opt_dcn_lds_rows = 16; // option "dcn_lds_rows": tile rows, 16 | 8 (three workgroups per CU; measured slower: 2.570 vs 2.551 ms per step, profiles/r06_dcn_lds.md)
 
@@ -505,8 +785,39 @@ template <int TR, typename TX, bool OF> static int launch_dcn_lds(const mfx_dcn_
     return MFX_OK;
 }
 
+static int launch_dcn_lds_split(const mfx_dcn_desc* d, hipStream_t st) {
+    constexpr int R = 7, TR = 8;
+    DcnLGeom g;
+    g.B = d->B; g.H = d->H; g.W = d->W; g.C = d->C;
+    g.tiles_x = (d->W + 15) / 16; g.tiles_y = (d->H + TR - 1) / TR;
+    g.nslice = d->C / 16; g.fsteps_pair = g.nslice * 5; g.fsteps_far = d->K_pad / 32; g.cpt_far = d->C / 32;
+    EpiArgs ep;
+    ep.scale = d->scale; ep.shift = d->shift; ep.res = nullptr; ep.y = d->y; ep.ldy = d->ldy; ep.ldres = 0;
+    ep.Cout = d->Cout; ep.act = d->act; ep.K_pad = d->K_pad; ep.nk = 0; ep.tiles_n = 1;
+    constexpr int smem = (16 + 2 * (R + 1)) * (TR + 2 * (R + 1)) * 80 + (9 * TR * 16 + 32) * 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        MFX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_lds_split_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    if (!d->offmask) return mfx_fail(MFX_ERR_ARG, "dcn: offmask is NULL (the split-precision LDS kernel does not compute the offsets itself)");
+    const size_t pair_lo = (size_t)(d->Cout_pad / 16) * g.fsteps_pair * 64, far_lo = (size_t)(d->Cout_pad / 16) * g.fsteps_far * 64;   // 16-byte units to the lo arrays
+    hipLaunchKernelGGL((dcn_lds_split_kernel<R>), dim3(d->B * g.tiles_y * g.tiles_x), dim3(256), smem, st, reinterpret_cast<const float*>(d->x), d->offmask,
+                       reinterpret_cast<const u32x4*>(d->w_pair_f16), reinterpret_cast<const u32x4*>(d->w_frag_f16), pair_lo, far_lo, g, ep);
+    MFX_HIP_CHECK(hipGetLastError());
+    return MFX_OK;
+}
+
 // returns 1 if handled, 0 to fall through to the older kernels, < 0 on error
 int try_dcn_lds(const mfx_dcn_desc* d, hipStream_t st) {
+    if (d->dtype == MFX_F16X2) {                              // split precision: fp32 maps, [hi | lo] weight arrays (see dcn_lds_split_kernel)
+        if (!g_opt_dcn_lds || !d->w_pair_f16 || !d->w_frag_f16 || d->nonsquare) return 0;
+        if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dil != 1 || d->Ho != d->H || d->Wo != d->W) return 0;
+        if (d->C % 32 != 0 || d->K_pad != 9 * d->C || d->Cout_pad != 64 || d->Cout % 4 != 0) return 0;
+        if (g_opt_dcn_lds < 2 && !(d->C == 64 && (long)d->B * d->H * d->W >= 65536)) return 0;
+        const int rc = launch_dcn_lds_split(d, st);
+        return rc == MFX_OK ? 1 : rc;
+    }
     if (!dcn_lds_auto(d)) return 0;
     const bool of = dcn_lds_fuses_offset_conv(d);
     int rc;
@@ -521,3 +832,5 @@ int try_dcn_lds(const mfx_dcn_desc* d, hipStream_t st) {
 }
 
 }  // namespace mfx
+
+MFX_RANGE_FLAG_ACCESSOR(dcn_lds)      // split-precision range sentinel of this translation unit (common.h)

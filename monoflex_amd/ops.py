@@ -395,7 +395,21 @@ def dcn_pair_fragments(weight, cout_pad):
 
 
 def add_f16_fragments(p: PackedConv, weight):
-    """Attach the fp16 fragment-major weights the DCN LDS-patch kernels multiply with (bf16 / fp16 mode, 3x3/s1/p1)."""
+    """Attach the fp16 fragment-major weights the DCN LDS-patch kernels multiply with (bf16 / fp16 mode, 3x3/s1/p1; split precision: the (hi, lo) halves
+    of the scaled weights as two consecutive arrays each -- csrc/dcn_lds.hip dcn_lds_split_kernel)."""
+    if p.split and p.kh == 3 and p.kw == 3 and p.Cout_pad == 64 and weight.shape[1] % 32 == 0 and p.K_pad == 9 * weight.shape[1]:
+        Cout, Cin, kh, kw = weight.shape
+        w = weight.detach().float().to(p.w.device)
+        ws = split_weight_scale(w.permute(0, 2, 3, 1).reshape(Cout, -1))        # the scale pack_conv folded into p.scale (same matrix, same maximum)
+        w = w * ws
+        hi = w.half()
+        lo = (w - hi.float()).half()
+        p.w_pair_f16 = torch.cat((dcn_pair_fragments(hi.float(), p.Cout_pad).reshape(-1), dcn_pair_fragments(lo.float(), p.Cout_pad).reshape(-1))).contiguous()
+
+        def frag(h):
+            return fragment_major(_pad_rows_cols(h.float().permute(0, 2, 3, 1).reshape(Cout, -1), p.Cout_pad, p.K_pad).half().contiguous(), torch.float16).reshape(-1)
+        p.w_frag_f16 = torch.cat((frag(hi), frag(lo))).contiguous()
+        return p
     if p.w_frag is not None and p.w.dtype in (torch.float16, torch.bfloat16) and p.kh == 3 and p.kw == 3 and p.Cout_pad == 64 \
             and weight.shape[1] % 16 == 0 and not p.split:
         p.w_pair_f16 = dcn_pair_fragments(weight.to(p.w.device), p.Cout_pad)

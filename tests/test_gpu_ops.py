@@ -574,6 +574,43 @@ def test_dcn_lds_kernel_matches_the_gather_kernel(dtype, rows, B, C, Cout, H, W,
     assert float((got - ref).abs().mean()) <= 2.5 * float((want - ref).abs().mean()) + 1e-6
 
 
+@pytest.mark.parametrize("B,C,Cout,H,W,off_std,far", [(2, 64, 64, 32, 48, 1.5, 0.0), (1, 64, 64, 20, 40, 2.5, 0.02), (2, 128, 64, 48, 64, 3.0, 0.01),
+                                                      (1, 64, 64, 16, 16, 12.0, 0.0), (8, 64, 64, 96, 320, 2.5, 0.001)])
+def test_dcn_lds_split_kernel_matches_the_fp32_kernel(B, C, Cout, H, W, off_std, far):
+    """Split precision (MFX_F16X2: the mode that carries the north-star gate): csrc/dcn_lds.hip dcn_lds_split_kernel -- fp32 patch in LDS, fp32 blend, (hi, lo)
+    fp16 operand pairs, three MFMAs per product -- against the library's fp32 kernel (v_mfma_f32_16x16x4_f32) and its split-precision gather kernel on
+    the same fp32 values: fp32-grade agreement (the reference computes in fp32: src/cuda/dcn_v2_cuda.cu:58), far pass and partial tiles included, and the
+    range sentinel stays clear."""
+    from monoflex_amd import lib as L, ops
+    g = _g(79)
+    x = torch.randn(B, H, W, C, generator=g).relu().to(DEV)
+    om = torch.zeros(B, H, W, 32)
+    om[..., :18] = torch.randn(B, H, W, 18, generator=g) * off_std
+    if far > 0:
+        wild = torch.rand(B, H, W, 18, generator=g) < far
+        om[..., :18] = torch.where(wild, torch.randn(B, H, W, 18, generator=g) * 40.0, om[..., :18])
+    om[..., 18:27] = torch.rand(B, H, W, 9, generator=g)
+    om = om.to(DEV)
+    w = torch.randn(Cout, C, 3, 3, generator=g) * (1.0 / (3 * C ** 0.5))
+    sc, sh = torch.rand(Cout, generator=g).to(DEV) + 0.5, torch.randn(Cout, generator=g).to(DEV) * 0.1
+    p32 = ops.pack_conv(w.to(DEV), torch.float32, sc, sh, stride=1, pad=1, act=L.ACT_RELU)
+    ps = ops.pack_conv(w.to(DEV), ops.F16X2, sc, sh, stride=1, pad=1, act=L.ACT_RELU)
+    ops.add_f16_fragments(ps, w)
+    assert ps.split and ps.w_pair_f16 is not None and ps.w_frag_f16 is not None
+    lib_ = L.load()
+    L.f16x2_range_ok()                                         # clear the flag
+    L.check(lib_.mfx_set_option(b"dcn_lds", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_patch", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_wave", 0), "opt")
+    ref = ops.dcn(x, om, p32).cpu()
+    gather = ops.dcn(x, om, ps).cpu()
+    L.check(lib_.mfx_set_option(b"dcn_lds", 2), "opt")
+    got = ops.dcn(x, om, ps).cpu()
+    assert L.f16x2_range_ok()
+    scale = max(1.0, float(ref.abs().max()))
+    e_new, e_old = float((got - ref).abs().max()), float((gather - ref).abs().max())
+    assert e_new <= 2e-5 * scale, (e_new, e_old)
+    assert e_new <= 3.0 * e_old + 2e-6 * scale, (e_new, e_old)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,C,Cout,H,W", [(2, 512, 256, 12, 40), (2, 256, 64, 24, 80), (1, 128, 64, 13, 37), (1, 256, 128, 7, 9)])
 def test_dcn_project_then_sample_matches_the_gather_kernel(dtype, B, C, Cout, H, W):
