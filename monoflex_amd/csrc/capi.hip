@@ -21,10 +21,10 @@ extern "C" int mfx_abi_version(void) { return MFX_ABI_VERSION; }
 
 // split-precision range sentinel: the per-translation-unit flags of common.h's lds_operand<f32s_t>
 int mfx_range_flag_conv_halo(int), mfx_range_flag_conv_kernels(int), mfx_range_flag_dcn_wave(int), mfx_range_flag_f1_fused(int), mfx_range_flag_heads(int),
-    mfx_range_flag_stem(int), mfx_range_flag_dcn_lds(int);
+    mfx_range_flag_stem(int), mfx_range_flag_dcn_lds(int), mfx_range_flag_conv_cws(int);
 extern "C" int mfx_f16x2_range_check(int reset) {
     int (*const f[])(int) = {mfx_range_flag_conv_halo, mfx_range_flag_conv_kernels, mfx_range_flag_dcn_wave, mfx_range_flag_f1_fused, mfx_range_flag_heads,
-                             mfx_range_flag_stem, mfx_range_flag_dcn_lds};
+                             mfx_range_flag_stem, mfx_range_flag_dcn_lds, mfx_range_flag_conv_cws};
     int any = 0;
     for (auto fn : f) {
         const int v = fn(reset);

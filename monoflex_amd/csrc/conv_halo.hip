@@ -427,6 +427,7 @@ template <typename T, typename TO, int WN, int FN, int WK = 1, bool ST = false>
 static int launch_halo_st(const mfx_conv_desc* d, hipStream_t st);
 
 int try_conv_cw(const mfx_conv_desc* d, int v, hipStream_t st);      // conv_cw.hip: 0 = ran, 1 = no instantiation, < 0 = error
+int try_conv_cws(const mfx_conv_desc* d, int v, hipStream_t st);     // conv_cws.hip: the same for split precision
 
 static bool g_halo_stats_ran = false;    // set by the launch that ran a statistics-accumulating instantiation (read by try_conv_halo)
 
@@ -574,6 +575,11 @@ static int try_conv_halo_impl(const mfx_conv_desc* d, hipStream_t st) {
         static const bool trace = getenv("MFX_TRACE_CW") != nullptr;      // which layers stay on the run-time-geometry kernel
         if (trace) fprintf(stderr, "cw-fallback v=%d Ck=%d Cout=%d/%d s=%d HxW=%dx%d B=%d stats=%d out=%d res=%d act=%d\n", v, d->Ck, d->Cout, d->Cout_pad, d->stride,
                            d->H, d->W, d->B, d->stats ? 1 : 0, d->out_dtype, d->res ? 1 : 0, d->act);
+    }
+    if (d->dtype == MFX_F16X2 && g_opt_halo_cg <= 0 && g_opt_halo_pair) {
+        // split precision, compile-time-geometry form of the pair-walking kernel (conv_cws.hip): bit-identical output
+        const int r = try_conv_cws(d, v, st);
+        if (r <= 0) return r == 0 ? 1 : r;
     }
     int rc;
     if (d->dtype == MFX_F32) rc = halo_variant<float, float>(v, d, st);

@@ -796,6 +796,60 @@ def test_conv_cw_kernel_is_bit_identical_to_the_halo_kernel(dtype, C, Cout, B, H
         L.check(lib_.mfx_set_option(b"halo", 1), "opt")
 
 
+@pytest.mark.parametrize("v,C,Cout,B,H,W", [(6, 64, 64, 2, 24, 48), (6, 64, 64, 1, 13, 37), (7, 64, 128, 1, 19, 33), (7, 128, 128, 2, 16, 32), (7, 128, 128, 1, 13, 37),
+                                            (11, 128, 128, 1, 10, 20), (11, 256, 256, 2, 16, 32), (11, 256, 256, 1, 11, 21), (11, 512, 512, 2, 12, 40), (11, 512, 512, 1, 9, 17)])
+def test_conv_cws_split_precision_kernel_is_bit_identical_to_the_halo_kernel(v, C, Cout, B, H, W):
+    """csrc/conv_cws.hip (r06: the split-precision pair-walking 3x3 kernel with compile-time geometry, a software-pipelined K loop and a branch-free patch
+    load) keeps the K order, the accumulation order (hi.hi, lo.hi, hi.lo per pair and row) and the epilogue arithmetic of
+    conv3x3_wave_kernel<f32s_t, .., PR>: same bits, with and without the residual, every activation, full and ragged tiles, one to eight channel
+    groups, 1- and 2-way K splits; and fp32-grade agreement with torch (the reference computes in fp32)."""
+    ops, L = _ops()
+    g = _g(151)
+    x = torch.randn(B, H, W, C, generator=g).to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+    res = torch.randn(B, H, W, Cout, generator=g).to(DEV)
+    lib_ = L.load()
+    L.f16x2_range_ok()
+    for act in (L.ACT_RELU, L.ACT_LEAKY, L.ACT_NONE):
+        sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+        p = ops.pack_conv(w, ops.F16X2, sc, sh, stride=1, pad=1, act=act)
+        assert p.split and p.w_frag_pair is not None
+        for r in (res, None):
+            L.check(lib_.mfx_set_option(b"halo", v + 1), "opt")
+            L.check(lib_.mfx_set_option(b"halo_cws", 0), "opt")
+            want = ops.conv2d(x, p, res=r)
+            L.check(lib_.mfx_set_option(b"halo_cws", 1), "opt")
+            got = ops.conv2d(x, p, res=r)
+            assert got.dtype == torch.float32 and torch.equal(got.view(torch.int32), want.view(torch.int32)), (act, r is not None)
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().cpu(), None, padding=1).permute(0, 2, 3, 1) * sc.double().cpu() + sh.double().cpu()
+        ref = torch.relu(ref) if act == L.ACT_RELU else torch.nn.functional.leaky_relu(ref, 0.01) if act == L.ACT_LEAKY else ref
+        assert float((got.double().cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    L.check(lib_.mfx_reset_options(), "reset")
+    assert L.f16x2_range_ok()
+
+
+@pytest.mark.parametrize("C,B,H,W", [(64, 2, 24, 48), (128, 2, 16, 32), (128, 1, 13, 37), (256, 1, 11, 21), (512, 2, 12, 40), (512, 1, 9, 17)])
+def test_conv_cws_offset_mask_conv_is_bit_identical_to_the_halo_kernel(C, B, H, W):
+    """The DCN modules' 27-channel offset / mask conv in split precision on conv3x3_cws_kernel's one-slice / four-way K-split instantiation (18 pairs over
+    four waves: the fifth pair only on two of them): same bits as conv3x3_wave_kernel's variant 8."""
+    ops, L = _ops()
+    g = _g(153)
+    x = torch.randn(B, H, W, C, generator=g).to(DEV)
+    w = (torch.randn(27, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+    bias = torch.randn(27, generator=g).to(DEV)
+    p = ops.pack_conv(w, ops.F16X2, None, bias, stride=1, pad=1, act=L.ACT_DCN_OFFMASK, cout=32)
+    lib_ = L.load()
+    L.check(lib_.mfx_set_option(b"halo_cws", 0), "opt")
+    want = ops.conv2d(x, p, out_dtype=torch.float32)
+    L.check(lib_.mfx_set_option(b"halo_cws", 1), "opt")
+    got = ops.conv2d(x, p, out_dtype=torch.float32)
+    L.check(lib_.mfx_reset_options(), "reset")
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, bias, padding=1).permute(0, 2, 3, 1)
+    ref = torch.cat((ref[..., :18], torch.sigmoid(ref[..., 18:27])), -1)
+    assert float((got[..., :27] - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("v,C,Cout,stride,exact", [(6, 32, 64, 1, True), (7, 32, 128, 1, True), (11, 32, 256, 1, False), (12, 128, 64, 1, True), (13, 256, 64, 1, True),
                                                    (5, 64, 256, 1, True)])
