@@ -22,13 +22,13 @@
 
 namespace mfx {
 
-template <typename T, int N>
+template <typename T, int N, int TB = 3, int TWO = 0>
 __global__ __launch_bounds__(256, 4) void dcn_sample_kernel(const T* __restrict__ P, const float* __restrict__ om, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, T* __restrict__ y, int B, int H, int W, int ldy, int act,
                                                         int tiles_x, int tiles_y) {
     constexpr int CH = N / 8;                 // lanes per pixel
     constexpr int PX = 256 / CH;              // pixels per workgroup
-    constexpr int TW = PX >= 32 ? 8 : 4;      // block width; height = PX / TW  (32 -> 8 x 4, 16 -> 4 x 4, 8 -> 4 x 2)
+    constexpr int TW = TWO > 0 ? TWO : (PX >= 32 ? 8 : 4);      // block width; height = PX / TW  (32 -> 8 x 4, 16 -> 4 x 4, 8 -> 4 x 2)
     constexpr int TH = PX / TW;
     constexpr int LDP = 9 * N;                // elements per pixel row of P
     __shared__ __attribute__((aligned(16))) float gw[PX * 9][4];
@@ -72,10 +72,10 @@ __global__ __launch_bounds__(256, 4) void dcn_sample_kernel(const T* __restrict_
     const T* Pc = P + c8;
     // (batches stay batches: fully unrolled, the compiler hoists all 36 loads -- 202 VGPRs, two waves per SIMD)
 #pragma unroll 1
-    for (int t0 = 0; t0 < 9; t0 += 3) {
-        u32x4 v[3][4]; f32x4 wq[3];
+    for (int t0 = 0; t0 < 9; t0 += TB) {
+        u32x4 v[TB][4]; f32x4 wq[TB];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < TB; ++t) {
             const int4 o = *reinterpret_cast<const int4*>(go[pl * 9 + t0 + t]);
             wq[t] = *reinterpret_cast<const f32x4*>(gw[pl * 9 + t0 + t]);
             v[t][0] = *reinterpret_cast<const u32x4*>(Pc + (uint32_t)o.x);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 4) void dcn_sample_kernel(const T* __restrict_
             v[t][3] = *reinterpret_cast<const u32x4*>(Pc + (uint32_t)o.w);
         }
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < TB; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float f[8];
@@ -102,14 +102,21 @@ __global__ __launch_bounds__(256, 4) void dcn_sample_kernel(const T* __restrict_
     }
 }
 
-template <typename T, int N>
-static int launch_dcn_sample(const void* P, const float* om, const float* scale, const float* shift, void* y, int B, int H, int W, int ldy, int act, hipStream_t st) {
-    constexpr int CH = N / 8, PX = 256 / CH, TW = PX >= 32 ? 8 : 4, TH = PX / TW;
+template <typename T, int N, int TB = 3, int TWO = 0>
+static int launch_dcn_sample_v(const void* P, const float* om, const float* scale, const float* shift, void* y, int B, int H, int W, int ldy, int act, hipStream_t st) {
+    constexpr int CH = N / 8, PX = 256 / CH, TW = TWO > 0 ? TWO : (PX >= 32 ? 8 : 4), TH = PX / TW;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    hipLaunchKernelGGL((dcn_sample_kernel<T, N>), dim3(B * tiles_y * tiles_x), dim3(256), 0, st, reinterpret_cast<const T*>(P), om, scale, shift,
+    hipLaunchKernelGGL((dcn_sample_kernel<T, N, TB, TWO>), dim3(B * tiles_y * tiles_x), dim3(256), 0, st, reinterpret_cast<const T*>(P), om, scale, shift,
                        reinterpret_cast<T*>(y), B, H, W, ldy, act, tiles_x, tiles_y);
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
+}
+// (r06 sweep, tools/probes/dcn_sample_sweep.py, 128 -> 64 @ 48 x 160: 22-24 us whatever the offsets' spread (0 .. 6 px), the block shape (8 x 4, 16 x 2, 4 x 8,
+// 32 x 1) or the batch (1 or 3 taps): 283 MB of 16-byte-per-lane row gathers in 22.5 us = 12.6 TB/s -- the same rate the fused gather kernels reach
+// (566 MB in 45 us).  That is this chip's practical texture-path rate for scattered 128-byte rows, and the bound of every gather-based DCN form.)
+template <typename T, int N>
+static int launch_dcn_sample(const void* P, const float* om, const float* scale, const float* shift, void* y, int B, int H, int W, int ldy, int act, hipStream_t st) {
+    return launch_dcn_sample_v<T, N>(P, om, scale, shift, y, B, H, W, ldy, act, st);
 }
 
 template <typename T>

@@ -127,6 +127,7 @@ SYMBOLS = {
     "mfx_cat_conv1x1_nhwc": (_I, [ctypes.POINTER(CatDesc), _P]),
     "mfx_dcn_nhwc": (_I, [ctypes.POINTER(DcnDesc), _P]),
     "mfx_dcn_sample_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mfx_project_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_maxpool2x2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mfx_upsample_add_nhwc": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

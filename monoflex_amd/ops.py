@@ -464,6 +464,7 @@ def dcn(x, offmask, p: PackedConv):
 # 1x1 kernel AND with the vendor's GEMM), so the byte limit below keeps it to the two small-map channel-reducing modules.
 DCN_PS = [os.environ.get("MFX_DCN_PS", "1") != "0"]      # MFX_DCN_PS=0: every layer on the fused gather kernels (A/B)
 DCN_PS_MAX_BYTES = [24 << 20]
+PROJECT_AS = [os.environ.get("MFX_PROJECT_AS", "1") != "0"]      # the projection on csrc/gemm_as.hip (0: mfx_conv2d_nhwc's 1x1 kernel)
 
 
 def dcn_ps_pack(p: PackedConv):
@@ -487,7 +488,14 @@ def dcn_ps(x, offmask, p: PackedConv):
     """DCNv2 + scale/shift + act as two launches: the 1x1 projection of the whole map (dense GEMM), then the bilinear sampling of the projected map."""
     _need_cuda(x, offmask)
     B, H, W, C = x.shape
-    proj = conv2d(x, dcn_ps_pack(p))                            # (B, H, W, 9 * Cout), rows [(tap, n)]
+    pp = dcn_ps_pack(p)
+    # measured (profiles/r06_dcn_ps.md, B = 8): the activation-stationary kernel wins where the map is store-bound or wide -- K = 128 (35.9 -> 23.0 us,
+    # 63.3 -> 35.1), K = 512 (29.7 -> 26.5), K = 256 with 2304 outputs (47.4 -> 35.0) -- and loses on 256 -> 576 / 1152 (16.6 -> 20.4, 27.4 -> 25.8: a tie)
+    if PROJECT_AS[0] and pp.K_pad == C and (C in (128, 512) or (C == 256 and 9 * p.Cout >= 2304)):
+        proj = torch.empty((B, H, W, 9 * p.Cout), dtype=x.dtype, device=x.device)      # rows [(tap, n)]
+        L.check(L.load().mfx_project_nhwc(_ptr(x), _ptr(pp.w), _ptr(proj), B * H * W, C, 9 * p.Cout, C, 9 * p.Cout, _dt(x.dtype), _stream()), "mfx_project_nhwc")
+    else:
+        proj = conv2d(x, pp)                                    # the tiled implicit-GEMM kernel
     y = torch.empty((B, H, W, p.Cout), dtype=x.dtype, device=x.device)
     L.check(L.load().mfx_dcn_sample_nhwc(_ptr(proj), _ptr(offmask), _ptr(p.scale), _ptr(p.shift), _ptr(y), B, H, W, p.Cout, p.Cout, p.act,
                                          _dt(x.dtype), _stream()), "mfx_dcn_sample_nhwc")

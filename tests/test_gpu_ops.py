@@ -631,6 +631,28 @@ def test_dcn_project_then_sample_matches_the_gather_kernel(dtype, B, C, Cout, H,
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,K,N", [(3840, 512, 2304), (1001, 128, 576), (15360, 256, 2304), (130, 256, 576), (61440, 128, 576)])
+def test_project_gemm_equals_the_tiled_1x1_kernel(dtype, M, K, N):
+    """csrc/gemm_as.hip (mfx_project_nhwc: activation-stationary GEMM, weight rows of a fragment pair permuted for 16-byte stores, channel chunks split
+    over workgroups on small maps) against mfx_conv2d_nhwc's 1x1 kernel on the same operands -- the same fp32 sums, rounded once: equal bits except
+    where the two summation orders straddle a 16-bit rounding boundary -- and against torch; ragged M."""
+    ops, L = _ops()
+    g = _g(161)
+    x = torch.randn(1, 1, M, K, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(N, K, 1, 1, generator=g) / K ** 0.5).to(DEV)
+    p = ops.pack_conv(w, dtype, None, None, stride=1, pad=0, act=L.ACT_NONE)
+    assert p.K_pad == K and p.Cout_pad == N
+    want = ops.conv2d(x, p).view(M, N)
+    got = torch.empty(M, N, dtype=dtype, device=DEV)
+    L.check(L.load().mfx_project_nhwc(x.data_ptr(), p.w.data_ptr(), got.data_ptr(), M, K, N, K, N, L.MFX_BF16 if dtype == torch.bfloat16 else L.MFX_F16,
+                                      torch.cuda.current_stream().cuda_stream), "mfx_project_nhwc")
+    ref = x.view(M, K).float() @ w.view(N, K).to(dtype).float().t()
+    tol = (2e-2 if dtype == torch.bfloat16 else 3e-3) * max(1.0, float(ref.abs().max()))
+    assert float((got.float() - ref).abs().max()) <= tol
+    assert float((got.float() - want.float()).abs().max()) <= tol and float((got != want).float().mean()) <= 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("rows", [16, 8])
 def test_dcn_lds_module_with_the_offset_conv_inside(dtype, rows):
     """The 64 -> 64 module as ONE launch of dcn_lds_kernel<OF> (offset / mask conv of the tile inside, phase 0) against the two-launch form

@@ -38,8 +38,8 @@ def timed(fn):
     return e0.elapsed_time(e1) / (5 * N) * 1e3
 
 
-print("| layer (B=%d) | projection us | TF/s | sampling us | projected map MB | fused gather kernel us | vendor GEMM (yardstick) us |" % B)
-print("|---|---|---|---|---|---|---|")
+print("| layer (B=%d) | projection us (tiled 1x1 kernel) | TF/s | projection us (gemm_as) | max diff | sampling us | projected map MB | fused gather kernel us | vendor GEMM (yardstick) us |" % B)
+print("|---|---|---|---|---|---|---|---|---|")
 for (H, W, Ci, Co) in SHAPES:
     torch.manual_seed(0)
     x = torch.randn(B, H, W, Ci, device="cuda").relu().to(dt)
@@ -52,6 +52,9 @@ for (H, W, Ci, Co) in SHAPES:
     proj = ops.conv2d(x, pp)
     y = torch.empty(B, H, W, Co, device="cuda", dtype=dt)
     tp = timed(lambda: ops.conv2d(x, pp))
+    pa = torch.empty_like(proj)
+    ta = timed(lambda: L.mfx_project_nhwc(x.data_ptr(), pp.w.data_ptr(), pa.data_ptr(), B * H * W, Ci, 9 * Co, Ci, 9 * Co, lib.MFX_BF16, torch.cuda.current_stream().cuda_stream))
+    err = float((pa.float() - proj.float()).abs().max())
     ts = timed(lambda: L.mfx_dcn_sample_nhwc(proj.data_ptr(), om.data_ptr(), p.scale.data_ptr(), p.shift.data_ptr(), y.data_ptr(), B, H, W, Co, Co, 1,
                                              lib.MFX_BF16, torch.cuda.current_stream().cuda_stream))
     tk = timed(lambda: ops.dcn(x, om, p))
@@ -59,4 +62,4 @@ for (H, W, Ci, Co) in SHAPES:
     out2 = torch.empty(x2.shape[0], w2.shape[1], device="cuda", dtype=dt)
     tv = timed(lambda: torch.matmul(x2, w2, out=out2))         # what a tuned library GEMM does with the same shape (not used by the product)
     gf = 2.0 * B * H * W * 9 * Ci * Co / 1e9
-    print("| %dx%d %d->%d | %.1f | %.0f | %.1f | %.1f | %.1f | %.1f |" % (H, W, Ci, Co, tp, gf / tp * 1e3, ts, proj.numel() * 2 / 1e6, tk, tv), flush=True)
+    print("| %dx%d %d->%d | %.1f | %.0f | %.1f | %.4f | %.1f | %.1f | %.1f | %.1f |" % (H, W, Ci, Co, tp, gf / tp * 1e3, ta, err, ts, proj.numel() * 2 / 1e6, tk, tv), flush=True)
