@@ -47,7 +47,7 @@ HEADS_GFLOP_PER_IMG = 2 * 41.185    # Appendix A: 9 x (3x3 64->256 + 1x1) per im
 PEAK_BF16_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_F32_TFLOPS = 157.3
 # PMC passes of the heads kernel (tools/pmc_heads.sh <tag>): the newest committed measurement (the bf16 kernel is unchanged since r03)
-HEADS_TRAFFIC_JSON = next((f for f in (os.path.join(ROOT, "profiles", t + "_heads_traffic.json") for t in ("r05", "r04", "r03")) if os.path.exists(f)),
+HEADS_TRAFFIC_JSON = next((f for f in (os.path.join(ROOT, "profiles", t + "_heads_traffic.json") for t in ("r06", "r05", "r04", "r03")) if os.path.exists(f)),
                           os.path.join(ROOT, "profiles", "r03_heads_traffic.json"))
 
 

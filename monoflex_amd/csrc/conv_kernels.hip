@@ -297,6 +297,7 @@ extern int g_opt_halo_cw, g_opt_cw_rows6, g_opt_halo_cws;
 extern int g_opt_halo, g_opt_halo_cg, g_opt_halo_pair, g_opt_halo_s2, g_opt_dcn_wave, g_opt_dcn_patch, g_opt_dcn_patch_fn8, g_opt_dcn_wgrad_m;
 }
 extern long g_cnt_dcn_bt_fused, g_cnt_dcn_bt_fly;
+extern int g_opt_ext_bwd_fast;
 extern int g_opt_dcn_bt_fly;
 extern int g_opt_dcn_bt_fuse_min_chunks, g_opt_dcn_bt_fuse_blocks, g_opt_dcn_bt_fuse_wgrad, g_opt_heads_planes, g_opt_heads_persist, g_opt_heads_dbg, g_opt_heads_mfma32, g_opt_dcn_bt_cs, g_opt_dcn_bt_cs_wgs, g_opt_dcn_bt_dbg, g_opt_wgrad_tr, g_opt_wgrad_tr_blocks, g_opt_bn_blocks, g_opt_bn_apply_blocks, g_opt_wgrad_patch, g_opt_wgrad_patch_blocks, g_opt_wgrad_patch_waves;
 extern int g_opt_topk_strips;                                                                                           // decode.hip (global namespace)
@@ -429,7 +430,7 @@ static int* option_slot(const std::string& n) {
         {"conv_tile", &g_opt_conv_tile}, {"dcn_tile", &g_opt_dcn_tile}, {"cat_tile", &g_opt_cat_tile}, {"kc", &g_opt_kc}, {"ksplit", &g_opt_ksplit},
         {"dcn_ksplit", &g_opt_dcn_ksplit}, {"wgrad_mfma", &g_opt_wgrad_mfma}, {"wgrad_blocks", &g_opt_wgrad_blocks}, {"wgrad_ws", &g_opt_wgrad_ws},
         {"wgrad_ws_blocks", &g_opt_wgrad_ws_blocks}, {"dcn_wgrad_m", &g_opt_dcn_wgrad_m}, {"halo", &g_opt_halo}, {"halo_cg", &g_opt_halo_cg},
-        {"halo_cw", &g_opt_halo_cw}, {"halo_cws", &g_opt_halo_cws}, {"cw_rows6", &g_opt_cw_rows6}, {"halo_pair", &g_opt_halo_pair}, {"halo_s2", &g_opt_halo_s2}, {"dcn_wave", &g_opt_dcn_wave}, {"dcn_patch", &g_opt_dcn_patch}, {"dcn_lds", &g_opt_dcn_lds}, {"dcn_lds_rows", &g_opt_dcn_lds_rows},
+        {"halo_cw", &g_opt_halo_cw}, {"halo_cws", &g_opt_halo_cws}, {"ext_bwd_fast", &g_opt_ext_bwd_fast}, {"cw_rows6", &g_opt_cw_rows6}, {"halo_pair", &g_opt_halo_pair}, {"halo_s2", &g_opt_halo_s2}, {"dcn_wave", &g_opt_dcn_wave}, {"dcn_patch", &g_opt_dcn_patch}, {"dcn_lds", &g_opt_dcn_lds}, {"dcn_lds_rows", &g_opt_dcn_lds_rows},
         {"dcn_patch_fn8", &g_opt_dcn_patch_fn8}, {"dcn_fuse_off", &g_opt_dcn_fuse_off}, {"topk_strips", &g_opt_topk_strips},
 #ifdef MFX_PROBES
         {"dcn_bt_dbg", &g_opt_dcn_bt_dbg}, {"heads_dbg", &g_opt_heads_dbg},

@@ -284,8 +284,41 @@ static int dcn_bwd_core(const T* x, const float* om, const T* wT, const T* go, T
     return MFX_OK;
 }
 
+// ---- fast route of the `_ext` backward (r06): 3x3 / stride 1 / pad 1 / dilation 1 with power-of-two channel counts >= 64 -- the model's own DCN geometry -- runs the
+// tile-owned second-generation kernels (dcn_bwd_tile.hip: d(columns) GEMM on the matrix cores, grad_input gathered per tile in LDS instead of scattered with
+// global atomics, weight gradient as an MFMA GEMM) behind the same NCHW boundary; d_raw's mask channels are asked for as the gradient of the mask ITSELF
+// (BtGeom.raw_mask): `_ext` takes the mask as an input and knows nothing of the sigmoid in front of it (src/dcn_v2.h:48-59).
+int g_opt_ext_bwd_fast = 1;  // option "ext_bwd_fast": 0 = the first-generation scatter backward for every geometry
+extern "C" size_t mfx_dcn_backward_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int dtype);
+int mfx_internal_dcn_backward_v2_f32_rawmask(const float* x, const float* offmask, const float* weight_oihw, const float* dy, float* dx, float* d_raw,
+                                             float* dweight, float* dbias, int B, int C, int H, int W, int Cout, void* workspace, size_t workspace_bytes, void* stream);
+static bool ext_bwd_fast_ok(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
+    return g_opt_ext_bwd_fast && !g_opt_det && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && C >= 64 && (C & (C - 1)) == 0 &&
+           Cout >= 64 && (Cout & (Cout - 1)) == 0 && H < 4096 && W < 4096 && (long)B * H * W < (1L << 31) / 32;
+}
+struct FastLayout { size_t x, om, go, gx, gom, v2, total; };
+static FastLayout fast_layout(int B, int C, int H, int W, int Cout) {
+    FastLayout L; size_t o = 0;
+    const size_t M = (size_t)B * H * W;
+    L.x = o;   o += al256(M * C * 4);
+    L.om = o;  o += al256(M * 32 * 4);
+    L.go = o;  o += al256(M * Cout * 4);
+    L.gx = o;  o += al256(M * C * 4);
+    L.gom = o; o += al256(M * 32 * 4);
+    L.v2 = o;  o += al256(mfx_dcn_backward_v2_workspace_bytes(B, C, H, W, Cout, MFX_F32));
+    L.total = o;
+    return L;
+}
+
 extern "C" size_t mfx_dcn_v2_backward_workspace_bytes_(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
-    return bwd_layout(bwd_geom(B, C, H, W, Cout, kh, kw, sh, ph, dh, sw, pw, dw)).total;
+    const size_t slow = bwd_layout(bwd_geom(B, C, H, W, Cout, kh, kw, sh, ph, dh, sw, pw, dw)).total;
+    // the fast route may be taken by a channel SLICE of the layer (deformable groups: C / dg channels per call of backward_one): size for the largest
+    // power of two <= C, which bounds every slice that qualifies (fast_layout grows with C)
+    int Cp2 = 64;
+    while (Cp2 * 2 <= C) Cp2 *= 2;
+    if (C < 64 || !ext_bwd_fast_ok(B, Cp2, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw)) return slow;
+    const size_t fast = fast_layout(B, Cp2, H, W, Cout).total;
+    return fast > slow ? fast : slow;
 }
 
 int mfx_internal_ext_slice(const float* src, float* dst, int B, int Cs, int cs0, int Cd, int cd0, int Cg, int HW, int accumulate, void* stream);   // dcn_ext.hip
@@ -294,8 +327,27 @@ int mfx_internal_ext_slice(const float* src, float* dst, int B, int Cs, int cs0,
 static int backward_one(const float* input, const float* weight, const float* offset, const float* mask, const float* grad_output,
                         float* grad_input, float* grad_offset, float* grad_mask, float* grad_weight, float* grad_bias,
                         int B, int C, int Cout, const BwdGeom& g, char* ws, void* stream) {
-    const BwdLayout L = bwd_layout(g);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (ext_bwd_fast_ok(B, C, g.H, g.W, Cout, g.kh, g.kw, g.stride, g.stride_w, g.pad, g.pad_w, g.dil, g.dil_w)) {
+        const FastLayout F = fast_layout(B, C, g.H, g.W, Cout);
+        float* x = (float*)(ws + F.x); float* om = (float*)(ws + F.om); float* go = (float*)(ws + F.go); float* gx = (float*)(ws + F.gx); float* gom = (float*)(ws + F.gom);
+        const int HW = g.H * g.W;
+        int rc = mfx_nchw_to_nhwc(input, x, B, C, g.H, g.W, C, MFX_F32, stream);
+        if (rc) return rc;
+        rc = mfx_nchw_to_nhwc(grad_output, go, B, Cout, g.H, g.W, Cout, MFX_F32, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bwd_pack_offmask, BWD_GRID((long)g.M * 32), dim3(256), 0, st, offset, mask, om, B, HW, g.kk);
+        MFX_HIP_CHECK(hipGetLastError());
+        // grad_weight arrives as (Cout, C, 3, 3) and grad_bias as (Cout): the caller's own layouts -- written in place
+        rc = mfx_internal_dcn_backward_v2_f32_rawmask(x, om, weight, go, gx, gom, grad_weight, grad_bias, B, C, g.H, g.W, Cout, ws + F.v2, F.total - F.v2, stream);
+        if (rc) return rc;
+        rc = mfx_nhwc_to_nchw(gx, grad_input, B, C, g.H, g.W, C, MFX_F32, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bwd_unpack_offmask, BWD_GRID((long)g.M * 3 * g.kk), dim3(256), 0, st, gom, grad_offset, grad_mask, B, HW, g.kk);
+        MFX_HIP_CHECK(hipGetLastError());
+        return MFX_OK;
+    }
+    const BwdLayout L = bwd_layout(g);
     float* x = (float*)(ws + L.x); float* om = (float*)(ws + L.om); float* wT = (float*)(ws + L.wT);
     float* go = (float*)(ws + L.go); float* gcol = (float*)(ws + L.gcol); float* gx = (float*)(ws + L.gx);
     float* gom = (float*)(ws + L.gom); float* gwp = (float*)(ws + L.gwp); float* gb = (float*)(ws + L.gb);

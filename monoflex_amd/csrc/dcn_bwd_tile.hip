@@ -65,7 +65,8 @@ constexpr int BT_FCAP = 512;   // far corners staged per workgroup before one gl
 #endif
 constexpr int BT_CH = BT_TH + 2 * BT_D, BT_CW = BT_TW + 2 * BT_D;        // candidate window (24 x 32 pixels)
 
-struct BtGeom { int B, H, W, C, tiles_x, tiles_y, Kp, CS, nslices, dbg; };
+struct BtGeom { int B, H, W, C, tiles_x, tiles_y, Kp, CS, nslices, dbg;
+                int raw_mask; };   // 1: d_raw[18 + tap] = d loss / d mask (the `_ext` contract: the mask is an INPUT there); 0: through the sigmoid of the mask logit
 
 struct SampGeo { int h0, w0; float lh, lw, mask; int inside; };
 
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const T* __restrict
         if (cl == 0 && q0.ok) {
             float* o = graw + q0.m * 32;
             o[2 * q0.tap] = gh * q0.mask; o[2 * q0.tap + 1] = gw * q0.mask;
-            o[18 + q0.tap] = gm * q0.mask * (1.f - q0.mask);                   // through the sigmoid of the mask logit
+            o[18 + q0.tap] = g.raw_mask ? gm : gm * q0.mask * (1.f - q0.mask);                   // through the sigmoid of the mask logit
             if (q0.tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
         }
         q0 = q1; r0 = r1; pre1 = pre2;
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const T* __re
                 gh = bt_group_sum<8>(gh); gw = bt_group_sum<8>(gw); gm = bt_group_sum<8>(gm);
                 if (cl == 0) {
                     float* o = graw + l0.m * 32;
-                    o[2 * l0.tap] = gh * e0.mask; o[2 * l0.tap + 1] = gw * e0.mask; o[18 + l0.tap] = gm * e0.mask * (1.f - e0.mask);
+                    o[2 * l0.tap] = gh * e0.mask; o[2 * l0.tap + 1] = gw * e0.mask; o[18 + l0.tap] = g.raw_mask ? gm : gm * e0.mask * (1.f - e0.mask);
                     if (l0.tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
                 }
             }
@@ -1164,7 +1165,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_fly_kernel(const T* 
                 gh = bt_group_sum<8>(gh); gw = bt_group_sum<8>(gw); gm = bt_group_sum<8>(gm);
                 if (cl == 0) {
                     float* o = graw + l0.m * 32;
-                    o[2 * l0.tap] = gh * e0.mask; o[2 * l0.tap + 1] = gw * e0.mask; o[18 + l0.tap] = gm * e0.mask * (1.f - e0.mask);
+                    o[2 * l0.tap] = gh * e0.mask; o[2 * l0.tap + 1] = gw * e0.mask; o[18 + l0.tap] = g.raw_mask ? gm : gm * e0.mask * (1.f - e0.mask);
                     if (l0.tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
                 }
             }
@@ -1216,7 +1217,7 @@ static BtLayout bt_layout(int B, int C, int H, int W, int Cout, int es) {
 template <typename T>
 static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* weight, const T* dy, T* dx, float* d_raw,
                                 float* dweight, float* dbias, int B, int C, int H, int W, int Cout, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                size_t workspace_bytes, void* stream, int raw_mask = 0) {
     constexpr int es = (int)sizeof(T);
     constexpr int dt = ElemTraits<T>::DT;                    // MFX_F32 / MFX_BF16 / MFX_F16
     const BtLayout L = bt_layout(B, C, H, W, Cout, es);
@@ -1236,7 +1237,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     }
     BtGeom g;
     g.B = B; g.H = H; g.W = W; g.C = C; g.tiles_x = (W + BT_TW - 1) / BT_TW; g.tiles_y = (H + BT_TH - 1) / BT_TH; g.Kp = K;
-    g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg;
+    g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg; g.raw_mask = raw_mask;
     if constexpr (!std::is_same<T, float>::value) {
         // gcol-free form (third generation): 64 -> 64, 16-bit, the shapes the fused sample + weight-gradient kernel takes
         const long nchunks = M / SF_PX;
@@ -1338,6 +1339,14 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
 
 }  // namespace mfx
 using namespace mfx;
+
+// library-internal (dcn_bwd.hip, the `_ext` boundary): the fp32 second-generation backward with d_raw's mask channels as the gradient of the MASK itself
+int mfx_internal_dcn_backward_v2_f32_rawmask(const float* x, const float* offmask, const float* weight_oihw, const float* dy, float* dx, float* d_raw,
+                                             float* dweight, float* dbias, int B, int C, int H, int W, int Cout, void* workspace, size_t workspace_bytes, void* stream) {
+    if (C < 64 || (C & (C - 1)) || Cout < 64 || (Cout & (Cout - 1)) || H >= 4096 || W >= 4096 || (long)B * H * W >= (1L << 31) / 32)
+        return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_backward_v2 (raw mask): shape outside the tile-owned kernels' range");
+    return dcn_backward_v2_impl<float>(x, offmask, weight_oihw, dy, dx, d_raw, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream, 1);
+}
 
 extern "C" size_t mfx_dcn_backward_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int dtype) {
     return bt_layout(B, C, H, W, Cout, dtype == MFX_F32 ? 4 : 2).total;

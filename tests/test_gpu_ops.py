@@ -210,6 +210,30 @@ def test_ext_dcn_zero_offset_known_answer():
     assert float((x - 2 * out).abs().max()) < 1e-10
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 64, 20, 36), (2, 128, 64, 9, 17), (1, 64, 128, 16, 16)])
+def test_ext_dcn_v2_backward_fast_route_equals_the_scatter_route(shape):
+    """`_ext.dcn_v2_backward` behind the C boundary takes the tile-owned second-generation kernels where the geometry is the model's own (3x3 / stride 1 /
+    pad 1, power-of-two channel counts >= 64; option ext_bwd_fast) -- with d_raw's mask channels as the gradient of the MASK (the boundary takes the mask as
+    an input: no sigmoid derivative, src/dcn_v2.h:48-59) -- and the first-generation scatter kernels elsewhere: the same five gradients on both routes,
+    also for a mask that is no sigmoid output (values outside (0, 1), zeros) and offsets that leave the map."""
+    from monoflex_amd import lib as L
+    from monoflex_amd.model.backbone.DCNv2 import _ext
+    x, off, msk, w, b = _dcn_case(24, *shape, off_scale=3.0)
+    msk = torch.randn(msk.shape, generator=_g(6)) * 0.8                        # any real mask, not sigmoid(...)
+    msk[:, ::3] = 0.0
+    go = torch.randn(shape[0], shape[2], shape[3], shape[4], generator=_g(5))
+    args = [t.to(DEV) for t in (x, w, b, off, msk, go)]
+    lib_ = L.load()
+    L.check(lib_.mfx_set_option(b"ext_bwd_fast", 0), "opt")
+    slow = [t.cpu() for t in _ext.dcn_v2_backward(*args, 3, 3, 1, 1, 1, 1, 1, 1, 1)]
+    L.check(lib_.mfx_set_option(b"ext_bwd_fast", 1), "opt")
+    fast = [t.cpu() for t in _ext.dcn_v2_backward(*args, 3, 3, 1, 1, 1, 1, 1, 1, 1)]
+    L.check(lib_.mfx_reset_options(), "reset")
+    for f_, s_, name in zip(fast, slow, ["grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"]):
+        scale = max(1.0, float(s_.abs().max()))
+        assert float((f_ - s_).abs().max()) < 2e-4 * scale, name
+
+
 @pytest.mark.parametrize("shape", [(2, 2, 2, 4, 4), (2, 8, 8, 12, 20), (1, 64, 64, 12, 20), (2, 128, 64, 6, 10)])
 def test_ext_dcn_v2_backward_vs_oracle(shape):
     from monoflex_amd.model.backbone.DCNv2 import _ext
@@ -530,7 +554,7 @@ def test_offset_conv_k_split_waves(dtype, B, H, W, C):
         L.check(lib_.mfx_set_option(b"halo", 1), "opt")
 
 
-def _dcn_case(B, C, Cout, H, W, off_std, dtype, far_frac=0.0, seed=71):
+def _dcn_nhwc_case(B, C, Cout, H, W, off_std, dtype, far_frac=0.0, seed=71):
     from monoflex_amd import lib as L, ops
     g = _g(seed)
     x = torch.randn(B, H, W, C, generator=g).relu().to(dtype).to(DEV)
@@ -558,7 +582,7 @@ def test_dcn_lds_kernel_matches_the_gather_kernel(dtype, rows, B, C, Cout, H, W,
     heights, against the library's gather kernel and its fp32 kernel on the same values: in-patch samples, samples that leave the patch or the
     image (the far pass: `far` = fraction of wild offsets; std 12 on a 16 x 16 map = mostly far), partial tiles, 4 to 16 channel slices."""
     from monoflex_amd import lib as L, ops
-    x, om, p, p32 = _dcn_case(B, C, Cout, H, W, off_std, dtype, far)
+    x, om, p, p32 = _dcn_nhwc_case(B, C, Cout, H, W, off_std, dtype, far)
     assert p.w_pair_f16 is not None
     lib_ = L.load()
     L.check(lib_.mfx_set_option(b"dcn_lds", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_patch", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_wave", 0), "opt")
@@ -618,7 +642,7 @@ def test_dcn_project_then_sample_matches_the_gather_kernel(dtype, B, C, Cout, H,
     interpolation commutes with the contraction over channels) against the fused gather kernel and the fp32 kernel: the same op up to the 16-bit
     rounding of the projected map; odd map sizes (partial pixel blocks), offsets that leave the image."""
     from monoflex_amd import lib as L, ops
-    x, om, p, p32 = _dcn_case(B, C, Cout, H, W, 3.0, dtype, 0.02, seed=73)
+    x, om, p, p32 = _dcn_nhwc_case(B, C, Cout, H, W, 3.0, dtype, 0.02, seed=73)
     lib_ = L.load()
     L.check(lib_.mfx_set_option(b"dcn_patch", 0), "opt"); L.check(lib_.mfx_set_option(b"dcn_wave", 0), "opt")
     ref = ops.dcn(x.float(), om, p32).cpu()
