@@ -38,6 +38,57 @@ def _device_guarded(cls):
     return cls
 
 
+# ---- weight gradients on a side stream (r06) ----------------------------------------------------------------------------------------------
+# The backward pass is a CHAIN of data-gradient kernels (conv dgrad -> BN backward -> conv dgrad ...), most of them one-round launches that leave the chip
+# half empty; the weight-gradient kernels (3.7 ms of the 18.3 ms step: MFMA GEMMs over the pixels + their partial-sum reduces) hang off that chain as leaves --
+# nothing reads a dW before the optimizer.  With WGRAD_SIDE[0] set (engine.trainer.GraphedTrainStep sets it around its backward passes) AND MFX_WGRAD_STREAM=1 in
+# the environment they are enqueued on a second stream that waits for the event of their inputs and is joined ONCE, by a callback the autograd
+# engine runs when the backward pass ends (so p.grad is complete before anything after backward() looks at it).  Inside a hipGraph capture the fork / join
+# become graph edges.  Tensors read or written across the fork carry `record_stream` marks, so the caching allocator does not hand their memory to the other
+# stream early (inside a capture: not before the capture ends).  Never on for plain `loss.backward()` calls: a DDP reducer hook would read a
+# gradient the moment autograd accumulates it, before the join.
+# MEASURED (r06 call 24, B = 8, one hipGraph, same box, alternating): 18.49 / 19.04 ms with the side stream, 18.62 / 18.62 ms without -- no gain: at B = 8 the
+# backward chain's kernels are throughput-bound, not idle-bound (the same picture as two sub-batch streams in inference: a wash at B = 8, +6 % at B = 32).
+# The GPU suite is green with it on (551 passed).  OFF by default.
+WGRAD_SIDE = [False]
+_WGRAD_STREAM_ON = __import__("os").environ.get("MFX_WGRAD_STREAM", "0") == "1"
+_side_streams = {}
+_join_pending = [False]
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+def _join_side_streams():
+    _join_pending[0] = False
+    for key, side in _side_streams.items():
+        torch.cuda.current_stream(torch.device(*key)).wait_stream(side)
+
+
+def on_wgrad_stream(fn, inputs):
+    """Run `fn()` (weight-gradient launches; returns a tensor or a tuple of tensors / None) on the side stream when enabled; `inputs` are the tensors it reads."""
+    if not (WGRAD_SIDE[0] and _WGRAD_STREAM_ON) or not inputs or not inputs[0].is_cuda:
+        return fn()
+    dev = inputs[0].device
+    cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in inputs:
+        t.record_stream(side)
+    for t in (out if isinstance(out, tuple) else (out,)):
+        if t is not None:
+            t.record_stream(cur)                              # produced on the side stream, consumed (optimizer, flat-buffer copy) on the main one after the join
+    if not _join_pending[0]:
+        _join_pending[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+    return out
+
+
 def _wgrad(x, dy, kh, kw, stride, pad, Ho, Wo, Ck=None, x_pixstride=None, in_hw=None):
     """fp32 (Cout, kh*kw, Ck) weight gradient."""
     B, H, W, Cx = x.shape
@@ -322,14 +373,20 @@ def _conv_backward(x, weight, dy, stride, pad, has_bias, Cout, needs, res=None):
             dx = dx[..., :Cin]
             if res is not None:
                 dx = dx + res
-    if needs[1]:
-        dwf = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-        ws = ops._splitk_workspace(x.device)                 # per-slab partial tiles (bf16 path), shared per stream
-        L.check(L.load().mfx_conv_wgrad_oihw(_ptr(x), _ptr(dy), _ptr(dwf), B, H, W, Cin, Cin, kh, kw, stride, pad, pad, Ho, Wo, Cp, Cp,
-                                             Cout, Cin, _dt(x.dtype), _ptr(ws), ws.numel() * 4, _stream()), "mfx_conv_wgrad_oihw")
-        dw = dwf if weight.dtype == torch.float32 else dwf.to(weight.dtype)
-    if has_bias and needs[2]:
-        db = _colsum(dy)[:Cout]
+    need_w, need_b = bool(needs[1]), bool(has_bias and needs[2])
+    if need_w or need_b:
+        def leaves():                                           # the parameter gradients: leaves of the backward graph (see on_wgrad_stream)
+            dw_ = db_ = None
+            if need_w:
+                dwf = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                ws = ops._splitk_workspace(x.device)          # per-slab partial tiles (bf16 path), shared per stream
+                L.check(L.load().mfx_conv_wgrad_oihw(_ptr(x), _ptr(dy), _ptr(dwf), B, H, W, Cin, Cin, kh, kw, stride, pad, pad, Ho, Wo, Cp, Cp,
+                                                     Cout, Cin, _dt(x.dtype), _ptr(ws), ws.numel() * 4, _stream()), "mfx_conv_wgrad_oihw")
+                dw_ = dwf if weight.dtype == torch.float32 else dwf.to(weight.dtype)
+            if need_b:
+                db_ = _colsum(dy)[:Cout]
+            return dw_, db_
+        dw, db = on_wgrad_stream(leaves, [dy, x])
     return dx, dw, db
 
 
@@ -417,7 +474,7 @@ class CatConv1x1Fn(Function):
         need_dx = any(ctx.needs_input_grad[1 + i] for i in range(len(xs)))
         # data-gradient operand of the whole Root in one launch: WT[c][o] = W[o][c]; source i uses rows [off, off + C_i)
         wt = _pack_weight(weight, dy.dtype, 1, Ctot, Cout, 1, 0, 0) if need_dx else None
-        dws, dxs, off = [], [], 0
+        dxs, off = [], 0
         for i, x in enumerate(xs):
             C = x.shape[3]
             if ctx.needs_input_grad[1 + i]:
@@ -425,10 +482,13 @@ class CatConv1x1Fn(Function):
                 dxs.append(ops.conv2d(dy, pt))
             else:
                 dxs.append(None)
-            if ctx.needs_input_grad[0]:
-                dws.append(_wgrad(x, dy, 1, 1, 1, 0, x.shape[1], x.shape[2]).view(Cout, C))
             off += C
-        dw = torch.cat(dws, 1).view_as(weight).to(weight.dtype) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[0]:
+            def leaves():                                       # the Root's weight gradient, source by source: a leaf of the backward graph (on_wgrad_stream)
+                parts = [_wgrad(x, dy, 1, 1, 1, 0, x.shape[1], x.shape[2]).view(Cout, x.shape[3]) for x in xs]
+                return torch.cat(parts, 1).view_as(weight).to(weight.dtype)
+            dw = on_wgrad_stream(leaves, [dy, *xs])
         return (dw, *dxs)
 
 

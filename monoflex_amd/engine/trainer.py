@@ -295,7 +295,8 @@ class GraphedTrainStep:
             with torch.cuda.graph(gk, pool=None if k == 0 else g0.pool(), capture_error_mode="thread_local"):
                 if k == 0:
                     self.loss, thunks = self._forward_cut()
-                thunks[k]()
+                with self._side_wgrads():
+                    thunks[k]()
                 self._flatten(k)
             self.graphs.append(gk)
         self._point_grads_at_views()
@@ -309,13 +310,27 @@ class GraphedTrainStep:
             from .. import autograd as AG
             AG.pack_all_weights()
 
+    def _side_wgrads(self):
+        """Context: weight gradients of the backward passes inside run on the library's side stream (autograd.on_wgrad_stream), joined when each pass ends."""
+        from .. import autograd as AG
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev = AG.WGRAD_SIDE[0]
+                AG.WGRAD_SIDE[0] = bool(self.images.is_cuda)
+
+            def __exit__(self_, *a):
+                AG.WGRAD_SIDE[0] = self_.prev
+        return _Ctx()
+
     def _fwd_bwd(self):
         """Whole step in one autograd graph (single-GPU form)."""
         self._pack()
         loss_dict, _ = self.model(self.images, self.targets)
         losses = sum(loss_dict.values())
         self.optimizer.zero_grad(set_to_none=True)
-        self._scaled(losses).backward()
+        with self._side_wgrads():
+            self._scaled(losses).backward()
         return losses.detach()
 
     def _scaled(self, losses):
@@ -407,7 +422,8 @@ class GraphedTrainStep:
             return loss
         loss, thunks = self._forward_cut()
         for k, t in enumerate(thunks):
-            t()
+            with self._side_wgrads():
+                t()
             self._flatten(k)
             self._exchange(k)
         self._finish_exchange()
