@@ -131,6 +131,7 @@ class _PackRegistry:
         self.entries = {}              # key -> dict(ref, weight version, buffers, descriptor fields)
         self.tables = {}               # (device, dtype) -> (keys, descs tensor, prefix tensor, total)
         self.dirty = set()
+        self.arenas = {}               # device -> fragment arena of the 64-channel DCN operands (_arena_slot)
 
     def lookup(self, weight, dtype, mode, rows, ck, stride, pad_h, pad_w, register=True):
         import weakref
@@ -147,9 +148,16 @@ class _PackRegistry:
             K_pad = (kh * kw * ck + kr - 1) // kr * kr
             cp = ops.cout_pad(rows)
             packed = torch.empty((cp, K_pad), dtype=dtype, device=weight.device)
-            frag = torch.empty_like(packed) if (kh == 3 and kw == 3 and stride in (1, 2) and pad_h == 1 and pad_w == 1) else None
+            frag = f16 = None
+            if kh == 3 and kw == 3 and stride in (1, 2) and pad_h == 1 and pad_w == 1:
+                if register and dtype == torch.bfloat16 and ck == 64 and cp in (32, 64) and stride == 1 and mode == 0:
+                    # a 64-channel DCN layer's operands (_with_f16_fragments): the fragments of all such layers share one arena, so their
+                    # IEEE-fp16 copies are ONE cast per step (pack_all) instead of one per operand
+                    frag, f16 = self._arena_slot(weight.device, cp, K_pad)
+                if frag is None:
+                    frag = torch.empty_like(packed)
             e = dict(ref=None, ptr=weight.data_ptr(), version=-1, packed=packed, frag=frag, cp=cp, K_pad=K_pad,
-                     shape=(Cout, Cin, kh, kw), mode=mode, ck=ck, fp32=weight.dtype == torch.float32)
+                     shape=(Cout, Cin, kh, kw), mode=mode, ck=ck, fp32=weight.dtype == torch.float32, f16=f16, f16_version=-2)
             if register:
                 tk = (weight.device, dtype)
                 # the entry (and its packed buffers) goes away with the parameter
@@ -159,6 +167,23 @@ class _PackRegistry:
             else:
                 e["ref"] = weakref.ref(weight)
         return e
+
+    ARENA_ELEMS = 48 * 64 * 576            # bf16 fragments of up to 48 64-channel 3x3 operands (5.3 MB + its fp16 twin) per device
+
+    def _arena_slot(self, dev, cp, K_pad):
+        """(bf16 fragment buffer, its fp16 twin) carved from the device's fragment arena, or (None, None) when it is full / a capture is running."""
+        if torch.cuda.is_current_stream_capturing():
+            return None, None
+        a = self.arenas.get(dev)
+        if a is None:
+            a = self.arenas[dev] = dict(b16=torch.zeros(self.ARENA_ELEMS, dtype=torch.bfloat16, device=dev),
+                                        f16=torch.zeros(self.ARENA_ELEMS, dtype=torch.float16, device=dev), used=0)
+        n = cp * K_pad
+        if a["used"] + n > self.ARENA_ELEMS:
+            return None, None
+        o = a["used"]
+        a["used"] += n                                          # (slots are not recycled: a model's operands are registered once)
+        return a["b16"][o:o + n].view(cp, K_pad), a["f16"][o:o + n].view(cp, K_pad)
 
     def _drop(self, key, table_key):
         if self.entries.pop(key, None) is not None:
@@ -218,6 +243,12 @@ class _PackRegistry:
                         "mfx_pack_conv_weights_batched")
             for e in live:
                 e["version"] = e["ref"]()._version
+            a = self.arenas.get(dev)
+            if a is not None and dtype == torch.bfloat16 and a["used"]:
+                a["f16"][:a["used"]].copy_(a["b16"][:a["used"]])          # bf16 -> fp16 of every arena fragment (exactness: _with_f16_fragments)
+                for e in live:
+                    if e.get("f16") is not None:
+                        e["f16_version"] = e["version"]
 
 
 _PACKS = _PackRegistry()
@@ -291,7 +322,10 @@ def _pack_weight(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, shift=None
     else:                                                      # a temporary (stacked head weights, a view): nothing to remember
         e = _PACKS.lookup(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, register=False)
         _PACKS.pack_one(e, weight, dtype)
-    return ops.PackedConv(e["packed"], None, shift, kh, kw, stride, pad_h, pad_w, 1, ck, rows, e["cp"], e["K_pad"], L.ACT_NONE, e["frag"])
+    p = ops.PackedConv(e["packed"], None, shift, kh, kw, stride, pad_h, pad_w, 1, ck, rows, e["cp"], e["K_pad"], L.ACT_NONE, e["frag"])
+    p.transient = True                                         # rebuilt every step: no derived operand is worth packing behind it (ops.dcn_ps_applies)
+    p.entry = e
+    return p
 
 
 def _with_f16_fragments(p, x):
@@ -303,7 +337,11 @@ def _with_f16_fragments(p, x):
     first-generation gather."""
     if p.w_frag is not None and p.Ck == 64 and p.Cout_pad in (32, 64) and x.shape[0] * x.shape[1] * x.shape[2] >= 65536:      # (32: the module's offset/mask conv, run inside that kernel)
         if p.w.dtype == torch.bfloat16:
-            p.w_frag_f16 = p.w_frag.to(torch.float16)
+            e = getattr(p, "entry", None)
+            if e is not None and e.get("f16") is not None and e["f16_version"] == e["version"] and e["frag"] is p.w_frag:
+                p.w_frag_f16 = e["f16"]                        # this step's batched cast (_PackRegistry.pack_all)
+            else:
+                p.w_frag_f16 = p.w_frag.to(torch.float16)
         elif p.w.dtype == torch.float16:
             p.w_frag_f16 = p.w_frag                            # fp16 mode: the fragments already are IEEE fp16
     return p
@@ -322,7 +360,8 @@ class Conv2dFn(Function):
         the kernel supports that (ops.conv2d.last_stats_done)."""
         x = _c(x)
         Cout, Cin, kh, kw = weight.shape
-        cpad = _pad_channels(Cout, out_dtype or x.dtype)
+        # (padded to the chunk of the COMPUTE type also where the map is written in fp32: the backward pass then casts dy and has nothing to pad)
+        cpad = _pad_channels(Cout, x.dtype)
         shift = None
         if bias is not None:
             cp = ops.cout_pad(cpad)
@@ -402,7 +441,7 @@ class HeadConvGatherFn(Function):
     def forward(ctx, f, weight, bias, rowmap):
         f = _c(f)
         Cout, Cin = weight.shape[0], weight.shape[1]
-        cpad = _pad_channels(Cout, torch.float32)
+        cpad = _pad_channels(Cout, f.dtype)
         shift = _padded_bias(bias, ops.cout_pad(cpad)) if bias is not None else None
         y = ops.conv2d(f, _pack_weight(weight, f.dtype, 0, cpad, Cin, 1, 0, 0, shift), out_dtype=torch.float32)
         e = f.view(-1, Cin).index_select(0, rowmap)

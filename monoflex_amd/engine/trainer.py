@@ -46,7 +46,9 @@ def wrap_data_parallel(model, device_ids=None, bucket_cap_mb=25):
 
 class PreparedTargets(list):
     """The per-image targets of one batch plus their device-side stacked form, built once per batch (outside any graph
-    capture): `.edge` = (edge_indices, edge_lens) for the predictor, `.loss` = (heat maps, stacked fields) for the loss."""
+    capture): `.edge` = (edge_indices, edge_lens) for the predictor, `.loss` = (heat maps, stacked fields) for the loss, `.edge_plan` = the
+    edge fusion's index tensors (predictor.edge_plan: functions of the targets alone; None without edge fusion)."""
+    edge_plan = None
 
 
 def prepare_targets(model, targets, device, fields=None):
@@ -58,6 +60,7 @@ def prepare_targets(model, targets, device, fields=None):
     if fields is None:
         pt.edge = stack_edge_fields(targets, device)
         pt.loss = m.heads.loss_evaluator.prepare_targets(targets, device)
+        pt.edge_plan = _edge_plan(m, pt)
         return pt
     dev = torch.device(device)
     pt.edge = (fields["edge_indices"].to(device=dev, dtype=torch.int32).contiguous(), fields["edge_len"].to(device=dev, dtype=torch.int32).contiguous())
@@ -70,7 +73,23 @@ def prepare_targets(model, targets, device, fields=None):
     d["calib_f32"] = torch.tensor([[c.f_u, c.f_v, c.c_u, c.c_v, c.b_x, c.b_y] for c in calibs], dtype=torch.float32).to(dev)
     d["object_rows"] = m.heads.loss_evaluator.pack_objects(d)
     pt.loss = (fields["hm"].to(dev), d)
+    pt.edge_plan = _edge_plan(m, pt)
     return pt
+
+
+def total_loss(loss_dict):
+    """The step's scalar loss: the sum of the weighted terms (trainer.py:111).  The fused loss hands it over ready-made (`loss_dict.total`: two
+    launches instead of the ten adds of a Python `sum` and their ten backward nodes)."""
+    t = getattr(loss_dict, "total", None)
+    return t if t is not None else sum(loss_dict.values())
+
+
+def _edge_plan(m, pt):
+    pr = getattr(m.heads, "predictor", None)
+    if pr is None or not (getattr(pr, "enable_edge_fusion", False) and getattr(pr, "fused_edge_nodes", False)) or not pt.edge[0].is_cuda:
+        return None
+    with torch.no_grad():
+        return pr.edge_plan(pt.edge[0], pt.edge[1], pt.loss[1].get("object_rows"))
 
 
 class LossScaler:
@@ -327,7 +346,7 @@ class GraphedTrainStep:
         """Whole step in one autograd graph (single-GPU form)."""
         self._pack()
         loss_dict, _ = self.model(self.images, self.targets)
-        losses = sum(loss_dict.values())
+        losses = total_loss(loss_dict)
         self.optimizer.zero_grad(set_to_none=True)
         with self._side_wgrads():
             self._scaled(losses).backward()
@@ -351,7 +370,7 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         if self.nseg == 1:
             loss_dict, _ = self.model(self.images, self.targets)
-            losses = sum(loss_dict.values())
+            losses = total_loss(loss_dict)
             scaled = self._scaled(losses)
             return losses.detach(), [lambda: scaled.backward()]
         cuts = {}
@@ -365,7 +384,7 @@ class GraphedTrainStep:
             loss_dict, _ = self.model(self.images, self.targets)
         finally:
             self.net.set_backward_cuts(None)
-        losses = sum(loss_dict.values())
+        losses = total_loss(loss_dict)
         return losses.detach(), self.net.backward_thunks(self._scaled(losses), cuts)
 
     def _flatten(self, k):
@@ -501,12 +520,16 @@ def _clone_targets(pt):
     out = PreparedTargets(list(pt))
     out.edge = tuple(t.clone() for t in pt.edge)
     out.loss = (pt.loss[0].clone(), {k: (v.clone() if torch.is_tensor(v) else v) for k, v in pt.loss[1].items()})
+    if getattr(pt, "edge_plan", None) is not None:
+        out.edge_plan = {k: v.clone() for k, v in pt.edge_plan.items()}
     return out
 
 
 def _target_tensors(pt):
     out = list(pt.edge) + [pt.loss[0]]
     out += [v for k, v in sorted(pt.loss[1].items()) if torch.is_tensor(v)]
+    if getattr(pt, "edge_plan", None) is not None:
+        out += [v for k, v in sorted(pt.edge_plan.items())]
     return out
 
 
@@ -517,7 +540,7 @@ def train_step(model, optimizer, images, targets, grad_norm_clip=-1.0, scheduler
         from .. import autograd as AG
         AG.pack_all_weights()                                   # every conv operand of the step from the current parameters, one launch
     loss_dict, log_loss_dict = model(images, targets)
-    losses = sum(loss_dict.values())
+    losses = total_loss(loss_dict)
     optimizer.zero_grad(set_to_none=True)
     (losses if scaler is None else scaler.scale_loss(losses)).backward()
     if scaler is not None:

@@ -29,6 +29,11 @@ def make_loss_evaluator(cfg):
     return Loss_Computation(cfg)
 
 
+class _LossDict(dict):
+    """The loss terms by name; `.total` (optional) = their sum, already on the autograd graph (engine/trainer.total_loss)."""
+    total = None
+
+
 def _wmean(v, w, floor=1.0):
     """sum(w*v)/max(sum(w), floor): mean of v over the rows selected by the 0/1 weights w."""
     return (v * w).sum() / torch.clamp(w.sum(), min=floor)
@@ -363,8 +368,10 @@ class Loss_Computation:
             reg = predictions['reg'].permute(0, 2, 3, 1)                          # the predictor's NHWC map: a view
             terms, logged = AG.ObjectLossFn.apply(reg.float(), rows.to(dev), cfg, 0)
         t = terms.unbind(0)
-        loss_dict = {'hm_loss': self._heat_term(predictions, heat, dev), 'bbox_loss': t[0], 'dims_loss': t[5], 'orien_loss': t[4],
-                     'offset_loss': t[2]}
+        loss_dict = _LossDict({'hm_loss': self._heat_term(predictions, heat, dev), 'bbox_loss': t[0], 'dims_loss': t[5], 'orien_loss': t[4],
+                               'offset_loss': t[2]})
+        if self.separate_trunc_offset and terms.shape[0] == 10:
+            loss_dict.total = terms.sum() + loss_dict['hm_loss']           # every entry of `terms` is one of the dict's terms
         if self.separate_trunc_offset:
             loss_dict['trunc_offset_loss'] = t[3]
         loss_dict.update({'corner_loss': t[6], 'depth_loss': t[1], 'keypoint_loss': t[7], 'keypoint_depth_loss': t[8],

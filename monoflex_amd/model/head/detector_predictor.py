@@ -225,7 +225,7 @@ class _predictor(nn.Module):
                 ops.edge_scatter_add(hm, choff, cout, o, edge_indices, edge_lens, planar=planar if choff == 0 else None)
         return hm
 
-    def forward_train(self, features, edge_indices=None, edge_lens=None, object_rows=None):
+    def forward_train(self, features, edge_indices=None, edge_lens=None, object_rows=None, plan=None):
         """Training form (detector_predictor.py:125-169), unfused and differentiable: per branch
         conv3x3 -> ABN(batch statistics, leaky 0.01) -> one 1x1 conv over the branch's stacked heads; edge fusion
         gathers the two trunks at the border points.  Returns (class logits (B,H,W,ncls), regression (B,H,W,50)).
@@ -233,7 +233,10 @@ class _predictor(nn.Module):
         With `object_rows` (the loss's packed object table, fp32 [N,72]) the regression branches whose activation nothing else
         reads are evaluated at the object centres only (csrc/head_sparse.hip) and the second result is the GATHERED table
         (N,50) -- the rows select_point_of_interest would pick (layers/utils.py:120-145); the class head (dense focal loss) and
-        the 3d_offset head (edge fusion reads its trunk) keep the dense path."""
+        the 3d_offset head (edge fusion reads its trunk) keep the dense path.
+
+        `plan` (`edge_plan`): the index tensors of the edge fusion that are functions of the targets alone, prepared with the batch
+        (engine/trainer.prepare_targets) instead of being rebuilt by ~45 tiny launches inside every step."""
         B, H, W, _ = features.shape
         trunks = [self.class_head] + list(self.reg_features)
         lasts = [[self.class_head[2]]] + [list(h) for h in self.reg_heads]
@@ -255,10 +258,9 @@ class _predictor(nn.Module):
             if edge_indices is None:
                 raise ValueError("edge fusion is enabled: targets must carry edge_indices / edge_len")
             if fuse_nodes:                                   # functions of the targets only, shared by both fusions
-                Lm = edge_indices.shape[1]
-                rm = make_edge_rowmap(edge_indices, H, W).long()                          # rows of positions -1 .. L (replicate padding, k = 3)
-                rowmap, rows_center = rm, rm.view(B, Lm + 2)[:, 1:-1].reshape(-1)
-                valid_l = (torch.arange(Lm, device=features.device).view(1, Lm) < edge_lens.view(B, 1)).float().unsqueeze(-1)
+                if plan is None:
+                    plan = self.edge_plan(edge_indices, edge_lens, None, H, W)
+                rowmap, rows_center, valid_l = plan["rowmap"], plan["rows_center"], plan["valid_l"]
         for bi, (t, heads) in enumerate(zip(trunks, lasts)):
             w = heads[0].weight if len(heads) == 1 else torch.cat([h.weight for h in heads], 0)
             b = heads[0].bias if len(heads) == 1 else torch.cat([h.bias for h in heads], 0)
@@ -330,10 +332,12 @@ class _predictor(nn.Module):
                 # an object centre that is a border pixel receives that pixel's fused edge output (valid border pixels are unique per image):
                 # slot map pixel -> edge position, -1 elsewhere; invalid positions write to a dummy slot
                 Lmax = edge_indices.shape[1]
-                e_idx, hit = edge_position_of_rows(rows, rows_center, valid_l, B, H, W)
+                if "e_idx" not in plan:
+                    plan = dict(plan, **self.edge_plan_rows(rows, rows_center, valid_l, B, H, W))
                 co = o_off.shape[-1]
-                add = o_off.reshape(B * Lmax, co).float()[e_idx.clamp_min(0)] * hit.unsqueeze(1).to(torch.float32)
-                gram_tab = torch.cat((gram_tab[:, :lo_off], gram_tab[:, lo_off:lo_off + co] + add, gram_tab[:, lo_off + co:]), dim=1)
+                # (index_select / index_add: their gradients are one launch each; advanced indexing sorts its indices in the backward pass)
+                add = o_off.reshape(B * Lmax, co).float().index_select(0, plan["e_idx"]) * plan["hit"]
+                gram_tab = gram_tab.index_add(1, plan["off_cols"], add)                       # columns lo_off .. lo_off + co
             return cls, gram_tab
         if gram:
             from monoflex_amd.gram_heads import gram_reg_heads
@@ -349,6 +353,28 @@ class _predictor(nn.Module):
         # the dense 3d_offset head at the centres (index_select: its gradient is one index_add_, no sort as behind advanced indexing)
         off_rows = regs[oi].reshape(-1, regs[oi].shape[-1]).index_select(0, (bidx * H + cy) * W + cx)[:, :n_off]
         return cls, torch.cat((tab[:, :lo], off_rows, tab[:, lo + n_off:]), dim=1)
+
+    def edge_plan(self, edge_indices, edge_lens, object_rows=None, H=None, W=None):
+        """The edge fusion's index tensors, functions of the targets only (static shapes, no host sync): `rowmap` long [B (L + 2)] pixel rows of
+        the sequence positions -1 .. L (replicate padding, k = 3), `rows_center` [B L] the positions 0 .. L - 1, `valid_l` float [B, L, 1] =
+        (l < edge_len[b]); with the loss's object table also `e_idx` / `hit` (`edge_plan_rows`)."""
+        H, W = H or self.output_height, W or self.output_width
+        B, Lm = edge_indices.shape[0], edge_indices.shape[1]
+        rm = make_edge_rowmap(edge_indices, H, W).long()
+        plan = {"rowmap": rm, "rows_center": rm.view(B, Lm + 2)[:, 1:-1].reshape(-1).contiguous(),
+                "valid_l": (torch.arange(Lm, device=rm.device).view(1, Lm) < edge_lens.view(B, 1)).float().unsqueeze(-1)}
+        if object_rows is not None:
+            plan.update(self.edge_plan_rows(object_rows, plan["rows_center"], plan["valid_l"], B, H, W))
+        return plan
+
+    def edge_plan_rows(self, rows, rows_center, valid_l, B, H, W):
+        """`e_idx` long [N]: the flat edge position whose border pixel is object n's centre pixel (0 where none), `hit` float [N, 1]: whether there
+        is one, `off_cols` long [2]: the columns of the regression table the fused 3d_offset output is added to."""
+        e_idx, hit = edge_position_of_rows(rows, rows_center, valid_l, B, H, W)
+        oi, oj = self.offset_index
+        lo = sum(sum(c) for c in self.regression_channel_cfg[:oi]) + sum(self.regression_channel_cfg[oi][:oj])
+        return {"e_idx": e_idx.clamp_min(0), "hit": hit.unsqueeze(1).to(torch.float32),
+                "off_cols": torch.arange(lo, lo + self.trunc_offset_conv[3].out_channels, device=rows.device)}
 
     def _gram_table(self, features, rows, sp, edge_rowmap, oi):
         """All sparse branches in `sp` through monoflex_amd/gram_heads.py: (table (N, 50), the 3d_offset trunk's activation rows at `edge_rowmap`)."""
@@ -366,9 +392,10 @@ class _predictor(nn.Module):
         x = features.permute(0, 2, 3, 1).contiguous()
         ei, el = getattr(targets, "edge", None) or stack_edge_fields(targets, x.device)
         if self.training and object_rows is not None:
-            logits, reg_rows = self.forward_train(x, ei, el, object_rows)
-            cls = torch.sigmoid(logits).clamp(min=1e-4, max=1 - 1e-4)           # (attached: see below)
-            return {'cls': cls.permute(0, 3, 1, 2), 'reg': None, 'reg_rows': reg_rows, 'cls_logits_nhwc': logits}
+            logits, reg_rows = self.forward_train(x, ei, el, object_rows, plan=getattr(targets, "edge_plan", None))
+            # 'cls' (see below) is built when somebody reads it: the fused loss takes the raw logits
+            return _LazyMaps(lambda: torch.sigmoid(logits).clamp(min=1e-4, max=1 - 1e-4).permute(0, 3, 1, 2),
+                             {'reg': None, 'reg_rows': reg_rows, 'cls_logits_nhwc': logits})
         if self.training:
             logits, reg = self.forward_train(x, ei, el)
             # 'cls' keeps the reference's contract (sigmoid_hm of the logits, NCHW, differentiable); this build's loss uses the raw
@@ -379,6 +406,27 @@ class _predictor(nn.Module):
         hm = self.forward_nhwc(x, ei, el)
         cls = torch.sigmoid(hm[..., :self.num_classes]).clamp(min=1e-4, max=1 - 1e-4).permute(0, 3, 1, 2)
         return {'cls': cls, 'reg': hm[..., REG_OFF:REG_OFF + 50].permute(0, 3, 1, 2), 'hm_nhwc': hm, 'cls_planar': self.last_cls_planar}
+
+
+class _LazyMaps(dict):
+    """The predictor's output dict whose 'cls' entry (sigmoid + clamp of the logits, NCHW view: two launches and an autograd branch) is
+    computed on first access."""
+
+    def __init__(self, make_cls, items):
+        super().__init__(items)
+        self._make_cls = make_cls
+
+    def __missing__(self, key):
+        if key != 'cls':
+            raise KeyError(key)
+        self['cls'] = v = self._make_cls()
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key == 'cls' else super().get(key, default)
+
+    def __contains__(self, key):
+        return key == 'cls' or super().__contains__(key)
 
 
 def edge_position_of_rows(rows, rows_center, valid_l, B, H, W):

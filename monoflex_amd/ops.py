@@ -478,6 +478,8 @@ def dcn_ps_pack(p: PackedConv):
 
 def dcn_ps_applies(x, p: PackedConv):
     B, H, W, C = x.shape
+    if getattr(p, "transient", False):                         # training: the projection operand would be re-packed (six launches) every step
+        return False
     return (DCN_PS[0] and x.dtype in (torch.bfloat16, torch.float16) and not p.split and p.kh == 3 and p.kw == 3 and p.stride == 1 and p.pad_h == 1
             and p.dil_w == 1 and p.K_pad == 9 * C and C >= 128 and p.Cout == p.Cout_pad and p.Cout in (64, 128, 256)
             and B * H * W * 9 * p.Cout * 2 <= DCN_PS_MAX_BYTES[0])

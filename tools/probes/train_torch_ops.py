@@ -48,5 +48,5 @@ for ev in prof.events():
     by[k][1] += 1
 tot = sum(v[0] for v in by.values())
 print("torch-native device time in one step: %.0f us" % tot)
-for (name, frame), (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:45]:
+for (name, frame), (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:140]:
     print("%8.1f us %4d  %-28s %s" % (t, n, name, frame))
