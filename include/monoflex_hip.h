@@ -337,6 +337,8 @@ int mfx_pack_conv_weights_batched(const mfx_pack_desc* descs_dev, const long lon
                                   int dtype, void* stream);
 /* out[c] = sum_m x[m*ld + c]  (bias gradients) */
 int mfx_colsum(const void* x, float* out, long M, int C, int ld, int dtype, void* stream);
+/* out[c] += sum_m x[m*ld + c]: the same without the zero fill (a caller that carves many `out` vectors from one arena zeroes the arena once) */
+int mfx_colsum_add(const void* x, float* out, long M, int C, int ld, int dtype, void* stream);
 /* train-mode BatchNorm over [M][C]: per-channel sum and sum of squares (fp32, overwritten) */
 int mfx_bn_stats(const void* x, float* sum, float* sumsq, long M, int C, int dtype, void* stream);
 /* per-channel epilogue of mfx_bn_stats: mean = sum/count, biased var, rstd, scale = gamma*rstd, shift = beta - mean*scale, and
@@ -408,6 +410,11 @@ size_t mfx_dcn_backward_v2_workspace_bytes(int B, int C, int H, int W, int Cout,
 int mfx_dcn_backward_v2(const void* x, const float* offmask, const float* weight_oihw, const void* dy, void* dx,
                         float* d_raw, float* dweight, float* dbias, int B, int C, int H, int W, int Cout, int dtype,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The same with `d_raw` written in the activation dtype when `raw_in_act_dtype` != 0 (16-bit layers: the rows the offset conv's own
+ * backward pass consumes, without the fp32 map and its cast in between; each value is the fp32 result rounded once).  MFX_F32: fp32 either way. */
+int mfx_dcn_backward_v2_rt(const void* x, const float* offmask, const float* weight_oihw, const void* dy, void* dx,
+                           void* d_raw, int raw_in_act_dtype, float* dweight, float* dbias, int B, int C, int H, int W, int Cout, int dtype,
+                           void* workspace, size_t workspace_bytes, void* stream);
 /* Heat-map loss (penalty-reduced focal loss, model/layers/focal_loss.py:29-55 on sigmoid_hm(logits), layers/utils.py:39-42)
  * in one pass: logits fp32 NHWC (B,H,W,ncls), target fp32 NCHW (B,ncls,H,W) -> sums2 = [loss_sum, num_pos] (overwritten) and
  * dlogits (B,H,W,ncls) = d(loss_sum)/d(logit), the clamp of the sigmoid included. */

@@ -16,6 +16,7 @@ Gradient recipes (DESIGN.md section 4.6 has the kernels):
   loss      FocalLossFn (heat map), ObjectLossFn (the nine per-object terms, forward-mode gradient rows)
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -102,9 +103,61 @@ def _wgrad(x, dy, kh, kw, stride, pad, Ho, Wo, Ck=None, x_pixstride=None, in_hw=
     return dw
 
 
+class _SumArena:
+    """Zeroed fp32 scratch the bias-gradient column sums of one backward pass are carved from: ONE fill at the top of the pass instead of one
+    per biased conv (23 launches of a training step).  Opt-in (`sum_arena`: engine/trainer.GraphedTrainStep, which owns the step's gradients):
+    the vectors handed out stay valid until the next `begin()` on the device -- the same lifetime as the gradients of a captured step."""
+    ELEMS = 1 << 15
+
+    def __init__(self):
+        self.on = False
+        self.bufs = {}              # device -> [buffer, floats used]
+
+    def begin(self, device):
+        b = self.bufs.get(device)
+        if b is None:
+            if torch.cuda.is_current_stream_capturing():
+                return
+            b = self.bufs[device] = [torch.zeros(self.ELEMS, dtype=torch.float32, device=device), 0]
+        b[0].zero_()
+        b[1] = 0
+
+    def take(self, device, n):
+        b = self.bufs.get(device)
+        if not self.on or b is None or b[1] + n > self.ELEMS:
+            return None
+        o = b[1]
+        b[1] += (n + 3) // 4 * 4
+        return b[0][o:o + n]
+
+
+SUM_ARENA = _SumArena()
+
+
+class sum_arena:
+    """Context: the backward passes inside take their bias-gradient sums from SUM_ARENA (zeroed here, once)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def __enter__(self):
+        self.prev = SUM_ARENA.on
+        if self.device.type == "cuda":
+            SUM_ARENA.on = True
+            SUM_ARENA.begin(self.device)
+        return self
+
+    def __exit__(self, *a):
+        SUM_ARENA.on = self.prev
+
+
 def _colsum(t):
     C = t.shape[-1]
     M = t.numel() // C
+    out = SUM_ARENA.take(t.device, C) if SUM_ARENA.on else None
+    if out is not None:
+        L.check(L.load().mfx_colsum_add(_ptr(t), _ptr(out), M, C, C, _dt(t.dtype), _stream()), "mfx_colsum_add")
+        return out
     out = torch.empty(C, dtype=torch.float32, device=t.device)
     L.check(L.load().mfx_colsum(_ptr(t), _ptr(out), M, C, C, _dt(t.dtype), _stream()), "mfx_colsum")
     return out
@@ -836,6 +889,7 @@ class DCNFn(Function):
         return dx.to(xdtype), dom, dw.to(weight.dtype), db, None, None, None, None
 
 
+_RAW16 = [os.environ.get("MFX_DCN_RAW16", "1") != "0"]     # the DCN backward's offset / mask gradient rows in the activation type (0: fp32 + a cast, A/B)
 _DCN_BWD_V1 = [False]          # tests: force the first-generation (global-atomics) backward for comparison
 
 
@@ -878,12 +932,13 @@ class DCNModuleFn(Function):
         dt = _dt(x.dtype)
         ws = ops._workspace(lib_.mfx_dcn_backward_v2_workspace_bytes(B, C, H, W, Cout, dt), x.device)
         dx = torch.empty_like(x)
-        draw = torch.empty_like(om)
+        # the raw offset / mask gradient in the activation type: what the offset conv's backward consumes (16-bit layers: no fp32 map, no cast)
+        draw = torch.empty(om.shape, dtype=x.dtype if _RAW16[0] else torch.float32, device=x.device)
         dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
         wc = _c(weight.detach() if weight.dtype == torch.float32 else weight.detach().float())
-        L.check(lib_.mfx_dcn_backward_v2(_ptr(x), _ptr(om), _ptr(wc), _ptr(dy if dy.dtype == x.dtype else dy.to(x.dtype)), _ptr(dx), _ptr(draw),
-                                         _ptr(dw), _ptr(db), B, C, H, W, Cout, dt, _ptr(ws), ws.numel(), _stream()), "mfx_dcn_backward_v2")
+        L.check(lib_.mfx_dcn_backward_v2_rt(_ptr(x), _ptr(om), _ptr(wc), _ptr(dy if dy.dtype == x.dtype else dy.to(x.dtype)), _ptr(dx), _ptr(draw), int(_RAW16[0]),
+                                            _ptr(dw), _ptr(db), B, C, H, W, Cout, dt, _ptr(ws), ws.numel(), _stream()), "mfx_dcn_backward_v2_rt")
         dx, dw_off, db_off = _conv_backward(x, w_off, draw, 1, 1, True, ctx.n_off, (True, True, True), res=dx)
         return dx, dw_off, db_off, dw if weight.dtype == torch.float32 else dw.to(weight.dtype), db
 

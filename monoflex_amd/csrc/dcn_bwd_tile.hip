@@ -66,7 +66,13 @@ constexpr int BT_FCAP = 512;   // far corners staged per workgroup before one gl
 constexpr int BT_CH = BT_TH + 2 * BT_D, BT_CW = BT_TW + 2 * BT_D;        // candidate window (24 x 32 pixels)
 
 struct BtGeom { int B, H, W, C, tiles_x, tiles_y, Kp, CS, nslices, dbg;
-                int raw_mask; };   // 1: d_raw[18 + tap] = d loss / d mask (the `_ext` contract: the mask is an INPUT there); 0: through the sigmoid of the mask logit
+                int raw_mask;      // 1: d_raw[18 + tap] = d loss / d mask (the `_ext` contract: the mask is an INPUT there); 0: through the sigmoid of the mask logit
+                int raw16; };      // 1: d_raw rows are written in the activation type T (16-bit layers: what the offset conv's backward consumes), 0: fp32
+
+// one channel of a pixel's d_raw row (32 channels per pixel)
+template <typename T> __device__ __forceinline__ void raw_put(float* graw, int raw16, size_t idx, float v) {
+    if (raw16) ElemTraits<T>::store(reinterpret_cast<T*>(graw) + idx, v); else graw[idx] = v;
+}
 
 struct SampGeo { int h0, w0; float lh, lw, mask; int inside; };
 
@@ -84,6 +90,13 @@ __device__ __forceinline__ SampGeo samp_geo(const BtGeom& g, const float* __rest
     s.w0 = (int)fminf(fmaxf(wf, -4.f), 32000.f);
     s.mask = om_row[18 + tap];
     return s;
+}
+
+// two transposed 8-byte LDS reads (ds_read_b64_tr_b16: the 16-bit elements of a 16-lane group's rows come back transposed), at `a` and `a + 512`
+__device__ __forceinline__ u32x4 bt_tr2(uint32_t a) {
+    uint64_t l, h;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l), "=&v"(h) : "v"(a) : "memory");
+    return u32x4{(uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32)};
 }
 
 // sum over the LPS (8 or 16) consecutive lanes that share one sample, on the VALU's DPP path (no LDS crossbar):
@@ -515,10 +528,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_kernel(const T* __restrict
         }
         gh = bt_group_sum<LPS>(gh); gw = bt_group_sum<LPS>(gw); gm = bt_group_sum<LPS>(gm);
         if (cl == 0 && q0.ok) {
-            float* o = graw + q0.m * 32;
-            o[2 * q0.tap] = gh * q0.mask; o[2 * q0.tap + 1] = gw * q0.mask;
-            o[18 + q0.tap] = g.raw_mask ? gm : gm * q0.mask * (1.f - q0.mask);                   // through the sigmoid of the mask logit
-            if (q0.tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
+            const size_t o = (size_t)q0.m * 32;
+            raw_put<T>(graw, g.raw16, o + 2 * q0.tap, gh * q0.mask); raw_put<T>(graw, g.raw16, o + 2 * q0.tap + 1, gw * q0.mask);
+            raw_put<T>(graw, g.raw16, o + 18 + q0.tap, g.raw_mask ? gm : gm * q0.mask * (1.f - q0.mask));      // through the sigmoid of the mask logit
+            if (q0.tap == 0) {
+#pragma unroll
+                for (int z = 27; z < 32; ++z) raw_put<T>(graw, g.raw16, o + z, 0.f);
+            }
         }
         q0 = q1; r0 = r1; pre1 = pre2;
     }
@@ -560,11 +576,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const T* __re
     const int l16 = lane & 15, gq = lane >> 4;
     const uint32_t lane_off = (uint32_t)((4 * gq + (l16 >> 2)) * 32 + (l16 & 3) * 8);
     const uint32_t lds_a = (uint32_t)(uintptr_t)lds;
-    auto tr2 = [](uint32_t a) {
-        uint64_t l, h;
-        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l), "=&v"(h) : "v"(a) : "memory");
-        return u32x4{(uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32)};
-    };
+    auto tr2 = [](uint32_t a) { return bt_tr2(a); };
 
     // The lane's samples form one stream over (chunk, it = 0..2), software-pipelined as in dcn_bwd_sample_kernel: while sample i
     // is blended, the five gathers of sample i+1 are in flight and the raw offsets of sample i+2 are being fetched -- also across
@@ -648,9 +660,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_kernel(const T* __re
                 *reinterpret_cast<u32x4*>(stage + (tl * 4 + (cl >> 1)) * SF_TILE + l0.px * 32 + (cl & 1) * 16) = ElemTraits<T>::pack(cv);
                 gh = bt_group_sum<8>(gh); gw = bt_group_sum<8>(gw); gm = bt_group_sum<8>(gm);
                 if (cl == 0) {
-                    float* o = graw + l0.m * 32;
-                    o[2 * l0.tap] = gh * e0.mask; o[2 * l0.tap + 1] = gw * e0.mask; o[18 + l0.tap] = g.raw_mask ? gm : gm * e0.mask * (1.f - e0.mask);
-                    if (l0.tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
+                    const size_t o = (size_t)l0.m * 32;
+                    raw_put<T>(graw, g.raw16, o + 2 * l0.tap, gh * e0.mask); raw_put<T>(graw, g.raw16, o + 2 * l0.tap + 1, gw * e0.mask);
+                    raw_put<T>(graw, g.raw16, o + 18 + l0.tap, g.raw_mask ? gm : gm * e0.mask * (1.f - e0.mask));
+                    if (l0.tap == 0) {
+#pragma unroll
+                        for (int z = 27; z < 32; ++z) raw_put<T>(graw, g.raw16, o + z, 0.f);
+                    }
                 }
             }
             l0 = l1; e0 = e1; r0 = r1; l1 = l2; p1 = p2;
@@ -1026,11 +1042,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_fly_kernel(const T* 
     const int l16 = lane & 15, gq = lane >> 4;
     const uint32_t lane_off = (uint32_t)((4 * gq + (l16 >> 2)) * 32 + (l16 & 3) * 8);
     const uint32_t lds_a = (uint32_t)(uintptr_t)lds;
-    auto tr2 = [](uint32_t a) {
-        uint64_t l, h;
-        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l), "=&v"(h) : "v"(a) : "memory");
-        return u32x4{(uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32)};
-    };
+    auto tr2 = [](uint32_t a) { return bt_tr2(a); };
     // W fragments of this wave's 48 (tap, c) rows: A operand, row n = 48 wv + 16 j + l16 of the tap group, k = o
     u32x4 wfr[3][2];
 #pragma unroll
@@ -1164,9 +1176,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_fly_kernel(const T* 
                 *reinterpret_cast<u32x4*>(stage + (tl * 4 + (cl >> 1)) * SF_TILE + l0.px * 32 + (cl & 1) * 16) = ElemTraits<T>::pack(cv);
                 gh = bt_group_sum<8>(gh); gw = bt_group_sum<8>(gw); gm = bt_group_sum<8>(gm);
                 if (cl == 0) {
-                    float* o = graw + l0.m * 32;
-                    o[2 * l0.tap] = gh * e0.mask; o[2 * l0.tap + 1] = gw * e0.mask; o[18 + l0.tap] = g.raw_mask ? gm : gm * e0.mask * (1.f - e0.mask);
-                    if (l0.tap == 0) { o[27] = 0.f; o[28] = 0.f; o[29] = 0.f; o[30] = 0.f; o[31] = 0.f; }
+                    const size_t o = (size_t)l0.m * 32;
+                    raw_put<T>(graw, g.raw16, o + 2 * l0.tap, gh * e0.mask); raw_put<T>(graw, g.raw16, o + 2 * l0.tap + 1, gw * e0.mask);
+                    raw_put<T>(graw, g.raw16, o + 18 + l0.tap, g.raw_mask ? gm : gm * e0.mask * (1.f - e0.mask));
+                    if (l0.tap == 0) {
+#pragma unroll
+                        for (int z = 27; z < 32; ++z) raw_put<T>(graw, g.raw16, o + z, 0.f);
+                    }
                 }
             }
             l0 = l1; e0 = e1; r0 = r1; l1 = l2; p1 = p2;
@@ -1217,7 +1233,7 @@ static BtLayout bt_layout(int B, int C, int H, int W, int Cout, int es) {
 template <typename T>
 static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* weight, const T* dy, T* dx, float* d_raw,
                                 float* dweight, float* dbias, int B, int C, int H, int W, int Cout, void* workspace,
-                                size_t workspace_bytes, void* stream, int raw_mask = 0) {
+                                size_t workspace_bytes, void* stream, int raw_mask = 0, int raw16 = 0) {
     constexpr int es = (int)sizeof(T);
     constexpr int dt = ElemTraits<T>::DT;                    // MFX_F32 / MFX_BF16 / MFX_F16
     const BtLayout L = bt_layout(B, C, H, W, Cout, es);
@@ -1237,7 +1253,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     }
     BtGeom g;
     g.B = B; g.H = H; g.W = W; g.C = C; g.tiles_x = (W + BT_TW - 1) / BT_TW; g.tiles_y = (H + BT_TH - 1) / BT_TH; g.Kp = K;
-    g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg; g.raw_mask = raw_mask;
+    g.CS = C >= 128 ? 128 : 64; g.nslices = C / g.CS; g.dbg = g_opt_dcn_bt_dbg; g.raw_mask = raw_mask; g.raw16 = (raw16 && es == 2) ? 1 : 0;
     if constexpr (!std::is_same<T, float>::value) {
         // gcol-free form (third generation): 64 -> 64, 16-bit, the shapes the fused sample + weight-gradient kernel takes
         const long nchunks = M / SF_PX;
@@ -1352,18 +1368,30 @@ extern "C" size_t mfx_dcn_backward_v2_workspace_bytes(int B, int C, int H, int W
     return bt_layout(B, C, H, W, Cout, dtype == MFX_F32 ? 4 : 2).total;
 }
 
-extern "C" int mfx_dcn_backward_v2(const void* x, const float* offmask, const float* weight_oihw, const void* dy, void* dx,
-                                   float* d_raw, float* dweight, float* dbias, int B, int C, int H, int W, int Cout, int dtype,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
+static int dcn_backward_v2_entry(const void* x, const float* offmask, const float* weight_oihw, const void* dy, void* dx, void* d_raw, int raw16,
+                                 float* dweight, float* dbias, int B, int C, int H, int W, int Cout, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !offmask || !weight_oihw || !dy || !dx || !d_raw || !dweight || !dbias) return mfx_fail(MFX_ERR_ARG, "dcn_backward_v2: null pointer");
     if (C < 64 || (C & (C - 1)) || Cout < 64 || (Cout & (Cout - 1))) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_backward_v2: C and Cout must be powers of two >= 64");
     if (H >= 4096 || W >= 4096 || (long)B * H * W >= (1L << 31) / 32) return mfx_fail(MFX_ERR_UNSUPPORTED, "dcn_backward_v2: map too large");
     if (B * H * W == 0) return MFX_OK;
+    float* dr = reinterpret_cast<float*>(d_raw);
     if (dtype == MFX_F32)
-        return dcn_backward_v2_impl<float>((const float*)x, offmask, weight_oihw, (const float*)dy, (float*)dx, d_raw, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream);
+        return dcn_backward_v2_impl<float>((const float*)x, offmask, weight_oihw, (const float*)dy, (float*)dx, dr, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream);
     if (dtype == MFX_BF16)
-        return dcn_backward_v2_impl<bf16_t>((const bf16_t*)x, offmask, weight_oihw, (const bf16_t*)dy, (bf16_t*)dx, d_raw, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream);
+        return dcn_backward_v2_impl<bf16_t>((const bf16_t*)x, offmask, weight_oihw, (const bf16_t*)dy, (bf16_t*)dx, dr, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream, 0, raw16);
     if (dtype == MFX_F16)
-        return dcn_backward_v2_impl<half_t>((const half_t*)x, offmask, weight_oihw, (const half_t*)dy, (half_t*)dx, d_raw, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream);
+        return dcn_backward_v2_impl<half_t>((const half_t*)x, offmask, weight_oihw, (const half_t*)dy, (half_t*)dx, dr, dweight, dbias, B, C, H, W, Cout, workspace, workspace_bytes, stream, 0, raw16);
     return mfx_fail(MFX_ERR_ARG, "dcn_backward_v2: bad dtype");
+}
+
+extern "C" int mfx_dcn_backward_v2(const void* x, const float* offmask, const float* weight_oihw, const void* dy, void* dx,
+                                   float* d_raw, float* dweight, float* dbias, int B, int C, int H, int W, int Cout, int dtype,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    return dcn_backward_v2_entry(x, offmask, weight_oihw, dy, dx, d_raw, 0, dweight, dbias, B, C, H, W, Cout, dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mfx_dcn_backward_v2_rt(const void* x, const float* offmask, const float* weight_oihw, const void* dy, void* dx,
+                                      void* d_raw, int raw_in_act_dtype, float* dweight, float* dbias, int B, int C, int H, int W, int Cout, int dtype,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    return dcn_backward_v2_entry(x, offmask, weight_oihw, dy, dx, d_raw, raw_in_act_dtype != 0, dweight, dbias, B, C, H, W, Cout, dtype, workspace, workspace_bytes, stream);
 }

@@ -1201,6 +1201,11 @@ extern "C" int mfx_colsum(const void* x, float* out, long M, int C, int ld, int 
     return mfx_internal_colsum_add(x, out, M, C, ld, dtype, stream);
 }
 
+extern "C" int mfx_colsum_add(const void* x, float* out, long M, int C, int ld, int dtype, void* stream) {
+    if (!x || !out) return mfx_fail(MFX_ERR_ARG, "colsum_add: null pointer");
+    return mfx_internal_colsum_add(x, out, M, C, ld, dtype, stream);
+}
+
 int mfx_internal_colsum_add(const void* x, float* out, long M, int C, int ld, int dtype, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (M == 0) return MFX_OK;

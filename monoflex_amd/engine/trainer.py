@@ -314,8 +314,10 @@ class GraphedTrainStep:
             with torch.cuda.graph(gk, pool=None if k == 0 else g0.pool(), capture_error_mode="thread_local"):
                 if k == 0:
                     self.loss, thunks = self._forward_cut()
+                self._arena_piece = k
                 with self._side_wgrads():
                     thunks[k]()
+                self._arena_piece = 0
                 self._flatten(k)
             self.graphs.append(gk)
         self._point_grads_at_views()
@@ -337,9 +339,21 @@ class GraphedTrainStep:
             def __enter__(self_):
                 self_.prev = AG.WGRAD_SIDE[0]
                 AG.WGRAD_SIDE[0] = bool(self.images.is_cuda)
+                # ... and the bias-gradient sums of the pass come from one arena zeroed here.  One arena state per STEP: the pieces of a split
+                # backward continue in it (`begin` only in front of the first)
+                self_.arena = None
+                if self.images.is_cuda and getattr(self, "_arena_piece", 0) == 0:
+                    self_.arena = AG.sum_arena(self.images.device)
+                    self_.arena.__enter__()
+                elif self.images.is_cuda:
+                    self_.was_on, AG.SUM_ARENA.on = AG.SUM_ARENA.on, True
 
             def __exit__(self_, *a):
                 AG.WGRAD_SIDE[0] = self_.prev
+                if self_.arena is not None:
+                    self_.arena.__exit__(*a)
+                elif self.images.is_cuda:
+                    AG.SUM_ARENA.on = self_.was_on
         return _Ctx()
 
     def _fwd_bwd(self):
@@ -441,8 +455,10 @@ class GraphedTrainStep:
             return loss
         loss, thunks = self._forward_cut()
         for k, t in enumerate(thunks):
+            self._arena_piece = k
             with self._side_wgrads():
                 t()
+            self._arena_piece = 0
             self._flatten(k)
             self._exchange(k)
         self._finish_exchange()

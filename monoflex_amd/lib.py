@@ -143,6 +143,7 @@ SYMBOLS = {
     "mfx_conv_wgrad_oihw": (_I, [_P, _P, _P] + [_I] * 17 + [_P, _S, _P]),
     "mfx_pack_conv_weight": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
     "mfx_colsum": (_I, [_P, _P, ctypes.c_long, _I, _I, _I, _P]),
+    "mfx_colsum_add": (_I, [_P, _P, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_stats": (_I, [_P, _P, _P, ctypes.c_long, _I, _I, _P]),
     "mfx_bn_finalize": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, ctypes.c_long, _P, _P, _P, _P, _I, _P]),
     "mfx_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, ctypes.c_long, _I, _I, _I, _P]),
@@ -170,6 +171,7 @@ SYMBOLS = {
     "mfx_dcn_backward_nhwc_bf16": (_I, [_P] * 8 + [_I] * 10 + [_P, _S, _P]),
     "mfx_dcn_backward_v2_workspace_bytes": (_S, [_I] * 6),
     "mfx_dcn_backward_v2": (_I, [_P] * 8 + [_I] * 6 + [_P, _S, _P]),
+    "mfx_dcn_backward_v2_rt": (_I, [_P] * 6 + [_I] + [_P] * 2 + [_I] * 6 + [_P, _S, _P]),
     "mfx_focal_loss": (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "mfx_object_loss": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, ctypes.POINTER(ObjectLossCfg), _P, _P, _P]),
     "mfx_object_loss_backward": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),

@@ -315,3 +315,25 @@ def test_forward_surface_matches_reference_contract():
     assert vis["heat_map"].shape == (1, 3, 16, 32)
     with pytest.raises(RuntimeError):
         m(img.cpu(), [make_test_target(S.synthetic_target(32, 16))])       # no CPU fallback
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16x2"])
+def test_inference_step_is_bitwise_repeatable(dtype):
+    """No kernel of the forward + decode path accumulates with atomics, so five launches on the same inputs must agree bit for bit in every written
+    channel of the head map, in the top-K table and in the decoded boxes; a difference is a race or an uncovered hardware hazard in some kernel
+    (r06: tools/probes/infer_repeat.py runs the same check over all modes and batch sizes)."""
+    import bench
+    from monoflex_amd import synthetic as S
+    from monoflex_amd.structures.params_3d import make_test_target
+    dev = torch.device("cuda:0")
+    model, _, _ = bench.build_model(dtype, dev)
+    B = 2
+    images = bench.bench_images(B, 0, dev)
+    tg = model.device_targets([make_test_target(S.synthetic_target(320, 96)) for _ in range(B)], dev)
+    with torch.no_grad():
+        det0, topk0, valid0, hm0 = [t.clone() for t in model.detect_device(images, *tg)]
+        for _ in range(4):
+            det, topk, valid, hm = model.detect_device(images, *tg)
+            torch.cuda.synchronize()
+            assert torch.equal(hm[..., :3], hm0[..., :3]) and torch.equal(hm[..., 8:58], hm0[..., 8:58])
+            assert torch.equal(topk, topk0) and torch.equal(valid, valid0) and torch.equal(det[valid0.bool()], det0[valid0.bool()])

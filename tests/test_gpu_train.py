@@ -2,6 +2,7 @@
 reference's layer (nn.Conv2d / BatchNorm2d / MaxPool2d / ConvTranspose2d / the oracle's DCNv2 restatement), then the
 whole network (train-mode BN) against the CPU oracle under a fixed linear surrogate loss.  fp32; tolerances are
 relative to the largest gradient entry of each tensor."""
+import ctypes
 import os
 
 import numpy as np
@@ -1005,6 +1006,92 @@ def test_dcn_tile_owned_backward_vs_oracle(cin, cout, H, W, off_std, dtype):
     if not bf:                                                   # fp32: both generations are exact up to summation order
         for n, a, b_ in zip(names, got["v2"], got["v1"]):
             assert _rel(a, b_) < 3e-4, (n, _rel(a, b_))
+
+
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+@pytest.mark.parametrize("C,Cout,H,W,fly", [(64, 64, 32, 64, 1), (64, 64, 32, 64, 0), (128, 64, 12, 40, 0)])
+def test_dcn_backward_raw_gradient_in_the_activation_type(C, Cout, H, W, fly, half):
+    """mfx_dcn_backward_v2_rt with `raw_in_act_dtype` (r06): the offset / mask gradient rows written in the 16-bit activation type are the fp32 rows
+    of mfx_dcn_backward_v2 rounded once -- bit for bit what the cast in between produced -- for the three kernels that write them (gcol-free fused
+    sample + weight gradient, the fused kernel behind a d(columns) GEMM, the plain sample kernel of the wide layers); the other outputs are the same call."""
+    from monoflex_amd import lib as L
+    lib_ = L.load()
+    dt = DT[half]
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    x = torch.randn(B, H, W, C, generator=g).to(DEV).to(dt)
+    om = torch.zeros(B, H, W, 32)
+    om[..., :18] = torch.randn(B, H, W, 18, generator=g) * 2.5
+    om[..., 18:27] = torch.sigmoid(torch.randn(B, H, W, 9, generator=g))
+    om = om.to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * 0.05).to(DEV)
+    dy = torch.randn(B, H, W, Cout, generator=g).to(DEV).to(dt)
+    code = L.MFX_BF16 if half == "bf16" else L.MFX_F16
+    nws = lib_.mfx_dcn_backward_v2_workspace_bytes(B, C, H, W, Cout, code)
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())                                      # noqa: E731
+    outs = {}
+    try:
+        L.check(lib_.mfx_set_option(b"dcn_bt_fuse_min_chunks", 1), "opt")
+        L.check(lib_.mfx_set_option(b"dcn_bt_fly", fly), "opt")
+        for raw16 in (0, 1):
+            dx = torch.empty_like(x)
+            draw = torch.full((B, H, W, 32), float("nan"), dtype=dt if raw16 else torch.float32, device=DEV)
+            dw, db = torch.empty(Cout, C, 3, 3, device=DEV), torch.empty(Cout, device=DEV)
+            L.check(lib_.mfx_dcn_backward_v2_rt(ptr(x), ptr(om), ptr(w), ptr(dy), ptr(dx), ptr(draw), raw16, ptr(dw), ptr(db), B, C, H, W, Cout, code,
+                                                ptr(ws), nws, None), "mfx_dcn_backward_v2_rt")
+            torch.cuda.synchronize()
+            outs[raw16] = (draw, dw, db)
+    finally:
+        L.check(lib_.mfx_set_option(b"dcn_bt_fuse_min_chunks", 1024), "opt")
+        L.check(lib_.mfx_set_option(b"dcn_bt_fly", 1), "opt")
+    assert outs[0][0].dtype == torch.float32 and outs[1][0].dtype == dt
+    assert torch.equal(outs[0][0].to(dt), outs[1][0])
+    assert bool((outs[1][0][..., 27:] == 0).all()) and float(outs[1][0].float().abs().max()) > 0
+    assert _rel(outs[1][1], outs[0][1]) < 1e-5 and _rel(outs[1][2], outs[0][2]) < 1e-5
+
+
+@pytest.mark.parametrize("form", ["fly", "fused", "unfused"])
+def test_dcn_backward_is_repeatable(form):
+    """The tile-owned DCN backward launched five times on the same inputs (64 -> 64 @ 2 x 96 x 320, bf16: the shape of the training step's five
+    full-resolution layers): the offset / mask gradient rows and the weight gradient carry no atomics, so every launch must produce the same BITS.
+    r06 found them differing run to run in ~0.03 % of the samples (lanes 48..63 of a wave; up to 20 % of an entry) with the SLP-vectorised
+    packed-fp32 code of that translation unit -- build.py compiles it with -fno-slp-vectorize since (profiles/r06_dcnbwd_repeatability.md).
+    grad_input is exempt: its far corners are added with packed 16-bit atomics (arrival-order rounding)."""
+    from monoflex_amd import lib as L
+    lib_ = L.load()
+    dt, code = torch.bfloat16, L.MFX_BF16
+    g = torch.Generator().manual_seed(5)
+    B, C, Cout, H, W = 2, 64, 64, 96, 320
+    x = torch.randn(B, H, W, C, generator=g).to(DEV).to(dt)
+    om = torch.zeros(B, H, W, 32)
+    om[..., :18] = torch.randn(B, H, W, 18, generator=g) * 1.5
+    om[..., 18:27] = torch.sigmoid(torch.randn(B, H, W, 9, generator=g))
+    om = om.to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * 0.05).to(DEV)
+    dy = torch.randn(B, H, W, Cout, generator=g).to(DEV).to(dt)
+    nws = lib_.mfx_dcn_backward_v2_workspace_bytes(B, C, H, W, Cout, code)
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())                                      # noqa: E731
+    runs = []
+    try:
+        L.check(lib_.mfx_set_option(b"dcn_bt_fuse_wgrad", 0 if form == "unfused" else 1), "opt")
+        L.check(lib_.mfx_set_option(b"dcn_bt_fly", 1 if form == "fly" else 0), "opt")
+        for _ in range(5):
+            dx = torch.empty_like(x)
+            draw = torch.zeros((B, H, W, 32), dtype=dt, device=DEV)
+            dw, db = torch.empty(Cout, C, 3, 3, device=DEV), torch.empty(Cout, device=DEV)
+            L.check(lib_.mfx_dcn_backward_v2_rt(ptr(x), ptr(om), ptr(w), ptr(dy), ptr(dx), ptr(draw), 1, ptr(dw), ptr(db), B, C, H, W, Cout, code,
+                                                ptr(ws), nws, None), "mfx_dcn_backward_v2_rt")
+            torch.cuda.synchronize()
+            runs.append((draw, dw))
+    finally:
+        L.check(lib_.mfx_set_option(b"dcn_bt_fuse_wgrad", 1), "opt")
+        L.check(lib_.mfx_set_option(b"dcn_bt_fly", 1), "opt")
+    for draw, dw in runs[1:]:
+        assert torch.equal(draw, runs[0][0]), "offset / mask gradient rows differ between launches: %d entries" % int((draw != runs[0][0]).sum())
+        if form != "unfused":                                    # (the unfused form's weight-gradient GEMM may add its slabs with atomics)
+            assert torch.equal(dw, runs[0][1]), "weight gradient differs between launches: %d entries" % int((dw != runs[0][1]).sum())
 
 
 @pytest.mark.parametrize("half", ["bf16", "fp16"])
