@@ -335,6 +335,28 @@ typedef struct mfx_pack_desc {
 } mfx_pack_desc;
 int mfx_pack_conv_weights_batched(const mfx_pack_desc* descs_dev, const long long* prefix_dev, int n, long long total_chunks,
                                   int dtype, void* stream);
+/* AdamW over every parameter tensor in one launch (csrc/adamw.hip; reference solver/__init__.py:10-60 builds torch.optim.AdamW, whose step this
+ * replaces on the device path: engine/trainer.py:121).  fp32 tensors; `descs_dev` / `prefix_dev` / `groups_dev` live on the device: tensor i owns the
+ * chunks [prefix[i], prefix[i+1]) of mfx_adamw_chunk_elems() elements, prefix has n + 1 entries.  Arithmetic of torch's `_fused_adamw_` (capturable):
+ * step counters (fp32 device scalars, one per tensor) are advanced first, learning rates are device scalars, bias corrections in double, decoupled
+ * weight decay.  `found_inf` (device fp32 scalar or NULL): when non-zero the call changes nothing (the fp16 loss scaler's skipped step). */
+typedef struct mfx_adamw_desc {
+    void* p;                      /* parameter, updated in place */
+    const void* g;                /* gradient */
+    void* m;                      /* exp_avg */
+    void* v;                      /* exp_avg_sq */
+    float* step;                  /* step counter (device scalar) */
+    long long numel;
+    int group;                    /* index into the group table */
+    int pad_;
+} mfx_adamw_desc;
+typedef struct mfx_adamw_group {
+    const float* lr;              /* device scalar */
+    float beta1, beta2, eps, weight_decay;
+} mfx_adamw_group;
+int mfx_adamw_chunk_elems(void);
+int mfx_adamw_multi(const mfx_adamw_desc* descs_dev, const long long* prefix_dev, int n, long long total_chunks,
+                    const mfx_adamw_group* groups_dev, const float* found_inf, void* stream);
 /* out[c] = sum_m x[m*ld + c]  (bias gradients) */
 int mfx_colsum(const void* x, float* out, long M, int C, int ld, int dtype, void* stream);
 /* out[c] += sum_m x[m*ld + c]: the same without the zero fill (a caller that carves many `out` vectors from one arena zeroes the arena once) */

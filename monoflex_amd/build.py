@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libmonoflex_hip.so")
-SOURCES = ["capi.hip", "conv_kernels.hip", "conv_halo.hip", "conv_cw.hip", "conv_cws.hip", "misc_kernels.hip", "stem.hip", "f1_fused.hip", "heads.hip", "decode.hip", "dcn_wave.hip", "dcn_patch.hip", "dcn_lds.hip", "dcn_ps.hip", "gemm_as.hip", "dcn_ext.hip", "dcn_bwd.hip", "dcn_bwd_tile.hip", "train_kernels.hip", "wgrad_tr.hip", "loss_kernels.hip", "head_sparse.hip", "gram_heads.hip", "kitti_encode.hip", "kitti_eval.hip"]
+SOURCES = ["capi.hip", "conv_kernels.hip", "conv_halo.hip", "conv_cw.hip", "conv_cws.hip", "misc_kernels.hip", "stem.hip", "f1_fused.hip", "heads.hip", "decode.hip", "dcn_wave.hip", "dcn_patch.hip", "dcn_lds.hip", "dcn_ps.hip", "gemm_as.hip", "dcn_ext.hip", "dcn_bwd.hip", "dcn_bwd_tile.hip", "train_kernels.hip", "adamw.hip", "wgrad_tr.hip", "loss_kernels.hip", "head_sparse.hip", "gram_heads.hip", "kitti_encode.hip", "kitti_eval.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("MFX_PROBES") == "1":      # probe build: compiles the timing-probe switches in (options heads_dbg / dcn_bt_dbg: wrong results by design)
     FLAGS.append("-DMFX_PROBES")

@@ -10,6 +10,8 @@ import os
 
 import torch
 
+from ..solver import finish_capture, optimizer_step
+
 DEAD_PARAMETER_SUFFIXES = ("base.level3.project.0.weight", "base.level3.project.1.weight", "base.level3.project.1.bias",
                            "base.level4.project.0.weight", "base.level4.project.1.weight", "base.level4.project.1.bias")
 
@@ -268,6 +270,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         try:
             self._capture()
+            finish_capture(self.optimizer)                    # (the one-launch AdamW's pointer tables: solver.MultiTensorAdamW)
         finally:
             self._restore_state(snap)
             torch.cuda.synchronize()
@@ -374,7 +377,7 @@ class GraphedTrainStep:
         if self.scaler is not None:
             self.scaler.unscale_([self.flat] if self.flat is not None else [p.grad for p in self.net.parameters() if p.grad is not None])
         self._clip()
-        self.optimizer.step()
+        optimizer_step(self.optimizer)
         if self.scaler is not None:
             self.scaler.update()
 
@@ -563,7 +566,7 @@ def train_step(model, optimizer, images, targets, grad_norm_clip=-1.0, scheduler
         scaler.unscale_([p.grad for p in model.parameters() if p.grad is not None])
     if grad_norm_clip > 0:
         torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], grad_norm_clip)
-    optimizer.step()
+    optimizer_step(optimizer)
     if scaler is not None:
         scaler.update()
     if scheduler is not None:

@@ -70,6 +70,15 @@ class KittiEvalDesc(ctypes.Structure):
         [(n, c_int) for n in ("B", "n_gt", "n_dt", "num_classes", "num_k", "compute_aos")] + [("n_pairs", ctypes.c_int64)]
 
 
+class AdamWDesc(ctypes.Structure):                              # mfx_adamw_desc
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("step", c_void_p), ("numel", ctypes.c_longlong),
+                ("group", c_int), ("pad_", c_int)]
+
+
+class AdamWGroup(ctypes.Structure):                             # mfx_adamw_group
+    _fields_ = [("lr", c_void_p), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float)]
+
+
 class PackDesc(ctypes.Structure):                               # mfx_pack_desc
     _fields_ = [("w", c_void_p), ("packed", c_void_p), ("frag", c_void_p)] + \
         [(n, c_int) for n in ("Cout", "Cin", "kh", "kw", "mode", "rows_pad", "K_pad", "ck")]
@@ -142,6 +151,8 @@ SYMBOLS = {
     "mfx_conv_wgrad_nhwc_dil": (_I, [_P, _P, _P] + [_I] * 16 + [_P]),
     "mfx_conv_wgrad_oihw": (_I, [_P, _P, _P] + [_I] * 17 + [_P, _S, _P]),
     "mfx_pack_conv_weight": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "mfx_adamw_chunk_elems": (_I, []),
+    "mfx_adamw_multi": (_I, [_P, _P, _I, ctypes.c_longlong, _P, _P, _P]),
     "mfx_colsum": (_I, [_P, _P, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_colsum_add": (_I, [_P, _P, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_stats": (_I, [_P, _P, _P, ctypes.c_long, _I, _I, _P]),

@@ -101,3 +101,142 @@ def build_scheduler(optimizer, cfg=None, iters_per_epoch=1, last_epoch=-1, total
                 f *= decay
         return f
     return torch.optim.lr_scheduler.LambdaLR(optimizer, factor, last_epoch=last_epoch)
+
+
+class MultiTensorAdamW:
+    """`optimizer.step()` of a torch.optim.AdamW (fused, capturable, device-scalar learning rates: what `build_optimizer` makes on a GPU) as ONE HIP launch
+    over all parameter tensors (csrc/adamw.hip) instead of torch's chunked multi-tensor kernels (25 launches / 345 us of the B = 8 training step).
+    The optimizer object stays the owner of everything -- param_groups, `state[p] = {step, exp_avg, exp_avg_sq}` in torch's own layout -- so
+    state_dict() / load_state_dict() / LR schedulers / the loss scaler's `found_inf` hook work unchanged; only the arithmetic runs elsewhere.
+
+    The kernel reads a pointer table on the device.  Eagerly the table is rebuilt and uploaded every call (gradients are fresh tensors each step).
+    Inside a stream capture the addresses of the step's gradients are known once backward has been captured, but a host-to-device copy cannot be:
+    the launch is recorded against the preallocated table and `finish_capture()` fills it once the capture has ended (before the first replay)."""
+
+    def __init__(self, optimizer):
+        self.opt = optimizer
+        self.tables = {}          # device -> (descs tensor, prefix tensor, groups tensor, capacity)
+        self.pending = []
+
+    @staticmethod
+    def eligible(optimizer):
+        if type(optimizer) is not torch.optim.AdamW:
+            return False
+        for g in optimizer.param_groups:
+            if not g.get("capturable") or g.get("amsgrad") or g.get("maximize") or not torch.is_tensor(g["lr"]) or not g["lr"].is_cuda \
+                    or g["lr"].dtype != torch.float32 or g.get("differentiable"):
+                return False
+            for p in g["params"]:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or p.is_sparse:
+                    return False
+        return True
+
+    def _tables(self, dev, n, ngroups):
+        from . import lib as L
+        t = self.tables.get(dev)
+        if t is None or t[3] < n or t[2].numel() < ngroups * ctypes_sizeof(L.AdamWGroup):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("MultiTensorAdamW: the pointer tables must exist before a capture (run one eager step first)")
+            cap = max(n, sum(len(g["params"]) for g in self.opt.param_groups))
+            t = (torch.zeros(cap * ctypes_sizeof(L.AdamWDesc), dtype=torch.uint8, device=dev), torch.zeros(cap + 1, dtype=torch.int64, device=dev),
+                 torch.zeros(max(ngroups, len(self.opt.param_groups)) * ctypes_sizeof(L.AdamWGroup), dtype=torch.uint8, device=dev), cap)
+            self.tables[dev] = t
+        return t
+
+    @torch.no_grad()
+    def step(self):
+        import numpy as np
+        from . import lib as L
+        opt = self.opt
+        chunk = L.load().mfx_adamw_chunk_elems()
+        by_dev = {}
+        for gi, g in enumerate(opt.param_groups):
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                st = opt.state[p]
+                if len(st) == 0:                                       # torch's lazy state initialisation (adamw.py `_init_group`)
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                gr = p.grad
+                if gr.dtype != torch.float32 or not gr.is_contiguous() or gr.is_sparse:
+                    raise RuntimeError("MultiTensorAdamW: dense contiguous fp32 gradients only")
+                by_dev.setdefault(p.device, []).append((gi, p, gr, st))
+        found_inf = getattr(opt, "found_inf", None)
+        opt._opt_called = True                                         # (what torch's wrapped step() tells the LR schedulers)
+        capturing = torch.cuda.is_current_stream_capturing()
+        for dev, items in by_dev.items():
+            n = len(items)
+            descs = (L.AdamWDesc * n)()
+            prefix = np.zeros(n + 1, dtype=np.int64)
+            for i, (gi, p, gr, st) in enumerate(items):
+                d = descs[i]
+                d.p, d.g, d.m, d.v, d.step = p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()
+                d.numel, d.group = p.numel(), gi
+                prefix[i + 1] = prefix[i] + (p.numel() + chunk - 1) // chunk
+            groups = (L.AdamWGroup * len(opt.param_groups))()
+            for gi, g in enumerate(opt.param_groups):
+                groups[gi].lr = g["lr"].data_ptr()
+                groups[gi].beta1, groups[gi].beta2 = float(g["betas"][0]), float(g["betas"][1])
+                groups[gi].eps, groups[gi].weight_decay = float(g["eps"]), float(g["weight_decay"])
+            dt, pt, gt, _ = self._tables(dev, n, len(opt.param_groups))
+            host = (torch.from_numpy(np.frombuffer(bytes(descs), dtype=np.uint8).copy()), torch.from_numpy(prefix),
+                    torch.from_numpy(np.frombuffer(bytes(groups), dtype=np.uint8).copy()))
+            if capturing:
+                self.pending.append((dt, pt, gt, host))
+            else:
+                self._upload(dt, pt, gt, host)
+            with torch.cuda.device(dev):
+                L.check(L.load().mfx_adamw_multi(ctypes_ptr(dt), ctypes_ptr(pt), n, int(prefix[n]), ctypes_ptr(gt),
+                                                 ctypes_ptr(found_inf) if found_inf is not None else None,
+                                                 ctypes_stream()), "mfx_adamw_multi")
+
+    @staticmethod
+    def _upload(dt, pt, gt, host):
+        dt[:host[0].numel()].copy_(host[0])
+        pt[:host[1].numel()].copy_(host[1])
+        gt[:host[2].numel()].copy_(host[2])
+
+    def finish_capture(self):
+        """Fill the tables of the launches recorded during a capture (call after the capture has ended, before the first replay)."""
+        for dt, pt, gt, host in self.pending:
+            self._upload(dt, pt, gt, host)
+        self.pending = []
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+
+def ctypes_sizeof(t):
+    import ctypes
+    return ctypes.sizeof(t)
+
+
+def ctypes_ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ctypes_stream():
+    import ctypes
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+HIP_ADAMW = [__import__("os").environ.get("MFX_HIP_ADAMW", "1") != "0"]      # MFX_HIP_ADAMW=0: torch's own fused AdamW step (A/B)
+
+
+def optimizer_step(optimizer):
+    """`optimizer.step()`; a GPU AdamW built by `build_optimizer` takes the one-launch HIP form (MultiTensorAdamW) -- eagerly and inside captures alike,
+    so a replayed step and an eager step stay the same arithmetic."""
+    mt = getattr(optimizer, "_mfx_multi", None)
+    if mt is None and HIP_ADAMW[0] and MultiTensorAdamW.eligible(optimizer):
+        mt = optimizer._mfx_multi = MultiTensorAdamW(optimizer)
+    if mt is None or not HIP_ADAMW[0]:
+        return optimizer.step()
+    return mt.step()
+
+
+def finish_capture(optimizer):
+    mt = getattr(optimizer, "_mfx_multi", None)
+    if mt is not None:
+        mt.finish_capture()
