@@ -124,7 +124,7 @@ class _SumArena:
 
     def take(self, device, n):
         b = self.bufs.get(device)
-        if not self.on or b is None or b[1] + n > self.ELEMS:
+        if not self.on or not SUM_ARENA_ON[0] or b is None or b[1] + n > self.ELEMS:
             return None
         o = b[1]
         b[1] += (n + 3) // 4 * 4
@@ -132,6 +132,7 @@ class _SumArena:
 
 
 SUM_ARENA = _SumArena()
+SUM_ARENA_ON = [os.environ.get("MFX_SUM_ARENA", "1") != "0"]       # 0: a zero fill per bias-gradient sum, as before (A/B)
 
 
 class sum_arena:
@@ -184,6 +185,9 @@ class _PackRegistry:
         self.entries = {}              # key -> dict(ref, weight version, buffers, descriptor fields)
         self.tables = {}               # (device, dtype) -> (keys, descs tensor, prefix tensor, total)
         self.dirty = set()
+        self.scope_ids = None
+        self.scope = None              # pack_scope: {(device, dtype) -> table} restricted to one model's parameters, used INSTEAD of self.tables
+        self.capture_unpacked = set()  # (device, dtype) whose batched packing could not be recorded in the running capture
         self.arenas = {}               # device -> fragment arena of the 64-channel DCN operands (_arena_slot)
 
     def lookup(self, weight, dtype, mode, rows, ck, stride, pad_h, pad_w, register=True):
@@ -250,7 +254,9 @@ class _PackRegistry:
                                               e["ck"], _dt(dtype), _stream()), "mfx_pack_conv_weight")
         e["version"] = weight._version
 
-    def _rebuild(self, dev, dtype):
+    def _rebuild(self, dev, dtype, only=None):
+        """The (keys, descriptor table, chunk prefix, chunk count) of the registered operands on (dev, dtype) -- all of them (stored in self.tables), or
+        those of the parameters whose id() is in `only` (returned, not stored: pack_scope)."""
         import numpy as np
         keys, descs, prefix, total = [], [], [0], 0
         chunk = L.load().mfx_pack_chunk_elems()
@@ -259,7 +265,7 @@ class _PackRegistry:
             if w is None or w.data_ptr() != e["ptr"]:
                 del self.entries[key]
                 continue
-            if key[1] != dtype or w.device != dev or not e["fp32"] or not w.is_contiguous():
+            if key[1] != dtype or w.device != dev or not e["fp32"] or not w.is_contiguous() or (only is not None and id(w) not in only):
                 continue
             d = L.PackDesc()
             d.w, d.packed, d.frag = w.data_ptr(), e["packed"].data_ptr(), (e["frag"].data_ptr() if e["frag"] is not None else None)
@@ -269,22 +275,36 @@ class _PackRegistry:
             total += (e["cp"] * e["K_pad"] + chunk - 1) // chunk
             prefix.append(total)
         if not keys:
-            self.tables.pop((dev, dtype), None)
-            return
+            if only is None:
+                self.tables.pop((dev, dtype), None)
+            return None
         dt = torch.from_numpy(np.frombuffer(b"".join(descs), dtype=np.uint8).copy()).to(dev)
         pt = torch.tensor(prefix, dtype=torch.int64).to(dev)
-        self.tables[(dev, dtype)] = (keys, dt, pt, total)
+        if only is None:
+            self.tables[(dev, dtype)] = (keys, dt, pt, total)
+        return keys, dt, pt, total
 
     def pack_all(self):
         capturing = torch.cuda.is_current_stream_capturing()
-        for tk in list(self.dirty):
-            if not capturing:                                  # the tables are uploaded from the host: not inside a capture
-                self._rebuild(*tk)
-                self.dirty.discard(tk)
-        for (dev, dtype), (keys, dt, pt, total) in list(self.tables.items()):
+        self.capture_unpacked = set()
+        scoped = self.scope is not None
+        if not scoped:
+            for tk in list(self.dirty):
+                if not capturing:                              # the tables are uploaded from the host: not inside a capture
+                    self._rebuild(*tk)
+                    self.dirty.discard(tk)
+                else:
+                    self.capture_unpacked.add(tk)              # operands registered since the last rebuild are not in the table
+        for (dev, dtype), (keys, dt, pt, total) in list((self.scope if scoped else self.tables).items()):
             live = [self.entries.get(k) for k in keys]
             if any(e is None or e["ref"]() is None or e["ref"]().data_ptr() != e["ptr"] for e in live):
+                if scoped:
+                    raise RuntimeError("pack_scope: a parameter of the scoped model went away or moved")
                 if capturing:
+                    # the table names dead parameters and cannot be rebuilt inside a capture: nothing is recorded for (dev, dtype) here, and
+                    # `_pack_weight` packs every operand it hands out during this capture on demand (one launch each) -- slower replays, never
+                    # stale operands.  (engine/trainer.GraphedTrainStep captures inside a `pack_scope`, which cannot get here.)
+                    self.capture_unpacked.add((dev, dtype))
                     continue
                 self._rebuild(dev, dtype)
                 if (dev, dtype) not in self.tables:
@@ -331,13 +351,13 @@ class _PadRegistry:
             e["version"] = vec._version
         return e["buf"]
 
-    def refresh_all(self):
+    def refresh_all(self, only=None):
         live = []
         for key, e in list(self.entries.items()):
             v = e["ref"]()
             if v is None or v.data_ptr() != e["ptr"]:
                 del self.entries[key]
-            else:
+            elif only is None or id(v) in only:
                 live.append((e, v))
         if live:                                               # unconditional, like the batched packing: a captured step replays it
             torch._foreach_copy_([e["buf"][:e["m"]] for e, _ in live], [v.detach() for _, v in live])
@@ -361,7 +381,34 @@ def pack_all_weights():
     """Re-pack every conv operand the training path has used so far, one launch per (device, dtype), and refresh the padded bias
     vectors; call at the top of a step."""
     _PACKS.pack_all()
-    _PADS.refresh_all()
+    _PADS.refresh_all(_PACKS.scope_ids)
+
+
+class pack_scope:
+    """Context for CAPTURING a step of one model: inside it `pack_all_weights()` touches only the operands / padded biases of `params`, through
+    descriptor tables built here (before the capture: they are uploaded from the host) and kept alive by this object -- keep it as long as the graph.
+    Why: the registry's own tables name the operands of EVERY model that is alive at the time and are replaced whenever that set changes.  A graph
+    captured against them would (a) read a freed table after the next rebuild and (b) keep re-packing the operands of other models after those
+    have been freed -- writes into memory that belongs to somebody else by then.  r06: seen as order-dependent mismatches of the graph-vs-eager tests
+    once an unrelated reference cycle delayed the collection of earlier tests' models (tools/probes/syncbn_flaky_dbg.py)."""
+
+    def __init__(self, params):
+        ps = list(params)
+        self.ids = {id(p) for p in ps}
+        self.keep = ps
+        self.tables = {}
+        for key in {(e["ref"]().device, k[1]) for k, e in list(_PACKS.entries.items()) if e["ref"]() is not None and id(e["ref"]()) in self.ids}:
+            t = _PACKS._rebuild(key[0], key[1], only=self.ids)
+            if t is not None:
+                self.tables[key] = t
+
+    def __enter__(self):
+        self.prev = (_PACKS.scope, _PACKS.scope_ids)
+        _PACKS.scope, _PACKS.scope_ids = self.tables, self.ids
+        return self
+
+    def __exit__(self, *a):
+        _PACKS.scope, _PACKS.scope_ids = self.prev
 
 
 def _pack_weight(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, shift=None):
@@ -370,7 +417,7 @@ def _pack_weight(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, shift=None
     Cout, Cin, kh, kw = weight.shape
     if isinstance(weight, torch.nn.Parameter):
         e = _PACKS.lookup(weight, dtype, mode, rows, ck, stride, pad_h, pad_w)
-        if e["version"] != weight._version:
+        if e["version"] != weight._version or ((weight.device, dtype) in _PACKS.capture_unpacked and torch.cuda.is_current_stream_capturing()):
             _PACKS.pack_one(e, weight, dtype)
     else:                                                      # a temporary (stacked head weights, a view): nothing to remember
         e = _PACKS.lookup(weight, dtype, mode, rows, ck, stride, pad_h, pad_w, register=False)

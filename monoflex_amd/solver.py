@@ -111,12 +111,16 @@ class MultiTensorAdamW:
 
     The kernel reads a pointer table on the device.  Eagerly the table is rebuilt and uploaded every call (gradients are fresh tensors each step).
     Inside a stream capture the addresses of the step's gradients are known once backward has been captured, but a host-to-device copy cannot be:
-    the launch is recorded against the preallocated table and `finish_capture()` fills it once the capture has ended (before the first replay)."""
+    the launch is recorded against tables of its own (allocated by the preceding eager step -- NOT inside the capture: see step() -- and never
+    reused by eager steps) and `finish_capture()` fills them once the capture has ended (before the first replay)."""
 
     def __init__(self, optimizer):
-        self.opt = optimizer
+        import weakref
+        self._opt = weakref.ref(optimizer)     # (the optimizer holds this object: no reference cycle, or its parameters outlive their last user until a GC pass)
         self.tables = {}          # device -> (descs tensor, prefix tensor, groups tensor, capacity)
         self.pending = []
+        self.captured = []
+        self.spare = {}           # device -> a table set allocated by the last eager step for the next captured launch
 
     @staticmethod
     def eligible(optimizer):
@@ -131,23 +135,24 @@ class MultiTensorAdamW:
                     return False
         return True
 
+    def _new_tables(self, dev, n, ngroups):
+        from . import lib as L
+        cap = max(n, sum(len(g["params"]) for g in self._opt().param_groups))
+        return (torch.zeros(cap * ctypes_sizeof(L.AdamWDesc), dtype=torch.uint8, device=dev), torch.zeros(cap + 1, dtype=torch.int64, device=dev),
+                torch.zeros(max(ngroups, len(self._opt().param_groups)) * ctypes_sizeof(L.AdamWGroup), dtype=torch.uint8, device=dev), cap)
+
     def _tables(self, dev, n, ngroups):
         from . import lib as L
         t = self.tables.get(dev)
         if t is None or t[3] < n or t[2].numel() < ngroups * ctypes_sizeof(L.AdamWGroup):
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("MultiTensorAdamW: the pointer tables must exist before a capture (run one eager step first)")
-            cap = max(n, sum(len(g["params"]) for g in self.opt.param_groups))
-            t = (torch.zeros(cap * ctypes_sizeof(L.AdamWDesc), dtype=torch.uint8, device=dev), torch.zeros(cap + 1, dtype=torch.int64, device=dev),
-                 torch.zeros(max(ngroups, len(self.opt.param_groups)) * ctypes_sizeof(L.AdamWGroup), dtype=torch.uint8, device=dev), cap)
-            self.tables[dev] = t
+            t = self.tables[dev] = self._new_tables(dev, n, ngroups)
         return t
 
     @torch.no_grad()
     def step(self):
         import numpy as np
         from . import lib as L
-        opt = self.opt
+        opt = self._opt()
         chunk = L.load().mfx_adamw_chunk_elems()
         by_dev = {}
         for gi, g in enumerate(opt.param_groups):
@@ -180,13 +185,23 @@ class MultiTensorAdamW:
                 groups[gi].lr = g["lr"].data_ptr()
                 groups[gi].beta1, groups[gi].beta2 = float(g["betas"][0]), float(g["betas"][1])
                 groups[gi].eps, groups[gi].weight_decay = float(g["eps"]), float(g["weight_decay"])
-            dt, pt, gt, _ = self._tables(dev, n, len(opt.param_groups))
             host = (torch.from_numpy(np.frombuffer(bytes(descs), dtype=np.uint8).copy()), torch.from_numpy(prefix),
                     torch.from_numpy(np.frombuffer(bytes(groups), dtype=np.uint8).copy()))
             if capturing:
+                # tables of their own for a captured launch: an eager step of the same optimizer later must not overwrite what the replays read.  They
+                # were allocated by the last EAGER step (`spare`), outside the graph's memory pool -- a block of that pool is reused by other captured
+                # temporaries, whose kernels would overwrite the table at every replay before this launch reads it
+                sp = self.spare.pop(dev, None)
+                if sp is None or sp[3] < n:
+                    raise RuntimeError("MultiTensorAdamW: run one eager optimizer step before capturing one (it allocates the captured launch's tables)")
+                dt, pt, gt = sp[:3]
+                self.captured.append(sp)
                 self.pending.append((dt, pt, gt, host))
             else:
+                dt, pt, gt, _ = self._tables(dev, n, len(opt.param_groups))
                 self._upload(dt, pt, gt, host)
+                if dev not in self.spare:
+                    self.spare[dev] = self._new_tables(dev, n, len(opt.param_groups))
             with torch.cuda.device(dev):
                 L.check(L.load().mfx_adamw_multi(ctypes_ptr(dt), ctypes_ptr(pt), n, int(prefix[n]), ctypes_ptr(gt),
                                                  ctypes_ptr(found_inf) if found_inf is not None else None,
