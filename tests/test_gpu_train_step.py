@@ -307,6 +307,48 @@ def test_graphed_train_step_equals_the_eager_step_bitwise(split, dtype, nccl_wor
         assert worst < tol, worst
 
 
+def test_captured_step_survives_other_models_coming_and_going(deterministic):
+    """A captured step re-packs its conv operands from tables of its own that name only ITS model's parameters (autograd.pack_scope).  Against the
+    registry's shared tables it would (a) read a freed table once another model registers operands (the table is rebuilt) and (b) keep re-packing the
+    operands of a model that was alive at capture time after that model is gone -- writes into memory that is somebody else's by then (r06: seen as
+    order-dependent mismatches of the graph-vs-eager tests).  Here: model c runs a step (its operands are registered), b's step is captured, c is freed
+    and its memory overwritten, model d registers new operands; b's replays must still equal the eager twin to the bit, and d must be undisturbed."""
+    import gc
+    from monoflex_amd.engine.trainer import GraphedTrainStep, train_step
+    from monoflex_amd.solver import build_optimizer
+    cfg = _cfg("bf16")
+    c = _model("bf16", seed=9)
+    imgs, tg = _batch(c)
+    opt_c = build_optimizer(c, cfg, capturable=True)
+    train_step(c, opt_c, imgs, tg)
+    b = _model("bf16")
+    opt_b = build_optimizer(b, cfg, capturable=True)
+    step = GraphedTrainStep(b, opt_b, imgs, tg, warmup=2)
+    torch.cuda.synchronize()
+    del c, opt_c
+    gc.collect()
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(96)]      # whatever reuses c's memory now holds NaNs ...
+    torch.cuda.synchronize()
+    a = _model("bf16", seed=5)
+    a.load_state_dict({k: v.detach().clone() for k, v in b.state_dict().items()})
+    opt_a = build_optimizer(a, cfg, capturable=True)
+    opt_a.load_state_dict(copy.deepcopy(opt_b.state_dict()))
+    d = _model("bf16", seed=11)
+    opt_d = build_optimizer(d, cfg, capturable=True)
+    loss_d0 = train_step(d, opt_d, imgs, tg)[0].clone()                                # ... and the registry's tables are rebuilt for d's operands
+    for it in range(2):
+        loss_b = step().clone()
+        loss_a = train_step(a, opt_a, imgs, tg)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(loss_a, loss_b), (it, float(loss_a), float(loss_b))
+        sa, sb = a.state_dict(), b.state_dict()
+        assert not [k for k in sa if not torch.equal(sa[k], sb[k])], it
+    assert all(bool(torch.isnan(j).all()) for j in junk)                               # nothing wrote into the freed model's memory
+    d2 = _model("bf16", seed=11)
+    opt_d2 = build_optimizer(d2, cfg, capturable=True)
+    assert torch.equal(train_step(d2, opt_d2, imgs, tg)[0], loss_d0)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_c3_c4_per_gpu_shape_segmented_graphed_step(dtype, nccl_world1):
     """BASELINE configs[2] / [3] per-GPU shape -- B = 8 images of 1280x384, 16-bit activations (bf16; fp16 = configs[3]'s "fp16 MFMA
