@@ -204,7 +204,7 @@ int mfx_dcn_fuses_offset_conv(const mfx_dcn_desc* d);
 int mfx_dcn_sample_nhwc(const void* P, const float* offmask, const float* scale, const float* shift, void* y,
                         int B, int H, int W, int N, int ldy, int act, int dtype, void* stream);
 /* The projection half as a kernel of its own (csrc/gemm_as.hip): y[m][n] = sum_k x[m][k] * w[n][k], x [M][ldx >= K] and y [M][ldy >= N] in `dtype`
- * (MFX_BF16 / MFX_F16), w [N][K] K-contiguous (mfx_conv2d_nhwc's 1x1 weight layout), K in {128, 256, 512}, N a multiple of 64; fp32 accumulate, no
+ * (MFX_BF16 / MFX_F16), w [N][K] K-contiguous (mfx_conv2d_nhwc's 1x1 weight layout), K in {64, 128, 256, 512}, N a multiple of 64; fp32 accumulate, no
  * epilogue.  Activation-stationary: a workgroup keeps 128 pixels' rows in registers and streams the output channels (the map is store-bound). */
 int mfx_project_nhwc(const void* x, const void* w, void* y, int M, int K, int N, int ldx, int ldy, int dtype, void* stream);
 

@@ -37,6 +37,7 @@ int mfx_internal_wgrad_slab_sum(const float* ws, int nslab, int Cout, int Ck, in
 int mfx_internal_colsum_add(const void* x, float* out, long M, int C, int ld, int dtype, void* stream);      // train_kernels.hip: sums ADDED into a zeroed `out`
 
 int g_opt_dcn_bt_fuse_blocks = 170; // option "dcn_bt_fuse_blocks": workgroups per tap group of the fused kernel
+int g_opt_dcn_bt_gcol_as = 1;      // option "dcn_bt_gcol_as": d(columns) = dy . W^T of the 16-bit layers on the activation-stationary GEMM (gemm_as.hip); 0: the tiled 1x1 kernel
 int g_opt_dcn_bt_fly = 1;          // option "dcn_bt_fly": 64 -> 64 16-bit layers rebuild d(columns) from dy inside both consumers (no [M][9C] matrix in memory)
 long g_cnt_dcn_bt_fly = 0;         // counter "dcn_bt_fly": backward calls that took the gcol-free form
 int g_opt_dcn_bt_fuse_wgrad = 1;   // option "dcn_bt_fuse_wgrad": 64 -> 64 bf16 layers accumulate grad_weight inside the sample kernel (no columns in memory)
@@ -1295,7 +1296,13 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
     cd.B = 1; cd.H = 1; cd.W = (int)M; cd.x_pixstride = Cout; cd.Ck = Cout; cd.kh = 1; cd.kw = 1; cd.stride = 1; cd.dil_w = 1;
     cd.Ho = 1; cd.Wo = (int)M; cd.M = (int)M; cd.Cout = K; cd.Cout_pad = K; cd.K_pad = Cout; cd.ldy = K;
     cd.act = MFX_ACT_NONE; cd.dtype = dt; cd.out_dtype = dt;
-    int rc = mfx_conv2d_nhwc(&cd, stream);
+    int rc;
+    // 16-bit layers: the activation-stationary GEMM (gemm_as.hip) -- K = Cout is short (64 .. 256) and the M x 9C result is bound by its own stores,
+    // the shape that kernel was written for (profiles/r06_dcn_ps.md: 1.4 - 1.8x the tiled kernel on such maps); option "dcn_bt_gcol_as" = 0: the tiled kernel
+    if (es == 2 && g_opt_dcn_bt_gcol_as && (Cout == 64 || Cout == 128 || Cout == 256) && K % 64 == 0)
+        rc = mfx_project_nhwc(dy, wT, gcol, (int)M, Cout, K, Cout, K, dt, stream);
+    else
+        rc = mfx_conv2d_nhwc(&cd, stream);
     if (rc) return rc;
     BtGeom gs = g;                                             // the sample kernel loops its slices inside a lane group: widest slice
     // tile kernel: one workgroup per (tile, slice).  On the small maps 128-channel slices leave the chip under-filled

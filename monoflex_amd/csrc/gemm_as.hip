@@ -1,5 +1,5 @@
 // Dense GEMM with a short K and a wide N, activation-stationary (r06): the projection half of the project-then-sample DCN (csrc/dcn_ps.hip),
-//     y[m][n] = sum_k x[m][k] * w[n][k],      x: [M][K] 16-bit rows (K = 128 / 256 / 512 input channels), w: [N][K] K-contiguous (N = 9 Cout = 576 .. 2304).
+//     y[m][n] = sum_k x[m][k] * w[n][k],      x: [M][K] 16-bit rows (K = 64 / 128 / 256 / 512 input channels), w: [N][K] K-contiguous (N = 9 Cout = 576 .. 2304).
 // Why a kernel of its own: with K this short an output element costs K multiply-adds and 2 bytes of store -- the layer's floor is WRITING the map
 // (70.8 MB at 5.5 TB/s = 13 us for 128 -> 64 @ 48 x 160, B = 8: tools/probes/membw_probe.py), and the tiled implicit-GEMM kernel (conv_kernels.hip) spends
 // 36 us on it: two k-iterations per 64 x 64 tile, i.e. a prologue (operand tiles -> LDS, barrier) and an epilogue (LDS staging) per 128 MFMAs and nothing
@@ -122,10 +122,11 @@ static int launch_gemm_as(const void* x, const void* w, void* y, int M, int N, i
 }
 
 template <typename T> static int dispatch_gemm_as(const void* x, const void* w, void* y, int M, int K, int N, int ldx, int ldy, hipStream_t st) {
+    if (K == 64) return launch_gemm_as<T, 64, 2, 64>(x, w, y, M, N, ldx, ldy, st);          // (r06: d(columns) = dy . W^T of the 64-output DCN layers' backward)
     if (K == 128) return launch_gemm_as<T, 128, 2, 64>(x, w, y, M, N, ldx, ldy, st);
     if (K == 256) return launch_gemm_as<T, 256, 2, 64>(x, w, y, M, N, ldx, ldy, st);
     if (K == 512) return launch_gemm_as<T, 512, 2, 32>(x, w, y, M, N, ldx, ldy, st);
-    return mfx_fail(MFX_ERR_UNSUPPORTED, "project: K must be 128, 256 or 512");
+    return mfx_fail(MFX_ERR_UNSUPPORTED, "project: K must be 64, 128, 256 or 512");
 }
 
 }  // namespace mfx

@@ -655,7 +655,8 @@ def test_dcn_project_then_sample_matches_the_gather_kernel(dtype, B, C, Cout, H,
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,K,N", [(3840, 512, 2304), (1001, 128, 576), (15360, 256, 2304), (130, 256, 576), (61440, 128, 576)])
+@pytest.mark.parametrize("M,K,N", [(3840, 512, 2304), (1001, 128, 576), (15360, 256, 2304), (130, 256, 576), (61440, 128, 576), (61440, 64, 1152),
+                                   (999, 64, 2304)])
 def test_project_gemm_equals_the_tiled_1x1_kernel(dtype, M, K, N):
     """csrc/gemm_as.hip (mfx_project_nhwc: activation-stationary GEMM, weight rows of a fragment pair permuted for 16-byte stores, channel chunks split
     over workgroups on small maps) against mfx_conv2d_nhwc's 1x1 kernel on the same operands -- the same fp32 sums, rounded once: equal bits except
