@@ -1045,6 +1045,7 @@ int g_opt_wgrad_blocks = 600;   // option "wgrad_blocks": target workgroup count
                                 // more than the extra workgroups hide)
 int g_opt_wgrad_ws = 1;        // option "wgrad_ws": 0 = always accumulate the tiles with atomics
 int g_opt_wgrad_ws_blocks = 1200;  // option "wgrad_ws_blocks": target workgroup count when partial tiles go to the workspace (step: 1200 -> 58.0 ms, 2400 -> 58.3, 4800 -> 58.6; atomics: 59.6)
+int g_opt_wgrad_min_m = 128;   // option "wgrad_min_m": fewest pixels of a slab of the MFMA weight-gradient kernel.  r06: 1024 left the 1x1 / Root layers of the 24x80 and 12x40 maps with 8-16 slabs (120-240 workgroups of 32 iterations each: 31 us per layer for 4 GFLOP); same-box step 17.50 (1024) / 17.31 (512) / 17.27 (256) / 17.23-17.31 (128) / 17.26 (64) ms
 int g_opt_wgrad_mfma = 1;     // option "wgrad_mfma": 0 = VALU kernel for bf16 too, 1 = 64x64 MFMA tiles, 3 = 128x128 where they fit
 
 // CALL_16 is written once for both 16-bit activation types: T16 = bf16_t or half_t
@@ -1091,7 +1092,7 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int B, int 
         int slabs = std::max(1, (use_ws ? g_opt_wgrad_ws_blocks : g_opt_wgrad_blocks) / tiles);
         if (use_ws) slabs = (int)std::min<long>(slabs, (long)(workspace_bytes / sizeof(float)) / ws_slab);
         if (use_ws && slabs < 1) slabs = 1;
-        g.m_per_block = std::max(1024, (int)(((long)g.M / slabs + 31) / 32 * 32));
+        g.m_per_block = std::max(std::max(32, g_opt_wgrad_min_m / 32 * 32), (int)(((long)g.M / slabs + 31) / 32 * 32));
         const int nslab = cdivt(g.M, g.m_per_block);
         bool ws_ok = use_ws && (size_t)nslab * ws_slab * sizeof(float) <= workspace_bytes;
         if (!ws_ok && g_opt_det) { g.m_per_block = (g.M + 31) / 32 * 32; }     // atomics: a single slab per tile adds into zeros exactly once
