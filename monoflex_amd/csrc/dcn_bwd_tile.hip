@@ -37,6 +37,7 @@ int mfx_internal_wgrad_slab_sum(const float* ws, int nslab, int Cout, int Ck, in
 int mfx_internal_colsum_add(const void* x, float* out, long M, int C, int ld, int dtype, void* stream);      // train_kernels.hip: sums ADDED into a zeroed `out`
 
 int g_opt_dcn_bt_fuse_blocks = 170; // option "dcn_bt_fuse_blocks": workgroups per tap group of the fused kernel
+int g_opt_dcn_bt_fly_bias = 1;     // option "dcn_bt_fly_bias": the gcol-free sample kernel also sums grad_bias from the dy rows it loads (0: a separate column-sum pass)
 int g_opt_dcn_bt_gcol_as = 1;      // option "dcn_bt_gcol_as": d(columns) = dy . W^T of the 16-bit layers on the activation-stationary GEMM (gemm_as.hip); 0: the tiled 1x1 kernel
 int g_opt_dcn_bt_fly = 1;          // option "dcn_bt_fly": 64 -> 64 16-bit layers rebuild d(columns) from dy inside both consumers (no [M][9C] matrix in memory)
 long g_cnt_dcn_bt_fly = 0;         // counter "dcn_bt_fly": backward calls that took the gcol-free form
@@ -1024,9 +1025,13 @@ template <typename T, bool WG>                                              // T
 __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_fly_kernel(const T* __restrict__ x, const float* __restrict__ om,
                                                                       const T* __restrict__ wT, const T* __restrict__ dy, BtGeom g,
                                                                       int chunks_per_block, int nchunks, float* __restrict__ graw,
-                                                                      float* __restrict__ ws, T* __restrict__ gcol) {
+                                                                      float* __restrict__ ws, T* __restrict__ gcol, float* __restrict__ dbias) {
     __shared__ __attribute__((aligned(16))) char lds[2 * SF_STAGE + SG_TILE];
     char* gt = lds + 2 * SF_STAGE;
+    // grad_bias[o] = sum of dy over the pixels (r06): the tap-group-0 workgroups see every dy row once (their `dyv` loads), so they sum it on the way
+    // -- eight channels per thread, folded over the chunk's 32 pixels at the end -- instead of a separate column-sum pass over dy (24 us per layer)
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool bias_here = dbias != nullptr && blockIdx.y == 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sl = lane >> 3, cl = lane & 7;                                  // sample slot in the wave, 8-channel group
@@ -1114,6 +1119,12 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_fly_kernel(const T* 
         char* stage = lds + ((ch - c_begin) & 1) * SF_STAGE;
         // dy rows of the chunk: [o sub][pixel][32 B]  (this stage's previous readers -- the MFMAs of chunk ch - 2 -- are two barriers back)
         *reinterpret_cast<u32x4*>(stage + (SF_BT + ((tid & 7) >> 1)) * SF_TILE + (tid >> 3) * 32 + (tid & 1) * 16) = dyv;
+        if (bias_here) {
+            float f8[8];
+            ElemTraits<T>::unpack(dyv, f8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] += f8[e];
+        }
         dyv = dy_rows(ch + 1);                                                // next chunk's rows: in flight through this one
         __syncthreads();                                                      // dy rows visible; every wave is done reading the g tile of the previous chunk
         {   // g^T rows 48 wv .. +48 = W . dy^T  ->  gt[pixel][192]
@@ -1212,6 +1223,19 @@ __global__ __launch_bounds__(256) void dcn_bwd_sample_wgrad_fly_kernel(const T* 
 #pragma unroll
             for (int r = 0; r < 4; ++r) slab[(size_t)(i * 16 + (lane >> 4) * 4 + r) * 576 + k] = acc[i][j][r];
     }
+    if (bias_here) {                                                          // thread (pixel tid >> 3, channel group tid & 7) -> [32][64] floats, 64 column sums, one atomic each
+        __syncthreads();                                                      // (every wave is done with the stages)
+        float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) *reinterpret_cast<f32x4*>(red + (tid >> 3) * 64 + (tid & 7) * 8 + e) = f32x4{bsum[e], bsum[e + 1], bsum[e + 2], bsum[e + 3]};
+        __syncthreads();
+        if (tid < 64) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) t += red[r * 64 + tid];
+            unsafeAtomicAdd(dbias + tid, t);
+        }
+    }
 }
 
 static inline size_t bt_al(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1265,13 +1289,14 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
             const int cpb = (int)((nchunks + nblk - 1) / nblk);
             nblk = (int)((nchunks + cpb - 1) / cpb);
             float* slabs = reinterpret_cast<float*>(ws + L.wg);
+            const bool bias_in_kernel = g_opt_dcn_bt_fly_bias != 0;          // (dbias was zeroed by bt_pack_weight_t)
             const bool write_gcol = g_opt_dcn_bt_fly == 2;                   // 2: d(columns) written by the sample kernel, gathered by the second-generation tile kernel
             if (write_gcol)
                 hipLaunchKernelGGL((dcn_bwd_sample_wgrad_fly_kernel<T, true>), dim3((unsigned)nblk, 3), dim3(256), 0, st, x, offmask, (const T*)wT, dy, g, cpb, (int)nchunks,
-                                   d_raw, slabs, gcol);
+                                   d_raw, slabs, gcol, bias_in_kernel ? dbias : (float*)nullptr);
             else
                 hipLaunchKernelGGL((dcn_bwd_sample_wgrad_fly_kernel<T, false>), dim3((unsigned)nblk, 3), dim3(256), 0, st, x, offmask, (const T*)wT, dy, g, cpb, (int)nchunks,
-                                   d_raw, slabs, (T*)nullptr);
+                                   d_raw, slabs, (T*)nullptr, bias_in_kernel ? dbias : (float*)nullptr);
             MFX_HIP_CHECK(hipGetLastError());
             ++g_cnt_dcn_bt_fused; ++g_cnt_dcn_bt_fly;
             int rc2 = mfx_internal_wgrad_slab_sum(slabs, nblk, Cout, C, 3, 3, dweight, stream);
@@ -1287,7 +1312,7 @@ static int dcn_backward_v2_impl(const T* x, const float* offmask, const float* w
             hipLaunchKernelGGL(dcn_bwd_far_fly_kernel<T>, dim3(1024), dim3(256), 0, st, dy, (const T*)wT, (const u32x4*)flist, (const int*)cnt, far_cap, g, dx);
             }
             MFX_HIP_CHECK(hipGetLastError());
-            return mfx_internal_colsum_add(dy, dbias, M, Cout, Cout, dt, stream);
+            return bias_in_kernel ? MFX_OK : mfx_internal_colsum_add(dy, dbias, M, Cout, Cout, dt, stream);
         }
     }
     // d(columns)[m][k] = sum_o dy[m][o] * W[o][k]   (dcn_v2_cuda.cu:273) as a 1x1 implicit GEMM on the matrix cores

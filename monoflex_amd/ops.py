@@ -463,7 +463,7 @@ def dcn(x, offmask, p: PackedConv):
 # 256 -> 64 @ 24 x 80: 30 -> 24 us) and loses from 35 MB up (the projection GEMM is bound by writing the map: 70.8 MB take 33-47 us with this library's
 # 1x1 kernel AND with the vendor's GEMM), so the byte limit below keeps it to the two small-map channel-reducing modules.
 DCN_PS = [os.environ.get("MFX_DCN_PS", "1") != "0"]      # MFX_DCN_PS=0: every layer on the fused gather kernels (A/B)
-DCN_PS_MAX_BYTES = [24 << 20]
+DCN_PS_MAX_BYTES = [int(os.environ.get("MFX_DCN_PS_MAX_MB", "24")) << 20]
 PROJECT_AS = [os.environ.get("MFX_PROJECT_AS", "1") != "0"]      # the projection on csrc/gemm_as.hip (0: mfx_conv2d_nhwc's 1x1 kernel)
 
 
