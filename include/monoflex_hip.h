@@ -408,6 +408,9 @@ size_t mfx_upsample_bwd_workspace_bytes(int B, int H, int C, int f);
  * atomics, no zero-fill, bit-reproducible); without it the workgroups add into dw with fp32 atomics */
 int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* dy, void* dx, float* dw,
                           int B, int H, int W, int C, int f, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* the same with dw written in the parameter's own layout (C, 1, 2f, 2f) -- no transposition left for the caller; needs the workspace */
+int mfx_upsample_bwd_nhwc_oihw(const void* x, const float* w, const void* dy, void* dx, float* dw,
+                          int B, int H, int W, int C, int f, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* up[b,2oh,2ow,:] = dy[b,oh,ow,:], zeros elsewhere (data gradient of a stride-2 conv = stride-1 conv of `up`) */
 int mfx_zero_insert2_nhwc(const void* dy, void* up, int B, int Ho, int Wo, int C, int H, int W, int dtype, void* stream);
 /* DCNv2 backward on NHWC fp32 activations (no layout transforms): see dcn_bwd.hip */

@@ -857,12 +857,12 @@ class UpsampleAddFn(Function):
         dy = _c(dy)
         B, H, W, C = x.shape
         dx = torch.empty_like(x)
-        dw = torch.empty((4 * f * f, C), dtype=torch.float32, device=x.device)
+        dw = torch.empty(ctx.wshape, dtype=torch.float32, device=x.device)                  # written in the parameter's layout (C, 1, 2f, 2f)
         nws = L.load().mfx_upsample_bwd_workspace_bytes(B, H, C, f)
         ws = torch.empty(nws // 4, dtype=torch.float32, device=x.device)
-        L.check(L.load().mfx_upsample_bwd_nhwc(_ptr(x), _ptr(wt), _ptr(dy), _ptr(dx), _ptr(dw), B, H, W, C, f, _dt(x.dtype), _ptr(ws), nws,
-                                               _stream()), "mfx_upsample_bwd_nhwc")
-        return dx, dw.t().reshape(ctx.wshape).contiguous(), dy, None
+        L.check(L.load().mfx_upsample_bwd_nhwc_oihw(_ptr(x), _ptr(wt), _ptr(dy), _ptr(dx), _ptr(dw), B, H, W, C, f, _dt(x.dtype), _ptr(ws), nws,
+                                                    _stream()), "mfx_upsample_bwd_nhwc_oihw")
+        return dx, dw, dy, None
 
 
 @_device_guarded

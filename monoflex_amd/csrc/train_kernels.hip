@@ -1001,7 +1001,8 @@ __global__ __launch_bounds__(1024) void upsample_bwd_dw_kernel(const T* __restri
 
 // sum of the workgroups' partial blocks, fixed order: 16 columns x 16 row groups per workgroup (every thread 1/16 of the rows with
 // independent loads in flight, then an LDS fold) -- one thread per column walking all 256 rows took 15 us of pure load latency
-__global__ __launch_bounds__(256) void upsample_dw_sum_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ dw) {
+// `C_tr` > 0: the sums are written in the PARAMETER's layout (C, 1, k, k) = [c][tap] instead of [tap][c]
+__global__ __launch_bounds__(256) void upsample_dw_sum_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ dw, int C_tr) {
     __shared__ float red[16][17];
     const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + col;
@@ -1014,7 +1015,8 @@ __global__ __launch_bounds__(256) void upsample_dw_sum_kernel(const float* __res
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) t += red[q][col];
-        dw[i] = t;
+        if (C_tr > 0) { const int tap = i / C_tr, c = i - tap * C_tr; dw[(size_t)c * (n / C_tr) + tap] = t; }
+        else dw[i] = t;
     }
 }
 
@@ -1470,8 +1472,8 @@ extern "C" size_t mfx_upsample_bwd_workspace_bytes(int B, int H, int C, int f) {
     return (size_t)((nrows + ppb - 1) / ppb) * 4 * f * f * C * sizeof(float);
 }
 
-extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* dy, void* dx, float* dw,
-                                     int B, int H, int W, int C, int f, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+static int upsample_bwd_impl(const void* x, const float* w, const void* dy, void* dx, float* dw,
+                             int B, int H, int W, int C, int f, int dtype, void* workspace, size_t workspace_bytes, void* stream, int dw_oihw) {
     if (!x || !w || !dy || !dx || !dw) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: null pointer");
     const int E = dtype == MFX_F32 ? 4 : 8;
     if (C % E != 0 || f < 1) return mfx_fail(MFX_ERR_ARG, "upsample_bwd: bad C or f");
@@ -1484,6 +1486,7 @@ extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* 
         part = reinterpret_cast<float*>(workspace);            // partial sums per workgroup, summed in order: no atomics, no zero-fill
         ppb = upsample_dw_rows_per_block(nrows);
     } else {
+        if (dw_oihw) return mfx_fail(MFX_ERR_WORKSPACE, "upsample_bwd (parameter-layout gradient): needs the workspace of mfx_upsample_bwd_workspace_bytes");
         MFX_HIP_CHECK(mfx::zero_async(dw, (size_t)4 * f * f * C * sizeof(float), st));
         ppb = g_opt_det ? nrows : (nrows >= 1024 ? 2 : 1);     // input rows per block: >= ~512 blocks (deterministic: one workgroup)
     }
@@ -1498,10 +1501,20 @@ extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* 
           hipLaunchKernelGGL(upsample_bwd_dw_kernel<T16>, dim3(cdivt(nrows, ppb)), dim3(1024), dw_smem, st, (const T16*)x, (const T16*)dy, dw, B, H, W, C, f, ppb, part); });
     if (part) {
         const int n = 4 * f * f * C;
-        hipLaunchKernelGGL(upsample_dw_sum_kernel, dim3(cdivt(n, 16)), dim3(256), 0, st, part, cdivt(nrows, ppb), n, dw);
+        hipLaunchKernelGGL(upsample_dw_sum_kernel, dim3(cdivt(n, 16)), dim3(256), 0, st, part, cdivt(nrows, ppb), n, dw, dw_oihw ? C : 0);
     }
     MFX_HIP_CHECK(hipGetLastError());
     return MFX_OK;
+}
+
+extern "C" int mfx_upsample_bwd_nhwc(const void* x, const float* w, const void* dy, void* dx, float* dw,
+                                     int B, int H, int W, int C, int f, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return upsample_bwd_impl(x, w, dy, dx, dw, B, H, W, C, f, dtype, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int mfx_upsample_bwd_nhwc_oihw(const void* x, const float* w, const void* dy, void* dx, float* dw,
+                                          int B, int H, int W, int C, int f, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return upsample_bwd_impl(x, w, dy, dx, dw, B, H, W, C, f, dtype, workspace, workspace_bytes, stream, 1);
 }
 
 extern "C" int mfx_zero_insert2_nhwc(const void* dy, void* up, int B, int Ho, int Wo, int C, int H, int W, int dtype, void* stream) {

@@ -176,6 +176,7 @@ SYMBOLS = {
     "mfx_maxpool2x2_bwd_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mfx_upsample_bwd_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "mfx_upsample_bwd_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "mfx_upsample_bwd_nhwc_oihw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
     "mfx_zero_insert2_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mfx_dcn_backward_nhwc_workspace_bytes": (_S, [_I] * 10),
     "mfx_dcn_backward_nhwc": (_I, [_P] * 8 + [_I] * 10 + [_P, _S, _P]),
