@@ -381,7 +381,12 @@ int mfx_bn_act_bwd(const void* x, const void* a, const void* da, const float* me
  * it zero again), the finalize step (mean/rstd, running statistics with momentum and the unbiased variance, num_batches_tracked += 1;
  * torch.nn.BatchNorm2d train-mode semantics, model/backbone/dla_dcn.py BatchNorm calls) happens in the prologue of the apply
  * kernel.  mean/rstd (C floats each) are outputs for the backward.  Replaces stats + finalize + act_fwd (and reduce + apply +
- * two gradient copies) with two launches each and no zero-fill launches. */
+ * two gradient copies) with two launches each and no zero-fill launches.
+ * r06: where the map fits the registers of one co-resident grid (<= 32 MB per operand) and is large enough for it to pay, both entries run as ONE
+ * launch -- sums, a grid barrier on words of the same scratch, then the element-wise pass from registers (options "bn_onepass" bit 0 backward /
+ * bit 1 forward, "bn_onepass_min_chunks", "bn_onepass_fwd_min_chunks", "bn_onepass_grid"; not in deterministic mode).  Same expressions, same
+ * outputs to rounding (only the summation order of the column sums differs).  Such a launch spins on other workgroups of ITSELF: at most one of
+ * them may be in flight on a device, i.e. issue mfx_bn_train_* of one device on one stream (the training step does). */
 size_t mfx_bn_scratch_bytes(void);
 int mfx_bn_ncopy(int C);      /* copies of the [2C] sums inside the scratch (the conv epilogue adds into copy workgroup % ncopy) */
 /* stats_done != 0: the producing conv already added the statistics of x to the scratch (mfx_conv_desc.stats): no statistics launch */

@@ -302,7 +302,7 @@ extern int g_opt_dcn_bt_fly;
 extern int g_opt_wgrad_min_m;
 extern int g_opt_dcn_bt_gcol_as;
 extern int g_opt_dcn_bt_fly_bias;
-extern int g_opt_dcn_bt_fuse_min_chunks, g_opt_dcn_bt_fuse_blocks, g_opt_dcn_bt_fuse_wgrad, g_opt_heads_planes, g_opt_heads_persist, g_opt_heads_dbg, g_opt_heads_mfma32, g_opt_dcn_bt_cs, g_opt_dcn_bt_cs_wgs, g_opt_dcn_bt_dbg, g_opt_wgrad_tr, g_opt_wgrad_tr_blocks, g_opt_bn_blocks, g_opt_bn_apply_blocks, g_opt_wgrad_patch, g_opt_wgrad_patch_blocks, g_opt_wgrad_patch_waves;
+extern int g_opt_dcn_bt_fuse_min_chunks, g_opt_dcn_bt_fuse_blocks, g_opt_dcn_bt_fuse_wgrad, g_opt_heads_planes, g_opt_heads_persist, g_opt_heads_dbg, g_opt_heads_mfma32, g_opt_dcn_bt_cs, g_opt_dcn_bt_cs_wgs, g_opt_dcn_bt_dbg, g_opt_wgrad_tr, g_opt_wgrad_tr_blocks, g_opt_bn_blocks, g_opt_bn_apply_blocks, g_opt_bn_onepass, g_opt_bn_onepass_grid, g_opt_bn_onepass_min_chunks, g_opt_bn_onepass_fwd_min_chunks, g_opt_wgrad_patch, g_opt_wgrad_patch_blocks, g_opt_wgrad_patch_waves;
 extern int g_opt_topk_strips;                                                                                           // decode.hip (global namespace)
 extern int g_opt_wgrad_mfma, g_opt_wgrad_blocks, g_opt_wgrad_ws, g_opt_wgrad_ws_blocks;                                   // train_kernels.hip (global namespace)
 namespace mfx {
@@ -441,7 +441,7 @@ static int* option_slot(const std::string& n) {
         {"wgrad_tr", &g_opt_wgrad_tr}, {"bn_blocks", &g_opt_bn_blocks}, {"heads_planes", &g_opt_heads_planes}, {"heads_mfma32", &g_opt_heads_mfma32}, {"heads_persist", &g_opt_heads_persist},
         {"dcn_bt_fuse_wgrad", &g_opt_dcn_bt_fuse_wgrad}, {"dcn_bt_fly", &g_opt_dcn_bt_fly}, {"dcn_bt_gcol_as", &g_opt_dcn_bt_gcol_as}, {"dcn_bt_fly_bias", &g_opt_dcn_bt_fly_bias}, {"wgrad_min_m", &g_opt_wgrad_min_m}, {"dcn_bt_fuse_blocks", &g_opt_dcn_bt_fuse_blocks},
         {"deterministic", &g_opt_det}, {"dcn_bt_fuse_min_chunks", &g_opt_dcn_bt_fuse_min_chunks}, {"dcn_bt_cs", &g_opt_dcn_bt_cs},
-        {"dcn_bt_cs_wgs", &g_opt_dcn_bt_cs_wgs}, {"bn_apply_blocks", &g_opt_bn_apply_blocks}, {"wgrad_patch", &g_opt_wgrad_patch},
+        {"dcn_bt_cs_wgs", &g_opt_dcn_bt_cs_wgs}, {"bn_apply_blocks", &g_opt_bn_apply_blocks}, {"bn_onepass", &g_opt_bn_onepass}, {"bn_onepass_grid", &g_opt_bn_onepass_grid}, {"bn_onepass_min_chunks", &g_opt_bn_onepass_min_chunks}, {"bn_onepass_fwd_min_chunks", &g_opt_bn_onepass_fwd_min_chunks}, {"wgrad_patch", &g_opt_wgrad_patch},
         {"wgrad_patch_waves", &g_opt_wgrad_patch_waves}, {"wgrad_patch_blocks", &g_opt_wgrad_patch_blocks}, {"wgrad_tr_blocks", &g_opt_wgrad_tr_blocks}};
     for (const auto& e : table)
         if (n == e.first) return e.second;

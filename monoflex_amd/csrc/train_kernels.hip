@@ -1348,7 +1348,337 @@ static int bn_ncopy(int C) { return std::max(1, BN_SCRATCH_COLS / (2 * C)); }
 constexpr int BN_TICKET_WORDS = BN_TICKET_GROUPS * BN_TICKET_STRIDE + BN_TICKET_STRIDE;
 extern "C" int mfx_bn_ncopy(int C) { return C > 0 && 2 * C <= BN_SCRATCH_COLS ? bn_ncopy(C) : 0; }
 
-extern "C" size_t mfx_bn_scratch_bytes(void) { return (size_t)(2 * BN_SCRATCH_COLS + 2 * BN_TICKET_WORDS) * sizeof(float); }
+// grid-barrier words of the one-pass kernels (below): 32 first-level counters on separate lines, then [top, stuck flag, ...], then 32 go words
+constexpr int BN_BAR_GROUPS = 32, BN_BAR_STRIDE = 32;
+constexpr int BN_BAR_WORDS = (2 * BN_BAR_GROUPS + 1) * BN_BAR_STRIDE;
+// layout (floats / words): [fwd sums 1024][bwd sums 1024][fwd tickets][bwd tickets][barrier]
+extern "C" size_t mfx_bn_scratch_bytes(void) { return (size_t)(2 * BN_SCRATCH_COLS + 2 * BN_TICKET_WORDS + BN_BAR_WORDS) * sizeof(float); }
+
+
+// ------------------------------------------------------------------------------------------------
+// ONE-pass train-mode BN (r06): statistics (or the backward sums) and the element-wise pass in ONE launch, the map held in REGISTERS
+// between the two.  The two-launch forms read every operand twice; on the 12x40 .. 96x320 maps of DLA levels 2-5 and the DCN modules each
+// of the two launches is latency-bound (15 us for 2-8 MB), so half of a step's 2.9 ms of BN passes is launch + first-touch latency.
+// Here every thread loads its NCH 16-byte chunks of each operand at once (all loads in flight), folds them into the column sums
+// (LDS, then one global atomic per column and workgroup into the layer's self-clearing scratch, as the two-launch forms do), meets
+// the other workgroups at a GRID BARRIER, reads the totals and finishes from its registers.  The grid never exceeds the co-resident
+// capacity of the device (occupancy query x CUs, checked by the launcher), so the barrier cannot starve; its counters are two-level
+// (32 first-level lines), reset by the last workgroup to leave, and the spin is bounded (a flag word is set instead of hanging).
+// Only ONE such kernel may be in flight on the device: they are launched on the step's main stream only.
+// ------------------------------------------------------------------------------------------------
+// No cache maintenance is needed around this barrier -- and none is done: agent-scope release / acquire fences write back and invalidate the
+// whole L2 of an XCD, and 1900 waves doing that cost 25-30 us per launch (first form of this kernel, r06 call 48: three times SLOWER than the two
+// launches).  Everything the workgroups exchange (the column sums, the counters) is only ever touched with agent-scope ATOMICS, which are performed
+// at the device's coherence point past every cache; what the barrier must guarantee is order, and s_waitcnt vmcnt(0) gives it: a thread's adds into
+// the sums are acknowledged before its workgroup arrives.
+// Arrival is two-level (32 first-level lines); the very last arrival raises one GO word per group (32 lanes, 32 lines) and every workgroup polls
+// its own group's word: 16 pollers per line, none of them on a line that still takes arrivals.
+__device__ __forceinline__ void bn_grid_barrier(unsigned* bar, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's adds into the sums have been performed
+    __syncthreads();
+    if (tid < 64) {
+        const unsigned G = gridDim.x, grp = blockIdx.x % BN_BAR_GROUPS;
+        const unsigned members = (G - grp + BN_BAR_GROUPS - 1) / BN_BAR_GROUPS;
+        const unsigned groups = G < (unsigned)BN_BAR_GROUPS ? G : (unsigned)BN_BAR_GROUPS;
+        unsigned* top = bar + BN_BAR_GROUPS * BN_BAR_STRIDE;
+        unsigned* go = bar + (BN_BAR_GROUPS + 1) * BN_BAR_STRIDE;
+        int last = 0;
+        if (tid == 0 && __hip_atomic_fetch_add(bar + grp * BN_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1)
+            last = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+        last = __shfl(last, 0);
+        if (last && (unsigned)tid < groups) __hip_atomic_store(go + tid * BN_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && !last) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(go + grp * BN_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 21)) { atomicOr(top + 1, 1u); break; }   // never expected: the grid is co-resident by construction
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// The chunks stay PACKED in registers across the barrier: without this the compiler keeps the unpacked floats of the first phase alive (twice the
+// registers for 16-bit maps) and spills.
+__device__ __forceinline__ void bn_keep_packed(u32x4& c) { asm volatile("" : "+v"(c)); }
+
+// the totals, read past every non-coherent cache (the adds were agent-scope atomics of other XCDs' workgroups in THIS launch)
+__device__ __forceinline__ void bn_fold_copies_coherent(const float* sums, int C, int ncopy, float* colsum, int tid) {
+    const int cols = 2 * C;
+    for (int j = tid; j < cols; j += 256) {
+        float t = 0.f;
+        for (int k = 0; k < ncopy; ++k) t += __hip_atomic_load(sums + (size_t)k * cols + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        colsum[j] = t;
+    }
+    __syncthreads();
+}
+
+// bn_release_scratch + the barrier words (every workgroup is past the barrier once it holds a leave ticket)
+__device__ __forceinline__ void bn_release_scratch_bar(float* sums, unsigned* cnt, unsigned* bar, unsigned ticket, int tid, int* s_last) {
+    bn_release_scratch(sums, cnt, ticket, tid, s_last);
+    if (*s_last && tid < 2 * BN_BAR_GROUPS + 1) bar[tid * BN_BAR_STRIDE] = 0u;   // 32 first-level counters, `top` (the stuck flag beside it stays), 32 go words
+}
+
+template <typename T, int NCH, bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void bn_fwd_onepass_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+        const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var, long long* nbt,
+        float momentum, float eps, float inv_count, float unbias, float* sums, unsigned* counter, unsigned* bar, int ncopy,
+        float* __restrict__ mean_out, float* __restrict__ rstd_out, long total_chunks, int C, int act) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    extern __shared__ float sred[];                          // [256 / CPR][2 * C]
+    __shared__ float colsum[BN_SCRATCH_COLS];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, CPR = C / E, cc = tid % CPR;
+    const uint32_t nthr = gridDim.x * 256u, i0 = blockIdx.x * 256u + tid, total = (uint32_t)total_chunks;      // 256 and the grid stride are multiples of CPR: one channel chunk per thread;
+    const char* xb = reinterpret_cast<const char*>(x);        // 32-bit byte offsets from uniform bases (the launcher bounds the map at 32 MB): no 64-bit address per slot and operand
+    u32x4 xr[NCH], rr[HAS_RES ? NCH : 1];
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+        const uint32_t i = i0 + (uint32_t)s * nthr;
+        xr[s] = u32x4{0u, 0u, 0u, 0u};
+        if (i < total) xr[s] = *reinterpret_cast<const u32x4*>(xb + i * 16u);
+    }
+    if constexpr (HAS_RES) {
+#pragma unroll
+        for (int s = 0; s < NCH; ++s) {
+            const uint32_t i = i0 + (uint32_t)s * nthr;
+            rr[s] = u32x4{0u, 0u, 0u, 0u};
+            if (i < total) rr[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(res) + i * 16u);
+        }
+    }
+    float acc[2][E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {                          // (a missing chunk is zeros: it adds nothing)
+        float v[E];
+        ElemTraits<T>::unpack(xr[s], v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { acc[0][e] += v[e]; acc[1][e] += v[e] * v[e]; }
+    }
+    {
+        float* sp = sums + (size_t)(blockIdx.x % ncopy) * 2 * C;
+        float* const outs[2] = {sp, sp + C};
+        block_reduce_columns<E, 2>(acc, sred, C, CPR, tid, outs);
+    }
+    bn_grid_barrier(bar, tid);
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) { bn_keep_packed(xr[s]); if constexpr (HAS_RES) bn_keep_packed(rr[s]); }
+    bn_fold_copies_coherent(sums, C, ncopy, colsum, tid);
+    const unsigned ticket = tid == 0 ? bn_take_ticket(counter) : 0u;
+    float sc[E], sh[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int c = cc * E + e;
+        const float m = colsum[c] * inv_count;
+        const float v = fmaxf(colsum[C + c] * inv_count - m * m, 0.f);
+        const float r = rsqrtf(v + eps);
+        sc[e] = gamma[c] * r; sh[e] = beta[c] - m * sc[e];
+    }
+    if (blockIdx.x == 0) {
+        for (int c = tid; c < C; c += 256) {
+            const float m = colsum[c] * inv_count;
+            const float v = fmaxf(colsum[C + c] * inv_count - m * m, 0.f);
+            mean_out[c] = m; rstd_out[c] = rsqrtf(v + eps);
+            if (running_mean) {
+                running_mean[c] = running_mean[c] * (1.f - momentum) + m * momentum;
+                running_var[c] = running_var[c] * (1.f - momentum) + v * unbias * momentum;
+            }
+        }
+        if (tid == 0 && nbt) *nbt += 1;
+    }
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+        const uint32_t i = i0 + (uint32_t)s * nthr;
+        if (i < total) {
+            float v[E];
+            ElemTraits<T>::unpack(xr[s], v);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = v[e] * sc[e] + sh[e];
+            if constexpr (HAS_RES) {
+                float r[E];
+                ElemTraits<T>::unpack(rr[s], r);
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] += r[e];
+            }
+            apply_act_chunk<E>(v, act, 0);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y) + i * 16u) = ElemTraits<T>::pack(v);
+        }
+    }
+    bn_release_scratch_bar(sums, counter, bar, ticket, tid, &s_last);
+}
+
+template <typename T, int NCH, bool HAS_A>
+__global__ __launch_bounds__(256, 2) void bn_bwd_onepass_kernel(const T* __restrict__ x, const T* __restrict__ a, const T* __restrict__ da,
+        const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+        float* sums, unsigned* counter, unsigned* bar, int ncopy, float invM, T* __restrict__ dx, T* __restrict__ dres,
+        float* __restrict__ dgamma, float* __restrict__ dbeta, long total_chunks, int C, int act) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    extern __shared__ float sred[];                          // [256 / CPR][2 * C]
+    __shared__ float colsum[BN_SCRATCH_COLS];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, CPR = C / E, cc = tid % CPR;
+    const uint32_t nthr = gridDim.x * 256u, i0 = blockIdx.x * 256u + tid, total = (uint32_t)total_chunks;
+    const char* xb = reinterpret_cast<const char*>(x);
+    const bool recompute = act != ACT_NONE && !HAS_A;              // see bn_bwd_reduce_kernel
+    u32x4 xr[NCH], dr[NCH], ar[HAS_A ? NCH : 1];
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+        const uint32_t i = i0 + (uint32_t)s * nthr;
+        xr[s] = u32x4{0u, 0u, 0u, 0u}; dr[s] = u32x4{0u, 0u, 0u, 0u};
+        if (i < total) { xr[s] = *reinterpret_cast<const u32x4*>(xb + i * 16u); dr[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(da) + i * 16u); }
+        if constexpr (HAS_A) {
+            ar[s] = u32x4{0u, 0u, 0u, 0u};
+            if (i < total) ar[s] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a) + i * 16u);
+        }
+    }
+    float mu[E], rs[E], sc[E], sh[E], acc[2][E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int c = cc * E + e;
+        acc[0][e] = 0.f; acc[1][e] = 0.f; mu[e] = mean[c]; rs[e] = rstd[c];
+        sc[e] = recompute ? gamma[c] * rs[e] : 0.f;
+        sh[e] = recompute ? beta[c] - mu[e] * sc[e] : 0.f;
+    }
+    // derivative of the activation from its output: 1 above the threshold, `slope` below (none: threshold -inf; relu: 0 / 0; leaky: 0 / 0.01)
+    const float thr = act == ACT_NONE ? -__builtin_inff() : 0.f, slope = act == ACT_LEAKY ? 0.01f : (act == ACT_RELU ? 0.f : 1.f);
+    auto grad = [&](int s, float (&xv)[E], float (&gq)[E]) {      // g = da * act'(a), the two-launch forms' expression
+        float dv[E], av[E];
+        ElemTraits<T>::unpack(xr[s], xv); ElemTraits<T>::unpack(dr[s], dv);
+        if constexpr (HAS_A) ElemTraits<T>::unpack(ar[s], av);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (!HAS_A) av[e] = xv[e] * sc[e] + sh[e];
+            gq[e] = dv[e] * (av[e] > thr ? 1.f : slope);      // act_grad() without a branch on `act` (the compiler made three copies of the kernel body)
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {                          // (a missing chunk has da = 0: it adds nothing)
+        float xv[E], gq[E];
+        grad(s, xv, gq);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { acc[0][e] += gq[e]; acc[1][e] += gq[e] * (xv[e] - mu[e]) * rs[e]; }
+        if (NCH >= 16) __builtin_amdgcn_sched_barrier(0);     // one slot's floats at a time: the packed chunks are what must stay in registers
+    }
+    {
+        float* sp = sums + (size_t)(blockIdx.x % ncopy) * 2 * C;
+        float* const outs[2] = {sp, sp + C};
+        block_reduce_columns<E, 2>(acc, sred, C, CPR, tid, outs);
+    }
+    bn_grid_barrier(bar, tid);
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) { bn_keep_packed(xr[s]); bn_keep_packed(dr[s]); if constexpr (HAS_A) bn_keep_packed(ar[s]); }
+    bn_fold_copies_coherent(sums, C, ncopy, colsum, tid);
+    const unsigned ticket = tid == 0 ? bn_take_ticket(counter) : 0u;
+    float ca[E], cb[E], cd[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int c = cc * E + e;
+        const float sg = colsum[c], sgx = colsum[C + c];
+        ca[e] = gamma[c] * rs[e]; cb[e] = -ca[e] * rs[e] * sgx * invM; cd[e] = -cb[e] * mu[e] - ca[e] * sg * invM;
+    }
+    if (blockIdx.x == 0)
+        for (int c = tid; c < C; c += 256) { dgamma[c] = colsum[C + c]; dbeta[c] = colsum[c]; }
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+        const uint32_t i = i0 + (uint32_t)s * nthr;
+        if (i < total) {
+            float xv[E], gq[E], ov[E];
+            grad(s, xv, gq);
+#pragma unroll
+            for (int e = 0; e < E; ++e) ov[e] = ca[e] * gq[e] + cb[e] * xv[e] + cd[e];
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(dx) + i * 16u) = ElemTraits<T>::pack(ov);
+            if (dres) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(dres) + i * 16u) = ElemTraits<T>::pack(gq);
+        }
+        if (NCH >= 16) __builtin_amdgcn_sched_barrier(0);
+    }
+    bn_release_scratch_bar(sums, counter, bar, ticket, tid, &s_last);
+}
+
+int g_opt_bn_onepass = 3;          // option "bn_onepass": bit 0 = backward, bit 1 = forward in one launch where the map fits (0 = the two-launch forms everywhere)
+int g_opt_bn_onepass_min_chunks = 200000;       // option "bn_onepass_min_chunks": smaller maps keep the two launches (backward)
+int g_opt_bn_onepass_fwd_min_chunks = 900000;   // option "bn_onepass_fwd_min_chunks": the same for the forward
+int g_opt_bn_onepass_grid = 0;     // option "bn_onepass_grid": workgroup cap (0 = by map size, see bn_onepass_plan)
+
+// co-resident workgroups of the one-pass kernels: 2 per CU by their launch bounds; asked of the runtime once per kernel
+template <typename K> static int bn_onepass_capacity(K kernel, size_t smem) {
+    int dev = 0, per_cu = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) != hipSuccess) return 0;
+    return std::min(per_cu, 2) * cus;
+}
+
+// slots per thread (2 / 4 / 8 / 16) and grid for `chunks` 16-byte chunks; 0 = the map does not fit the registers of one resident grid
+static int bn_onepass_plan(long chunks, int cap, int* grid, int max_nch, long min_chunks) {
+    // measured per shape (tools/bn_bench.py, B = 8, bf16; r06 calls 49 / 50, us one-pass vs two launches): the barrier costs about what a launch
+    // boundary costs, so one launch wins by the re-read it saves and by nothing else.  Backward: 64 ch @ 96x320 29.6 vs 37.1 (512 workgroups),
+    // 128 @ 48x160 20.4 vs 28.8 (256), 256 @ 24x80 16.4 vs 21.8 (256), 512 @ 12x40 16.5 vs 20.8 (128).  Forward: 19.2 vs 21.6, 12.9 vs 15.0, then
+    // a loss (14.6 vs 12.4 at 256 channels): the forward keeps its two launches below ~0.9 M chunks.  Fewer, fatter workgroups on the smaller maps:
+    // every workgroup adds 2C columns into the sums and takes part in the barrier.
+    if (chunks < min_chunks) return 0;
+    const int want = g_opt_bn_onepass_grid > 0 ? g_opt_bn_onepass_grid : (chunks > (1 << 20) ? 512 : (chunks > 300000 ? 256 : 128));
+    cap = std::min(cap, want);
+    if (cap < 32 || chunks * 16 >= (1ll << 31)) return 0;
+    for (int nch = 2; nch <= max_nch; nch *= 2)
+        if ((long)nch * 256 * cap >= chunks) { *grid = (int)((chunks + 256L * nch - 1) / (256L * nch)); return nch; }
+    return 0;
+}
+
+#define BN_ONEPASS_NCH(NCH_, ...) switch (NCH_) { case 2: { constexpr int N_ = 2; __VA_ARGS__; } break; case 4: { constexpr int N_ = 4; __VA_ARGS__; } break; \
+                                                  case 8: { constexpr int N_ = 8; __VA_ARGS__; } break; default: { constexpr int N_ = 16; __VA_ARGS__; } break; }
+
+template <typename T>
+static int bn_fwd_onepass(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          long long* nbt, float momentum, float eps, long M, int C, int act, float* scratch, float* mean, float* rstd, hipStream_t st) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
+    static int cap_res = -1, cap_nores = -1;
+    int& cap = res ? cap_res : cap_nores;
+    if (cap < 0) cap = res ? bn_onepass_capacity(bn_fwd_onepass_kernel<T, 16, true>, smem) : bn_onepass_capacity(bn_fwd_onepass_kernel<T, 16, false>, smem);
+    const long chunks = M * (C / E);
+    int grid = 0;
+    const int nch = bn_onepass_plan(chunks, cap, &grid, 16, std::min(g_opt_bn_onepass_min_chunks, g_opt_bn_onepass_fwd_min_chunks) == 0 ? 0 : g_opt_bn_onepass_fwd_min_chunks);
+    if (!nch) return 1;
+    const int ncopy = bn_ncopy(C);
+    const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+    unsigned* counter = reinterpret_cast<unsigned*>(scratch + 2 * BN_SCRATCH_COLS);
+    unsigned* bar = counter + 2 * BN_TICKET_WORDS;
+    if (res) {
+        BN_ONEPASS_NCH(nch, hipLaunchKernelGGL((bn_fwd_onepass_kernel<T, N_, true>), dim3(grid), dim3(256), smem, st, (const T*)x, (const T*)res, (T*)y, gamma, beta,
+                                  running_mean, running_var, nbt, momentum, eps, (float)(1.0 / (double)M), unbias, scratch, counter, bar, ncopy, mean, rstd, chunks, C, act))
+    } else {
+        BN_ONEPASS_NCH(nch, hipLaunchKernelGGL((bn_fwd_onepass_kernel<T, N_, false>), dim3(grid), dim3(256), smem, st, (const T*)x, (const T*)res, (T*)y, gamma, beta,
+                                  running_mean, running_var, nbt, momentum, eps, (float)(1.0 / (double)M), unbias, scratch, counter, bar, ncopy, mean, rstd, chunks, C, act))
+    }
+    return 0;
+}
+
+template <typename T>
+static int bn_bwd_onepass(const void* x, const void* a, const void* da, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          void* dx, void* dres, float* dgamma, float* dbeta, long M, int C, int act, float* scratch, hipStream_t st) {
+    constexpr int E = ElemTraits<T>::ELEMS;
+    const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
+    static int cap_a = -1, cap_noa = -1;
+    int& cap = a ? cap_a : cap_noa;
+    if (cap < 0) cap = a ? bn_onepass_capacity(bn_bwd_onepass_kernel<T, 16, true>, smem) : bn_onepass_capacity(bn_bwd_onepass_kernel<T, 16, false>, smem);
+    const long chunks = M * (C / E);
+    int grid = 0;
+    const int nch = bn_onepass_plan(chunks, cap, &grid, a ? 8 : 16, g_opt_bn_onepass_min_chunks);      // three operands x 16 slots do not fit 256 registers
+    if (!nch) return 1;
+    const int ncopy = bn_ncopy(C);
+    float* sums = scratch + BN_SCRATCH_COLS;
+    unsigned* counter = reinterpret_cast<unsigned*>(scratch + 2 * BN_SCRATCH_COLS) + BN_TICKET_WORDS;
+    unsigned* bar = reinterpret_cast<unsigned*>(scratch + 2 * BN_SCRATCH_COLS) + 2 * BN_TICKET_WORDS;
+    if (a) {
+        BN_ONEPASS_NCH(nch, hipLaunchKernelGGL((bn_bwd_onepass_kernel<T, N_, true>), dim3(grid), dim3(256), smem, st, (const T*)x, (const T*)a, (const T*)da, mean, rstd, gamma, beta,
+                                sums, counter, bar, ncopy, 1.f / (float)M, (T*)dx, (T*)dres, dgamma, dbeta, chunks, C, act))
+    } else {
+        BN_ONEPASS_NCH(nch, hipLaunchKernelGGL((bn_bwd_onepass_kernel<T, N_, false>), dim3(grid), dim3(256), smem, st, (const T*)x, (const T*)a, (const T*)da, mean, rstd, gamma, beta,
+                                sums, counter, bar, ncopy, 1.f / (float)M, (T*)dx, (T*)dres, dgamma, dbeta, chunks, C, act))
+    }
+    return 0;
+}
 
 extern "C" int mfx_bn_train_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, long long* num_batches_tracked, float momentum, float eps, long M, int C, int act,
@@ -1362,6 +1692,12 @@ extern "C" int mfx_bn_train_fwd(const void* x, const void* res, void* y, const f
     const int E = dtype == MFX_F32 ? 4 : 8, ncopy = bn_ncopy(C);
     const int rows = bn_rows_per_block(M, C, dtype, ncopy);
     const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
+    if (!stats_done && (g_opt_bn_onepass & 2) && !g_opt_det) {          // statistics + element-wise pass in one launch where the map fits the registers of one grid
+        int r = 1;
+        DISPATCH_T(dtype, r = bn_fwd_onepass<float>(x, res, y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, M, C, act, scratch, mean, rstd, st),
+                          r = bn_fwd_onepass<T16>(x, res, y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, M, C, act, scratch, mean, rstd, st));
+        if (r == 0) { MFX_HIP_CHECK(hipGetLastError()); return MFX_OK; }
+    }
     if (!stats_done)
         DISPATCH_T(dtype, hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, M, C, rows, scratch, scratch + C, ncopy),
                           hipLaunchKernelGGL(bn_stats_kernel<T16>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const T16*)x, M, C, rows, scratch, scratch + C, ncopy));
@@ -1431,6 +1767,12 @@ extern "C" int mfx_bn_train_bwd(const void* x, const void* a, const void* da, co
     const int E = dtype == MFX_F32 ? 4 : 8, ncopy = bn_ncopy(C);
     const int rows = bn_rows_per_block(M, C, dtype, ncopy);
     const size_t smem = (size_t)(256 / (C / E)) * 2 * C * sizeof(float);
+    if ((g_opt_bn_onepass & 1) && !g_opt_det) {
+        int r = 1;
+        DISPATCH_T(dtype, r = bn_bwd_onepass<float>(x, a, da, mean, rstd, gamma, beta, dx, dres, dgamma, dbeta, M, C, act, scratch, st),
+                          r = bn_bwd_onepass<T16>(x, a, da, mean, rstd, gamma, beta, dx, dres, dgamma, dbeta, M, C, act, scratch, st));
+        if (r == 0) { MFX_HIP_CHECK(hipGetLastError()); return MFX_OK; }
+    }
     float* sums = scratch + BN_SCRATCH_COLS;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(cdivt(M, rows)), dim3(256), smem, st, (const float*)x, (const float*)a, (const float*)da, mean, rstd, M, C, rows, act, sums, sums + C, ncopy, gamma, beta),

@@ -190,6 +190,77 @@ def test_bn_two_launch_form_reuses_its_scratch(C, shape, dt):
     assert float(AG._bn_scratch(bn_a.weight).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("C,shape,dt,act,res", [
+    (512, (8, 12, 40), "bf16", "relu", False),        # DLA level 5 (2 slots per thread)
+    (256, (8, 24, 80), "bf16", "relu", True),         # level 4, residual (4 slots)
+    (128, (8, 48, 160), "bf16", "relu", False),       # level 3 (8 slots)
+    (64, (8, 96, 320), "bf16", "relu", False),        # level 2 / the DCN modules (16 slots)
+    (64, (8, 96, 320), "bf16", "relu", True),         # forward one pass (16 slots x 2 operands), backward falls back (3 operands x 16 slots)
+    (64, (8, 96, 320), "fp16", "leaky", False),
+    (128, (3, 13, 17), "bf16", "none", False),        # ragged: the last slot of most threads is empty
+    (16, (2, 40, 64), "fp32", "relu", True),
+    (32, (1, 7, 9), "fp16", "leaky", True),           # fewer chunks than one workgroup has threads
+    (32, (8, 192, 640), "bf16", "relu", False),       # 63 MB: does not fit one resident grid -> the two-launch form on both sides
+])
+def test_bn_one_pass_kernels_equal_the_two_launch_form(C, shape, dt, act, res):
+    """r06: statistics + element-wise pass in one launch with a grid barrier (csrc/train_kernels.hip bn_fwd_onepass_kernel /
+    bn_bwd_onepass_kernel).  Same expressions as the two-launch form, only the summation order of the column sums differs: outputs,
+    every gradient and the running statistics agree to rounding; the scratch (sums, tickets, barrier words, stuck flag) is zero
+    after every call; three repetitions re-use it."""
+    from monoflex_amd import autograd as AG
+    from monoflex_amd import lib as L
+    dtype = DT[dt]
+    code = {"relu": L.ACT_RELU, "leaky": L.ACT_LEAKY, "none": L.ACT_NONE}[act]
+    g = torch.Generator().manual_seed(C + shape[1])
+    B, H, W = shape
+    bn_a, bn_b = torch.nn.BatchNorm2d(C).to(DEV), torch.nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.rand(C, generator=g) + 0.5); bn_a.bias.copy_(torch.randn(C, generator=g) * 0.5)
+    bn_b.load_state_dict(bn_a.state_dict())
+    tol = 2e-2 if dt != "fp32" else 1e-4
+    for it in range(3):
+        x = (torch.randn(B, H, W, C, generator=g) * (1 + 0.5 * it) + 0.3 * it).to(DEV).to(dtype)
+        rs = torch.randn(B, H, W, C, generator=g).to(DEV).to(dtype) if res else None
+        r = torch.randn(B, H, W, C, generator=g).to(DEV).to(dtype)
+        outs = []
+        for bn, onepass in ((bn_a, 3), (bn_b, 0)):             # 3 = backward and forward; every size (the defaults keep small maps and the forward on two launches)
+            L.check(L.load().mfx_set_option(b"bn_onepass", onepass), "set_option")
+            L.check(L.load().mfx_set_option(b"bn_onepass_min_chunks", 0), "set_option")
+            try:
+                xd = x.clone().requires_grad_()
+                rd = rs.clone().requires_grad_() if res else None
+                bn.zero_grad()
+                y = AG.bn_act(xd, bn, code, rd)
+                y.backward(r)
+                outs.append((y.detach(), xd.grad, rd.grad if res else xd.grad, bn.weight.grad.clone(), bn.bias.grad.clone()))
+            finally:
+                L.check(L.load().mfx_reset_options(), "reset_options")
+        for i, (a, b) in enumerate(zip(*outs)):
+            if dt != "fp32" and i < 3:         # (see test_bn_two_launch_form_reuses_its_scratch: values on the activation threshold may switch sides)
+                d = (a.float() - b.float()).abs()
+                assert float((d > tol * b.float().abs().max()).float().mean()) < 2e-5, (it, i, _rel(a.float(), b.float()))
+                continue
+            assert _rel(a.float(), b.float()) < (tol if i < 3 else (2e-3 if dt != "fp32" else 2e-4)), (it, i, _rel(a.float(), b.float()))
+        assert float(AG._bn_scratch(bn_a.weight).abs().max()) == 0.0, "the one-pass kernels must leave sums, tickets and barrier words zero"
+    assert _rel(bn_a.running_mean, bn_b.running_mean) < 1e-5 and _rel(bn_a.running_var, bn_b.running_var) < 1e-5
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 3
+    # and against torch (fp32 arithmetic on the same 16-bit inputs)
+    bn_t = torch.nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn_t.weight.copy_(bn_a.weight); bn_t.bias.copy_(bn_a.bias)
+    xt = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_()
+    t = bn_t(xt)
+    if res:
+        t = t + rs.float().permute(0, 3, 1, 2)
+    yt = {"relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.01), "none": lambda v: v}[act](t)
+    yt.backward(r.float().permute(0, 3, 1, 2))
+    ya, dxa = outs[0][0], outs[0][1]
+    d = (dxa.float().permute(0, 3, 1, 2) - xt.grad).abs()
+    assert float((d > tol * xt.grad.abs().max()).float().mean()) < 1e-4
+    assert _rel(ya.float().permute(0, 3, 1, 2), yt.detach()) < (1e-2 if dt != "fp32" else 1e-5)
+    assert _rel(outs[0][3], bn_t.weight.grad) < 5e-3 and _rel(outs[0][4], bn_t.bias.grad) < 5e-3
+
+
 @pytest.mark.parametrize("act", ["relu", "leaky"])
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 def test_bn_backward_recomputes_the_activation_sign_from_its_input(act, dt):
