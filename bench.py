@@ -720,7 +720,7 @@ def run_train(args, rank, world, device, steps=None, warmup=None, leg=False, dty
                    "timing": {"repeats": len(all_s), "reported": "median repeat", "steps_per_repeat": steps,
                               "ms_per_step_each": [round(1e3 * t / steps, 4) for t in all_s]},
                    "model_tflops_per_s": round(TRAIN_GFLOP_PER_IMG * n_img / elapsed / 1e3, 2), "loss_last_step": loss_v,
-                   "h2d_excluded": True, **loss_scale_info},
+                   "h2d_excluded": True, "bn_one_launch_barriers_ok": bool(lib.bn_onepass_ok()), **loss_scale_info},
         "roofline": roof,
     }
     if leg:

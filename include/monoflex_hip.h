@@ -388,6 +388,9 @@ int mfx_bn_act_bwd(const void* x, const void* a, const void* da, const float* me
  * outputs to rounding (only the summation order of the column sums differs).  Such a launch spins on other workgroups of ITSELF: at most one of
  * them may be in flight on a device, i.e. issue mfx_bn_train_* of one device on one stream (the training step does). */
 size_t mfx_bn_scratch_bytes(void);
+/* 1 if a one-pass launch gave up at its barrier since the last reset (bounded spin; its outputs are then wrong), 0 if none, < 0 on error.
+ * Cannot happen with one training process per device.  Synchronises the device; engine/trainer.py asks wherever it reads the loss. */
+int mfx_bn_onepass_stuck(int reset);
 int mfx_bn_ncopy(int C);      /* copies of the [2C] sums inside the scratch (the conv epilogue adds into copy workgroup % ncopy) */
 /* stats_done != 0: the producing conv already added the statistics of x to the scratch (mfx_conv_desc.stats): no statistics launch */
 int mfx_bn_train_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* running_mean,

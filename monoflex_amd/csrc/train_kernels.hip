@@ -1371,6 +1371,8 @@ extern "C" size_t mfx_bn_scratch_bytes(void) { return (size_t)(2 * BN_SCRATCH_CO
 // launches).  Everything the workgroups exchange (the column sums, the counters) is only ever touched with agent-scope ATOMICS, which are performed
 // at the device's coherence point past every cache; what the barrier must guarantee is order, and s_waitcnt vmcnt(0) gives it: a thread's adds into
 // the sums are acknowledged before its workgroup arrives.
+__device__ unsigned g_bn_onepass_stuck = 0u;      // raised when a barrier's bounded spin ran out (mfx_bn_onepass_stuck reads it)
+
 // Arrival is two-level (32 first-level lines); the very last arrival raises one GO word per group (32 lanes, 32 lines) and every workgroup polls
 // its own group's word: 16 pollers per line, none of them on a line that still takes arrivals.
 __device__ __forceinline__ void bn_grid_barrier(unsigned* bar, int tid) {
@@ -1391,7 +1393,7 @@ __device__ __forceinline__ void bn_grid_barrier(unsigned* bar, int tid) {
             unsigned spins = 0;
             while (__hip_atomic_load(go + grp * BN_BAR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 21)) { atomicOr(top + 1, 1u); break; }   // never expected: the grid is co-resident by construction
+                if (++spins > (1u << 21)) { atomicOr(top + 1, 1u); atomicOr(&g_bn_onepass_stuck, 1u); break; }   // never expected in one process: the grid is co-resident by construction
             }
         }
     }
@@ -1678,6 +1680,15 @@ static int bn_bwd_onepass(const void* x, const void* a, const void* da, const fl
                                 sums, counter, bar, ncopy, 1.f / (float)M, (T*)dx, (T*)dres, dgamma, dbeta, chunks, C, act))
     }
     return 0;
+}
+
+// 1 if a one-pass BN launch gave up waiting at its grid barrier since the last reset (its outputs are then wrong): another process's kernels
+// held the CUs its remaining workgroups needed (two processes training on ONE device), or two such launches were in flight.  Synchronises.
+extern "C" int mfx_bn_onepass_stuck(int reset) {
+    unsigned v = 0u;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_bn_onepass_stuck), sizeof(v)) != hipSuccess) return mfx_fail(MFX_ERR_LAUNCH, "bn_onepass_stuck: copy from the device failed");
+    if (reset && v) { const unsigned z = 0u; if (hipMemcpyToSymbol(HIP_SYMBOL(g_bn_onepass_stuck), &z, sizeof(z)) != hipSuccess) return mfx_fail(MFX_ERR_LAUNCH, "bn_onepass_stuck: reset failed"); }
+    return v ? 1 : 0;
 }
 
 extern "C" int mfx_bn_train_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* running_mean,

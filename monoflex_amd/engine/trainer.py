@@ -707,6 +707,10 @@ def do_train(cfg, distributed, model, data_loader, data_loaders_val, optimizer, 
         arguments["iteration"] = iteration
         if iteration % 10 == 0 or iteration == max_iter:
             loss_v = float(losses)
+            from .. import lib as L
+            if torch.cuda.is_available() and not L.bn_onepass_ok():
+                raise RuntimeError("a one-launch BatchNorm timed out at its grid barrier (another process is computing on this device?): "
+                                   "results since the last check are invalid -- rerun with MFX_OPTIONS=bn_onepass=0")
             logger.info("iter: %d  loss: %.4f  lr: %.8f  %.3f s/iter", iteration, loss_v, optimizer.param_groups[0]["lr"],
                         (time.time() - t0) / (iteration - start_iter))
         if comm.get_rank() == 0 and checkpointer is not None:

@@ -174,6 +174,7 @@ SYMBOLS = {
     "mfx_bn_bwd_reduce": (_I, [_P] * 7 + [ctypes.c_long, _I, _I, _I, _P]),
     "mfx_bn_bwd_apply": (_I, [_P] * 10 + [ctypes.c_long, ctypes.c_long, _I, _I, _I, _P]),
     "mfx_maxpool2x2_bwd_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mfx_bn_onepass_stuck": (_I, [_I]),
     "mfx_upsample_bwd_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "mfx_upsample_bwd_nhwc": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
     "mfx_upsample_bwd_nhwc_oihw": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
@@ -231,6 +232,19 @@ def f16x2_range_ok(reset=True):
     rc = load().mfx_f16x2_range_check(1 if reset else 0)
     if rc < 0:
         check(rc, "mfx_f16x2_range_check")
+    return rc == 0
+
+
+def bn_onepass_ok(reset=True):
+    """False if a one-launch BatchNorm (csrc/train_kernels.hip bn_*_onepass_kernel) gave up waiting at its grid barrier since the last reset: its
+    workgroups did not all become resident, which needs another PROCESS computing on the same device (or two such launches in flight at once).
+    The outputs of that launch are wrong; run with MFX_OPTIONS=bn_onepass=0 in such a setup.  Synchronises the device."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    rc = load().mfx_bn_onepass_stuck(1 if reset else 0)
+    if rc < 0:
+        check(rc, "mfx_bn_onepass_stuck")
     return rc == 0
 
 
