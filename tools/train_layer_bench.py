@@ -63,7 +63,7 @@ def dominant_kernel_roofline(dtype, B, device, H=96, W=320, C=64, Cout=64, reps=
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype], 4)}
     traffic = traffic_source = None
     try:                                                       # PMC pass of the same group (tools/pmc_dcnbwd.sh), committed with its raw CSV
-        for tag in ("r05", "r04", "r03", "r02"):                      # the newest committed measurement
+        for tag in ("r06", "r05", "r04", "r03", "r02"):               # the newest committed measurement
             f = os.path.join(ROOT, "profiles", tag + "_dcnbwd_traffic.json")
             if not os.path.exists(f):
                 continue
