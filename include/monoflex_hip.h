@@ -285,6 +285,15 @@ int mfx_decode_boxes(const float* hmap, int ld, int reg_off, const float* scores
                      int ncls, int B, int H, int W, int K, const float* calib, const int32_t* pad,
                      const int32_t* img_size, float threshold, float* det, float* topk, int32_t* valid,
                      void* stream);
+/* The same with the reference's other `output_depth` settings (detector_infer.py:149-198; engine/inference.py:154 walks them for
+ * `eval_all_depths`): which of the four depth estimates (direct, keypoint centre / 02 / 13) becomes the box depth, and which uncertainty
+ * scales the score.  mfx_decode_boxes is MFX_DEPTH_SOFT (runs/monoflex.yaml).  'oracle' needs ground truth and is not a decode mode here. */
+enum { MFX_DEPTH_SOFT = 0, MFX_DEPTH_HARD = 1, MFX_DEPTH_MEAN = 2, MFX_DEPTH_DIRECT = 3, MFX_DEPTH_KEYPOINTS_AVG = 4,
+       MFX_DEPTH_KEYPOINTS_CENTER = 5, MFX_DEPTH_KEYPOINTS_02 = 6, MFX_DEPTH_KEYPOINTS_13 = 7 };
+int mfx_decode_boxes_mode(const float* hmap, int ld, int reg_off, const float* scores, const int32_t* index,
+                          int ncls, int B, int H, int W, int K, const float* calib, const int32_t* pad,
+                          const int32_t* img_size, float threshold, int depth_mode, float* det, float* topk, int32_t* valid,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (3) training path (reference: autograd over nn.Conv2d / BatchNorm2d / MaxPool2d / ConvTranspose2d and

@@ -254,6 +254,7 @@ struct DecodeConst {
     float dim_mean[3][3];     // (l,h,w) per class, config/defaults.py:206-208
     float depth_min, depth_max;
     float down_ratio, eps;
+    int depth_mode;           // MFX_DEPTH_* (detector_infer.py:149-198 `output_depth`)
 };
 
 // key2channel offsets of runs/monoflex.yaml:27-28
@@ -320,12 +321,30 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(const float* hmap, in
     d3 = fminf(fmaxf(d3, dc.depth_min), dc.depth_max);
     const float u1 = expf(r[R_KPT_UNC + 0]), u2 = expf(r[R_KPT_UNC + 1]), u3 = expf(r[R_KPT_UNC + 2]);
 
-    // 'soft' fusion (detector_infer.py:176-198)
-    float w0 = 1.f / u0, w1 = 1.f / u1, w2 = 1.f / u2, w3 = 1.f / u3;
-    const float ws = ((w0 + w1) + w2) + w3;
-    w0 /= ws; w1 /= ws; w2 /= ws; w3 /= ws;
-    const float depth = ((d0 * w0 + d1 * w1) + d2 * w2) + d3 * w3;
-    const float sigma = ((w0 * u0 + w1 * u1) + w2 * u2) + w3 * u3;
+    // which depth leaves the four estimates, and the uncertainty that scales the score with it (detector_infer.py:149-198 `output_depth`)
+    float depth, sigma;
+    if (dc.depth_mode == MFX_DEPTH_SOFT) {                    // 'soft' (:186-192; runs/monoflex.yaml)
+        float w0 = 1.f / u0, w1 = 1.f / u1, w2 = 1.f / u2, w3 = 1.f / u3;
+        const float ws = ((w0 + w1) + w2) + w3;
+        w0 /= ws; w1 /= ws; w2 /= ws; w3 /= ws;
+        depth = ((d0 * w0 + d1 * w1) + d2 * w2) + d3 * w3;
+        sigma = ((w0 * u0 + w1 * u1) + w2 * u2) + w3 * u3;
+    } else if (dc.depth_mode == MFX_DEPTH_HARD) {             // 'hard' (:180-184): the estimate of the largest weight 1 / u (first of equals, as argmax)
+        const float w0 = 1.f / u0, w1 = 1.f / u1, w2 = 1.f / u2, w3 = 1.f / u3;
+        depth = d0; float wb = w0;
+        if (w1 > wb) { wb = w1; depth = d1; }
+        if (w2 > wb) { wb = w2; depth = d2; }
+        if (w3 > wb) { wb = w3; depth = d3; }
+        sigma = fminf(fminf(u0, u1), fminf(u2, u3));
+    } else if (dc.depth_mode == MFX_DEPTH_MEAN) {             // 'mean' (:194-198)
+        depth = (((d0 + d1) + d2) + d3) / 4.f; sigma = (((u0 + u1) + u2) + u3) / 4.f;
+    } else if (dc.depth_mode == MFX_DEPTH_DIRECT) {           // 'direct' (:149-152)
+        depth = d0; sigma = u0;
+    } else if (dc.depth_mode == MFX_DEPTH_KEYPOINTS_AVG) {    // 'keypoints_avg' (:155-157)
+        depth = ((d1 + d2) + d3) / 3.f; sigma = ((u1 + u2) + u3) / 3.f;
+    } else if (dc.depth_mode == MFX_DEPTH_KEYPOINTS_CENTER) { depth = d1; sigma = u1; }   // (:159-161)
+    else if (dc.depth_mode == MFX_DEPTH_KEYPOINTS_02) { depth = d2; sigma = u2; }          // (:163-165)
+    else { depth = d3; sigma = u3; }                                                         // 'keypoints_13' (:167-169)
 
     // decode_location_flatten (anno_encoder.py:142-155) + project_image_to_rect (kitti_utils.py:350-369)
     const float u = (px + r[R_OFF3D + 0]) * dc.down_ratio - padx;
@@ -407,12 +426,20 @@ extern "C" int mfx_decode_boxes(const float* hmap, int ld, int reg_off, const fl
                                 int ncls, int B, int H, int W, int K, const float* calib, const int32_t* pad,
                                 const int32_t* img_size, float threshold, float* det, float* topk, int32_t* valid,
                                 void* stream) {
+    return mfx_decode_boxes_mode(hmap, ld, reg_off, scores, index, ncls, B, H, W, K, calib, pad, img_size, threshold, MFX_DEPTH_SOFT, det, topk, valid, stream);
+}
+
+extern "C" int mfx_decode_boxes_mode(const float* hmap, int ld, int reg_off, const float* scores, const int32_t* index,
+                                     int ncls, int B, int H, int W, int K, const float* calib, const int32_t* pad,
+                                     const int32_t* img_size, float threshold, int depth_mode, float* det, float* topk, int32_t* valid,
+                                     void* stream) {
+    if (depth_mode < MFX_DEPTH_SOFT || depth_mode > MFX_DEPTH_KEYPOINTS_13) return mfx_fail(MFX_ERR_ARG, "decode_boxes: depth_mode must be one of MFX_DEPTH_*");
     if (!hmap || !scores || !index || !calib || !pad || !img_size || !det || !topk || !valid)
         return mfx_fail(MFX_ERR_ARG, "decode_boxes: null pointer");
     if (K > 256 || ncls != 3) return mfx_fail(MFX_ERR_UNSUPPORTED, "decode_boxes: K <= 256, 3 classes (dimension means)");
     if (B == 0) return MFX_OK;
     DecodeConst dc = {{{3.8840f, 1.5261f, 1.6286f}, {0.8423f, 1.7607f, 0.6602f}, {1.7635f, 1.7372f, 0.5968f}},
-                      0.1f, 100.f, 4.f, 1e-3f};
+                      0.1f, 100.f, 4.f, 1e-3f, depth_mode};
     const size_t smem = (size_t)ncls * K * 8 + (size_t)K * 4;
     hipLaunchKernelGGL(decode_boxes_kernel, dim3(B), dim3(256), smem, reinterpret_cast<hipStream_t>(stream),
                        hmap, ld, reg_off, scores, index, ncls, H, W, K, calib, pad, img_size, threshold, dc, det, topk, valid);

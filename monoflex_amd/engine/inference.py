@@ -21,6 +21,8 @@ def compute_on_dataset(model, data_loader, device, predict_folder, timer=None, o
     n, busy = 0, 0.0
     dev = torch.device(device)
     overlap = bool(overlap) and dev.type == "cuda" and hasattr(model, "detect_device")
+    if getattr(getattr(getattr(model, "heads", None), "post_processor", None), "output_depth", None) == "oracle":
+        overlap = False                                            # reads each image's ground truth on the host (PostProcessor.decode_oracle)
     pending = None
 
     def finish(p):
@@ -91,3 +93,52 @@ def inference(model, data_loader, dataset_name, eval_types=("detections",), devi
         logger.info("metric = %s\n%s", metric, result)
         ret_dicts.append(ret_dict)
     return ret_dicts, result, {}
+
+
+EVAL_DEPTH_METHODS = ("oracle", "hard", "soft", "mean", "direct", "keypoints_center", "keypoints_02", "keypoints_13")   # engine/inference.py:154
+
+
+def inference_all_depths(model, data_loader, dataset_name, eval_types=("detections",), device="cuda", output_folder=None, metrics=("R40",)):
+    """`--eval_all_depths` (engine/inference.py:131-198): the evaluation once per depth-solving method, each into
+    `<output_folder>/eval_all_depths/<method>`, by re-assigning `post_processor.output_depth` between passes (the decode kernel reads the mode
+    per launch; 'oracle' needs the ground-truth fields of a validation split).  Logs the Car AP@0.70 bev/3d line per method and the ranking by
+    3D moderate.  -> {method: ret_dict} on rank 0 (the reference returns (None, None, None); the log lines are its product), the attribute restored."""
+    import numpy as np
+    import torch.distributed as dist
+    logger = logging.getLogger("monoflex.inference")
+    dataset = data_loader.dataset
+    post = model.heads.post_processor
+    before = post.output_depth
+    root = os.path.join(output_folder, "eval_all_depths")
+    rank0 = not (dist.is_available() and dist.is_initialized() and dist.get_rank() != 0)
+    ret = {}
+    try:
+        for method in EVAL_DEPTH_METHODS:
+            logger.info("evaluation with depth method: %s", method)
+            folder = os.path.join(root, method)
+            os.makedirs(folder, exist_ok=True)
+            if rank0:
+                for f in os.listdir(folder):                               # stale predictions of an earlier run (:162-164)
+                    os.remove(os.path.join(folder, f))
+            barrier()
+            post.output_depth = method
+            compute_on_dataset(model, data_loader, torch.device(device), folder)
+            barrier()
+            if rank0:
+                _, ret[method] = evaluate_python(label_path=dataset.label_dir, result_path=folder, label_split_file=dataset.imageset_txt,
+                                                 current_class=dataset.classes, metric="R40", device=device)
+    finally:
+        post.output_depth = before
+    if not rank0:
+        return None
+    cls, thresh = "Car", 0.7
+    logger.info("%s AP@%.2f, %.2f:", cls, thresh, thresh)
+    key = lambda kind, level: "%s_%s_%.2f/%s" % (cls, kind, thresh, level)
+    for method in EVAL_DEPTH_METHODS:
+        d = ret[method]
+        logger.info("bev/3d AP, method %s:", method)
+        logger.info("%.4f/%.4f, %.4f/%.4f, %.4f/%.4f", d[key("bev", "easy")], d[key("3d", "easy")], d[key("bev", "moderate")],
+                    d[key("3d", "moderate")], d[key("bev", "hard")], d[key("3d", "hard")])
+    order = np.argsort(-np.array([ret[m][key("3d", "moderate")] for m in EVAL_DEPTH_METHODS]))
+    logger.info("Cls %s, Thresh %s, Sort: %s", cls, thresh, " > ".join(EVAL_DEPTH_METHODS[i] for i in order))
+    return ret

@@ -195,7 +195,11 @@ SYMBOLS = {
     "mfx_kitti_eval_thresholds": (_I, [ctypes.POINTER(KittiEvalDesc), _P, _P]),
     "mfx_kitti_eval_match_pass2": (_I, [ctypes.POINTER(KittiEvalDesc), _P]),
     "mfx_decode_boxes": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P]),
+    "mfx_decode_boxes_mode": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P]),
 }
+
+# mfx_decode_boxes_mode's depth_mode (include/monoflex_hip.h MFX_DEPTH_*), by the reference's `output_depth` names (detector_infer.py:149-198)
+DEPTH_MODES = {"soft": 0, "hard": 1, "mean": 2, "direct": 3, "keypoints_avg": 4, "keypoints_center": 5, "keypoints_02": 6, "keypoints_13": 7}
 
 _lib = None
 

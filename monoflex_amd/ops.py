@@ -691,16 +691,19 @@ def decode_topk(hmap, ch_off, ncls, K, planar=None):
 
 
 @on_tensor_device
-def decode_boxes(hmap, reg_off, scores, index, calib, pad, img_size, threshold):
+def decode_boxes(hmap, reg_off, scores, index, calib, pad, img_size, threshold, depth_mode="soft"):
+    """`depth_mode`: the reference's `output_depth` name (lib.DEPTH_MODES; 'oracle' needs ground truth and is not a decode mode)."""
     _need_cuda(hmap, scores, index, calib, pad, img_size)
+    if depth_mode not in L.DEPTH_MODES:
+        raise ValueError("decode_boxes: output_depth %r is not one of %s" % (depth_mode, sorted(L.DEPTH_MODES)))
     B, H, W, ld = hmap.shape
     ncls, K = scores.shape[1], scores.shape[2]
     det = torch.empty((B, K, 14), dtype=torch.float32, device=hmap.device)
     topk = torch.empty((B, K, 5), dtype=torch.float32, device=hmap.device)
     valid = torch.empty((B, K), dtype=torch.int32, device=hmap.device)
-    L.check(L.load().mfx_decode_boxes(_ptr(hmap), ld, reg_off, _ptr(scores), _ptr(index), ncls, B, H, W, K, _ptr(calib),
-                                      _ptr(pad), _ptr(img_size), ctypes.c_float(threshold), _ptr(det), _ptr(topk),
-                                      _ptr(valid), _stream()), "mfx_decode_boxes")
+    L.check(L.load().mfx_decode_boxes_mode(_ptr(hmap), ld, reg_off, _ptr(scores), _ptr(index), ncls, B, H, W, K, _ptr(calib),
+                                           _ptr(pad), _ptr(img_size), ctypes.c_float(threshold), L.DEPTH_MODES[depth_mode], _ptr(det), _ptr(topk),
+                                           _ptr(valid), _stream()), "mfx_decode_boxes_mode")
     return det, topk, valid
 
 

@@ -250,6 +250,9 @@ def run_case(name, out_w, out_h, seeds, cls_bias, store_full, n_images=None):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 
 
+DEPTH_MODES = ["hard", "mean", "direct", "keypoints_avg", "keypoints_center", "keypoints_02", "keypoints_13"]
+
+
 def run_decode_cases():
     """Reference PostProcessor alone on synthetic head maps (cheap): includes an image with zero
     detections (detector_infer.py:106-113) and one where only some of the 50 slots pass 0.2."""
@@ -266,6 +269,35 @@ def run_decode_cases():
         out["case%d_seed" % n], out["case%d_shift" % n] = np.array(seed), np.array(shift)
         out["case%d_result" % n] = result.numpy()
         print("decode case", n, tuple(result.shape))
+        if n > 1:
+            continue
+        # the other `output_depth` settings (detector_infer.py:149-198; engine/inference.py:154 walks them) on the same maps
+        for mode in DEPTH_MODES:
+            post.output_depth = mode
+            r_m, _, _ = post({"cls": cls.clone(), "reg": reg.clone()}, [reference_target(tgt)], test=True)
+            out["case%d_result_%s" % (n, mode)] = r_m.numpy()
+        # 'oracle' (get_oracle_depths, :238-277) reads ground truth: every third 'mean' detection becomes an object whose box is the detection's
+        # shifted by (1.5, -1) px (IoU stays above 0.5 for all but the thinnest boxes) at 0.93 x its mean depth, plus two objects no detection meets
+        mean_rows = torch.from_numpy(out["case%d_result_mean" % n])[::3]
+        gt_boxes = torch.cat((mean_rows[:, 2:6] + torch.tensor([1.5, -1.0, 1.5, -1.0]), torch.tensor([[5., 5., 30., 40.], [1100., 200., 1180., 260.]])))
+        gt_cls = torch.cat((mean_rows[:, 0], torch.tensor([0., 1.]))).long()
+        gt_depth = torch.cat((mean_rows[:, 11] * 0.93, torch.tensor([20., 35.])))
+        G = gt_boxes.shape[0]
+        t_o = reference_target(tgt)
+        reg_mask = torch.zeros(G + 3, dtype=torch.uint8); reg_mask[:G] = 1        # padded target rows, as the dataset makes them
+        pad_rows = lambda t: torch.cat((t, t.new_zeros((3,) + tuple(t.shape[1:]))))
+        t_o.add_field("reg_mask", reg_mask)
+        t_o.add_field("cls_ids", pad_rows(gt_cls))
+        t_o.add_field("gt_bboxes", pad_rows(gt_boxes))
+        t_o.add_field("locations", pad_rows(torch.stack((torch.zeros(G), torch.zeros(G), gt_depth), dim=1)))
+        post.output_depth = "oracle"
+        r_o, _, _ = post({"cls": cls.clone(), "reg": reg.clone()}, [t_o], test=True)
+        post.output_depth = "soft"
+        out["case%d_result_oracle" % n] = r_o.numpy()
+        out["case%d_gt_boxes" % n], out["case%d_gt_cls" % n], out["case%d_gt_depth" % n] = gt_boxes.numpy(), gt_cls.numpy(), gt_depth.numpy()
+        differs = float((torch.from_numpy(out["case%d_result_mean" % n])[:, 11] != r_o[:, 11]).float().mean())
+        print("decode case", n, "modes", DEPTH_MODES, "oracle rows that left the mean: %.2f" % differs)
+        assert 0.1 < differs < 0.9
     out["meta"] = np.array(repr(dict(case="decode_only", torch=torch.__version__,
                                      maps="logits=randn*0.8-2+shift; cls=clamp(sigmoid); reg=randn*0.7 (same generator)")))
     np.savez_compressed(os.path.join(GOLD, "decode_only.npz"), **out)

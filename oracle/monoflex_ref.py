@@ -348,8 +348,36 @@ class Calib:
         return np.array([self.f_u, self.f_v, self.c_u, self.c_v, self.b_x, self.b_y], dtype=np.float32)
 
 
-def decode_image(cls_hm, reg, calib, pad_size, img_size, threshold=0.2, K=50):
-    """cls_hm (1,3,H,W) post sigmoid/clamp; reg (1,50,H,W); returns dict with top-K and (N,14) rows."""
+def box_iou(a, b):
+    """engine/visualize_infer.py:23-27 (axis-aligned boxes, no +1)."""
+    inter = max(min(a[2], b[2]) - max(a[0], b[0]), 0) * max(min(a[3], b[3]) - max(a[1], b[1]), 0)
+    return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
+
+
+def oracle_depth_choice(boxes, clses, d_all, u_all, gt_boxes, gt_clses, gt_depths, iou_thresh=0.5):
+    """detector_infer.py:238-277 `get_oracle_depths`: per detection, the nearest ground-truth box of its class (centre distance);
+    if their 2D IoU reaches 0.5 the estimate closest to the true depth, otherwise the mean of the estimates.
+    -> (depth, sigma, choice) with choice in {-1: mean, 0..3: column of d_all}."""
+    depth, sigma = d_all.mean(dim=1), u_all.mean(dim=1)
+    choice = torch.full((d_all.shape[0],), -1, dtype=torch.long)
+    if gt_boxes.shape[0] == 0:
+        return depth, sigma, choice
+    gt_c = (gt_boxes[:, :2] + gt_boxes[:, 2:]) / 2
+    for i in range(boxes.shape[0]):
+        c = (boxes[i, :2] + boxes[i, 2:]) / 2
+        dis = torch.sum((c.reshape(1, 2) - gt_c) ** 2, dim=1)
+        dis[gt_clses != clses[i]] = 9999
+        near = torch.argmin(dis)
+        if box_iou(boxes[i].numpy(), gt_boxes[near].numpy()) < iou_thresh:
+            continue
+        k = torch.argmin(torch.abs(d_all[i] - gt_depths[near]))
+        depth[i], sigma[i], choice[i] = d_all[i, k], u_all[i, k], k
+    return depth, sigma, choice
+
+
+def decode_image(cls_hm, reg, calib, pad_size, img_size, threshold=0.2, K=50, output_depth='soft', gt=None):
+    """cls_hm (1,3,H,W) post sigmoid/clamp; reg (1,50,H,W); returns dict with top-K and (N,14) rows.
+    `output_depth`: detector_infer.py:149-198; 'oracle' takes gt = dict(boxes (G,4), clses (G,), depths (G,))."""
     assert cls_hm.shape[0] == 1
     heat = nms_hm(cls_hm)
     scores, indexs, clses, ys, xs = select_topk(heat, K)
@@ -394,13 +422,28 @@ def decode_image(cls_hm, reg, calib, pad_size, img_size, threshold=0.2, K=50):
     z13 = (f_u * h3d.unsqueeze(-1) / (F.relu(d13) * DOWN_RATIO + EPS_KPT)).mean(dim=1)
     d_kpt = torch.stack([t.clamp(*DEPTH_RANGE) for t in (zc, z02, z13)], dim=1)
     u_kpt = pois[:, key2channel('corner_uncertainty')].exp()
-    # infer.py:176-198 'soft'
+    # infer.py:149-198: which estimate becomes the depth, and the uncertainty that goes with it
     d_all = torch.cat((d_direct.unsqueeze(1), d_kpt), dim=1)
     u_all = torch.cat((u_direct, u_kpt), dim=1)
     wts = 1 / u_all
-    wts = wts / wts.sum(dim=1, keepdim=True)
-    depth = torch.sum(d_all * wts, dim=1)
-    sigma = torch.sum(wts * u_all, dim=1)
+    single = {'direct': 0, 'keypoints_center': 1, 'keypoints_02': 2, 'keypoints_13': 3}
+    if output_depth == 'soft':
+        wts = wts / wts.sum(dim=1, keepdim=True)
+        depth = torch.sum(d_all * wts, dim=1)
+        sigma = torch.sum(wts * u_all, dim=1)
+    elif output_depth == 'hard':
+        depth = d_all[torch.arange(d_all.shape[0]), wts.argmax(dim=1)]
+        sigma = u_all.min(dim=1).values
+    elif output_depth == 'mean':
+        depth, sigma = d_all.mean(dim=1), u_all.mean(dim=1)
+    elif output_depth == 'keypoints_avg':
+        depth, sigma = d_kpt.mean(dim=1), u_kpt.mean(dim=1)
+    elif output_depth in single:
+        depth, sigma = d_all[:, single[output_depth]], u_all[:, single[output_depth]]
+    elif output_depth == 'oracle':
+        depth, sigma, out['oracle_choice'] = oracle_depth_choice(box, clses, d_all, u_all, gt['boxes'], gt['clses'], gt['depths'])
+    else:
+        raise ValueError(output_depth)
     # anno_encoder.py:142-155 + kitti_utils.py:350-369
     uv = (pts + off3d) * DOWN_RATIO - pad
     x = ((uv[:, 0] - float(calib.c_u)) * depth) / float(calib.f_u) + float(calib.b_x)

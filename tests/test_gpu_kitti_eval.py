@@ -124,3 +124,42 @@ def test_inference_loop_end_to_end(tmp_path):
     assert compute_on_dataset(model, loader, "cuda", str(tmp_path / "seq"), timer, overlap=False) == n and timer["inference_seconds"] > 0
     for f in files:
         assert (tmp_path / "seq" / f).read_bytes() == (tmp_path / "out" / "data" / f).read_bytes(), f
+
+
+def test_eval_all_depths_walks_every_method(tmp_path):
+    """`--eval_all_depths` (engine/inference.py:131-198): eight passes over a generated validation directory, one result folder per depth-solving
+    method, `output_depth` restored afterwards; the 'soft' pass writes the files the plain evaluation writes, the other passes different ones;
+    'oracle' reads the ground-truth fields of the val split (detector_infer.py:238-277)."""
+    from PIL import Image
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.data import DeviceLoader, InferenceSampler, KITTIDataset
+    from monoflex_amd.engine.inference import EVAL_DEPTH_METHODS, inference, inference_all_depths
+    from monoflex_amd.model.detector import KeypointDetector
+    for d in ("image_2", "label_2", "calib", "ImageSets"):
+        (tmp_path / d).mkdir()
+    P = np.asarray(S.KITTI_P2).reshape(-1)
+    n = 3
+    for i in range(n):
+        Image.fromarray(np.random.RandomState(i).randint(0, 256, (375, 1242, 3)).astype(np.uint8)).save(tmp_path / "image_2" / ("%06d.png" % i))
+        (tmp_path / "label_2" / ("%06d.txt" % i)).write_text("\n".join(S.synthetic_kitti_labels(70 + i, 1242, 375, 8, z_range=(5, 38), occl_max=1)))
+        (tmp_path / "calib" / ("%06d.txt" % i)).write_text("P2: " + " ".join("%.12e" % v for v in P) + "\nP3: " + " ".join("%.12e" % v for v in P) + "\n")
+    (tmp_path / "ImageSets" / "val.txt").write_text("".join("%06d\n" % i for i in range(n)))
+    cfg = get_cfg(os.path.join(ROOT, "runs", "monoflex.yaml"), ["MODEL.COMPUTE_DTYPE", "bf16"])
+    cfg.MODEL.PRETRAIN = False
+    ds = KITTIDataset(cfg, str(tmp_path), is_train=False)
+    torch.manual_seed(0)
+    model = KeypointDetector(cfg).cuda()
+    model.load_state_dict(S.synthetic_state_dict(model.state_dict(), seed=0, cls_bias=-1.0))
+    loader = DeviceLoader(ds, batch_size=2, sampler=InferenceSampler(len(ds)))
+    inference(model, loader, "kitti_val", output_folder=str(tmp_path / "out"))
+    ret = inference_all_depths(model, loader, "kitti_val", output_folder=str(tmp_path / "out"))
+    assert model.heads.post_processor.output_depth == "soft"
+    assert tuple(ret) == EVAL_DEPTH_METHODS and all("Car_3d_0.70/moderate" in d for d in ret.values())
+    texts = {}
+    for m in EVAL_DEPTH_METHODS:
+        folder = tmp_path / "out" / "eval_all_depths" / m
+        assert sorted(os.listdir(folder)) == ["%06d.txt" % i for i in range(n)]
+        texts[m] = b"".join((folder / f).read_bytes() for f in sorted(os.listdir(folder)))
+    assert texts["soft"] == b"".join((tmp_path / "out" / "data" / ("%06d.txt" % i)).read_bytes() for i in range(n))
+    # the methods decode different rows (with synthetic weights several keypoint estimates sit on the 100 m clamp and coincide)
+    assert len(set(texts.values())) >= 4 and texts["soft"] != texts["mean"] and texts["direct"] != texts["hard"]

@@ -423,6 +423,49 @@ def test_decode_vs_reference_goldens(golden_dir):
     assert n >= 4
 
 
+@pytest.mark.parametrize("mode", ["hard", "mean", "direct", "keypoints_avg", "keypoints_center", "keypoints_02", "keypoints_13", "oracle"])
+def test_decode_depth_modes_vs_reference_goldens(golden_dir, mode):
+    """The reference's other `output_depth` settings (detector_infer.py:149-198) through mfx_decode_boxes_mode, and 'oracle' (get_oracle_depths,
+    :238-277) through PostProcessor.decode_oracle, against rows captured from the reference's PostProcessor on the same maps."""
+    import os
+    from monoflex_amd import synthetic as S
+    from monoflex_amd.config import get_cfg
+    from monoflex_amd.model.head.detector_infer import make_post_processor
+    from monoflex_amd.structures.params_3d import Calibration, ParamsList
+    ops, L = _ops()
+    g = np.load(os.path.join(golden_dir, "decode_only.npz"))
+    tgt = S.synthetic_target(320, 96)
+    cfg = get_cfg(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "runs", "monoflex.yaml"), [])
+    post = make_post_processor(cfg)
+    post.output_depth = mode
+    for n in (0, 1):
+        gen = _g(int(g["case%d_seed" % n]))
+        logits = torch.randn(1, 3, 96, 320, generator=gen) * 0.8 - 2.0 + float(g["case%d_shift" % n])
+        reg = torch.randn(1, 50, 96, 320, generator=gen) * 0.7
+        hm = torch.zeros(1, 96, 320, 64)
+        hm[..., :3] = logits.permute(0, 2, 3, 1)
+        hm[..., 8:58] = reg.permute(0, 2, 3, 1)
+        t = ParamsList(image_size=tgt["size"], is_train=False)
+        t.add_field("pad_size", tgt["pad_size"])
+        t.add_field("calib", Calibration(tgt["P"]))
+        if mode == "oracle":
+            G = g["case%d_gt_boxes" % n].shape[0]
+            pad_rows = lambda a: torch.cat((torch.from_numpy(a), torch.zeros((2,) + a.shape[1:], dtype=torch.from_numpy(a).dtype)))
+            t.add_field("reg_mask", torch.cat((torch.ones(G, dtype=torch.uint8), torch.zeros(2, dtype=torch.uint8))))
+            t.add_field("cls_ids", pad_rows(g["case%d_gt_cls" % n]))
+            t.add_field("gt_bboxes", pad_rows(g["case%d_gt_boxes" % n]))
+            t.add_field("locations", pad_rows(np.stack((np.zeros(G, np.float32), np.zeros(G, np.float32), g["case%d_gt_depth" % n]), axis=1)))
+            with pytest.raises(ValueError):
+                post.decode_device(hm.to(DEV), *post.prepare_targets([t], DEV))
+        res, _, _ = post({"hm_nhwc": hm.to(DEV), "cls": None}, [t])
+        want = g["case%d_result_%s" % (n, mode)]
+        assert tuple(res.shape) == want.shape, (n, res.shape, want.shape)
+        assert np.allclose(res.cpu().numpy(), want, rtol=1e-4, atol=2e-3), (n, mode, np.abs(res.cpu().numpy() - want).max())
+    with pytest.raises(ValueError):
+        ops.decode_boxes(hm.to(DEV), 8, *ops.decode_topk(hm.to(DEV), 0, 3, 50), torch.zeros(1, 6, device=DEV), torch.zeros(1, 2, dtype=torch.int32, device=DEV),
+                         torch.tensor([1280, 384], dtype=torch.int32, device=DEV), 0.2, depth_mode="combine")
+
+
 def _topk_reference(logits, K):
     """torch restatement of nms_hm + per-class top-K with ties toward the lower flat index (layers/utils.py:39-77)."""
     heat = torch.sigmoid(logits).clamp(1e-4, 1 - 1e-4)

@@ -118,6 +118,34 @@ def test_decode_only_vs_reference(golden_dir):
     assert 0 in shapes and any(0 < s < 50 for s in shapes) and 50 in shapes   # all three decode paths covered
 
 
+DEPTH_MODES = ["hard", "mean", "direct", "keypoints_avg", "keypoints_center", "keypoints_02", "keypoints_13"]
+
+
+@pytest.mark.parametrize("mode", DEPTH_MODES + ["oracle"])
+def test_decode_depth_modes_vs_reference(golden_dir, mode):
+    """The reference's other `output_depth` settings (detector_infer.py:149-198, get_oracle_depths :238-277) on the maps of cases 0 and 1:
+    rows captured from the reference's PostProcessor with the attribute re-assigned as engine/inference.py:166 does."""
+    g = np.load(os.path.join(golden_dir, "decode_only.npz"))
+    tgt = S.synthetic_target(320, 96)
+    for n in (0, 1):
+        gen = torch.Generator().manual_seed(int(g["case%d_seed" % n]))
+        logits = torch.randn(1, 3, 96, 320, generator=gen) * 0.8 - 2.0 + float(g["case%d_shift" % n])
+        cls = torch.sigmoid(logits).clamp(1e-4, 1 - 1e-4)
+        reg = torch.randn(1, 50, 96, 320, generator=gen) * 0.7
+        gt = None
+        if mode == "oracle":
+            gt = dict(boxes=torch.from_numpy(g["case%d_gt_boxes" % n]), clses=torch.from_numpy(g["case%d_gt_cls" % n]),
+                      depths=torch.from_numpy(g["case%d_gt_depth" % n]))
+        dec = R.decode_image(cls, reg, R.Calib(tgt["P"]), tgt["pad_size"], tgt["size"], output_depth=mode, gt=gt)
+        want = g["case%d_result_%s" % (n, mode)]
+        assert dec["result"].shape == want.shape
+        assert np.allclose(dec["result"].numpy(), want, rtol=1e-5, atol=1e-4), (n, mode)
+        assert not np.allclose(want[:, 9:], g["case%d_result" % n][:, 9:], atol=1e-4)       # the mode does change the rows
+        if mode == "oracle":
+            ch = dec["oracle_choice"]
+            assert (ch >= 0).any() and (ch < 0).any()                                           # matched and unmatched detections
+
+
 def test_edge_indices_match_reference_count():
     # SURVEY 8c: 1242x375 in 1280x384 with pad (19,4) -> 807 border points, edge_len 806
     t = S.synthetic_target(320, 96)
