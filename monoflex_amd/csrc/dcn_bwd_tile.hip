@@ -57,7 +57,10 @@ int g_opt_dcn_bt_dbg = 0;      // option "dcn_bt_dbg": experiment switches of dc
 
 namespace mfx {
 
-constexpr int BT_TH = 8, BT_TW = 16, BT_D = 8, BT_NPIX = BT_TH * BT_TW;
+#ifndef BT_D_VAL
+#define BT_D_VAL 8            // ring of the candidate window (pixels): a corner further than this from its sample's tile goes to the far list
+#endif
+constexpr int BT_TH = 8, BT_TW = 16, BT_D = BT_D_VAL, BT_NPIX = BT_TH * BT_TW;
 constexpr int BT_FCAP = 512;   // far corners staged per workgroup before one global reservation
 #ifndef BT_ROWS_IN_FLIGHT
 #define BT_ROWS_IN_FLIGHT 8
@@ -66,6 +69,8 @@ constexpr int BT_FCAP = 512;   // far corners staged per workgroup before one gl
 #define BT_LCAP_BF16 62       // 4-byte list entries per target pixel (mean 36, sigma ~6): 32 KB of lists = four workgroups per CU
 #endif
 constexpr int BT_CH = BT_TH + 2 * BT_D, BT_CW = BT_TW + 2 * BT_D;        // candidate window (24 x 32 pixels)
+constexpr int BT_WIN = BT_CH * BT_CW, BT_ROUNDS = (BT_WIN + 255) / 256;  // window pixels, and how many of them a thread takes (3 at D = 8)
+static_assert(BT_CH <= 32 && BT_CW <= 32, "list entries keep window coordinates in 5 + 5 bits");
 
 struct BtGeom { int B, H, W, C, tiles_x, tiles_y, Kp, CS, nslices, dbg;
                 int raw_mask;      // 1: d_raw[18 + tap] = d loss / d mask (the `_ext` contract: the mask is an INPUT there); 0: through the sigmoid of the mask logit
@@ -222,9 +227,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_kernel(const float* __restri
     // window = tile grown by D pixels (BT_CH x BT_CW = 3 x 256 pixels): one thread per pixel, its 9 taps from registers.
     // Own samples (window pixel inside the tile): corners in the tile are listed; corners elsewhere are left to the owner of
     // their tile unless this pixel lies outside that tile's window ("far").  Ring samples: only corners inside the tile.
-    static_assert(BT_CH * BT_CW == 3 * 256, "three candidate pixels per thread");
-    for (int round = 0; round < (BT_PROBE(g, 4) ? 0 : 3); ++round) {
+    for (int round = 0; round < (BT_PROBE(g, 4) ? 0 : BT_ROUNDS); ++round) {
         const int cp = round * 256 + tid;
+        if (BT_WIN % 256 != 0 && cp >= BT_WIN) continue;
         const int wy = cp / BT_CW, wx = cp - wy * BT_CW;
         const int my = ty0 - BT_D + wy, mx = tx0 - BT_D + wx;
         const bool own = wy >= BT_D && wy < BT_D + BT_TH && wx >= BT_D && wx < BT_D + BT_TW;
@@ -756,18 +761,17 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_fly_kernel(const float* __re
     };
 
     // ---------------- phase 1: bin the (sample, corner) pairs of the candidate window by target pixel, ONE TAP AT A TIME ----------------
-    static_assert(BT_CH * BT_CW == 3 * 256, "three candidate pixels per thread");
     {
         // the window's raw offset / mask rows stay in registers across the nine taps (re-reading three values per (pixel, tap) from L1
         // measured slower: 176 vs 111 us for this phase alone)
-        float o[3][28];
-        bool valid[3];
+        float o[BT_ROUNDS][28];
+        bool valid[BT_ROUNDS];
 #pragma unroll
-        for (int round = 0; round < 3; ++round) {
+        for (int round = 0; round < BT_ROUNDS; ++round) {
             const int cp = round * 256 + tid;
             const int wy = cp / BT_CW, wx = cp - wy * BT_CW;
             const int my = ty0 - BT_D + wy, mx = tx0 - BT_D + wx;
-            valid[round] = my >= 0 && my < g.H && mx >= 0 && mx < g.W && !BT_PROBE(g, 4);
+            valid[round] = (BT_WIN % 256 == 0 || cp < BT_WIN) && my >= 0 && my < g.H && mx >= 0 && mx < g.W && !BT_PROBE(g, 4);
             const float* r = om + (size_t)(mb + (long)(valid[round] ? my : 0) * g.W + (valid[round] ? mx : 0)) * 32;
 #pragma unroll
             for (int q4 = 0; q4 < 28; q4 += 4) {
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_tile_fly_kernel(const float* __re
         for (int tap = 0; tap < 9; ++tap) {
             const int th = tap / 3, tw = tap - th * 3;
 #pragma unroll
-            for (int round = 0; round < 3; ++round) {
+            for (int round = 0; round < BT_ROUNDS; ++round) {
                 if (!valid[round]) continue;
                 const int cp = round * 256 + tid;
                 const int wy = cp / BT_CW, wx = cp - wy * BT_CW;
