@@ -162,3 +162,20 @@ def dcn_v2_torch(input, offset, mask, weight, bias, stride=1, padding=1, dilatio
     col = torch.stack(cols, dim=2)                      # B, C, kh*kw, Ho, Wo
     out = torch.einsum("ock,bckhw->bohw", weight.view(Cout, C, kh * kw), col)
     return out + bias.view(1, Cout, 1, 1)
+
+
+def dcn_v2_grid_sample(x, off, msk, w, b, pad=1):
+    """Modulated deformable 3x3 / stride-1 convolution with torch.nn.functional.grid_sample as the sampler: the bilinear rule (zero beyond the map, corner
+    by corner) and its input / coordinate derivatives are the LIBRARY's, not a restatement written for this repository.  Channel 2k of `off` moves tap k
+    along y, 2k + 1 along x (dcn_v2_im2col_cpu.cpp:150-161)."""
+    B, C, H, W = x.shape
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=x.dtype), torch.arange(W, dtype=x.dtype), indexing="ij")
+    out = b.view(1, -1, 1, 1).expand(B, w.shape[0], H, W).clone()
+    for k in range(9):
+        i, j = divmod(k, 3)
+        py = ys + (i - pad) + off[:, 2 * k]
+        px = xs + (j - pad) + off[:, 2 * k + 1]
+        grid = torch.stack((2 * px / (W - 1) - 1, 2 * py / (H - 1) - 1), dim=-1)
+        smp = torch.nn.functional.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=True) * msk[:, k:k + 1]
+        out = out + torch.einsum("oc,bchw->bohw", w[:, :, i, j], smp)
+    return out

@@ -84,23 +84,6 @@ def test_c_vs_torch_forward_and_grads():
         assert ((gc - leaf.grad).abs().max() / scale) < 2e-5, name
 
 
-def _dcn_by_grid_sample(x, off, msk, w, b, pad=1):
-    """Modulated deformable 3x3 / stride-1 convolution with torch.nn.functional.grid_sample as the sampler: the bilinear rule (zero beyond the map, corner
-    by corner) and its input / coordinate derivatives are the LIBRARY's, not a restatement written for this repository.  Channel 2k of `off` moves tap k
-    along y, 2k + 1 along x (dcn_v2_im2col_cpu.cpp:150-161)."""
-    B, C, H, W = x.shape
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=x.dtype), torch.arange(W, dtype=x.dtype), indexing="ij")
-    out = b.view(1, -1, 1, 1).expand(B, w.shape[0], H, W).clone()
-    for k in range(9):
-        i, j = divmod(k, 3)
-        py = ys + (i - pad) + off[:, 2 * k]
-        px = xs + (j - pad) + off[:, 2 * k + 1]
-        grid = torch.stack((2 * px / (W - 1) - 1, 2 * py / (H - 1) - 1), dim=-1)
-        smp = torch.nn.functional.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=True) * msk[:, k:k + 1]
-        out = out + torch.einsum("oc,bchw->bohw", w[:, :, i, j], smp)
-    return out
-
-
 def test_c_oracle_vs_library_bilinear_sampler():
     """the fractional-offset arithmetic of oracle/dcn_v2_ref.c (forward, and all five gradients) against a formulation whose sampler
     is PyTorch's own grid_sample in float64 -- offsets with std 2 on a 12 x 20 map, so samples cross the border band (-1, 0) / (H - 1, H) where the
@@ -110,7 +93,7 @@ def test_c_oracle_vs_library_bilinear_sampler():
     off[1, :, 5, 7] = -30.0
     a = dcn_ref.dcn_v2_conv(x, off, msk, w, b, 1, 1, 1, 1)
     leaves = [t_.double().clone().requires_grad_() for t_ in (x, off, msk, w, b)]
-    t = _dcn_by_grid_sample(*leaves)
+    t = dcn_ref.dcn_v2_grid_sample(*leaves)
     assert (a.double() - t).abs().max() < 2e-5
     band = ((torch.arange(12.).view(1, 1, 12, 1) - 1 + off[:, 0:1]) < 0) & ((torch.arange(12.).view(1, 1, 12, 1) - 1 + off[:, 0:1]) > -1)
     assert int(band.sum()) > 5                                    # the case does exercise the guarded band
