@@ -453,11 +453,15 @@ class Conv2dFn(Function):
     multiple of the 16-byte chunk (extra channels are exactly zero); callers slice."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, out_dtype=None, act=L.ACT_NONE, stats=None):
+    def forward(ctx, x, weight, bias, stride, pad, out_dtype=None, act=L.ACT_NONE, stats=None, alias=False):
         """`act` = ACT_DCN_OFFMASK fuses the sigmoid of the DCN mask channels into the epilogue; the CONSUMER (DCNFn with
         post_sigmoid=True) then hands back the gradient of the pre-activation, which is what backward() below expects.
         `stats` = the scratch of the train-mode BN that follows: the conv's epilogue adds the output's statistics to it where
-        the kernel supports that (ops.conv2d.last_stats_done)."""
+        the kernel supports that (ops.conv2d.last_stats_done).
+        `alias` = True: returns (y, x') with x' the input again, as an output of THIS node -- for an input that has a second consumer next to
+        the conv (the identity residual of a BasicBlock, dla_dcn.py:84-98).  The gradient of x' then arrives here instead of at an autograd
+        add, and the data-gradient conv takes it as its epilogue residual: one element-wise pass over the map less per block."""
+        x_in = x
         x = _c(x)
         Cout, Cin, kh, kw = weight.shape
         # (padded to the chunk of the COMPUTE type also where the map is written in fp32: the backward pass then casts dy and has nothing to pad)
@@ -474,15 +478,22 @@ class Conv2dFn(Function):
         y = ops.conv2d(x, p, out_dtype=out_dtype, stats=stats)     # bf16 mode: fp32 out for DCN offsets and the head maps
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, bias is not None, Cout)
+        if alias:
+            return y, x_in.view(x_in.shape)
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_alias=None):
         x, weight = ctx.saved_tensors
         stride, pad, has_bias, Cout = ctx.cfg
-        dx, dw, db = _conv_backward(x, weight, dy, stride, pad, has_bias, Cout, ctx.needs_input_grad[:3])
-        return dx, dw, db, None, None, None, None, None
+        res = None
+        if g_alias is not None and ctx.needs_input_grad[0]:
+            res = _c(g_alias if g_alias.dtype == x.dtype else g_alias.to(x.dtype))
+        if dy is None:                                          # (only the alias was used downstream)
+            return res, None, None, None, None, None, None, None, None
+        dx, dw, db = _conv_backward(x, weight, dy, stride, pad, has_bias, Cout, ctx.needs_input_grad[:3], res=res)
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def _conv_backward(x, weight, dy, stride, pad, has_bias, Cout, needs, res=None):
@@ -706,6 +717,7 @@ _BN_SEPARATE = [False]          # True: the five-launch form (stats, finalize, a
 _BN_READ_OUTPUT = [False]       # True: the backward always reads the forward output for the activation derivative (test switch)
 _CONV_STATS_OFF = [__import__('os').environ.get('MFX_CONV_STATS', '1') == '0']       # True: convs never accumulate the following BN's statistics (test switch; env MFX_CONV_STATS=0)
 _CONV_STATS_MAX_COUT = [128]
+RESIDUAL_ALIAS = [__import__('os').environ.get('MFX_RESIDUAL_ALIAS', '1') != '0']      # BasicBlock identity residual through Conv2dFn's alias output (env MFX_RESIDUAL_ALIAS=0: autograd adds the two gradients)
 _BN_SCRATCH = {}
 
 
@@ -1210,9 +1222,14 @@ def bn_fuses_statistics(bn, sync=None):
     return _sync_group(sync) is None
 
 
-def conv2d_bn_stats(x, weight, bias, stride, pad, bn):
+def conv2d_bn_stats(x, weight, bias, stride, pad, bn, alias=False):
     """conv2d whose epilogue also accumulates the batch statistics of its output for the train-mode BN `bn` that follows.
-    Returns (y, stats_done): pass stats_done on to bn_act / SparseRegHeadsFn."""
+    Returns (y, stats_done): pass stats_done on to bn_act / SparseRegHeadsFn.  `alias`: (y, stats_done, x') -- Conv2dFn's second output."""
+    if alias:
+        fused = bn_fuses_statistics(bn) and weight.shape[0] <= _CONV_STATS_MAX_COUT[0] and x.shape[0] * x.shape[1] * x.shape[2] != 0
+        y, xr = Conv2dFn.apply(x, weight, bias, stride, pad, None, L.ACT_NONE, _bn_scratch(bn.weight) if fused else None, True)
+        done = bool(fused and ops.conv2d.last_stats_done)
+        return (y if y.shape[-1] == weight.shape[0] else y[..., :weight.shape[0]]), done, xr
     # wide outputs pay more for the epilogue's atomics (one per column and wave, each covering only the wave's 128 pixels) than
     # the separate pass costs: 64->256 @ 96x320 went 80 -> 150 us against a 33 us statistics pass; up to 128 channels it is +1..2 us
     if not bn_fuses_statistics(bn) or weight.shape[0] > _CONV_STATS_MAX_COUT[0] or x.shape[0] * x.shape[1] * x.shape[2] == 0:

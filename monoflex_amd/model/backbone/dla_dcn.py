@@ -78,6 +78,12 @@ class BasicBlock(nn.Module):
         if residual is None:
             residual = x
         if self.training:
+            if residual is x and self.stride == 1 and AG.RESIDUAL_ALIAS[0]:
+                # identity residual: x feeds conv1 AND the add behind bn2.  conv1's node hands x on as a second output, so the residual's gradient
+                # arrives at that node and rides the data-gradient conv's epilogue (no autograd add over the map)
+                y, done, xr = AG.conv2d_bn_stats(x, self.conv1.weight, self.conv1.bias, 1, self.conv1.padding[0], self.bn1, alias=True)
+                out = AG.bn_act(y, self.bn1, L.ACT_RELU, None, stats_done=done)
+                return _train_conv_bn(out, self.conv2, self.bn2, L.ACT_RELU, res=xr)
             out = _train_conv_bn(x, self.conv1, self.bn1, L.ACT_RELU)
             return _train_conv_bn(out, self.conv2, self.bn2, L.ACT_RELU, res=residual)
         out = ops.conv2d(x, _conv_bn(self, "c1", self.conv1, self.bn1, x.dtype, L.ACT_RELU))

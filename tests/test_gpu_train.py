@@ -141,6 +141,57 @@ def test_bn_act_grads(act, res):
         assert _rel(rd.grad.permute(0, 3, 1, 2), rr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("dt,C,extra", [("fp32", 64, False), ("fp32", 128, True), ("bf16", 64, True), ("bf16", 256, False)])
+def test_basic_block_identity_residual_through_the_conv_node(dt, C, extra):
+    """A BasicBlock with the identity residual (dla_dcn.py:84-98, tree2 of every Tree): x feeds conv1 and the add behind bn2.  conv1's node returns x as
+    a second output, so the residual's gradient reaches that node and is added by the data-gradient conv's epilogue (no autograd add).  Same
+    forward, same gradients as torch's block, and as the two-consumer form (MFX_RESIDUAL_ALIAS=0); `extra` gives x a third consumer that autograd
+    still adds."""
+    from monoflex_amd import autograd as AG
+    from monoflex_amd.model.backbone.dla_dcn import BasicBlock
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, C, 12, 20, generator=g)
+    blk = BasicBlock(C, C).train()
+    with torch.no_grad():
+        for bn in (blk.bn1, blk.bn2):
+            bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    ref = {k: v.clone() for k, v in blk.state_dict().items()}
+
+    def torch_block(xr):
+        c1 = F.conv2d(xr, pr["conv1.weight"], None, 1, 1)
+        b1 = F.relu(F.batch_norm(c1, None, None, pr["bn1.weight"], pr["bn1.bias"], True, 0.1, 1e-5))
+        c2 = F.conv2d(b1, pr["conv2.weight"], None, 1, 1)
+        return F.relu(F.batch_norm(c2, None, None, pr["bn2.weight"], pr["bn2.bias"], True, 0.1, 1e-5) + xr)
+    pr = {k: v.clone().requires_grad_() for k, v in ref.items() if v.is_floating_point() and "running" not in k}
+    xr = x.clone().requires_grad_()
+    yr = torch_block(xr)
+    r = torch.randn(yr.shape, generator=g)
+    ((yr * r).sum() + ((xr * xr).sum() if extra else 0.0)).backward()
+
+    got = {}
+    for alias in (True, False):
+        AG.RESIDUAL_ALIAS[0] = alias
+        try:
+            b = BasicBlock(C, C).to(DEV).train()
+            b.load_state_dict(ref)
+            xd = _nhwc(x).to(DEV).to(DT[dt]).requires_grad_()
+            yd = b(xd)
+            ((yd.float() * _nhwc(r).to(DEV)).sum() + ((xd.float() * xd.float()).sum() if extra else 0.0)).backward()
+            got[alias] = (yd.detach().float().permute(0, 3, 1, 2), xd.grad.float().permute(0, 3, 1, 2), b.conv1.weight.grad.clone(), b.conv2.weight.grad.clone(),
+                          b.bn2.weight.grad.clone())
+        finally:
+            AG.RESIDUAL_ALIAS[0] = True
+    tol = 2e-4 if dt == "fp32" else 3e-2
+    names = ("y", "dx", "dconv1", "dconv2", "dgamma2")
+    errs = {al: [_rel(a, w) for a, w in zip(got[al], (yr, xr.grad, pr["conv1.weight"].grad, pr["conv2.weight"].grad, pr["bn2.weight"].grad))] for al in (True, False)}
+    for n, e_alias, e_two in zip(names, errs[True], errs[False]):
+        # against torch's fp32 block: inside the mode's tolerance, and never worse than the two-consumer form by more than rounding
+        assert e_alias < max(tol, 1.5 * e_two), (n, e_alias, e_two)
+    assert _rel(got[True][0], got[False][0]) < (1e-5 if dt == "fp32" else 1e-2)      # the forward is the same launches (statistics summed by atomics: not bitwise)
+    for a, o in zip(got[True][1:], got[False][1:]):
+        assert _rel(a, o) < (1e-5 if dt == "fp32" else 2e-2)
+
+
 @pytest.mark.parametrize("C,shape,dt", [(16, (2, 40, 64), "fp32"), (64, (3, 12, 20), "bf16"), (512, (2, 6, 10), "fp32"), (128, (8, 48, 160), "bf16"),
                                          (64, (3, 12, 20), "fp16"), (128, (8, 48, 160), "fp16")])
 def test_bn_two_launch_form_reuses_its_scratch(C, shape, dt):
