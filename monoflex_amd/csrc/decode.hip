@@ -205,6 +205,31 @@ __global__ __launch_bounds__(kStripThreads) void decode_topk_strip_kernel(const 
     __syncthreads();
     const int need = K < nloc ? K : nloc;
     const bool skip_zero = sh[0] >= need;
+    float* ov = cand_v + (((size_t)b * ncls + cls) * S + strip) * K;
+    int* oi = cand_i + (((size_t)b * ncls + cls) * S + strip) * K;
+    // Fast path (the usual case: the 3x3 NMS leaves ~1 pixel in 9, a few hundred per strip): when the survivors alone fill the strip's top-K and fit
+    // the list below, they are compacted and every survivor COUNTS the survivors ahead of it under the same total order (value desc, flat index
+    // asc: one 64-bit key, heat bits high -- heat > 0, so bit order is value order -- and ~index low).  Its count is its rank: ranks < need are the
+    // strip's top-K, already sorted.  Same set as the radix selection below (which stays for dense maps and for strips that must take zeros).
+    constexpr int kSurvCap = 512;
+    __shared__ unsigned long long surv[kSurvCap];
+    const int ns = sh[0];
+    if (ns >= need && ns <= kSurvCap && need > 0) {
+        for (int q = tid; q < nloc; q += kStripThreads) {
+            const float h = nm[q];
+            if (h != 0.f) surv[atomicAdd(&cnt, 1)] = ((unsigned long long)__float_as_uint(h) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)q);
+        }
+        __syncthreads();
+        for (int c = tid; c < ns; c += kStripThreads) {
+            const unsigned long long mine = surv[c];
+            int rank = 0;
+#pragma unroll 8
+            for (int u = 0; u < ns; ++u) rank += surv[u] > mine ? 1 : 0;            // (every lane reads the same entry: one broadcast LDS read)
+            if (rank < need) { ov[rank] = __uint_as_float((uint32_t)(mine >> 32)); oi[rank] = r0 * W + (int)(0xffffffffu - (uint32_t)mine); }
+        }
+        for (int t = need + tid; t < K; t += kStripThreads) { ov[t] = -1.f; oi[t] = 0x7fffffff; }
+        return;
+    }
     __syncthreads();
     int take_eq = 0, dummy = 0;
     const uint32_t T = select_kth<4>([&](int q) { return __float_as_uint(nm[q]); }, [&](int q) { return !skip_zero || nm[q] != 0.f; },
@@ -219,8 +244,6 @@ __global__ __launch_bounds__(kStripThreads) void decode_topk_strip_kernel(const 
         }
     }
     __syncthreads();
-    float* ov = cand_v + (((size_t)b * ncls + cls) * S + strip) * K;
-    int* oi = cand_i + (((size_t)b * ncls + cls) * S + strip) * K;
     const int n = cnt < need ? cnt : need;                          // == need by construction
     for (int t = tid; t < K; t += kStripThreads) {
         if (t < n) { ov[t] = cv[t]; oi[t] = ci[t]; }
