@@ -303,7 +303,7 @@ extern int g_opt_wgrad_min_m;
 extern int g_opt_dcn_bt_gcol_as;
 extern int g_opt_dcn_bt_fly_bias;
 extern int g_opt_dcn_bt_fuse_min_chunks, g_opt_dcn_bt_fuse_blocks, g_opt_dcn_bt_fuse_wgrad, g_opt_heads_planes, g_opt_heads_persist, g_opt_heads_dbg, g_opt_heads_mfma32, g_opt_dcn_bt_cs, g_opt_dcn_bt_cs_wgs, g_opt_dcn_bt_dbg, g_opt_wgrad_tr, g_opt_wgrad_tr_blocks, g_opt_bn_blocks, g_opt_bn_apply_blocks, g_opt_bn_onepass, g_opt_bn_onepass_grid, g_opt_bn_onepass_min_chunks, g_opt_bn_onepass_fwd_min_chunks, g_opt_wgrad_patch, g_opt_wgrad_patch_blocks, g_opt_wgrad_patch_waves;
-extern int g_opt_topk_strips;                                                                                           // decode.hip (global namespace)
+extern int g_opt_topk_strips, g_opt_topk_merge_z, g_opt_topk_merge_threads;                                                                                           // decode.hip (global namespace)
 extern int g_opt_wgrad_mfma, g_opt_wgrad_blocks, g_opt_wgrad_ws, g_opt_wgrad_ws_blocks;                                   // train_kernels.hip (global namespace)
 namespace mfx {
 int try_dcn_wave(const mfx_dcn_desc* d, hipStream_t st);      // dcn_wave.hip
@@ -434,7 +434,7 @@ static int* option_slot(const std::string& n) {
         {"dcn_ksplit", &g_opt_dcn_ksplit}, {"wgrad_mfma", &g_opt_wgrad_mfma}, {"wgrad_blocks", &g_opt_wgrad_blocks}, {"wgrad_ws", &g_opt_wgrad_ws},
         {"wgrad_ws_blocks", &g_opt_wgrad_ws_blocks}, {"dcn_wgrad_m", &g_opt_dcn_wgrad_m}, {"halo", &g_opt_halo}, {"halo_cg", &g_opt_halo_cg},
         {"halo_cw", &g_opt_halo_cw}, {"halo_cws", &g_opt_halo_cws}, {"ext_bwd_fast", &g_opt_ext_bwd_fast}, {"cw_rows6", &g_opt_cw_rows6}, {"halo_pair", &g_opt_halo_pair}, {"halo_s2", &g_opt_halo_s2}, {"dcn_wave", &g_opt_dcn_wave}, {"dcn_patch", &g_opt_dcn_patch}, {"dcn_lds", &g_opt_dcn_lds}, {"dcn_lds_rows", &g_opt_dcn_lds_rows},
-        {"dcn_patch_fn8", &g_opt_dcn_patch_fn8}, {"dcn_fuse_off", &g_opt_dcn_fuse_off}, {"topk_strips", &g_opt_topk_strips},
+        {"dcn_patch_fn8", &g_opt_dcn_patch_fn8}, {"dcn_fuse_off", &g_opt_dcn_fuse_off}, {"topk_strips", &g_opt_topk_strips}, {"topk_merge_z", &g_opt_topk_merge_z}, {"topk_merge_threads", &g_opt_topk_merge_threads},
 #ifdef MFX_PROBES
         {"dcn_bt_dbg", &g_opt_dcn_bt_dbg}, {"heads_dbg", &g_opt_heads_dbg},
 #endif

@@ -407,6 +407,7 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(const float* hmap, in
 }  // namespace mfx
 using namespace mfx;
 
+int g_opt_topk_merge_z = 16, g_opt_topk_merge_threads = 512;   // options "topk_merge_z" / "topk_merge_threads": workgroups per (class, image) map and their size in the merge
 int g_opt_topk_strips = 8;       // row strips per (class, image) map when a workspace is supplied; 1 = single-workgroup kernel
 
 extern "C" size_t mfx_decode_topk_workspace_bytes(int ncls, int B, int K) {
@@ -430,7 +431,7 @@ extern "C" int mfx_decode_topk(const float* hmap, long b_stride, long c_stride, 
         if (smem <= 48 * 1024) {
             hipLaunchKernelGGL(decode_topk_strip_kernel, dim3(S, ncls, B), dim3(kStripThreads), smem, st,
                                hmap, b_stride, c_stride, p_stride, H, W, K, rows_per, cand_v, cand_i);
-            hipLaunchKernelGGL(decode_topk_merge_kernel, dim3(ncls, B, 4), dim3(512), (size_t)S * K * 8, st, cand_v, cand_i, S * K, K, scores, index);
+            hipLaunchKernelGGL(decode_topk_merge_kernel, dim3(ncls, B, g_opt_topk_merge_z < 1 ? 1 : g_opt_topk_merge_z), dim3(g_opt_topk_merge_threads), (size_t)S * K * 8, st, cand_v, cand_i, S * K, K, scores, index);
             MFX_HIP_CHECK(hipGetLastError());
             return MFX_OK;
         }
