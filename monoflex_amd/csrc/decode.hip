@@ -159,7 +159,10 @@ __global__ __launch_bounds__(kTopkThreads) void decode_topk_kernel(const float* 
 // (its rows + one halo row each side for the NMS) is reduced to its own exact top-K by one small workgroup, and a second
 // tiny kernel merges the S*K candidates.  Any element of the global top-K is in the top-K of its strip under the same total
 // order (value desc, flat index asc), so the result is identical.
-constexpr int kStripThreads = 256;
+#ifndef MFX_STRIP_THREADS
+#define MFX_STRIP_THREADS 1024
+#endif
+constexpr int kStripThreads = MFX_STRIP_THREADS;
 
 __global__ __launch_bounds__(kStripThreads) void decode_topk_strip_kernel(const float* hmap, long b_stride, long c_stride, long p_stride,
                                                                           int H, int W, int K, int rows_per, float* cand_v, int* cand_i) {
